@@ -1,0 +1,387 @@
+"""CPU ORACLE — test infrastructure, NOT product code.
+
+A NumPy restatement of the reference's (boelnasr/ManipulaPy v1.4.1) NumPy-CPU algorithm for
+the batched trajectory + rigid-body-dynamics hot path.  Only `tests/`,
+`__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this module; the
+product path (manipulapy_amd/) never does and fails loudly without its HIP library.
+
+Parity status: PINNED.  `tests/test_oracle_golden.py` checks every function below against
+  * the reference's own test data files tests/data/dynamics_golden_{ur5,panda}.npz
+    (kept byte-for-byte in tests/golden/), with the reference's own tolerances
+    (tests/test_dynamics_golden.py:77-83: rtol 1e-7, atol 1e-9 / 1e-8), and
+  * fixtures produced by importing the reference in the build container
+    (tests/golden/make_golden.py): model tables, FK, Jacobians, M, c, g, ID, FD for
+    ur5 / iiwa14 / panda / xarm6, planner-level trajectory dumps.
+
+Every function cites the reference file:line (relative to the reference repo root,
+ManipulaPy/...) whose arithmetic it follows.  The algorithm is deliberately the
+reference's O(n^2)-per-mass-matrix, (1+2n)-mass-matrices-per-point formulation
+(tau = M qdd + c + g + Js^T F with a central-difference Christoffel c), not RNEA: it is the
+definition of "correct" that the HIP kernels are compared against.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+FD_EPS = 1e-6  # dynamics/cache.py:24 (epsilon of the central difference)
+G_DEFAULT = np.array([0.0, 0.0, -9.81])  # dynamics/forces.py:78, planning/trajectory_dynamics.py:54
+
+
+# --------------------------------------------------------------------------- model tables
+@dataclass
+class RobotTables:
+    """The constant tables the reference's hot path consumes (urdf/core.py:670-769)."""
+
+    S: np.ndarray  # (6, n) space screws [w; v]
+    M_ee: np.ndarray  # (4, 4) home pose of the end effector
+    G: np.ndarray  # (n, 6, 6) spatial inertia per link, twist order [w; v]
+    Mcom: np.ndarray  # (n, 4, 4) home pose of each link's CoM frame (Mlist_per_link)
+    joint_limits: np.ndarray  # (n, 2)
+    B: Optional[np.ndarray] = None  # (6, n) body screws
+    name: str = ""
+
+    @property
+    def n(self) -> int:
+        return self.S.shape[1]
+
+    def body_screws(self) -> np.ndarray:
+        # urdf/core.py:755-758: B = Ad(M^-1) S
+        if self.B is not None:
+            return self.B
+        return adjoint(np.linalg.inv(self.M_ee)) @ self.S
+
+
+def load_tables(path: str) -> RobotTables:
+    z = np.load(path)
+    return RobotTables(
+        S=z["S_list"].astype(np.float64),
+        M_ee=z["M_ee"].astype(np.float64),
+        G=z["Glist"].astype(np.float64),
+        Mcom=z["Mlist_per_link"].astype(np.float64),
+        joint_limits=z["joint_limits"].astype(np.float64),
+        B=z["B_list"].astype(np.float64) if "B_list" in z.files else None,
+        name=str(z["ee_name"]) if "ee_name" in z.files else "",
+    )
+
+
+# --------------------------------------------------------------------------- se(3) pieces
+def skew(v):
+    """utils/so3.py:22-30."""
+    return np.array([[0.0, -v[2], v[1]], [v[2], 0.0, -v[0]], [-v[1], v[0], 0.0]], dtype=np.result_type(v, np.float32))
+
+
+def exp_twist(S, theta):
+    """utils/se3.py:33-42 — se(3) exponential for a unit-|w| (or w=0) screw.
+
+    R = I + sin(t)[w] + (1-cos(t))[w]^2 ;  p = (t I + (1-cos t)[w] + (t - sin t)[w]^2) v.
+    The trig runs in the dtype of `theta`, as in the reference.
+    """
+    S = np.asarray(S)
+    W = skew(S[:3])
+    W2 = W @ W
+    s, c = np.sin(theta), np.cos(theta)
+    R = np.eye(3) + s * W + (1 - c) * W2
+    Gm = np.eye(3) * theta + (1 - c) * W + (theta - s) * W2
+    T = np.zeros((4, 4), dtype=R.dtype)
+    T[:3, :3] = R
+    T[:3, 3] = Gm @ S[3:]
+    T[3, 3] = 1.0
+    return T
+
+
+def adjoint(T):
+    """utils/se3.py:45-52 — [[R, 0], [[p]R, R]] for twists ordered [w; v]."""
+    R, p = T[:3, :3], T[:3, 3]
+    A = np.zeros((6, 6), dtype=R.dtype)
+    A[:3, :3] = R
+    A[3:, 3:] = R
+    A[3:, :3] = skew(p) @ R
+    return A
+
+
+# --------------------------------------------------------------------------- kinematics
+def _theta_array(theta):
+    # kinematics/fk.py:55-58: backend arrays keep their dtype, everything else -> float64
+    th = np.asarray(theta)
+    if not isinstance(theta, np.ndarray) or th.dtype.kind in "biu":
+        th = np.asarray(theta, dtype=np.float64)
+    return th
+
+
+def fk_space(tab: RobotTables, theta):
+    """kinematics/fk.py:59-70 — T = prod_i exp([S_i] th_i) . M ; accepts a truncated theta."""
+    th = _theta_array(theta)
+    T = np.eye(4, dtype=th.dtype)
+    for i in range(len(th)):
+        T = T @ exp_twist(tab.S[:, i], th[i])
+    return T @ tab.M_ee
+
+
+def fk_body(tab: RobotTables, theta):
+    """kinematics/fk.py:72-81 — T = M . prod_i exp([B_i] th_i)."""
+    th = _theta_array(theta)
+    B = tab.body_screws()
+    T = np.eye(4, dtype=th.dtype)
+    for i in range(len(th)):
+        T = T @ exp_twist(B[:, i], th[i])
+    return tab.M_ee @ T
+
+
+def jacobian_space(tab: RobotTables, theta):
+    """kinematics/jacobian.py:62-73 — column i = Ad(prod_{j<i} exp) S_i."""
+    th = _theta_array(theta)
+    if len(th) == 0:
+        return np.zeros((6, 0), dtype=th.dtype)
+    T = np.eye(4, dtype=th.dtype)
+    cols = []
+    for i in range(len(th)):
+        cols.append(adjoint(T) @ tab.S[:, i])
+        T = T @ exp_twist(tab.S[:, i], th[i])
+    return np.stack(cols, axis=1)
+
+
+def jacobian_body(tab: RobotTables, theta):
+    """kinematics/jacobian.py:74-90 — last column B_n, earlier ones Ad(prod exp(-B_{j} th_{j})) B_i."""
+    th = _theta_array(theta)
+    B = tab.body_screws()
+    n = len(th)
+    T = np.eye(4, dtype=th.dtype)
+    cols = [None] * n
+    cols[n - 1] = B[:, n - 1]
+    for i in range(n - 2, -1, -1):
+        T = T @ exp_twist(B[:, i + 1], -th[i + 1])
+        cols[i] = adjoint(T) @ B[:, i]
+    return np.stack(cols, axis=1)
+
+
+# --------------------------------------------------------------------------- dynamics
+def _link_com_jacobians(tab: RobotTables, theta):
+    """Shared by mass_matrix / gravity_forces (dynamics/mass_matrix.py:62-91, forces.py:100-120).
+
+    For link k: T_k_com = FK(theta[:k+1]) . inv(FK(0_{k+1})) . Mcom_k, and
+    J_k[:, :k+1] = Ad(inv(T_k_com)) . J_s[:, :k+1], zero for downstream joints.
+    Yields (k, T_k_com, J_k).
+    """
+    n = len(theta)
+    Js = jacobian_space(tab, theta)
+    for k in range(n):
+        T_k = fk_space(tab, theta[: k + 1])
+        T_k0 = fk_space(tab, np.zeros(k + 1))
+        T_k_com = T_k @ (np.linalg.inv(T_k0) @ tab.Mcom[k])
+        Jk = np.zeros((6, n), dtype=np.float64)
+        Jk[:, : k + 1] = adjoint(np.linalg.inv(T_k_com)) @ Js[:, : k + 1]
+        yield k, T_k_com, Jk
+
+
+def mass_matrix(tab: RobotTables, theta):
+    """dynamics/mass_matrix.py:62-99 — M = sum_k J_k^T G_k J_k, then 0.5 (M + M^T)."""
+    n = len(theta)
+    M = np.zeros((n, n))
+    for k, _, Jk in _link_com_jacobians(tab, theta):
+        M = M + Jk.T @ tab.G[k] @ Jk
+    return 0.5 * (M + M.T)
+
+
+def mass_matrix_derivatives(tab: RobotTables, theta, eps: float = FD_EPS):
+    """dynamics/cache.py:39-52 — dM[:, :, k] = (M(th + eps e_k) - M(th - eps e_k)) / (2 eps)."""
+    theta = np.asarray(theta, dtype=np.float64)
+    n = len(theta)
+    dM = np.zeros((n, n, n))
+    for k in range(n):
+        e = np.zeros(n)
+        e[k] = 1.0
+        dM[:, :, k] = (mass_matrix(tab, theta + eps * e) - mass_matrix(tab, theta - eps * e)) / (2.0 * eps)
+    return dM
+
+
+def velocity_quadratic_forces(tab: RobotTables, theta, dtheta):
+    """dynamics/forces.py:45-58 — c_i = dth^T Gamma_i dth, Gamma_i = 0.5 (dM_i + dM_i^T - dM[:, :, i])."""
+    dth = np.asarray(dtheta, dtype=np.float64)
+    dM = mass_matrix_derivatives(tab, theta)
+    n = len(dth)
+    c = np.zeros(n)
+    for i in range(n):
+        gamma = 0.5 * (dM[i] + dM[i].T - dM[:, :, i])
+        c[i] = dth @ (gamma @ dth)
+    return c
+
+
+def gravity_forces(tab: RobotTables, theta, g=None):
+    """dynamics/forces.py:100-133 — sum_k J_k^T [0; m_k R_k^T (-g)], m_k = G_k[3, 3]."""
+    g = G_DEFAULT if g is None else np.asarray(g, dtype=np.float64)
+    n = len(theta)
+    out = np.zeros(n)
+    for k, T_k_com, Jk in _link_com_jacobians(tab, theta):
+        m_k = tab.G[k][3, 3]
+        F = np.concatenate((np.zeros(3), m_k * (T_k_com[:3, :3].T @ (-g))))
+        out = out + Jk.T @ F
+    return out
+
+
+def inverse_dynamics(tab: RobotTables, theta, dtheta, ddtheta, g, Ftip):
+    """dynamics/id_fd.py:37-48 — tau = M qdd + c + g + J_s^T Ftip (Ftip is a SPACE-frame wrench)."""
+    M = mass_matrix(tab, theta)
+    c = velocity_quadratic_forces(tab, theta, dtheta)
+    gf = gravity_forces(tab, theta, g)
+    Jt = jacobian_space(tab, theta).T
+    return M @ np.asarray(ddtheta) + c + gf + Jt @ np.asarray(Ftip)
+
+
+def forward_dynamics(tab: RobotTables, theta, dtheta, tau, g, Ftip):
+    """dynamics/id_fd.py:71-83 — qdd = solve(M, tau - c - g - J_s^T Ftip)."""
+    M = mass_matrix(tab, theta)
+    c = velocity_quadratic_forces(tab, theta, dtheta)
+    gf = gravity_forces(tab, theta, g)
+    Jt = jacobian_space(tab, theta).T
+    rhs = np.asarray(tau) - c - gf - Jt @ np.asarray(Ftip)
+    return np.linalg.solve(M, rhs)
+
+
+# --------------------------------------------------------------------------- time scaling
+def time_scaling(tau, Tf, method):
+    """planning/trajectory.py:51-68 (numba path): cubic / quintic s, s', s''; anything else -> zeros.
+
+    `tau` may be an array; all math in float64.
+    """
+    tau = np.asarray(tau, dtype=np.float64)
+    if method == 3:
+        s = 3.0 * tau * tau - 2.0 * tau * tau * tau
+        sd = 6.0 * tau * (1.0 - tau) / Tf
+        sdd = 6.0 / (Tf * Tf) * (1.0 - 2.0 * tau)
+    elif method == 5:
+        t2 = tau * tau
+        t3 = t2 * tau
+        t4 = t2 * t2
+        t5 = t4 * tau
+        s = 10.0 * t3 - 15.0 * t4 + 6.0 * t5
+        sd = (30.0 * t2 - 60.0 * t3 + 30.0 * t4) / Tf
+        sdd = (60.0 * tau - 180.0 * t2 + 120.0 * t3) / (Tf * Tf)
+    else:
+        s = sd = sdd = np.zeros_like(tau)
+    return s, sd, sdd
+
+
+def trajectory_points(thetastart, thetaend, Tf, N, method):
+    """planning/trajectory.py:15-75 (`_trajectory_cpu_fallback`, numba semantics).
+
+    float32 endpoints, float32 difference, float64 scalar math, float32 store.
+    t = idx * (Tf / (N - 1)), tau = t / Tf.  (N = 1 divides by zero in the reference too.)
+    Returns (pos, vel, acc), each (N, n) float32, WITHOUT the joint-limit clip.
+    """
+    a = np.asarray(thetastart, dtype=np.float32)
+    b = np.asarray(thetaend, dtype=np.float32)
+    idx = np.arange(N, dtype=np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t = idx * (Tf / (N - 1)) if N > 1 else idx * np.inf
+        tau = t / Tf
+    s, sd, sdd = time_scaling(tau, float(Tf), method)
+    d = (b - a).astype(np.float64)  # float32 subtraction first, as numba types it
+    pos = (s[:, None] * d[None, :] + a.astype(np.float64)[None, :]).astype(np.float32)
+    vel = (sd[:, None] * d[None, :]).astype(np.float32)
+    acc = (sdd[:, None] * d[None, :]).astype(np.float32)
+    return pos, vel, acc
+
+
+def trajectory_points_numpy_twin(thetastart, thetaend, Tf, N, method):
+    """cuda_kernels/trajectory_kernels.py:20-88 (`trajectory_cpu_fallback`, the registry's CPU launcher).
+
+    float32 linspace math; other `method` -> linear; N <= 1 or Tf <= 0 -> sit at start.
+    """
+    a = np.asarray(thetastart)
+    b = np.asarray(thetaend)
+    if N <= 1 or Tf <= 0.0:
+        s = sd = sdd = np.zeros(N, dtype=np.float32)
+    else:
+        t = np.linspace(0, Tf, N, dtype=np.float32)
+        tau = t / Tf
+        if method == 3:
+            s = 3.0 * tau**2 - 2.0 * tau**3
+            sd = 6.0 * tau * (1.0 - tau) / Tf
+            sdd = 6.0 * (1.0 - 2.0 * tau) / (Tf * Tf)
+        elif method == 5:
+            s = 10.0 * tau**3 - 15.0 * tau**4 + 6.0 * tau**5
+            sd = (30.0 * tau**2 - 60.0 * tau**3 + 30.0 * tau**4) / Tf
+            sdd = (60.0 * tau - 180.0 * tau**2 + 120.0 * tau**3) / (Tf * Tf)
+        else:
+            s, sd, sdd = tau, np.ones_like(tau) / Tf, np.zeros_like(tau)
+    d = b - a
+    pos = a[None, :] + s[:, None] * d[None, :]
+    return (pos.astype(np.float32), (sd[:, None] * d[None, :]).astype(np.float32),
+            (sdd[:, None] * d[None, :]).astype(np.float32))
+
+
+# --------------------------------------------------------------------------- planner level
+def joint_trajectory(joint_limits, thetastart, thetaend, Tf, N, method):
+    """planning/trajectory.py:276-333 — generate, then clip POSITIONS to float32 joint limits."""
+    lim = np.asarray(joint_limits, dtype=np.float32)  # planning/trajectory_planning.py:218
+    pos, vel, acc = trajectory_points(thetastart, thetaend, Tf, N, method)
+    pos = np.clip(pos, lim[:, 0], lim[:, 1])
+    return {"positions": pos, "velocities": vel, "accelerations": acc}
+
+
+def batch_joint_trajectory(joint_limits, start_batch, end_batch, Tf, N, method):
+    """planning/trajectory.py:431-502 — per-trajectory loop, stack, clip; empty batch -> (0, N, n) zeros."""
+    sb = np.asarray(start_batch)
+    eb = np.asarray(end_batch)
+    B, n = sb.shape
+    if B == 0:
+        z = np.zeros((0, N, n), dtype=np.float32)
+        return {"positions": z, "velocities": z.copy(), "accelerations": z.copy()}
+    rows = [trajectory_points(sb[i], eb[i], Tf, N, method) for i in range(B)]
+    lim = np.asarray(joint_limits, dtype=np.float32)
+    pos = np.clip(np.stack([r[0] for r in rows]), lim[:, 0], lim[:, 1])
+    return {"positions": pos, "velocities": np.stack([r[1] for r in rows]),
+            "accelerations": np.stack([r[2] for r in rows])}
+
+
+def inverse_dynamics_trajectory(tab, q, qd, qdd, g=None, Ftip=None, torque_limits=None, dtype=np.float32):
+    """planning/trajectory_dynamics.py:308-380 — per-row inverse_dynamics, rows cast to float32, clip.
+
+    `dtype=np.float64` gives the per-point float64 oracle with the same clip.
+    """
+    g = G_DEFAULT if g is None else np.asarray(g, dtype=np.float64)
+    Ftip = np.zeros(6) if Ftip is None else np.asarray(Ftip, dtype=np.float64)
+    q = np.asarray(q)
+    N, n = q.shape
+    out = np.zeros((N, n), dtype=dtype)
+    for i in range(N):
+        out[i] = inverse_dynamics(tab, q[i], qd[i], qdd[i], g, Ftip).astype(dtype)
+    if torque_limits is not None:
+        tl = np.asarray(torque_limits, dtype=np.float32)  # planning/trajectory_planning.py:219-223
+        out = np.clip(out, tl[:, 0].astype(dtype), tl[:, 1].astype(dtype))
+    return out
+
+
+def forward_dynamics_trajectory(tab, theta0, dtheta0, taumat, g, Ftipmat, dt, intRes, joint_limits=None):
+    """planning/trajectory_dynamics.py:580-708 — semi-implicit Euler roll-out.
+
+    Row 0 = initial state (acc 0).  For i >= 1, `intRes` sub-steps of dt/intRes:
+    qdd = FD(q, qd, taumat[i], g, Ftipmat[i]); qd += qdd h; q += qd_new h; q = clip(q, float32 limits).
+    Rows stored float32; the recorded acceleration is the LAST sub-step's.
+    """
+    lim = np.asarray(tab.joint_limits if joint_limits is None else joint_limits, dtype=np.float32)
+    q = np.asarray(theta0)
+    qd = np.asarray(dtheta0)
+    taumat = np.asarray(taumat)
+    N, n = taumat.shape[0], q.shape[0]
+    if N == 0:
+        raise IndexError("index 0 is out of bounds for axis 0 with size 0")
+    P = [q.astype(np.float32)]
+    V = [qd.astype(np.float32)]
+    A = [np.zeros(n, dtype=np.float32)]
+    h = dt / intRes
+    for i in range(1, N):
+        last = np.zeros(n, dtype=np.float32)
+        for _ in range(intRes):
+            qdd = forward_dynamics(tab, q, qd, taumat[i], g, Ftipmat[i])
+            qd = (qd + qdd * h).astype(qd.dtype)
+            q = (q + qd * h).astype(q.dtype)
+            q = np.clip(q, lim[:, 0], lim[:, 1])
+            last = qdd
+        P.append(q.astype(np.float32))
+        V.append(qd.astype(np.float32))
+        A.append(np.asarray(last, dtype=np.float32))
+    return {"positions": np.stack(P), "velocities": np.stack(V), "accelerations": np.stack(A)}

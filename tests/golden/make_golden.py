@@ -1,0 +1,288 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures by IMPORTING the reference (ManipulaPy v1.4.1).
+
+Runs only in the build container, where /root/reference exists; the GPU box never
+sees the reference, only the small .npz files this script writes next to itself.
+
+    PYTHONHASHSEED=0 python tests/golden/make_golden.py
+
+What it does:
+  * creates a throw-away `numba` stub in a temp dir (numba is absent here; only
+    ManipulaPy.planning / ManipulaPy.cuda_kernels import it, dynamics/kinematics do not);
+  * re-executes itself with PYTHONHASHSEED=0 so the reference's set-ordered
+    end-effector choice (urdf/core.py:461-462, :388-392) is pinned;
+  * builds URDF -> SerialManipulator / ManipulatorDynamics through the reference's public
+    consumer path (urdf_processor.py:82-138) for ur5 / iiwa14 / panda / xarm6 and dumps
+      model_<robot>.npz    : the constant tables the hot path consumes
+      dynamics_<robot>.npz : inputs + reference outputs at 25 configurations
+                             (recipe of the reference's tests/test_dynamics_golden.py:107-182,
+                             extended with random Ftip, FK, Jacobians, forward dynamics)
+      trajectory_ur5.npz   : joint_trajectory / batch_joint_trajectory /
+                             inverse_dynamics_trajectory / forward_dynamics_trajectory dumps
+      reference_cpu_timings.json : cold-cache per-point timings of the reference
+
+Nothing from /root/reference is copied: the fixtures hold numbers only.
+dynamics_golden_{ur5,panda}.npz in this directory are the reference's OWN test data
+files (tests/data/), kept byte-for-byte as the primary known-answer pin.
+"""
+import json
+import os
+import sys
+import tempfile
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+SEED = 20260705  # same seed the reference's golden test uses (tests/test_dynamics_golden.py:53)
+
+NUMBA_STUB = '''
+def _ident(*a, **k):
+    if len(a) == 1 and callable(a[0]) and not k:
+        return a[0]
+    return lambda f: f
+njit = jit = vectorize = guvectorize = _ident
+prange = range
+class _Cfg: pass
+config = _Cfg()
+float32 = int32 = float64 = int64 = None
+'''
+
+
+def _reexec_pinned():
+    if os.environ.get("_MP_GOLDEN_CHILD") == "1":
+        return
+    stub = tempfile.mkdtemp(prefix="mp_numba_stub_")
+    os.makedirs(os.path.join(stub, "numba"))
+    with open(os.path.join(stub, "numba", "__init__.py"), "w") as f:
+        f.write(NUMBA_STUB)
+    env = dict(os.environ)
+    env.update(
+        _MP_GOLDEN_CHILD="1",
+        PYTHONHASHSEED="0",
+        NUMBA_DISABLE_CUDA="1",
+        MPLBACKEND="Agg",
+        MANIPULAPY_QUIET="1",
+        PYTHONPATH=os.pathsep.join([stub, REF, env.get("PYTHONPATH", "")]),
+    )
+    os.execve(sys.executable, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env)
+
+
+_reexec_pinned()
+
+import warnings  # noqa: E402
+
+import numpy as np  # noqa: E402
+
+warnings.simplefilter("ignore")
+
+from ManipulaPy.ManipulaPy_data import get_robot_urdf  # noqa: E402
+from ManipulaPy.urdf_processor import URDFToSerialManipulator  # noqa: E402
+
+ROBOTS = ["ur5", "iiwa14", "panda", "xarm6"]
+G_VEC = np.array([0.0, 0.0, -9.81])
+FTIP_REF = np.array([1.0, -2.0, 0.5, 3.0, -1.5, 0.75])  # tests/test_dynamics_golden.py:145
+
+
+def build(robot):
+    proc = URDFToSerialManipulator(get_robot_urdf(robot), load_meshes=False)
+    return proc, proc.serial_manipulator, proc.dynamics
+
+
+def finite_limits(sm, n):
+    lims = getattr(sm, "joint_limits", None) or [(None, None)] * n
+    out = np.empty((n, 2))
+    for i in range(n):
+        lo, hi = lims[i] if i < len(lims) else (None, None)
+        out[i, 0] = -np.pi if lo is None else float(lo)
+        out[i, 1] = np.pi if hi is None else float(hi)
+    return out
+
+
+def clear_caches(dyn):
+    dyn._mass_matrix_cache.clear()
+    dyn._mass_matrix_derivative_cache.clear()
+
+
+def dump_model(robot, proc, sm, dyn):
+    n = sm.S_list.shape[1]
+    ee = getattr(proc.robot, "end_effector_link", None)
+    ee_name = getattr(ee, "name", str(ee))
+    np.savez(
+        os.path.join(HERE, f"model_{robot}.npz"),
+        n=np.int64(n),
+        S_list=np.asarray(sm.S_list, dtype=np.float64),
+        B_list=np.asarray(sm.B_list, dtype=np.float64),
+        M_ee=np.asarray(sm.M_list, dtype=np.float64),
+        Glist=np.asarray(dyn.Glist, dtype=np.float64),
+        Mlist_per_link=np.asarray(dyn.Mlist_per_link, dtype=np.float64),
+        joint_limits=finite_limits(sm, n),
+        ee_name=np.array(ee_name),
+    )
+    return n
+
+
+def dump_dynamics(robot, sm, dyn, n, seed_off):
+    rng = np.random.default_rng(SEED + seed_off)
+    lims = finite_limits(sm, n)
+    lo, hi = lims[:, 0], lims[:, 1]
+    thetas = [np.zeros(n), lo.copy(), hi.copy(), np.full(n, 0.02)]
+    while len(thetas) < 25:
+        thetas.append(rng.uniform(lo, hi))
+    thetas = np.array(thetas)
+    K = len(thetas)
+    dthetas = rng.uniform(-1, 1, (K, n))
+    ddthetas = rng.uniform(-1, 1, (K, n))
+    ftips = rng.uniform(-3, 3, (K, 6))
+    ftips[:5] = 0.0
+    ftips[5] = FTIP_REF
+    out = {k: [] for k in ("mass_matrix", "inverse_dynamics", "gravity_forces",
+                            "velocity_quadratic_forces", "forward_dynamics",
+                            "fk_space", "fk_body", "jac_space", "jac_body")}
+    for i in range(K):
+        clear_caches(dyn)
+        th, dth, ddth, ft = thetas[i], dthetas[i], ddthetas[i], ftips[i]
+        out["mass_matrix"].append(np.asarray(dyn.mass_matrix(th)))
+        out["velocity_quadratic_forces"].append(np.asarray(dyn.velocity_quadratic_forces(th, dth)))
+        out["gravity_forces"].append(np.asarray(dyn.gravity_forces(th, G_VEC)))
+        tau = np.asarray(dyn.inverse_dynamics(th, dth, ddth, G_VEC, ft))
+        out["inverse_dynamics"].append(tau)
+        # forward dynamics of the torques just computed -> should give ddth back
+        out["forward_dynamics"].append(np.asarray(dyn.forward_dynamics(th, dth, tau, G_VEC, ft)))
+        out["fk_space"].append(np.asarray(sm.forward_kinematics(th, frame="space")))
+        out["fk_body"].append(np.asarray(sm.forward_kinematics(th, frame="body")))
+        out["jac_space"].append(np.asarray(sm.jacobian(th, frame="space")))
+        out["jac_body"].append(np.asarray(sm.jacobian(th, frame="body")))
+    np.savez(
+        os.path.join(HERE, f"dynamics_{robot}.npz"),
+        thetas=thetas, dthetas=dthetas, ddthetas=ddthetas, g=G_VEC, ftips=ftips,
+        **{k: np.array(v, dtype=np.float64) for k, v in out.items()},
+    )
+
+
+def dump_trajectories():
+    """Planner-level dumps (UR5 + xarm6) through OptimizedTrajectoryPlanning(use_cuda=False)."""
+    from ManipulaPy.cuda_kernels.trajectory_kernels import trajectory_cpu_fallback
+    from ManipulaPy.planning import OptimizedTrajectoryPlanning
+
+    proc, sm, dyn = build("ur5")
+    n = sm.S_list.shape[1]
+    lims = finite_limits(sm, n)
+    planner = OptimizedTrajectoryPlanning(
+        sm, get_robot_urdf("ur5"), dyn, lims.tolist(), use_cuda=False)
+    rng = np.random.default_rng(SEED + 100)
+    lo, hi = lims[:, 0], lims[:, 1]
+    start = rng.uniform(lo, hi).astype(np.float32)
+    end = rng.uniform(lo, hi).astype(np.float32)
+    d = {"joint_limits": lims, "start": start, "end": end}
+
+    # C1: UR5 quintic N=1000 (BASELINE.json configs[0]) + cubic N=500 + N=3 known answer
+    for tag, (N, method, Tf) in {"q1000": (1000, 5, 2.0), "c500": (500, 3, 1.5)}.items():
+        r = planner.joint_trajectory(start, end, Tf, N, method)
+        for k in ("positions", "velocities", "accelerations"):
+            d[f"jt_{tag}_{k}"] = np.asarray(r[k])
+        d[f"jt_{tag}_args"] = np.array([N, method, Tf], dtype=np.float64)
+        # NumPy twin (float32 linspace math), cuda_kernels/trajectory_kernels.py:20-88
+        p, v, a = trajectory_cpu_fallback(start, end, Tf, N, method)
+        d[f"np_{tag}_positions"], d[f"np_{tag}_velocities"], d[f"np_{tag}_accelerations"] = p, v, a
+    # exceeding the limits on purpose -> exercises the clip (planning/trajectory.py:311-313)
+    far = (hi + 0.5).astype(np.float32)
+    r = planner.joint_trajectory(start, far, 1.0, 32, 5)
+    d["jt_clip_end"] = far
+    for k in ("positions", "velocities", "accelerations"):
+        d[f"jt_clip_{k}"] = np.asarray(r[k])
+    # linear / unsupported method on the NumPy twin (the numba one yields zeros for it)
+    p, v, a = trajectory_cpu_fallback(start, end, 2.0, 16, 1)
+    d["np_lin16_positions"], d["np_lin16_velocities"], d["np_lin16_accelerations"] = p, v, a
+
+    # batch (B=5, N=16), planning/trajectory.py:335-502 (sequential CPU path)
+    B = 5
+    bs = rng.uniform(lo, hi, (B, n)).astype(np.float32)
+    be = rng.uniform(lo, hi, (B, n)).astype(np.float32)
+    r = planner.batch_joint_trajectory(bs, be, 2.0, 16, 5)
+    d["batch_start"], d["batch_end"] = bs, be
+    for k in ("positions", "velocities", "accelerations"):
+        d[f"batch_{k}"] = np.asarray(r[k])
+
+    # inverse_dynamics_trajectory, N=64 quintic, float64 inputs
+    N = 64
+    r = planner.joint_trajectory(start, end, 2.0, N, 5)
+    q = np.asarray(r["positions"], dtype=np.float64)
+    qd = np.asarray(r["velocities"], dtype=np.float64)
+    qdd = np.asarray(r["accelerations"], dtype=np.float64)
+    clear_caches(dyn)
+    tau32 = np.asarray(planner.inverse_dynamics_trajectory(q, qd, qdd))
+    tau64 = np.array([np.asarray(dyn.inverse_dynamics(q[i], qd[i], qdd[i], G_VEC, np.zeros(6)))
+                      for i in range(N)])
+    d["idt_q"], d["idt_qd"], d["idt_qdd"] = q, qd, qdd
+    d["idt_tau_f32"], d["idt_tau_f64"] = tau32, tau64
+    # with a wrench and tight torque limits -> clip behaviour (planning/trajectory_dynamics.py:369-373)
+    tl = np.stack([-np.full(n, 20.0), np.full(n, 15.0)], axis=1)
+    planner2 = OptimizedTrajectoryPlanning(
+        sm, get_robot_urdf("ur5"), dyn, lims.tolist(), torque_limits=tl.tolist(), use_cuda=False)
+    d["idt_torque_limits"] = tl
+    d["idt_ftip"] = FTIP_REF
+    d["idt_tau_f32_clip_ftip"] = np.asarray(
+        planner2.inverse_dynamics_trajectory(q[:16], qd[:16], qdd[:16], G_VEC, FTIP_REF))
+    np.savez(os.path.join(HERE, "trajectory_ur5.npz"), **d)
+
+    # forward_dynamics_trajectory roll-out: xarm6, N=8, intRes=2
+    proc, sm, dyn = build("xarm6")
+    n = sm.S_list.shape[1]
+    lims = finite_limits(sm, n)
+    planner = OptimizedTrajectoryPlanning(
+        sm, get_robot_urdf("xarm6"), dyn, lims.tolist(), use_cuda=False)
+    rng = np.random.default_rng(SEED + 200)
+    th0 = rng.uniform(-0.5, 0.5, n)
+    dth0 = rng.uniform(-0.2, 0.2, n)
+    N = 8
+    taumat = rng.uniform(-1, 1, (N, n)) * 0.5
+    Ftipmat = np.tile(FTIP_REF, (N, 1)) * rng.uniform(0.5, 1.0, (N, 1))
+    r = planner.forward_dynamics_trajectory(th0, dth0, taumat, G_VEC, Ftipmat, 0.01, 2)
+    np.savez(
+        os.path.join(HERE, "fd_trajectory_xarm6.npz"),
+        joint_limits=lims, theta0=th0, dtheta0=dth0, taumat=taumat, g=G_VEC,
+        Ftipmat=Ftipmat, dt=np.float64(0.01), intRes=np.int64(2),
+        positions=np.asarray(r["positions"]), velocities=np.asarray(r["velocities"]),
+        accelerations=np.asarray(r["accelerations"]),
+    )
+
+
+def time_reference():
+    """Cold-cache single-thread timings of the reference's inverse_dynamics."""
+    res = {"host": "build container", "cores_visible": os.cpu_count(), "threads_used": 1,
+           "numpy": np.__version__, "note": "caches cleared before every call; float64 inputs"}
+    for robot in ROBOTS:
+        proc, sm, dyn = build(robot)
+        n = sm.S_list.shape[1]
+        lims = finite_limits(sm, n)
+        rng = np.random.default_rng(SEED + 300)
+        ts = []
+        for _ in range(12):
+            th = rng.uniform(lims[:, 0], lims[:, 1])
+            dth, ddth = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+            clear_caches(dyn)
+            t0 = time.perf_counter()
+            dyn.inverse_dynamics(th, dth, ddth, G_VEC, np.zeros(6))
+            ts.append(time.perf_counter() - t0)
+        med = float(np.median(ts))
+        res[robot] = {"dof": n, "inverse_dynamics_ms_per_point": med * 1e3,
+                      "joint_timesteps_per_s_per_core": n / med}
+    with open(os.path.join(HERE, "reference_cpu_timings.json"), "w") as f:
+        json.dump(res, f, indent=1)
+
+
+def main():
+    assert os.environ.get("PYTHONHASHSEED") == "0"
+    for i, robot in enumerate(ROBOTS):
+        proc, sm, dyn = build(robot)
+        n = dump_model(robot, proc, sm, dyn)
+        dump_dynamics(robot, sm, dyn, n, i)
+        print(f"{robot}: n={n} dumped", flush=True)
+    dump_trajectories()
+    print("trajectories dumped", flush=True)
+    time_reference()
+    print("timings dumped")
+
+
+if __name__ == "__main__":
+    main()
