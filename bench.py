@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: joint-timesteps/s of inverse_dynamics_trajectory over B x N rows.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c4] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W          (one rank per GPU)
+
+A "step" is one pass of the hot path over one batch of synthetic input that is already resident in
+HBM: config c2 (default, the one BASELINE.json's metric is quoted on) = UR5 (6 DOF), B = 4096
+trajectories x N = 1000 timesteps, float32, materialised q / qd / qdd histories -> tau.  With more than
+one rank every GPU gets its own B trajectories (weak scaling), computes its shard with no exchange,
+and the step ends with the RCCL all-gather that reassembles the full torque history on every GPU.
+
+torch is used ONLY for the multi-process rendezvous (gloo barrier / max / 128-byte id broadcast); the
+compute path is ctypes -> libmanipula_hip.so.  Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (robot, B per GPU, N, dtype, what the step runs)
+    "c2": dict(robot="ur5", B=4096, N=1000, dtype="f32", op="id",
+               desc="UR5 6-DOF, B=4096 x N=1000, inverse_dynamics_trajectory fp32 (BASELINE configs[1])"),
+    "c3": dict(robot="iiwa14", B=65536, N=500, dtype="f64", op="fk_jac_id",
+               desc="KUKA iiwa14 7-DOF, B=65536 x N=500, FK + Jacobian + ID fused fp64 (BASELINE configs[2])"),
+    "c4": dict(robot="panda", B=32768, N=200, dtype="f32", op="id",
+               desc="Franka Panda (8 DOF as the reference parses it), B=32768/GPU x N=200, ID fp32 (BASELINE configs[3] per-GPU shard)"),
+}
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+SEED = 20260705
+
+
+def algorithmic_bytes_per_row(cfg, n):
+    """SURVEY §8(d).  id: read q, qd, qdd + write tau = 4 values per joint-timestep.
+    fk_jac_id: in 3n, out n + 16 + 6n values per timestep."""
+    w = 4 if cfg["dtype"] == "f32" else 8
+    return (4 * n) * w if cfg["op"] == "id" else (3 * n + n + 16 + 6 * n) * w
+
+
+def cpu_baseline(robot, q, qd, qdd, budget_s=12.0):
+    """The CPU oracle (NumPy restatement of the reference algorithm, oracle/ref_numpy.py) timed on this
+    box's host cores on a bounded sample of the SAME rows.  Reported, never shipped."""
+    from oracle import ref_numpy as ref
+
+    tab = ref.load_tables(os.path.join(ROOT, "tests", "golden", f"model_{robot}.npz"))
+    n = tab.n
+    done, t0 = 0, time.perf_counter()
+    out = []
+    while done < q.shape[0] and (time.perf_counter() - t0) < budget_s:
+        out.append(ref.inverse_dynamics(tab, q[done].astype(np.float64), qd[done].astype(np.float64),
+                                        qdd[done].astype(np.float64), ref.G_DEFAULT, np.zeros(6)))
+        done += 1
+    dt = time.perf_counter() - t0
+    return {"value": done * n / dt, "unit": "joint-timesteps/s", "cores": 1, "kind": "port",
+            "sample": f"first {done} rows of the benchmark input, {dt:.1f} s, single thread, NumPy oracle "
+                      f"(reference algorithm: 1+2n mass matrices per point)"}, np.array(out)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="multi-GPU: skip the all-gather (compute-only figure)")
+    args = ap.parse_args()
+
+    from manipulapy_amd import _hip, robots, sharding
+
+    info = sharding.dist_env()
+    world = info.world
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs one process per GPU: launch with torch.distributed.run "
+                             f"--nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    hg = sharding.HostGather(info)  # gloo; no-op for a single process
+
+    cfg = CONFIGS[args.config]
+    t = robots.robot_tables(cfg["robot"])
+    n = t["S_list"].shape[1]
+    B, N = cfg["B"], cfg["N"]
+    rows = B * N
+    dt_np = np.float32 if cfg["dtype"] == "f32" else np.float64
+    wbytes = np.dtype(dt_np).itemsize
+
+    ctx = _hip.HipContext(info.local_rank)
+    ctx.selftest()
+    props = ctx.properties()
+    model = _hip.HipModel(t["S_list"], t["Mlist_per_link"], t["Glist"], t["M_ee"], t["joint_limits"])
+
+    # ---- synthetic input, generated ON the device: start / end ~ U(joint limits), quintic, Tf = 2
+    cid = {"c2": 2, "c3": 3, "c4": 4}[args.config]
+    rng = np.random.default_rng(SEED + cid + 1000 * info.rank)
+    lo, hi = t["joint_limits"][:, 0], t["joint_limits"][:, 1]
+    start = rng.uniform(lo, hi, (B, n)).astype(np.float32)
+    end = rng.uniform(lo, hi, (B, n)).astype(np.float32)
+    d_start, d_end = ctx.to_device(start), ctx.to_device(end)
+    nb32 = rows * n * 4
+    d_q32, d_qd32, d_qdd32 = ctx.alloc(nb32), ctx.alloc(nb32), ctx.alloc(nb32)
+    ctx.batch_trajectory(model, d_start, d_end, B, N, 2.0, 5, d_q32, d_qd32, d_qdd32)
+    ctx.synchronize()
+    if cfg["dtype"] == "f32":
+        d_q, d_qd, d_qdd = d_q32, d_qd32, d_qdd32
+    else:  # float64 configs: widen the same histories on the host once (setup, untimed)
+        chunk = 1 << 22
+        d_q, d_qd, d_qdd = (ctx.alloc(rows * n * 8) for _ in range(3))
+        for src, dst in ((d_q32, d_q), (d_qd32, d_qd), (d_qdd32, d_qdd)):
+            h = src.download((rows * n,), np.float32).astype(np.float64)
+            dst.upload(h)
+            del h
+        for b in (d_q32, d_qd32, d_qdd32):
+            b.free()
+    nb = rows * n * wbytes
+    d_tau_all = ctx.alloc(nb * world) if world > 1 and not args.no_gather else None
+    d_tau = ctx.alloc(nb)
+    d_T = ctx.alloc(rows * 16 * wbytes) if cfg["op"] == "fk_jac_id" else None
+    d_J = ctx.alloc(rows * 6 * n * wbytes) if cfg["op"] == "fk_jac_id" else None
+
+    comm = None
+    if world > 1 and not args.no_gather:
+        uid = _hip.HipContext.comm_unique_id() if info.rank == 0 else None
+        uid = hg.broadcast_bytes(uid, _hip.UNIQUE_ID_BYTES)
+        comm = ctx.comm_create(uid, world, info.rank)
+
+    def step():
+        if cfg["op"] == "id":
+            ctx.id_trajectory(model, d_q, d_qd, d_qdd, rows, d_tau, dtype=dt_np)
+        else:
+            ctx.fk_jac_id(model, d_q, d_qd, d_qdd, rows, d_T, d_J, d_tau, dtype=dt_np)
+
+    def gather():
+        if comm is not None:
+            comm.allgather(d_tau, d_tau_all, nb)
+
+    for _ in range(args.warmup):
+        step()
+        gather()
+    ctx.synchronize()
+
+    # ---- timed region: exactly K steps between barrier + device sync on both sides
+    ev = [(ctx.event(), ctx.event()) for _ in range(args.steps)]
+    hg.barrier()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        step()
+        ev[k][1].record()   # HIP events on the launch stream bracket the dominant kernel alone
+        gather()
+    ctx.synchronize()
+    hg.barrier()
+    elapsed = hg.max(time.perf_counter() - t0)
+    kern_ms = float(np.mean([b.elapsed_ms_since(a) for a, b in ev]))
+    kern_ms_all = hg.max(kern_ms)
+
+    jt_per_step = rows * n * world
+    value = jt_per_step * args.steps / elapsed
+    alg_bytes = algorithmic_bytes_per_row(cfg, n) * rows  # per launch (one rank's kernel)
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+
+    result = {
+        "metric": "joint-timesteps/sec (NxBxDOF) inverse-dynamics trajectory",
+        "value": value, "unit": "joint-timesteps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": cfg["dtype"], "data": "synthetic",
+        "config": {"workload": cfg["desc"], "robot": cfg["robot"], "dof": n, "B_per_gpu": B, "N": N,
+                   "rows_per_gpu": rows, "op": cfg["op"], "inputs": "q/qd/qdd histories resident in HBM",
+                   "sharding": f"batch axis over {world} rank(s)" + ("" if world == 1 else
+                               (", no gather" if args.no_gather else ", RCCL all-gather of tau each step"))},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                     "kernel": "k_id" if cfg["op"] == "id" else "k_fk_jac_id", "kernel_ms": kern_ms,
+                     "kernel_ms_max_over_ranks": kern_ms_all, "algorithmic_bytes_per_launch": alg_bytes},
+        "device": props["name"],
+    }
+    traffic_file = os.path.join(ROOT, "profiles", f"traffic_{args.config}.json")
+    if os.path.exists(traffic_file):  # measured HBM bytes per launch from the rocprofv3 --pmc passes
+        with open(traffic_file) as f:
+            result["roofline"]["traffic"] = json.load(f).get("hbm_bytes_per_launch")
+
+    if info.rank == 0 and world == 1 and not args.no_cpu_baseline:
+        ns = 4096
+        q = d_q.download((rows, n), dt_np)[:ns]
+        qd = d_qd.download((rows, n), dt_np)[:ns]
+        qdd = d_qdd.download((rows, n), dt_np)[:ns]
+        base, tau_cpu = cpu_baseline(cfg["robot"], q, qd, qdd)
+        result["cpu_baseline"] = base
+        tau_gpu = d_tau.download((rows, n), dt_np)[: len(tau_cpu)]
+        err = np.abs(tau_gpu.astype(np.float64) - tau_cpu)
+        result["parity_sample"] = {"rows": int(len(tau_cpu)), "max_abs_err": float(err.max()),
+                                   "max_abs_tau": float(np.abs(tau_cpu).max())}
+    if info.rank == 0:
+        print(json.dumps(result), flush=True)
+    if comm is not None:
+        comm.destroy()
+    ctx.destroy()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,159 @@
+/* manipula_hip.h — C ABI of libmanipula_hip.so (MI355X / gfx950).
+ *
+ * The drop-in boundary for the batched trajectory + rigid-body-dynamics hot path of
+ * boelnasr/ManipulaPy v1.4.1.  The reference has no FFI: its "GPU side" is a set of Python
+ * launchers behind a kernel registry (ManipulaPy/cuda_kernels/registry.py:46-89, :828-867) and
+ * mixin methods that launch Numba kernels directly (planning/trajectory_dynamics.py:248-260,
+ * :524-539; planning/trajectory.py:643).  Each entry point below is what such a launcher binds
+ * (through ctypes); the reference interface it replaces is cited per function.
+ *
+ * Conventions
+ *   - every function returns int: 0 = MP_OK, otherwise an MP_ERR_* code; mp_last_error() returns
+ *     the thread-local message of the last failure on the calling thread.  There is NO CPU fallback
+ *     anywhere behind this ABI: without a usable GPU the compute calls fail with MP_ERR_HIP.
+ *   - arrays are C-contiguous (row-major), exactly the shapes the reference's Python API uses;
+ *     "d_" parameters are device pointers obtained from mp_malloc (16-byte aligned), "h_" or
+ *     unprefixed pointers are host memory owned by the caller.
+ *   - kernels are enqueued on the context's compute stream and return immediately; the *_host
+ *     variants copy in, launch, copy out and synchronise before returning.
+ *   - a context is bound to one device; one context per process per GPU (one process per GPU for
+ *     multi-GPU jobs, see mp_comm_*).  Calls on one context must not race from several threads.
+ */
+#ifndef MANIPULA_HIP_H
+#define MANIPULA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MP_OK 0
+#define MP_ERR_INVALID 1      /* bad argument (null pointer, shape, alignment, dof mismatch) */
+#define MP_ERR_HIP 2          /* HIP runtime failure (no device, launch error, out of memory) */
+#define MP_ERR_MODEL 3        /* robot tables rejected by the model compiler */
+#define MP_ERR_UNSUPPORTED 4  /* valid request this build does not implement */
+#define MP_ERR_COMM 5         /* RCCL failure */
+
+#define MP_MAX_DOF 8
+#define MP_UNIQUE_ID_BYTES 128
+
+typedef struct mp_ctx mp_ctx;     /* device context: device id, streams, device-buffer pool */
+typedef struct mp_model mp_model; /* compiled robot model (host object, passed to kernels by value) */
+typedef struct mp_event mp_event; /* HIP event on the context's compute stream */
+typedef struct mp_comm mp_comm;   /* RCCL communicator (one rank per process) */
+
+/* ---- library / device ----------------------------------------------------------------------- */
+int mp_version(void);                 /* ABI version, currently 1 */
+const char* mp_last_error(void);      /* message of the last error on this thread ("" if none) */
+/* Number of visible HIP devices; 0 with MP_OK when the runtime loads but finds none.
+ * Replaces the reference's CUDA probe, cuda_kernels/_runtime.py:32-73 / registry.py:92-137. */
+int mp_device_count(int* count);
+int mp_ctx_create(int device_id, mp_ctx** out);
+int mp_ctx_destroy(mp_ctx* ctx);
+int mp_ctx_synchronize(mp_ctx* ctx);  /* waits for every stream of the context */
+/* name, CU count, total HBM bytes — replaces get_gpu_properties(), cuda_kernels/registry.py:335-356 */
+int mp_ctx_properties(mp_ctx* ctx, char* name, size_t name_len, int* compute_units, uint64_t* hbm_bytes);
+/* Launch a 1-block probe kernel that writes its lane ids and check the result on the host.
+ * Replaces the reference's device self-test kernel, cuda_kernels/_runtime.py:127-138. */
+int mp_selftest(mp_ctx* ctx);
+
+/* ---- device memory (pooled per context; replaces _GlobalCudaMemoryPool, cuda_kernels/memory.py:55-118,
+ *      and the pinned-H2D helper _h2d_pinned, cuda_kernels/memory.py:12-50) ----------------------- */
+int mp_malloc(mp_ctx* ctx, size_t bytes, void** d_ptr);
+int mp_free(mp_ctx* ctx, void* d_ptr);            /* returns the buffer to the pool */
+int mp_pool_trim(mp_ctx* ctx);                    /* releases pooled buffers back to the driver */
+int mp_memcpy_h2d(mp_ctx* ctx, void* d_dst, const void* h_src, size_t bytes); /* synchronous */
+int mp_memcpy_d2h(mp_ctx* ctx, void* h_dst, const void* d_src, size_t bytes); /* synchronous */
+int mp_memset(mp_ctx* ctx, void* d_dst, int value, size_t bytes);
+
+/* ---- timing on the compute stream ------------------------------------------------------------ */
+int mp_event_create(mp_ctx* ctx, mp_event** out);
+int mp_event_destroy(mp_event* ev);
+int mp_event_record(mp_ctx* ctx, mp_event* ev);   /* on the stream the kernels are launched on */
+int mp_event_elapsed_ms(mp_event* start, mp_event* stop, float* ms); /* synchronises on `stop` */
+
+/* ---- robot model ------------------------------------------------------------------------------
+ * Inputs are the reference's constant tables (urdf/core.py:670-769; ManipulatorDynamics ctor,
+ * dynamics/manipulator_dynamics.py:43-86), float64 row-major:
+ *   S (6,n) space screws [w;v]; Mcom n x (4,4) = Mlist_per_link; G n x (6,6) = Glist;
+ *   M_ee (4,4) = M_list; joint_limits (n,2) or NULL (= unbounded); torque_limits (n,2) or NULL
+ *   (= +-inf, planning/trajectory_planning.py:219-223).  Limits are rounded to float32 as the
+ *   planner stores them (:218).  No device is needed: the model is host data. */
+int mp_model_create(int n, const double* S, const double* Mcom, const double* G, const double* M_ee,
+                    const double* joint_limits, const double* torque_limits, mp_model** out);
+int mp_model_destroy(mp_model* model);
+int mp_model_dof(const mp_model* model, int* n);
+/* Compiled per-joint parameters, 16 doubles per joint (see csrc/mp_model.h): for inspection/tests. */
+int mp_model_params(const mp_model* model, double* out /* n*16 */);
+/* End-effector pose through the compiled chain on the HOST in float64 (model self-check helper). */
+int mp_model_fk_host(const mp_model* model, const double* q /* n */, double* T /* 16 */);
+
+/* ---- hot path, device pointers ----------------------------------------------------------------
+ * g: (3,) gravity vector or NULL (= [0,0,-9.81], planning/trajectory_dynamics.py:54);
+ * Ftip: (6,) SPACE-frame wrench [m;f] or NULL (= 0) (dynamics/id_fd.py:41-47). */
+
+/* pos/vel/acc (B,N,n) float32 for B start/end pairs (B,n): time scaling of
+ * planning/trajectory.py:15-75 + clip of positions to the joint limits (:311-313, :479-481).
+ * Replaces batch_trajectory_kernel, cuda_kernels/trajectory_kernels.py:763-831, and its launcher
+ * optimized_batch_trajectory_generation (:1204-1290); B = 1 is joint_trajectory (registry launchers
+ * "trajectory.*", cuda_kernels/registry.py:828-867).  method: 3 cubic, 5 quintic, else zeros. */
+int mp_batch_trajectory_f32(mp_ctx* ctx, const mp_model* model, const float* d_start, const float* d_end,
+                            int64_t B, int64_t N, double Tf, int method, float* d_pos, float* d_vel, float* d_acc);
+
+/* tau (rows,n) = clip(inverse_dynamics(q, qd, qdd, g, Ftip), torque_limits) for `rows` independent
+ * (trajectory, timestep) rows.  Replaces _inverse_dynamics_gpu / inverse_dynamics_kernel
+ * (planning/trajectory_dynamics.py:92-306, cuda_kernels/trajectory_kernels.py:521-602) with the
+ * arithmetic of _inverse_dynamics_cpu (:308-380) -> dynamics/id_fd.py:16-48. */
+int mp_id_trajectory_f32(mp_ctx* ctx, const mp_model* model, const float* d_q, const float* d_qd,
+                         const float* d_qdd, int64_t rows, const double* g, const double* Ftip, float* d_tau);
+int mp_id_trajectory_f64(mp_ctx* ctx, const mp_model* model, const double* d_q, const double* d_qd,
+                         const double* d_qdd, int64_t rows, const double* g, const double* Ftip, double* d_tau);
+
+/* joint_trajectory -> inverse_dynamics_trajectory fused: tau (B,N,n) straight from (B,n) start/end
+ * pairs; the intermediate positions (clipped) / velocities / accelerations are rounded to float32
+ * exactly as the two-call pipeline would store them, but never touch HBM. */
+int mp_traj_id_fused_f32(mp_ctx* ctx, const mp_model* model, const float* d_start, const float* d_end,
+                         int64_t B, int64_t N, double Tf, int method, const double* g, const double* Ftip,
+                         float* d_tau);
+
+/* Per row: T (4,4) = forward_kinematics(q,"space") (kinematics/fk.py:59-70), J (6,n) =
+ * jacobian(q,"space") (kinematics/jacobian.py:62-73), tau as above.  Any of d_T / d_J / d_tau may
+ * be NULL to skip that output (d_qd/d_qdd may then be NULL too). */
+int mp_fk_jac_id_f64(mp_ctx* ctx, const mp_model* model, const double* d_q, const double* d_qd,
+                     const double* d_qdd, int64_t rows, const double* g, const double* Ftip, double* d_T,
+                     double* d_J, double* d_tau);
+int mp_fk_jac_id_f32(mp_ctx* ctx, const mp_model* model, const float* d_q, const float* d_qd,
+                     const float* d_qdd, int64_t rows, const double* g, const double* Ftip, float* d_T,
+                     float* d_J, float* d_tau);
+
+/* ---- hot path, host pointers (what a Python gpu_launcher calls): H2D, launch, D2H, synchronise - */
+int mp_batch_trajectory_host_f32(mp_ctx* ctx, const mp_model* model, const float* start, const float* end,
+                                 int64_t B, int64_t N, double Tf, int method, float* pos, float* vel, float* acc);
+int mp_id_trajectory_host_f32(mp_ctx* ctx, const mp_model* model, const float* q, const float* qd,
+                              const float* qdd, int64_t rows, const double* g, const double* Ftip, float* tau);
+int mp_id_trajectory_host_f64(mp_ctx* ctx, const mp_model* model, const double* q, const double* qd,
+                              const double* qdd, int64_t rows, const double* g, const double* Ftip, double* tau);
+int mp_traj_id_fused_host_f32(mp_ctx* ctx, const mp_model* model, const float* start, const float* end,
+                              int64_t B, int64_t N, double Tf, int method, const double* g, const double* Ftip,
+                              float* tau);
+int mp_fk_jac_id_host_f64(mp_ctx* ctx, const mp_model* model, const double* q, const double* qd,
+                          const double* qdd, int64_t rows, const double* g, const double* Ftip, double* T,
+                          double* J, double* tau);
+
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI (new; the reference is single-device) ------
+ * Trajectory batches are sharded over ranks with no exchange during compute; the only collective is
+ * the all-gather that reassembles the torque history.  Rank 0 creates the id, the launcher
+ * broadcasts its 128 bytes out of band (bench.py uses the torch.distributed gloo store). */
+int mp_comm_unique_id(uint8_t id[MP_UNIQUE_ID_BYTES]);
+int mp_comm_create(mp_ctx* ctx, const uint8_t id[MP_UNIQUE_ID_BYTES], int nranks, int rank, mp_comm** out);
+int mp_comm_destroy(mp_comm* comm);
+/* d_recv (nranks * bytes_per_rank) <- every rank's d_send (bytes_per_rank); enqueued on the compute
+ * stream after the kernels already queued there. */
+int mp_comm_allgather(mp_comm* comm, const void* d_send, void* d_recv, size_t bytes_per_rank);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MANIPULA_HIP_H */

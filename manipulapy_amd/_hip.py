@@ -1,0 +1,415 @@
+"""ctypes binding of libmanipula_hip.so (include/manipula_hip.h).
+
+This is the whole FFI: no PyTorch, CuPy or Triton on the product path.  There is no CPU fallback
+behind it — if the library or a GPU is missing the calls raise (`HipUnavailableError` /
+`HipError`), they never silently compute somewhere else.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+from typing import Optional, Sequence
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_ENV = "MANIPULAPY_HIP_LIB"  # override the library path
+DEFAULT_LIB = os.path.join(_PKG, "libmanipula_hip.so")
+
+MP_OK = 0
+MP_MAX_DOF = 8
+UNIQUE_ID_BYTES = 128
+
+
+class HipError(RuntimeError):
+    """A libmanipula_hip call returned a non-zero code (message from mp_last_error)."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"[manipula_hip rc={code}] {message}")
+        self.code = code
+
+
+class HipUnavailableError(RuntimeError):
+    """The native library cannot be loaded, or no GPU is visible."""
+
+
+_c_dp = ctypes.POINTER(ctypes.c_double)
+_c_fp = ctypes.POINTER(ctypes.c_float)
+_vp = ctypes.c_void_p
+_i64 = ctypes.c_int64
+
+# name -> (restype, argtypes); the list is also what tests/test_cabi_symbols.py checks against the header
+SIGNATURES = {
+    "mp_version": (ctypes.c_int, []),
+    "mp_last_error": (ctypes.c_char_p, []),
+    "mp_device_count": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
+    "mp_ctx_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_vp)]),
+    "mp_ctx_destroy": (ctypes.c_int, [_vp]),
+    "mp_ctx_synchronize": (ctypes.c_int, [_vp]),
+    "mp_ctx_properties": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint64)]),
+    "mp_selftest": (ctypes.c_int, [_vp]),
+    "mp_malloc": (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.POINTER(_vp)]),
+    "mp_free": (ctypes.c_int, [_vp, _vp]),
+    "mp_pool_trim": (ctypes.c_int, [_vp]),
+    "mp_memcpy_h2d": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t]),
+    "mp_memcpy_d2h": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t]),
+    "mp_memset": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_size_t]),
+    "mp_event_create": (ctypes.c_int, [_vp, ctypes.POINTER(_vp)]),
+    "mp_event_destroy": (ctypes.c_int, [_vp]),
+    "mp_event_record": (ctypes.c_int, [_vp, _vp]),
+    "mp_event_elapsed_ms": (ctypes.c_int, [_vp, _vp, ctypes.POINTER(ctypes.c_float)]),
+    "mp_model_create": (ctypes.c_int, [ctypes.c_int, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, ctypes.POINTER(_vp)]),
+    "mp_model_destroy": (ctypes.c_int, [_vp]),
+    "mp_model_dof": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int)]),
+    "mp_model_params": (ctypes.c_int, [_vp, _c_dp]),
+    "mp_model_fk_host": (ctypes.c_int, [_vp, _c_dp, _c_dp]),
+    "mp_batch_trajectory_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, ctypes.c_double, ctypes.c_int, _vp, _vp, _vp]),
+    "mp_id_trajectory_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _c_dp, _c_dp, _vp]),
+    "mp_id_trajectory_f64": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _c_dp, _c_dp, _vp]),
+    "mp_traj_id_fused_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, ctypes.c_double, ctypes.c_int, _c_dp, _c_dp, _vp]),
+    "mp_fk_jac_id_f64": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _c_dp, _c_dp, _vp, _vp, _vp]),
+    "mp_fk_jac_id_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _c_dp, _c_dp, _vp, _vp, _vp]),
+    "mp_batch_trajectory_host_f32": (ctypes.c_int, [_vp, _vp, _c_fp, _c_fp, _i64, _i64, ctypes.c_double, ctypes.c_int, _c_fp, _c_fp, _c_fp]),
+    "mp_id_trajectory_host_f32": (ctypes.c_int, [_vp, _vp, _c_fp, _c_fp, _c_fp, _i64, _c_dp, _c_dp, _c_fp]),
+    "mp_id_trajectory_host_f64": (ctypes.c_int, [_vp, _vp, _c_dp, _c_dp, _c_dp, _i64, _c_dp, _c_dp, _c_dp]),
+    "mp_traj_id_fused_host_f32": (ctypes.c_int, [_vp, _vp, _c_fp, _c_fp, _i64, _i64, ctypes.c_double, ctypes.c_int, _c_dp, _c_dp, _c_fp]),
+    "mp_fk_jac_id_host_f64": (ctypes.c_int, [_vp, _vp, _c_dp, _c_dp, _c_dp, _i64, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp]),
+    "mp_comm_unique_id": (ctypes.c_int, [ctypes.POINTER(ctypes.c_uint8)]),
+    "mp_comm_create": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint8), ctypes.c_int, ctypes.c_int, ctypes.POINTER(_vp)]),
+    "mp_comm_destroy": (ctypes.c_int, [_vp]),
+    "mp_comm_allgather": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t]),
+}
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def lib_path() -> str:
+    return os.environ.get(LIB_ENV, DEFAULT_LIB)
+
+
+def load_library():
+    """Load (once) and type the shared library.  Raises HipUnavailableError if it is not built."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        path = lib_path()
+        if not os.path.exists(path):
+            raise HipUnavailableError(
+                f"{path} not found: build it with `python -m manipulapy_amd.build` (needs hipcc); "
+                "there is no CPU fallback for the HIP backend")
+        try:
+            lib = ctypes.CDLL(path)
+        except OSError as exc:
+            raise HipUnavailableError(f"cannot load {path}: {exc}") from exc
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+def _check(rc: int) -> None:
+    if rc != MP_OK:
+        msg = load_library().mp_last_error()
+        raise HipError(rc, msg.decode("utf-8", "replace") if msg else "unknown error")
+
+
+def device_count() -> int:
+    """Number of visible GPUs (0 if none).  Raises only when the library itself is missing."""
+    n = ctypes.c_int(0)
+    rc = load_library().mp_device_count(ctypes.byref(n))
+    if rc != MP_OK:
+        return 0
+    return int(n.value)
+
+
+def _dptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(_c_dp)
+
+
+def _fptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(_c_fp)
+
+
+def _as_c(a, dtype, shape=None, name="array") -> np.ndarray:
+    arr = np.ascontiguousarray(a, dtype=dtype)
+    if shape is not None and tuple(arr.shape) != tuple(shape):
+        raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(arr.shape)}")
+    return arr
+
+
+def _vec_or_none(v, k, name):
+    if v is None:
+        return None
+    return _as_c(v, np.float64, (k,), name)
+
+
+class DeviceBuffer:
+    """A pooled device allocation (mp_malloc / mp_free)."""
+
+    def __init__(self, ctx: "HipContext", nbytes: int):
+        self.ctx = ctx
+        self.nbytes = int(nbytes)
+        p = _vp()
+        _check(ctx.lib.mp_malloc(ctx.handle, ctypes.c_size_t(max(self.nbytes, 1)), ctypes.byref(p)))
+        self.ptr = p
+
+    def upload(self, host: np.ndarray) -> "DeviceBuffer":
+        host = np.ascontiguousarray(host)
+        if host.nbytes > self.nbytes:
+            raise ValueError("upload larger than the device buffer")
+        _check(self.ctx.lib.mp_memcpy_h2d(self.ctx.handle, self.ptr, host.ctypes.data_as(_vp), ctypes.c_size_t(host.nbytes)))
+        return self
+
+    def download(self, shape, dtype) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        if out.nbytes > self.nbytes:
+            raise ValueError("download larger than the device buffer")
+        _check(self.ctx.lib.mp_memcpy_d2h(self.ctx.handle, out.ctypes.data_as(_vp), self.ptr, ctypes.c_size_t(out.nbytes)))
+        return out
+
+    def free(self) -> None:
+        if self.ptr is not None and self.ctx.handle is not None:
+            self.ctx.lib.mp_free(self.ctx.handle, self.ptr)
+        self.ptr = None
+
+    def offset(self, nbytes: int) -> ctypes.c_void_p:
+        return _vp(self.ptr.value + int(nbytes))
+
+
+class HipEvent:
+    def __init__(self, ctx: "HipContext"):
+        self.ctx = ctx
+        p = _vp()
+        _check(ctx.lib.mp_event_create(ctx.handle, ctypes.byref(p)))
+        self.handle = p
+
+    def record(self) -> None:
+        _check(self.ctx.lib.mp_event_record(self.ctx.handle, self.handle))
+
+    def elapsed_ms_since(self, start: "HipEvent") -> float:
+        ms = ctypes.c_float(0)
+        _check(self.ctx.lib.mp_event_elapsed_ms(start.handle, self.handle, ctypes.byref(ms)))
+        return float(ms.value)
+
+    def destroy(self) -> None:
+        if self.handle is not None:
+            self.ctx.lib.mp_event_destroy(self.handle)
+            self.handle = None
+
+
+class HipModel:
+    """Compiled robot model (mp_model_create).  Host-only object: no GPU needed to build one."""
+
+    def __init__(self, S_list, Mlist_per_link, Glist, M_ee, joint_limits=None, torque_limits=None):
+        self.lib = load_library()
+        S = _as_c(S_list, np.float64, name="S_list")
+        if S.ndim != 2 or S.shape[0] != 6:
+            raise ValueError(f"S_list must be (6, n), got {S.shape}")
+        n = S.shape[1]
+        Mc = _as_c(Mlist_per_link, np.float64, (n, 4, 4), "Mlist_per_link")
+        G = _as_c(Glist, np.float64, (n, 6, 6), "Glist")
+        Me = _as_c(M_ee, np.float64, (4, 4), "M_list")
+        jl = None if joint_limits is None else _as_c(joint_limits, np.float64, (n, 2), "joint_limits")
+        tl = None if torque_limits is None else _as_c(torque_limits, np.float64, (n, 2), "torque_limits")
+        p = _vp()
+        _check(self.lib.mp_model_create(n, _dptr(S), _dptr(Mc), _dptr(G), _dptr(Me), _dptr(jl), _dptr(tl), ctypes.byref(p)))
+        self.handle = p
+        self.n = n
+
+    def params(self) -> np.ndarray:
+        out = np.zeros((self.n, 16))
+        _check(self.lib.mp_model_params(self.handle, _dptr(out)))
+        return out
+
+    def fk_host(self, q) -> np.ndarray:
+        q = _as_c(q, np.float64, (self.n,), "q")
+        T = np.zeros((4, 4))
+        _check(self.lib.mp_model_fk_host(self.handle, _dptr(q), _dptr(T)))
+        return T
+
+    def destroy(self) -> None:
+        if getattr(self, "handle", None) is not None:
+            self.lib.mp_model_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class HipContext:
+    """One device context (streams + pooled device memory).  Fails loudly without a GPU."""
+
+    def __init__(self, device_id: int = 0):
+        self.lib = load_library()
+        self.handle = None
+        n = ctypes.c_int(0)
+        rc = self.lib.mp_device_count(ctypes.byref(n))
+        if rc != MP_OK or n.value <= 0:
+            raise HipUnavailableError("no HIP device visible: the HIP backend has no CPU fallback")
+        p = _vp()
+        _check(self.lib.mp_ctx_create(int(device_id), ctypes.byref(p)))
+        self.handle = p
+        self.device_id = int(device_id)
+
+    # ---- plumbing
+    def synchronize(self) -> None:
+        _check(self.lib.mp_ctx_synchronize(self.handle))
+
+    def selftest(self) -> None:
+        _check(self.lib.mp_selftest(self.handle))
+
+    def properties(self) -> dict:
+        name = ctypes.create_string_buffer(256)
+        cu = ctypes.c_int(0)
+        mem = ctypes.c_uint64(0)
+        _check(self.lib.mp_ctx_properties(self.handle, name, 256, ctypes.byref(cu), ctypes.byref(mem)))
+        # key names follow the reference's get_gpu_properties() (cuda_kernels/registry.py:335-356)
+        return {"name": name.value.decode(), "multiprocessor_count": int(cu.value), "total_memory": int(mem.value),
+                "warp_size": 64}
+
+    def alloc(self, nbytes: int) -> DeviceBuffer:
+        return DeviceBuffer(self, nbytes)
+
+    def to_device(self, host: np.ndarray) -> DeviceBuffer:
+        host = np.ascontiguousarray(host)
+        return DeviceBuffer(self, host.nbytes).upload(host)
+
+    def event(self) -> HipEvent:
+        return HipEvent(self)
+
+    def trim_pool(self) -> None:
+        _check(self.lib.mp_pool_trim(self.handle))
+
+    def destroy(self) -> None:
+        if self.handle is not None:
+            self.lib.mp_ctx_destroy(self.handle)
+            self.handle = None
+
+    # ---- hot path on device buffers (asynchronous)
+    def id_trajectory(self, model: HipModel, d_q, d_qd, d_qdd, rows: int, d_tau, g=None, Ftip=None, dtype=np.float32):
+        fn = self.lib.mp_id_trajectory_f32 if np.dtype(dtype) == np.float32 else self.lib.mp_id_trajectory_f64
+        g = _vec_or_none(g, 3, "g")
+        F = _vec_or_none(Ftip, 6, "Ftip")
+        _check(fn(self.handle, model.handle, _p(d_q), _p(d_qd), _p(d_qdd), int(rows), _dptr(g), _dptr(F), _p(d_tau)))
+
+    def batch_trajectory(self, model, d_start, d_end, B, N, Tf, method, d_pos, d_vel, d_acc):
+        _check(self.lib.mp_batch_trajectory_f32(self.handle, model.handle, _p(d_start), _p(d_end), int(B), int(N),
+                                                float(Tf), int(method), _p(d_pos), _p(d_vel), _p(d_acc)))
+
+    def traj_id_fused(self, model, d_start, d_end, B, N, Tf, method, d_tau, g=None, Ftip=None):
+        g = _vec_or_none(g, 3, "g")
+        F = _vec_or_none(Ftip, 6, "Ftip")
+        _check(self.lib.mp_traj_id_fused_f32(self.handle, model.handle, _p(d_start), _p(d_end), int(B), int(N),
+                                             float(Tf), int(method), _dptr(g), _dptr(F), _p(d_tau)))
+
+    def fk_jac_id(self, model, d_q, d_qd, d_qdd, rows, d_T, d_J, d_tau, g=None, Ftip=None, dtype=np.float64):
+        fn = self.lib.mp_fk_jac_id_f64 if np.dtype(dtype) == np.float64 else self.lib.mp_fk_jac_id_f32
+        g = _vec_or_none(g, 3, "g")
+        F = _vec_or_none(Ftip, 6, "Ftip")
+        _check(fn(self.handle, model.handle, _p(d_q), _p(d_qd), _p(d_qdd), int(rows), _dptr(g), _dptr(F), _p(d_T), _p(d_J), _p(d_tau)))
+
+    # ---- hot path on host arrays (what the registry's gpu launchers call; synchronous)
+    def id_trajectory_host(self, model: HipModel, q, qd, qdd, g=None, Ftip=None, dtype=np.float32) -> np.ndarray:
+        dtype = np.dtype(dtype)
+        q = _as_c(q, dtype, name="q")
+        if q.ndim != 2 or q.shape[1] != model.n:
+            raise ValueError(f"q must be (rows, {model.n}), got {q.shape}")
+        qd = _as_c(qd, dtype, q.shape, "qd")
+        qdd = _as_c(qdd, dtype, q.shape, "qdd")
+        tau = np.empty_like(q)
+        g = _vec_or_none(g, 3, "g")
+        F = _vec_or_none(Ftip, 6, "Ftip")
+        if dtype == np.float32:
+            _check(self.lib.mp_id_trajectory_host_f32(self.handle, model.handle, _fptr(q), _fptr(qd), _fptr(qdd),
+                                                      q.shape[0], _dptr(g), _dptr(F), _fptr(tau)))
+        else:
+            _check(self.lib.mp_id_trajectory_host_f64(self.handle, model.handle, _dptr(q), _dptr(qd), _dptr(qdd),
+                                                      q.shape[0], _dptr(g), _dptr(F), _dptr(tau)))
+        return tau
+
+    def batch_trajectory_host(self, model: HipModel, start, end, Tf, N, method):
+        start = _as_c(start, np.float32, name="thetastart_batch")
+        if start.ndim != 2 or start.shape[1] != model.n:
+            raise ValueError(f"thetastart_batch must be (B, {model.n}), got {start.shape}")
+        end = _as_c(end, np.float32, start.shape, "thetaend_batch")
+        B = start.shape[0]
+        out = [np.zeros((B, int(N), model.n), dtype=np.float32) for _ in range(3)]
+        _check(self.lib.mp_batch_trajectory_host_f32(self.handle, model.handle, _fptr(start), _fptr(end), B, int(N),
+                                                     float(Tf), int(method), _fptr(out[0]), _fptr(out[1]), _fptr(out[2])))
+        return tuple(out)
+
+    def traj_id_fused_host(self, model: HipModel, start, end, Tf, N, method, g=None, Ftip=None) -> np.ndarray:
+        start = _as_c(start, np.float32, name="thetastart_batch")
+        if start.ndim != 2 or start.shape[1] != model.n:
+            raise ValueError(f"thetastart_batch must be (B, {model.n}), got {start.shape}")
+        end = _as_c(end, np.float32, start.shape, "thetaend_batch")
+        B = start.shape[0]
+        tau = np.zeros((B, int(N), model.n), dtype=np.float32)
+        g = _vec_or_none(g, 3, "g")
+        F = _vec_or_none(Ftip, 6, "Ftip")
+        _check(self.lib.mp_traj_id_fused_host_f32(self.handle, model.handle, _fptr(start), _fptr(end), B, int(N),
+                                                  float(Tf), int(method), _dptr(g), _dptr(F), _fptr(tau)))
+        return tau
+
+    def fk_jac_id_host(self, model: HipModel, q, qd=None, qdd=None, g=None, Ftip=None, want_T=True, want_J=True):
+        q = _as_c(q, np.float64, name="q")
+        if q.ndim != 2 or q.shape[1] != model.n:
+            raise ValueError(f"q must be (rows, {model.n}), got {q.shape}")
+        rows = q.shape[0]
+        want_tau = qd is not None and qdd is not None
+        qd = _as_c(qd, np.float64, q.shape, "qd") if want_tau else None
+        qdd = _as_c(qdd, np.float64, q.shape, "qdd") if want_tau else None
+        T = np.zeros((rows, 4, 4)) if want_T else None
+        J = np.zeros((rows, 6, model.n)) if want_J else None
+        tau = np.zeros((rows, model.n)) if want_tau else None
+        g = _vec_or_none(g, 3, "g")
+        F = _vec_or_none(Ftip, 6, "Ftip")
+        _check(self.lib.mp_fk_jac_id_host_f64(self.handle, model.handle, _dptr(q), _dptr(qd), _dptr(qdd), rows,
+                                              _dptr(g), _dptr(F), _dptr(T), _dptr(J), _dptr(tau)))
+        return T, J, tau
+
+    # ---- RCCL
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = (ctypes.c_uint8 * UNIQUE_ID_BYTES)()
+        _check(load_library().mp_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_create(self, unique_id: bytes, nranks: int, rank: int) -> "HipComm":
+        return HipComm(self, unique_id, nranks, rank)
+
+
+def _p(buf):
+    if buf is None:
+        return None
+    if isinstance(buf, DeviceBuffer):
+        return buf.ptr
+    return buf  # already a c_void_p
+
+
+class HipComm:
+    def __init__(self, ctx: HipContext, unique_id: bytes, nranks: int, rank: int):
+        if len(unique_id) != UNIQUE_ID_BYTES:
+            raise ValueError("unique id must be 128 bytes")
+        self.ctx = ctx
+        self.nranks, self.rank = int(nranks), int(rank)
+        buf = (ctypes.c_uint8 * UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
+        p = _vp()
+        _check(ctx.lib.mp_comm_create(ctx.handle, buf, self.nranks, self.rank, ctypes.byref(p)))
+        self.handle = p
+
+    def allgather(self, d_send, d_recv, bytes_per_rank: int) -> None:
+        _check(self.ctx.lib.mp_comm_allgather(self.handle, _p(d_send), _p(d_recv), ctypes.c_size_t(int(bytes_per_rank))))
+
+    def destroy(self) -> None:
+        if self.handle is not None:
+            self.ctx.lib.mp_comm_destroy(self.handle)
+            self.handle = None

@@ -1,0 +1,520 @@
+// C ABI of libmanipula_hip.so — see include/manipula_hip.h for the contract.
+// Host-only translation unit (no device code): context / streams / pooled device memory / events,
+// model handles, argument validation and the host-pointer convenience wrappers.
+#include <hip/hip_runtime_api.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <new>
+#include <vector>
+
+#include "../../include/manipula_hip.h"
+#include "mp_kernels.h"
+#include "mp_model_compile.h"
+
+// ------------------------------------------------------------------------------------- objects
+struct mp_ctx {
+  int device = -1;
+  hipStream_t compute = nullptr;
+  hipStream_t copy = nullptr;
+  std::map<size_t, std::vector<void*>> free_by_size;  // pool: exact-size free lists
+  std::map<void*, size_t> live;                        // every buffer handed out -> its size
+};
+struct mp_model {
+  MpModel<double> d;
+  MpModel<float> f;
+};
+struct mp_event {
+  hipEvent_t ev = nullptr;
+  int device = -1;
+};
+
+namespace {
+thread_local char g_err[512] = "";
+
+int set_err(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  std::vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+int hip_err(hipError_t e, const char* what) {
+  return set_err(MP_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+#define HIP_TRY(expr)                                   \
+  do {                                                  \
+    hipError_t e_ = (expr);                             \
+    if (e_ != hipSuccess) return hip_err(e_, #expr);    \
+  } while (0)
+#define REQUIRE(cond, ...)                                        \
+  do {                                                            \
+    if (!(cond)) return set_err(MP_ERR_INVALID, __VA_ARGS__);     \
+  } while (0)
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+const double kG[3] = {0.0, 0.0, -9.81};  // reference planning/trajectory_dynamics.py:54
+
+bool any_nonzero(const double* F) {
+  if (!F) return false;
+  for (int k = 0; k < 6; ++k)
+    if (F[k] != 0.0) return true;
+  return false;
+}
+int bind(mp_ctx* ctx) {
+  HIP_TRY(hipSetDevice(ctx->device));
+  return MP_OK;
+}
+template <typename T> const MpModel<T>& pick(const mp_model* m);
+template <> const MpModel<float>& pick<float>(const mp_model* m) { return m->f; }
+template <> const MpModel<double>& pick<double>(const mp_model* m) { return m->d; }
+
+template <typename T>
+void make_call(const mp_model* m, const double* g, const double* Ftip, MpCall<T>* c) {
+  MpCall<double> cd;
+  mp_make_call(m->d, g ? g : kG, Ftip, &cd);
+  mp_call_cast(cd, c);
+}
+
+// RAII device scratch from the pool for the *_host wrappers
+struct Scratch {
+  mp_ctx* ctx;
+  std::vector<void*> bufs;
+  explicit Scratch(mp_ctx* c) : ctx(c) {}
+  ~Scratch() { for (void* p : bufs) mp_free(ctx, p); }
+  int get(size_t bytes, void** p) {
+    int rc = mp_malloc(ctx, bytes ? bytes : 16, p);
+    if (rc == MP_OK) bufs.push_back(*p);
+    return rc;
+  }
+};
+#define H2D(dst, src, bytes) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->compute))
+#define D2H(dst, src, bytes) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->compute))
+
+
+// template bodies shared by the f32 / f64 entry points (C++ linkage)
+template <typename T>
+static int id_impl(const char* fn, mp_ctx* ctx, const mp_model* model, const T* d_q, const T* d_qd, const T* d_qdd,
+                   int64_t rows, const double* g, const double* Ftip, T* d_tau) {
+  REQUIRE(ctx && model, "%s: null context or model", fn);
+  if (int rc = bind(ctx)) return rc;
+  REQUIRE(rows >= 0, "%s: negative row count %lld", fn, (long long)rows);
+  if (rows == 0) return MP_OK;
+  REQUIRE(d_q && d_qd && d_qdd && d_tau, "%s: null device pointer", fn);
+  REQUIRE(aligned16(d_q) && aligned16(d_qd) && aligned16(d_qdd) && aligned16(d_tau),
+          "%s: device pointers must be 16-byte aligned", fn);
+  MpCall<T> c;
+  make_call<T>(model, g, Ftip, &c);
+  HIP_TRY(mpk_id<T>(ctx->compute, pick<T>(model), c, any_nonzero(Ftip), d_q, d_qd, d_qdd, d_tau, (long)rows));
+  return MP_OK;
+}
+
+template <typename T>
+static int fkjid_impl(const char* fn, mp_ctx* ctx, const mp_model* model, const T* d_q, const T* d_qd, const T* d_qdd,
+                      int64_t rows, const double* g, const double* Ftip, T* d_T, T* d_J, T* d_tau) {
+  REQUIRE(ctx && model, "%s: null context or model", fn);
+  if (int rc = bind(ctx)) return rc;
+  REQUIRE(rows >= 0, "%s: negative row count %lld", fn, (long long)rows);
+  if (rows == 0) return MP_OK;
+  REQUIRE(d_q, "%s: null d_q", fn);
+  REQUIRE(d_T || d_J || d_tau, "%s: at least one output is required", fn);
+  REQUIRE(!d_tau || (d_qd && d_qdd), "%s: d_tau requested without d_qd / d_qdd", fn);
+  REQUIRE(aligned16(d_q) && aligned16(d_qd) && aligned16(d_qdd) && aligned16(d_T) && aligned16(d_J) && aligned16(d_tau),
+          "%s: device pointers must be 16-byte aligned", fn);
+  MpCall<T> c;
+  make_call<T>(model, g, Ftip, &c);
+  HIP_TRY(mpk_fk_jac_id<T>(ctx->compute, pick<T>(model), c, any_nonzero(Ftip), d_q, d_qd, d_qdd, d_T, d_J, d_tau, (long)rows));
+  return MP_OK;
+}
+
+template <typename T>
+static int id_host_impl(const char* fn, mp_ctx* ctx, const mp_model* model, const T* q, const T* qd, const T* qdd,
+                        int64_t rows, const double* g, const double* Ftip, T* tau) {
+  REQUIRE(ctx && model, "%s: null context or model", fn);
+  if (int rc = bind(ctx)) return rc;
+  REQUIRE(rows >= 0, "%s: negative row count", fn);
+  if (rows == 0) return MP_OK;
+  REQUIRE(q && qd && qdd && tau, "%s: null host pointer", fn);
+  const size_t bytes = (size_t)rows * (size_t)model->d.n * sizeof(T);
+  Scratch sc(ctx);
+  void *dq, *dqd, *dqdd, *dt;
+  if (int rc = sc.get(bytes, &dq)) return rc;
+  if (int rc = sc.get(bytes, &dqd)) return rc;
+  if (int rc = sc.get(bytes, &dqdd)) return rc;
+  if (int rc = sc.get(bytes, &dt)) return rc;
+  H2D(dq, q, bytes);
+  H2D(dqd, qd, bytes);
+  H2D(dqdd, qdd, bytes);
+  if (int rc = id_impl<T>(fn, ctx, model, (T*)dq, (T*)dqd, (T*)dqdd, rows, g, Ftip, (T*)dt)) return rc;
+  D2H(tau, dt, bytes);
+  HIP_TRY(hipStreamSynchronize(ctx->compute));
+  return MP_OK;
+}
+}  // namespace
+
+extern "C" {
+
+// ------------------------------------------------------------------------------ library / device
+int mp_version(void) { return 1; }
+const char* mp_last_error(void) { return g_err; }
+
+int mp_device_count(int* count) {
+  REQUIRE(count, "mp_device_count: null output");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e == hipErrorNoDevice) { *count = 0; (void)hipGetLastError(); return MP_OK; }
+  if (e != hipSuccess) { *count = 0; return hip_err(e, "hipGetDeviceCount"); }
+  *count = n;
+  return MP_OK;
+}
+
+int mp_ctx_create(int device_id, mp_ctx** out) {
+  REQUIRE(out, "mp_ctx_create: null output");
+  *out = nullptr;
+  int n = 0;
+  HIP_TRY(hipGetDeviceCount(&n));
+  REQUIRE(device_id >= 0 && device_id < n, "mp_ctx_create: device %d not in [0, %d)", device_id, n);
+  HIP_TRY(hipSetDevice(device_id));
+  mp_ctx* c = new (std::nothrow) mp_ctx;
+  REQUIRE(c, "mp_ctx_create: out of host memory");
+  c->device = device_id;
+  hipError_t e = hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking);
+  if (e != hipSuccess) { delete c; return hip_err(e, "hipStreamCreate"); }
+  *out = c;
+  return MP_OK;
+}
+
+int mp_ctx_destroy(mp_ctx* ctx) {
+  if (!ctx) return MP_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipDeviceSynchronize();
+  for (auto& kv : ctx->live) (void)hipFree(kv.first);
+  if (ctx->compute) (void)hipStreamDestroy(ctx->compute);
+  if (ctx->copy) (void)hipStreamDestroy(ctx->copy);
+  delete ctx;
+  return MP_OK;
+}
+
+int mp_ctx_synchronize(mp_ctx* ctx) {
+  REQUIRE(ctx, "mp_ctx_synchronize: null context");
+  if (int rc = bind(ctx)) return rc;
+  HIP_TRY(hipStreamSynchronize(ctx->compute));
+  HIP_TRY(hipStreamSynchronize(ctx->copy));
+  return MP_OK;
+}
+
+int mp_ctx_properties(mp_ctx* ctx, char* name, size_t name_len, int* compute_units, uint64_t* hbm_bytes) {
+  REQUIRE(ctx, "mp_ctx_properties: null context");
+  hipDeviceProp_t p;
+  HIP_TRY(hipGetDeviceProperties(&p, ctx->device));
+  if (name && name_len) std::snprintf(name, name_len, "%s (%s)", p.name, p.gcnArchName);
+  if (compute_units) *compute_units = p.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = (uint64_t)p.totalGlobalMem;
+  return MP_OK;
+}
+
+int mp_selftest(mp_ctx* ctx) {
+  REQUIRE(ctx, "mp_selftest: null context");
+  if (int rc = bind(ctx)) return rc;
+  Scratch sc(ctx);
+  void* d = nullptr;
+  if (int rc = sc.get(64 * sizeof(int), &d)) return rc;
+  HIP_TRY(hipMemsetAsync(d, 0xFF, 64 * sizeof(int), ctx->compute));
+  HIP_TRY(mpk_selftest(ctx->compute, static_cast<int*>(d)));
+  int h[64];
+  HIP_TRY(hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, ctx->compute));
+  HIP_TRY(hipStreamSynchronize(ctx->compute));
+  for (int i = 0; i < 64; ++i)
+    if (h[i] != i) return set_err(MP_ERR_HIP, "mp_selftest: lane %d wrote %d", i, h[i]);
+  return MP_OK;
+}
+
+// ---------------------------------------------------------------------------------- device memory
+int mp_malloc(mp_ctx* ctx, size_t bytes, void** d_ptr) {
+  REQUIRE(ctx && d_ptr, "mp_malloc: null argument");
+  *d_ptr = nullptr;
+  if (int rc = bind(ctx)) return rc;
+  if (bytes == 0) bytes = 16;
+  bytes = (bytes + 255) & ~size_t(255);
+  auto it = ctx->free_by_size.find(bytes);
+  if (it != ctx->free_by_size.end() && !it->second.empty()) {
+    *d_ptr = it->second.back();
+    it->second.pop_back();
+    return MP_OK;
+  }
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e == hipErrorOutOfMemory) {  // give the pool back and retry once
+    (void)hipGetLastError();
+    mp_pool_trim(ctx);
+    e = hipMalloc(&p, bytes);
+  }
+  if (e != hipSuccess) return hip_err(e, "hipMalloc");
+  ctx->live[p] = bytes;
+  *d_ptr = p;
+  return MP_OK;
+}
+
+int mp_free(mp_ctx* ctx, void* d_ptr) {
+  REQUIRE(ctx, "mp_free: null context");
+  if (!d_ptr) return MP_OK;
+  auto it = ctx->live.find(d_ptr);
+  REQUIRE(it != ctx->live.end(), "mp_free: pointer %p was not allocated by this context", d_ptr);
+  ctx->free_by_size[it->second].push_back(d_ptr);
+  return MP_OK;
+}
+
+int mp_pool_trim(mp_ctx* ctx) {
+  REQUIRE(ctx, "mp_pool_trim: null context");
+  if (int rc = bind(ctx)) return rc;
+  (void)hipStreamSynchronize(ctx->compute);
+  (void)hipStreamSynchronize(ctx->copy);
+  for (auto& kv : ctx->free_by_size)
+    for (void* p : kv.second) {
+      (void)hipFree(p);
+      ctx->live.erase(p);
+    }
+  ctx->free_by_size.clear();
+  return MP_OK;
+}
+
+int mp_memcpy_h2d(mp_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
+  REQUIRE(ctx && (bytes == 0 || (d_dst && h_src)), "mp_memcpy_h2d: null argument");
+  if (bytes == 0) return MP_OK;
+  if (int rc = bind(ctx)) return rc;
+  HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->compute));
+  HIP_TRY(hipStreamSynchronize(ctx->compute));
+  return MP_OK;
+}
+int mp_memcpy_d2h(mp_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
+  REQUIRE(ctx && (bytes == 0 || (h_dst && d_src)), "mp_memcpy_d2h: null argument");
+  if (bytes == 0) return MP_OK;
+  if (int rc = bind(ctx)) return rc;
+  HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->compute));
+  HIP_TRY(hipStreamSynchronize(ctx->compute));
+  return MP_OK;
+}
+int mp_memset(mp_ctx* ctx, void* d_dst, int value, size_t bytes) {
+  REQUIRE(ctx && (bytes == 0 || d_dst), "mp_memset: null argument");
+  if (bytes == 0) return MP_OK;
+  if (int rc = bind(ctx)) return rc;
+  HIP_TRY(hipMemsetAsync(d_dst, value, bytes, ctx->compute));
+  return MP_OK;
+}
+
+// ----------------------------------------------------------------------------------------- events
+int mp_event_create(mp_ctx* ctx, mp_event** out) {
+  REQUIRE(ctx && out, "mp_event_create: null argument");
+  if (int rc = bind(ctx)) return rc;
+  mp_event* e = new (std::nothrow) mp_event;
+  REQUIRE(e, "mp_event_create: out of host memory");
+  e->device = ctx->device;
+  hipError_t he = hipEventCreate(&e->ev);
+  if (he != hipSuccess) { delete e; return hip_err(he, "hipEventCreate"); }
+  *out = e;
+  return MP_OK;
+}
+int mp_event_destroy(mp_event* ev) {
+  if (!ev) return MP_OK;
+  (void)hipSetDevice(ev->device);
+  (void)hipEventDestroy(ev->ev);
+  delete ev;
+  return MP_OK;
+}
+int mp_event_record(mp_ctx* ctx, mp_event* ev) {
+  REQUIRE(ctx && ev, "mp_event_record: null argument");
+  if (int rc = bind(ctx)) return rc;
+  HIP_TRY(hipEventRecord(ev->ev, ctx->compute));
+  return MP_OK;
+}
+int mp_event_elapsed_ms(mp_event* start, mp_event* stop, float* ms) {
+  REQUIRE(start && stop && ms, "mp_event_elapsed_ms: null argument");
+  HIP_TRY(hipSetDevice(stop->device));
+  HIP_TRY(hipEventSynchronize(stop->ev));
+  HIP_TRY(hipEventElapsedTime(ms, start->ev, stop->ev));
+  return MP_OK;
+}
+
+// ------------------------------------------------------------------------------------------ model
+int mp_model_create(int n, const double* S, const double* Mcom, const double* G, const double* M_ee,
+                    const double* joint_limits, const double* torque_limits, mp_model** out) {
+  REQUIRE(out, "mp_model_create: null output");
+  *out = nullptr;
+  REQUIRE(S && Mcom && G && M_ee, "mp_model_create: S, Mcom, G and M_ee are required");
+  REQUIRE(n >= 1 && n <= MP_MAX_DOF, "mp_model_create: dof %d outside 1..%d", n, MP_MAX_DOF);
+  mp_model* m = new (std::nothrow) mp_model;
+  REQUIRE(m, "mp_model_create: out of host memory");
+  char msg[400] = "";
+  int rc = mp_compile_model(n, S, Mcom, G, M_ee, joint_limits, torque_limits, &m->d, msg, sizeof msg);
+  if (rc) {
+    delete m;
+    return set_err(MP_ERR_MODEL, "mp_model_create: %s", msg);
+  }
+  mp_model_cast(m->d, &m->f);
+  *out = m;
+  return MP_OK;
+}
+int mp_model_destroy(mp_model* model) {
+  delete model;
+  return MP_OK;
+}
+int mp_model_dof(const mp_model* model, int* n) {
+  REQUIRE(model && n, "mp_model_dof: null argument");
+  *n = model->d.n;
+  return MP_OK;
+}
+int mp_model_params(const mp_model* model, double* out) {
+  REQUIRE(model && out, "mp_model_params: null argument");
+  static_assert(sizeof(MpJoint<double>) == 16 * sizeof(double), "MpJoint layout");
+  for (int i = 0; i < model->d.n; ++i) std::memcpy(out + 16 * i, &model->d.j[i], 16 * sizeof(double));
+  return MP_OK;
+}
+int mp_model_fk_host(const mp_model* model, const double* q, double* T) {
+  REQUIRE(model && q && T, "mp_model_fk_host: null argument");
+  mp_compiled_fk(model->d, q, T);
+  return MP_OK;
+}
+
+// ---------------------------------------------------------------------- hot path, device pointers
+#define CHECK_COMMON(fn)                                              \
+  REQUIRE(ctx && model, fn ": null context or model");                \
+  if (int rc_ = bind(ctx)) return rc_;
+
+int mp_batch_trajectory_f32(mp_ctx* ctx, const mp_model* model, const float* d_start, const float* d_end, int64_t B,
+                            int64_t N, double Tf, int method, float* d_pos, float* d_vel, float* d_acc) {
+  CHECK_COMMON("mp_batch_trajectory_f32");
+  REQUIRE(B >= 0 && N >= 0, "mp_batch_trajectory_f32: negative B (%lld) or N (%lld)", (long long)B, (long long)N);
+  if (B == 0 || N == 0) return MP_OK;
+  REQUIRE(d_start && d_end && d_pos && d_vel && d_acc, "mp_batch_trajectory_f32: null device pointer");
+  REQUIRE(aligned16(d_start) && aligned16(d_end) && aligned16(d_pos) && aligned16(d_vel) && aligned16(d_acc),
+          "mp_batch_trajectory_f32: device pointers must be 16-byte aligned");
+  HIP_TRY(mpk_batch_traj(ctx->compute, model->f, d_start, d_end, (long)B, (long)N, Tf, method, d_pos, d_vel, d_acc));
+  return MP_OK;
+}
+
+int mp_id_trajectory_f32(mp_ctx* ctx, const mp_model* model, const float* d_q, const float* d_qd, const float* d_qdd,
+                         int64_t rows, const double* g, const double* Ftip, float* d_tau) {
+  return id_impl<float>("mp_id_trajectory_f32", ctx, model, d_q, d_qd, d_qdd, rows, g, Ftip, d_tau);
+}
+int mp_id_trajectory_f64(mp_ctx* ctx, const mp_model* model, const double* d_q, const double* d_qd,
+                         const double* d_qdd, int64_t rows, const double* g, const double* Ftip, double* d_tau) {
+  return id_impl<double>("mp_id_trajectory_f64", ctx, model, d_q, d_qd, d_qdd, rows, g, Ftip, d_tau);
+}
+
+int mp_traj_id_fused_f32(mp_ctx* ctx, const mp_model* model, const float* d_start, const float* d_end, int64_t B,
+                         int64_t N, double Tf, int method, const double* g, const double* Ftip, float* d_tau) {
+  CHECK_COMMON("mp_traj_id_fused_f32");
+  REQUIRE(B >= 0 && N >= 0, "mp_traj_id_fused_f32: negative B (%lld) or N (%lld)", (long long)B, (long long)N);
+  if (B == 0 || N == 0) return MP_OK;
+  REQUIRE(d_start && d_end && d_tau, "mp_traj_id_fused_f32: null device pointer");
+  REQUIRE(aligned16(d_start) && aligned16(d_end) && aligned16(d_tau),
+          "mp_traj_id_fused_f32: device pointers must be 16-byte aligned");
+  MpCall<float> c;
+  make_call<float>(model, g, Ftip, &c);
+  HIP_TRY(mpk_traj_id(ctx->compute, model->f, c, any_nonzero(Ftip), d_start, d_end, (long)B, (long)N, Tf, method, d_tau));
+  return MP_OK;
+}
+
+int mp_fk_jac_id_f64(mp_ctx* ctx, const mp_model* model, const double* d_q, const double* d_qd, const double* d_qdd,
+                     int64_t rows, const double* g, const double* Ftip, double* d_T, double* d_J, double* d_tau) {
+  return fkjid_impl<double>("mp_fk_jac_id_f64", ctx, model, d_q, d_qd, d_qdd, rows, g, Ftip, d_T, d_J, d_tau);
+}
+int mp_fk_jac_id_f32(mp_ctx* ctx, const mp_model* model, const float* d_q, const float* d_qd, const float* d_qdd,
+                     int64_t rows, const double* g, const double* Ftip, float* d_T, float* d_J, float* d_tau) {
+  return fkjid_impl<float>("mp_fk_jac_id_f32", ctx, model, d_q, d_qd, d_qdd, rows, g, Ftip, d_T, d_J, d_tau);
+}
+
+// ------------------------------------------------------------------------ hot path, host pointers
+int mp_batch_trajectory_host_f32(mp_ctx* ctx, const mp_model* model, const float* start, const float* end, int64_t B,
+                                 int64_t N, double Tf, int method, float* pos, float* vel, float* acc) {
+  CHECK_COMMON("mp_batch_trajectory_host_f32");
+  REQUIRE(B >= 0 && N >= 0, "mp_batch_trajectory_host_f32: negative B or N");
+  if (B == 0 || N == 0) return MP_OK;
+  REQUIRE(start && end && pos && vel && acc, "mp_batch_trajectory_host_f32: null host pointer");
+  const size_t n = (size_t)model->d.n, in_b = (size_t)B * n * sizeof(float), out_b = (size_t)B * (size_t)N * n * sizeof(float);
+  Scratch sc(ctx);
+  void *ds, *de, *dp, *dv, *da;
+  if (int rc = sc.get(in_b, &ds)) return rc;
+  if (int rc = sc.get(in_b, &de)) return rc;
+  if (int rc = sc.get(out_b, &dp)) return rc;
+  if (int rc = sc.get(out_b, &dv)) return rc;
+  if (int rc = sc.get(out_b, &da)) return rc;
+  H2D(ds, start, in_b);
+  H2D(de, end, in_b);
+  if (int rc = mp_batch_trajectory_f32(ctx, model, (float*)ds, (float*)de, B, N, Tf, method, (float*)dp, (float*)dv, (float*)da)) return rc;
+  D2H(pos, dp, out_b);
+  D2H(vel, dv, out_b);
+  D2H(acc, da, out_b);
+  HIP_TRY(hipStreamSynchronize(ctx->compute));
+  return MP_OK;
+}
+
+int mp_id_trajectory_host_f32(mp_ctx* ctx, const mp_model* model, const float* q, const float* qd, const float* qdd,
+                              int64_t rows, const double* g, const double* Ftip, float* tau) {
+  return id_host_impl<float>("mp_id_trajectory_host_f32", ctx, model, q, qd, qdd, rows, g, Ftip, tau);
+}
+int mp_id_trajectory_host_f64(mp_ctx* ctx, const mp_model* model, const double* q, const double* qd,
+                              const double* qdd, int64_t rows, const double* g, const double* Ftip, double* tau) {
+  return id_host_impl<double>("mp_id_trajectory_host_f64", ctx, model, q, qd, qdd, rows, g, Ftip, tau);
+}
+
+int mp_traj_id_fused_host_f32(mp_ctx* ctx, const mp_model* model, const float* start, const float* end, int64_t B,
+                              int64_t N, double Tf, int method, const double* g, const double* Ftip, float* tau) {
+  CHECK_COMMON("mp_traj_id_fused_host_f32");
+  REQUIRE(B >= 0 && N >= 0, "mp_traj_id_fused_host_f32: negative B or N");
+  if (B == 0 || N == 0) return MP_OK;
+  REQUIRE(start && end && tau, "mp_traj_id_fused_host_f32: null host pointer");
+  const size_t n = (size_t)model->d.n, in_b = (size_t)B * n * sizeof(float), out_b = (size_t)B * (size_t)N * n * sizeof(float);
+  Scratch sc(ctx);
+  void *ds, *de, *dt;
+  if (int rc = sc.get(in_b, &ds)) return rc;
+  if (int rc = sc.get(in_b, &de)) return rc;
+  if (int rc = sc.get(out_b, &dt)) return rc;
+  H2D(ds, start, in_b);
+  H2D(de, end, in_b);
+  if (int rc = mp_traj_id_fused_f32(ctx, model, (float*)ds, (float*)de, B, N, Tf, method, g, Ftip, (float*)dt)) return rc;
+  D2H(tau, dt, out_b);
+  HIP_TRY(hipStreamSynchronize(ctx->compute));
+  return MP_OK;
+}
+
+int mp_fk_jac_id_host_f64(mp_ctx* ctx, const mp_model* model, const double* q, const double* qd, const double* qdd,
+                          int64_t rows, const double* g, const double* Ftip, double* T, double* J, double* tau) {
+  CHECK_COMMON("mp_fk_jac_id_host_f64");
+  REQUIRE(rows >= 0, "mp_fk_jac_id_host_f64: negative row count");
+  if (rows == 0) return MP_OK;
+  REQUIRE(q && (T || J || tau), "mp_fk_jac_id_host_f64: q and at least one output are required");
+  REQUIRE(!tau || (qd && qdd), "mp_fk_jac_id_host_f64: tau requested without qd / qdd");
+  const size_t n = (size_t)model->d.n, rb = (size_t)rows * n * sizeof(double);
+  Scratch sc(ctx);
+  void *dq = nullptr, *dqd = nullptr, *dqdd = nullptr, *dT = nullptr, *dJ = nullptr, *dt = nullptr;
+  if (int rc = sc.get(rb, &dq)) return rc;
+  H2D(dq, q, rb);
+  if (tau) {
+    if (int rc = sc.get(rb, &dqd)) return rc;
+    if (int rc = sc.get(rb, &dqdd)) return rc;
+    if (int rc = sc.get(rb, &dt)) return rc;
+    H2D(dqd, qd, rb);
+    H2D(dqdd, qdd, rb);
+  }
+  if (T) if (int rc = sc.get((size_t)rows * 16 * sizeof(double), &dT)) return rc;
+  if (J) if (int rc = sc.get(rb * 6, &dJ)) return rc;
+  if (int rc = mp_fk_jac_id_f64(ctx, model, (double*)dq, (double*)dqd, (double*)dqdd, rows, g, Ftip, (double*)dT,
+                                (double*)dJ, (double*)dt))
+    return rc;
+  if (T) D2H(T, dT, (size_t)rows * 16 * sizeof(double));
+  if (J) D2H(J, dJ, rb * 6);
+  if (tau) D2H(tau, dt, rb);
+  HIP_TRY(hipStreamSynchronize(ctx->compute));
+  return MP_OK;
+}
+
+}  // extern "C"
+
+// exposed to mp_comm.cpp
+hipStream_t mp_ctx_compute_stream(mp_ctx* ctx) { return ctx->compute; }
+int mp_ctx_device(mp_ctx* ctx) { return ctx->device; }
+int mp_set_error(int code, const char* msg) { return set_err(code, "%s", msg); }

@@ -1,0 +1,21 @@
+// Launcher prototypes (defined in mp_kernels.hip); every launch is asynchronous on `s`.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include "mp_model.h"
+
+hipError_t mpk_selftest(hipStream_t s, int* d_out /* 64 ints */);
+
+template <typename T>
+hipError_t mpk_id(hipStream_t s, const MpModel<T>& M, const MpCall<T>& C, bool ftip, const T* q, const T* qd,
+                  const T* qdd, T* tau, long rows);
+
+hipError_t mpk_batch_traj(hipStream_t s, const MpModel<float>& M, const float* start, const float* end, long B,
+                          long Nt, double Tf, int method, float* pos, float* vel, float* acc);
+
+hipError_t mpk_traj_id(hipStream_t s, const MpModel<float>& M, const MpCall<float>& C, bool ftip, const float* start,
+                       const float* end, long B, long Nt, double Tf, int method, float* tau);
+
+template <typename T>
+hipError_t mpk_fk_jac_id(hipStream_t s, const MpModel<T>& M, const MpCall<T>& C, bool ftip, const T* q, const T* qd,
+                         const T* qdd, T* Tout, T* Jout, T* tau, long rows);

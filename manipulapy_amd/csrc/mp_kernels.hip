@@ -1,0 +1,234 @@
+// HIP kernels for gfx950 (MI355X): one thread per (trajectory, timestep) row.
+//
+// Layout in HBM: exactly the reference's API arrays — q / qd / qdd / tau are (rows, n) row-major
+// ("array of rows"), T is (rows, 4, 4), J is (rows, 6, n), start/end are (B, n).  A wavefront's 64
+// rows are one contiguous 64*n*sizeof(T) span per array, read/written with the widest vector access
+// the row size allows (16 / 8 / 4 bytes per lane).  The robot model and the per-call constants are
+// kernel ARGUMENTS (kernarg segment -> scalar loads -> SGPR operands): zero per-thread traffic.
+// No MFMA: there is no dense contraction on this path (BASELINE.json north_star).
+#include <hip/hip_runtime.h>
+
+#include "mp_core.h"
+#include "mp_kernels.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+// ---- widest legal vector type for a run of COUNT elements of T whose start is COUNT*sizeof(T)-strided
+template <typename T, int BYTES> struct VecOf;
+template <> struct VecOf<float, 16> { using type = float4; static constexpr int K = 4; };
+template <> struct VecOf<float, 8> { using type = float2; static constexpr int K = 2; };
+template <> struct VecOf<float, 4> { using type = float; static constexpr int K = 1; };
+template <> struct VecOf<double, 16> { using type = double2; static constexpr int K = 2; };
+template <> struct VecOf<double, 8> { using type = double; static constexpr int K = 1; };
+
+template <typename T, int COUNT>
+struct RunIO {
+  static constexpr int BYTES = COUNT * (int)sizeof(T);
+  static constexpr int W = (BYTES % 16 == 0) ? 16 : (BYTES % 8 == 0) ? 8 : 4;
+  using VO = VecOf<T, W>;
+  using V = typename VO::type;
+  static constexpr int K = VO::K;
+  static_assert(COUNT % K == 0, "run must be a whole number of vectors");
+
+  static __device__ __forceinline__ void load(const T* __restrict__ base, long run, T (&v)[COUNT]) {
+    const V* src = reinterpret_cast<const V*>(base + run * COUNT);
+#pragma unroll
+    for (int k = 0; k < COUNT / K; ++k) {
+      union { V vec; T e[K]; } u;
+      u.vec = src[k];
+#pragma unroll
+      for (int j = 0; j < K; ++j) v[k * K + j] = u.e[j];
+    }
+  }
+  static __device__ __forceinline__ void store(T* __restrict__ base, long run, const T (&v)[COUNT]) {
+    V* dst = reinterpret_cast<V*>(base + run * COUNT);
+#pragma unroll
+    for (int k = 0; k < COUNT / K; ++k) {
+      union { V vec; T e[K]; } u;
+#pragma unroll
+      for (int j = 0; j < K; ++j) u.e[j] = v[k * K + j];
+      dst[k] = u.vec;
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------- probe
+__global__ void k_selftest(int* out) { out[threadIdx.x] = (int)threadIdx.x; }
+
+// ------------------------------------------------------------------------- inverse dynamics
+template <typename T, int N, bool HAS_FTIP>
+__global__ __launch_bounds__(kBlock) void k_id(const MpModel<T> M, const MpCall<T> C, const T* __restrict__ q,
+                                               const T* __restrict__ qd, const T* __restrict__ qdd,
+                                               T* __restrict__ tau, long rows) {
+  const long r = (long)blockIdx.x * kBlock + threadIdx.x;
+  if (r >= rows) return;
+  T a[N], b[N], c[N], t[N];
+  RunIO<T, N>::load(q, r, a);
+  RunIO<T, N>::load(qd, r, b);
+  RunIO<T, N>::load(qdd, r, c);
+  MpJointState<T, N> js;
+  mp_joint_state<T, N>(M, a, js);
+  mp_rnea<T, N, HAS_FTIP>(M, C, js, b, c, t);
+#pragma unroll
+  for (int j = 0; j < N; ++j) t[j] = mp_clip(t[j], M.taumin[j], M.taumax[j]);
+  RunIO<T, N>::store(tau, r, t);
+}
+
+// -------------------------------------------------------------- trajectory generation pieces
+// Row (b, t) of the time-scaled point-to-point trajectory, reference planning/trajectory.py:45-73,
+// with the positions clipped to the joint limits (:311-313).
+template <int N>
+__device__ __forceinline__ void traj_row(const MpModel<float>& M, const float* __restrict__ start,
+                                         const float* __restrict__ end, long b, long t, long Nt, double Tf,
+                                         int method, float (&pos)[N], float (&vel)[N], float (&acc)[N]) {
+  float a[N], e[N];
+  RunIO<float, N>::load(start, b, a);
+  RunIO<float, N>::load(end, b, e);
+  const double tt = (double)t * (Tf / (double)(Nt - 1));
+  const double tau = tt / Tf;
+  double s, sd, sdd;
+  mp_time_scaling(method, tau, Tf, s, sd, sdd);
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const double d = (double)(e[j] - a[j]);  // float32 difference first, as the reference types it
+    pos[j] = mp_clip((float)(s * d + (double)a[j]), M.qmin[j], M.qmax[j]);
+    vel[j] = (float)(sd * d);
+    acc[j] = (float)(sdd * d);
+  }
+}
+
+template <int N>
+__global__ __launch_bounds__(kBlock) void k_batch_traj(const MpModel<float> M, const float* __restrict__ start,
+                                                       const float* __restrict__ end, long B, long Nt, double Tf,
+                                                       int method, float* __restrict__ pos, float* __restrict__ vel,
+                                                       float* __restrict__ acc) {
+  const long r = (long)blockIdx.x * kBlock + threadIdx.x;
+  if (r >= B * Nt) return;
+  const long b = r / Nt, t = r - b * Nt;
+  float p[N], v[N], a[N];
+  traj_row<N>(M, start, end, b, t, Nt, Tf, method, p, v, a);
+  RunIO<float, N>::store(pos, r, p);
+  RunIO<float, N>::store(vel, r, v);
+  RunIO<float, N>::store(acc, r, a);
+}
+
+template <int N, bool HAS_FTIP>
+__global__ __launch_bounds__(kBlock) void k_traj_id(const MpModel<float> M, const MpCall<float> C,
+                                                    const float* __restrict__ start, const float* __restrict__ end,
+                                                    long B, long Nt, double Tf, int method, float* __restrict__ tau) {
+  const long r = (long)blockIdx.x * kBlock + threadIdx.x;
+  if (r >= B * Nt) return;
+  const long b = r / Nt, t = r - b * Nt;
+  float p[N], v[N], a[N], tq[N];
+  traj_row<N>(M, start, end, b, t, Nt, Tf, method, p, v, a);
+  MpJointState<float, N> js;
+  mp_joint_state<float, N>(M, p, js);
+  mp_rnea<float, N, HAS_FTIP>(M, C, js, v, a, tq);
+#pragma unroll
+  for (int j = 0; j < N; ++j) tq[j] = mp_clip(tq[j], M.taumin[j], M.taumax[j]);
+  RunIO<float, N>::store(tau, r, tq);
+}
+
+// ------------------------------------------------------------- FK + space Jacobian + ID fused
+template <typename T, int N, bool HAS_FTIP>
+__global__ __launch_bounds__(kBlock) void k_fk_jac_id(const MpModel<T> M, const MpCall<T> C, const T* __restrict__ q,
+                                                      const T* __restrict__ qd, const T* __restrict__ qdd,
+                                                      T* __restrict__ Tout, T* __restrict__ Jout,
+                                                      T* __restrict__ tau, long rows) {
+  const long r = (long)blockIdx.x * kBlock + threadIdx.x;
+  if (r >= rows) return;
+  T a[N];
+  RunIO<T, N>::load(q, r, a);
+  MpJointState<T, N> js;
+  mp_joint_state<T, N>(M, a, js);
+  if (Tout != nullptr || Jout != nullptr) {
+    T TT[16], JJ[6 * N];
+    mp_fk_jac<T, N, true>(M, js, TT, JJ);
+    if (Tout != nullptr) RunIO<T, 16>::store(Tout, r, TT);
+    if (Jout != nullptr) RunIO<T, 6 * N>::store(Jout, r, JJ);
+  }
+  if (tau != nullptr) {
+    T b[N], c[N], t[N];
+    RunIO<T, N>::load(qd, r, b);
+    RunIO<T, N>::load(qdd, r, c);
+    mp_rnea<T, N, HAS_FTIP>(M, C, js, b, c, t);
+#pragma unroll
+    for (int j = 0; j < N; ++j) t[j] = mp_clip(t[j], M.taumin[j], M.taumax[j]);
+    RunIO<T, N>::store(tau, r, t);
+  }
+}
+
+inline unsigned grid_for(long rows) { return (unsigned)((rows + kBlock - 1) / kBlock); }
+
+#define MP_DISPATCH_N(n, ...)                                   \
+  switch (n) {                                                  \
+    case 1: { constexpr int N = 1; __VA_ARGS__; } break;        \
+    case 2: { constexpr int N = 2; __VA_ARGS__; } break;        \
+    case 3: { constexpr int N = 3; __VA_ARGS__; } break;        \
+    case 4: { constexpr int N = 4; __VA_ARGS__; } break;        \
+    case 5: { constexpr int N = 5; __VA_ARGS__; } break;        \
+    case 6: { constexpr int N = 6; __VA_ARGS__; } break;        \
+    case 7: { constexpr int N = 7; __VA_ARGS__; } break;        \
+    case 8: { constexpr int N = 8; __VA_ARGS__; } break;        \
+    default: return hipErrorInvalidValue;                       \
+  }
+
+}  // namespace
+
+hipError_t mpk_selftest(hipStream_t s, int* d_out) {
+  hipLaunchKernelGGL(k_selftest, dim3(1), dim3(64), 0, s, d_out);
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t mpk_id(hipStream_t s, const MpModel<T>& M, const MpCall<T>& C, bool ftip, const T* q, const T* qd,
+                  const T* qdd, T* tau, long rows) {
+  if (rows <= 0) return hipSuccess;
+  MP_DISPATCH_N(M.n, {
+    if (ftip) hipLaunchKernelGGL((k_id<T, N, true>), dim3(grid_for(rows)), dim3(kBlock), 0, s, M, C, q, qd, qdd, tau, rows);
+    else hipLaunchKernelGGL((k_id<T, N, false>), dim3(grid_for(rows)), dim3(kBlock), 0, s, M, C, q, qd, qdd, tau, rows);
+  })
+  return hipGetLastError();
+}
+template hipError_t mpk_id<float>(hipStream_t, const MpModel<float>&, const MpCall<float>&, bool, const float*,
+                                  const float*, const float*, float*, long);
+template hipError_t mpk_id<double>(hipStream_t, const MpModel<double>&, const MpCall<double>&, bool, const double*,
+                                   const double*, const double*, double*, long);
+
+hipError_t mpk_batch_traj(hipStream_t s, const MpModel<float>& M, const float* start, const float* end, long B,
+                          long Nt, double Tf, int method, float* pos, float* vel, float* acc) {
+  const long rows = B * Nt;
+  if (rows <= 0) return hipSuccess;
+  MP_DISPATCH_N(M.n, {
+    hipLaunchKernelGGL((k_batch_traj<N>), dim3(grid_for(rows)), dim3(kBlock), 0, s, M, start, end, B, Nt, Tf, method, pos, vel, acc);
+  })
+  return hipGetLastError();
+}
+
+hipError_t mpk_traj_id(hipStream_t s, const MpModel<float>& M, const MpCall<float>& C, bool ftip, const float* start,
+                       const float* end, long B, long Nt, double Tf, int method, float* tau) {
+  const long rows = B * Nt;
+  if (rows <= 0) return hipSuccess;
+  MP_DISPATCH_N(M.n, {
+    if (ftip) hipLaunchKernelGGL((k_traj_id<N, true>), dim3(grid_for(rows)), dim3(kBlock), 0, s, M, C, start, end, B, Nt, Tf, method, tau);
+    else hipLaunchKernelGGL((k_traj_id<N, false>), dim3(grid_for(rows)), dim3(kBlock), 0, s, M, C, start, end, B, Nt, Tf, method, tau);
+  })
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t mpk_fk_jac_id(hipStream_t s, const MpModel<T>& M, const MpCall<T>& C, bool ftip, const T* q, const T* qd,
+                         const T* qdd, T* Tout, T* Jout, T* tau, long rows) {
+  if (rows <= 0) return hipSuccess;
+  MP_DISPATCH_N(M.n, {
+    if (ftip) hipLaunchKernelGGL((k_fk_jac_id<T, N, true>), dim3(grid_for(rows)), dim3(kBlock), 0, s, M, C, q, qd, qdd, Tout, Jout, tau, rows);
+    else hipLaunchKernelGGL((k_fk_jac_id<T, N, false>), dim3(grid_for(rows)), dim3(kBlock), 0, s, M, C, q, qd, qdd, Tout, Jout, tau, rows);
+  })
+  return hipGetLastError();
+}
+template hipError_t mpk_fk_jac_id<float>(hipStream_t, const MpModel<float>&, const MpCall<float>&, bool, const float*,
+                                         const float*, const float*, float*, float*, float*, long);
+template hipError_t mpk_fk_jac_id<double>(hipStream_t, const MpModel<double>&, const MpCall<double>&, bool,
+                                          const double*, const double*, const double*, double*, double*, double*, long);

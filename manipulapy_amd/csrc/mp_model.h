@@ -1,0 +1,51 @@
+// Compiled robot model: the wave-uniform constant block every kernel receives BY VALUE in its
+// kernarg segment (scalar loads -> SGPRs; no VGPR, LDS or HBM traffic per thread).
+//
+// The reference describes a robot by space screws S_i, per-link CoM home poses Mcom_i and CoM-frame
+// spatial inertias G_i (reference ManipulaPy/urdf/core.py:670-769).  Evaluating its dynamics in those
+// frames costs a general 3x3 rotation per transform.  The host-side model compiler
+// (mp_model_compile.cpp) re-expresses the same robot in modified-DH link frames chosen so that
+//      T_{i-1,i}(q_i) = Rx(alpha_i) Tx(a_i) Rz(off_i + q_i) Tz(d_i)          (revolute)
+//                     = Rx(alpha_i) Tx(a_i) Rz(off_i)       Tz(d_i + q_i)    (prismatic)
+// i.e. every motion/force transform is two axis-aligned rotations (4 mul + 2 add each) and two
+// axis-aligned shifts (2 FMA each), and the joint motion subspace is a unit vector.  Link inertias
+// are moved to the link-frame origin (mass, first moment h = m c, inertia about the origin).
+// Dynamics are frame-invariant, so the joint torques are the reference's up to rounding.
+#pragma once
+
+#ifndef MP_MAX_DOF
+#define MP_MAX_DOF 8
+#endif
+
+template <typename T>
+struct MpJoint {
+  T ca, sa;    // cos / sin of alpha_i  (rotation about parent x)
+  T a;         // shift along parent x
+  T d;         // shift along own z at q = 0
+  T off;       // joint-angle offset (rotation about own z at q = 0)
+  T rev;       // 1 = revolute, 0 = prismatic
+  T m;         // link mass
+  T hx, hy, hz;                       // first moment m * c (c = CoM in link frame)
+  T Ixx, Ixy, Ixz, Iyy, Iyz, Izz;     // rotational inertia about the link-frame ORIGIN
+};
+
+template <typename T>
+struct MpModel {
+  int n;
+  int pad_[3];
+  T base_R[9];   // pose of link frame 1 (at q1 = 0, before its own Rz/Tz) in the space frame
+  T base_p[3];
+  T tool_R[9];   // end-effector home pose M_ee in link frame n
+  T tool_p[3];
+  MpJoint<T> j[MP_MAX_DOF];
+  T qmin[MP_MAX_DOF], qmax[MP_MAX_DOF];       // joint limits (float32-rounded, as the planner holds them)
+  T taumin[MP_MAX_DOF], taumax[MP_MAX_DOF];   // torque limits (+-inf by default)
+};
+
+// Per-call constants derived on the host in fp64 (gravity / tip wrench seen from link frame 1's parent).
+template <typename T>
+struct MpCall {
+  T a0[3];      // base_R^T * (-g): linear acceleration of the (fictitiously accelerated) base
+  T F1n[3];     // Ftip moment, expressed in the pre-joint-1 frame
+  T F1f[3];     // Ftip force,  expressed in the pre-joint-1 frame
+};

@@ -1,0 +1,104 @@
+"""ManipulatorDynamics — host-side mirror of ManipulaPy/dynamics/manipulator_dynamics.py.
+
+Same constructor signature (dynamics/manipulator_dynamics.py:43-86) and the same public methods:
+mass_matrix (mass_matrix.py:16-99), velocity_quadratic_forces / gravity_forces (forces.py:26-133),
+inverse_dynamics / forward_dynamics (id_fd.py:16-83), partial_derivative (forces.py:16-24).
+Every method evaluates the HIP inverse-dynamics kernel through the kernel registry
+("dynamics.inverse_trajectory", float64):
+
+    inverse_dynamics(q, qd, qdd, g, F)      = ID(q, qd, qdd, g, F)
+    gravity_forces(q, g)                    = ID(q, 0, 0, g, 0)
+    velocity_quadratic_forces(q, qd)        = ID(q, qd, 0, 0, 0)
+    mass_matrix(q)[:, j]                    = ID(q, 0, e_j, 0, 0)        (one n-row launch)
+    forward_dynamics(q, qd, tau, g, F)      = solve(M, tau - ID(q, qd, 0, g, F))
+
+which are exact identities of tau = M qdd + c + g + Js^T F.  There is no value-keyed cache (the
+reference's caches exist to amortise its 1 + 2n mass-matrix evaluations per point, which the
+analytic recursion does not need) and no legacy (Mlist_per_link=None) approximation.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+
+from . import _hip
+from .kinematics import SerialManipulator
+from .registry import execute_registered_kernel
+
+__all__ = ["ManipulatorDynamics"]
+
+_ZERO3 = np.zeros(3)
+
+
+class ManipulatorDynamics(SerialManipulator):
+    def __init__(self, M_list, omega_list, r_list, b_list, S_list, B_list, Glist, Mlist_per_link=None) -> None:
+        super().__init__(M_list, omega_list, r_list, b_list, S_list, B_list)
+        self.Glist = Glist
+        self.Mlist_per_link = Mlist_per_link
+        self._dyn_model: Optional[_hip.HipModel] = None
+
+    # ---- compiled model
+    def hip_model(self, joint_limits=None, torque_limits=None) -> _hip.HipModel:
+        """Compile (once) the model the kernels consume.  Limits, if given, build a separate model
+        (the planner passes its own float32 limits)."""
+        if self.Mlist_per_link is None:
+            raise NotImplementedError(
+                "ManipulatorDynamics without Mlist_per_link: the reference's legacy approximation "
+                "(dynamics/mass_matrix.py:101-132) is documented as incorrect and is not reproduced; construct "
+                "the dynamics with per-link CoM transforms (URDFToSerialManipulator does).")
+        if joint_limits is None and torque_limits is None:
+            if self._dyn_model is None:
+                self._dyn_model = _hip.HipModel(self.S_list, np.asarray(self.Mlist_per_link), np.asarray(self.Glist), self._M_ee)
+            return self._dyn_model
+        return _hip.HipModel(self.S_list, np.asarray(self.Mlist_per_link), np.asarray(self.Glist), self._M_ee,
+                             joint_limits, torque_limits)
+
+    def _id(self, q, qd, qdd, g, Ftip) -> np.ndarray:
+        return execute_registered_kernel("dynamics.inverse_trajectory", self.hip_model(), q, qd, qdd, g, Ftip,
+                                         dtype=np.float64)
+
+    # ---- public API
+    def mass_matrix(self, thetalist) -> np.ndarray:
+        q = np.asarray(thetalist, dtype=np.float64)
+        n = q.shape[0]
+        Q = np.tile(q, (n, 1))
+        M = self._id(Q, np.zeros((n, n)), np.eye(n), _ZERO3, None).T  # row j = M e_j -> transpose to columns
+        return 0.5 * (M + M.T)  # the reference symmetrises (mass_matrix.py:96)
+
+    def velocity_quadratic_forces(self, thetalist, dthetalist) -> np.ndarray:
+        q = np.asarray(thetalist, dtype=np.float64)[None, :]
+        qd = np.asarray(dthetalist, dtype=np.float64)[None, :]
+        return self._id(q, qd, np.zeros_like(q), _ZERO3, None)[0]
+
+    def gravity_forces(self, thetalist, g=None) -> np.ndarray:
+        q = np.asarray(thetalist, dtype=np.float64)[None, :]
+        g = [0.0, 0.0, -9.81] if g is None else g
+        z = np.zeros_like(q)
+        return self._id(q, z, z, g, None)[0]
+
+    def inverse_dynamics(self, thetalist, dthetalist, ddthetalist, g, Ftip) -> np.ndarray:
+        q = np.asarray(thetalist, dtype=np.float64)[None, :]
+        qd = np.asarray(dthetalist, dtype=np.float64)[None, :]
+        qdd = np.asarray(ddthetalist, dtype=np.float64)[None, :]
+        return self._id(q, qd, qdd, g, Ftip)[0]
+
+    def forward_dynamics(self, thetalist, dthetalist, taulist, g, Ftip) -> np.ndarray:
+        q = np.asarray(thetalist, dtype=np.float64)
+        n = q.shape[0]
+        # one launch: rows 0..n-1 give M's columns, row n gives the bias c + g + Js^T F
+        Q = np.tile(q, (n + 1, 1))
+        Qd = np.zeros((n + 1, n))
+        Qd[n] = np.asarray(dthetalist, dtype=np.float64)
+        Qdd = np.vstack([np.eye(n), np.zeros((1, n))])
+        bias = self._id(Q[n:], Qd[n:], Qdd[n:], g, Ftip)[0]
+        M = self._id(Q[:n], Qd[:n], Qdd[:n], _ZERO3, None).T
+        M = 0.5 * (M + M.T)
+        return np.linalg.solve(M, np.asarray(taulist, dtype=np.float64) - bias)
+
+    def partial_derivative(self, i: int, j: int, k: int, thetalist, epsilon: float = 1e-6) -> float:
+        """dM[i, j] / dtheta_k by the reference's central difference (dynamics/cache.py:39-52)."""
+        q = np.asarray(thetalist, dtype=np.float64)
+        e = np.zeros_like(q)
+        e[k] = epsilon
+        return float((self.mass_matrix(q + e)[i, j] - self.mass_matrix(q - e)[i, j]) / (2.0 * epsilon))

@@ -1,0 +1,113 @@
+"""SerialManipulator — host-side mirror of ManipulaPy/kinematics/serial_manipulator.py for the hot path.
+
+Constructor signature and the FK / Jacobian methods follow the reference
+(kinematics/serial_manipulator.py:46-121, fk.py:39-86, jacobian.py:39-93); the arithmetic runs in
+the HIP kernel `k_fk_jac_id` through the kernel registry ("kinematics.fk_jacobian").  IK solvers,
+plotting and the other concerns of the reference class are out of scope.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+from . import _hip
+from .registry import execute_registered_kernel
+
+__all__ = ["SerialManipulator"]
+
+
+def _skew(v):
+    return np.array([[0.0, -v[2], v[1]], [v[2], 0.0, -v[0]], [-v[1], v[0], 0.0]])
+
+
+def _adjoint(T):
+    """[[R, 0], [[p]R, R]] for twists ordered [w; v] (reference utils/se3.py:45-52)."""
+    R, p = T[:3, :3], T[:3, 3]
+    A = np.zeros((6, 6))
+    A[:3, :3] = R
+    A[3:, 3:] = R
+    A[3:, :3] = _skew(p) @ R
+    return A
+
+
+def _screws_from_axes(omega_list, r_list) -> np.ndarray:
+    """S_i = [w_i ; -w_i x r_i] (reference utils/screw.py extract_screw_list)."""
+    w = np.asarray(omega_list, dtype=np.float64)
+    r = np.asarray(r_list, dtype=np.float64)
+    if w.shape[0] != 3:
+        w = w.T
+    if r.shape[0] != 3:
+        r = r.T
+    return np.vstack([w, np.cross(-w.T, r.T).T])
+
+
+class SerialManipulator:
+    """Kinematic model of a serial chain described by space screws and a home pose."""
+
+    def __init__(self, M_list, omega_list, r_list=None, b_list=None, S_list=None, B_list=None, G_list=None,
+                 joint_limits: Optional[List[Tuple[Optional[float], Optional[float]]]] = None) -> None:
+        self.M_list = np.asarray(M_list, dtype=np.float64)
+        self.G_list = G_list
+        self.omega_list = omega_list
+        if S_list is None:
+            if r_list is None:
+                raise ValueError("either S_list or (omega_list, r_list) is required")
+            S_list = _screws_from_axes(omega_list, r_list)
+        self.S_list = np.asarray(S_list, dtype=np.float64)
+        self.r_list = r_list
+        self.b_list = b_list
+        M = self.M_list[-1] if self.M_list.ndim > 2 else self.M_list  # stacked poses: the last one (fk.py:69)
+        self._M_ee = np.ascontiguousarray(M, dtype=np.float64)
+        self.B_list = (np.asarray(B_list, dtype=np.float64) if B_list is not None
+                       else _adjoint(np.linalg.inv(self._M_ee)) @ self.S_list)  # urdf/core.py:755-758
+        n = self.S_list.shape[1]
+        # body-frame results are derived from the space-frame kernel, valid iff B = Ad(M^-1) S
+        self._B_consistent = bool(np.allclose(self.B_list, _adjoint(np.linalg.inv(self._M_ee)) @ self.S_list, atol=1e-8))
+        self.joint_limits = joint_limits if joint_limits is not None else [(None, None)] * n
+        self._hip_model: Optional[_hip.HipModel] = None
+
+    # ---- compiled model (kinematics only needs screws + home pose; unit inertias are placeholders)
+    def _kin_model(self) -> _hip.HipModel:
+        if self._hip_model is None:
+            n = self.S_list.shape[1]
+            Mcom = np.tile(self._M_ee, (n, 1, 1))
+            G = np.tile(np.eye(6), (n, 1, 1))
+            self._hip_model = _hip.HipModel(self.S_list, Mcom, G, self._M_ee)
+        return self._hip_model
+
+    def _space_fk_jac(self, thetalist, want_T=True, want_J=True):
+        q = np.atleast_2d(np.asarray(thetalist, dtype=np.float64))
+        n = self.S_list.shape[1]
+        if q.shape[1] != n:
+            raise ValueError(f"expected {n} joint values, got {q.shape[1]} (truncated chains are internal to the "
+                             "reference's mass matrix and not part of this API)")
+        T, J, _ = execute_registered_kernel("kinematics.fk_jacobian", self._kin_model(), q, want_T=want_T, want_J=want_J)
+        return T, J
+
+    def _require_consistent_B(self, frame: str) -> None:
+        if frame == "body" and not self._B_consistent:
+            raise NotImplementedError("body-frame kinematics needs B_list == Ad(M^-1) S_list in this build")
+
+    def forward_kinematics(self, thetalist, frame: str = "space") -> np.ndarray:
+        """End-effector pose (4, 4).  A 2-D `thetalist` (rows, n) returns (rows, 4, 4)."""
+        if frame not in ("space", "body"):
+            raise ValueError("Invalid frame specified. Choose 'space' or 'body'.")
+        # M . prod exp([B_i] q_i) == prod exp([S_i] q_i) . M whenever B = Ad(M^-1) S
+        self._require_consistent_B(frame)
+        T, _ = self._space_fk_jac(thetalist, want_T=True, want_J=False)
+        return T if np.ndim(thetalist) == 2 else T[0]
+
+    def jacobian(self, thetalist, frame: str = "space") -> np.ndarray:
+        """(6, n) Jacobian, or (rows, 6, n) for a 2-D `thetalist`."""
+        if frame not in ("space", "body"):
+            raise ValueError("Invalid frame specified. Choose 'space' or 'body'.")
+        self._require_consistent_B(frame)
+        T, J = self._space_fk_jac(thetalist, want_T=(frame == "body"), want_J=True)
+        if frame == "body":  # J_b = Ad(T_sb^-1) J_s
+            J = np.stack([_adjoint(np.linalg.inv(T[i])) @ J[i] for i in range(J.shape[0])])
+        return J if np.ndim(thetalist) == 2 else J[0]
+
+    def end_effector_velocity(self, thetalist, dthetalist, frame: str = "space") -> np.ndarray:
+        """reference kinematics/velocity.py:35-60."""
+        return self.jacobian(thetalist, frame=frame) @ np.asarray(dthetalist, dtype=np.float64)

@@ -1,0 +1,212 @@
+"""OptimizedTrajectoryPlanning — host-side mirror of the reference planner facade for the hot path.
+
+Reference: ManipulaPy/planning/trajectory_planning.py:116-399 (constructor, routing),
+planning/trajectory.py:103-502 (joint / batch trajectories), planning/trajectory_dynamics.py:31-90,
+:308-380 (inverse_dynamics_trajectory), :710-735 (calculate_derivatives).
+
+What is kept: the constructor signature (positional + keyword-only arguments), float32 limits,
+`performance_stats`, the `_should_use_gpu` routing rule (forced CPU pin -> live routing predicate ->
+work threshold), result dtypes / shapes (float32 (N, n) / (B, N, n)), joint-limit and torque-limit
+clipping, default gravity / zero wrench.
+
+What is different, on purpose:
+  * a failing GPU launch raises instead of silently recomputing on the CPU
+    (reference planning/trajectory.py:270-274, trajectory_dynamics.py:292-302);
+  * the dynamics have no CPU twin here: with the NumPy backend (or use_cuda=False)
+    inverse_dynamics_trajectory raises BackendNotSupportedError — the reference remains the CPU
+    implementation; trajectory GENERATION does have its NumPy path (BASELINE config 0);
+  * collision avoidance is absent (host-only, mesh-dependent, a no-op without meshes — SURVEY §8c);
+  * `batch_inverse_dynamics_trajectory` is new: joint_trajectory -> inverse_dynamics_trajectory fused
+    on the device for B start/end pairs.
+"""
+from __future__ import annotations
+
+import logging
+import time
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+
+from . import registry as _reg
+from .backend import get_backend
+
+__all__ = ["OptimizedTrajectoryPlanning", "TrajectoryPlanning"]
+
+logger = logging.getLogger("ManipulaPy.planning.trajectory_planning")  # name kept
+
+
+class OptimizedTrajectoryPlanning:
+    def __init__(self, serial_manipulator, urdf_path, dynamics, joint_limits, torque_limits=None, *,
+                 use_cuda: Optional[bool] = None, cuda_threshold: int = 10, memory_pool_size_mb: Optional[int] = None,
+                 enable_profiling: bool = False, auto_optimize: bool = True, kernel_type: str = "auto",
+                 target_speedup: float = 40.0) -> None:
+        self.serial_manipulator = serial_manipulator
+        self.dynamics = dynamics
+        self.urdf_path = urdf_path
+        self.joint_limits = np.asarray(joint_limits, dtype=np.float32)
+        self.torque_limits = (np.asarray(torque_limits, dtype=np.float32) if torque_limits is not None
+                              else np.array([[-np.inf, np.inf]] * len(joint_limits), dtype=np.float32))
+        self.kernel_type = kernel_type if kernel_type is not None else "auto"
+        self.target_speedup = target_speedup if target_speedup is not None else 40.0
+        self.enable_profiling = bool(enable_profiling)
+        self.collision_checker = None  # out of scope
+        self.potential_field = None
+        self._last_cpu_time = 0.0
+        self.performance_stats = {"gpu_calls": 0, "cpu_calls": 0, "total_gpu_time": 0.0, "total_cpu_time": 0.0,
+                                  "memory_transfers": 0, "kernel_launches": 0, "speedup_achieved": 0.0,
+                                  "best_kernel_used": "none"}
+        del auto_optimize, memory_pool_size_mb  # CUDA-environment knobs with no HIP counterpart
+
+        physical = _reg.check_hip_availability()
+        detected = _reg._hip_routing_enabled(physical)
+        self._physical_cuda = physical
+        self._forced_cpu = use_cuda is False
+        if use_cuda is None:
+            self.cuda_available = detected
+        elif use_cuda and not detected:
+            raise RuntimeError("use_cuda=True requested but no GPU-capable backend with a HIP device is active. "
+                               "Select the 'hip' backend on a machine with an MI355X.")
+        else:
+            self.cuda_available = bool(use_cuda)
+        self.gpu_properties = _reg.get_gpu_properties() if self.cuda_available else None
+        if self.cuda_available and self.gpu_properties:
+            cus = self.gpu_properties["multiprocessor_count"]
+            per_cu = 1000 if self.target_speedup >= 40 else 500
+            self.cpu_threshold = max(int(cuda_threshold), int(cus * per_cu / len(joint_limits)))
+        else:
+            self.cpu_threshold = int(cuda_threshold)
+        self._model = None
+
+    # ------------------------------------------------------------------ plumbing
+    def _hip_model(self):
+        """Dynamics tables + THIS planner's float32 joint / torque limits, compiled once."""
+        if self._model is None:
+            self._model = self.dynamics.hip_model(self.joint_limits.astype(np.float64), self.torque_limits.astype(np.float64))
+        return self._model
+
+    def _should_use_gpu(self, N: int, num_joints: int) -> bool:
+        """reference planning/trajectory_planning.py:356-399."""
+        if getattr(self, "_forced_cpu", False):
+            return False
+        physical = getattr(self, "_physical_cuda", self.cuda_available)
+        if not _reg._hip_routing_enabled(physical):
+            return False
+        return N * num_joints >= self.cpu_threshold
+
+    def _gpu_routed(self) -> bool:
+        """Routing for operations that exist only on the device (no work threshold)."""
+        if getattr(self, "_forced_cpu", False):
+            return False
+        return _reg._hip_routing_enabled(getattr(self, "_physical_cuda", self.cuda_available))
+
+    def _count(self, kind: str, t0: float) -> None:
+        dt = time.time() - t0
+        self.performance_stats[f"{kind}_calls"] += 1
+        self.performance_stats[f"total_{kind}_time"] += dt
+        if kind == "gpu":
+            self.performance_stats["kernel_launches"] += 1
+            self.performance_stats["best_kernel_used"] = "hip"
+        else:
+            self._last_cpu_time = dt
+
+    def _clip_positions(self, pos: np.ndarray) -> np.ndarray:
+        return np.clip(pos, self.joint_limits[:, 0], self.joint_limits[:, 1])
+
+    # ------------------------------------------------------------------ trajectories
+    def joint_trajectory(self, thetastart, thetaend, Tf, N, method, kernel_type=None, enable_monitoring=None) -> Dict[str, np.ndarray]:
+        """positions / velocities / accelerations, each (N, n) float32 (reference planning/trajectory.py:103-169)."""
+        del enable_monitoring
+        backend = get_backend()
+        start = np.array(backend.to_numpy(backend.asarray(thetastart)), dtype=np.float32)
+        end = np.array(backend.to_numpy(backend.asarray(thetaend)), dtype=np.float32)
+        t0 = time.time()
+        if self._should_use_gpu(int(N), len(start)):
+            variant = kernel_type or self.kernel_type or "auto"
+            entry = _reg.get_registered_kernel(f"trajectory.{variant}")  # fail-closed on unknown names
+            pos, vel, acc = entry.gpu_launcher(self._hip_model(), start, end, Tf, int(N), int(method))
+            self._count("gpu", t0)
+        else:
+            pos, vel, acc = _reg.trajectory_cpu(start, end, float(Tf), int(N), int(method))
+            pos = self._clip_positions(pos)
+            self._count("cpu", t0)
+        return {"positions": backend.asarray(pos), "velocities": backend.asarray(vel), "accelerations": backend.asarray(acc)}
+
+    def batch_joint_trajectory(self, thetastart_batch, thetaend_batch, Tf, N, method, kernel_type=None) -> Dict[str, np.ndarray]:
+        """(B, N, n) float32 arrays (reference planning/trajectory.py:335-502)."""
+        del kernel_type
+        backend = get_backend()
+        sb = np.asarray(backend.to_numpy(backend.asarray(thetastart_batch)), dtype=np.float32)
+        eb = np.asarray(backend.to_numpy(backend.asarray(thetaend_batch)), dtype=np.float32)
+        if sb.ndim != 2 or sb.shape != eb.shape:
+            raise ValueError(f"start/end batches must both be (B, n); got {sb.shape} and {eb.shape}")
+        B, n = sb.shape
+        t0 = time.time()
+        if B == 0:
+            z = np.zeros((0, int(N), n), dtype=np.float32)
+            return {"positions": z, "velocities": z.copy(), "accelerations": z.copy()}
+        if self._gpu_routed():
+            pos, vel, acc = _reg.execute_registered_kernel("trajectory.batch", self._hip_model(), sb, eb, Tf, int(N), int(method))
+            self._count("gpu", t0)
+        else:
+            pos, vel, acc = _reg.trajectory_cpu(sb, eb, float(Tf), int(N), int(method))
+            pos = self._clip_positions(pos)
+            self._count("cpu", t0)
+        return {"positions": backend.asarray(pos), "velocities": backend.asarray(vel), "accelerations": backend.asarray(acc)}
+
+    # ------------------------------------------------------------------ dynamics over trajectories
+    def inverse_dynamics_trajectory(self, thetalist_trajectory, dthetalist_trajectory, ddthetalist_trajectory,
+                                    gravity_vector=None, Ftip=None) -> np.ndarray:
+        """(rows, n) float32 torques, clipped to the torque limits
+        (reference planning/trajectory_dynamics.py:31-90, :308-380).  Rows are independent, so a
+        flattened (B*N, n) history is a valid input.  float64 inputs are evaluated in float64 and
+        then stored float32 exactly as the reference does (:354); float32 inputs run the float32 kernel."""
+        if gravity_vector is None:
+            gravity_vector = np.array([0.0, 0.0, -9.81])
+        if Ftip is None:
+            Ftip = [0, 0, 0, 0, 0, 0]
+        q = np.asarray(thetalist_trajectory)
+        if q.ndim != 2:
+            raise ValueError(f"trajectories must be (N, n); got {q.shape}")
+        if q.shape[0] == 0:
+            return np.zeros(q.shape, dtype=np.float32)
+        t0 = time.time()
+        if not self._gpu_routed():
+            _reg.get_registered_kernel("dynamics.inverse_trajectory").cpu_launcher()  # raises BackendNotSupportedError
+        dtype = np.float64 if q.dtype == np.float64 else np.float32
+        tau = _reg.execute_registered_kernel("dynamics.inverse_trajectory", self._hip_model(), q, dthetalist_trajectory,
+                                             ddthetalist_trajectory, gravity_vector, Ftip, dtype=dtype)
+        self._count("gpu", t0)
+        return get_backend().asarray(tau.astype(np.float32, copy=False))
+
+    def batch_inverse_dynamics_trajectory(self, thetastart_batch, thetaend_batch, Tf, N, method, gravity_vector=None,
+                                          Ftip=None) -> np.ndarray:
+        """(B, N, n) float32 torques of the time-scaled trajectories between B start/end pairs, i.e.
+        inverse_dynamics_trajectory(**batch_joint_trajectory(...)) without materialising the histories."""
+        sb = np.asarray(thetastart_batch, dtype=np.float32)
+        eb = np.asarray(thetaend_batch, dtype=np.float32)
+        if sb.ndim != 2 or sb.shape != eb.shape:
+            raise ValueError(f"start/end batches must both be (B, n); got {sb.shape} and {eb.shape}")
+        if sb.shape[0] == 0:
+            return np.zeros((0, int(N), sb.shape[1]), dtype=np.float32)
+        t0 = time.time()
+        if not self._gpu_routed():
+            _reg.get_registered_kernel("dynamics.fused_trajectory_inverse").cpu_launcher()
+        tau = _reg.execute_registered_kernel("dynamics.fused_trajectory_inverse", self._hip_model(), sb, eb, Tf, int(N),
+                                             int(method), gravity_vector, Ftip)
+        self._count("gpu", t0)
+        return get_backend().asarray(tau)
+
+    # ------------------------------------------------------------------ helpers kept from the reference
+    def calculate_derivatives(self, positions, dt) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """First differences (reference planning/trajectory_dynamics.py:710-735)."""
+        p = np.asarray(positions)
+        v = (p[1:] - p[:-1]) / dt
+        a = (v[1:] - v[:-1]) / dt
+        j = (a[1:] - a[:-1]) / dt
+        return v, a, j
+
+    def get_performance_stats(self) -> Dict[str, float]:
+        return dict(self.performance_stats)
+
+
+TrajectoryPlanning = OptimizedTrajectoryPlanning  # alias kept by the reference (planning/__init__.py)

@@ -1,0 +1,286 @@
+"""Kernel registry + routing predicate, mirroring ManipulaPy/cuda_kernels/registry.py.
+
+Reference semantics kept:
+  * `KernelRegistration` is a frozen record (name, implementation, launch_config, cpu_fallback,
+    gpu_launcher, cpu_launcher, metadata) with read-only metadata        (registry.py:46-60)
+  * `KernelRegistry.register` refuses to replace a name (ValueError)      (:69-73)
+  * `KernelRegistry.get` raises KeyError naming the available kernels     (:75-83)
+  * `KernelRegistry.execute` picks gpu_launcher iff the physical probe succeeded AND the ACTIVE
+    backend is `gpu_capable`, read live at call time                      (:85-89, :729-732)
+
+Deliberate difference: the reference's GPU launchers swallow every exception and return the CPU
+result (trajectory_kernels.py:1083-1086).  Here a GPU launcher that fails RAISES — a silent CPU
+recompute would make every parity/throughput claim about the HIP path meaningless.  Operations
+that have no NumPy implementation in this build (the dynamics) raise `BackendNotSupportedError` from
+their cpu_launcher instead of computing on the host.
+"""
+from __future__ import annotations
+
+import os
+import threading
+from dataclasses import dataclass
+from types import MappingProxyType
+from typing import Any, Callable, Dict, Mapping, Optional, Tuple
+
+import numpy as np
+
+from . import _hip
+from .backend import get_backend
+
+__all__ = ["KernelRegistration", "KernelRegistry", "execute_registered_kernel", "get_registered_kernel",
+           "check_hip_availability", "get_context", "get_gpu_properties", "BackendNotSupportedError",
+           "trajectory_cpu", "HIP_DEVICE_ENV"]
+
+HIP_DEVICE_ENV = "MANIPULAPY_HIP_DEVICE"
+
+
+class BackendNotSupportedError(NotImplementedError):
+    """The requested operation only exists on the HIP path in this build (no CPU twin)."""
+
+
+@dataclass(frozen=True)
+class KernelRegistration:
+    name: str
+    implementation: Any            # C-ABI symbol name(s) behind the gpu launcher
+    launch_config: Callable[..., Any]
+    cpu_fallback: Optional[Callable[..., Any]]
+    gpu_launcher: Callable[..., Any]
+    cpu_launcher: Callable[..., Any]
+    metadata: Mapping[str, Any]
+
+    def __post_init__(self) -> None:
+        object.__setattr__(self, "metadata", MappingProxyType(dict(self.metadata)))
+
+
+class KernelRegistry:
+    """Fail-closed name -> operation table."""
+
+    def __init__(self) -> None:
+        self._entries: Dict[str, KernelRegistration] = {}
+
+    def register(self, entry: KernelRegistration) -> None:
+        if entry.name in self._entries:
+            raise ValueError(f"HIP kernel '{entry.name}' is already registered")
+        self._entries[entry.name] = entry
+
+    def get(self, name: str) -> KernelRegistration:
+        try:
+            return self._entries[name]
+        except KeyError:
+            available = ", ".join(sorted(self._entries))
+            raise KeyError(f"Unknown HIP kernel '{name}'. Available kernels: {available}") from None
+
+    def names(self):
+        return sorted(self._entries)
+
+    def execute(self, name: str, *args: Any, **kwargs: Any) -> Any:
+        entry = self.get(name)
+        launcher = entry.gpu_launcher if _hip_routing_enabled() else entry.cpu_launcher
+        return launcher(*args, **kwargs)
+
+
+# ------------------------------------------------------------------------------ device probe / ctx
+_probe_lock = threading.Lock()
+_probe_result: Optional[bool] = None
+_ctx: Optional[_hip.HipContext] = None
+
+
+def check_hip_availability() -> bool:
+    """Physical probe: the library loads and at least one GPU is visible.  Cached per process.
+
+    Replaces check_cuda_availability (reference registry.py:92-137).  `MANIPULAPY_FORCE_CPU=1`
+    pins it to False (reference tests/conftest.py:85).
+    """
+    global _probe_result
+    with _probe_lock:
+        if _probe_result is None:
+            if os.environ.get("MANIPULAPY_FORCE_CPU") == "1":
+                _probe_result = False
+            else:
+                try:
+                    _probe_result = _hip.device_count() > 0
+                except _hip.HipUnavailableError:
+                    _probe_result = False
+        return _probe_result
+
+
+def _reset_probe_for_tests(value: Optional[bool] = None) -> None:
+    global _probe_result
+    with _probe_lock:
+        _probe_result = value
+
+
+def _hip_routing_enabled(hip_available: Optional[bool] = None) -> bool:
+    """GPU launchers run iff a GPU is physically there AND the active backend is gpu_capable
+    (reference `_cuda_routing_enabled`, registry.py:729-732)."""
+    physical = check_hip_availability() if hip_available is None else hip_available
+    return bool(physical and getattr(get_backend(), "gpu_capable", False))
+
+
+def default_device_id() -> int:
+    for key in (HIP_DEVICE_ENV, "LOCAL_RANK"):
+        v = os.environ.get(key)
+        if v is not None and v.strip() != "":
+            return int(v)
+    return 0
+
+
+def get_context() -> _hip.HipContext:
+    """The process-wide device context (one process drives one GPU).  Raises without a GPU."""
+    global _ctx
+    with _probe_lock:
+        if _ctx is None:
+            _ctx = _hip.HipContext(default_device_id())
+        return _ctx
+
+
+def get_gpu_properties() -> Optional[Dict[str, Any]]:
+    """reference registry.py:335-356; None when no GPU."""
+    if not check_hip_availability():
+        return None
+    return get_context().properties()
+
+
+# ------------------------------------------------------------------------------ host-side NumPy path
+def trajectory_cpu(thetastart, thetaend, Tf: float, N: int, method: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """Time-scaled point-to-point trajectory on the host (NumPy backend plumbing, BASELINE config 0).
+
+    Same arithmetic as the HIP kernel and the reference's numba loop (planning/trajectory.py:45-73):
+    float32 endpoints, float64 polynomial in tau = idx / (N - 1), float32 store; cubic / quintic,
+    any other `method` -> zeros.  No joint-limit clip here (the planner applies it).
+    """
+    a = np.asarray(thetastart, dtype=np.float32)
+    b = np.asarray(thetaend, dtype=np.float32)
+    n = a.shape[-1]
+    N = int(N)
+    if N <= 0:
+        z = np.zeros(a.shape[:-1] + (0, n), dtype=np.float32)
+        return z, z.copy(), z.copy()
+    k = np.arange(N, dtype=np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        tau = (k * (float(Tf) / (N - 1)) if N > 1 else k * np.inf) / float(Tf)
+    if method == 3:
+        s = 3.0 * tau * tau - 2.0 * tau * tau * tau
+        sd = 6.0 * tau * (1.0 - tau) / Tf
+        sdd = 6.0 / (Tf * Tf) * (1.0 - 2.0 * tau)
+    elif method == 5:
+        t2 = tau * tau
+        t3 = t2 * tau
+        t4 = t2 * t2
+        t5 = t4 * tau
+        s = 10.0 * t3 - 15.0 * t4 + 6.0 * t5
+        sd = (30.0 * t2 - 60.0 * t3 + 30.0 * t4) / Tf
+        sdd = (60.0 * tau - 180.0 * t2 + 120.0 * t3) / (Tf * Tf)
+    else:
+        s = sd = sdd = np.zeros(N)
+    d = (b - a).astype(np.float64)[..., None, :]
+    a64 = a.astype(np.float64)[..., None, :]
+    pos = (s[:, None] * d + a64).astype(np.float32)
+    vel = (sd[:, None] * d).astype(np.float32)
+    acc = (sdd[:, None] * d).astype(np.float32)
+    return pos, vel, acc
+
+
+# ------------------------------------------------------------------------------ launchers
+def _no_cpu(name: str) -> Callable[..., Any]:
+    def launcher(*_a: Any, **_k: Any) -> Any:
+        raise BackendNotSupportedError(
+            f"'{name}' exists only on the HIP path of manipulapy_amd: it needs set_backend('hip') AND a "
+            "visible MI355X (no CPU twin is shipped; the reference's NumPy backend remains the CPU "
+            "implementation)")
+    return launcher
+
+
+def _launch_trajectory_gpu(model, thetastart, thetaend, Tf, N, method, use_pinned=True, *, variant="auto",
+                           enable_monitoring=True):
+    """(pos, vel, acc) host float32 (N, n), positions clipped to the model's joint limits.
+    Signature follows reference registry.py:828-851 with the compiled model prepended."""
+    del use_pinned, variant, enable_monitoring
+    s = np.asarray(thetastart, dtype=np.float32)[None, :]
+    e = np.asarray(thetaend, dtype=np.float32)[None, :]
+    p, v, a = get_context().batch_trajectory_host(model, s, e, Tf, N, method)
+    return p[0], v[0], a[0]
+
+
+def _launch_trajectory_cpu(model, thetastart, thetaend, Tf, N, method, use_pinned=True, *, variant="auto",
+                           enable_monitoring=True):
+    del model, use_pinned, variant, enable_monitoring
+    return trajectory_cpu(thetastart, thetaend, Tf, N, method)
+
+
+def _launch_batch_trajectory_gpu(model, start_batch, end_batch, Tf, N, method):
+    return get_context().batch_trajectory_host(model, start_batch, end_batch, Tf, N, method)
+
+
+def _launch_batch_trajectory_cpu(model, start_batch, end_batch, Tf, N, method):
+    del model
+    return trajectory_cpu(start_batch, end_batch, Tf, N, method)
+
+
+def _launch_id_gpu(model, q, qd, qdd, g=None, Ftip=None, dtype=np.float32):
+    return get_context().id_trajectory_host(model, q, qd, qdd, g, Ftip, dtype=dtype)
+
+
+def _launch_fused_gpu(model, start_batch, end_batch, Tf, N, method, g=None, Ftip=None):
+    return get_context().traj_id_fused_host(model, start_batch, end_batch, Tf, N, method, g, Ftip)
+
+
+def _launch_fk_jac_gpu(model, q, qd=None, qdd=None, g=None, Ftip=None, want_T=True, want_J=True):
+    return get_context().fk_jac_id_host(model, q, qd, qdd, g, Ftip, want_T, want_J)
+
+
+def _grid_1d(rows: int, block: int = 256):
+    """Launch shape every kernel uses: one thread per (trajectory, timestep) row, 256-thread blocks
+    (4 wavefronts of 64).  Replaces the CUDA block heuristics of reference registry.py:409-515."""
+    rows = int(rows)
+    return ((max(rows, 0) + block - 1) // block,), (block,)
+
+
+_TRAJECTORY_VARIANTS = ("auto", "auto_tune", "standard", "vectorized", "memory_optimized", "warp_optimized",
+                        "cache_friendly")
+
+
+def _bind_variant(function: Callable[..., Any], variant: str) -> Callable[..., Any]:
+    def bound(*args: Any, **kwargs: Any) -> Any:
+        kwargs.setdefault("variant", variant)
+        return function(*args, **kwargs)
+    return bound
+
+
+def _build_kernel_registry() -> KernelRegistry:
+    reg = KernelRegistry()
+    # the reference's seven trajectory variant names stay valid; on gfx950 they are one kernel
+    for variant in _TRAJECTORY_VARIANTS:
+        reg.register(KernelRegistration(
+            name=f"trajectory.{variant}", implementation="mp_batch_trajectory_host_f32",
+            launch_config=_grid_1d, cpu_fallback=trajectory_cpu,
+            gpu_launcher=_bind_variant(_launch_trajectory_gpu, variant),
+            cpu_launcher=_bind_variant(_launch_trajectory_cpu, variant),
+            metadata={"family": "trajectory", "variant": variant, "dimensions": 1}))
+    reg.register(KernelRegistration(
+        name="trajectory.batch", implementation="mp_batch_trajectory_host_f32", launch_config=_grid_1d,
+        cpu_fallback=trajectory_cpu, gpu_launcher=_launch_batch_trajectory_gpu,
+        cpu_launcher=_launch_batch_trajectory_cpu,
+        metadata={"family": "trajectory", "variant": "batch", "dimensions": 1}))
+    for name, impl, gpu in (
+        ("dynamics.inverse_trajectory", "mp_id_trajectory_host_f32 / _f64", _launch_id_gpu),
+        ("dynamics.fused_trajectory_inverse", "mp_traj_id_fused_host_f32", _launch_fused_gpu),
+        ("kinematics.fk_jacobian", "mp_fk_jac_id_host_f64", _launch_fk_jac_gpu),
+    ):
+        reg.register(KernelRegistration(
+            name=name, implementation=impl, launch_config=_grid_1d, cpu_fallback=None, gpu_launcher=gpu,
+            cpu_launcher=_no_cpu(name), metadata={"family": name.split(".")[0], "variant": "hip", "dimensions": 1}))
+    return reg
+
+
+_KERNEL_REGISTRY = _build_kernel_registry()
+
+
+def get_registered_kernel(name: str) -> KernelRegistration:
+    return _KERNEL_REGISTRY.get(name)
+
+
+def execute_registered_kernel(name: str, *args: Any, **kwargs: Any) -> Any:
+    """Run a registered operation on the GPU (hip backend + device present) or through its explicit
+    CPU launcher (reference registry.py:963-965)."""
+    return _KERNEL_REGISTRY.execute(name, *args, **kwargs)

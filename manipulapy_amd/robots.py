@@ -1,0 +1,39 @@
+"""Robot model tables for the benchmark robots.
+
+The reference builds these tables from URDFs (urdf_processor.py:82-138 -> urdf/core.py:670-769).  A
+native URDF reader is a "next" row; until then the tables of the four configuration
+robots are shipped as small .npz fixtures captured from the reference (tests/golden/make_golden.py)
+— numbers only — so the GPU box, which has no reference, can build the same robots.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, Tuple
+
+import numpy as np
+
+_DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+ROBOTS = ("ur5", "iiwa14", "panda", "xarm6")
+
+
+def robot_tables(name: str) -> Dict[str, np.ndarray]:
+    """S_list (6,n), M_ee (4,4), Glist (n,6,6), Mlist_per_link (n,4,4), joint_limits (n,2), B_list (6,n)."""
+    if name not in ROBOTS:
+        raise KeyError(f"unknown robot {name!r}; available: {', '.join(ROBOTS)}")
+    z = np.load(os.path.join(_DATA, f"model_{name}.npz"))
+    return {k: z[k] for k in ("S_list", "B_list", "M_ee", "Glist", "Mlist_per_link", "joint_limits")}
+
+
+def load_robot(name: str) -> Tuple["SerialManipulator", "ManipulatorDynamics", np.ndarray]:
+    """(serial_manipulator, dynamics, joint_limits) built like URDFToSerialManipulator(...) would
+    (reference urdf_processor.py:264-302)."""
+    from .dynamics import ManipulatorDynamics
+    from .kinematics import SerialManipulator
+
+    t = robot_tables(name)
+    sm = SerialManipulator(M_list=t["M_ee"], omega_list=t["S_list"][:3], S_list=t["S_list"], B_list=t["B_list"],
+                           G_list=t["Glist"], joint_limits=[tuple(r) for r in t["joint_limits"]])
+    dyn = ManipulatorDynamics(M_list=t["M_ee"], omega_list=t["S_list"][:3], r_list=None, b_list=None,
+                              S_list=t["S_list"], B_list=t["B_list"], Glist=t["Glist"],
+                              Mlist_per_link=t["Mlist_per_link"])
+    return sm, dyn, t["joint_limits"]

@@ -1,0 +1,62 @@
+// TEST INFRASTRUCTURE — host instantiation of the device math (manipulapy_amd/csrc/mp_core.h) so the
+// GPU-less CI box can check the model compiler + recursion against the oracle.  Never linked into or
+// called by the product library; the product path only runs these templates inside HIP kernels.
+#include <cstring>
+
+#include "../../manipulapy_amd/csrc/mp_core.h"
+#include "../../manipulapy_amd/csrc/mp_model_compile.h"
+
+namespace {
+template <typename T, int N>
+void run_id(const MpModel<T>& M, const MpCall<T>& C, bool ftip, long rows, const double* q, const double* qd,
+            const double* qdd, double* tau, double* Tout, double* Jout) {
+  for (long r = 0; r < rows; ++r) {
+    T a[N], b[N], c[N], t[N];
+    for (int j = 0; j < N; ++j) { a[j] = (T)q[r * N + j]; b[j] = (T)qd[r * N + j]; c[j] = (T)qdd[r * N + j]; }
+    MpJointState<T, N> js;
+    mp_joint_state<T, N>(M, a, js);
+    if (ftip) mp_rnea<T, N, true>(M, C, js, b, c, t);
+    else mp_rnea<T, N, false>(M, C, js, b, c, t);
+    for (int j = 0; j < N; ++j) tau[r * N + j] = (double)mp_clip(t[j], M.taumin[j], M.taumax[j]);
+    if (Tout) {
+      T TT[16], JJ[6 * N];
+      mp_fk_jac<T, N, true>(M, js, TT, JJ);
+      for (int k = 0; k < 16; ++k) Tout[r * 16 + k] = (double)TT[k];
+      for (int k = 0; k < 6 * N; ++k) Jout[r * 6 * N + k] = (double)JJ[k];
+    }
+  }
+}
+template <typename T>
+int run(const MpModel<double>& Md, const MpCall<double>& Cd, bool ftip, long rows, const double* q, const double* qd,
+        const double* qdd, double* tau, double* Tout, double* Jout) {
+  MpModel<T> M;
+  MpCall<T> C;
+  mp_model_cast(Md, &M);
+  mp_call_cast(Cd, &C);
+  switch (Md.n) {
+#define CASE(N) case N: run_id<T, N>(M, C, ftip, rows, q, qd, qdd, tau, Tout, Jout); return 0;
+    CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
+#undef CASE
+  }
+  return 1;
+}
+}  // namespace
+
+extern "C" int hostsim_run(int n, const double* S, const double* Mcom, const double* G, const double* M_ee,
+                           const double* joint_limits, const double* torque_limits, const double* g,
+                           const double* Ftip, long rows, const double* q, const double* qd, const double* qdd,
+                           int use_f32, double* tau, double* Tout, double* Jout, double* params_out, char* err,
+                           long errlen) {
+  MpModel<double> Md;
+  int rc = mp_compile_model(n, S, Mcom, G, M_ee, joint_limits, torque_limits, &Md, err, (size_t)errlen);
+  if (rc) return rc;
+  if (params_out)
+    for (int i = 0; i < n; ++i) std::memcpy(params_out + 16 * i, &Md.j[i], 16 * sizeof(double));
+  MpCall<double> Cd;
+  mp_make_call(Md, g, Ftip, &Cd);
+  bool ftip = false;
+  if (Ftip)
+    for (int k = 0; k < 6; ++k) ftip |= (Ftip[k] != 0.0);
+  return use_f32 ? run<float>(Md, Cd, ftip, rows, q, qd, qdd, tau, Tout, Jout)
+                 : run<double>(Md, Cd, ftip, rows, q, qd, qdd, tau, Tout, Jout);
+}

@@ -1,0 +1,341 @@
+"""GPU parity tests (run on an MI355X: `pytest -m gpu`).  Everything goes through the C ABI
+(manipulapy_amd/_hip.py -> libmanipula_hip.so); the checker is the CPU oracle / the golden fixtures.
+
+Tolerances (BASELINE.json north_star: 1e-6 rel fp64 / 1e-4 rel fp32 against the NumPy CPU backend):
+  fp64:  |d| <= 1e-6 * |ref| + 1e-7   — the 1e-7 absolute floor (N.m) sits above the reference's own
+         central-difference noise (~3e-9, reference tests/test_dynamics_golden.py:62-76 uses atol 1e-8)
+         and is needed for torque components that are exactly or nearly zero.
+  fp32:  |d| <= 1e-4 * |ref| + 1e-4 * max|ref row|  — elementwise relative, with a floor tied to the
+         row's own scale for near-zero components (float32 cancellation cannot be relative to ~0).
+"""
+import numpy as np
+import pytest
+
+from conftest import ROBOTS, golden_path
+from oracle import ref_numpy as ref
+
+pytestmark = pytest.mark.gpu
+
+F64_RTOL, F64_ATOL = 1e-6, 1e-7
+F32_RTOL, F32_ROW = 1e-4, 1e-4
+
+
+def assert_f64(got, want):
+    np.testing.assert_allclose(got, want, rtol=F64_RTOL, atol=F64_ATOL)
+
+
+def assert_f32(got, want):
+    want = np.asarray(want, dtype=np.float64)
+    got = np.asarray(got, dtype=np.float64)
+    floor = F32_ROW * np.abs(want).max(axis=-1, keepdims=True)
+    bad = np.abs(got - want) > F32_RTOL * np.abs(want) + floor
+    assert not bad.any(), f"max abs err {np.abs(got - want).max():.3e}, {bad.sum()} elements outside tolerance"
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from manipulapy_amd import _hip
+
+    c = _hip.HipContext(0)
+    c.selftest()
+    yield c
+    c.destroy()
+
+
+@pytest.fixture(scope="module")
+def models(tables):
+    from manipulapy_amd import _hip
+
+    return {r: _hip.HipModel(t.S, t.Mcom, t.G, t.M_ee, t.joint_limits) for r, t in tables.items()}
+
+
+def test_native_library_is_the_one_loaded(ctx):
+    import manipulapy_amd
+    from manipulapy_amd import _hip
+
+    assert _hip.lib_path().endswith("libmanipula_hip.so")
+    with open("/proc/self/maps") as f:
+        assert "libmanipula_hip.so" in f.read()
+    p = ctx.properties()
+    assert p["multiprocessor_count"] > 0 and p["warp_size"] == 64
+    assert manipulapy_amd.check_hip_availability()
+
+
+@pytest.mark.parametrize("robot", ROBOTS)
+def test_inverse_dynamics_golden_f64(robot, ctx, models, dyn_golden):
+    z = dyn_golden[robot]
+    for i in range(len(z["thetas"])):  # per-row Ftip -> one launch per configuration
+        tau = ctx.id_trajectory_host(models[robot], z["thetas"][i:i + 1], z["dthetas"][i:i + 1], z["ddthetas"][i:i + 1],
+                                     z["g"], z["ftips"][i], dtype=np.float64)
+        assert_f64(tau[0], z["inverse_dynamics"][i])
+
+
+@pytest.mark.parametrize("robot", ["ur5", "panda"])
+def test_inverse_dynamics_reference_own_goldens_f64(robot, ctx, models):
+    """The reference's own tests/data/dynamics_golden_*.npz (byte-identical copies)."""
+    z = np.load(golden_path(f"dynamics_golden_{robot}.npz"))
+    for i in range(len(z["thetas"])):
+        tau = ctx.id_trajectory_host(models[robot], z["thetas"][i:i + 1], z["dthetas"][i:i + 1], z["ddthetas"][i:i + 1],
+                                     z["g"], z["ftips"][i], dtype=np.float64)
+        assert_f64(tau[0], z["inverse_dynamics"][i])
+        zero = np.zeros_like(z["thetas"][i:i + 1])
+        grav = ctx.id_trajectory_host(models[robot], z["thetas"][i:i + 1], zero, zero, z["g"], None, dtype=np.float64)
+        assert_f64(grav[0], z["gravity_forces"][i])
+        cor = ctx.id_trajectory_host(models[robot], z["thetas"][i:i + 1], z["dthetas"][i:i + 1], zero, np.zeros(3), None,
+                                     dtype=np.float64)
+        assert_f64(cor[0], z["velocity_quadratic_forces"][i])
+
+
+@pytest.mark.parametrize("robot", ROBOTS)
+def test_inverse_dynamics_golden_f32(robot, ctx, models, dyn_golden):
+    z = dyn_golden[robot]
+    zero_ftip = [i for i in range(len(z["thetas"])) if not z["ftips"][i].any()]
+    tau = ctx.id_trajectory_host(models[robot], z["thetas"][zero_ftip], z["dthetas"][zero_ftip], z["ddthetas"][zero_ftip],
+                                 z["g"], None, dtype=np.float32)
+    assert tau.dtype == np.float32
+    assert_f32(tau, z["inverse_dynamics"][zero_ftip])
+    for i in range(5, len(z["thetas"]), 4):
+        t = ctx.id_trajectory_host(models[robot], z["thetas"][i:i + 1], z["dthetas"][i:i + 1], z["ddthetas"][i:i + 1],
+                                   z["g"], z["ftips"][i], dtype=np.float32)
+        assert_f32(t, z["inverse_dynamics"][i:i + 1])
+
+
+@pytest.mark.parametrize("robot", ROBOTS)
+def test_fk_jacobian_golden_f64(robot, ctx, models, dyn_golden):
+    z = dyn_golden[robot]
+    T, J, tau = ctx.fk_jac_id_host(models[robot], z["thetas"], z["dthetas"], z["ddthetas"], z["g"], None)
+    np.testing.assert_allclose(T, z["fk_space"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(J, z["jac_space"], rtol=1e-9, atol=1e-12)
+    zero = [i for i in range(len(z["thetas"])) if not z["ftips"][i].any()]
+    assert_f64(tau[zero], z["inverse_dynamics"][zero])
+    # outputs can be requested separately
+    T2, J2, tau2 = ctx.fk_jac_id_host(models[robot], z["thetas"], want_J=False)
+    assert J2 is None and tau2 is None
+    np.testing.assert_array_equal(T2, T)
+
+
+def test_mass_matrix_and_forward_dynamics_via_api(dyn_golden, tables):
+    """ManipulatorDynamics mirror under the hip backend (per-point API, float64)."""
+    import manipulapy_amd as mp
+
+    for robot in ("ur5", "panda"):
+        sm, dyn, _ = mp.load_robot(robot)
+        z = dyn_golden[robot]
+        with mp.use_backend("hip"):
+            for i in (0, 5, 11, 24):
+                M = dyn.mass_matrix(z["thetas"][i])
+                np.testing.assert_allclose(M, z["mass_matrix"][i], rtol=1e-6, atol=1e-8)
+                assert_f64(dyn.gravity_forces(z["thetas"][i], z["g"]), z["gravity_forces"][i])
+                assert_f64(dyn.velocity_quadratic_forces(z["thetas"][i], z["dthetas"][i]), z["velocity_quadratic_forces"][i])
+                assert_f64(dyn.inverse_dynamics(z["thetas"][i], z["dthetas"][i], z["ddthetas"][i], z["g"], z["ftips"][i]),
+                           z["inverse_dynamics"][i])
+                qdd = dyn.forward_dynamics(z["thetas"][i], z["dthetas"][i], z["inverse_dynamics"][i], z["g"], z["ftips"][i])
+                np.testing.assert_allclose(qdd, z["forward_dynamics"][i], rtol=1e-5, atol=1e-6)
+                np.testing.assert_allclose(sm.forward_kinematics(z["thetas"][i]), z["fk_space"][i], atol=1e-12)
+                np.testing.assert_allclose(sm.forward_kinematics(z["thetas"][i], "body"), z["fk_body"][i], atol=1e-12)
+                np.testing.assert_allclose(sm.jacobian(z["thetas"][i], "body"), z["jac_body"][i], atol=1e-10)
+
+
+def test_batch_trajectory_against_fixture_and_oracle(ctx, models):
+    z = np.load(golden_path("trajectory_ur5.npz"))
+    m = models["ur5"]
+    for tag in ("q1000", "c500"):
+        N, method, Tf = z[f"jt_{tag}_args"]
+        p, v, a = ctx.batch_trajectory_host(m, z["start"][None], z["end"][None], float(Tf), int(N), int(method))
+        o = ref.joint_trajectory(z["joint_limits"], z["start"], z["end"], float(Tf), int(N), int(method))
+        for got, key in ((p, "positions"), (v, "velocities"), (a, "accelerations")):
+            assert got.dtype == np.float32 and got.shape == (1, int(N), 6)
+            # float64 polynomial rounded to float32: at most 1 ulp apart from the oracle (FMA contraction)
+            np.testing.assert_allclose(got[0], o[key], rtol=2.5e-7, atol=1e-7)
+            np.testing.assert_allclose(got[0], z[f"jt_{tag}_{key}"], rtol=3e-7, atol=1e-6)
+    # clip to the joint limits
+    p, _, _ = ctx.batch_trajectory_host(m, z["start"][None], z["jt_clip_end"][None], 1.0, 32, 5)
+    np.testing.assert_allclose(p[0], z["jt_clip_positions"], rtol=3e-7, atol=1e-6)
+    # batch + unsupported method -> zeros (planning/trajectory.py:67-68)
+    p, v, a = ctx.batch_trajectory_host(m, z["batch_start"], z["batch_end"], 2.0, 16, 5)
+    np.testing.assert_allclose(p, z["batch_positions"], rtol=3e-7, atol=1e-6)
+    np.testing.assert_allclose(a, z["batch_accelerations"], rtol=3e-7, atol=1e-6)
+    p, v, a = ctx.batch_trajectory_host(m, z["batch_start"], z["batch_end"], 2.0, 16, 9)
+    assert not v.any() and not a.any()
+    np.testing.assert_array_equal(p, np.clip(np.broadcast_to(z["batch_start"][:, None, :], p.shape),
+                                             z["joint_limits"][:, 0].astype(np.float32), z["joint_limits"][:, 1].astype(np.float32)))
+    # N = 3 known answer (reference tests/test_backend_dispatch.py:2712-2727)
+    m2 = models["ur5"]
+    s = np.zeros((1, 6), np.float32); e = np.ones((1, 6), np.float32)
+    p, v, a = ctx.batch_trajectory_host(m2, s, e, 2.0, 3, 5)
+    np.testing.assert_array_equal(p[0, :, 0], np.array([0, 0.5, 1], np.float32))
+    np.testing.assert_array_equal(v[0, :, 0], np.array([0, 0.9375, 0], np.float32))
+    np.testing.assert_array_equal(a[0, :, 0], np.zeros(3, np.float32))
+
+
+def test_inverse_dynamics_trajectory_planner_level(tables):
+    """OptimizedTrajectoryPlanning under the hip backend vs the reference's planner dump."""
+    import manipulapy_amd as mp
+
+    z = np.load(golden_path("trajectory_ur5.npz"))
+    sm, dyn, lim = mp.load_robot("ur5")
+    with mp.use_backend("hip"):
+        pl = mp.OptimizedTrajectoryPlanning(sm, None, dyn, lim)
+        assert pl.cuda_available
+        tau = pl.inverse_dynamics_trajectory(z["idt_q"], z["idt_qd"], z["idt_qdd"])  # float64 in -> f64 kernel, f32 out
+        assert tau.dtype == np.float32 and tau.shape == (64, 6)
+        np.testing.assert_allclose(tau, z["idt_tau_f32"], rtol=2e-6, atol=2e-6)
+        tau32 = pl.inverse_dynamics_trajectory(z["idt_q"].astype(np.float32), z["idt_qd"].astype(np.float32),
+                                               z["idt_qdd"].astype(np.float32))
+        assert_f32(tau32, z["idt_tau_f64"])
+        pl2 = mp.OptimizedTrajectoryPlanning(sm, None, dyn, lim, torque_limits=z["idt_torque_limits"])
+        tc = pl2.inverse_dynamics_trajectory(z["idt_q"][:16], z["idt_qd"][:16], z["idt_qdd"][:16], None, z["idt_ftip"])
+        np.testing.assert_allclose(tc, z["idt_tau_f32_clip_ftip"], rtol=2e-6, atol=2e-6)
+        assert tc.max() <= 15.0 and tc.min() >= -20.0
+        # empty trajectory
+        assert pl.inverse_dynamics_trajectory(np.zeros((0, 6)), np.zeros((0, 6)), np.zeros((0, 6))).shape == (0, 6)
+        # joint_trajectory on the device (N * n above the work threshold)
+        N = 20000
+        r = pl.joint_trajectory(z["start"], z["end"], 2.0, N, 5)
+        assert pl.performance_stats["gpu_calls"] >= 3
+        o = ref.joint_trajectory(lim, z["start"], z["end"], 2.0, N, 5)
+        np.testing.assert_allclose(r["positions"], o["positions"], rtol=2.5e-7, atol=1e-7)
+        np.testing.assert_allclose(r["accelerations"], o["accelerations"], rtol=2.5e-7, atol=1e-6)
+
+
+def test_fused_equals_two_step_pipeline(ctx, models):
+    """fused kernel == batch_trajectory followed by id_trajectory, bit for bit (same float32 intermediates)."""
+    rng = np.random.default_rng(7)
+    for robot in ("ur5", "panda"):
+        m = models[robot]
+        z = np.load(golden_path(f"model_{robot}.npz"))
+        lo, hi = z["joint_limits"][:, 0], z["joint_limits"][:, 1]
+        B, N = 37, 129  # ragged: neither a multiple of the block nor of the wave
+        s = rng.uniform(lo, hi, (B, m.n)).astype(np.float32)
+        e = rng.uniform(lo, hi, (B, m.n)).astype(np.float32)
+        p, v, a = ctx.batch_trajectory_host(m, s, e, 2.0, N, 5)
+        two = ctx.id_trajectory_host(m, p.reshape(-1, m.n), v.reshape(-1, m.n), a.reshape(-1, m.n), None, None)
+        fused = ctx.traj_id_fused_host(m, s, e, 2.0, N, 5)
+        np.testing.assert_array_equal(fused.reshape(-1, m.n), two)
+
+
+@pytest.mark.parametrize("robot,dtype", [("ur5", np.float32), ("iiwa14", np.float64), ("panda", np.float32), ("xarm6", np.float64)])
+def test_random_rows_against_oracle(robot, dtype, ctx, models, tables):
+    """Seeded random rows (positions inside the joint limits) vs the CPU oracle, incl. a wrench."""
+    rng = np.random.default_rng(20260705)
+    tab, m = tables[robot], models[robot]
+    rows = 48
+    q = rng.uniform(tab.joint_limits[:, 0], tab.joint_limits[:, 1], (rows, tab.n)).astype(dtype)
+    qd = rng.uniform(-2, 2, (rows, tab.n)).astype(dtype)
+    qdd = rng.uniform(-4, 4, (rows, tab.n)).astype(dtype)
+    F = np.array([1.0, -2.0, 0.5, 3.0, -1.5, 0.75])
+    g = np.array([0.3, -0.2, -9.81])
+    want = ref.inverse_dynamics_trajectory(tab, q.astype(np.float64), qd.astype(np.float64), qdd.astype(np.float64), g, F,
+                                           dtype=np.float64)
+    got = ctx.id_trajectory_host(m, q, qd, qdd, g, F, dtype=dtype)
+    (assert_f32 if dtype == np.float32 else assert_f64)(got, want)
+
+
+def test_size_independent_properties_full_config(ctx, models):
+    """BASELINE config 2 size (B=4096 x N=1000, UR5 float32) through device buffers:
+    (a) linearity in qdd:  ID(q, 0, a1 + a2, g=0) == ID(q, 0, a1, 0) + ID(q, 0, a2, 0)
+    (b) gravity superposition: ID(q, qd, qdd, g) - ID(q, qd, qdd, 0) == ID(q, 0, 0, g)
+    (c) the fused kernel equals the two-step pipeline on every one of the 4.1 M rows."""
+    m = models["ur5"]
+    z = np.load(golden_path("model_ur5.npz"))
+    rng = np.random.default_rng(20260705 + 2)
+    B, N, n = 4096, 1000, 6
+    lo, hi = z["joint_limits"][:, 0], z["joint_limits"][:, 1]
+    s = rng.uniform(lo, hi, (B, n)).astype(np.float32)
+    e = rng.uniform(lo, hi, (B, n)).astype(np.float32)
+    rows = B * N
+    nb = rows * n * 4
+    d_s, d_e = ctx.to_device(s), ctx.to_device(e)
+    bufs = [ctx.alloc(nb) for _ in range(7)]
+    d_q, d_qd, d_qdd, d_t1, d_t2, d_t3, d_zero = bufs
+    ctx.lib.mp_memset(ctx.handle, d_zero.ptr, 0, nb)
+    ctx.batch_trajectory(m, d_s, d_e, B, N, 2.0, 5, d_q, d_qd, d_qdd)
+    zero3 = np.zeros(3)
+    # (c)
+    ctx.id_trajectory(m, d_q, d_qd, d_qdd, rows, d_t1)
+    ctx.traj_id_fused(m, d_s, d_e, B, N, 2.0, 5, d_t2)
+    t_two = d_t1.download((rows, n), np.float32)
+    t_fused = d_t2.download((rows, n), np.float32)
+    np.testing.assert_array_equal(t_two, t_fused)
+    assert np.isfinite(t_two).all()
+    # (b)
+    ctx.id_trajectory(m, d_q, d_qd, d_qdd, rows, d_t2, g=zero3)
+    ctx.id_trajectory(m, d_q, d_zero, d_zero, rows, d_t3)
+    t_nog = d_t2.download((rows, n), np.float32)
+    t_g = d_t3.download((rows, n), np.float32)
+    scale = np.abs(t_two).max(axis=1, keepdims=True) + np.abs(t_g).max(axis=1, keepdims=True)
+    assert (np.abs((t_two - t_nog) - t_g) <= 2e-5 * scale + 1e-5).all()
+    # (a): a1 = qdd, a2 = qd used as a second acceleration field
+    ctx.id_trajectory(m, d_q, d_zero, d_qdd, rows, d_t1, g=zero3)
+    ctx.id_trajectory(m, d_q, d_zero, d_qd, rows, d_t2, g=zero3)
+    a1 = d_t1.download((rows, n), np.float32)
+    a2 = d_t2.download((rows, n), np.float32)
+    qdd = d_qdd.download((rows, n), np.float32)
+    qd = d_qd.download((rows, n), np.float32)
+    d_qdd.upload(qdd + qd)
+    ctx.id_trajectory(m, d_q, d_zero, d_qdd, rows, d_t3, g=zero3)
+    a12 = d_t3.download((rows, n), np.float32)
+    scale = np.abs(a1).max(axis=1, keepdims=True) + np.abs(a2).max(axis=1, keepdims=True)
+    assert (np.abs(a12 - (a1 + a2)) <= 2e-5 * scale + 1e-5).all()
+    # spot-check 16 rows of the full-size run against the oracle
+    tab = ref.load_tables(golden_path("model_ur5.npz"))
+    q = d_q.download((rows, n), np.float32)
+    idx = rng.integers(0, rows, 16)
+    want = ref.inverse_dynamics_trajectory(tab, q[idx].astype(np.float64), qd[idx].astype(np.float64),
+                                           qdd[idx].astype(np.float64), dtype=np.float64)
+    assert_f32(t_two[idx], want)
+    for b in bufs + [d_s, d_e]:
+        b.free()
+
+
+def test_edge_cases_and_errors(ctx, models):
+    from manipulapy_amd import _hip
+
+    m = models["ur5"]
+    # empty inputs are a no-op
+    assert ctx.id_trajectory_host(m, np.zeros((0, 6), np.float32), np.zeros((0, 6), np.float32), np.zeros((0, 6), np.float32)).shape == (0, 6)
+    assert ctx.batch_trajectory_host(m, np.zeros((0, 6)), np.zeros((0, 6)), 1.0, 5, 5)[0].shape == (0, 5, 6)
+    # wrong dof
+    with pytest.raises(ValueError):
+        ctx.id_trajectory_host(m, np.zeros((4, 7)), np.zeros((4, 7)), np.zeros((4, 7)))
+    # one row, 63/64/65 rows (wave boundaries), 257 rows (block boundary)
+    rng = np.random.default_rng(3)
+    tab = ref.load_tables(golden_path("model_ur5.npz"))
+    big = rng.uniform(-1, 1, (257, 3, 6))
+    full = ctx.id_trajectory_host(m, big[:, 0], big[:, 1], big[:, 2], dtype=np.float64)
+    for rows in (1, 63, 64, 65):
+        part = ctx.id_trajectory_host(m, big[:rows, 0], big[:rows, 1], big[:rows, 2], dtype=np.float64)
+        np.testing.assert_array_equal(part, full[:rows])
+    want = ref.inverse_dynamics_trajectory(tab, big[250:, 0], big[250:, 1], big[250:, 2], dtype=np.float64)
+    assert_f64(full[250:], want)
+    # torque clip inside the kernel
+    mc = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee, tab.joint_limits, np.array([[-5.0, 4.0]] * 6))
+    clipped = ctx.id_trajectory_host(mc, big[:, 0], big[:, 1], big[:, 2], dtype=np.float64)
+    np.testing.assert_array_equal(clipped, np.clip(full, -5.0, 4.0))
+    # misaligned device pointer is rejected, not launched
+    d = ctx.alloc(1024)
+    with pytest.raises(_hip.HipError):
+        ctx.id_trajectory(m, d.offset(4), d, d, 1, d)
+    d.free()
+
+
+def test_2r_planar_analytical_on_gpu(ctx):
+    """Analytical 2R planar arm (reference tests/test_v132_regressions.py:126-286) on the device, n = 2."""
+    from manipulapy_amd import _hip
+    from test_oracle_golden import _planar_2r
+
+    tab, (l1, l2, m1, m2) = _planar_2r()
+    m = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee)
+    th = np.array([[0.3, -0.7], [1.2, 0.4]])
+    dq = np.array([[0.7, -0.4], [0.1, 0.9]])
+    ddq = np.array([[0.2, 0.5], [-1.0, 0.3]])
+    g = np.array([0.0, -9.81, 0.0])
+    tau = ctx.id_trajectory_host(m, th, dq, ddq, g, None, dtype=np.float64)
+    for r in range(2):
+        c2, s2 = np.cos(th[r, 1]), np.sin(th[r, 1])
+        M = np.array([[m1 * l1**2 + m2 * (l1**2 + 2 * l1 * l2 * c2 + l2**2), m2 * (l1 * l2 * c2 + l2**2)],
+                      [m2 * (l1 * l2 * c2 + l2**2), m2 * l2**2]])
+        c = np.array([-m2 * l1 * l2 * s2 * (2 * dq[r, 0] * dq[r, 1] + dq[r, 1] ** 2), m2 * l1 * l2 * s2 * dq[r, 0] ** 2])
+        c1, c12 = np.cos(th[r, 0]), np.cos(th[r, 0] + th[r, 1])
+        gv = np.array([(m1 + m2) * 9.81 * l1 * c1 + m2 * 9.81 * l2 * c12, m2 * 9.81 * l2 * c12])
+        np.testing.assert_allclose(tau[r], M @ ddq[r] + c + gv, rtol=1e-12, atol=1e-12)

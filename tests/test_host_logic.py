@@ -1,0 +1,295 @@
+"""CPU-only tests of the host side: C-ABI symbol export, backend / kernel registries, routing,
+planner plumbing on the NumPy backend, the model compiler + device math (host instantiation) against
+the oracle, and the multi-process sharding logic over gloo.  No compute call reaches a GPU here."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROBOTS, ROOT, golden_path
+from oracle import ref_numpy as ref
+
+import manipulapy_amd as mp
+from manipulapy_amd import _hip, registry, sharding
+
+
+# ----------------------------------------------------------------------------- C ABI
+def _header_functions():
+    text = open(os.path.join(ROOT, "include", "manipula_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mp_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_cabi_library_loads_and_exports_every_declared_symbol():
+    from manipulapy_amd.build import build
+
+    lib = ctypes.CDLL(build(verbose=False))  # compiles for gfx950 if stale; needs no GPU
+    declared = _header_functions()
+    assert len(declared) >= 35
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/manipula_hip.h but not exported"
+    assert sorted(_hip.SIGNATURES) == declared, "ctypes signature table and header disagree"
+    assert _hip.load_library().mp_version() == 1
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    if _hip.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(_hip.HipUnavailableError):
+        _hip.HipContext(0)
+    sm, dyn, lim = mp.load_robot("ur5")
+    with mp.use_backend("hip"):
+        with pytest.raises(mp.BackendNotSupportedError):
+            dyn.mass_matrix(np.zeros(6))
+        pl = mp.OptimizedTrajectoryPlanning(sm, None, dyn, lim)
+        with pytest.raises(mp.BackendNotSupportedError):
+            pl.inverse_dynamics_trajectory(np.zeros((3, 6)), np.zeros((3, 6)), np.zeros((3, 6)))
+        with pytest.raises(RuntimeError):
+            mp.OptimizedTrajectoryPlanning(sm, None, dyn, lim, use_cuda=True)
+
+
+def test_product_never_imports_the_oracle():
+    for root, _, files in os.walk(os.path.join(ROOT, "manipulapy_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip")):
+                src = open(os.path.join(root, f)).read()
+                assert "oracle" not in src.replace("the oracle", "").replace("oracle backend", ""), f"{f} mentions oracle"
+
+
+# ----------------------------------------------------------------------------- model compiler (host)
+@pytest.mark.parametrize("robot", ROBOTS)
+def test_model_compiler_fk_matches_oracle(robot, tables):
+    tab = tables[robot]
+    m = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee, tab.joint_limits)
+    rng = np.random.default_rng(1)
+    for _ in range(8):
+        q = rng.uniform(tab.joint_limits[:, 0], tab.joint_limits[:, 1])
+        np.testing.assert_allclose(m.fk_host(q), ref.fk_space(tab, q), atol=1e-12)
+    p = m.params()
+    assert p.shape == (tab.n, 16)
+    np.testing.assert_allclose(p[:, 0] ** 2 + p[:, 1] ** 2, 1.0, atol=1e-12)  # cos^2 + sin^2 of alpha
+    np.testing.assert_allclose(p[:, 6], tab.G[:, 3, 3])                        # masses survive
+    assert set(np.unique(p[:, 5])) <= {0.0, 1.0}                                # joint type flags
+
+
+def test_model_compiler_rejects_bad_tables(tables):
+    tab = tables["ur5"]
+    S = tab.S.copy(); S[:3, 2] *= 1.5
+    with pytest.raises(_hip.HipError, match="unit"):
+        _hip.HipModel(S, tab.Mcom, tab.G, tab.M_ee)
+    G = tab.G.copy(); G[1, 0, 4] = 0.3
+    with pytest.raises(_hip.HipError, match="blockdiag"):
+        _hip.HipModel(tab.S, tab.Mcom, G, tab.M_ee)
+    with pytest.raises(ValueError):
+        _hip.HipModel(tab.S, tab.Mcom[:3], tab.G, tab.M_ee)
+    with pytest.raises((_hip.HipError, ValueError)):
+        _hip.HipModel(np.zeros((6, 9)), np.zeros((9, 4, 4)), np.zeros((9, 6, 6)), np.eye(4))
+
+
+# ----------------------------------------------------------------------------- device math on the host
+@pytest.fixture(scope="module")
+def hostsim():
+    """g++ build of the SAME templates the kernels instantiate (tests/hostsim/hostsim.cpp)."""
+    src = os.path.join(ROOT, "tests", "hostsim", "hostsim.cpp")
+    out = os.path.join(ROOT, "tests", "hostsim", "libmp_hostsim.so")
+    deps = [src] + [os.path.join(ROOT, "manipulapy_amd", "csrc", f) for f in ("mp_core.h", "mp_model.h", "mp_model_compile.cpp", "mp_model_compile.h")]
+    if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", out, src,
+                        os.path.join(ROOT, "manipulapy_amd", "csrc", "mp_model_compile.cpp")], check=True)
+    lib = ctypes.CDLL(out)
+    dp = ctypes.POINTER(ctypes.c_double)
+
+    def run(tab, q, qd, qdd, g, Ftip, f32, torque_limits=None):
+        P = lambda a: None if a is None else a.ctypes.data_as(dp)
+        c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        rows, n = q.shape
+        S, Mc, G, Me, jl = c(tab.S), c(tab.Mcom), c(tab.G), c(tab.M_ee), c(tab.joint_limits)
+        tl = None if torque_limits is None else c(torque_limits)
+        q, qd, qdd, g, Ftip = c(q), c(qd), c(qdd), c(g), c(Ftip)
+        tau, T, J = np.zeros((rows, n)), np.zeros((rows, 4, 4)), np.zeros((rows, 6, n))
+        err = ctypes.create_string_buffer(256)
+        rc = lib.hostsim_run(n, P(S), P(Mc), P(G), P(Me), P(jl), P(tl), P(g), P(Ftip), ctypes.c_long(rows), P(q), P(qd),
+                             P(qdd), int(f32), P(tau), P(T), P(J), None, err, ctypes.c_long(256))
+        assert rc == 0, err.value
+        return tau, T, J
+    return run
+
+
+@pytest.mark.parametrize("robot", ROBOTS)
+def test_device_math_matches_golden_on_host(robot, hostsim, tables, dyn_golden):
+    tab, z = tables[robot], dyn_golden[robot]
+    for i in range(len(z["thetas"])):
+        a = (z["thetas"][i:i + 1], z["dthetas"][i:i + 1], z["ddthetas"][i:i + 1], z["g"], z["ftips"][i])
+        tau, T, J = hostsim(tab, *a, 0)
+        np.testing.assert_allclose(tau[0], z["inverse_dynamics"][i], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(T[0], z["fk_space"][i], atol=1e-12)
+        np.testing.assert_allclose(J[0], z["jac_space"][i], atol=1e-12)
+        t32, _, _ = hostsim(tab, *a, 1)
+        want = z["inverse_dynamics"][i]
+        assert (np.abs(t32[0] - want) <= 1e-4 * np.abs(want) + 1e-4 * np.abs(want).max()).all()
+
+
+def test_float32_sincos_accuracy(hostsim, tables):
+    """The float32 trig used by the kernels: 1-DOF 'robot' whose FK rotation exposes sin/cos directly."""
+    S = np.array([[0, 0, 1, 0, 0, 0]], dtype=float).T
+    tab = ref.RobotTables(S=S, M_ee=np.eye(4), G=np.eye(6)[None], Mcom=np.eye(4)[None], joint_limits=np.array([[-10.0, 10.0]]))
+    q = np.linspace(-9.5, 9.5, 4001)[:, None].astype(np.float32).astype(np.float64)
+    z = np.zeros_like(q)
+    _, T, _ = hostsim(tab, q, z, z, np.zeros(3), np.zeros(6), 1)
+    assert np.abs(T[:, 0, 0] - np.cos(q[:, 0])).max() < 2.5e-7
+    assert np.abs(T[:, 1, 0] - np.sin(q[:, 0])).max() < 2.5e-7
+
+
+# ----------------------------------------------------------------------------- backend registry
+def test_backend_registry_semantics():
+    """reference backend/__init__.py:65-237 / tests/test_backend_dispatch.py registry cases."""
+    assert isinstance(mp.get_backend(), mp.NumpyBackend) and not mp.get_backend().gpu_capable
+    with pytest.raises(ValueError, match="already registered"):
+        mp.register("numpy", mp.NumpyBackend())
+    with pytest.raises(ValueError, match="Registered backends: hip, numpy"):
+        mp.set_backend("nope")
+    with pytest.raises(ImportError):
+        mp.set_backend("cupy")
+    with mp.use_backend("hip") as b:
+        assert b.gpu_capable and mp.get_backend() is b and b.is_concrete
+        assert b.cache_token() is b
+    assert not mp.get_backend().gpu_capable
+    with pytest.raises(RuntimeError):
+        with mp.use_backend("hip"):
+            raise RuntimeError("boom")
+    assert not mp.get_backend().gpu_capable  # restored after an exception
+    a = np.arange(3.0)
+    b = mp.get_backend()
+    assert b.clip(a, 0.5, 1.5) is not a and a[0] == 0.0  # primitives never mutate their inputs
+    assert b.to_numpy(b.asarray([1, 2])).dtype.kind == "i" and b.is_backend_array(a)
+
+
+# ----------------------------------------------------------------------------- kernel registry / routing
+def test_kernel_registry_semantics():
+    """reference tests/test_cuda_kernels_cpu.py:50-118."""
+    names = registry._KERNEL_REGISTRY.names()
+    for v in ("auto", "auto_tune", "standard", "vectorized", "memory_optimized", "warp_optimized", "cache_friendly"):
+        assert f"trajectory.{v}" in names
+    for n in ("trajectory.batch", "dynamics.inverse_trajectory", "dynamics.fused_trajectory_inverse", "kinematics.fk_jacobian"):
+        assert n in names
+    with pytest.raises(KeyError, match="Available kernels: dynamics.fused_trajectory_inverse"):
+        mp.get_registered_kernel("trajectory.nope")
+    entry = mp.get_registered_kernel("trajectory.standard")
+    with pytest.raises(ValueError, match="already registered"):
+        registry._KERNEL_REGISTRY.register(entry)
+    with pytest.raises(TypeError):
+        entry.metadata["variant"] = "x"  # read-only metadata
+    with pytest.raises(Exception):
+        entry.name = "other"  # frozen record
+    assert entry.metadata["family"] == "trajectory" and entry.launch_config(1000) == ((4,), (256,))
+
+
+def test_routing_predicate_and_execute(monkeypatch):
+    """GPU launcher iff physical probe AND backend.gpu_capable, read live
+    (reference registry.py:85-89, :729-732; tests/test_backend_dispatch.py:2545-2663)."""
+    calls = []
+    reg = registry.KernelRegistry()
+    reg.register(registry.KernelRegistration("t.op", "sym", registry._grid_1d, None, lambda *a: calls.append("gpu") or "G",
+                                             lambda *a: calls.append("cpu") or "C", {"family": "t"}))
+    monkeypatch.setattr(registry, "_probe_result", True)
+    assert registry._hip_routing_enabled() is False          # numpy backend active
+    assert reg.execute("t.op") == "C"
+    with mp.use_backend("hip"):
+        assert registry._hip_routing_enabled() is True
+        assert reg.execute("t.op") == "G"
+        assert registry._hip_routing_enabled(False) is False  # explicit physical override
+    monkeypatch.setattr(registry, "_probe_result", False)
+    with mp.use_backend("hip"):
+        assert reg.execute("t.op") == "C"
+    assert calls == ["cpu", "gpu", "cpu"]
+
+
+def test_gpu_launcher_errors_propagate(monkeypatch):
+    """No silent CPU recompute: a failing GPU launch surfaces (deliberate difference from
+    reference trajectory_kernels.py:1083-1086)."""
+    if _hip.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    sm, dyn, lim = mp.load_robot("ur5")
+    pl = mp.OptimizedTrajectoryPlanning(sm, None, dyn, lim, cuda_threshold=1)  # NumPy backend: CPU routing
+    monkeypatch.setattr(registry, "_probe_result", True)  # pretend the probe saw a GPU
+    with mp.use_backend("hip"):
+        with pytest.raises(_hip.HipUnavailableError):  # the constructor asks the device for its properties
+            mp.OptimizedTrajectoryPlanning(sm, None, dyn, lim)
+        pl._physical_cuda = True  # backend switched after construction: routing is re-read live
+        assert pl._should_use_gpu(100, 6)
+        with pytest.raises((_hip.HipUnavailableError, _hip.HipError)):
+            pl.joint_trajectory(np.zeros(6), np.ones(6), 1.0, 100, 5)
+        assert pl.performance_stats["cpu_calls"] == 0 and pl.performance_stats["gpu_calls"] == 0
+
+
+# ----------------------------------------------------------------------------- planner on the NumPy backend
+def test_planner_numpy_backend_config0():
+    """BASELINE config 0: UR5 quintic joint_trajectory N=1000 on the NumPy CPU backend (plumbing)."""
+    z = np.load(golden_path("trajectory_ur5.npz"))
+    sm, dyn, lim = mp.load_robot("ur5")
+    pl = mp.OptimizedTrajectoryPlanning(sm, "ur5.urdf", dyn, lim.tolist(), use_cuda=False)
+    assert pl.joint_limits.dtype == np.float32 and np.isinf(pl.torque_limits).all()
+    assert not pl._should_use_gpu(10**9, 6)
+    r = pl.joint_trajectory(z["start"], z["end"], 2.0, 1000, 5)
+    o = ref.joint_trajectory(lim, z["start"], z["end"], 2.0, 1000, 5)
+    for k in ("positions", "velocities", "accelerations"):
+        assert r[k].dtype == np.float32 and r[k].shape == (1000, 6)
+        np.testing.assert_array_equal(r[k], o[k])
+        np.testing.assert_allclose(r[k], z[f"jt_q1000_{k}"], rtol=3e-7, atol=1e-6)
+    # endpoints / zero boundary derivatives (reference tests/test_cuda_kernels_cpu.py:227-261)
+    np.testing.assert_allclose(r["positions"][0], z["start"], atol=1e-6)
+    np.testing.assert_allclose(r["positions"][-1], z["end"], atol=1e-6)
+    assert np.abs(r["velocities"][[0, -1]]).max() < 1e-6 and np.abs(r["accelerations"][[0, -1]]).max() < 1e-5
+    # clip to limits (reference tests/test_path_planning_unit.py:86-123)
+    c = pl.joint_trajectory(z["start"], z["jt_clip_end"], 1.0, 32, 5)
+    np.testing.assert_allclose(c["positions"], z["jt_clip_positions"], rtol=3e-7, atol=1e-6)
+    b = pl.batch_joint_trajectory(z["batch_start"], z["batch_end"], 2.0, 16, 5)
+    np.testing.assert_allclose(b["positions"], z["batch_positions"], rtol=3e-7, atol=1e-6)
+    assert pl.batch_joint_trajectory(np.zeros((0, 6)), np.zeros((0, 6)), 1.0, 4, 5)["positions"].shape == (0, 4, 6)
+    assert pl.performance_stats["cpu_calls"] == 3 and pl.performance_stats["gpu_calls"] == 0
+    v, a, j = pl.calculate_derivatives(r["positions"], 0.002)
+    assert v.shape == (999, 6) and a.shape == (998, 6) and j.shape == (997, 6)
+    with pytest.raises(mp.BackendNotSupportedError):
+        pl.inverse_dynamics_trajectory(r["positions"], r["velocities"], r["accelerations"])
+    with pytest.raises(KeyError):
+        with mp.use_backend("hip"):
+            registry._reset_probe_for_tests(True)
+            try:
+                p2 = mp.OptimizedTrajectoryPlanning.__new__(mp.OptimizedTrajectoryPlanning)
+                p2.__dict__.update(pl.__dict__); p2._forced_cpu = False; p2._physical_cuda = True; p2.cpu_threshold = 1
+                p2.joint_trajectory(z["start"], z["end"], 2.0, 10, 5, kernel_type="bogus")
+            finally:
+                registry._reset_probe_for_tests(None)
+
+
+# ----------------------------------------------------------------------------- sharding
+def test_shard_ranges_cover_exactly():
+    for total in (0, 1, 7, 4096, 4099):
+        for world in (1, 2, 3, 8):
+            spans = [sharding.shard_range(total, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        sharding.shard_range(4, 2, 2)
+
+
+def test_two_process_gloo_shard_and_gather(tmp_path):
+    """world_size = 2 over gloo on the CPU: each rank generates its shard of a batch trajectory on the
+    NumPy path, the all-gather reassembles the full (B, N, n) history in rank order."""
+    worker = os.path.join(ROOT, "tests", "_dist_worker.py")
+    out = tmp_path / "result.npz"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", PYTHONPATH=ROOT, MANIPULAPY_FORCE_CPU="1")
+    port = 29500 + (os.getpid() % 400)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), worker, str(out)]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    z = np.load(out)
+    np.testing.assert_array_equal(z["gathered"], z["single"])
+    assert z["world"] == 2 and abs(float(z["max_val"]) - 1.0) < 1e-12
