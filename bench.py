@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="multi-GPU: skip the all-gather (compute-only figure)")
+    ap.add_argument("--B", type=int, default=0, help="experiments only: override the config's trajectories per GPU")
+    ap.add_argument("--N", type=int, default=0, help="experiments only: override the config's timesteps")
     args = ap.parse_args()
 
     from manipulapy_amd import _hip, robots, sharding
@@ -87,7 +89,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     hg = sharding.HostGather(info)  # gloo; no-op for a single process
 
-    cfg = CONFIGS[args.config]
+    cfg = dict(CONFIGS[args.config])
+    if args.B or args.N:
+        cfg["B"], cfg["N"] = args.B or cfg["B"], args.N or cfg["N"]
+        cfg["desc"] += f" [OVERRIDDEN: B={cfg['B']} N={cfg['N']}]"
     t = robots.robot_tables(cfg["robot"])
     n = t["S_list"].shape[1]
     B, N = cfg["B"], cfg["N"]

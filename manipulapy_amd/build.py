@@ -31,13 +31,16 @@ def _stale(target: str, deps: list[str]) -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, variant: str = "", defines: tuple = ()) -> str:
+    """`variant` / `defines` build an experimental copy (libmanipula_hip_<variant>.so with -D flags) for
+    A/B measurements: select it at run time with MANIPULAPY_HIP_LIB=<path>."""
     hipcc = _hipcc()
-    objdir = os.path.join(PKG, "build")
+    objdir = os.path.join(PKG, "build" + (f"_{variant}" if variant else ""))
+    lib = LIB if not variant else os.path.join(PKG, f"libmanipula_hip_{variant}.so")
     os.makedirs(objdir, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     common = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
-              "-ffp-contract=fast", "-fno-slp-vectorize"]
+              "-ffp-contract=fast", "-fno-slp-vectorize"] + [f"-D{d}" for d in defines]
     objs = []
     for src in SOURCES:
         path = os.path.join(CSRC, src)
@@ -48,13 +51,18 @@ def build(force: bool = False, verbose: bool = True) -> str:
             if verbose:
                 print("[build]", " ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)
-    if force or _stale(LIB, objs):
-        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs + ["-ldl"]
+    if force or _stale(lib, objs):
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib] + objs + ["-ldl"]
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    args = [a for a in sys.argv[1:] if a != "--force"]
+    variant = ""
+    if "--variant" in args:
+        variant = args[args.index("--variant") + 1]
+    defs = tuple(a[2:] for a in args if a.startswith("-D"))
+    print(build(force="--force" in sys.argv, variant=variant, defines=defs))

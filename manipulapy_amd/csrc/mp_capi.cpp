@@ -3,7 +3,9 @@
 // model handles, argument validation and the host-pointer convenience wrappers.
 #include <hip/hip_runtime_api.h>
 
+#include <atomic>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -21,10 +23,13 @@ struct mp_ctx {
   hipStream_t copy = nullptr;
   std::map<size_t, std::vector<void*>> free_by_size;  // pool: exact-size free lists
   std::map<void*, size_t> live;                        // every buffer handed out -> its size
+  std::map<uint64_t, void*> dev_models;                // model uid -> float32 model resident on this device
+  int compute_units = 0;
 };
 struct mp_model {
   MpModel<double> d;
   MpModel<float> f;
+  uint64_t uid;  // never reused, so a context's device copies cannot alias a destroyed model
 };
 struct mp_event {
   hipEvent_t ev = nullptr;
@@ -94,6 +99,49 @@ struct Scratch {
 #define D2H(dst, src, bytes) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->compute))
 
 
+// float32 model resident in device memory (read by the persistent kernels with scalar loads)
+int device_model(mp_ctx* ctx, const mp_model* model, const MpModel<float>** out) {
+  auto it = ctx->dev_models.find(model->uid);
+  if (it == ctx->dev_models.end()) {
+    void* d = nullptr;
+    if (int rc = mp_malloc(ctx, sizeof(MpModel<float>), &d)) return rc;
+    HIP_TRY(hipMemcpy(d, &model->f, sizeof(MpModel<float>), hipMemcpyHostToDevice));
+    it = ctx->dev_models.emplace(model->uid, d).first;
+  }
+  *out = static_cast<const MpModel<float>*>(it->second);
+  return MP_OK;
+}
+
+// MANIPULAPY_HIP_PERSIST = blocks per CU of the persistent float32 kernel (0 = plain one-shot kernel)
+int persist_blocks_per_cu() {
+  static const int v = [] { const char* e = getenv("MANIPULAPY_HIP_PERSIST"); return e ? atoi(e) : 0; }();
+  return v;
+}
+
+int launch_id(mp_ctx* ctx, const mp_model* model, const MpCall<double>& c, bool ftip, const double* q, const double* qd,
+              const double* qdd, double* tau, long rows) {
+  HIP_TRY(mpk_id<double>(ctx->compute, model->d, c, ftip, q, qd, qdd, tau, rows));
+  return MP_OK;
+}
+int launch_id(mp_ctx* ctx, const mp_model* model, const MpCall<float>& c, bool ftip, const float* q, const float* qd,
+              const float* qdd, float* tau, long rows) {
+  const int per_cu = persist_blocks_per_cu();
+  const long pairs = rows / 2;
+  const long blocks = (long)per_cu * ctx->compute_units;
+  if (per_cu > 0 && pairs > blocks * 256) {  // enough work for every resident lane to loop
+    const MpModel<float>* dm = nullptr;
+    if (int rc = device_model(ctx, model, &dm)) return rc;
+    HIP_TRY(mpk_id_f32_persist(ctx->compute, dm, model->d.n, c, ftip, q, qd, qdd, tau, pairs, (int)blocks));
+    const long done = 2 * pairs;
+    if (done == rows) return MP_OK;
+    const long off = done * model->d.n;
+    HIP_TRY(mpk_id<float>(ctx->compute, model->f, c, ftip, q + off, qd + off, qdd + off, tau + off, rows - done));
+    return MP_OK;
+  }
+  HIP_TRY(mpk_id<float>(ctx->compute, model->f, c, ftip, q, qd, qdd, tau, rows));
+  return MP_OK;
+}
+
 // template bodies shared by the f32 / f64 entry points (C++ linkage)
 template <typename T>
 static int id_impl(const char* fn, mp_ctx* ctx, const mp_model* model, const T* d_q, const T* d_qd, const T* d_qdd,
@@ -107,8 +155,7 @@ static int id_impl(const char* fn, mp_ctx* ctx, const mp_model* model, const T* 
           "%s: device pointers must be 16-byte aligned", fn);
   MpCall<T> c;
   make_call<T>(model, g, Ftip, &c);
-  HIP_TRY(mpk_id<T>(ctx->compute, pick<T>(model), c, any_nonzero(Ftip), d_q, d_qd, d_qdd, d_tau, (long)rows));
-  return MP_OK;
+  return launch_id(ctx, model, c, any_nonzero(Ftip), d_q, d_qd, d_qdd, d_tau, (long)rows);
 }
 
 template <typename T>
@@ -180,6 +227,10 @@ int mp_ctx_create(int device_id, mp_ctx** out) {
   mp_ctx* c = new (std::nothrow) mp_ctx;
   REQUIRE(c, "mp_ctx_create: out of host memory");
   c->device = device_id;
+  {
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device_id) == hipSuccess) c->compute_units = p.multiProcessorCount;
+  }
   hipError_t e = hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking);
   if (e != hipSuccess) { delete c; return hip_err(e, "hipStreamCreate"); }
@@ -354,6 +405,8 @@ int mp_model_create(int n, const double* S, const double* Mcom, const double* G,
     return set_err(MP_ERR_MODEL, "mp_model_create: %s", msg);
   }
   mp_model_cast(m->d, &m->f);
+  static std::atomic<uint64_t> next_uid{1};
+  m->uid = next_uid.fetch_add(1);
   *out = m;
   return MP_OK;
 }

@@ -26,6 +26,36 @@
 #define MP_HD inline
 #endif
 
+// ----------------------------------------------------------------------------- arithmetic types
+// The per-row math is written once for an arithmetic type T and a scalar type S = MpTraits<T>::S that
+// the wave-uniform model constants use:
+//   T = float / double : one row per lane;
+//   T = mp_f2 (2 x float): TWO rows per lane, so that every operation becomes a packed
+//       v_pk_{fma,mul,add}_f32 — on gfx950 a scalar v_fma_f32 and a v_pk_fma_f32 occupy the SIMD for
+//       the same ~4.5 cycles per wave-instruction (profiles/r01_ubench_valu.txt), so packing doubles
+//       the float32 rate (70 -> 130 TFLOP/s measured).
+#if defined(__clang__)
+#define MP_HAS_PACKED 1
+typedef float mp_f2 __attribute__((ext_vector_type(2)));
+typedef int mp_i2 __attribute__((ext_vector_type(2)));
+#endif
+
+template <typename T> struct MpTraits;
+template <> struct MpTraits<float> {
+  using S = float;
+  static MP_HD float splat(float v) { return v; }
+};
+template <> struct MpTraits<double> {
+  using S = double;
+  static MP_HD double splat(double v) { return v; }
+};
+#if MP_HAS_PACKED
+template <> struct MpTraits<mp_f2> {
+  using S = float;
+  static MP_HD mp_f2 splat(float v) { return (mp_f2){v, v}; }
+};
+#endif
+
 // ------------------------------------------------------------------------------------------- trig
 // float: Cody-Waite reduction by pi/2 (two FMAs, exact enough for |x| < ~1e4) + the classic minimax
 // polynomials on [-pi/4, pi/4]; ~1 ulp, branch-free, ~24 VALU instructions for BOTH results.
@@ -54,17 +84,48 @@ MP_HD void mp_sincos(double x, double& s, double& c) {
   c = std::cos(x);
 #endif
 }
+#if MP_HAS_PACKED
+// the same algorithm on two rows at once (packed FMAs; rint / cvt / selects stay per component)
+MP_HD void mp_sincos(mp_f2 x, mp_f2& s, mp_f2& c) {
+  const mp_f2 k = __builtin_elementwise_rint(x * 0.636619772367581343f);
+  mp_f2 r = __builtin_elementwise_fma(-k, (mp_f2)(1.57079637050628662109375f), x);
+  r = __builtin_elementwise_fma(-k, (mp_f2)(-4.37113900018624283e-8f), r);
+  const mp_f2 r2 = r * r;
+  mp_f2 ps = __builtin_elementwise_fma(r2, (mp_f2)(-1.9515295891e-4f), (mp_f2)(8.3321608736e-3f));
+  ps = __builtin_elementwise_fma(r2, ps, (mp_f2)(-1.6666654611e-1f));
+  ps = __builtin_elementwise_fma(r * r2, ps, r);
+  mp_f2 pc = __builtin_elementwise_fma(r2, (mp_f2)(2.443315711809948e-5f), (mp_f2)(-1.388731625493765e-3f));
+  pc = __builtin_elementwise_fma(r2, pc, (mp_f2)(4.166664568298827e-2f));
+  pc = __builtin_elementwise_fma(r2 * r2, pc, __builtin_elementwise_fma(r2, (mp_f2)(-0.5f), (mp_f2)(1.0f)));
+  const mp_i2 q = __builtin_convertvector(k, mp_i2);
+  const mp_i2 odd = (q & 1) != 0;
+  const mp_f2 a = odd ? pc : ps;
+  const mp_f2 b = odd ? ps : pc;
+  s = ((q & 2) != 0) ? -a : a;
+  c = (((q + 1) & 2) != 0) ? -b : b;
+}
+#endif
 
-template <typename T> MP_HD T mp_min(T a, T b) { return a < b ? a : b; }
-template <typename T> MP_HD T mp_max(T a, T b) { return a > b ? a : b; }
-template <typename T> MP_HD T mp_clip(T v, T lo, T hi) { return mp_min(mp_max(v, lo), hi); }  // np.clip order
+MP_HD float mp_min(float a, float b) { return a < b ? a : b; }
+MP_HD float mp_max(float a, float b) { return a > b ? a : b; }
+MP_HD double mp_min(double a, double b) { return a < b ? a : b; }
+MP_HD double mp_max(double a, double b) { return a > b ? a : b; }
+#if MP_HAS_PACKED
+MP_HD mp_f2 mp_min(mp_f2 a, mp_f2 b) { return (a < b) ? a : b; }
+MP_HD mp_f2 mp_max(mp_f2 a, mp_f2 b) { return (a > b) ? a : b; }
+#endif
+// np.clip order: max with the lower bound first, then min with the upper bound
+template <typename T>
+MP_HD T mp_clip(T v, typename MpTraits<T>::S lo, typename MpTraits<T>::S hi) {
+  return mp_min(mp_max(v, MpTraits<T>::splat(lo)), MpTraits<T>::splat(hi));
+}
 
 // ------------------------------------------------------------------------------ axis-aligned steps
 // Motion vector (w, v), parent -> child coordinates, child pose in parent = (E, r):
 //     w' = E^T w,  v' = E^T (v + w x r).
 // step A: E = Rx(alpha), r = (a, 0, 0);   step B: E = Rz(theta), r = (0, 0, d).
-template <typename T>
-MP_HD void mp_motion_A(T ca, T sa, T a, T& wx, T& wy, T& wz, T& vx, T& vy, T& vz) {
+template <typename T, typename S>
+MP_HD void mp_motion_A(S ca, S sa, S a, T& wx, T& wy, T& wz, T& vx, T& vy, T& vz) {
   const T ty = vy + a * wz, tz = vz - a * wy;
   vy = ca * ty + sa * tz;
   vz = ca * tz - sa * ty;
@@ -84,8 +145,8 @@ MP_HD void mp_motion_B(T c, T s, T d, T& wx, T& wy, T& wz, T& vx, T& vy, T& vz) 
   (void)wz; (void)vz;
 }
 // Force vector (n, f), parent -> child coordinates:  f' = E^T f,  n' = E^T (n - r x f).
-template <typename T>
-MP_HD void mp_force_down_A(T ca, T sa, T a, T& nx, T& ny, T& nz, T& fx, T& fy, T& fz) {
+template <typename T, typename S>
+MP_HD void mp_force_down_A(S ca, S sa, S a, T& nx, T& ny, T& nz, T& fx, T& fy, T& fz) {
   const T ty = ny + a * fz, tz = nz - a * fy;
   ny = ca * ty + sa * tz;
   nz = ca * tz - sa * ty;
@@ -114,8 +175,8 @@ MP_HD void mp_force_up_B(T c, T s, T d, T& nx, T& ny, T& nz, T& fx, T& fy, T& fz
   ny = my + d * gx;
   (void)nz; (void)fz;
 }
-template <typename T>
-MP_HD void mp_force_up_A(T ca, T sa, T a, T& nx, T& ny, T& nz, T& fx, T& fy, T& fz) {
+template <typename T, typename S>
+MP_HD void mp_force_up_A(S ca, S sa, S a, T& nx, T& ny, T& nz, T& fx, T& fy, T& fz) {
   const T gy = ca * fy - sa * fz, gz = sa * fy + ca * fz;
   const T my = ca * ny - sa * nz, mz = sa * ny + ca * nz;
   fy = gy; fz = gz;
@@ -131,11 +192,13 @@ struct MpJointState {
   T s[N], c[N], d[N];
 };
 
-template <typename T, int N>
-MP_HD void mp_joint_state(const MpModel<T>& M, const T (&q)[N], MpJointState<T, N>& js) {
+// `MT` is any view of an MpModel<S>: the by-value kernarg struct, or the same struct behind a
+// constant-address-space pointer (persistent kernels re-read it with scalar loads every iteration).
+template <typename T, int N, typename MT>
+MP_HD void mp_joint_state(const MT& M, const T (&q)[N], MpJointState<T, N>& js) {
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    const MpJoint<T>& J = M.j[i];
+    const auto& J = M.j[i];
     const T qr = J.rev * q[i];
     mp_sincos(J.off + qr, js.s[i], js.c[i]);
     js.d[i] = J.d + (q[i] - qr);
@@ -143,19 +206,25 @@ MP_HD void mp_joint_state(const MpModel<T>& M, const T (&q)[N], MpJointState<T, 
 }
 
 // Recursive Newton-Euler in the compiled link frames.  tau is NOT clipped here.
-template <typename T, int N, bool HAS_FTIP>
-MP_HD void mp_rnea(const MpModel<T>& M, const MpCall<T>& C, const MpJointState<T, N>& js, const T (&qd)[N],
-                   const T (&qdd)[N], T (&tau)[N]) {
+template <typename T, int N, bool HAS_FTIP, typename MT>
+MP_HD void mp_rnea(const MT& M, const MpCall<typename MpTraits<T>::S>& C,
+                   const MpJointState<T, N>& js, const T (&qd)[N], const T (&qdd)[N], T (&tau)[N]) {
+  using S = typename MpTraits<T>::S;
+  using TR = MpTraits<T>;
+  const T zero = TR::splat(S(0));
   T fnx[N], fny[N], fnz[N], ffx[N], ffy[N], ffz[N];
-  T wx = 0, wy = 0, wz = 0, vx = 0, vy = 0, vz = 0;
-  T dwx = 0, dwy = 0, dwz = 0, dvx = C.a0[0], dvy = C.a0[1], dvz = C.a0[2];
-  T tnx = 0, tny = 0, tnz = 0, tfx = 0, tfy = 0, tfz = 0;
-  if (HAS_FTIP) { tnx = C.F1n[0]; tny = C.F1n[1]; tnz = C.F1n[2]; tfx = C.F1f[0]; tfy = C.F1f[1]; tfz = C.F1f[2]; }
+  T wx = zero, wy = zero, wz = zero, vx = zero, vy = zero, vz = zero;
+  T dwx = zero, dwy = zero, dwz = zero, dvx = TR::splat(C.a0[0]), dvy = TR::splat(C.a0[1]), dvz = TR::splat(C.a0[2]);
+  T tnx = zero, tny = zero, tnz = zero, tfx = zero, tfy = zero, tfz = zero;
+  if (HAS_FTIP) {
+    tnx = TR::splat(C.F1n[0]); tny = TR::splat(C.F1n[1]); tnz = TR::splat(C.F1n[2]);
+    tfx = TR::splat(C.F1f[0]); tfy = TR::splat(C.F1f[1]); tfz = TR::splat(C.F1f[2]);
+  }
 
   // forward pass: twists, accelerations, body wrenches
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    const MpJoint<T>& J = M.j[i];
+    const auto& J = M.j[i];
     if (i > 0) {
       mp_motion_A(J.ca, J.sa, J.a, wx, wy, wz, vx, vy, vz);
       mp_motion_A(J.ca, J.sa, J.a, dwx, dwy, dwz, dvx, dvy, dvz);
@@ -201,8 +270,8 @@ MP_HD void mp_rnea(const MpModel<T>& M, const MpCall<T>& C, const MpJointState<T
   // backward pass
 #pragma unroll
   for (int i = N - 1; i >= 0; --i) {
-    const MpJoint<T>& J = M.j[i];
-    tau[i] = J.rev * fnz[i] + (T(1) - J.rev) * ffz[i];
+    const auto& J = M.j[i];
+    tau[i] = J.rev * fnz[i] + (S(1) - J.rev) * ffz[i];
     if (i > 0) {
       T nx = fnx[i], ny = fny[i], nz = fnz[i], fx = ffx[i], fy = ffy[i], fz = ffz[i];
       mp_force_up_B(js.c[i], js.s[i], js.d[i], nx, ny, nz, fx, fy, fz);
@@ -217,16 +286,18 @@ MP_HD void mp_rnea(const MpModel<T>& M, const MpCall<T>& C, const MpJointState<T
 // T (4x4 row-major) = prod T_{i-1,i}(q_i) . tool ;  J (6 x N row-major), column i = [z_i ; o_i x z_i]
 // (revolute) or [0 ; z_i] (prismatic), z_i / o_i = axis / origin of link frame i in the space frame —
 // identical to Ad(prod_{j<i} exp) S_i because link frame i's z axis IS joint axis i.
-template <typename T, int N, bool WANT_J>
-MP_HD void mp_fk_jac(const MpModel<T>& M, const MpJointState<T, N>& js, T* Tout, T* Jout) {
+template <typename T, int N, bool WANT_J, typename MT>
+MP_HD void mp_fk_jac(const MT& M, const MpJointState<T, N>& js, T* Tout, T* Jout) {
+  using S = typename MpTraits<T>::S;
+  using TR = MpTraits<T>;
   // columns of R and origin p of the running frame
-  T x0 = M.base_R[0], x1 = M.base_R[3], x2 = M.base_R[6];
-  T y0 = M.base_R[1], y1 = M.base_R[4], y2 = M.base_R[7];
-  T z0 = M.base_R[2], z1 = M.base_R[5], z2 = M.base_R[8];
-  T p0 = M.base_p[0], p1 = M.base_p[1], p2 = M.base_p[2];
+  T x0 = TR::splat(M.base_R[0]), x1 = TR::splat(M.base_R[3]), x2 = TR::splat(M.base_R[6]);
+  T y0 = TR::splat(M.base_R[1]), y1 = TR::splat(M.base_R[4]), y2 = TR::splat(M.base_R[7]);
+  T z0 = TR::splat(M.base_R[2]), z1 = TR::splat(M.base_R[5]), z2 = TR::splat(M.base_R[8]);
+  T p0 = TR::splat(M.base_p[0]), p1 = TR::splat(M.base_p[1]), p2 = TR::splat(M.base_p[2]);
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    const MpJoint<T>& J = M.j[i];
+    const auto& J = M.j[i];
     if (i > 0) {  // . Rx(alpha) Tx(a)
       p0 += J.a * x0; p1 += J.a * x1; p2 += J.a * x2;
       const T a0 = y0, a1 = y1, a2 = y2;
@@ -236,7 +307,7 @@ MP_HD void mp_fk_jac(const MpModel<T>& M, const MpJointState<T, N>& js, T* Tout,
     if (WANT_J) {  // the joint axis is fixed in the PARENT link: read it before the joint moves the frame
       // revolute: [z ; p x z] with p any point of the axis (the frame origin before Tz is on it)
       const T cx = p1 * z2 - p2 * z1, cy = p2 * z0 - p0 * z2, cz = p0 * z1 - p1 * z0;
-      const T r = J.rev, pr = T(1) - J.rev;
+      const S r = J.rev, pr = S(1) - J.rev;
       Jout[0 * N + i] = r * z0; Jout[1 * N + i] = r * z1; Jout[2 * N + i] = r * z2;
       Jout[3 * N + i] = r * cx + pr * z0; Jout[4 * N + i] = r * cy + pr * z1; Jout[5 * N + i] = r * cz + pr * z2;
     }
@@ -247,15 +318,15 @@ MP_HD void mp_fk_jac(const MpModel<T>& M, const MpJointState<T, N>& js, T* Tout,
     y0 = c * y0 - s * b0; y1 = c * y1 - s * b1; y2 = c * y2 - s * b2;
     p0 += d * z0; p1 += d * z1; p2 += d * z2;
   }
-  const T* R = M.tool_R;
-  const T* t = M.tool_p;
+  const auto& R = M.tool_R;
+  const auto& t = M.tool_p;
   Tout[0] = x0 * R[0] + y0 * R[3] + z0 * R[6]; Tout[1] = x0 * R[1] + y0 * R[4] + z0 * R[7]; Tout[2] = x0 * R[2] + y0 * R[5] + z0 * R[8];
   Tout[4] = x1 * R[0] + y1 * R[3] + z1 * R[6]; Tout[5] = x1 * R[1] + y1 * R[4] + z1 * R[7]; Tout[6] = x1 * R[2] + y1 * R[5] + z1 * R[8];
   Tout[8] = x2 * R[0] + y2 * R[3] + z2 * R[6]; Tout[9] = x2 * R[1] + y2 * R[4] + z2 * R[7]; Tout[10] = x2 * R[2] + y2 * R[5] + z2 * R[8];
   Tout[3] = p0 + x0 * t[0] + y0 * t[1] + z0 * t[2];
   Tout[7] = p1 + x1 * t[0] + y1 * t[1] + z1 * t[2];
   Tout[11] = p2 + x2 * t[0] + y2 * t[1] + z2 * t[2];
-  Tout[12] = 0; Tout[13] = 0; Tout[14] = 0; Tout[15] = 1;
+  Tout[12] = TR::splat(S(0)); Tout[13] = TR::splat(S(0)); Tout[14] = TR::splat(S(0)); Tout[15] = TR::splat(S(1));
 }
 
 // ------------------------------------------------------------------------------------ time scaling

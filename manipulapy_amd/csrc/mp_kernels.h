@@ -19,3 +19,8 @@ hipError_t mpk_traj_id(hipStream_t s, const MpModel<float>& M, const MpCall<floa
 template <typename T>
 hipError_t mpk_fk_jac_id(hipStream_t s, const MpModel<T>& M, const MpCall<T>& C, bool ftip, const T* q, const T* qd,
                          const T* qdd, T* Tout, T* Jout, T* tau, long rows);
+
+// float32 persistent / prefetching form of the inverse-dynamics kernel: `pairs` row pairs (2 rows per
+// lane), model resident in device memory, fixed grid of `blocks` x 256 threads.
+hipError_t mpk_id_f32_persist(hipStream_t s, const MpModel<float>* d_model, int n, const MpCall<float>& C, bool ftip,
+                              const float* q, const float* qd, const float* qdd, float* tau, long pairs, int blocks);

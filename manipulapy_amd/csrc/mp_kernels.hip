@@ -8,12 +8,20 @@
 // No MFMA: there is no dense contraction on this path (BASELINE.json north_star).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "mp_core.h"
 #include "mp_kernels.h"
 
 namespace {
 
 constexpr int kBlock = 256;
+#ifndef MP_PK_BLOCK
+#define MP_PK_BLOCK 256  // threads per block of the packed kernels (no LDS / barriers: any multiple of 64 works)
+#endif
+#ifndef MP_PK_MINW
+#define MP_PK_MINW 2  // min waves per SIMD requested for the packed kernels (register cap = 512 / MINW)
+#endif
 
 // ---- widest legal vector type for a run of COUNT elements of T whose start is COUNT*sizeof(T)-strided
 template <typename T, int BYTES> struct VecOf;
@@ -117,9 +125,10 @@ __global__ __launch_bounds__(kBlock) void k_batch_traj(const MpModel<float> M, c
 template <int N, bool HAS_FTIP>
 __global__ __launch_bounds__(kBlock) void k_traj_id(const MpModel<float> M, const MpCall<float> C,
                                                     const float* __restrict__ start, const float* __restrict__ end,
-                                                    long B, long Nt, double Tf, int method, float* __restrict__ tau) {
-  const long r = (long)blockIdx.x * kBlock + threadIdx.x;
-  if (r >= B * Nt) return;
+                                                    long row0, long rows, long Nt, double Tf, int method,
+                                                    float* __restrict__ tau) {
+  const long r = row0 + (long)blockIdx.x * kBlock + threadIdx.x;
+  if (r >= rows) return;
   const long b = r / Nt, t = r - b * Nt;
   float p[N], v[N], a[N], tq[N];
   traj_row<N>(M, start, end, b, t, Nt, Tf, method, p, v, a);
@@ -129,6 +138,110 @@ __global__ __launch_bounds__(kBlock) void k_traj_id(const MpModel<float> M, cons
 #pragma unroll
   for (int j = 0; j < N; ++j) tq[j] = mp_clip(tq[j], M.taumin[j], M.taumax[j]);
   RunIO<float, N>::store(tau, r, tq);
+}
+
+// ------------------------------------------------- float32, two rows per lane (packed v_pk_* math)
+// Lane t owns rows 2t and 2t+1 — one contiguous 2*N*4-byte run per array, so the loads/stores are
+// also twice as wide per lane.  The launcher sends an odd trailing row to the one-row-per-lane kernel.
+template <int N>
+__device__ __forceinline__ void load_pair(const float* __restrict__ base, long pair, mp_f2 (&v)[N]) {
+  float f[2 * N];
+  RunIO<float, 2 * N>::load(base, pair, f);
+#pragma unroll
+  for (int j = 0; j < N; ++j) v[j] = (mp_f2){f[j], f[N + j]};
+}
+template <int N>
+__device__ __forceinline__ void store_pair(float* __restrict__ base, long pair, const mp_f2 (&v)[N]) {
+  float f[2 * N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) { f[j] = v[j].x; f[N + j] = v[j].y; }
+  RunIO<float, 2 * N>::store(base, pair, f);
+}
+
+template <int N, bool HAS_FTIP>
+__global__ __launch_bounds__(MP_PK_BLOCK, MP_PK_MINW) void k_id_pk(const MpModel<float> M, const MpCall<float> C,
+                                                     const float* __restrict__ q, const float* __restrict__ qd,
+                                                     const float* __restrict__ qdd, float* __restrict__ tau, long pairs) {
+  const long p = (long)blockIdx.x * MP_PK_BLOCK + threadIdx.x;
+  if (p >= pairs) return;
+  mp_f2 a[N], b[N], c[N], t[N];
+  load_pair<N>(q, p, a);
+  load_pair<N>(qd, p, b);
+  load_pair<N>(qdd, p, c);
+  MpJointState<mp_f2, N> js;
+  mp_joint_state<mp_f2, N>(M, a, js);
+  mp_rnea<mp_f2, N, HAS_FTIP>(M, C, js, b, c, t);
+#pragma unroll
+  for (int j = 0; j < N; ++j) t[j] = mp_clip(t[j], M.taumin[j], M.taumax[j]);
+  store_pair<N>(tau, p, t);
+}
+
+// Persistent form of k_id_pk: a fixed grid walks the pairs with a grid stride and keeps the NEXT
+// pair's 3 x 2N inputs in flight (registers) while the current pair is being computed, so the HBM
+// latency that the plain kernel exposes at the head of every wave is hidden behind ~1250 VALU
+// instructions.  The model is read through a constant-address-space pointer that is laundered every
+// iteration: without that the compiler hoists all ~100 scalar loads out of the loop and spills the
+// SGPRs through v_writelane / v_readlane (measured: +50 % VALU instructions).
+typedef const __attribute__((address_space(4))) MpModel<float> MpModelConstF;
+
+template <int N, bool HAS_FTIP>
+__global__ __launch_bounds__(kBlock, MP_PK_MINW) void k_id_pk_persist(const MpModel<float>* __restrict__ Mdev,
+                                                             const MpCall<float> C, const float* __restrict__ q,
+                                                             const float* __restrict__ qd, const float* __restrict__ qdd,
+                                                             float* __restrict__ tau, long pairs) {
+  const long stride = (long)gridDim.x * kBlock;
+  long p = (long)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= pairs) return;
+  float fa[2 * N], fb[2 * N], fc[2 * N];
+  RunIO<float, 2 * N>::load(q, p, fa);
+  RunIO<float, 2 * N>::load(qd, p, fb);
+  RunIO<float, 2 * N>::load(qdd, p, fc);
+  while (true) {
+    mp_f2 a[N], b[N], c[N], t[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) { a[j] = (mp_f2){fa[j], fa[N + j]}; b[j] = (mp_f2){fb[j], fb[N + j]}; c[j] = (mp_f2){fc[j], fc[N + j]}; }
+    const long pn = p + stride;
+    const bool more = pn < pairs;
+    if (more) {  // prefetch: these loads are only waited for at the top of the next iteration
+      RunIO<float, 2 * N>::load(q, pn, fa);
+      RunIO<float, 2 * N>::load(qd, pn, fb);
+      RunIO<float, 2 * N>::load(qdd, pn, fc);
+    }
+    MpModelConstF* Mc = (MpModelConstF*)Mdev;
+    asm volatile("" : "+s"(Mc));  // opaque to LICM / CSE: constants are (re)loaded where they are used
+    MpJointState<mp_f2, N> js;
+    mp_joint_state<mp_f2, N>(*Mc, a, js);
+    mp_rnea<mp_f2, N, HAS_FTIP>(*Mc, C, js, b, c, t);
+#pragma unroll
+    for (int j = 0; j < N; ++j) t[j] = mp_clip(t[j], Mc->taumin[j], Mc->taumax[j]);
+    store_pair<N>(tau, p, t);
+    if (!more) break;
+    p = pn;
+  }
+}
+
+template <int N, bool HAS_FTIP>
+__global__ __launch_bounds__(kBlock, MP_PK_MINW) void k_traj_id_pk(const MpModel<float> M, const MpCall<float> C,
+                                                          const float* __restrict__ start, const float* __restrict__ end,
+                                                          long pairs, long Nt, double Tf, int method, float* __restrict__ tau) {
+  const long p = (long)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= pairs) return;
+  const long r0 = 2 * p;
+  const long b0 = r0 / Nt, t0 = r0 - b0 * Nt;
+  const bool wrap = t0 + 1 >= Nt;  // the pair may straddle two trajectories
+  const long b1 = wrap ? b0 + 1 : b0, t1 = wrap ? 0 : t0 + 1;
+  float p0[N], v0[N], a0[N], p1[N], v1[N], a1[N];
+  traj_row<N>(M, start, end, b0, t0, Nt, Tf, method, p0, v0, a0);
+  traj_row<N>(M, start, end, b1, t1, Nt, Tf, method, p1, v1, a1);
+  mp_f2 qq[N], qd[N], qdd[N], tq[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) { qq[j] = (mp_f2){p0[j], p1[j]}; qd[j] = (mp_f2){v0[j], v1[j]}; qdd[j] = (mp_f2){a0[j], a1[j]}; }
+  MpJointState<mp_f2, N> js;
+  mp_joint_state<mp_f2, N>(M, qq, js);
+  mp_rnea<mp_f2, N, HAS_FTIP>(M, C, js, qd, qdd, tq);
+#pragma unroll
+  for (int j = 0; j < N; ++j) tq[j] = mp_clip(tq[j], M.taumin[j], M.taumax[j]);
+  store_pair<N>(tau, p, tq);
 }
 
 // ------------------------------------------------------------- FK + space Jacobian + ID fused
@@ -162,6 +275,15 @@ __global__ __launch_bounds__(kBlock) void k_fk_jac_id(const MpModel<T> M, const 
 
 inline unsigned grid_for(long rows) { return (unsigned)((rows + kBlock - 1) / kBlock); }
 
+// float32 variant selection (A/B switch for profiling): MANIPULAPY_HIP_F32 = "packed" (default) | "scalar"
+inline bool use_packed_f32() {
+  static const bool packed = [] {
+    const char* e = getenv("MANIPULAPY_HIP_F32");
+    return !(e && e[0] == 's');
+  }();
+  return packed;
+}
+
 #define MP_DISPATCH_N(n, ...)                                   \
   switch (n) {                                                  \
     case 1: { constexpr int N = 1; __VA_ARGS__; } break;        \
@@ -177,14 +299,49 @@ inline unsigned grid_for(long rows) { return (unsigned)((rows + kBlock - 1) / kB
 
 }  // namespace
 
+hipError_t mpk_id_f32_persist(hipStream_t s, const MpModel<float>* d_model, int n, const MpCall<float>& C, bool ftip,
+                              const float* q, const float* qd, const float* qdd, float* tau, long pairs, int blocks) {
+  if (pairs <= 0) return hipSuccess;
+  MP_DISPATCH_N(n, {
+    if (ftip) hipLaunchKernelGGL((k_id_pk_persist<N, true>), dim3(blocks), dim3(kBlock), 0, s, d_model, C, q, qd, qdd, tau, pairs);
+    else hipLaunchKernelGGL((k_id_pk_persist<N, false>), dim3(blocks), dim3(kBlock), 0, s, d_model, C, q, qd, qdd, tau, pairs);
+  })
+  return hipGetLastError();
+}
+
 hipError_t mpk_selftest(hipStream_t s, int* d_out) {
   hipLaunchKernelGGL(k_selftest, dim3(1), dim3(64), 0, s, d_out);
   return hipGetLastError();
 }
 
-template <typename T>
-hipError_t mpk_id(hipStream_t s, const MpModel<T>& M, const MpCall<T>& C, bool ftip, const T* q, const T* qd,
-                  const T* qdd, T* tau, long rows) {
+template <>
+hipError_t mpk_id<float>(hipStream_t s, const MpModel<float>& M, const MpCall<float>& C, bool ftip, const float* q,
+                         const float* qd, const float* qdd, float* tau, long rows) {
+  if (rows <= 0) return hipSuccess;
+  using T = float;
+  long done = 0;
+  if (use_packed_f32() && rows >= 2) {  // two rows per lane; an odd trailing row goes to the scalar kernel
+    const long pairs = rows / 2;
+    MP_DISPATCH_N(M.n, {
+      const unsigned gb = (unsigned)((pairs + MP_PK_BLOCK - 1) / MP_PK_BLOCK);
+      if (ftip) hipLaunchKernelGGL((k_id_pk<N, true>), dim3(gb), dim3(MP_PK_BLOCK), 0, s, M, C, q, qd, qdd, tau, pairs);
+      else hipLaunchKernelGGL((k_id_pk<N, false>), dim3(gb), dim3(MP_PK_BLOCK), 0, s, M, C, q, qd, qdd, tau, pairs);
+    })
+    done = 2 * pairs;
+    if (done == rows) return hipGetLastError();
+  }
+  const long off = done * M.n, rest = rows - done;
+  MP_DISPATCH_N(M.n, {
+    if (ftip) hipLaunchKernelGGL((k_id<T, N, true>), dim3(grid_for(rest)), dim3(kBlock), 0, s, M, C, q + off, qd + off, qdd + off, tau + off, rest);
+    else hipLaunchKernelGGL((k_id<T, N, false>), dim3(grid_for(rest)), dim3(kBlock), 0, s, M, C, q + off, qd + off, qdd + off, tau + off, rest);
+  })
+  return hipGetLastError();
+}
+
+template <>
+hipError_t mpk_id<double>(hipStream_t s, const MpModel<double>& M, const MpCall<double>& C, bool ftip, const double* q,
+                          const double* qd, const double* qdd, double* tau, long rows) {
+  using T = double;
   if (rows <= 0) return hipSuccess;
   MP_DISPATCH_N(M.n, {
     if (ftip) hipLaunchKernelGGL((k_id<T, N, true>), dim3(grid_for(rows)), dim3(kBlock), 0, s, M, C, q, qd, qdd, tau, rows);
@@ -192,10 +349,6 @@ hipError_t mpk_id(hipStream_t s, const MpModel<T>& M, const MpCall<T>& C, bool f
   })
   return hipGetLastError();
 }
-template hipError_t mpk_id<float>(hipStream_t, const MpModel<float>&, const MpCall<float>&, bool, const float*,
-                                  const float*, const float*, float*, long);
-template hipError_t mpk_id<double>(hipStream_t, const MpModel<double>&, const MpCall<double>&, bool, const double*,
-                                   const double*, const double*, double*, long);
 
 hipError_t mpk_batch_traj(hipStream_t s, const MpModel<float>& M, const float* start, const float* end, long B,
                           long Nt, double Tf, int method, float* pos, float* vel, float* acc) {
@@ -211,9 +364,20 @@ hipError_t mpk_traj_id(hipStream_t s, const MpModel<float>& M, const MpCall<floa
                        const float* end, long B, long Nt, double Tf, int method, float* tau) {
   const long rows = B * Nt;
   if (rows <= 0) return hipSuccess;
+  long done = 0;
+  if (use_packed_f32() && rows >= 2) {
+    const long pairs = rows / 2;
+    MP_DISPATCH_N(M.n, {
+      if (ftip) hipLaunchKernelGGL((k_traj_id_pk<N, true>), dim3(grid_for(pairs)), dim3(kBlock), 0, s, M, C, start, end, pairs, Nt, Tf, method, tau);
+      else hipLaunchKernelGGL((k_traj_id_pk<N, false>), dim3(grid_for(pairs)), dim3(kBlock), 0, s, M, C, start, end, pairs, Nt, Tf, method, tau);
+    })
+    done = 2 * pairs;
+    if (done == rows) return hipGetLastError();
+  }
+  const long rest = rows - done;
   MP_DISPATCH_N(M.n, {
-    if (ftip) hipLaunchKernelGGL((k_traj_id<N, true>), dim3(grid_for(rows)), dim3(kBlock), 0, s, M, C, start, end, B, Nt, Tf, method, tau);
-    else hipLaunchKernelGGL((k_traj_id<N, false>), dim3(grid_for(rows)), dim3(kBlock), 0, s, M, C, start, end, B, Nt, Tf, method, tau);
+    if (ftip) hipLaunchKernelGGL((k_traj_id<N, true>), dim3(grid_for(rest)), dim3(kBlock), 0, s, M, C, start, end, done, rows, Nt, Tf, method, tau);
+    else hipLaunchKernelGGL((k_traj_id<N, false>), dim3(grid_for(rest)), dim3(kBlock), 0, s, M, C, start, end, done, rows, Nt, Tf, method, tau);
   })
   return hipGetLastError();
 }

@@ -26,6 +26,45 @@ void run_id(const MpModel<T>& M, const MpCall<T>& C, bool ftip, long rows, const
     }
   }
 }
+#if MP_HAS_PACKED
+// two rows per "lane", exactly as k_id_pk does on the device
+template <int N>
+void run_id_packed(const MpModel<float>& M, const MpCall<float>& C, bool ftip, long rows, const double* q,
+                   const double* qd, const double* qdd, double* tau) {
+  for (long r = 0; r < rows; r += 2) {
+    const long r1 = (r + 1 < rows) ? r + 1 : r;
+    mp_f2 a[N], b[N], c[N], t[N];
+    for (int j = 0; j < N; ++j) {
+      a[j] = (mp_f2){(float)q[r * N + j], (float)q[r1 * N + j]};
+      b[j] = (mp_f2){(float)qd[r * N + j], (float)qd[r1 * N + j]};
+      c[j] = (mp_f2){(float)qdd[r * N + j], (float)qdd[r1 * N + j]};
+    }
+    MpJointState<mp_f2, N> js;
+    mp_joint_state<mp_f2, N>(M, a, js);
+    if (ftip) mp_rnea<mp_f2, N, true>(M, C, js, b, c, t);
+    else mp_rnea<mp_f2, N, false>(M, C, js, b, c, t);
+    for (int j = 0; j < N; ++j) {
+      const mp_f2 v = mp_clip(t[j], M.taumin[j], M.taumax[j]);
+      tau[r * N + j] = (double)v.x;
+      tau[r1 * N + j] = (double)((r1 == r) ? v.x : v.y);
+    }
+  }
+}
+int run_packed(const MpModel<double>& Md, const MpCall<double>& Cd, bool ftip, long rows, const double* q,
+               const double* qd, const double* qdd, double* tau) {
+  MpModel<float> M;
+  MpCall<float> C;
+  mp_model_cast(Md, &M);
+  mp_call_cast(Cd, &C);
+  switch (Md.n) {
+#define CASE(N) case N: run_id_packed<N>(M, C, ftip, rows, q, qd, qdd, tau); return 0;
+    CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
+#undef CASE
+  }
+  return 1;
+}
+#endif
+
 template <typename T>
 int run(const MpModel<double>& Md, const MpCall<double>& Cd, bool ftip, long rows, const double* q, const double* qd,
         const double* qdd, double* tau, double* Tout, double* Jout) {
@@ -57,6 +96,9 @@ extern "C" int hostsim_run(int n, const double* S, const double* Mcom, const dou
   bool ftip = false;
   if (Ftip)
     for (int k = 0; k < 6; ++k) ftip |= (Ftip[k] != 0.0);
+#if MP_HAS_PACKED
+  if (use_f32 == 2) return run_packed(Md, Cd, ftip, rows, q, qd, qdd, tau);  // float32, two rows per lane
+#endif
   return use_f32 ? run<float>(Md, Cd, ftip, rows, q, qd, qdd, tau, Tout, Jout)
                  : run<double>(Md, Cd, ftip, rows, q, qd, qdd, tau, Tout, Jout);
 }

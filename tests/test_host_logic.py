@@ -14,6 +14,8 @@ from conftest import ROBOTS, ROOT, golden_path
 from oracle import ref_numpy as ref
 
 import manipulapy_amd as mp
+
+HOST_CXX = "/opt/rocm/lib/llvm/bin/clang++"  # the packed (ext_vector_type) math needs clang
 from manipulapy_amd import _hip, registry, sharding
 
 
@@ -98,7 +100,7 @@ def hostsim():
     out = os.path.join(ROOT, "tests", "hostsim", "libmp_hostsim.so")
     deps = [src] + [os.path.join(ROOT, "manipulapy_amd", "csrc", f) for f in ("mp_core.h", "mp_model.h", "mp_model_compile.cpp", "mp_model_compile.h")]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
-        subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", out, src,
+        subprocess.run([HOST_CXX, "-O2", "-std=c++17", "-ffp-contract=fast", "-shared", "-fPIC", "-o", out, src,
                         os.path.join(ROOT, "manipulapy_amd", "csrc", "mp_model_compile.cpp")], check=True)
     lib = ctypes.CDLL(out)
     dp = ctypes.POINTER(ctypes.c_double)
@@ -128,9 +130,10 @@ def test_device_math_matches_golden_on_host(robot, hostsim, tables, dyn_golden):
         np.testing.assert_allclose(tau[0], z["inverse_dynamics"][i], rtol=1e-6, atol=1e-7)
         np.testing.assert_allclose(T[0], z["fk_space"][i], atol=1e-12)
         np.testing.assert_allclose(J[0], z["jac_space"][i], atol=1e-12)
-        t32, _, _ = hostsim(tab, *a, 1)
         want = z["inverse_dynamics"][i]
-        assert (np.abs(t32[0] - want) <= 1e-4 * np.abs(want) + 1e-4 * np.abs(want).max()).all()
+        for mode in (1, 2):  # float32 one row per lane / two rows per lane (packed)
+            t32, _, _ = hostsim(tab, *a, mode)
+            assert (np.abs(t32[0] - want) <= 1e-4 * np.abs(want) + 1e-4 * np.abs(want).max()).all()
 
 
 def test_float32_sincos_accuracy(hostsim, tables):
