@@ -35,6 +35,9 @@ CONFIGS = {
                desc="KUKA iiwa14 7-DOF, B=65536 x N=500, FK + Jacobian + ID fused fp64 (BASELINE configs[2])"),
     "c4": dict(robot="panda", B=32768, N=200, dtype="f32", op="id",
                desc="Franka Panda (8 DOF as the reference parses it), B=32768/GPU x N=200, ID fp32 (BASELINE configs[3] per-GPU shard)"),
+    "c5": dict(robot="xarm6", B=131072, N=100, dtype="f32", op="fd_traj",
+               desc="xArm6 (6 DOF; the reference ships no xArm7), gravity + per-step Ftip, B=131072/GPU x N=100, mass matrix + "
+                    "forward-dynamics roll-out fp32, dt=0.01 intRes=1 (BASELINE configs[4] per-GPU shard)"),
 }
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 SEED = 20260705
@@ -44,6 +47,8 @@ def algorithmic_bytes_per_row(cfg, n):
     """SURVEY §8(d).  id: read q, qd, qdd + write tau = 4 values per joint-timestep.
     fk_jac_id: in 3n, out n + 16 + 6n values per timestep."""
     w = 4 if cfg["dtype"] == "f32" else 8
+    if cfg["op"] == "fd_traj":  # per timestep: in tau (n) + Ftip (6), out pos/vel/acc (3n float32)
+        return (n + 6) * w + 3 * n * 4
     return (4 * n) * w if cfg["op"] == "id" else (3 * n + n + 16 + 6 * n) * w
 
 
@@ -64,6 +69,75 @@ def cpu_baseline(robot, q, qd, qdd, budget_s=12.0):
     return {"value": done * n / dt, "unit": "joint-timesteps/s", "cores": 1, "kind": "port",
             "sample": f"first {done} rows of the benchmark input, {dt:.1f} s, single thread, NumPy oracle "
                       f"(reference algorithm: 1+2n mass matrices per point)"}, np.array(out)
+
+
+FTIP_REF = np.array([1.0, -2.0, 0.5, 3.0, -1.5, 0.75])  # the reference's own non-zero wrench (tests/test_dynamics_golden.py:145)
+
+
+def bench_fd(args, cfg, info, hg, ctx, model, t, props):
+    """Config c5: B independent forward-dynamics roll-outs (mass matrix + bias + solve + integrate per step).
+    Sequential in time, so the path is VALU-bound by construction; the HBM roofline line is reported as asked."""
+    from oracle import ref_numpy as ref
+
+    n = t["S_list"].shape[1]
+    B, N, world = cfg["B"], cfg["N"], info.world
+    rng = np.random.default_rng(SEED + 5 + 1000 * info.rank)
+    th0 = rng.uniform(-0.5, 0.5, (B, n)).astype(np.float32)
+    dth0 = rng.uniform(-0.2, 0.2, (B, n)).astype(np.float32)
+    taumat = (rng.uniform(-1, 1, (B, N, n)) * 0.01).astype(np.float32)
+    Fm = np.broadcast_to(FTIP_REF.astype(np.float32), (B, N, 6)).copy()
+    g = np.array([0.0, 0.0, -9.81])
+    d_th0, d_dth0, d_tau, d_F = ctx.to_device(th0), ctx.to_device(dth0), ctx.to_device(taumat), ctx.to_device(Fm)
+    ob = B * N * n * 4
+    d_pos, d_vel, d_acc = ctx.alloc(ob), ctx.alloc(ob), ctx.alloc(ob)
+
+    def step():
+        ctx.fd_trajectory(model, d_th0, d_dth0, d_tau, d_F, B, N, g, 0.01, 1, d_pos, d_vel, d_acc, dtype=np.float32)
+
+    for _ in range(args.warmup):
+        step()
+    ctx.synchronize()
+    ev = [(ctx.event(), ctx.event()) for _ in range(args.steps)]
+    hg.barrier()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        step()
+        ev[k][1].record()
+    ctx.synchronize()
+    hg.barrier()
+    elapsed = hg.max(time.perf_counter() - t0)
+    kern_ms = float(np.mean([b.elapsed_ms_since(a) for a, b in ev]))
+    alg_bytes = algorithmic_bytes_per_row(cfg, n) * B * N
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    result = {
+        "metric": "joint-timesteps/sec (NxBxDOF) forward-dynamics trajectory", "value": B * N * n * world * args.steps / elapsed,
+        "unit": "joint-timesteps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": cfg["dtype"], "data": "synthetic",
+        "config": {"workload": cfg["desc"], "robot": cfg["robot"], "dof": n, "B_per_gpu": B, "N": N, "op": cfg["op"],
+                   "sharding": f"batch axis over {world} rank(s), no collective in the timed step"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                     "traffic": None, "kernel": "k_fd_traj", "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                     "note": "sequential in time: VALU-bound (mass matrix + solve per step), HBM line shown for reference"},
+        "device": props["name"],
+    }
+    if info.rank == 0 and world == 1 and not args.no_cpu_baseline:
+        tab = ref.load_tables(os.path.join(ROOT, "tests", "golden", f"model_{cfg['robot']}.npz"))
+        r0 = ref.forward_dynamics_trajectory(tab, th0[0].astype(np.float64), dth0[0].astype(np.float64), taumat[0, :12].astype(np.float64),
+                                             g, Fm[0, :12].astype(np.float64), 0.01, 1)  # first 12 steps of trajectory 0
+        tc = time.perf_counter()
+        ref.forward_dynamics_trajectory(tab, th0[1].astype(np.float64), dth0[1].astype(np.float64), taumat[1, :12].astype(np.float64), g,
+                                        Fm[1, :12].astype(np.float64), 0.01, 1)
+        dtc = time.perf_counter() - tc
+        pos = d_pos.download((B, N, n), np.float32)
+        result["cpu_baseline"] = {"value": 11 * n / dtc, "unit": "joint-timesteps/s", "cores": 1, "kind": "port",
+                                  "sample": f"11 integration steps of one trajectory, {dtc:.1f} s, single thread, NumPy oracle"}
+        result["parity_sample"] = {"rows": 12, "max_abs_err": float(np.abs(pos[0, :12] - r0["positions"]).max())}
+    if info.rank == 0:
+        print(json.dumps(result), flush=True)
+    ctx.destroy()
 
 
 def main():
@@ -104,6 +178,9 @@ def main():
     ctx.selftest()
     props = ctx.properties()
     model = _hip.HipModel(t["S_list"], t["Mlist_per_link"], t["Glist"], t["M_ee"], t["joint_limits"])
+
+    if cfg["op"] == "fd_traj":
+        return bench_fd(args, cfg, info, hg, ctx, model, t, props)
 
     # ---- synthetic input, generated ON the device: start / end ~ U(joint limits), quintic, Tf = 2
     cid = {"c2": 2, "c3": 3, "c4": 4}[args.config]

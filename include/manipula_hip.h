@@ -128,6 +128,29 @@ int mp_fk_jac_id_f32(mp_ctx* ctx, const mp_model* model, const float* d_q, const
                      const float* d_qdd, int64_t rows, const double* g, const double* Ftip, float* d_T,
                      float* d_J, float* d_tau);
 
+/* M (rows,n,n) = mass_matrix(q) per row (dynamics/mass_matrix.py:16-99), symmetrised like the reference. */
+int mp_mass_matrix_f64(mp_ctx* ctx, const mp_model* model, const double* d_q, int64_t rows, double* d_M);
+int mp_mass_matrix_f32(mp_ctx* ctx, const mp_model* model, const float* d_q, int64_t rows, float* d_M);
+
+/* qdd (rows,n) = forward_dynamics(q, qd, tau, g, Ftip) per row = solve(M, tau - c - g - Js^T Ftip)
+ * (dynamics/id_fd.py:50-83); one g / Ftip for all rows. */
+int mp_forward_dynamics_f64(mp_ctx* ctx, const mp_model* model, const double* d_q, const double* d_qd,
+                            const double* d_tau, int64_t rows, const double* g, const double* Ftip, double* d_qdd);
+int mp_forward_dynamics_f32(mp_ctx* ctx, const mp_model* model, const float* d_q, const float* d_qd,
+                            const float* d_tau, int64_t rows, const double* g, const double* Ftip, float* d_qdd);
+
+/* forward_dynamics_trajectory for B independent trajectories (planning/trajectory_dynamics.py:382-423,
+ * :580-708; replaces forward_dynamics_kernel, cuda_kernels/trajectory_kernels.py:604-705): semi-implicit
+ * Euler, intRes sub-steps of dt/intRes, positions clipped to the joint limits after every sub-step, row 0 =
+ * initial state.  theta0/dtheta0 (B,n), taumat (B,N,n), Ftipmat (B,N,6) or NULL (= no wrench); the state is
+ * integrated in the input precision, pos/vel/acc (B,N,n) are float32 as the reference stores them. */
+int mp_fd_trajectory_f32(mp_ctx* ctx, const mp_model* model, const float* d_theta0, const float* d_dtheta0,
+                         const float* d_taumat, const float* d_Ftipmat, int64_t B, int64_t N, const double* g,
+                         double dt, int intRes, float* d_pos, float* d_vel, float* d_acc);
+int mp_fd_trajectory_f64(mp_ctx* ctx, const mp_model* model, const double* d_theta0, const double* d_dtheta0,
+                         const double* d_taumat, const double* d_Ftipmat, int64_t B, int64_t N, const double* g,
+                         double dt, int intRes, float* d_pos, float* d_vel, float* d_acc);
+
 /* ---- hot path, host pointers (what a Python gpu_launcher calls): H2D, launch, D2H, synchronise - */
 int mp_batch_trajectory_host_f32(mp_ctx* ctx, const mp_model* model, const float* start, const float* end,
                                  int64_t B, int64_t N, double Tf, int method, float* pos, float* vel, float* acc);
@@ -141,6 +164,16 @@ int mp_traj_id_fused_host_f32(mp_ctx* ctx, const mp_model* model, const float* s
 int mp_fk_jac_id_host_f64(mp_ctx* ctx, const mp_model* model, const double* q, const double* qd,
                           const double* qdd, int64_t rows, const double* g, const double* Ftip, double* T,
                           double* J, double* tau);
+
+int mp_mass_matrix_host_f64(mp_ctx* ctx, const mp_model* model, const double* q, int64_t rows, double* M);
+int mp_forward_dynamics_host_f64(mp_ctx* ctx, const mp_model* model, const double* q, const double* qd,
+                                 const double* tau, int64_t rows, const double* g, const double* Ftip, double* qdd);
+int mp_fd_trajectory_host_f32(mp_ctx* ctx, const mp_model* model, const float* theta0, const float* dtheta0,
+                              const float* taumat, const float* Ftipmat, int64_t B, int64_t N, const double* g,
+                              double dt, int intRes, float* pos, float* vel, float* acc);
+int mp_fd_trajectory_host_f64(mp_ctx* ctx, const mp_model* model, const double* theta0, const double* dtheta0,
+                              const double* taumat, const double* Ftipmat, int64_t B, int64_t N, const double* g,
+                              double dt, int intRes, float* pos, float* vel, float* acc);
 
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI (new; the reference is single-device) ------
  * Trajectory batches are sharded over ranks with no exchange during compute; the only collective is

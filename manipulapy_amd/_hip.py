@@ -70,6 +70,16 @@ SIGNATURES = {
     "mp_traj_id_fused_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, ctypes.c_double, ctypes.c_int, _c_dp, _c_dp, _vp]),
     "mp_fk_jac_id_f64": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _c_dp, _c_dp, _vp, _vp, _vp]),
     "mp_fk_jac_id_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _c_dp, _c_dp, _vp, _vp, _vp]),
+    "mp_mass_matrix_f64": (ctypes.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    "mp_mass_matrix_f32": (ctypes.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    "mp_forward_dynamics_f64": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _c_dp, _c_dp, _vp]),
+    "mp_forward_dynamics_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _c_dp, _c_dp, _vp]),
+    "mp_fd_trajectory_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _c_dp, ctypes.c_double, ctypes.c_int, _vp, _vp, _vp]),
+    "mp_fd_trajectory_f64": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _c_dp, ctypes.c_double, ctypes.c_int, _vp, _vp, _vp]),
+    "mp_mass_matrix_host_f64": (ctypes.c_int, [_vp, _vp, _c_dp, _i64, _c_dp]),
+    "mp_forward_dynamics_host_f64": (ctypes.c_int, [_vp, _vp, _c_dp, _c_dp, _c_dp, _i64, _c_dp, _c_dp, _c_dp]),
+    "mp_fd_trajectory_host_f32": (ctypes.c_int, [_vp, _vp, _c_fp, _c_fp, _c_fp, _c_fp, _i64, _i64, _c_dp, ctypes.c_double, ctypes.c_int, _c_fp, _c_fp, _c_fp]),
+    "mp_fd_trajectory_host_f64": (ctypes.c_int, [_vp, _vp, _c_dp, _c_dp, _c_dp, _c_dp, _i64, _i64, _c_dp, ctypes.c_double, ctypes.c_int, _c_fp, _c_fp, _c_fp]),
     "mp_batch_trajectory_host_f32": (ctypes.c_int, [_vp, _vp, _c_fp, _c_fp, _i64, _i64, ctypes.c_double, ctypes.c_int, _c_fp, _c_fp, _c_fp]),
     "mp_id_trajectory_host_f32": (ctypes.c_int, [_vp, _vp, _c_fp, _c_fp, _c_fp, _i64, _c_dp, _c_dp, _c_fp]),
     "mp_id_trajectory_host_f64": (ctypes.c_int, [_vp, _vp, _c_dp, _c_dp, _c_dp, _i64, _c_dp, _c_dp, _c_dp]),
@@ -375,6 +385,57 @@ class HipContext:
         _check(self.lib.mp_fk_jac_id_host_f64(self.handle, model.handle, _dptr(q), _dptr(qd), _dptr(qdd), rows,
                                               _dptr(g), _dptr(F), _dptr(T), _dptr(J), _dptr(tau)))
         return T, J, tau
+
+    def mass_matrix_host(self, model: HipModel, q) -> np.ndarray:
+        q = _as_c(q, np.float64, name="q")
+        if q.ndim != 2 or q.shape[1] != model.n:
+            raise ValueError(f"q must be (rows, {model.n}), got {q.shape}")
+        M = np.zeros((q.shape[0], model.n, model.n))
+        _check(self.lib.mp_mass_matrix_host_f64(self.handle, model.handle, _dptr(q), q.shape[0], _dptr(M)))
+        return M
+
+    def forward_dynamics_host(self, model: HipModel, q, qd, tau, g=None, Ftip=None) -> np.ndarray:
+        q = _as_c(q, np.float64, name="q")
+        if q.ndim != 2 or q.shape[1] != model.n:
+            raise ValueError(f"q must be (rows, {model.n}), got {q.shape}")
+        qd = _as_c(qd, np.float64, q.shape, "qd")
+        tau = _as_c(tau, np.float64, q.shape, "tau")
+        out = np.zeros_like(q)
+        g = _vec_or_none(g, 3, "g")
+        F = _vec_or_none(Ftip, 6, "Ftip")
+        _check(self.lib.mp_forward_dynamics_host_f64(self.handle, model.handle, _dptr(q), _dptr(qd), _dptr(tau), q.shape[0],
+                                                     _dptr(g), _dptr(F), _dptr(out)))
+        return out
+
+    def fd_trajectory_host(self, model: HipModel, theta0, dtheta0, taumat, g, Ftipmat, dt, intRes, dtype=np.float64):
+        """B trajectories: theta0/dtheta0 (B,n), taumat (B,N,n), Ftipmat (B,N,6) or None -> 3 x (B,N,n) float32."""
+        dtype = np.dtype(dtype)
+        th = _as_c(theta0, dtype, name="thetalist")
+        if th.ndim != 2 or th.shape[1] != model.n:
+            raise ValueError(f"thetalist must be (B, {model.n}), got {th.shape}")
+        B = th.shape[0]
+        dth = _as_c(dtheta0, dtype, th.shape, "dthetalist")
+        tm = _as_c(taumat, dtype, name="taumat")
+        if tm.ndim != 3 or tm.shape[0] != B or tm.shape[2] != model.n:
+            raise ValueError(f"taumat must be (B, N, {model.n}), got {tm.shape}")
+        N = tm.shape[1]
+        Fm = None if Ftipmat is None else _as_c(Ftipmat, dtype, (B, N, 6), "Ftipmat")
+        g = _vec_or_none(g, 3, "g")
+        out = [np.zeros((B, N, model.n), dtype=np.float32) for _ in range(3)]
+        if dtype == np.float32:
+            fn, ptr = self.lib.mp_fd_trajectory_host_f32, _fptr
+        else:
+            fn, ptr = self.lib.mp_fd_trajectory_host_f64, _dptr
+        _check(fn(self.handle, model.handle, ptr(th), ptr(dth), ptr(tm), ptr(Fm), B, N, _dptr(g), float(dt), int(intRes),
+                  _fptr(out[0]), _fptr(out[1]), _fptr(out[2])))
+        return tuple(out)
+
+    def fd_trajectory(self, model, d_theta0, d_dtheta0, d_taumat, d_Ftipmat, B, N, g, dt, intRes, d_pos, d_vel, d_acc,
+                      dtype=np.float32):
+        fn = self.lib.mp_fd_trajectory_f32 if np.dtype(dtype) == np.float32 else self.lib.mp_fd_trajectory_f64
+        g = _vec_or_none(g, 3, "g")
+        _check(fn(self.handle, model.handle, _p(d_theta0), _p(d_dtheta0), _p(d_taumat), _p(d_Ftipmat), int(B), int(N), _dptr(g),
+                  float(dt), int(intRes), _p(d_pos), _p(d_vel), _p(d_acc)))
 
     # ---- RCCL
     @staticmethod

@@ -199,6 +199,85 @@ static int id_host_impl(const char* fn, mp_ctx* ctx, const mp_model* model, cons
   HIP_TRY(hipStreamSynchronize(ctx->compute));
   return MP_OK;
 }
+
+template <typename T>
+static int mm_impl(const char* fn, mp_ctx* ctx, const mp_model* model, const T* d_q, int64_t rows, T* d_M) {
+  REQUIRE(ctx && model, "%s: null context or model", fn);
+  if (int rc = bind(ctx)) return rc;
+  REQUIRE(rows >= 0, "%s: negative row count", fn);
+  if (rows == 0) return MP_OK;
+  REQUIRE(d_q && d_M, "%s: null device pointer", fn);
+  REQUIRE(aligned16(d_q) && aligned16(d_M), "%s: device pointers must be 16-byte aligned", fn);
+  HIP_TRY(mpk_mass_matrix<T>(ctx->compute, pick<T>(model), d_q, d_M, (long)rows));
+  return MP_OK;
+}
+
+template <typename T>
+static int fdyn_impl(const char* fn, mp_ctx* ctx, const mp_model* model, const T* d_q, const T* d_qd, const T* d_tau,
+                     int64_t rows, const double* g, const double* Ftip, T* d_qdd) {
+  REQUIRE(ctx && model, "%s: null context or model", fn);
+  if (int rc = bind(ctx)) return rc;
+  REQUIRE(rows >= 0, "%s: negative row count", fn);
+  if (rows == 0) return MP_OK;
+  REQUIRE(d_q && d_qd && d_tau && d_qdd, "%s: null device pointer", fn);
+  REQUIRE(aligned16(d_q) && aligned16(d_qd) && aligned16(d_tau) && aligned16(d_qdd), "%s: device pointers must be 16-byte aligned", fn);
+  MpCall<T> c;
+  make_call<T>(model, g, Ftip, &c);
+  HIP_TRY(mpk_forward_dynamics<T>(ctx->compute, pick<T>(model), c, any_nonzero(Ftip), d_q, d_qd, d_tau, d_qdd, (long)rows));
+  return MP_OK;
+}
+
+template <typename T>
+static int fdtraj_impl(const char* fn, mp_ctx* ctx, const mp_model* model, const T* d_theta0, const T* d_dtheta0,
+                       const T* d_taumat, const T* d_Ftipmat, int64_t B, int64_t N, const double* g, double dt, int intRes,
+                       float* d_pos, float* d_vel, float* d_acc) {
+  REQUIRE(ctx && model, "%s: null context or model", fn);
+  if (int rc = bind(ctx)) return rc;
+  REQUIRE(B >= 0 && N >= 0, "%s: negative B or N", fn);
+  REQUIRE(intRes >= 0, "%s: negative intRes", fn);
+  if (B == 0 || N == 0) return MP_OK;
+  REQUIRE(d_theta0 && d_dtheta0 && d_taumat && d_pos && d_vel && d_acc, "%s: null device pointer", fn);
+  REQUIRE(aligned16(d_theta0) && aligned16(d_dtheta0) && aligned16(d_taumat) && aligned16(d_Ftipmat) && aligned16(d_pos) &&
+              aligned16(d_vel) && aligned16(d_acc), "%s: device pointers must be 16-byte aligned", fn);
+  MpCall<T> c;
+  make_call<T>(model, g, nullptr, &c);
+  const T h = intRes > 0 ? (T)(dt / intRes) : (T)0;
+  HIP_TRY(mpk_fd_traj<T>(ctx->compute, pick<T>(model), c, d_theta0, d_dtheta0, d_taumat, d_Ftipmat, (long)B, (long)N, h, intRes,
+                         d_pos, d_vel, d_acc));
+  return MP_OK;
+}
+
+template <typename T>
+static int fdtraj_host_impl(const char* fn, mp_ctx* ctx, const mp_model* model, const T* theta0, const T* dtheta0,
+                            const T* taumat, const T* Ftipmat, int64_t B, int64_t N, const double* g, double dt, int intRes,
+                            float* pos, float* vel, float* acc) {
+  REQUIRE(ctx && model, "%s: null context or model", fn);
+  if (int rc = bind(ctx)) return rc;
+  REQUIRE(B >= 0 && N >= 0, "%s: negative B or N", fn);
+  if (B == 0 || N == 0) return MP_OK;
+  REQUIRE(theta0 && dtheta0 && taumat && pos && vel && acc, "%s: null host pointer", fn);
+  const size_t n = (size_t)model->d.n, sb = (size_t)B * n * sizeof(T), tb = (size_t)B * (size_t)N * n * sizeof(T);
+  const size_t fb = (size_t)B * (size_t)N * 6 * sizeof(T), ob = (size_t)B * (size_t)N * n * sizeof(float);
+  Scratch sc(ctx);
+  void *d0, *d1, *dt_, *df = nullptr, *dp, *dv, *da;
+  if (int rc = sc.get(sb, &d0)) return rc;
+  if (int rc = sc.get(sb, &d1)) return rc;
+  if (int rc = sc.get(tb, &dt_)) return rc;
+  if (Ftipmat) if (int rc = sc.get(fb, &df)) return rc;
+  if (int rc = sc.get(ob, &dp)) return rc;
+  if (int rc = sc.get(ob, &dv)) return rc;
+  if (int rc = sc.get(ob, &da)) return rc;
+  H2D(d0, theta0, sb);
+  H2D(d1, dtheta0, sb);
+  H2D(dt_, taumat, tb);
+  if (Ftipmat) H2D(df, Ftipmat, fb);
+  if (int rc = fdtraj_impl<T>(fn, ctx, model, (T*)d0, (T*)d1, (T*)dt_, (T*)df, B, N, g, dt, intRes, (float*)dp, (float*)dv, (float*)da)) return rc;
+  D2H(pos, dp, ob);
+  D2H(vel, dv, ob);
+  D2H(acc, da, ob);
+  HIP_TRY(hipStreamSynchronize(ctx->compute));
+  return MP_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -565,7 +644,84 @@ int mp_fk_jac_id_host_f64(mp_ctx* ctx, const mp_model* model, const double* q, c
   return MP_OK;
 }
 
+int mp_mass_matrix_f64(mp_ctx* ctx, const mp_model* model, const double* d_q, int64_t rows, double* d_M) {
+  return mm_impl<double>("mp_mass_matrix_f64", ctx, model, d_q, rows, d_M);
+}
+int mp_mass_matrix_f32(mp_ctx* ctx, const mp_model* model, const float* d_q, int64_t rows, float* d_M) {
+  return mm_impl<float>("mp_mass_matrix_f32", ctx, model, d_q, rows, d_M);
+}
+int mp_forward_dynamics_f64(mp_ctx* ctx, const mp_model* model, const double* d_q, const double* d_qd, const double* d_tau,
+                            int64_t rows, const double* g, const double* Ftip, double* d_qdd) {
+  return fdyn_impl<double>("mp_forward_dynamics_f64", ctx, model, d_q, d_qd, d_tau, rows, g, Ftip, d_qdd);
+}
+int mp_forward_dynamics_f32(mp_ctx* ctx, const mp_model* model, const float* d_q, const float* d_qd, const float* d_tau,
+                            int64_t rows, const double* g, const double* Ftip, float* d_qdd) {
+  return fdyn_impl<float>("mp_forward_dynamics_f32", ctx, model, d_q, d_qd, d_tau, rows, g, Ftip, d_qdd);
+}
+int mp_fd_trajectory_f32(mp_ctx* ctx, const mp_model* model, const float* d_theta0, const float* d_dtheta0,
+                         const float* d_taumat, const float* d_Ftipmat, int64_t B, int64_t N, const double* g, double dt,
+                         int intRes, float* d_pos, float* d_vel, float* d_acc) {
+  return fdtraj_impl<float>("mp_fd_trajectory_f32", ctx, model, d_theta0, d_dtheta0, d_taumat, d_Ftipmat, B, N, g, dt, intRes,
+                            d_pos, d_vel, d_acc);
+}
+int mp_fd_trajectory_f64(mp_ctx* ctx, const mp_model* model, const double* d_theta0, const double* d_dtheta0,
+                         const double* d_taumat, const double* d_Ftipmat, int64_t B, int64_t N, const double* g, double dt,
+                         int intRes, float* d_pos, float* d_vel, float* d_acc) {
+  return fdtraj_impl<double>("mp_fd_trajectory_f64", ctx, model, d_theta0, d_dtheta0, d_taumat, d_Ftipmat, B, N, g, dt, intRes,
+                             d_pos, d_vel, d_acc);
+}
+int mp_fd_trajectory_host_f32(mp_ctx* ctx, const mp_model* model, const float* theta0, const float* dtheta0,
+                              const float* taumat, const float* Ftipmat, int64_t B, int64_t N, const double* g, double dt,
+                              int intRes, float* pos, float* vel, float* acc) {
+  return fdtraj_host_impl<float>("mp_fd_trajectory_host_f32", ctx, model, theta0, dtheta0, taumat, Ftipmat, B, N, g, dt, intRes,
+                                 pos, vel, acc);
+}
+int mp_fd_trajectory_host_f64(mp_ctx* ctx, const mp_model* model, const double* theta0, const double* dtheta0,
+                              const double* taumat, const double* Ftipmat, int64_t B, int64_t N, const double* g, double dt,
+                              int intRes, float* pos, float* vel, float* acc) {
+  return fdtraj_host_impl<double>("mp_fd_trajectory_host_f64", ctx, model, theta0, dtheta0, taumat, Ftipmat, B, N, g, dt,
+                                  intRes, pos, vel, acc);
+}
+int mp_mass_matrix_host_f64(mp_ctx* ctx, const mp_model* model, const double* q, int64_t rows, double* M) {
+  CHECK_COMMON("mp_mass_matrix_host_f64");
+  REQUIRE(rows >= 0, "mp_mass_matrix_host_f64: negative row count");
+  if (rows == 0) return MP_OK;
+  REQUIRE(q && M, "mp_mass_matrix_host_f64: null host pointer");
+  const size_t n = (size_t)model->d.n, qb = (size_t)rows * n * sizeof(double), mb = qb * n;
+  Scratch sc(ctx);
+  void *dq, *dM;
+  if (int rc = sc.get(qb, &dq)) return rc;
+  if (int rc = sc.get(mb, &dM)) return rc;
+  H2D(dq, q, qb);
+  if (int rc = mp_mass_matrix_f64(ctx, model, (double*)dq, rows, (double*)dM)) return rc;
+  D2H(M, dM, mb);
+  HIP_TRY(hipStreamSynchronize(ctx->compute));
+  return MP_OK;
+}
+int mp_forward_dynamics_host_f64(mp_ctx* ctx, const mp_model* model, const double* q, const double* qd, const double* tau,
+                                 int64_t rows, const double* g, const double* Ftip, double* qdd) {
+  CHECK_COMMON("mp_forward_dynamics_host_f64");
+  REQUIRE(rows >= 0, "mp_forward_dynamics_host_f64: negative row count");
+  if (rows == 0) return MP_OK;
+  REQUIRE(q && qd && tau && qdd, "mp_forward_dynamics_host_f64: null host pointer");
+  const size_t bytes = (size_t)rows * (size_t)model->d.n * sizeof(double);
+  Scratch sc(ctx);
+  void *dq, *dqd, *dt, *dout;
+  if (int rc = sc.get(bytes, &dq)) return rc;
+  if (int rc = sc.get(bytes, &dqd)) return rc;
+  if (int rc = sc.get(bytes, &dt)) return rc;
+  if (int rc = sc.get(bytes, &dout)) return rc;
+  H2D(dq, q, bytes);
+  H2D(dqd, qd, bytes);
+  H2D(dt, tau, bytes);
+  if (int rc = mp_forward_dynamics_f64(ctx, model, (double*)dq, (double*)dqd, (double*)dt, rows, g, Ftip, (double*)dout)) return rc;
+  D2H(qdd, dout, bytes);
+  HIP_TRY(hipStreamSynchronize(ctx->compute));
+  return MP_OK;
+}
+
 }  // extern "C"
+
 
 // exposed to mp_comm.cpp
 hipStream_t mp_ctx_compute_stream(mp_ctx* ctx) { return ctx->compute; }

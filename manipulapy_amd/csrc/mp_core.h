@@ -114,6 +114,8 @@ MP_HD double mp_max(double a, double b) { return a > b ? a : b; }
 MP_HD mp_f2 mp_min(mp_f2 a, mp_f2 b) { return (a < b) ? a : b; }
 MP_HD mp_f2 mp_max(mp_f2 a, mp_f2 b) { return (a > b) ? a : b; }
 #endif
+MP_HD float mp_sqrt(float x) { return sqrtf(x); }
+MP_HD double mp_sqrt(double x) { return sqrt(x); }
 // np.clip order: max with the lower bound first, then min with the upper bound
 template <typename T>
 MP_HD T mp_clip(T v, typename MpTraits<T>::S lo, typename MpTraits<T>::S hi) {
@@ -206,20 +208,19 @@ MP_HD void mp_joint_state(const MT& M, const T (&q)[N], MpJointState<T, N>& js) 
 }
 
 // Recursive Newton-Euler in the compiled link frames.  tau is NOT clipped here.
+// a0: linear acceleration of the base in the pre-joint-1 frame (= base_R^T (-g)), wave-uniform.
+// tipn / tipf: the tip wrench [moment; force] expressed in the pre-joint-1 frame, per row (ignored unless HAS_FTIP).
 template <typename T, int N, bool HAS_FTIP, typename MT>
-MP_HD void mp_rnea(const MT& M, const MpCall<typename MpTraits<T>::S>& C,
+MP_HD void mp_rnea(const MT& M, const typename MpTraits<T>::S (&a0)[3], const T (&tipn)[3], const T (&tipf)[3],
                    const MpJointState<T, N>& js, const T (&qd)[N], const T (&qdd)[N], T (&tau)[N]) {
   using S = typename MpTraits<T>::S;
   using TR = MpTraits<T>;
   const T zero = TR::splat(S(0));
   T fnx[N], fny[N], fnz[N], ffx[N], ffy[N], ffz[N];
   T wx = zero, wy = zero, wz = zero, vx = zero, vy = zero, vz = zero;
-  T dwx = zero, dwy = zero, dwz = zero, dvx = TR::splat(C.a0[0]), dvy = TR::splat(C.a0[1]), dvz = TR::splat(C.a0[2]);
+  T dwx = zero, dwy = zero, dwz = zero, dvx = TR::splat(a0[0]), dvy = TR::splat(a0[1]), dvz = TR::splat(a0[2]);
   T tnx = zero, tny = zero, tnz = zero, tfx = zero, tfy = zero, tfz = zero;
-  if (HAS_FTIP) {
-    tnx = TR::splat(C.F1n[0]); tny = TR::splat(C.F1n[1]); tnz = TR::splat(C.F1n[2]);
-    tfx = TR::splat(C.F1f[0]); tfy = TR::splat(C.F1f[1]); tfz = TR::splat(C.F1f[2]);
-  }
+  if (HAS_FTIP) { tnx = tipn[0]; tny = tipn[1]; tnz = tipn[2]; tfx = tipf[0]; tfy = tipf[1]; tfz = tipf[2]; }
 
   // forward pass: twists, accelerations, body wrenches
 #pragma unroll
@@ -280,6 +281,109 @@ MP_HD void mp_rnea(const MT& M, const MpCall<typename MpTraits<T>::S>& C,
       ffx[i - 1] += fx; ffy[i - 1] += fy; ffz[i - 1] += fz;
     }
   }
+}
+
+// Same with the wave-uniform per-call constants (gravity + one tip wrench for every row).
+template <typename T, int N, bool HAS_FTIP, typename MT>
+MP_HD void mp_rnea(const MT& M, const MpCall<typename MpTraits<T>::S>& C, const MpJointState<T, N>& js,
+                   const T (&qd)[N], const T (&qdd)[N], T (&tau)[N]) {
+  using TR = MpTraits<T>;
+  const T tn[3] = {TR::splat(C.F1n[0]), TR::splat(C.F1n[1]), TR::splat(C.F1n[2])};
+  const T tf[3] = {TR::splat(C.F1f[0]), TR::splat(C.F1f[1]), TR::splat(C.F1f[2])};
+  mp_rnea<T, N, HAS_FTIP>(M, C.a0, tn, tf, js, qd, qdd, tau);
+}
+
+// A space-frame wrench [m; f] seen from the pre-joint-1 frame: f' = R^T f, n' = R^T (n - p x f)
+// (what mp_make_call does on the host for a per-call wrench; here per row).
+template <typename T, typename MT>
+MP_HD void mp_wrench_to_frame1(const MT& M, const T (&F)[6], T (&tn)[3], T (&tf)[3]) {
+  const auto& R = M.base_R;
+  const auto& p = M.base_p;
+  const T nx = F[0] - (p[1] * F[5] - p[2] * F[4]), ny = F[1] - (p[2] * F[3] - p[0] * F[5]), nz = F[2] - (p[0] * F[4] - p[1] * F[3]);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    tn[k] = R[0 + k] * nx + R[3 + k] * ny + R[6 + k] * nz;
+    tf[k] = R[0 + k] * F[3] + R[3 + k] * F[4] + R[6 + k] * F[5];
+  }
+}
+
+// ------------------------------------------------------------- mass matrix / forward dynamics
+// M(q) column j = ID(q, 0, e_j, g = 0, F = 0): with the loops unrolled the zero velocities and the unit
+// acceleration are compile-time constants, so the velocity products and every term upstream of joint j
+// fold away.  Symmetrised like the reference (dynamics/mass_matrix.py:96).
+template <typename T, int N, typename MT>
+MP_HD void mp_mass_matrix(const MT& M, const MpJointState<T, N>& js, T (&Mq)[N][N]) {
+  using S = typename MpTraits<T>::S;
+  using TR = MpTraits<T>;
+  const S a0[3] = {S(0), S(0), S(0)};
+  const T zero = TR::splat(S(0));
+  const T z3[3] = {zero, zero, zero};
+  T col[N][N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    T qd[N], qdd[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) { qd[k] = zero; qdd[k] = (k == j) ? TR::splat(S(1)) : zero; }
+    mp_rnea<T, N, false>(M, a0, z3, z3, js, qd, qdd, col[j]);
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+#pragma unroll
+    for (int j = 0; j < N; ++j) Mq[i][j] = S(0.5) * (col[j][i] + col[i][j]);
+}
+
+// Solve M x = b for a symmetric positive definite M held in registers (Cholesky, fully unrolled).
+// The reference calls np.linalg.solve (LU with pivoting, dynamics/id_fd.py:82); for an SPD matrix both
+// give the same x up to rounding.  M is overwritten by its factor, b by the solution.
+template <typename T, int N>
+MP_HD void mp_spd_solve(T (&A)[N][N], T (&b)[N]) {
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    T d = A[j][j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) d -= A[j][k] * A[j][k];
+    const T inv = T(1) / mp_sqrt(d);
+    A[j][j] = inv;  // store 1 / L_jj
+#pragma unroll
+    for (int i = j + 1; i < N; ++i) {
+      T v = A[i][j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) v -= A[i][k] * A[j][k];
+      A[i][j] = v * inv;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) {  // L y = b
+    T v = b[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) v -= A[i][k] * b[k];
+    b[i] = v * A[i][i];
+  }
+#pragma unroll
+  for (int i = N - 1; i >= 0; --i) {  // L^T x = y
+    T v = b[i];
+#pragma unroll
+    for (int k = i + 1; k < N; ++k) v -= A[k][i] * b[k];
+    b[i] = v * A[i][i];
+  }
+}
+
+// qdd = M(q)^-1 (tau - bias), bias = ID(q, qd, 0, g, F)   (reference dynamics/id_fd.py:71-83)
+template <typename T, int N, bool HAS_FTIP, typename MT>
+MP_HD void mp_forward_dynamics(const MT& M, const typename MpTraits<T>::S (&a0)[3], const T (&tipn)[3],
+                               const T (&tipf)[3], const T (&q)[N], const T (&qd)[N], const T (&tau)[N], T (&qdd)[N]) {
+  using S = typename MpTraits<T>::S;
+  MpJointState<T, N> js;
+  mp_joint_state<T, N>(M, q, js);
+  T zero_acc[N], bias[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) zero_acc[k] = MpTraits<T>::splat(S(0));
+  mp_rnea<T, N, HAS_FTIP>(M, a0, tipn, tipf, js, qd, zero_acc, bias);
+  T Mq[N][N];
+  mp_mass_matrix<T, N>(M, js, Mq);
+#pragma unroll
+  for (int k = 0; k < N; ++k) qdd[k] = tau[k] - bias[k];
+  mp_spd_solve<T, N>(Mq, qdd);
 }
 
 // ------------------------------------------------------------------------- FK + space Jacobian

@@ -24,3 +24,13 @@ hipError_t mpk_fk_jac_id(hipStream_t s, const MpModel<T>& M, const MpCall<T>& C,
 // lane), model resident in device memory, fixed grid of `blocks` x 256 threads.
 hipError_t mpk_id_f32_persist(hipStream_t s, const MpModel<float>* d_model, int n, const MpCall<float>& C, bool ftip,
                               const float* q, const float* qd, const float* qdd, float* tau, long pairs, int blocks);
+
+template <typename T>
+hipError_t mpk_mass_matrix(hipStream_t s, const MpModel<T>& M, const T* q, T* Mout, long rows);
+template <typename T>
+hipError_t mpk_forward_dynamics(hipStream_t s, const MpModel<T>& M, const MpCall<T>& C, bool ftip, const T* q, const T* qd,
+                                const T* tau, T* qdd, long rows);
+// Ftipmat == nullptr: no tip wrench.  h = dt / intRes.  Outputs are float32 (B, Nt, n).
+template <typename T>
+hipError_t mpk_fd_traj(hipStream_t s, const MpModel<T>& M, const MpCall<T>& C, const T* theta0, const T* dtheta0,
+                       const T* taumat, const T* Ftipmat, long B, long Nt, T h, int intRes, float* pos, float* vel, float* acc);

@@ -273,6 +273,97 @@ __global__ __launch_bounds__(kBlock) void k_fk_jac_id(const MpModel<T> M, const 
   }
 }
 
+// ------------------------------------------------------------- mass matrix / forward dynamics
+template <typename T, int N>
+__global__ __launch_bounds__(kBlock) void k_mass_matrix(const MpModel<T> M, const T* __restrict__ q, T* __restrict__ Mout,
+                                                        long rows) {
+  const long r = (long)blockIdx.x * kBlock + threadIdx.x;
+  if (r >= rows) return;
+  T a[N];
+  RunIO<T, N>::load(q, r, a);
+  MpJointState<T, N> js;
+  mp_joint_state<T, N>(M, a, js);
+  T Mq[N][N];
+  mp_mass_matrix<T, N>(M, js, Mq);
+  T flat[N * N];
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+#pragma unroll
+    for (int j = 0; j < N; ++j) flat[i * N + j] = Mq[i][j];
+  RunIO<T, N * N>::store(Mout, r, flat);
+}
+
+// qdd = forward_dynamics(q, qd, tau, g, Ftip) per row; Ftip is one wrench for every row (per-call constant)
+template <typename T, int N, bool HAS_FTIP>
+__global__ __launch_bounds__(kBlock) void k_forward_dynamics(const MpModel<T> M, const MpCall<T> C, const T* __restrict__ q,
+                                                             const T* __restrict__ qd, const T* __restrict__ tau,
+                                                             T* __restrict__ qdd, long rows) {
+  const long r = (long)blockIdx.x * kBlock + threadIdx.x;
+  if (r >= rows) return;
+  T a[N], b[N], t[N], out[N];
+  RunIO<T, N>::load(q, r, a);
+  RunIO<T, N>::load(qd, r, b);
+  RunIO<T, N>::load(tau, r, t);
+  const T tn[3] = {C.F1n[0], C.F1n[1], C.F1n[2]}, tf[3] = {C.F1f[0], C.F1f[1], C.F1f[2]};
+  mp_forward_dynamics<T, N, HAS_FTIP>(M, C.a0, tn, tf, a, b, t, out);
+  RunIO<T, N>::store(qdd, r, out);
+}
+
+// forward_dynamics_trajectory (reference planning/trajectory_dynamics.py:580-708): one lane integrates one
+// trajectory — semi-implicit Euler, `intRes` sub-steps of dt/intRes per outer step, joint-limit clip after
+// every sub-step, rows stored float32, the recorded acceleration is the last sub-step's, row 0 = initial
+// state with zero acceleration.  Time is sequential; trajectories are independent.
+template <typename T, int N, bool HAS_FTIP>
+__global__ __launch_bounds__(kBlock) void k_fd_traj(const MpModel<T> M, const MpCall<T> C, const T* __restrict__ theta0,
+                                                    const T* __restrict__ dtheta0, const T* __restrict__ taumat,
+                                                    const T* __restrict__ Ftipmat, long B, long Nt, T h, int intRes,
+                                                    float* __restrict__ pos, float* __restrict__ vel, float* __restrict__ acc) {
+  const long b = (long)blockIdx.x * kBlock + threadIdx.x;
+  if (b >= B) return;
+  T q[N], qd[N];
+  RunIO<T, N>::load(theta0, b, q);
+  RunIO<T, N>::load(dtheta0, b, qd);
+  float o[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) o[j] = (float)q[j];
+  RunIO<float, N>::store(pos, b * Nt, o);
+#pragma unroll
+  for (int j = 0; j < N; ++j) o[j] = (float)qd[j];
+  RunIO<float, N>::store(vel, b * Nt, o);
+#pragma unroll
+  for (int j = 0; j < N; ++j) o[j] = 0.f;
+  RunIO<float, N>::store(acc, b * Nt, o);
+  for (long i = 1; i < Nt; ++i) {
+    T tau[N], tn[3] = {T(0), T(0), T(0)}, tf[3] = {T(0), T(0), T(0)};
+    RunIO<T, N>::load(taumat, b * Nt + i, tau);
+    if (HAS_FTIP) {
+      T F[6];
+      RunIO<T, 6>::load(Ftipmat, b * Nt + i, F);
+      mp_wrench_to_frame1(M, F, tn, tf);
+    }
+    T last[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) last[j] = T(0);
+    for (int s = 0; s < intRes; ++s) {
+      mp_forward_dynamics<T, N, HAS_FTIP>(M, C.a0, tn, tf, q, qd, tau, last);
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        qd[j] = qd[j] + last[j] * h;
+        q[j] = mp_clip(q[j] + qd[j] * h, M.qmin[j], M.qmax[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) o[j] = (float)q[j];
+    RunIO<float, N>::store(pos, b * Nt + i, o);
+#pragma unroll
+    for (int j = 0; j < N; ++j) o[j] = (float)qd[j];
+    RunIO<float, N>::store(vel, b * Nt + i, o);
+#pragma unroll
+    for (int j = 0; j < N; ++j) o[j] = (float)last[j];
+    RunIO<float, N>::store(acc, b * Nt + i, o);
+  }
+}
+
 inline unsigned grid_for(long rows) { return (unsigned)((rows + kBlock - 1) / kBlock); }
 
 // float32 variant selection (A/B switch for profiling): MANIPULAPY_HIP_F32 = "packed" (default) | "scalar"
@@ -396,3 +487,43 @@ template hipError_t mpk_fk_jac_id<float>(hipStream_t, const MpModel<float>&, con
                                          const float*, const float*, float*, float*, float*, long);
 template hipError_t mpk_fk_jac_id<double>(hipStream_t, const MpModel<double>&, const MpCall<double>&, bool,
                                           const double*, const double*, const double*, double*, double*, double*, long);
+
+template <typename T>
+hipError_t mpk_mass_matrix(hipStream_t s, const MpModel<T>& M, const T* q, T* Mout, long rows) {
+  if (rows <= 0) return hipSuccess;
+  MP_DISPATCH_N(M.n, { hipLaunchKernelGGL((k_mass_matrix<T, N>), dim3(grid_for(rows)), dim3(kBlock), 0, s, M, q, Mout, rows); })
+  return hipGetLastError();
+}
+template hipError_t mpk_mass_matrix<float>(hipStream_t, const MpModel<float>&, const float*, float*, long);
+template hipError_t mpk_mass_matrix<double>(hipStream_t, const MpModel<double>&, const double*, double*, long);
+
+template <typename T>
+hipError_t mpk_forward_dynamics(hipStream_t s, const MpModel<T>& M, const MpCall<T>& C, bool ftip, const T* q, const T* qd,
+                                const T* tau, T* qdd, long rows) {
+  if (rows <= 0) return hipSuccess;
+  MP_DISPATCH_N(M.n, {
+    if (ftip) hipLaunchKernelGGL((k_forward_dynamics<T, N, true>), dim3(grid_for(rows)), dim3(kBlock), 0, s, M, C, q, qd, tau, qdd, rows);
+    else hipLaunchKernelGGL((k_forward_dynamics<T, N, false>), dim3(grid_for(rows)), dim3(kBlock), 0, s, M, C, q, qd, tau, qdd, rows);
+  })
+  return hipGetLastError();
+}
+template hipError_t mpk_forward_dynamics<float>(hipStream_t, const MpModel<float>&, const MpCall<float>&, bool, const float*,
+                                                const float*, const float*, float*, long);
+template hipError_t mpk_forward_dynamics<double>(hipStream_t, const MpModel<double>&, const MpCall<double>&, bool,
+                                                 const double*, const double*, const double*, double*, long);
+
+template <typename T>
+hipError_t mpk_fd_traj(hipStream_t s, const MpModel<T>& M, const MpCall<T>& C, const T* theta0, const T* dtheta0,
+                       const T* taumat, const T* Ftipmat, long B, long Nt, T h, int intRes, float* pos, float* vel, float* acc) {
+  if (B <= 0 || Nt <= 0) return hipSuccess;
+  MP_DISPATCH_N(M.n, {
+    if (Ftipmat) hipLaunchKernelGGL((k_fd_traj<T, N, true>), dim3(grid_for(B)), dim3(kBlock), 0, s, M, C, theta0, dtheta0, taumat, Ftipmat, B, Nt, h, intRes, pos, vel, acc);
+    else hipLaunchKernelGGL((k_fd_traj<T, N, false>), dim3(grid_for(B)), dim3(kBlock), 0, s, M, C, theta0, dtheta0, taumat, Ftipmat, B, Nt, h, intRes, pos, vel, acc);
+  })
+  return hipGetLastError();
+}
+template hipError_t mpk_fd_traj<float>(hipStream_t, const MpModel<float>&, const MpCall<float>&, const float*, const float*,
+                                       const float*, const float*, long, long, float, int, float*, float*, float*);
+template hipError_t mpk_fd_traj<double>(hipStream_t, const MpModel<double>&, const MpCall<double>&, const double*,
+                                        const double*, const double*, const double*, long, long, double, int, float*, float*,
+                                        float*);

@@ -3,16 +3,16 @@
 Same constructor signature (dynamics/manipulator_dynamics.py:43-86) and the same public methods:
 mass_matrix (mass_matrix.py:16-99), velocity_quadratic_forces / gravity_forces (forces.py:26-133),
 inverse_dynamics / forward_dynamics (id_fd.py:16-83), partial_derivative (forces.py:16-24).
-Every method evaluates the HIP inverse-dynamics kernel through the kernel registry
-("dynamics.inverse_trajectory", float64):
+Every method evaluates a HIP kernel through the kernel registry (float64):
 
-    inverse_dynamics(q, qd, qdd, g, F)      = ID(q, qd, qdd, g, F)
-    gravity_forces(q, g)                    = ID(q, 0, 0, g, 0)
-    velocity_quadratic_forces(q, qd)        = ID(q, qd, 0, 0, 0)
-    mass_matrix(q)[:, j]                    = ID(q, 0, e_j, 0, 0)        (one n-row launch)
-    forward_dynamics(q, qd, tau, g, F)      = solve(M, tau - ID(q, qd, 0, g, F))
+    inverse_dynamics(q, qd, qdd, g, F)      "dynamics.inverse_trajectory"   ID(q, qd, qdd, g, F)
+    gravity_forces(q, g)                    "dynamics.inverse_trajectory"   ID(q, 0, 0, g, 0)
+    velocity_quadratic_forces(q, qd)        "dynamics.inverse_trajectory"   ID(q, qd, 0, 0, 0)
+    mass_matrix(q)                          "dynamics.mass_matrix"          columns ID(q, 0, e_j, 0, 0), symmetrised
+    forward_dynamics(q, qd, tau, g, F)      "dynamics.forward"              solve(M, tau - ID(q, qd, 0, g, F))
 
-which are exact identities of tau = M qdd + c + g + Js^T F.  There is no value-keyed cache (the
+which are exact identities of tau = M qdd + c + g + Js^T F.  2-D inputs (rows, n) evaluate all rows
+in one launch.  There is no value-keyed cache (the
 reference's caches exist to amortise its 1 + 2n mass-matrix evaluations per point, which the
 analytic recursion does not need) and no legacy (Mlist_per_link=None) approximation.
 """
@@ -60,11 +60,10 @@ class ManipulatorDynamics(SerialManipulator):
 
     # ---- public API
     def mass_matrix(self, thetalist) -> np.ndarray:
-        q = np.asarray(thetalist, dtype=np.float64)
-        n = q.shape[0]
-        Q = np.tile(q, (n, 1))
-        M = self._id(Q, np.zeros((n, n)), np.eye(n), _ZERO3, None).T  # row j = M e_j -> transpose to columns
-        return 0.5 * (M + M.T)  # the reference symmetrises (mass_matrix.py:96)
+        """(n, n) mass matrix, or (rows, n, n) for a 2-D `thetalist`."""
+        q = np.atleast_2d(np.asarray(thetalist, dtype=np.float64))
+        M = execute_registered_kernel("dynamics.mass_matrix", self.hip_model(), q)
+        return M if np.ndim(thetalist) == 2 else M[0]
 
     def velocity_quadratic_forces(self, thetalist, dthetalist) -> np.ndarray:
         q = np.asarray(thetalist, dtype=np.float64)[None, :]
@@ -84,17 +83,12 @@ class ManipulatorDynamics(SerialManipulator):
         return self._id(q, qd, qdd, g, Ftip)[0]
 
     def forward_dynamics(self, thetalist, dthetalist, taulist, g, Ftip) -> np.ndarray:
-        q = np.asarray(thetalist, dtype=np.float64)
-        n = q.shape[0]
-        # one launch: rows 0..n-1 give M's columns, row n gives the bias c + g + Js^T F
-        Q = np.tile(q, (n + 1, 1))
-        Qd = np.zeros((n + 1, n))
-        Qd[n] = np.asarray(dthetalist, dtype=np.float64)
-        Qdd = np.vstack([np.eye(n), np.zeros((1, n))])
-        bias = self._id(Q[n:], Qd[n:], Qdd[n:], g, Ftip)[0]
-        M = self._id(Q[:n], Qd[:n], Qdd[:n], _ZERO3, None).T
-        M = 0.5 * (M + M.T)
-        return np.linalg.solve(M, np.asarray(taulist, dtype=np.float64) - bias)
+        """qdd (n,), or (rows, n) for 2-D inputs (one g / Ftip for all rows)."""
+        q = np.atleast_2d(np.asarray(thetalist, dtype=np.float64))
+        qd = np.atleast_2d(np.asarray(dthetalist, dtype=np.float64))
+        tau = np.atleast_2d(np.asarray(taulist, dtype=np.float64))
+        qdd = execute_registered_kernel("dynamics.forward", self.hip_model(), q, qd, tau, g, Ftip)
+        return qdd if np.ndim(thetalist) == 2 else qdd[0]
 
     def partial_derivative(self, i: int, j: int, k: int, thetalist, epsilon: float = 1e-6) -> float:
         """dM[i, j] / dtheta_k by the reference's central difference (dynamics/cache.py:39-52)."""

@@ -17,7 +17,8 @@ What is different, on purpose:
     implementation; trajectory GENERATION does have its NumPy path (BASELINE config 0);
   * collision avoidance is absent (host-only, mesh-dependent, a no-op without meshes — SURVEY §8c);
   * `batch_inverse_dynamics_trajectory` is new: joint_trajectory -> inverse_dynamics_trajectory fused
-    on the device for B start/end pairs.
+    on the device for B start/end pairs; `batch_forward_dynamics_trajectory` is new: B roll-outs of
+    forward_dynamics_trajectory (planning/trajectory_dynamics.py:580-708) in one launch.
 """
 from __future__ import annotations
 
@@ -195,6 +196,39 @@ class OptimizedTrajectoryPlanning:
                                              int(method), gravity_vector, Ftip)
         self._count("gpu", t0)
         return get_backend().asarray(tau)
+
+    def forward_dynamics_trajectory(self, thetalist, dthetalist, taumat, g, Ftipmat, dt, intRes) -> Dict[str, np.ndarray]:
+        """Semi-implicit Euler roll-out of ONE trajectory (reference planning/trajectory_dynamics.py:382-423,
+        :580-708): positions / velocities / accelerations, each (N, n) float32.  The state is integrated in the
+        dtype of `thetalist` (float32 stays float32, everything else float64), as the reference does."""
+        th = np.asarray(thetalist)
+        tm = np.asarray(taumat)
+        if tm.ndim != 2:
+            raise ValueError(f"taumat must be (N, n); got {tm.shape}")
+        if tm.shape[0] == 0:  # the reference seeds row 0 unconditionally (:614-617)
+            raise IndexError("index 0 is out of bounds for axis 0 with size 0")
+        Fm = None if Ftipmat is None else np.asarray(Ftipmat)[None]
+        r = self.batch_forward_dynamics_trajectory(th[None], np.asarray(dthetalist)[None], tm[None], g, Fm, dt, intRes)
+        return {k: v[0] for k, v in r.items()}
+
+    def batch_forward_dynamics_trajectory(self, theta0_batch, dtheta0_batch, taumat_batch, g, Ftipmat_batch, dt, intRes
+                                          ) -> Dict[str, np.ndarray]:
+        """B independent roll-outs in one launch: theta0 / dtheta0 (B, n), taumat (B, N, n), Ftipmat (B, N, 6) or
+        None -> (B, N, n) float32 arrays.  New (the reference integrates one trajectory per call)."""
+        th = np.asarray(theta0_batch)
+        if th.ndim != 2:
+            raise ValueError(f"initial states must be (B, n); got {th.shape}")
+        dtype = np.float32 if th.dtype == np.float32 else np.float64
+        t0 = time.time()
+        if not self._gpu_routed():
+            _reg.get_registered_kernel("dynamics.forward_trajectory").cpu_launcher()  # raises BackendNotSupportedError
+        if g is None:
+            g = np.array([0.0, 0.0, -9.81])
+        pos, vel, acc = _reg.execute_registered_kernel("dynamics.forward_trajectory", self._hip_model(), th, dtheta0_batch,
+                                                       taumat_batch, g, Ftipmat_batch, dt, int(intRes), dtype=dtype)
+        self._count("gpu", t0)
+        b = get_backend()
+        return {"positions": b.asarray(pos), "velocities": b.asarray(vel), "accelerations": b.asarray(acc)}
 
     # ------------------------------------------------------------------ helpers kept from the reference
     def calculate_derivatives(self, positions, dt) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:

@@ -229,6 +229,18 @@ def _launch_fk_jac_gpu(model, q, qd=None, qdd=None, g=None, Ftip=None, want_T=Tr
     return get_context().fk_jac_id_host(model, q, qd, qdd, g, Ftip, want_T, want_J)
 
 
+def _launch_mass_matrix_gpu(model, q):
+    return get_context().mass_matrix_host(model, q)
+
+
+def _launch_forward_dynamics_gpu(model, q, qd, tau, g=None, Ftip=None):
+    return get_context().forward_dynamics_host(model, q, qd, tau, g, Ftip)
+
+
+def _launch_fd_trajectory_gpu(model, theta0, dtheta0, taumat, g, Ftipmat, dt, intRes, dtype=np.float64):
+    return get_context().fd_trajectory_host(model, theta0, dtheta0, taumat, g, Ftipmat, dt, intRes, dtype=dtype)
+
+
 def _grid_1d(rows: int, block: int = 256):
     """Launch shape every kernel uses: one thread per (trajectory, timestep) row, 256-thread blocks
     (4 wavefronts of 64).  Replaces the CUDA block heuristics of reference registry.py:409-515."""
@@ -266,6 +278,9 @@ def _build_kernel_registry() -> KernelRegistry:
         ("dynamics.inverse_trajectory", "mp_id_trajectory_host_f32 / _f64", _launch_id_gpu),
         ("dynamics.fused_trajectory_inverse", "mp_traj_id_fused_host_f32", _launch_fused_gpu),
         ("kinematics.fk_jacobian", "mp_fk_jac_id_host_f64", _launch_fk_jac_gpu),
+        ("dynamics.mass_matrix", "mp_mass_matrix_host_f64", _launch_mass_matrix_gpu),
+        ("dynamics.forward", "mp_forward_dynamics_host_f64", _launch_forward_dynamics_gpu),
+        ("dynamics.forward_trajectory", "mp_fd_trajectory_host_f32 / _f64", _launch_fd_trajectory_gpu),
     ):
         reg.register(KernelRegistration(
             name=name, implementation=impl, launch_config=_grid_1d, cpu_fallback=None, gpu_launcher=gpu,

@@ -81,6 +81,86 @@ int run(const MpModel<double>& Md, const MpCall<double>& Cd, bool ftip, long row
 }
 }  // namespace
 
+namespace {
+// forward-dynamics pieces on the host: mode 0 = mass matrix (out: rows x n x n), 1 = forward dynamics
+// (out: rows x n), 2 = one trajectory roll-out like k_fd_traj (out: 3 x N x n, float32 rounded rows)
+template <typename T, int N>
+void run_fd(const MpModel<T>& M, const MpCall<T>& C, int mode, long rows, const double* q, const double* qd,
+            const double* tau, const double* Ftipmat, double dt, int intRes, double* out) {
+  if (mode == 0) {
+    for (long r = 0; r < rows; ++r) {
+      T a[N];
+      for (int j = 0; j < N; ++j) a[j] = (T)q[r * N + j];
+      MpJointState<T, N> js;
+      mp_joint_state<T, N>(M, a, js);
+      T Mq[N][N];
+      mp_mass_matrix<T, N>(M, js, Mq);
+      for (int i = 0; i < N; ++i)
+        for (int j = 0; j < N; ++j) out[(r * N + i) * N + j] = (double)Mq[i][j];
+    }
+  } else if (mode == 1) {
+    const T tn[3] = {C.F1n[0], C.F1n[1], C.F1n[2]}, tf[3] = {C.F1f[0], C.F1f[1], C.F1f[2]};
+    for (long r = 0; r < rows; ++r) {
+      T a[N], b[N], t[N], o[N];
+      for (int j = 0; j < N; ++j) { a[j] = (T)q[r * N + j]; b[j] = (T)qd[r * N + j]; t[j] = (T)tau[r * N + j]; }
+      mp_forward_dynamics<T, N, true>(M, C.a0, tn, tf, a, b, t, o);
+      for (int j = 0; j < N; ++j) out[r * N + j] = (double)o[j];
+    }
+  } else {
+    const long Nt = rows;  // rows = timesteps of ONE trajectory; q / qd hold the initial state
+    T a[N], b[N];
+    for (int j = 0; j < N; ++j) { a[j] = (T)q[j]; b[j] = (T)qd[j]; }
+    double* pos = out; double* vel = out + Nt * N; double* acc = out + 2 * Nt * N;
+    for (int j = 0; j < N; ++j) { pos[j] = (float)a[j]; vel[j] = (float)b[j]; acc[j] = 0; }
+    const T h = intRes > 0 ? (T)(dt / intRes) : (T)0;
+    for (long i = 1; i < Nt; ++i) {
+      T t[N], tn[3] = {0, 0, 0}, tf[3] = {0, 0, 0}, last[N];
+      for (int j = 0; j < N; ++j) { t[j] = (T)tau[i * N + j]; last[j] = 0; }
+      if (Ftipmat) {
+        T F[6];
+        for (int k = 0; k < 6; ++k) F[k] = (T)Ftipmat[i * 6 + k];
+        mp_wrench_to_frame1(M, F, tn, tf);
+      }
+      for (int s = 0; s < intRes; ++s) {
+        mp_forward_dynamics<T, N, true>(M, C.a0, tn, tf, a, b, t, last);
+        for (int j = 0; j < N; ++j) {
+          b[j] = b[j] + last[j] * h;
+          a[j] = mp_clip(a[j] + b[j] * h, M.qmin[j], M.qmax[j]);
+        }
+      }
+      for (int j = 0; j < N; ++j) { pos[i * N + j] = (float)a[j]; vel[i * N + j] = (float)b[j]; acc[i * N + j] = (float)last[j]; }
+    }
+  }
+}
+template <typename T>
+int run_fd_t(const MpModel<double>& Md, const MpCall<double>& Cd, int mode, long rows, const double* q, const double* qd,
+             const double* tau, const double* Ftipmat, double dt, int intRes, double* out) {
+  MpModel<T> M;
+  MpCall<T> C;
+  mp_model_cast(Md, &M);
+  mp_call_cast(Cd, &C);
+  switch (Md.n) {
+#define CASE(N) case N: run_fd<T, N>(M, C, mode, rows, q, qd, tau, Ftipmat, dt, intRes, out); return 0;
+    CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
+#undef CASE
+  }
+  return 1;
+}
+}  // namespace
+
+extern "C" int hostsim_fd(int n, const double* S, const double* Mcom, const double* G, const double* M_ee,
+                          const double* joint_limits, const double* g, const double* Ftip, int mode, long rows,
+                          const double* q, const double* qd, const double* tau, const double* Ftipmat, double dt, int intRes,
+                          int use_f32, double* out, char* err, long errlen) {
+  MpModel<double> Md;
+  int rc = mp_compile_model(n, S, Mcom, G, M_ee, joint_limits, nullptr, &Md, err, (size_t)errlen);
+  if (rc) return rc;
+  MpCall<double> Cd;
+  mp_make_call(Md, g, Ftip, &Cd);
+  return use_f32 ? run_fd_t<float>(Md, Cd, mode, rows, q, qd, tau, Ftipmat, dt, intRes, out)
+                 : run_fd_t<double>(Md, Cd, mode, rows, q, qd, tau, Ftipmat, dt, intRes, out);
+}
+
 extern "C" int hostsim_run(int n, const double* S, const double* Mcom, const double* G, const double* M_ee,
                            const double* joint_limits, const double* torque_limits, const double* g,
                            const double* Ftip, long rows, const double* q, const double* qd, const double* qdd,

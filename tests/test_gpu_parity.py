@@ -342,3 +342,58 @@ def test_2r_planar_analytical_on_gpu(ctx):
         c1, c12 = np.cos(th[r, 0]), np.cos(th[r, 0] + th[r, 1])
         gv = np.array([(m1 + m2) * 9.81 * l1 * c1 + m2 * 9.81 * l2 * c12, m2 * 9.81 * l2 * c12])
         np.testing.assert_allclose(tau[r], M @ ddq[r] + c + gv, rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("robot", ROBOTS)
+def test_mass_matrix_and_forward_dynamics_kernels(robot, ctx, models, dyn_golden):
+    z = dyn_golden[robot]
+    M = ctx.mass_matrix_host(models[robot], z["thetas"])
+    np.testing.assert_allclose(M, z["mass_matrix"], rtol=1e-9, atol=1e-11)  # no finite difference in M: tight
+    np.testing.assert_array_equal(M, np.swapaxes(M, 1, 2))                  # symmetrised like the reference
+    assert (np.linalg.eigvalsh(M) > 0).all()
+    for i in range(len(z["thetas"])):
+        qdd = ctx.forward_dynamics_host(models[robot], z["thetas"][i:i + 1], z["dthetas"][i:i + 1],
+                                        z["inverse_dynamics"][i:i + 1], z["g"], z["ftips"][i])
+        # FD(ID(qdd)) == qdd: the recorded reference value carries its own finite-difference noise times M^-1
+        np.testing.assert_allclose(qdd[0], z["forward_dynamics"][i], rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(qdd[0], z["ddthetas"][i], rtol=1e-6, atol=1e-6)  # tau_ref carries ~3e-9 FD noise, times M^-1
+
+
+def test_forward_dynamics_trajectory_fixture_and_oracle(tables):
+    """forward_dynamics_trajectory vs the reference's planner dump (xarm6, N=8, intRes=2, per-step wrench)."""
+    import manipulapy_amd as mp
+
+    z = np.load(golden_path("fd_trajectory_xarm6.npz"))
+    sm, dyn, _ = mp.load_robot("xarm6")
+    with mp.use_backend("hip"):
+        pl = mp.OptimizedTrajectoryPlanning(sm, None, dyn, z["joint_limits"])
+        r = pl.forward_dynamics_trajectory(z["theta0"], z["dtheta0"], z["taumat"], z["g"], z["Ftipmat"], float(z["dt"]), int(z["intRes"]))
+        for k in ("positions", "velocities", "accelerations"):
+            assert r[k].dtype == np.float32 and r[k].shape == (8, 6)
+            np.testing.assert_allclose(r[k], z[k], rtol=2e-6, atol=2e-6 * max(1.0, float(np.abs(z[k]).max())))
+        np.testing.assert_array_equal(r["accelerations"][0], 0)
+        # float32 state: looser (1e-4 rel of the column scale), same trajectory
+        r32 = pl.forward_dynamics_trajectory(z["theta0"].astype(np.float32), z["dtheta0"].astype(np.float32),
+                                             z["taumat"].astype(np.float32), z["g"], z["Ftipmat"].astype(np.float32),
+                                             float(z["dt"]), int(z["intRes"]))
+        for k in ("positions", "velocities", "accelerations"):
+            assert np.abs(r32[k] - z[k]).max() <= 1e-4 * max(1.0, float(np.abs(z[k]).max()))
+        with pytest.raises(IndexError):
+            pl.forward_dynamics_trajectory(z["theta0"], z["dtheta0"], np.zeros((0, 6)), z["g"], np.zeros((0, 6)), 0.01, 1)
+        # batch of 3 different roll-outs == 3 single calls; no wrench; joint-limit clip engages
+        rng = np.random.default_rng(5)
+        B, N = 3, 12
+        th0 = rng.uniform(-0.5, 0.5, (B, 6)); dth0 = rng.uniform(-0.2, 0.2, (B, 6)); tm = rng.uniform(-1, 1, (B, N, 6))
+        lim = z["joint_limits"].copy(); lim[1] = [-0.05, 0.05]
+        th0[:, 1] = 0.0
+        pl2 = mp.OptimizedTrajectoryPlanning(sm, None, dyn, lim)
+        rb = pl2.batch_forward_dynamics_trajectory(th0, dth0, tm, z["g"], None, 0.02, 1)
+        assert rb["positions"].shape == (B, N, 6)
+        assert rb["positions"][:, :, 1].max() <= np.float32(0.05) and rb["positions"][:, :, 1].min() >= np.float32(-0.05)
+        tab = ref.load_tables(golden_path("model_xarm6.npz"))
+        for b in range(B):
+            one = pl2.forward_dynamics_trajectory(th0[b], dth0[b], tm[b], z["g"], None, 0.02, 1)
+            np.testing.assert_array_equal(one["positions"], rb["positions"][b])
+            o = ref.forward_dynamics_trajectory(tab, th0[b], dth0[b], tm[b], z["g"], np.zeros((N, 6)), 0.02, 1, joint_limits=lim)
+            for k in ("positions", "velocities", "accelerations"):
+                np.testing.assert_allclose(one[k], o[k], rtol=1e-5, atol=1e-5 * max(1.0, float(np.abs(o[k]).max())))

@@ -118,6 +118,19 @@ def hostsim():
                              P(qdd), int(f32), P(tau), P(T), P(J), None, err, ctypes.c_long(256))
         assert rc == 0, err.value
         return tau, T, J
+
+    def fd(tab, mode, rows, q, qd, tau, g, Ftip, Ftipmat=None, dt=0.0, intRes=0, f32=0, outshape=None):
+        P = lambda a: None if a is None else a.ctypes.data_as(dp)
+        c = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+        S, Mc, G, Me, jl = c(tab.S), c(tab.Mcom), c(tab.G), c(tab.M_ee), c(tab.joint_limits)
+        q, qd, tau, g, Ftip, Ftipmat = c(q), c(qd), c(tau), c(g), c(Ftip), c(Ftipmat)
+        out = np.zeros(outshape)
+        err = ctypes.create_string_buffer(256)
+        rc = lib.hostsim_fd(tab.n, P(S), P(Mc), P(G), P(Me), P(jl), P(g), P(Ftip), mode, ctypes.c_long(rows), P(q), P(qd), P(tau),
+                            P(Ftipmat), ctypes.c_double(dt), intRes, f32, P(out), err, ctypes.c_long(256))
+        assert rc == 0, err.value
+        return out
+    run.fd = fd
     return run
 
 
@@ -134,6 +147,31 @@ def test_device_math_matches_golden_on_host(robot, hostsim, tables, dyn_golden):
         for mode in (1, 2):  # float32 one row per lane / two rows per lane (packed)
             t32, _, _ = hostsim(tab, *a, mode)
             assert (np.abs(t32[0] - want) <= 1e-4 * np.abs(want) + 1e-4 * np.abs(want).max()).all()
+
+
+@pytest.mark.parametrize("robot", ROBOTS)
+def test_device_mass_matrix_and_forward_dynamics_on_host(robot, hostsim, tables, dyn_golden):
+    tab, z = tables[robot], dyn_golden[robot]
+    K, n = len(z["thetas"]), tab.n
+    M = hostsim.fd(tab, 0, K, z["thetas"], None, None, z["g"], np.zeros(6), outshape=(K, n, n))
+    np.testing.assert_allclose(M, z["mass_matrix"], rtol=1e-9, atol=1e-11)
+    for i in range(0, K, 3):
+        qdd = hostsim.fd(tab, 1, 1, z["thetas"][i:i + 1], z["dthetas"][i:i + 1], z["inverse_dynamics"][i:i + 1], z["g"], z["ftips"][i],
+                         outshape=(1, n))
+        np.testing.assert_allclose(qdd[0], z["forward_dynamics"][i], rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(qdd[0], z["ddthetas"][i], rtol=1e-6, atol=1e-6)  # tau_ref carries ~3e-9 FD noise, times M^-1
+
+
+def test_device_fd_trajectory_on_host(hostsim):
+    z = np.load(golden_path("fd_trajectory_xarm6.npz"))
+    tab = ref.load_tables(golden_path("model_xarm6.npz"))
+    tab.joint_limits = z["joint_limits"]
+    N = z["taumat"].shape[0]
+    for f32, tol in ((0, 2e-6), (1, 1e-4)):
+        out = hostsim.fd(tab, 2, N, z["theta0"], z["dtheta0"], z["taumat"], z["g"], np.zeros(6), z["Ftipmat"], float(z["dt"]),
+                         int(z["intRes"]), f32, outshape=(3, N, 6))
+        for k, key in enumerate(("positions", "velocities", "accelerations")):
+            assert np.abs(out[k] - z[key]).max() <= tol * max(1.0, float(np.abs(z[key]).max()))
 
 
 def test_float32_sincos_accuracy(hostsim, tables):
@@ -177,9 +215,10 @@ def test_kernel_registry_semantics():
     names = registry._KERNEL_REGISTRY.names()
     for v in ("auto", "auto_tune", "standard", "vectorized", "memory_optimized", "warp_optimized", "cache_friendly"):
         assert f"trajectory.{v}" in names
-    for n in ("trajectory.batch", "dynamics.inverse_trajectory", "dynamics.fused_trajectory_inverse", "kinematics.fk_jacobian"):
+    for n in ("trajectory.batch", "dynamics.inverse_trajectory", "dynamics.fused_trajectory_inverse", "kinematics.fk_jacobian",
+              "dynamics.mass_matrix", "dynamics.forward", "dynamics.forward_trajectory"):
         assert n in names
-    with pytest.raises(KeyError, match="Available kernels: dynamics.fused_trajectory_inverse"):
+    with pytest.raises(KeyError, match="Available kernels: dynamics.forward, dynamics.forward_trajectory"):
         mp.get_registered_kernel("trajectory.nope")
     entry = mp.get_registered_kernel("trajectory.standard")
     with pytest.raises(ValueError, match="already registered"):
