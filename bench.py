@@ -117,6 +117,7 @@ def bench_fd(args, cfg, info, hg, ctx, model, t, props):
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": cfg["dtype"], "data": "synthetic",
         "config": {"workload": cfg["desc"], "robot": cfg["robot"], "dof": n, "B_per_gpu": B, "N": N, "op": cfg["op"],
+                   "kernel_variant": "robot-specialised (hiprtc)" if cfg["specialized"] else "generic",
                    "sharding": f"batch axis over {world} rank(s), no collective in the timed step"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                      "traffic": None, "kernel": "k_fd_traj", "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes,
@@ -148,6 +149,7 @@ def main():
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="multi-GPU: skip the all-gather (compute-only figure)")
+    ap.add_argument("--no-specialize", action="store_true", help="use the generic kernels (no run-time robot specialisation)")
     ap.add_argument("--B", type=int, default=0, help="experiments only: override the config's trajectories per GPU")
     ap.add_argument("--N", type=int, default=0, help="experiments only: override the config's timesteps")
     args = ap.parse_args()
@@ -178,6 +180,9 @@ def main():
     ctx.selftest()
     props = ctx.properties()
     model = _hip.HipModel(t["S_list"], t["Mlist_per_link"], t["Glist"], t["M_ee"], t["joint_limits"])
+    if not args.no_specialize and cfg["dtype"] == "f32":
+        ctx.specialize(model)  # setup, untimed: hiprtc build of this robot's kernels (cached on disk)
+    cfg["specialized"] = ctx.is_specialized(model)
 
     if cfg["op"] == "fd_traj":
         return bench_fd(args, cfg, info, hg, ctx, model, t, props)
@@ -259,6 +264,7 @@ def main():
         "dtype": cfg["dtype"], "data": "synthetic",
         "config": {"workload": cfg["desc"], "robot": cfg["robot"], "dof": n, "B_per_gpu": B, "N": N,
                    "rows_per_gpu": rows, "op": cfg["op"], "inputs": "q/qd/qdd histories resident in HBM",
+                   "kernel_variant": "robot-specialised (hiprtc)" if cfg["specialized"] else "generic",
                    "sharding": f"batch axis over {world} rank(s)" + ("" if world == 1 else
                                (", no gather" if args.no_gather else ", RCCL all-gather of tau each step"))},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -87,8 +87,24 @@ int mp_model_destroy(mp_model* model);
 int mp_model_dof(const mp_model* model, int* n);
 /* Compiled per-joint parameters, 16 doubles per joint (see csrc/mp_model.h): for inspection/tests. */
 int mp_model_params(const mp_model* model, double* out /* n*16 */);
+/* The whole compiled model as the kernels receive it (struct MpModel<float|double>, csrc/mp_model.h):
+ * *bytes = its size; out may be NULL to query the size.  Used by the kernel specialiser and by tests. */
+int mp_model_blob(const mp_model* model, int use_f64, void* out, size_t* bytes);
 /* End-effector pose through the compiled chain on the HOST in float64 (model self-check helper). */
 int mp_model_fk_host(const mp_model* model, const double* q /* n */, double* T /* 16 */);
+
+/* ---- run-time specialisation (new; csrc/mp_jit.cpp) -------------------------------------------------
+ * Compile the float32 kernels with THIS robot's constants baked in (hiprtc, gfx950; on-disk cache in
+ * MANIPULAPY_HIP_CACHE or <library dir>/jit_cache) and load them on the context's device.  Afterwards
+ * mp_id_trajectory_f32 / mp_traj_id_fused_f32 / mp_fd_trajectory_f32 (+ their *_host forms) use them for
+ * this (context, model) pair; every other entry point keeps using the generic kernels.  Idempotent.
+ * MANIPULAPY_HIP_SPECIALIZE=0 makes the launchers ignore specialised kernels (A/B measurements). */
+int mp_model_specialize(mp_ctx* ctx, const mp_model* model);
+int mp_model_is_specialized(mp_ctx* ctx, const mp_model* model, int* yes);
+/* Generate + compile only (needs hiprtc, no GPU): code-object size and whether it came from the cache. */
+int mp_model_specialize_compile(const mp_model* model, size_t* code_bytes, int* from_cache);
+/* The generated translation unit (NUL-terminated).  *len = required size incl. NUL; buf may be NULL. */
+int mp_model_specialize_source(const mp_model* model, char* buf, size_t* len);
 
 /* ---- hot path, device pointers ----------------------------------------------------------------
  * g: (3,) gravity vector or NULL (= [0,0,-9.81], planning/trajectory_dynamics.py:54);

@@ -64,6 +64,11 @@ SIGNATURES = {
     "mp_model_dof": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int)]),
     "mp_model_params": (ctypes.c_int, [_vp, _c_dp]),
     "mp_model_fk_host": (ctypes.c_int, [_vp, _c_dp, _c_dp]),
+    "mp_model_specialize": (ctypes.c_int, [_vp, _vp]),
+    "mp_model_is_specialized": (ctypes.c_int, [_vp, _vp, ctypes.POINTER(ctypes.c_int)]),
+    "mp_model_specialize_compile": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_int)]),
+    "mp_model_specialize_source": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_size_t)]),
+    "mp_model_blob": (ctypes.c_int, [_vp, ctypes.c_int, _vp, ctypes.POINTER(ctypes.c_size_t)]),
     "mp_batch_trajectory_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, ctypes.c_double, ctypes.c_int, _vp, _vp, _vp]),
     "mp_id_trajectory_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _c_dp, _c_dp, _vp]),
     "mp_id_trajectory_f64": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _c_dp, _c_dp, _vp]),
@@ -236,6 +241,42 @@ class HipModel:
         _check(self.lib.mp_model_params(self.handle, _dptr(out)))
         return out
 
+    def specialize_source(self) -> str:
+        """The translation unit the run-time specialiser compiles for this robot."""
+        n = ctypes.c_size_t(0)
+        _check(self.lib.mp_model_specialize_source(self.handle, None, ctypes.byref(n)))
+        buf = ctypes.create_string_buffer(n.value)
+        _check(self.lib.mp_model_specialize_source(self.handle, buf, ctypes.byref(n)))
+        return buf.value.decode()
+
+    def specialize_compile(self):
+        """hiprtc-compile the specialised kernels (no GPU needed): (code bytes, came from the disk cache)."""
+        nb, cached = ctypes.c_size_t(0), ctypes.c_int(0)
+        _check(self.lib.mp_model_specialize_compile(self.handle, ctypes.byref(nb), ctypes.byref(cached)))
+        return int(nb.value), bool(cached.value)
+
+    def blob(self, dtype=np.float32) -> dict:
+        """The compiled model as the kernels see it, unpacked by field (csrc/mp_model.h layout)."""
+        f64 = np.dtype(dtype) == np.float64
+        nb = ctypes.c_size_t(0)
+        _check(self.lib.mp_model_blob(self.handle, int(f64), None, ctypes.byref(nb)))
+        raw = np.zeros(nb.value, dtype=np.uint8)
+        _check(self.lib.mp_model_blob(self.handle, int(f64), raw.ctypes.data_as(_vp), ctypes.byref(nb)))
+        w = 8 if f64 else 4
+        head = 16 if not f64 else 16  # int n + 3 pad ints
+        vals = raw[head:].view(np.float64 if f64 else np.float32)
+        o = 0
+        def take(k):
+            nonlocal o
+            v = vals[o:o + k].copy(); o += k
+            return v
+        d = {"n": int(raw[:4].view(np.int32)[0]), "base_R": take(9), "base_p": take(3), "tool_R": take(9), "tool_p": take(3)}
+        d["joints"] = take(16 * MP_MAX_DOF).reshape(MP_MAX_DOF, 16)
+        for k in ("qmin", "qmax", "taumin", "taumax"):
+            d[k] = take(MP_MAX_DOF)
+        assert o * w + head == nb.value, (o * w + head, nb.value)
+        return d
+
     def fk_host(self, q) -> np.ndarray:
         q = _as_c(q, np.float64, (self.n,), "q")
         T = np.zeros((4, 4))
@@ -284,6 +325,15 @@ class HipContext:
         # key names follow the reference's get_gpu_properties() (cuda_kernels/registry.py:335-356)
         return {"name": name.value.decode(), "multiprocessor_count": int(cu.value), "total_memory": int(mem.value),
                 "warp_size": 64}
+
+    def specialize(self, model: "HipModel") -> None:
+        """Load (compiling if needed) float32 kernels specialised for `model` on this device."""
+        _check(self.lib.mp_model_specialize(self.handle, model.handle))
+
+    def is_specialized(self, model: "HipModel") -> bool:
+        yes = ctypes.c_int(0)
+        _check(self.lib.mp_model_is_specialized(self.handle, model.handle, ctypes.byref(yes)))
+        return bool(yes.value)
 
     def alloc(self, nbytes: int) -> DeviceBuffer:
         return DeviceBuffer(self, nbytes)

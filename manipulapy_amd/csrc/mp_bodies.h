@@ -1,0 +1,180 @@
+// Device-side building blocks shared by the ahead-of-time kernels (mp_kernels.hip) and the run-time
+// specialised kernels (mp_jit.cpp compiles thin wrappers around the same bodies with one robot's
+// constants baked in).  Device code only; include after <hip/hip_runtime.h> (hipcc) or stand-alone (hiprtc).
+#pragma once
+
+#include "mp_core.h"
+
+// ---- widest legal vector type for a run of COUNT elements of T whose start is COUNT*sizeof(T)-strided
+template <typename T, int BYTES> struct VecOf;
+template <> struct VecOf<float, 16> { using type = float4; static constexpr int K = 4; };
+template <> struct VecOf<float, 8> { using type = float2; static constexpr int K = 2; };
+template <> struct VecOf<float, 4> { using type = float; static constexpr int K = 1; };
+template <> struct VecOf<double, 16> { using type = double2; static constexpr int K = 2; };
+template <> struct VecOf<double, 8> { using type = double; static constexpr int K = 1; };
+
+template <typename T, int COUNT>
+struct RunIO {
+  static constexpr int BYTES = COUNT * (int)sizeof(T);
+  static constexpr int W = (BYTES % 16 == 0) ? 16 : (BYTES % 8 == 0) ? 8 : 4;
+  using VO = VecOf<T, W>;
+  using V = typename VO::type;
+  static constexpr int K = VO::K;
+  static_assert(COUNT % K == 0, "run must be a whole number of vectors");
+
+  static __device__ __forceinline__ void load(const T* __restrict__ base, long run, T (&v)[COUNT]) {
+    const V* src = reinterpret_cast<const V*>(base + run * COUNT);
+#pragma unroll
+    for (int k = 0; k < COUNT / K; ++k) {
+      union { V vec; T e[K]; } u;
+      u.vec = src[k];
+#pragma unroll
+      for (int j = 0; j < K; ++j) v[k * K + j] = u.e[j];
+    }
+  }
+  static __device__ __forceinline__ void store(T* __restrict__ base, long run, const T (&v)[COUNT]) {
+    V* dst = reinterpret_cast<V*>(base + run * COUNT);
+#pragma unroll
+    for (int k = 0; k < COUNT / K; ++k) {
+      union { V vec; T e[K]; } u;
+#pragma unroll
+      for (int j = 0; j < K; ++j) u.e[j] = v[k * K + j];
+      dst[k] = u.vec;
+    }
+  }
+};
+
+
+// -------------------------------------------------------------- trajectory generation pieces
+// Row (b, t) of the time-scaled point-to-point trajectory, reference planning/trajectory.py:45-73,
+// with the positions clipped to the joint limits (:311-313).
+template <int N, typename MT>
+__device__ __forceinline__ void traj_row(const MT& M, const float* __restrict__ start,
+                                         const float* __restrict__ end, long b, long t, long Nt, double Tf,
+                                         int method, float (&pos)[N], float (&vel)[N], float (&acc)[N]) {
+  float a[N], e[N];
+  RunIO<float, N>::load(start, b, a);
+  RunIO<float, N>::load(end, b, e);
+  const double tt = (double)t * (Tf / (double)(Nt - 1));
+  const double tau = tt / Tf;
+  double s, sd, sdd;
+  mp_time_scaling(method, tau, Tf, s, sd, sdd);
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const double d = (double)(e[j] - a[j]);  // float32 difference first, as the reference types it
+    pos[j] = mp_clip((float)(s * d + (double)a[j]), M.qmin[j], M.qmax[j]);
+    vel[j] = (float)(sd * d);
+    acc[j] = (float)(sdd * d);
+  }
+}
+
+
+// ------------------------------------------------- float32, two rows per lane (packed v_pk_* math)
+template <int N>
+__device__ __forceinline__ void load_pair(const float* __restrict__ base, long pair, mp_f2 (&v)[N]) {
+  float f[2 * N];
+  RunIO<float, 2 * N>::load(base, pair, f);
+#pragma unroll
+  for (int j = 0; j < N; ++j) v[j] = (mp_f2){f[j], f[N + j]};
+}
+template <int N>
+__device__ __forceinline__ void store_pair(float* __restrict__ base, long pair, const mp_f2 (&v)[N]) {
+  float f[2 * N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) { f[j] = v[j].x; f[N + j] = v[j].y; }
+  RunIO<float, 2 * N>::store(base, pair, f);
+}
+
+
+// tau for the row pair `p` (rows 2p, 2p+1): the body of k_id_pk
+template <int N, bool HAS_FTIP, typename MT>
+__device__ __forceinline__ void mp_body_id_pk(const MT& M, const MpCall<float>& C, const float* __restrict__ q,
+                                              const float* __restrict__ qd, const float* __restrict__ qdd,
+                                              float* __restrict__ tau, long p) {
+  mp_f2 a[N], b[N], c[N], t[N];
+  load_pair<N>(q, p, a);
+  load_pair<N>(qd, p, b);
+  load_pair<N>(qdd, p, c);
+  MpJointState<mp_f2, N> js;
+  mp_joint_state<mp_f2, N>(M, a, js);
+  mp_rnea<mp_f2, N, HAS_FTIP>(M, C, js, b, c, t);
+#pragma unroll
+  for (int j = 0; j < N; ++j) t[j] = mp_clip(t[j], M.taumin[j], M.taumax[j]);
+  store_pair<N>(tau, p, t);
+}
+
+// generation fused into inverse dynamics for the row pair `p`: the body of k_traj_id_pk
+template <int N, bool HAS_FTIP, typename MT>
+__device__ __forceinline__ void mp_body_traj_id_pk(const MT& M, const MpCall<float>& C, const float* __restrict__ start,
+                                                   const float* __restrict__ end, long p, long Nt, double Tf, int method,
+                                                   float* __restrict__ tau) {
+  const long r0 = 2 * p;
+  const long b0 = r0 / Nt, t0 = r0 - b0 * Nt;
+  const bool wrap = t0 + 1 >= Nt;  // the pair may straddle two trajectories
+  const long b1 = wrap ? b0 + 1 : b0, t1 = wrap ? 0 : t0 + 1;
+  float p0[N], v0[N], a0[N], p1[N], v1[N], a1[N];
+  traj_row<N>(M, start, end, b0, t0, Nt, Tf, method, p0, v0, a0);
+  traj_row<N>(M, start, end, b1, t1, Nt, Tf, method, p1, v1, a1);
+  mp_f2 qq[N], qd[N], qdd[N], tq[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) { qq[j] = (mp_f2){p0[j], p1[j]}; qd[j] = (mp_f2){v0[j], v1[j]}; qdd[j] = (mp_f2){a0[j], a1[j]}; }
+  MpJointState<mp_f2, N> js;
+  mp_joint_state<mp_f2, N>(M, qq, js);
+  mp_rnea<mp_f2, N, HAS_FTIP>(M, C, js, qd, qdd, tq);
+#pragma unroll
+  for (int j = 0; j < N; ++j) tq[j] = mp_clip(tq[j], M.taumin[j], M.taumax[j]);
+  store_pair<N>(tau, p, tq);
+}
+
+// forward_dynamics_trajectory (reference planning/trajectory_dynamics.py:580-708): one lane integrates one
+// trajectory — semi-implicit Euler, `intRes` sub-steps of dt/intRes per outer step, joint-limit clip after
+// every sub-step, rows stored float32, the recorded acceleration is the last sub-step's, row 0 = initial
+// state with zero acceleration.  Time is sequential; trajectories are independent.  Body of k_fd_traj.
+template <typename T, int N, bool HAS_FTIP, typename MT>
+__device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C, const T* __restrict__ theta0,
+                                                const T* __restrict__ dtheta0, const T* __restrict__ taumat,
+                                                const T* __restrict__ Ftipmat, long b, long Nt, T h, int intRes,
+                                                float* __restrict__ pos, float* __restrict__ vel, float* __restrict__ acc) {
+  T q[N], qd[N];
+  RunIO<T, N>::load(theta0, b, q);
+  RunIO<T, N>::load(dtheta0, b, qd);
+  float o[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) o[j] = (float)q[j];
+  RunIO<float, N>::store(pos, b * Nt, o);
+#pragma unroll
+  for (int j = 0; j < N; ++j) o[j] = (float)qd[j];
+  RunIO<float, N>::store(vel, b * Nt, o);
+#pragma unroll
+  for (int j = 0; j < N; ++j) o[j] = 0.f;
+  RunIO<float, N>::store(acc, b * Nt, o);
+  for (long i = 1; i < Nt; ++i) {
+    T tau[N], tn[3] = {T(0), T(0), T(0)}, tf[3] = {T(0), T(0), T(0)};
+    RunIO<T, N>::load(taumat, b * Nt + i, tau);
+    if (HAS_FTIP) {
+      T F[6];
+      RunIO<T, 6>::load(Ftipmat, b * Nt + i, F);
+      mp_wrench_to_frame1(M, F, tn, tf);
+    }
+    T last[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) last[j] = T(0);
+    for (int s = 0; s < intRes; ++s) {
+      mp_forward_dynamics<T, N, HAS_FTIP>(M, C.a0, tn, tf, q, qd, tau, last);
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        qd[j] = qd[j] + last[j] * h;
+        q[j] = mp_clip(q[j] + qd[j] * h, M.qmin[j], M.qmax[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) o[j] = (float)q[j];
+    RunIO<float, N>::store(pos, b * Nt + i, o);
+#pragma unroll
+    for (int j = 0; j < N; ++j) o[j] = (float)qd[j];
+    RunIO<float, N>::store(vel, b * Nt + i, o);
+#pragma unroll
+    for (int j = 0; j < N; ++j) o[j] = (float)last[j];
+    RunIO<float, N>::store(acc, b * Nt + i, o);
+  }
+}

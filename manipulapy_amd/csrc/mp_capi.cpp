@@ -10,13 +10,19 @@
 #include <cstring>
 #include <map>
 #include <new>
+#include <string>
 #include <vector>
 
 #include "../../include/manipula_hip.h"
+#include "mp_jit.h"
 #include "mp_kernels.h"
 #include "mp_model_compile.h"
 
 // ------------------------------------------------------------------------------------- objects
+struct MpSpec {  // run-time specialised kernels of one model on one device
+  hipModule_t mod = nullptr;
+  hipFunction_t id_pk[2] = {nullptr, nullptr}, traj_id_pk[2] = {nullptr, nullptr}, fd_traj[2] = {nullptr, nullptr};
+};
 struct mp_ctx {
   int device = -1;
   hipStream_t compute = nullptr;
@@ -24,6 +30,7 @@ struct mp_ctx {
   std::map<size_t, std::vector<void*>> free_by_size;  // pool: exact-size free lists
   std::map<void*, size_t> live;                        // every buffer handed out -> its size
   std::map<uint64_t, void*> dev_models;                // model uid -> float32 model resident on this device
+  std::map<uint64_t, MpSpec> specs;                    // model uid -> specialised kernels (mp_model_specialize)
   int compute_units = 0;
 };
 struct mp_model {
@@ -99,6 +106,22 @@ struct Scratch {
 #define D2H(dst, src, bytes) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->compute))
 
 
+// MANIPULAPY_HIP_SPECIALIZE=0: ignore specialised kernels (A/B measurements)
+bool specialize_enabled() {
+  static const bool on = [] { const char* e = getenv("MANIPULAPY_HIP_SPECIALIZE"); return !(e && e[0] == '0'); }();
+  return on;
+}
+const MpSpec* find_spec(mp_ctx* ctx, const mp_model* model) {
+  if (!specialize_enabled()) return nullptr;
+  auto it = ctx->specs.find(model->uid);
+  return it == ctx->specs.end() ? nullptr : &it->second;
+}
+int launch_spec(mp_ctx* ctx, hipFunction_t fn, long threads, void** args) {
+  const unsigned grid = (unsigned)((threads + 255) / 256);
+  HIP_TRY(hipModuleLaunchKernel(fn, grid, 1, 1, 256, 1, 1, 0, ctx->compute, args, nullptr));
+  return MP_OK;
+}
+
 // float32 model resident in device memory (read by the persistent kernels with scalar loads)
 int device_model(mp_ctx* ctx, const mp_model* model, const MpModel<float>** out) {
   auto it = ctx->dev_models.find(model->uid);
@@ -125,8 +148,21 @@ int launch_id(mp_ctx* ctx, const mp_model* model, const MpCall<double>& c, bool 
 }
 int launch_id(mp_ctx* ctx, const mp_model* model, const MpCall<float>& c, bool ftip, const float* q, const float* qd,
               const float* qdd, float* tau, long rows) {
-  const int per_cu = persist_blocks_per_cu();
   const long pairs = rows / 2;
+  if (const MpSpec* sp = find_spec(ctx, model)) {
+    if (pairs > 0) {
+      MpCall<float> cc = c;
+      long np = pairs;
+      void* args[] = {&cc, &q, &qd, &qdd, &tau, &np};
+      if (int rc = launch_spec(ctx, sp->id_pk[ftip ? 1 : 0], pairs, args)) return rc;
+    }
+    const long done = 2 * pairs;
+    if (done == rows) return MP_OK;
+    const long off = done * model->d.n;  // odd trailing row: generic one-row kernel
+    HIP_TRY(mpk_id<float>(ctx->compute, model->f, c, ftip, q + off, qd + off, qdd + off, tau + off, rows - done));
+    return MP_OK;
+  }
+  const int per_cu = persist_blocks_per_cu();
   const long blocks = (long)per_cu * ctx->compute_units;
   if (per_cu > 0 && pairs > blocks * 256) {  // enough work for every resident lane to loop
     const MpModel<float>* dm = nullptr;
@@ -227,6 +263,20 @@ static int fdyn_impl(const char* fn, mp_ctx* ctx, const mp_model* model, const T
   return MP_OK;
 }
 
+// specialised forward-dynamics roll-out (float32 only): -1 = none available, otherwise the launch's return code
+int launch_fd_spec(mp_ctx* ctx, const mp_model* model, const MpCall<float>& c, const float* th0, const float* dth0,
+                    const float* taumat, const float* Fm, long B, long Nt, float h, int intRes, float* pos, float* vel, float* acc) {
+  const MpSpec* sp = find_spec(ctx, model);
+  if (!sp) return -1;
+  MpCall<float> cc = c;
+  void* args[] = {&cc, &th0, &dth0, &taumat, &Fm, &B, &Nt, &h, &intRes, &pos, &vel, &acc};
+  return launch_spec(ctx, sp->fd_traj[Fm ? 1 : 0], B, args);
+}
+int launch_fd_spec(mp_ctx*, const mp_model*, const MpCall<double>&, const double*, const double*, const double*, const double*,
+                   long, long, double, int, float*, float*, float*) {
+  return -1;
+}
+
 template <typename T>
 static int fdtraj_impl(const char* fn, mp_ctx* ctx, const mp_model* model, const T* d_theta0, const T* d_dtheta0,
                        const T* d_taumat, const T* d_Ftipmat, int64_t B, int64_t N, const double* g, double dt, int intRes,
@@ -242,6 +292,8 @@ static int fdtraj_impl(const char* fn, mp_ctx* ctx, const mp_model* model, const
   MpCall<T> c;
   make_call<T>(model, g, nullptr, &c);
   const T h = intRes > 0 ? (T)(dt / intRes) : (T)0;
+  const int src = launch_fd_spec(ctx, model, c, d_theta0, d_dtheta0, d_taumat, d_Ftipmat, (long)B, (long)N, h, intRes, d_pos, d_vel, d_acc);
+  if (src >= 0) return src;  // a specialised kernel exists for this model: launched (0) or failed (error code)
   HIP_TRY(mpk_fd_traj<T>(ctx->compute, pick<T>(model), c, d_theta0, d_dtheta0, d_taumat, d_Ftipmat, (long)B, (long)N, h, intRes,
                          d_pos, d_vel, d_acc));
   return MP_OK;
@@ -321,6 +373,7 @@ int mp_ctx_destroy(mp_ctx* ctx) {
   if (!ctx) return MP_OK;
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
+  for (auto& kv : ctx->specs) if (kv.second.mod) (void)hipModuleUnload(kv.second.mod);
   for (auto& kv : ctx->live) (void)hipFree(kv.first);
   if (ctx->compute) (void)hipStreamDestroy(ctx->compute);
   if (ctx->copy) (void)hipStreamDestroy(ctx->copy);
@@ -504,6 +557,61 @@ int mp_model_params(const mp_model* model, double* out) {
   for (int i = 0; i < model->d.n; ++i) std::memcpy(out + 16 * i, &model->d.j[i], 16 * sizeof(double));
   return MP_OK;
 }
+int mp_model_specialize_source(const mp_model* model, char* buf, size_t* len) {
+  REQUIRE(model && len, "mp_model_specialize_source: null argument");
+  const std::string src = mp_jit_source(model->f);
+  if (buf) {
+    REQUIRE(*len >= src.size() + 1, "mp_model_specialize_source: buffer too small");
+    std::memcpy(buf, src.c_str(), src.size() + 1);
+  }
+  *len = src.size() + 1;
+  return MP_OK;
+}
+int mp_model_specialize_compile(const mp_model* model, size_t* code_bytes, int* from_cache) {
+  REQUIRE(model, "mp_model_specialize_compile: null model");
+  std::vector<char> code;
+  std::string err;
+  bool cached = false;
+  if (mp_jit_compile(model->f, &code, &cached, &err)) return set_err(MP_ERR_UNSUPPORTED, "mp_model_specialize_compile: %s", err.c_str());
+  if (code_bytes) *code_bytes = code.size();
+  if (from_cache) *from_cache = cached ? 1 : 0;
+  return MP_OK;
+}
+int mp_model_is_specialized(mp_ctx* ctx, const mp_model* model, int* yes) {
+  REQUIRE(ctx && model && yes, "mp_model_is_specialized: null argument");
+  *yes = ctx->specs.count(model->uid) ? 1 : 0;
+  return MP_OK;
+}
+int mp_model_specialize(mp_ctx* ctx, const mp_model* model) {
+  REQUIRE(ctx && model, "mp_model_specialize: null argument");
+  if (ctx->specs.count(model->uid)) return MP_OK;
+  if (int rc = bind(ctx)) return rc;
+  std::vector<char> code;
+  std::string err;
+  if (mp_jit_compile(model->f, &code, nullptr, &err)) return set_err(MP_ERR_UNSUPPORTED, "mp_model_specialize: %s", err.c_str());
+  MpSpec sp;
+  HIP_TRY(hipModuleLoadData(&sp.mod, code.data()));
+  const char* names[3][2] = {{"mp_spec_id_pk_f0", "mp_spec_id_pk_f1"}, {"mp_spec_traj_id_pk_f0", "mp_spec_traj_id_pk_f1"},
+                             {"mp_spec_fd_traj_f0", "mp_spec_fd_traj_f1"}};
+  hipFunction_t* slots[3] = {sp.id_pk, sp.traj_id_pk, sp.fd_traj};
+  for (int k = 0; k < 3; ++k)
+    for (int f = 0; f < 2; ++f) {
+      hipError_t e = hipModuleGetFunction(&slots[k][f], sp.mod, names[k][f]);
+      if (e != hipSuccess) { (void)hipModuleUnload(sp.mod); return hip_err(e, names[k][f]); }
+    }
+  ctx->specs[model->uid] = sp;
+  return MP_OK;
+}
+int mp_model_blob(const mp_model* model, int use_f64, void* out, size_t* bytes) {
+  REQUIRE(model && bytes, "mp_model_blob: null argument");
+  const size_t need = use_f64 ? sizeof(MpModel<double>) : sizeof(MpModel<float>);
+  if (out) {
+    REQUIRE(*bytes >= need, "mp_model_blob: buffer of %zu bytes, need %zu", *bytes, need);
+    std::memcpy(out, use_f64 ? (const void*)&model->d : (const void*)&model->f, need);
+  }
+  *bytes = need;
+  return MP_OK;
+}
 int mp_model_fk_host(const mp_model* model, const double* q, double* T) {
   REQUIRE(model && q && T, "mp_model_fk_host: null argument");
   mp_compiled_fk(model->d, q, T);
@@ -546,7 +654,15 @@ int mp_traj_id_fused_f32(mp_ctx* ctx, const mp_model* model, const float* d_star
           "mp_traj_id_fused_f32: device pointers must be 16-byte aligned");
   MpCall<float> c;
   make_call<float>(model, g, Ftip, &c);
-  HIP_TRY(mpk_traj_id(ctx->compute, model->f, c, any_nonzero(Ftip), d_start, d_end, (long)B, (long)N, Tf, method, d_tau));
+  const bool ftip = any_nonzero(Ftip);
+  const long rows = (long)B * (long)N, pairs = rows / 2;
+  const MpSpec* sp = find_spec(ctx, model);
+  if (sp && pairs > 0 && rows == 2 * pairs) {  // an odd total falls through to the generic kernels
+    long np = pairs, nt = (long)N;
+    void* args[] = {&c, &d_start, &d_end, &np, &nt, &Tf, &method, &d_tau};
+    return launch_spec(ctx, sp->traj_id_pk[ftip ? 1 : 0], pairs, args);
+  }
+  HIP_TRY(mpk_traj_id(ctx->compute, model->f, c, ftip, d_start, d_end, (long)B, (long)N, Tf, method, d_tau));
   return MP_OK;
 }
 

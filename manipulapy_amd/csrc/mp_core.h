@@ -16,11 +16,13 @@
 // the analytic recursion does not.
 #pragma once
 
+#if !defined(__HIPCC_RTC__)
 #include <cmath>
+#endif
 
 #include "mp_model.h"
 
-#if defined(__HIPCC__)
+#if defined(__HIPCC__) || defined(__HIPCC_RTC__)
 #define MP_HD __host__ __device__ __forceinline__
 #else
 #define MP_HD inline
@@ -77,7 +79,7 @@ MP_HD void mp_sincos(float x, float& s, float& c) {
   c = ((q + 1) & 2) ? -b : b;
 }
 MP_HD void mp_sincos(double x, double& s, double& c) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC_RTC__)
   sincos(x, &s, &c);
 #else
   s = std::sin(x);

@@ -23,6 +23,7 @@ What is different, on purpose:
 from __future__ import annotations
 
 import logging
+import os
 import time
 from typing import Dict, Optional, Tuple
 
@@ -83,6 +84,13 @@ class OptimizedTrajectoryPlanning:
         """Dynamics tables + THIS planner's float32 joint / torque limits, compiled once."""
         if self._model is None:
             self._model = self.dynamics.hip_model(self.joint_limits.astype(np.float64), self.torque_limits.astype(np.float64))
+            if self._gpu_routed() and os.environ.get("MANIPULAPY_HIP_SPECIALIZE", "1") != "0":
+                # float32 kernels with this robot's constants baked in (hiprtc, ~1.5 s once, cached on disk);
+                # purely an optimisation: the generic kernels compute the same values
+                try:
+                    _reg.get_context().specialize(self._model)
+                except Exception as exc:  # pragma: no cover - depends on the hiprtc installation
+                    logger.warning("kernel specialisation unavailable (%s); using the generic kernels", exc)
         return self._model
 
     def _should_use_gpu(self, N: int, num_joints: int) -> bool:

@@ -397,3 +397,59 @@ def test_forward_dynamics_trajectory_fixture_and_oracle(tables):
             o = ref.forward_dynamics_trajectory(tab, th0[b], dth0[b], tm[b], z["g"], np.zeros((N, 6)), 0.02, 1, joint_limits=lim)
             for k in ("positions", "velocities", "accelerations"):
                 np.testing.assert_allclose(one[k], o[k], rtol=1e-5, atol=1e-5 * max(1.0, float(np.abs(o[k]).max())))
+
+
+@pytest.mark.parametrize("robot", ROBOTS)
+def test_specialised_kernels_match_generic_and_oracle(robot, tables, dyn_golden):
+    """Run-time specialised float32 kernels (mp_model_specialize) vs the generic ones vs the oracle:
+    inverse dynamics (with / without wrench, odd row count), fused generation + ID, forward-dynamics roll-out."""
+    from manipulapy_amd import _hip
+
+    tab, z = tables[robot], dyn_golden[robot]
+    ctx = _hip.HipContext(0)
+    try:
+        gen = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee, tab.joint_limits)
+        spec = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee, tab.joint_limits)
+        assert not ctx.is_specialized(spec)
+        ctx.specialize(spec)
+        ctx.specialize(spec)  # idempotent
+        assert ctx.is_specialized(spec) and not ctx.is_specialized(gen)
+        rng = np.random.default_rng(17)
+        rows = 2 * 257 + 1  # odd: the last row goes through the generic one-row kernel
+        q = rng.uniform(tab.joint_limits[:, 0], tab.joint_limits[:, 1], (rows, tab.n)).astype(np.float32)
+        qd = rng.uniform(-2, 2, (rows, tab.n)).astype(np.float32)
+        qdd = rng.uniform(-4, 4, (rows, tab.n)).astype(np.float32)
+        F = np.array([1.0, -2.0, 0.5, 3.0, -1.5, 0.75])
+        for wrench in (None, F):
+            a = ctx.id_trajectory_host(gen, q, qd, qdd, None, wrench)
+            b = ctx.id_trajectory_host(spec, q, qd, qdd, None, wrench)
+            assert (np.abs(a - b) <= 2e-5 * np.abs(a).max(axis=1, keepdims=True)).all()
+            idx = np.arange(0, rows, 37)
+            want = ref.inverse_dynamics_trajectory(tab, q[idx].astype(np.float64), qd[idx].astype(np.float64),
+                                                   qdd[idx].astype(np.float64), None, wrench, dtype=np.float64)
+            assert_f32(b[idx], want)
+        # golden rows
+        zero = [i for i in range(len(z["thetas"])) if not z["ftips"][i].any()]
+        t = ctx.id_trajectory_host(spec, z["thetas"][zero], z["dthetas"][zero], z["ddthetas"][zero], z["g"], None)
+        assert_f32(t, z["inverse_dynamics"][zero])
+        # fused generation + ID
+        s = rng.uniform(tab.joint_limits[:, 0], tab.joint_limits[:, 1], (6, tab.n)).astype(np.float32)
+        e = rng.uniform(tab.joint_limits[:, 0], tab.joint_limits[:, 1], (6, tab.n)).astype(np.float32)
+        fa = ctx.traj_id_fused_host(gen, s, e, 2.0, 51, 5)
+        fb = ctx.traj_id_fused_host(spec, s, e, 2.0, 51, 5)
+        assert (np.abs(fa - fb) <= 2e-5 * np.abs(fa).max(axis=2, keepdims=True)).all()
+        # forward-dynamics roll-out
+        B, N = 5, 10
+        th0 = rng.uniform(-0.3, 0.3, (B, tab.n)).astype(np.float32)
+        if robot == "panda":
+            th0[:, 3] = -1.5; th0[:, 5] = 1.0; th0[:, 7] = 0.02  # inside the one-sided limits
+        dth0 = rng.uniform(-0.2, 0.2, (B, tab.n)).astype(np.float32)
+        tm = rng.uniform(-1, 1, (B, N, tab.n)).astype(np.float32)
+        Fm = np.broadcast_to(F.astype(np.float32), (B, N, 6)).copy()
+        for wr in (None, Fm):
+            ra = ctx.fd_trajectory_host(gen, th0, dth0, tm, None, wr, 0.01, 1, dtype=np.float32)
+            rb = ctx.fd_trajectory_host(spec, th0, dth0, tm, None, wr, 0.01, 1, dtype=np.float32)
+            for xa, xb in zip(ra, rb):
+                assert np.abs(xa - xb).max() <= 2e-4 * max(1.0, float(np.abs(xa).max()))
+    finally:
+        ctx.destroy()

@@ -92,6 +92,24 @@ def test_model_compiler_rejects_bad_tables(tables):
         _hip.HipModel(np.zeros((6, 9)), np.zeros((9, 4, 4)), np.zeros((9, 6, 6)), np.eye(4))
 
 
+def test_kernel_specialiser_generates_and_compiles_without_a_gpu(tables, tmp_path, monkeypatch):
+    """mp_model_specialize_compile: hiprtc build of one robot's kernels needs no device; zeros / ones are
+    snapped in the emitted literal and the code object is cached on disk."""
+    monkeypatch.setenv("MANIPULAPY_HIP_CACHE", str(tmp_path))
+    tab = tables["ur5"]
+    m = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee, tab.joint_limits)
+    src = m.specialize_source()
+    assert "static constexpr MpModel<float> kM = {6," in src and 'extern "C" __global__' in src
+    for name in ("mp_spec_id_pk_f0", "mp_spec_id_pk_f1", "mp_spec_traj_id_pk_f0", "mp_spec_fd_traj_f1"):
+        assert name in src
+    assert "e-10f" not in src and "e-17f" not in src  # URDF dust is snapped to exact zeros
+    assert "inf" not in src.lower().replace("__builtin_inff", "")  # infinite limits are emitted as +-3e38
+    nb, cached = m.specialize_compile()
+    assert nb > 10000 and not cached
+    nb2, cached2 = m.specialize_compile()
+    assert nb2 == nb and cached2 and len(list(tmp_path.glob("*.hsaco"))) == 1
+
+
 # ----------------------------------------------------------------------------- device math on the host
 @pytest.fixture(scope="module")
 def hostsim():

@@ -7,7 +7,7 @@ import sys
 s = open(sys.argv[1]).read()
 keys = sys.argv[2:]
 for key in keys:
-    m = re.search(r'^(_ZN\S*' + re.escape(key) + r'\S*):', s, re.M)
+    m = re.search(r'^(_Z\S*' + re.escape(key) + r'\S*):', s, re.M)
     if not m:
         print(key, "not found"); continue
     i = m.end(); j = s.index('.Lfunc_end', i)
