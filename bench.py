@@ -182,7 +182,7 @@ def main():
     ctx.selftest()
     props = ctx.properties()
     model = _hip.HipModel(t["S_list"], t["Mlist_per_link"], t["Glist"], t["M_ee"], t["joint_limits"])
-    if not args.no_specialize and cfg["dtype"] == "f32":
+    if not args.no_specialize:
         ctx.specialize(model)  # setup, untimed: hiprtc build of this robot's kernels (cached on disk)
     cfg["specialized"] = ctx.is_specialized(model)
 

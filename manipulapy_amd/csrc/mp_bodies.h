@@ -7,10 +7,13 @@
 
 // ---- widest legal vector type for a run of COUNT elements of T whose start is COUNT*sizeof(T)-strided
 template <typename T, int BYTES> struct VecOf;
-template <> struct VecOf<float, 16> { using type = float4; static constexpr int K = 4; };
-template <> struct VecOf<float, 8> { using type = float2; static constexpr int K = 2; };
+typedef float mp_io_f4 __attribute__((ext_vector_type(4)));   // native vectors: dwordx4 / dwordx2 accesses,
+typedef float mp_io_f2 __attribute__((ext_vector_type(2)));   // and legal operands of the nontemporal builtins
+typedef double mp_io_d2 __attribute__((ext_vector_type(2)));
+template <> struct VecOf<float, 16> { using type = mp_io_f4; static constexpr int K = 4; };
+template <> struct VecOf<float, 8> { using type = mp_io_f2; static constexpr int K = 2; };
 template <> struct VecOf<float, 4> { using type = float; static constexpr int K = 1; };
-template <> struct VecOf<double, 16> { using type = double2; static constexpr int K = 2; };
+template <> struct VecOf<double, 16> { using type = mp_io_d2; static constexpr int K = 2; };
 template <> struct VecOf<double, 8> { using type = double; static constexpr int K = 1; };
 
 template <typename T, int COUNT>
@@ -27,7 +30,11 @@ struct RunIO {
 #pragma unroll
     for (int k = 0; k < COUNT / K; ++k) {
       union { V vec; T e[K]; } u;
+#if defined(MP_NT_LOAD)
+      u.vec = __builtin_nontemporal_load(&src[k]);
+#else
       u.vec = src[k];
+#endif
 #pragma unroll
       for (int j = 0; j < K; ++j) v[k * K + j] = u.e[j];
     }
@@ -39,7 +46,11 @@ struct RunIO {
       union { V vec; T e[K]; } u;
 #pragma unroll
       for (int j = 0; j < K; ++j) u.e[j] = v[k * K + j];
+#if defined(MP_NT_STORE)
+      __builtin_nontemporal_store(u.vec, &dst[k]);
+#else
       dst[k] = u.vec;
+#endif
     }
   }
 };
@@ -68,6 +79,49 @@ __device__ __forceinline__ void traj_row(const MT& M, const float* __restrict__ 
   }
 }
 
+
+// ------------------------------------------------------------------ one row per lane (float / double)
+// tau for row `r`: the body of k_id
+template <typename T, int N, bool HAS_FTIP, typename MT>
+__device__ __forceinline__ void mp_body_id(const MT& M, const MpCall<T>& C, const T* __restrict__ q, const T* __restrict__ qd,
+                                           const T* __restrict__ qdd, T* __restrict__ tau, long r) {
+  T a[N], b[N], c[N], t[N];
+  RunIO<T, N>::load(q, r, a);
+  RunIO<T, N>::load(qd, r, b);
+  RunIO<T, N>::load(qdd, r, c);
+  MpJointState<T, N> js;
+  mp_joint_state<T, N>(M, a, js);
+  mp_rnea<T, N, HAS_FTIP>(M, C, js, b, c, t);
+#pragma unroll
+  for (int j = 0; j < N; ++j) t[j] = mp_clip(t[j], M.taumin[j], M.taumax[j]);
+  RunIO<T, N>::store(tau, r, t);
+}
+
+// T (4x4), space Jacobian (6xN) and tau for row `r`, any output optional: the body of k_fk_jac_id
+template <typename T, int N, bool HAS_FTIP, typename MT>
+__device__ __forceinline__ void mp_body_fk_jac_id(const MT& M, const MpCall<T>& C, const T* __restrict__ q,
+                                                  const T* __restrict__ qd, const T* __restrict__ qdd, T* __restrict__ Tout,
+                                                  T* __restrict__ Jout, T* __restrict__ tau, long r) {
+  T a[N];
+  RunIO<T, N>::load(q, r, a);
+  MpJointState<T, N> js;
+  mp_joint_state<T, N>(M, a, js);
+  if (Tout != nullptr || Jout != nullptr) {
+    T TT[16], JJ[6 * N];
+    mp_fk_jac<T, N, true>(M, js, TT, JJ);
+    if (Tout != nullptr) RunIO<T, 16>::store(Tout, r, TT);
+    if (Jout != nullptr) RunIO<T, 6 * N>::store(Jout, r, JJ);
+  }
+  if (tau != nullptr) {
+    T b[N], c[N], t[N];
+    RunIO<T, N>::load(qd, r, b);
+    RunIO<T, N>::load(qdd, r, c);
+    mp_rnea<T, N, HAS_FTIP>(M, C, js, b, c, t);
+#pragma unroll
+    for (int j = 0; j < N; ++j) t[j] = mp_clip(t[j], M.taumin[j], M.taumax[j]);
+    RunIO<T, N>::store(tau, r, t);
+  }
+}
 
 // ------------------------------------------------- float32, two rows per lane (packed v_pk_* math)
 template <int N>

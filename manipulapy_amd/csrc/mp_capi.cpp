@@ -22,6 +22,7 @@
 struct MpSpec {  // run-time specialised kernels of one model on one device
   hipModule_t mod = nullptr;
   hipFunction_t id_pk[2] = {nullptr, nullptr}, traj_id_pk[2] = {nullptr, nullptr}, fd_traj[2] = {nullptr, nullptr};
+  hipFunction_t id_d[2] = {nullptr, nullptr}, fk_jac_id_d[2] = {nullptr, nullptr};
 };
 struct mp_ctx {
   int device = -1;
@@ -143,6 +144,11 @@ int persist_blocks_per_cu() {
 
 int launch_id(mp_ctx* ctx, const mp_model* model, const MpCall<double>& c, bool ftip, const double* q, const double* qd,
               const double* qdd, double* tau, long rows) {
+  if (const MpSpec* sp = find_spec(ctx, model)) {
+    MpCall<double> cc = c;
+    void* args[] = {&cc, &q, &qd, &qdd, &tau, &rows};
+    return launch_spec(ctx, sp->id_d[ftip ? 1 : 0], rows, args);
+  }
   HIP_TRY(mpk_id<double>(ctx->compute, model->d, c, ftip, q, qd, qdd, tau, rows));
   return MP_OK;
 }
@@ -194,6 +200,20 @@ static int id_impl(const char* fn, mp_ctx* ctx, const mp_model* model, const T* 
   return launch_id(ctx, model, c, any_nonzero(Ftip), d_q, d_qd, d_qdd, d_tau, (long)rows);
 }
 
+// specialised FK + Jacobian + ID (float64 only): -1 = none available, otherwise the launch's return code
+int launch_fkjid_spec(mp_ctx* ctx, const mp_model* model, const MpCall<double>& c, bool ftip, const double* q, const double* qd,
+                      const double* qdd, double* T, double* J, double* tau, long rows) {
+  const MpSpec* sp = find_spec(ctx, model);
+  if (!sp) return -1;
+  MpCall<double> cc = c;
+  void* args[] = {&cc, &q, &qd, &qdd, &T, &J, &tau, &rows};
+  return launch_spec(ctx, sp->fk_jac_id_d[ftip ? 1 : 0], rows, args);
+}
+int launch_fkjid_spec(mp_ctx*, const mp_model*, const MpCall<float>&, bool, const float*, const float*, const float*, float*, float*,
+                      float*, long) {
+  return -1;
+}
+
 template <typename T>
 static int fkjid_impl(const char* fn, mp_ctx* ctx, const mp_model* model, const T* d_q, const T* d_qd, const T* d_qdd,
                       int64_t rows, const double* g, const double* Ftip, T* d_T, T* d_J, T* d_tau) {
@@ -208,6 +228,8 @@ static int fkjid_impl(const char* fn, mp_ctx* ctx, const mp_model* model, const 
           "%s: device pointers must be 16-byte aligned", fn);
   MpCall<T> c;
   make_call<T>(model, g, Ftip, &c);
+  const int src = launch_fkjid_spec(ctx, model, c, any_nonzero(Ftip), d_q, d_qd, d_qdd, d_T, d_J, d_tau, (long)rows);
+  if (src >= 0) return src;
   HIP_TRY(mpk_fk_jac_id<T>(ctx->compute, pick<T>(model), c, any_nonzero(Ftip), d_q, d_qd, d_qdd, d_T, d_J, d_tau, (long)rows));
   return MP_OK;
 }
@@ -559,7 +581,7 @@ int mp_model_params(const mp_model* model, double* out) {
 }
 int mp_model_specialize_source(const mp_model* model, char* buf, size_t* len) {
   REQUIRE(model && len, "mp_model_specialize_source: null argument");
-  const std::string src = mp_jit_source(model->f);
+  const std::string src = mp_jit_source(model->f, model->d);
   if (buf) {
     REQUIRE(*len >= src.size() + 1, "mp_model_specialize_source: buffer too small");
     std::memcpy(buf, src.c_str(), src.size() + 1);
@@ -572,7 +594,7 @@ int mp_model_specialize_compile(const mp_model* model, size_t* code_bytes, int* 
   std::vector<char> code;
   std::string err;
   bool cached = false;
-  if (mp_jit_compile(model->f, &code, &cached, &err)) return set_err(MP_ERR_UNSUPPORTED, "mp_model_specialize_compile: %s", err.c_str());
+  if (mp_jit_compile(model->f, model->d, &code, &cached, &err)) return set_err(MP_ERR_UNSUPPORTED, "mp_model_specialize_compile: %s", err.c_str());
   if (code_bytes) *code_bytes = code.size();
   if (from_cache) *from_cache = cached ? 1 : 0;
   return MP_OK;
@@ -588,13 +610,14 @@ int mp_model_specialize(mp_ctx* ctx, const mp_model* model) {
   if (int rc = bind(ctx)) return rc;
   std::vector<char> code;
   std::string err;
-  if (mp_jit_compile(model->f, &code, nullptr, &err)) return set_err(MP_ERR_UNSUPPORTED, "mp_model_specialize: %s", err.c_str());
+  if (mp_jit_compile(model->f, model->d, &code, nullptr, &err)) return set_err(MP_ERR_UNSUPPORTED, "mp_model_specialize: %s", err.c_str());
   MpSpec sp;
   HIP_TRY(hipModuleLoadData(&sp.mod, code.data()));
-  const char* names[3][2] = {{"mp_spec_id_pk_f0", "mp_spec_id_pk_f1"}, {"mp_spec_traj_id_pk_f0", "mp_spec_traj_id_pk_f1"},
-                             {"mp_spec_fd_traj_f0", "mp_spec_fd_traj_f1"}};
-  hipFunction_t* slots[3] = {sp.id_pk, sp.traj_id_pk, sp.fd_traj};
-  for (int k = 0; k < 3; ++k)
+  const char* names[5][2] = {{"mp_spec_id_pk_f0", "mp_spec_id_pk_f1"}, {"mp_spec_traj_id_pk_f0", "mp_spec_traj_id_pk_f1"},
+                             {"mp_spec_fd_traj_f0", "mp_spec_fd_traj_f1"}, {"mp_spec_id_d_f0", "mp_spec_id_d_f1"},
+                             {"mp_spec_fk_jac_id_d_f0", "mp_spec_fk_jac_id_d_f1"}};
+  hipFunction_t* slots[5] = {sp.id_pk, sp.traj_id_pk, sp.fd_traj, sp.id_d, sp.fk_jac_id_d};
+  for (int k = 0; k < 5; ++k)
     for (int f = 0; f < 2; ++f) {
       hipError_t e = hipModuleGetFunction(&slots[k][f], sp.mod, names[k][f]);
       if (e != hipSuccess) { (void)hipModuleUnload(sp.mod); return hip_err(e, names[k][f]); }

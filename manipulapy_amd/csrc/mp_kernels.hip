@@ -33,16 +33,7 @@ __global__ __launch_bounds__(kBlock) void k_id(const MpModel<T> M, const MpCall<
                                                T* __restrict__ tau, long rows) {
   const long r = (long)blockIdx.x * kBlock + threadIdx.x;
   if (r >= rows) return;
-  T a[N], b[N], c[N], t[N];
-  RunIO<T, N>::load(q, r, a);
-  RunIO<T, N>::load(qd, r, b);
-  RunIO<T, N>::load(qdd, r, c);
-  MpJointState<T, N> js;
-  mp_joint_state<T, N>(M, a, js);
-  mp_rnea<T, N, HAS_FTIP>(M, C, js, b, c, t);
-#pragma unroll
-  for (int j = 0; j < N; ++j) t[j] = mp_clip(t[j], M.taumin[j], M.taumax[j]);
-  RunIO<T, N>::store(tau, r, t);
+  mp_body_id<T, N, HAS_FTIP>(M, C, q, qd, qdd, tau, r);
 }
 
 // -------------------------------------------------------------- trajectory generation pieces
@@ -152,25 +143,7 @@ __global__ __launch_bounds__(kBlock) void k_fk_jac_id(const MpModel<T> M, const 
                                                       T* __restrict__ tau, long rows) {
   const long r = (long)blockIdx.x * kBlock + threadIdx.x;
   if (r >= rows) return;
-  T a[N];
-  RunIO<T, N>::load(q, r, a);
-  MpJointState<T, N> js;
-  mp_joint_state<T, N>(M, a, js);
-  if (Tout != nullptr || Jout != nullptr) {
-    T TT[16], JJ[6 * N];
-    mp_fk_jac<T, N, true>(M, js, TT, JJ);
-    if (Tout != nullptr) RunIO<T, 16>::store(Tout, r, TT);
-    if (Jout != nullptr) RunIO<T, 6 * N>::store(Jout, r, JJ);
-  }
-  if (tau != nullptr) {
-    T b[N], c[N], t[N];
-    RunIO<T, N>::load(qd, r, b);
-    RunIO<T, N>::load(qdd, r, c);
-    mp_rnea<T, N, HAS_FTIP>(M, C, js, b, c, t);
-#pragma unroll
-    for (int j = 0; j < N; ++j) t[j] = mp_clip(t[j], M.taumin[j], M.taumax[j]);
-    RunIO<T, N>::store(tau, r, t);
-  }
+  mp_body_fk_jac_id<T, N, HAS_FTIP>(M, C, q, qd, qdd, Tout, Jout, tau, r);
 }
 
 // ------------------------------------------------------------- mass matrix / forward dynamics

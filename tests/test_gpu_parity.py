@@ -432,6 +432,15 @@ def test_specialised_kernels_match_generic_and_oracle(robot, tables, dyn_golden)
         zero = [i for i in range(len(z["thetas"])) if not z["ftips"][i].any()]
         t = ctx.id_trajectory_host(spec, z["thetas"][zero], z["dthetas"][zero], z["ddthetas"][zero], z["g"], None)
         assert_f32(t, z["inverse_dynamics"][zero])
+        # float64 specialised kernels: inverse dynamics and FK + Jacobian + ID
+        for i in range(0, len(z["thetas"]), 4):
+            t64 = ctx.id_trajectory_host(spec, z["thetas"][i:i + 1], z["dthetas"][i:i + 1], z["ddthetas"][i:i + 1], z["g"], z["ftips"][i],
+                                         dtype=np.float64)
+            assert_f64(t64[0], z["inverse_dynamics"][i])
+        Ts, Js, taus = ctx.fk_jac_id_host(spec, z["thetas"], z["dthetas"], z["ddthetas"], z["g"], None)
+        np.testing.assert_allclose(Ts, z["fk_space"], rtol=1e-9, atol=2e-12)
+        np.testing.assert_allclose(Js, z["jac_space"], rtol=1e-9, atol=2e-12)
+        assert_f64(taus[zero], z["inverse_dynamics"][zero])
         # fused generation + ID
         s = rng.uniform(tab.joint_limits[:, 0], tab.joint_limits[:, 1], (6, tab.n)).astype(np.float32)
         e = rng.uniform(tab.joint_limits[:, 0], tab.joint_limits[:, 1], (6, tab.n)).astype(np.float32)
