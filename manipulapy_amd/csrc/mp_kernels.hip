@@ -141,9 +141,9 @@ __global__ __launch_bounds__(kBlock) void k_fk_jac_id(const MpModel<T> M, const 
                                                       const T* __restrict__ qd, const T* __restrict__ qdd,
                                                       T* __restrict__ Tout, T* __restrict__ Jout,
                                                       T* __restrict__ tau, long rows) {
+  __shared__ __attribute__((aligned(16))) char lds[(kBlock / 64) * MP_WAVE_LDS_BYTES];  // one staging slice per wave
   const long r = (long)blockIdx.x * kBlock + threadIdx.x;
-  if (r >= rows) return;
-  mp_body_fk_jac_id<T, N, HAS_FTIP>(M, C, q, qd, qdd, Tout, Jout, tau, r);
+  mp_body_fk_jac_id<T, N, HAS_FTIP>(M, C, q, qd, qdd, Tout, Jout, tau, r, rows, lds + (threadIdx.x >> 6) * MP_WAVE_LDS_BYTES);
 }
 
 // ------------------------------------------------------------- mass matrix / forward dynamics
