@@ -1,9 +1,10 @@
 """Robot model tables for the benchmark robots.
 
-The reference builds these tables from URDFs (urdf_processor.py:82-138 -> urdf/core.py:670-769).  A
-native URDF reader is a "next" row; until then the tables of the four configuration
-robots are shipped as small .npz fixtures captured from the reference (tests/golden/make_golden.py)
-— numbers only — so the GPU box, which has no reference, can build the same robots.
+The reference builds these tables from URDFs (urdf_processor.py:82-138 -> urdf/core.py:670-769).
+`manipulapy_amd.urdf` reads any URDF the same way; this module additionally ships the tables of the four
+configuration robots as small .npz fixtures captured from the reference (tests/golden/make_golden.py,
+numbers only) — the pin the URDF reader is tested against, and what bench.py loads — next to the four
+URDF files themselves (tests/golden/urdf/, robot description data).
 """
 from __future__ import annotations
 
@@ -22,6 +23,14 @@ def robot_tables(name: str) -> Dict[str, np.ndarray]:
         raise KeyError(f"unknown robot {name!r}; available: {', '.join(ROBOTS)}")
     z = np.load(os.path.join(_DATA, f"model_{name}.npz"))
     return {k: z[k] for k in ("S_list", "B_list", "M_ee", "Glist", "Mlist_per_link", "joint_limits")}
+
+
+def robot_urdf(name: str) -> str:
+    """Path of the URDF of one of the benchmark robots (the counterpart of the reference's
+    ManipulaPy_data.get_robot_urdf for these four)."""
+    if name not in ROBOTS:
+        raise KeyError(f"unknown robot {name!r}; available: {', '.join(ROBOTS)}")
+    return os.path.join(_DATA, "urdf", f"{name}.urdf")
 
 
 def load_robot(name: str) -> Tuple["SerialManipulator", "ManipulatorDynamics", np.ndarray]:

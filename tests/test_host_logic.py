@@ -203,6 +203,48 @@ def test_float32_sincos_accuracy(hostsim, tables):
     assert np.abs(T[:, 1, 0] - np.sin(q[:, 0])).max() < 2.5e-7
 
 
+# ----------------------------------------------------------------------------- URDF reader
+@pytest.mark.parametrize("robot", ROBOTS)
+def test_urdf_reader_reproduces_reference_tables(robot):
+    """manipulapy_amd.urdf vs the tables the reference extracted from the same URDF (bit for bit)."""
+    from manipulapy_amd.urdf import extract_tables
+
+    z = np.load(golden_path(f"model_{robot}.npz"))
+    t = extract_tables(mp.robot_urdf(robot), tip_link=str(z["ee_name"]))
+    assert t["S_list"].shape == (6, int(z["n"]))
+    for mine, ref_key in (("S_list", "S_list"), ("M", "M_ee"), ("B_list", "B_list"), ("G_list", "Glist"),
+                          ("Mlist_per_link", "Mlist_per_link"), ("joint_limits", "joint_limits")):
+        np.testing.assert_array_equal(np.asarray(t[mine]), z[ref_key], err_msg=mine)
+    # deterministic default end effector: the leaf the BFS reaches last
+    assert extract_tables(mp.robot_urdf(robot))["ee_name"] == {"ur5": "tool0", "iiwa14": "iiwa_link_ee_kuka",
+                                                               "panda": "panda_rightfinger", "xarm6": "link6"}[robot]
+
+
+def test_urdf_processor_mirror_and_errors(tmp_path):
+    proc = mp.URDFToSerialManipulator(mp.robot_urdf("panda"), tip_link="panda_leftfinger")
+    assert proc.robot_data["actuated_joints_num"] == 8  # 7 arm joints + one finger; the mimic finger is excluded
+    assert proc.serial_manipulator.S_list.shape == (6, 8) and proc.dynamics.Mlist_per_link.shape == (8, 4, 4)
+    assert np.isclose(proc.robot_data["joint_limits"][7][1], 0.04)
+    m = proc.dynamics.hip_model()  # compiles (prismatic finger included) without a GPU
+    np.testing.assert_allclose(m.fk_host(np.zeros(8)), proc.robot_data["M"], atol=1e-12)
+    from manipulapy_amd.urdf import UrdfError, extract_tables
+    bad = tmp_path / "bad.urdf"
+    bad.write_text("<robot name='x'><link name='a'/><link name='b'/><joint name='j' type='floating'><parent link='a'/>"
+                   "<child link='b'/></joint></robot>")
+    with pytest.raises(UrdfError, match="floating"):
+        extract_tables(str(bad))
+    bad.write_text("<robot name='x'><link name='a'/></robot>")
+    with pytest.raises(UrdfError):
+        extract_tables(str(bad))
+    bad.write_text("<notrobot/>")
+    with pytest.raises(UrdfError, match="expected <robot>"):
+        extract_tables(str(bad))
+    with pytest.raises(UrdfError, match="tip_link"):
+        extract_tables(mp.robot_urdf("ur5"), tip_link="nope")
+    with pytest.raises(NotImplementedError):
+        mp.URDFToSerialManipulator(mp.robot_urdf("ur5"), load_meshes=True)
+
+
 # ----------------------------------------------------------------------------- backend registry
 def test_backend_registry_semantics():
     """reference backend/__init__.py:65-237 / tests/test_backend_dispatch.py registry cases."""
