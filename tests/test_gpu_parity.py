@@ -480,3 +480,35 @@ def test_rccl_communicator_single_rank(ctx):
     with pytest.raises(ValueError):
         ctx.comm_create(b"short", 1, 0)
     d_s.free(); d_r.free()
+
+
+@pytest.mark.parametrize("seed", [0, 2, 4, 5, 6, 8, 11, 16])
+def test_random_robots_on_gpu(seed, ctx):
+    """Randomised chains (tests/test_random_robots.py) through the C ABI: generic fp64 / fp32 and specialised kernels."""
+    from manipulapy_amd import _hip
+    from test_random_robots import FLAVOURS, random_robot
+
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(1, 9))
+    tab = random_robot(rng, n, FLAVOURS[seed % len(FLAVOURS)])
+    rows = 65
+    q = rng.uniform(-2.5, 2.5, (rows, n))
+    q[:, np.abs(tab.S[:3]).sum(axis=0) == 0] *= 0.1
+    qd, qdd = rng.uniform(-1, 1, (rows, n)), rng.uniform(-2, 2, (rows, n))
+    g, F = np.array([0.4, -0.3, -9.81]), rng.uniform(-3, 3, 6)
+    m = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee, tab.joint_limits)
+    want = ref.inverse_dynamics_trajectory(tab, q[:9], qd[:9], qdd[:9], g, F, dtype=np.float64)
+    scale = max(1.0, float(np.abs(want).max()))
+    T, J, tau = ctx.fk_jac_id_host(m, q, qd, qdd, g, F)
+    np.testing.assert_allclose(tau[:9], want, rtol=1e-6, atol=1e-6 * scale)
+    for r in range(0, rows, 16):
+        np.testing.assert_allclose(T[r], ref.fk_space(tab, q[r]), atol=1e-10)
+        np.testing.assert_allclose(J[r], ref.jacobian_space(tab, q[r]), atol=1e-10)
+    t32 = ctx.id_trajectory_host(m, q, qd, qdd, g, F, dtype=np.float32)
+    assert np.abs(t32[:9] - want).max() <= 2e-4 * scale
+    ctx.specialize(m)
+    s32 = ctx.id_trajectory_host(m, q, qd, qdd, g, F, dtype=np.float32)
+    s64 = ctx.id_trajectory_host(m, q, qd, qdd, g, F, dtype=np.float64)
+    assert np.abs(s32[:9] - want).max() <= 2e-4 * scale
+    np.testing.assert_allclose(s64[:9], want, rtol=1e-6, atol=1e-6 * scale)
+    assert np.abs(s32 - t32).max() <= 2e-4 * scale
