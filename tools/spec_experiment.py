@@ -118,4 +118,4 @@ open(out, "w").write(src)
 flags = ["-w", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=fast", "-fno-slp-vectorize"] + sys.argv[2:]
 subprocess.run(["/opt/rocm/bin/hipcc"] + flags + ["-o", os.path.join(ROOT, "tools", f"spec_{robot}"), out], check=True)
 subprocess.run(["/opt/rocm/bin/hipcc"] + flags + ["--offload-device-only", "-S", "-o", f"/tmp/spec_{robot}.s", out], check=True)
-subprocess.run([sys.executable, os.path.join(ROOT, "tools_isa_stats.py"), f"/tmp/spec_{robot}.s", "k_idILb0", "k_idILb1"])
+subprocess.run([sys.executable, os.path.join(ROOT, "tools/isa_stats.py"), f"/tmp/spec_{robot}.s", "k_idILb0", "k_idILb1"])
