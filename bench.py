@@ -182,7 +182,10 @@ def main():
     dt_np = np.float32 if cfg["dtype"] == "f32" else np.float64
     wbytes = np.dtype(dt_np).itemsize
 
-    ctx = _hip.HipContext(info.local_rank)
+    dev = info.local_rank
+    if os.environ.get("MANIPULAPY_BENCH_SHARE_DEVICE") == "1":  # development only: several ranks on one GPU
+        dev = info.local_rank % max(_hip.device_count(), 1)
+    ctx = _hip.HipContext(dev)
     ctx.selftest()
     props = ctx.properties()
     model = _hip.HipModel(t["S_list"], t["Mlist_per_link"], t["Glist"], t["M_ee"], t["joint_limits"])
@@ -261,18 +264,35 @@ def main():
     allgather = None
     if world > 1 and not args.no_gather:
         allgather = {"bytes_per_rank": nb, "collective": "ncclAllGather (RCCL), one call per step after the kernel"}
-        try:
-            uid = _hip.HipContext.comm_unique_id() if info.rank == 0 else None
-            uid = hg.broadcast_bytes(uid, _hip.UNIQUE_ID_BYTES)
-            comm = ctx.comm_create(uid, world, info.rank)
-            d_tau_all = ctx.alloc(nb * world)
-            wall_g, _ = timed(lambda: comm.allgather(d_tau, d_tau_all, nb))
-            ms_g = wall_g / args.steps * 1e3
-            allgather.update({"ms_per_step_with_allgather": ms_g, "value_with_allgather": rows * n * world * args.steps / wall_g,
-                              "busbw_GBps": nb * (world - 1) / max(ms_g - elapsed / args.steps * 1e3, 1e-6) / 1e6})
-            comm.destroy()
-        except Exception as exc:  # keep the compute line even if RCCL is unusable on this node
-            allgather["error"] = str(exc)[:300]
+
+        def gather_phase():
+            try:
+                uid = _hip.HipContext.comm_unique_id() if info.rank == 0 else None
+                uid = hg.broadcast_bytes(uid, _hip.UNIQUE_ID_BYTES)
+                comm = ctx.comm_create(uid, world, info.rank)
+                d_tau_all = ctx.alloc(nb * world)
+                wall_g, _ = timed(lambda: comm.allgather(d_tau, d_tau_all, nb))
+                ms_g = wall_g / args.steps * 1e3
+                allgather.update({"ms_per_step_with_allgather": ms_g,
+                                  "value_with_allgather": rows * n * world * args.steps / wall_g,
+                                  "busbw_GBps": nb * (world - 1) / max(ms_g - elapsed / args.steps * 1e3, 1e-6) / 1e6})
+                comm.destroy()
+            except Exception as exc:  # keep the compute line even if RCCL is unusable on this node
+                allgather["error"] = str(exc)[:300]
+
+        # a collective that never returns must not cost the compute line: bounded wait, then report and leave
+        import threading
+
+        th = threading.Thread(target=gather_phase, daemon=True)
+        th.start()
+        th.join(timeout=float(os.environ.get("MANIPULAPY_BENCH_GATHER_TIMEOUT", "120")))
+        if th.is_alive():
+            allgather["error"] = "timeout: the RCCL phase did not complete"
+            hung = True
+        else:
+            hung = False
+    else:
+        hung = False
 
     jt_per_step = rows * n * world
     value = jt_per_step * args.steps / elapsed
@@ -314,6 +334,8 @@ def main():
         result["allgather"] = allgather
     if info.rank == 0:
         print(json.dumps(result), flush=True)
+    if hung:
+        os._exit(0)  # a stuck collective cannot be cancelled from Python
     ctx.destroy()
 
 

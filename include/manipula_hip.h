@@ -167,6 +167,12 @@ int mp_fd_trajectory_f64(mp_ctx* ctx, const mp_model* model, const double* d_the
                          const double* d_taumat, const double* d_Ftipmat, int64_t B, int64_t N, const double* g,
                          double dt, int intRes, float* d_pos, float* d_vel, float* d_acc);
 
+/* cartesian_trajectory for B pose pairs (planning/trajectory.py:504-594, :676-737; replaces
+ * cartesian_trajectory_kernel, cuda_kernels/trajectory_kernels.py:707-759, and the host-side orientation loop):
+ * Xstart / Xend (B,4,4) float64; pos / vel / acc (B,N,3) and orientations (B,N,3,3) float32.  N >= 2. */
+int mp_cartesian_trajectory_f32(mp_ctx* ctx, const double* d_Xstart, const double* d_Xend, int64_t B, int64_t N, double Tf,
+                                int method, float* d_pos, float* d_vel, float* d_acc, float* d_orient);
+
 /* ---- hot path, host pointers (what a Python gpu_launcher calls): H2D, launch, D2H, synchronise - */
 int mp_batch_trajectory_host_f32(mp_ctx* ctx, const mp_model* model, const float* start, const float* end,
                                  int64_t B, int64_t N, double Tf, int method, float* pos, float* vel, float* acc);
@@ -190,6 +196,9 @@ int mp_fd_trajectory_host_f32(mp_ctx* ctx, const mp_model* model, const float* t
 int mp_fd_trajectory_host_f64(mp_ctx* ctx, const mp_model* model, const double* theta0, const double* dtheta0,
                               const double* taumat, const double* Ftipmat, int64_t B, int64_t N, const double* g,
                               double dt, int intRes, float* pos, float* vel, float* acc);
+
+int mp_cartesian_trajectory_host_f32(mp_ctx* ctx, const double* Xstart, const double* Xend, int64_t B, int64_t N, double Tf,
+                                     int method, float* pos, float* vel, float* acc, float* orient);
 
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI (new; the reference is single-device) ------
  * Trajectory batches are sharded over ranks with no exchange during compute; the only collective is

@@ -85,6 +85,8 @@ SIGNATURES = {
     "mp_forward_dynamics_host_f64": (ctypes.c_int, [_vp, _vp, _c_dp, _c_dp, _c_dp, _i64, _c_dp, _c_dp, _c_dp]),
     "mp_fd_trajectory_host_f32": (ctypes.c_int, [_vp, _vp, _c_fp, _c_fp, _c_fp, _c_fp, _i64, _i64, _c_dp, ctypes.c_double, ctypes.c_int, _c_fp, _c_fp, _c_fp]),
     "mp_fd_trajectory_host_f64": (ctypes.c_int, [_vp, _vp, _c_dp, _c_dp, _c_dp, _c_dp, _i64, _i64, _c_dp, ctypes.c_double, ctypes.c_int, _c_fp, _c_fp, _c_fp]),
+    "mp_cartesian_trajectory_f32": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, ctypes.c_double, ctypes.c_int, _vp, _vp, _vp, _vp]),
+    "mp_cartesian_trajectory_host_f32": (ctypes.c_int, [_vp, _c_dp, _c_dp, _i64, _i64, ctypes.c_double, ctypes.c_int, _c_fp, _c_fp, _c_fp, _c_fp]),
     "mp_batch_trajectory_host_f32": (ctypes.c_int, [_vp, _vp, _c_fp, _c_fp, _i64, _i64, ctypes.c_double, ctypes.c_int, _c_fp, _c_fp, _c_fp]),
     "mp_id_trajectory_host_f32": (ctypes.c_int, [_vp, _vp, _c_fp, _c_fp, _c_fp, _i64, _c_dp, _c_dp, _c_fp]),
     "mp_id_trajectory_host_f64": (ctypes.c_int, [_vp, _vp, _c_dp, _c_dp, _c_dp, _i64, _c_dp, _c_dp, _c_dp]),
@@ -435,6 +437,19 @@ class HipContext:
         _check(self.lib.mp_fk_jac_id_host_f64(self.handle, model.handle, _dptr(q), _dptr(qd), _dptr(qdd), rows,
                                               _dptr(g), _dptr(F), _dptr(T), _dptr(J), _dptr(tau)))
         return T, J, tau
+
+    def cartesian_trajectory_host(self, Xstart, Xend, Tf, N, method):
+        """B pose pairs (B,4,4) -> positions / velocities / accelerations (B,N,3), orientations (B,N,3,3), float32."""
+        Xs = _as_c(Xstart, np.float64, name="Xstart")
+        if Xs.ndim != 3 or Xs.shape[1:] != (4, 4):
+            raise ValueError(f"Xstart must be (B, 4, 4), got {Xs.shape}")
+        Xe = _as_c(Xend, np.float64, Xs.shape, "Xend")
+        B, N = Xs.shape[0], int(N)
+        pos, vel, acc = (np.zeros((B, N, 3), dtype=np.float32) for _ in range(3))
+        ori = np.zeros((B, N, 3, 3), dtype=np.float32)
+        _check(self.lib.mp_cartesian_trajectory_host_f32(self.handle, _dptr(Xs), _dptr(Xe), B, N, float(Tf), int(method),
+                                                         _fptr(pos), _fptr(vel), _fptr(acc), _fptr(ori)))
+        return pos, vel, acc, ori
 
     def mass_matrix_host(self, model: HipModel, q) -> np.ndarray:
         q = _as_c(q, np.float64, name="q")

@@ -859,6 +859,45 @@ int mp_forward_dynamics_host_f64(mp_ctx* ctx, const mp_model* model, const doubl
   return MP_OK;
 }
 
+int mp_cartesian_trajectory_f32(mp_ctx* ctx, const double* d_Xstart, const double* d_Xend, int64_t B, int64_t N, double Tf,
+                                int method, float* d_pos, float* d_vel, float* d_acc, float* d_orient) {
+  REQUIRE(ctx, "mp_cartesian_trajectory_f32: null context");
+  if (int rc = bind(ctx)) return rc;
+  REQUIRE(B >= 0 && N >= 0, "mp_cartesian_trajectory_f32: negative B or N");
+  if (B == 0 || N == 0) return MP_OK;
+  REQUIRE(N >= 2, "mp_cartesian_trajectory_f32: N = 1 divides by zero (Tf / (N - 1))");
+  REQUIRE(d_Xstart && d_Xend && d_pos && d_vel && d_acc && d_orient, "mp_cartesian_trajectory_f32: null device pointer");
+  REQUIRE(aligned16(d_Xstart) && aligned16(d_Xend), "mp_cartesian_trajectory_f32: pose pointers must be 16-byte aligned");
+  HIP_TRY(mpk_cartesian_traj(ctx->compute, d_Xstart, d_Xend, (long)B, (long)N, Tf, method, d_pos, d_vel, d_acc, d_orient));
+  return MP_OK;
+}
+int mp_cartesian_trajectory_host_f32(mp_ctx* ctx, const double* Xstart, const double* Xend, int64_t B, int64_t N, double Tf,
+                                     int method, float* pos, float* vel, float* acc, float* orient) {
+  REQUIRE(ctx, "mp_cartesian_trajectory_host_f32: null context");
+  if (int rc = bind(ctx)) return rc;
+  REQUIRE(B >= 0 && N >= 0, "mp_cartesian_trajectory_host_f32: negative B or N");
+  if (B == 0 || N == 0) return MP_OK;
+  REQUIRE(Xstart && Xend && pos && vel && acc && orient, "mp_cartesian_trajectory_host_f32: null host pointer");
+  const size_t xb = (size_t)B * 16 * sizeof(double), pb = (size_t)B * (size_t)N * 3 * sizeof(float);
+  Scratch sc(ctx);
+  void *ds, *de, *dp, *dv, *da, *dor;
+  if (int rc = sc.get(xb, &ds)) return rc;
+  if (int rc = sc.get(xb, &de)) return rc;
+  if (int rc = sc.get(pb, &dp)) return rc;
+  if (int rc = sc.get(pb, &dv)) return rc;
+  if (int rc = sc.get(pb, &da)) return rc;
+  if (int rc = sc.get(pb * 3, &dor)) return rc;
+  H2D(ds, Xstart, xb);
+  H2D(de, Xend, xb);
+  if (int rc = mp_cartesian_trajectory_f32(ctx, (double*)ds, (double*)de, B, N, Tf, method, (float*)dp, (float*)dv, (float*)da, (float*)dor)) return rc;
+  D2H(pos, dp, pb);
+  D2H(vel, dv, pb);
+  D2H(acc, da, pb);
+  D2H(orient, dor, pb * 3);
+  HIP_TRY(hipStreamSynchronize(ctx->compute));
+  return MP_OK;
+}
+
 }  // extern "C"
 
 

@@ -452,3 +452,90 @@ MP_HD void mp_time_scaling(int method, double tau, double Tf, double& s, double&
     s = sd = sdd = 0.0;
   }
 }
+
+// ------------------------------------------------------------------------- Cartesian straight line
+// cartesian_trajectory (reference planning/trajectory.py:504-594, :676-737): straight-line position,
+// orientation R_start exp(log(R_start^T R_end) s).  float64 math, float32 rows.
+// log: reference utils/so3.py:172-191 (+ :36-74 half-turn axis convention, :116-160 theta / sin theta);
+// exp: utils/so3.py:199-237 (Rodrigues with the theta^2 < 1e-4 Taylor branch).
+MP_HD void mp_log3(const double (&R)[9], double (&w)[3]) {
+  const double tr = R[0] + R[4] + R[8];
+  double cs = 0.5 * (tr - 1.0);
+  cs = cs < -1.0 ? -1.0 : (cs > 1.0 ? 1.0 : cs);
+  const double vee[3] = {R[7] - R[5], R[2] - R[6], R[3] - R[1]};
+  double vv = vee[0] * vee[0] + vee[1] * vee[1] + vee[2] * vee[2];
+  vv = vv < 1e-300 ? 1e-300 : vv;
+  const double sn = 0.5 * sqrt(vv);
+  const double theta = atan2(sn, cs);
+  if (theta > 3.14159265358979323846 - 1e-2) {  // half-turn band: axis from the symmetric part
+    const double s00 = R[0] - cs, s11 = R[4] - cs, s22 = R[8] - cs;
+    const double s01 = 0.5 * (R[1] + R[3]), s02 = 0.5 * (R[2] + R[6]), s12 = 0.5 * (R[5] + R[7]);
+    double c0, c1, c2, sref;
+    if (s22 >= 1e-6) { c0 = s02; c1 = s12; c2 = s22; sref = vee[2]; }
+    else if (s11 >= 1e-6) { c0 = s01; c1 = s11; c2 = s12; sref = vee[1]; }
+    else { c0 = s00; c1 = s01; c2 = s02; sref = vee[0]; }
+    double nn = c0 * c0 + c1 * c1 + c2 * c2;
+    nn = nn < 1e-24 ? 1e-24 : nn;
+    const double k = (sref >= 0.0 ? theta : -theta) / sqrt(nn);
+    w[0] = k * c0; w[1] = k * c1; w[2] = k * c2;
+    return;
+  }
+  const double u = 1.0 - cs;
+  const double coef = (cs > 1.0 - 5e-5) ? 1.0 + u / 3.0 + 4.0 * u * u / 45.0 : acos(cs) / sqrt(1.0 - cs * cs);
+  w[0] = 0.5 * coef * vee[0]; w[1] = 0.5 * coef * vee[1]; w[2] = 0.5 * coef * vee[2];
+}
+
+// out = Rs . exp([w])   (row-major 3x3)
+MP_HD void mp_rot_times_exp3(const double (&Rs)[9], const double (&w)[3], double (&out)[9]) {
+  const double t2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  double A, B;
+  if (t2 < 1e-4) {
+    A = 1.0 - t2 / 6.0 + t2 * t2 / 120.0;
+    B = 0.5 - t2 / 24.0 + t2 * t2 / 720.0;
+  } else {
+    const double t = sqrt(t2);
+    A = sin(t) / t;
+    B = (1.0 - cos(t)) / t2;
+  }
+  // E = I + A K + B K^2,  K = [w]x,  K^2 = w w^T - |w|^2 I
+  const double E[9] = {1.0 + B * (w[0] * w[0] - t2), -A * w[2] + B * w[0] * w[1], A * w[1] + B * w[0] * w[2],
+                       A * w[2] + B * w[0] * w[1], 1.0 + B * (w[1] * w[1] - t2), -A * w[0] + B * w[1] * w[2],
+                       -A * w[1] + B * w[0] * w[2], A * w[0] + B * w[1] * w[2], 1.0 + B * (w[2] * w[2] - t2)};
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[3 * r + c] = Rs[3 * r] * E[c] + Rs[3 * r + 1] * E[3 + c] + Rs[3 * r + 2] * E[6 + c];
+}
+
+// One timestep `i` of N between the poses Xs, Xe (4x4 row-major): position, velocity, acceleration, orientation.
+// Positions / orientations: cubic for method 3, QUINTIC for anything else; velocities / accelerations: cubic (3),
+// quintic (5), zero otherwise — the reference's two code paths differ and both are reproduced.
+MP_HD void mp_cartesian_point(const double (&Xs)[16], const double (&Xe)[16], long i, long N, double Tf, int method,
+                              float (&pos)[3], float (&vel)[3], float (&acc)[3], float (&ori)[9]) {
+  const double timegap = Tf / ((double)N - 1.0);
+  const double x = (timegap * (double)i) / Tf;
+  const double s = (method == 3) ? 3.0 * x * x - 2.0 * x * x * x : 10.0 * x * x * x - 15.0 * x * x * x * x + 6.0 * x * x * x * x * x;
+  const double Rs[9] = {Xs[0], Xs[1], Xs[2], Xs[4], Xs[5], Xs[6], Xs[8], Xs[9], Xs[10]};
+  const double Re[9] = {Xe[0], Xe[1], Xe[2], Xe[4], Xe[5], Xe[6], Xe[8], Xe[9], Xe[10]};
+  double D[9];  // Rs^T Re
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) D[3 * r + c] = Rs[r] * Re[c] + Rs[3 + r] * Re[3 + c] + Rs[6 + r] * Re[6 + c];
+  double w[3], O[9];
+  mp_log3(D, w);
+  const double ws[3] = {w[0] * s, w[1] * s, w[2] * s};
+  mp_rot_times_exp3(Rs, ws, O);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) ori[k] = (float)O[k];
+  const double tau = ((double)i * (Tf / (double)(N - 1))) / Tf;
+  double s2, sd, sdd;
+  mp_time_scaling(method, tau, Tf, s2, sd, sdd);
+  const double ps[3] = {Xs[3], Xs[7], Xs[11]}, pe[3] = {Xe[3], Xe[7], Xe[11]};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    pos[k] = (float)(s * pe[k] + (1.0 - s) * ps[k]);
+    vel[k] = (float)(sd * (pe[k] - ps[k]));
+    acc[k] = (float)(sdd * (pe[k] - ps[k]));
+  }
+}

@@ -34,3 +34,7 @@ hipError_t mpk_forward_dynamics(hipStream_t s, const MpModel<T>& M, const MpCall
 template <typename T>
 hipError_t mpk_fd_traj(hipStream_t s, const MpModel<T>& M, const MpCall<T>& C, const T* theta0, const T* dtheta0,
                        const T* taumat, const T* Ftipmat, long B, long Nt, T h, int intRes, float* pos, float* vel, float* acc);
+
+// Cartesian straight-line trajectories between B pose pairs (4x4 row-major float64): float32 (B,Nt,3) x3, (B,Nt,3,3)
+hipError_t mpk_cartesian_traj(hipStream_t s, const double* Xstart, const double* Xend, long B, long Nt, double Tf, int method,
+                              float* pos, float* vel, float* acc, float* ori);

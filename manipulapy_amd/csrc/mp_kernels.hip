@@ -192,6 +192,26 @@ __global__ __launch_bounds__(kBlock) void k_fd_traj(const MpModel<T> M, const Mp
   mp_body_fd_traj<T, N, HAS_FTIP>(M, C, theta0, dtheta0, taumat, Ftipmat, b, Nt, h, intRes, pos, vel, acc);
 }
 
+// ------------------------------------------------------------------- Cartesian straight-line path
+// one lane per (pose pair b, timestep i); outputs float32 (B,N,3) x3 and (B,N,3,3)
+__global__ __launch_bounds__(kBlock) void k_cartesian_traj(const double* __restrict__ Xstart, const double* __restrict__ Xend,
+                                                           long B, long Nt, double Tf, int method, float* __restrict__ pos,
+                                                           float* __restrict__ vel, float* __restrict__ acc,
+                                                           float* __restrict__ ori) {
+  const long r = (long)blockIdx.x * kBlock + threadIdx.x;
+  if (r >= B * Nt) return;
+  const long b = r / Nt, i = r - b * Nt;
+  double Xs[16], Xe[16];
+  RunIO<double, 16>::load(Xstart, b, Xs);
+  RunIO<double, 16>::load(Xend, b, Xe);
+  float p[3], v[3], a[3], o[9];
+  mp_cartesian_point(Xs, Xe, i, Nt, Tf, method, p, v, a, o);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { pos[r * 3 + k] = p[k]; vel[r * 3 + k] = v[k]; acc[r * 3 + k] = a[k]; }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) ori[r * 9 + k] = o[k];
+}
+
 inline unsigned grid_for(long rows) { return (unsigned)((rows + kBlock - 1) / kBlock); }
 
 // float32 variant selection (A/B switch for profiling): MANIPULAPY_HIP_F32 = "packed" (default) | "scalar"
@@ -355,3 +375,10 @@ template hipError_t mpk_fd_traj<float>(hipStream_t, const MpModel<float>&, const
 template hipError_t mpk_fd_traj<double>(hipStream_t, const MpModel<double>&, const MpCall<double>&, const double*,
                                         const double*, const double*, const double*, long, long, double, int, float*, float*,
                                         float*);
+
+hipError_t mpk_cartesian_traj(hipStream_t s, const double* Xstart, const double* Xend, long B, long Nt, double Tf, int method,
+                              float* pos, float* vel, float* acc, float* ori) {
+  if (B <= 0 || Nt <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_cartesian_traj, dim3(grid_for(B * Nt)), dim3(kBlock), 0, s, Xstart, Xend, B, Nt, Tf, method, pos, vel, acc, ori);
+  return hipGetLastError();
+}

@@ -162,6 +162,32 @@ class OptimizedTrajectoryPlanning:
             self._count("cpu", t0)
         return {"positions": backend.asarray(pos), "velocities": backend.asarray(vel), "accelerations": backend.asarray(acc)}
 
+    def cartesian_trajectory(self, Xstart, Xend, Tf, N, method) -> Dict[str, np.ndarray]:
+        """Straight-line Cartesian trajectory between two SE(3) poses (reference planning/trajectory.py:504-594):
+        positions / velocities / accelerations (N, 3) and orientations (N, 3, 3), float32."""
+        Xs, Xe = np.asarray(Xstart, dtype=np.float64), np.asarray(Xend, dtype=np.float64)
+        N = int(N)
+        if N < 0:
+            raise ValueError("negative dimensions are not allowed")
+        if N == 0:  # the reference's empty shapes (:555-559, :727-730)
+            return {"positions": np.zeros((0,), np.float32), "velocities": np.zeros((0, 3), np.float32),
+                    "accelerations": np.zeros((0, 3), np.float32), "orientations": np.zeros((0, 3, 3), np.float32)}
+        if N == 1:
+            raise ZeroDivisionError("float division by zero")  # timegap = Tf / (N - 1.0), as in the reference
+        r = self.batch_cartesian_trajectory(Xs[None], Xe[None], Tf, N, method)
+        return {k: v[0] for k, v in r.items()}
+
+    def batch_cartesian_trajectory(self, Xstart_batch, Xend_batch, Tf, N, method) -> Dict[str, np.ndarray]:
+        """B pose pairs (B, 4, 4) in one launch -> (B, N, 3) / (B, N, 3, 3) float32 arrays.  New."""
+        t0 = time.time()
+        if not self._gpu_routed():
+            _reg.get_registered_kernel("trajectory.cartesian").cpu_launcher()  # raises BackendNotSupportedError
+        pos, vel, acc, ori = _reg.execute_registered_kernel("trajectory.cartesian", Xstart_batch, Xend_batch, Tf, int(N), int(method))
+        self._count("gpu", t0)
+        b = get_backend()
+        return {"positions": b.asarray(pos), "velocities": b.asarray(vel), "accelerations": b.asarray(acc),
+                "orientations": b.asarray(ori)}
+
     # ------------------------------------------------------------------ dynamics over trajectories
     def inverse_dynamics_trajectory(self, thetalist_trajectory, dthetalist_trajectory, ddthetalist_trajectory,
                                     gravity_vector=None, Ftip=None) -> np.ndarray:

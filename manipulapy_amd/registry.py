@@ -241,6 +241,10 @@ def _launch_fd_trajectory_gpu(model, theta0, dtheta0, taumat, g, Ftipmat, dt, in
     return get_context().fd_trajectory_host(model, theta0, dtheta0, taumat, g, Ftipmat, dt, intRes, dtype=dtype)
 
 
+def _launch_cartesian_gpu(Xstart, Xend, Tf, N, method):
+    return get_context().cartesian_trajectory_host(Xstart, Xend, Tf, N, method)
+
+
 def _grid_1d(rows: int, block: int = 256):
     """Launch shape every kernel uses: one thread per (trajectory, timestep) row, 256-thread blocks
     (4 wavefronts of 64).  Replaces the CUDA block heuristics of reference registry.py:409-515."""
@@ -281,6 +285,7 @@ def _build_kernel_registry() -> KernelRegistry:
         ("dynamics.mass_matrix", "mp_mass_matrix_host_f64", _launch_mass_matrix_gpu),
         ("dynamics.forward", "mp_forward_dynamics_host_f64", _launch_forward_dynamics_gpu),
         ("dynamics.forward_trajectory", "mp_fd_trajectory_host_f32 / _f64", _launch_fd_trajectory_gpu),
+        ("trajectory.cartesian", "mp_cartesian_trajectory_host_f32", _launch_cartesian_gpu),
     ):
         reg.register(KernelRegistration(
             name=name, implementation=impl, launch_config=_grid_1d, cpu_fallback=None, gpu_launcher=gpu,

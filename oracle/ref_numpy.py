@@ -313,6 +313,71 @@ def trajectory_points_numpy_twin(thetastart, thetaend, Tf, N, method):
             (sdd[:, None] * d[None, :]).astype(np.float32))
 
 
+# --------------------------------------------------------------------------- SO(3) log / exp, Cartesian path
+def matrix_log3(R):
+    """utils/so3.py:172-191 (+ :36-74 half-turn axis, :116-160 theta/sin theta): rotation VECTOR of log(R).
+
+    theta = atan2(|vee(R - R^T)| / 2, (tr R - 1) / 2).  theta > pi - 1e-2: theta * n with n from the symmetric
+    part (column 2 if sym[2,2] >= 1e-6, else column 1 if sym[1,1] >= 1e-6, else column 0; sign of the matching
+    vee component, >= 0 -> +).  Otherwise 0.5 (theta / sin theta) vee, Taylor 1 + u/3 + 4u^2/45 in u = 1 - cos
+    for cos > 1 - 5e-5."""
+    R = np.asarray(R, dtype=np.float64)
+    cos_t = np.clip((np.trace(R) - 1) / 2, -1.0, 1.0)
+    vee = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    sin_t = np.sqrt(max(vee @ vee, 1e-300)) / 2
+    theta = np.arctan2(sin_t, cos_t)
+    if theta > np.pi - 1e-2:
+        sym = 0.5 * (R + R.T) - cos_t * np.eye(3)
+        j = 2 if sym[2, 2] >= 1e-6 else (1 if sym[1, 1] >= 1e-6 else 0)
+        cand = sym[:, j]
+        axis = cand / np.sqrt(max(cand @ cand, 1e-24))
+        return theta * (1.0 if vee[j] >= 0 else -1.0) * axis
+    u = 1.0 - cos_t
+    if cos_t > 1 - 5e-5:
+        coef = 1.0 + u / 3.0 + 4.0 * u * u / 45.0
+    else:
+        coef = np.arccos(cos_t) / np.sqrt(1.0 - cos_t * cos_t)
+    return 0.5 * coef * vee
+
+
+def matrix_exp3(rotvec):
+    """utils/so3.py:199-237 — Rodrigues I + A K + B K^2, A = sin t / t, B = (1 - cos t) / t^2 with the
+    t^2 < 1e-4 Taylor branch (1 - t^2/6 + t^4/120, 1/2 - t^2/24 + t^4/720)."""
+    w = np.asarray(rotvec, dtype=np.float64)
+    t2 = w @ w
+    if t2 < 1e-4:
+        A, B = 1.0 - t2 / 6.0 + t2 * t2 / 120.0, 0.5 - t2 / 24.0 + t2 * t2 / 720.0
+    else:
+        t = np.sqrt(t2)
+        A, B = np.sin(t) / t, (1 - np.cos(t)) / t2
+    K = skew(w)
+    return np.eye(3) + A * K + B * (K @ K)
+
+
+def cartesian_trajectory(Xstart, Xend, Tf, N, method):
+    """planning/trajectory.py:504-594 + :676-737.  positions / orientations use cubic for method 3 and QUINTIC
+    for anything else; velocities / accelerations use cubic (3), quintic (5), zeros otherwise.  float64 math,
+    float32 rows.  N = 1 divides by zero (ZeroDivisionError), as in the reference."""
+    Xs, Xe = np.asarray(Xstart, dtype=np.float64), np.asarray(Xend, dtype=np.float64)
+    N = int(N)
+    timegap = Tf / (N - 1.0)
+    Rs, ps, Re, pe = Xs[:3, :3], Xs[:3, 3], Xe[:3, :3], Xe[:3, 3]
+    w = matrix_log3(Rs.T @ Re)
+    pos, ori, vel, acc = [], [], [], []
+    for i in range(N):
+        t = timegap * i
+        s = 3 * (t / Tf) ** 2 - 2 * (t / Tf) ** 3 if method == 3 else 10 * (t / Tf) ** 3 - 15 * (t / Tf) ** 4 + 6 * (t / Tf) ** 5
+        ori.append(Rs @ matrix_exp3(w * s))
+        pos.append(s * pe + (1 - s) * ps)
+        tau = (i * (Tf / (N - 1))) / Tf
+        _, sd, sdd = time_scaling(tau, float(Tf), method)
+        vel.append(sd * (pe - ps))
+        acc.append(sdd * (pe - ps))
+    f32 = lambda a, shape: np.asarray(a, dtype=np.float32).reshape(shape)  # noqa: E731
+    return {"positions": f32(pos, (N, 3)), "velocities": f32(vel, (N, 3)), "accelerations": f32(acc, (N, 3)),
+            "orientations": f32(ori, (N, 3, 3))}
+
+
 # --------------------------------------------------------------------------- planner level
 def joint_trajectory(joint_limits, thetastart, thetaend, Tf, N, method):
     """planning/trajectory.py:276-333 — generate, then clip POSITIONS to float32 joint limits."""

@@ -19,6 +19,7 @@ What it does:
                              extended with random Ftip, FK, Jacobians, forward dynamics)
       trajectory_ur5.npz   : joint_trajectory / batch_joint_trajectory /
                              inverse_dynamics_trajectory / forward_dynamics_trajectory dumps
+      cartesian_ur5.npz    : cartesian_trajectory dumps (`make_golden.py cartesian` regenerates only this)
       reference_cpu_timings.json : cold-cache per-point timings of the reference
 
 Nothing from /root/reference is copied: the fixtures hold numbers only.
@@ -247,6 +248,39 @@ def dump_trajectories():
     )
 
 
+def dump_cartesian():
+    """cartesian_trajectory (planning/trajectory.py:504-594) dumps: generic pose pair, near-identity, near-pi and
+    exact half-turn rotations, cubic + quintic + 'other' method."""
+    from ManipulaPy.planning import OptimizedTrajectoryPlanning
+
+    proc, sm, dyn = build("ur5")
+    lims = finite_limits(sm, sm.S_list.shape[1])
+    planner = OptimizedTrajectoryPlanning(sm, get_robot_urdf("ur5"), dyn, lims.tolist(), use_cuda=False)
+    rng = np.random.default_rng(SEED + 400)
+
+    def rot(axis, ang):
+        axis = np.asarray(axis, float) / np.linalg.norm(axis)
+        K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+        return np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * (K @ K)
+
+    Xs = np.asarray(sm.forward_kinematics(rng.uniform(-2, 2, 6)))
+    cases = {"generic": np.asarray(sm.forward_kinematics(rng.uniform(-2, 2, 6)))}
+    for tag, (axis, ang) in {"tiny": ([1, 2, 3], 1e-5), "small": ([0, 1, 1], 5e-3), "nearpi": ([1, -1, 0.5], np.pi - 1e-3),
+                             "pi_z": ([0, 0, 1], np.pi), "pi_x": ([1, 0, 0], np.pi), "pi_gen": ([1, 2, -1], np.pi)}.items():
+        X = np.eye(4)
+        X[:3, :3] = Xs[:3, :3] @ rot(axis, ang)
+        X[:3, 3] = Xs[:3, 3] + rng.uniform(-0.3, 0.3, 3)
+        cases[tag] = X
+    d = {"Xstart": Xs}
+    for tag, Xe in cases.items():
+        d[f"{tag}_Xend"] = Xe
+        for method in (3, 5, 1):
+            r = planner.cartesian_trajectory(Xs, Xe, 2.0, 21, method)
+            for k in ("positions", "velocities", "accelerations", "orientations"):
+                d[f"{tag}_m{method}_{k}"] = np.asarray(r[k])
+    np.savez(os.path.join(HERE, "cartesian_ur5.npz"), **d)
+
+
 def time_reference():
     """Cold-cache single-thread timings of the reference's inverse_dynamics."""
     res = {"host": "build container", "cores_visible": os.cpu_count(), "threads_used": 1,
@@ -273,12 +307,17 @@ def time_reference():
 
 def main():
     assert os.environ.get("PYTHONHASHSEED") == "0"
+    if "cartesian" in sys.argv[1:]:  # only (re)generate the Cartesian-trajectory dump
+        dump_cartesian()
+        print("cartesian dumped")
+        return
     for i, robot in enumerate(ROBOTS):
         proc, sm, dyn = build(robot)
         n = dump_model(robot, proc, sm, dyn)
         dump_dynamics(robot, sm, dyn, n, i)
         print(f"{robot}: n={n} dumped", flush=True)
     dump_trajectories()
+    dump_cartesian()
     print("trajectories dumped", flush=True)
     time_reference()
     print("timings dumped")

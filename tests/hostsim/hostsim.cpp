@@ -182,3 +182,17 @@ extern "C" int hostsim_run(int n, const double* S, const double* Mcom, const dou
   return use_f32 ? run<float>(Md, Cd, ftip, rows, q, qd, qdd, tau, Tout, Jout)
                  : run<double>(Md, Cd, ftip, rows, q, qd, qdd, tau, Tout, Jout);
 }
+
+// Cartesian straight-line trajectory (mp_cartesian_point), N points between one pose pair
+extern "C" int hostsim_cartesian(const double* Xs, const double* Xe, long N, double Tf, int method, float* pos, float* vel,
+                                 float* acc, float* ori) {
+  double A[16], B[16];
+  for (int k = 0; k < 16; ++k) { A[k] = Xs[k]; B[k] = Xe[k]; }
+  for (long i = 0; i < N; ++i) {
+    float p[3], v[3], a[3], o[9];
+    mp_cartesian_point(A, B, i, N, Tf, method, p, v, a, o);
+    for (int k = 0; k < 3; ++k) { pos[i * 3 + k] = p[k]; vel[i * 3 + k] = v[k]; acc[i * 3 + k] = a[k]; }
+    for (int k = 0; k < 9; ++k) ori[i * 9 + k] = o[k];
+  }
+  return 0;
+}

@@ -512,3 +512,35 @@ def test_random_robots_on_gpu(seed, ctx):
     assert np.abs(s32[:9] - want).max() <= 2e-4 * scale
     np.testing.assert_allclose(s64[:9], want, rtol=1e-6, atol=1e-6 * scale)
     assert np.abs(s32 - t32).max() <= 2e-4 * scale
+
+
+def test_cartesian_trajectory_on_gpu(ctx):
+    """cartesian_trajectory through the planner (hip backend) vs the reference dump, all SO(3) log branches."""
+    import manipulapy_amd as mp
+
+    z = np.load(golden_path("cartesian_ur5.npz"))
+    sm, dyn, lim = mp.load_robot("ur5")
+    with mp.use_backend("hip"):
+        pl = mp.OptimizedTrajectoryPlanning(sm, None, dyn, lim)
+        for tag in ("generic", "tiny", "small", "nearpi", "pi_z", "pi_x", "pi_gen"):
+            for method in (3, 5, 1):
+                r = pl.cartesian_trajectory(z["Xstart"], z[f"{tag}_Xend"], 2.0, 21, method)
+                for k in ("positions", "velocities", "accelerations", "orientations"):
+                    want = z[f"{tag}_m{method}_{k}"]
+                    assert r[k].dtype == np.float32 and r[k].shape == want.shape
+                    np.testing.assert_allclose(r[k], want, rtol=2e-6, atol=2e-6, err_msg=f"{tag} m{method} {k}")
+        # batch = stacked singles; orientations stay orthonormal; end points hit
+        tags = ("generic", "small", "nearpi")
+        Xe = np.stack([z[f"{t}_Xend"] for t in tags])
+        rb = pl.batch_cartesian_trajectory(np.broadcast_to(z["Xstart"], Xe.shape), Xe, 2.0, 300, 5)
+        assert rb["orientations"].shape == (3, 300, 3, 3)
+        for b, t in enumerate(tags):
+            one = pl.cartesian_trajectory(z["Xstart"], z[f"{t}_Xend"], 2.0, 300, 5)
+            np.testing.assert_array_equal(one["orientations"], rb["orientations"][b])
+            np.testing.assert_allclose(rb["orientations"][b, -1], z[f"{t}_Xend"][:3, :3], atol=2e-6)
+            np.testing.assert_allclose(rb["positions"][b, -1], z[f"{t}_Xend"][:3, 3], atol=2e-6)
+        RtR = np.einsum("bnij,bnik->bnjk", rb["orientations"], rb["orientations"])
+        assert np.abs(RtR - np.eye(3)).max() < 5e-6
+        with pytest.raises(ZeroDivisionError):
+            pl.cartesian_trajectory(z["Xstart"], z["generic_Xend"], 2.0, 1, 5)
+        assert pl.cartesian_trajectory(z["Xstart"], z["generic_Xend"], 2.0, 0, 5)["orientations"].shape == (0, 3, 3)

@@ -148,7 +148,16 @@ def hostsim():
                             P(Ftipmat), ctypes.c_double(dt), intRes, f32, P(out), err, ctypes.c_long(256))
         assert rc == 0, err.value
         return out
+    def cartesian(Xs, Xe, N, Tf, method):
+        fp = ctypes.POINTER(ctypes.c_float)
+        Xs, Xe = np.ascontiguousarray(Xs, dtype=np.float64), np.ascontiguousarray(Xe, dtype=np.float64)
+        out = [np.zeros((N, 3), np.float32) for _ in range(3)] + [np.zeros((N, 3, 3), np.float32)]
+        rc = lib.hostsim_cartesian(Xs.ctypes.data_as(dp), Xe.ctypes.data_as(dp), ctypes.c_long(N), ctypes.c_double(Tf), int(method),
+                                   *[o.ctypes.data_as(fp) for o in out])
+        assert rc == 0
+        return out
     run.fd = fd
+    run.cartesian = cartesian
     return run
 
 
@@ -190,6 +199,16 @@ def test_device_fd_trajectory_on_host(hostsim):
                          int(z["intRes"]), f32, outshape=(3, N, 6))
         for k, key in enumerate(("positions", "velocities", "accelerations")):
             assert np.abs(out[k] - z[key]).max() <= tol * max(1.0, float(np.abs(z[key]).max()))
+
+
+def test_device_cartesian_trajectory_on_host(hostsim):
+    """SO(3) log / exp branches of the device code (near identity, near pi, exact half turns) vs the reference dump."""
+    z = np.load(golden_path("cartesian_ur5.npz"))
+    for tag in ("generic", "tiny", "small", "nearpi", "pi_z", "pi_x", "pi_gen"):
+        for method in (3, 5, 1):
+            got = hostsim.cartesian(z["Xstart"], z[f"{tag}_Xend"], 21, 2.0, method)
+            for g, k in zip(got, ("positions", "velocities", "accelerations", "orientations")):
+                np.testing.assert_allclose(g, z[f"{tag}_m{method}_{k}"], rtol=2e-6, atol=2e-6, err_msg=f"{tag} m{method} {k}")
 
 
 def test_float32_sincos_accuracy(hostsim, tables):
@@ -276,7 +295,7 @@ def test_kernel_registry_semantics():
     for v in ("auto", "auto_tune", "standard", "vectorized", "memory_optimized", "warp_optimized", "cache_friendly"):
         assert f"trajectory.{v}" in names
     for n in ("trajectory.batch", "dynamics.inverse_trajectory", "dynamics.fused_trajectory_inverse", "kinematics.fk_jacobian",
-              "dynamics.mass_matrix", "dynamics.forward", "dynamics.forward_trajectory"):
+              "dynamics.mass_matrix", "dynamics.forward", "dynamics.forward_trajectory", "trajectory.cartesian"):
         assert n in names
     with pytest.raises(KeyError, match="Available kernels: dynamics.forward, dynamics.forward_trajectory"):
         mp.get_registered_kernel("trajectory.nope")
