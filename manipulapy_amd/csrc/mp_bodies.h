@@ -263,13 +263,23 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
 #pragma unroll
   for (int j = 0; j < N; ++j) o[j] = 0.f;
   RunIO<float, N>::store(acc, b * Nt, o);
+  // step i's torque / wrench rows are fetched one step ahead, so the (lane-strided, latency-bound) loads overlap
+  // the previous step's arithmetic instead of stalling the head of every iteration
+  T tau_n[N], F_n[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) F_n[k] = T(0);
+  if (Nt > 1) {
+    RunIO<T, N>::load(taumat, b * Nt + 1, tau_n);
+    if (HAS_FTIP) RunIO<T, 6>::load(Ftipmat, b * Nt + 1, F_n);
+  }
   for (long i = 1; i < Nt; ++i) {
     T tau[N], tn[3] = {T(0), T(0), T(0)}, tf[3] = {T(0), T(0), T(0)};
-    RunIO<T, N>::load(taumat, b * Nt + i, tau);
-    if (HAS_FTIP) {
-      T F[6];
-      RunIO<T, 6>::load(Ftipmat, b * Nt + i, F);
-      mp_wrench_to_frame1(M, F, tn, tf);
+#pragma unroll
+    for (int j = 0; j < N; ++j) tau[j] = tau_n[j];
+    if (HAS_FTIP) mp_wrench_to_frame1(M, F_n, tn, tf);
+    if (i + 1 < Nt) {
+      RunIO<T, N>::load(taumat, b * Nt + i + 1, tau_n);
+      if (HAS_FTIP) RunIO<T, 6>::load(Ftipmat, b * Nt + i + 1, F_n);
     }
     T last[N];
 #pragma unroll

@@ -334,6 +334,83 @@ MP_HD void mp_mass_matrix(const MT& M, const MpJointState<T, N>& js, T (&Mq)[N][
     for (int j = 0; j < N; ++j) Mq[i][j] = S(0.5) * (col[j][i] + col[i][j]);
 }
 
+// Composite-rigid-body form of the same matrix (Featherstone's CRBA in the compiled link frames).  A rigid-body
+// inertia about a frame origin is (m, h = m c, I_o): 10 numbers, and the sum of rigid bodies is a rigid body, so
+// the composite inertia of links i..n stays in that form.  Moving it from child to parent coordinates across an
+// axis-aligned step costs one planar rotation of (h, I_o) plus a parallel-axis shift along one axis:
+//     h' = R h + m r,   I' = R I R^T + (2 (Rh).r) 1 - (Rh) r^T - r (Rh)^T + m (|r|^2 1 - r r^T).
+// Column i of M is then S_i^T of the force I^c_i S_i carried up the chain with the same force transforms the
+// Newton-Euler backward pass uses.  ~750 instructions at n = 6 against ~3300 for n unit-acceleration recursions.
+template <typename T>
+struct MpRbi {  // rigid-body inertia about the current frame's origin, in that frame's coordinates
+  T m, hx, hy, hz, xx, xy, xz, yy, yz, zz;
+};
+
+// child -> parent across Rz(theta) Tz(d):  R = Rz, r = (0, 0, d)
+template <typename T>
+MP_HD void mp_rbi_up_B(T c, T s, T d, MpRbi<T>& I) {
+  const T hx = c * I.hx - s * I.hy, hy = s * I.hx + c * I.hy;
+  const T cc = c * c, ss = s * s, sc = s * c;
+  const T xx = cc * I.xx - (sc + sc) * I.xy + ss * I.yy;
+  const T yy = ss * I.xx + (sc + sc) * I.xy + cc * I.yy;
+  const T xy = sc * (I.xx - I.yy) + (cc - ss) * I.xy;
+  const T xz = c * I.xz - s * I.yz, yz = s * I.xz + c * I.yz;
+  const T t = d * (I.hz + I.hz) + I.m * d * d;  // 2 (Rh).r + m |r|^2
+  I.xx = xx + t; I.yy = yy + t; I.xy = xy;
+  I.xz = xz - d * hx; I.yz = yz - d * hy;       // - (Rh) r^T - r (Rh)^T off-diagonals; zz: +2 d hz - 2 d hz = 0
+  I.hx = hx; I.hy = hy; I.hz = I.hz + I.m * d;
+}
+// child -> parent across Rx(alpha) Tx(a):  R = Rx, r = (a, 0, 0)
+template <typename T, typename S>
+MP_HD void mp_rbi_up_A(S ca, S sa, S a, MpRbi<T>& I) {
+  const T hy = ca * I.hy - sa * I.hz, hz = sa * I.hy + ca * I.hz;
+  const S cc = ca * ca, ss = sa * sa, sc = sa * ca;
+  const T yy = cc * I.yy - (sc + sc) * I.yz + ss * I.zz;
+  const T zz = ss * I.yy + (sc + sc) * I.yz + cc * I.zz;
+  const T yz = sc * (I.yy - I.zz) + (cc - ss) * I.yz;
+  const T xy = ca * I.xy - sa * I.xz, xz = sa * I.xy + ca * I.xz;
+  const T t = a * (I.hx + I.hx) + I.m * (a * a);
+  I.yy = yy + t; I.zz = zz + t; I.yz = yz;
+  I.xy = xy - a * hy; I.xz = xz - a * hz;
+  I.hy = hy; I.hz = hz; I.hx = I.hx + I.m * a;
+}
+
+template <typename T, int N, typename MT>
+MP_HD void mp_mass_matrix_crba(const MT& M, const MpJointState<T, N>& js, T (&Mq)[N][N]) {
+  using S = typename MpTraits<T>::S;
+  using TR = MpTraits<T>;
+  const T zero = TR::splat(S(0));
+  MpRbi<T> Ic;  // composite inertia of links i..N-1 in frame i
+  Ic.m = zero; Ic.hx = zero; Ic.hy = zero; Ic.hz = zero;
+  Ic.xx = zero; Ic.xy = zero; Ic.xz = zero; Ic.yy = zero; Ic.yz = zero; Ic.zz = zero;
+#pragma unroll
+  for (int i = N - 1; i >= 0; --i) {
+    const auto& J = M.j[i];
+    Ic.m = Ic.m + J.m; Ic.hx = Ic.hx + J.hx; Ic.hy = Ic.hy + J.hy; Ic.hz = Ic.hz + J.hz;
+    Ic.xx = Ic.xx + J.Ixx; Ic.xy = Ic.xy + J.Ixy; Ic.xz = Ic.xz + J.Ixz; Ic.yy = Ic.yy + J.Iyy; Ic.yz = Ic.yz + J.Iyz;
+    Ic.zz = Ic.zz + J.Izz;
+    // F = Ic S_i: S = [z;0] (revolute) -> n = Io[:, z], f = -h x z ;  S = [0;z] (prismatic) -> n = h x z, f = m z
+    const S r = J.rev, p = S(1) - J.rev;
+    T nx = r * Ic.xz + p * Ic.hy, ny = r * Ic.yz - p * Ic.hx, nz = r * Ic.zz;
+    T fx = -(r * Ic.hy), fy = r * Ic.hx, fz = p * Ic.m;
+    Mq[i][i] = r * nz + p * fz;
+#pragma unroll
+    for (int k = i; k > 0; --k) {  // carry F from frame k to frame k-1, read the component along joint k-1
+      const auto& Jk = M.j[k];
+      mp_force_up_B(js.c[k], js.s[k], js.d[k], nx, ny, nz, fx, fy, fz);
+      mp_force_up_A(Jk.ca, Jk.sa, Jk.a, nx, ny, nz, fx, fy, fz);
+      const auto& Jp = M.j[k - 1];
+      const T v = Jp.rev * nz + (S(1) - Jp.rev) * fz;
+      Mq[k - 1][i] = v;
+      Mq[i][k - 1] = v;
+    }
+    if (i > 0) {  // move the composite into frame i-1
+      mp_rbi_up_B(js.c[i], js.s[i], js.d[i], Ic);
+      mp_rbi_up_A(J.ca, J.sa, J.a, Ic);
+    }
+  }
+}
+
 // Solve M x = b for a symmetric positive definite M held in registers (Cholesky, fully unrolled).
 // The reference calls np.linalg.solve (LU with pivoting, dynamics/id_fd.py:82); for an SPD matrix both
 // give the same x up to rounding.  M is overwritten by its factor, b by the solution.
@@ -382,7 +459,7 @@ MP_HD void mp_forward_dynamics(const MT& M, const typename MpTraits<T>::S (&a0)[
   for (int k = 0; k < N; ++k) zero_acc[k] = MpTraits<T>::splat(S(0));
   mp_rnea<T, N, HAS_FTIP>(M, a0, tipn, tipf, js, qd, zero_acc, bias);
   T Mq[N][N];
-  mp_mass_matrix<T, N>(M, js, Mq);
+  mp_mass_matrix_crba<T, N>(M, js, Mq);
 #pragma unroll
   for (int k = 0; k < N; ++k) qdd[k] = tau[k] - bias[k];
   mp_spd_solve<T, N>(Mq, qdd);

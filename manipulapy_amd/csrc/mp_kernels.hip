@@ -157,7 +157,7 @@ __global__ __launch_bounds__(kBlock) void k_mass_matrix(const MpModel<T> M, cons
   MpJointState<T, N> js;
   mp_joint_state<T, N>(M, a, js);
   T Mq[N][N];
-  mp_mass_matrix<T, N>(M, js, Mq);
+  mp_mass_matrix_crba<T, N>(M, js, Mq);
   T flat[N * N];
 #pragma unroll
   for (int i = 0; i < N; ++i)

@@ -87,14 +87,15 @@ namespace {
 template <typename T, int N>
 void run_fd(const MpModel<T>& M, const MpCall<T>& C, int mode, long rows, const double* q, const double* qd,
             const double* tau, const double* Ftipmat, double dt, int intRes, double* out) {
-  if (mode == 0) {
+  if (mode == 0 || mode == 3) {  // 0: n unit-acceleration recursions, 3: composite-rigid-body algorithm
     for (long r = 0; r < rows; ++r) {
       T a[N];
       for (int j = 0; j < N; ++j) a[j] = (T)q[r * N + j];
       MpJointState<T, N> js;
       mp_joint_state<T, N>(M, a, js);
       T Mq[N][N];
-      mp_mass_matrix<T, N>(M, js, Mq);
+      if (mode == 0) mp_mass_matrix<T, N>(M, js, Mq);
+      else mp_mass_matrix_crba<T, N>(M, js, Mq);
       for (int i = 0; i < N; ++i)
         for (int j = 0; j < N; ++j) out[(r * N + i) * N + j] = (double)Mq[i][j];
     }

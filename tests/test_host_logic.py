@@ -180,8 +180,9 @@ def test_device_math_matches_golden_on_host(robot, hostsim, tables, dyn_golden):
 def test_device_mass_matrix_and_forward_dynamics_on_host(robot, hostsim, tables, dyn_golden):
     tab, z = tables[robot], dyn_golden[robot]
     K, n = len(z["thetas"]), tab.n
-    M = hostsim.fd(tab, 0, K, z["thetas"], None, None, z["g"], np.zeros(6), outshape=(K, n, n))
-    np.testing.assert_allclose(M, z["mass_matrix"], rtol=1e-9, atol=1e-11)
+    for mode in (0, 3):  # n unit-acceleration recursions / composite-rigid-body algorithm (the one the kernels use)
+        M = hostsim.fd(tab, mode, K, z["thetas"], None, None, z["g"], np.zeros(6), outshape=(K, n, n))
+        np.testing.assert_allclose(M, z["mass_matrix"], rtol=1e-9, atol=1e-11)
     for i in range(0, K, 3):
         qdd = hostsim.fd(tab, 1, 1, z["thetas"][i:i + 1], z["dthetas"][i:i + 1], z["inverse_dynamics"][i:i + 1], z["g"], z["ftips"][i],
                          outshape=(1, n))

@@ -88,9 +88,10 @@ def test_random_chain_matches_oracle(seed, hostsim):  # noqa: F811
         want = ref.inverse_dynamics(tab, q[r], qd[r], qdd[r], g, F)
         np.testing.assert_allclose(tau[r], want, rtol=1e-6, atol=1e-6 * max(1.0, np.abs(want).max()))
     # mass matrix / forward dynamics through the same frames
-    M = hostsim.fd(tab, 0, rows, q, None, None, g, np.zeros(6), outshape=(rows, n, n))
-    for r in range(rows):
-        np.testing.assert_allclose(M[r], ref.mass_matrix(tab, q[r]), rtol=1e-8, atol=1e-9)
+    for mode in (0, 3):  # unit-acceleration recursions and the composite-rigid-body algorithm
+        M = hostsim.fd(tab, mode, rows, q, None, None, g, np.zeros(6), outshape=(rows, n, n))
+        for r in range(rows):
+            np.testing.assert_allclose(M[r], ref.mass_matrix(tab, q[r]), rtol=1e-8, atol=1e-9)
     # float32, packed: loose tolerance (random robots are not well conditioned like real arms)
     t32, _, _ = hostsim(tab, q, qd, qdd, g, F, 2)
     for r in range(rows):
