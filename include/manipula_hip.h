@@ -173,6 +173,11 @@ int mp_fd_trajectory_f64(mp_ctx* ctx, const mp_model* model, const double* d_the
 int mp_cartesian_trajectory_f32(mp_ctx* ctx, const double* d_Xstart, const double* d_Xend, int64_t B, int64_t N, double Tf,
                                 int method, float* d_pos, float* d_vel, float* d_acc, float* d_orient);
 
+/* Fused potential field ("potential_field.fused", cuda_kernels/field_kernels.py:20-104, registry.py:870-897):
+ * potential (P,) and gradient (P,3) at positions (P,3) for one goal (3, host) and obstacles (O,3), float32. */
+int mp_potential_field_f32(mp_ctx* ctx, const float* d_positions, const float* goal, const float* d_obstacles, int64_t P,
+                           int64_t O, float influence_distance, float* d_potential, float* d_gradient);
+
 /* ---- hot path, host pointers (what a Python gpu_launcher calls): H2D, launch, D2H, synchronise - */
 int mp_batch_trajectory_host_f32(mp_ctx* ctx, const mp_model* model, const float* start, const float* end,
                                  int64_t B, int64_t N, double Tf, int method, float* pos, float* vel, float* acc);
@@ -199,6 +204,9 @@ int mp_fd_trajectory_host_f64(mp_ctx* ctx, const mp_model* model, const double* 
 
 int mp_cartesian_trajectory_host_f32(mp_ctx* ctx, const double* Xstart, const double* Xend, int64_t B, int64_t N, double Tf,
                                      int method, float* pos, float* vel, float* acc, float* orient);
+
+int mp_potential_field_host_f32(mp_ctx* ctx, const float* positions, const float* goal, const float* obstacles, int64_t P,
+                                int64_t O, float influence_distance, float* potential, float* gradient);
 
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI (new; the reference is single-device) ------
  * Trajectory batches are sharded over ranks with no exchange during compute; the only collective is

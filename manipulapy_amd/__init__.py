@@ -12,6 +12,7 @@ from .registry import (BackendNotSupportedError, KernelRegistration, KernelRegis
 from .kinematics import SerialManipulator
 from .dynamics import ManipulatorDynamics
 from .planning import OptimizedTrajectoryPlanning, TrajectoryPlanning
+from .control import ManipulatorController
 from .robots import load_robot, robot_tables, robot_urdf
 from .urdf import URDFToSerialManipulator
 
@@ -19,5 +20,5 @@ __version__ = "0.1.0"
 __all__ = ["ArrayBackend", "HipBackend", "NumpyBackend", "get_backend", "get_registered", "register", "set_backend",
            "use_backend", "BackendNotSupportedError", "KernelRegistration", "KernelRegistry", "check_hip_availability",
            "execute_registered_kernel", "get_context", "get_gpu_properties", "get_registered_kernel",
-           "SerialManipulator", "ManipulatorDynamics", "OptimizedTrajectoryPlanning", "TrajectoryPlanning",
+           "SerialManipulator", "ManipulatorDynamics", "OptimizedTrajectoryPlanning", "TrajectoryPlanning", "ManipulatorController",
            "load_robot", "robot_tables", "robot_urdf", "URDFToSerialManipulator"]

@@ -87,6 +87,8 @@ SIGNATURES = {
     "mp_fd_trajectory_host_f64": (ctypes.c_int, [_vp, _vp, _c_dp, _c_dp, _c_dp, _c_dp, _i64, _i64, _c_dp, ctypes.c_double, ctypes.c_int, _c_fp, _c_fp, _c_fp]),
     "mp_cartesian_trajectory_f32": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, ctypes.c_double, ctypes.c_int, _vp, _vp, _vp, _vp]),
     "mp_cartesian_trajectory_host_f32": (ctypes.c_int, [_vp, _c_dp, _c_dp, _i64, _i64, ctypes.c_double, ctypes.c_int, _c_fp, _c_fp, _c_fp, _c_fp]),
+    "mp_potential_field_f32": (ctypes.c_int, [_vp, _vp, _c_fp, _vp, _i64, _i64, ctypes.c_float, _vp, _vp]),
+    "mp_potential_field_host_f32": (ctypes.c_int, [_vp, _c_fp, _c_fp, _c_fp, _i64, _i64, ctypes.c_float, _c_fp, _c_fp]),
     "mp_batch_trajectory_host_f32": (ctypes.c_int, [_vp, _vp, _c_fp, _c_fp, _i64, _i64, ctypes.c_double, ctypes.c_int, _c_fp, _c_fp, _c_fp]),
     "mp_id_trajectory_host_f32": (ctypes.c_int, [_vp, _vp, _c_fp, _c_fp, _c_fp, _i64, _c_dp, _c_dp, _c_fp]),
     "mp_id_trajectory_host_f64": (ctypes.c_int, [_vp, _vp, _c_dp, _c_dp, _c_dp, _i64, _c_dp, _c_dp, _c_dp]),
@@ -450,6 +452,17 @@ class HipContext:
         _check(self.lib.mp_cartesian_trajectory_host_f32(self.handle, _dptr(Xs), _dptr(Xe), B, N, float(Tf), int(method),
                                                          _fptr(pos), _fptr(vel), _fptr(acc), _fptr(ori)))
         return pos, vel, acc, ori
+
+    def potential_field_host(self, positions, goal, obstacles, influence_distance):
+        """(potential (P,), gradient (P,3)) float32 for positions (P,3), goal (3,), obstacles (O,3)."""
+        pos = np.ascontiguousarray(positions, dtype=np.float32).reshape(-1, 3)
+        goal = np.ascontiguousarray(goal, dtype=np.float32).reshape(3)
+        obs = np.ascontiguousarray(obstacles, dtype=np.float32).reshape(-1, 3)
+        P, O = pos.shape[0], obs.shape[0]
+        pot, grad = np.zeros(P, dtype=np.float32), np.zeros((P, 3), dtype=np.float32)
+        _check(self.lib.mp_potential_field_host_f32(self.handle, _fptr(pos), _fptr(goal), _fptr(obs) if O else None, P, O,
+                                                    float(influence_distance), _fptr(pot), _fptr(grad)))
+        return pot, grad
 
     def mass_matrix_host(self, model: HipModel, q) -> np.ndarray:
         q = _as_c(q, np.float64, name="q")

@@ -898,6 +898,39 @@ int mp_cartesian_trajectory_host_f32(mp_ctx* ctx, const double* Xstart, const do
   return MP_OK;
 }
 
+int mp_potential_field_f32(mp_ctx* ctx, const float* d_positions, const float* goal, const float* d_obstacles, int64_t P,
+                           int64_t O, float influence_distance, float* d_potential, float* d_gradient) {
+  REQUIRE(ctx, "mp_potential_field_f32: null context");
+  if (int rc = bind(ctx)) return rc;
+  REQUIRE(P >= 0 && O >= 0, "mp_potential_field_f32: negative P or O");
+  if (P == 0) return MP_OK;
+  REQUIRE(d_positions && goal && d_potential && d_gradient && (O == 0 || d_obstacles), "mp_potential_field_f32: null pointer");
+  HIP_TRY(mpk_potential_field(ctx->compute, d_positions, goal, d_obstacles, (long)P, (long)O, influence_distance, d_potential, d_gradient));
+  return MP_OK;
+}
+int mp_potential_field_host_f32(mp_ctx* ctx, const float* positions, const float* goal, const float* obstacles, int64_t P,
+                                int64_t O, float influence_distance, float* potential, float* gradient) {
+  REQUIRE(ctx, "mp_potential_field_host_f32: null context");
+  if (int rc = bind(ctx)) return rc;
+  REQUIRE(P >= 0 && O >= 0, "mp_potential_field_host_f32: negative P or O");
+  if (P == 0) return MP_OK;
+  REQUIRE(positions && goal && potential && gradient && (O == 0 || obstacles), "mp_potential_field_host_f32: null pointer");
+  const size_t pb = (size_t)P * 3 * sizeof(float), ob = (size_t)O * 3 * sizeof(float);
+  Scratch sc(ctx);
+  void *dp, *dob = nullptr, *du, *dg;
+  if (int rc = sc.get(pb, &dp)) return rc;
+  if (O) if (int rc = sc.get(ob, &dob)) return rc;
+  if (int rc = sc.get((size_t)P * sizeof(float), &du)) return rc;
+  if (int rc = sc.get(pb, &dg)) return rc;
+  H2D(dp, positions, pb);
+  if (O) H2D(dob, obstacles, ob);
+  if (int rc = mp_potential_field_f32(ctx, (float*)dp, goal, (float*)dob, P, O, influence_distance, (float*)du, (float*)dg)) return rc;
+  D2H(potential, du, (size_t)P * sizeof(float));
+  D2H(gradient, dg, pb);
+  HIP_TRY(hipStreamSynchronize(ctx->compute));
+  return MP_OK;
+}
+
 }  // extern "C"
 
 

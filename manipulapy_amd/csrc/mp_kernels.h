@@ -38,3 +38,7 @@ hipError_t mpk_fd_traj(hipStream_t s, const MpModel<T>& M, const MpCall<T>& C, c
 // Cartesian straight-line trajectories between B pose pairs (4x4 row-major float64): float32 (B,Nt,3) x3, (B,Nt,3,3)
 hipError_t mpk_cartesian_traj(hipStream_t s, const double* Xstart, const double* Xend, long B, long Nt, double Tf, int method,
                               float* pos, float* vel, float* acc, float* ori);
+
+// Fused attractive + repulsive potential and gradient at P points against O obstacles (float32); goal on the host.
+hipError_t mpk_potential_field(hipStream_t s, const float* pos, const float* goal3_host, const float* obs, long P, long O,
+                               float influence, float* pot, float* grad);

@@ -212,6 +212,34 @@ __global__ __launch_bounds__(kBlock) void k_cartesian_traj(const double* __restr
   for (int k = 0; k < 9; ++k) ori[r * 9 + k] = o[k];
 }
 
+// ------------------------------------------------------------------- fused potential field
+// Per point: U = 1/2 |p - goal|^2 + sum_obs 1/2 (1/d - 1/d0)^2 over obstacles with 0 < d < d0, and its gradient
+// (reference cuda_kernels/field_kernels.py:20-104 / :113-161, float32).  One lane per point; the obstacle index is
+// wave-uniform, so obstacle coordinates arrive through scalar loads.
+__global__ __launch_bounds__(kBlock) void k_potential_field(const float* __restrict__ pos, float gx, float gy, float gz,
+                                                            const float* __restrict__ obs, long P, long O, float inv_d0,
+                                                            float d0sq, float* __restrict__ pot, float* __restrict__ grad) {
+  const long i = (long)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= P) return;
+  const float px = pos[3 * i], py = pos[3 * i + 1], pz = pos[3 * i + 2];
+  float dx = px - gx, dy = py - gy, dz = pz - gz;
+  float U = 0.5f * (dx * dx + dy * dy + dz * dz);
+  float Gx = dx, Gy = dy, Gz = dz;
+  for (long o = 0; o < O; ++o) {
+    const float ox = px - obs[3 * o], oy = py - obs[3 * o + 1], oz = pz - obs[3 * o + 2];
+    const float d2 = ox * ox + oy * oy + oz * oz;
+    if (d2 > 0.0f && d2 < d0sq) {
+      const float inv = 1.0f / sqrtf(d2);
+      const float t = inv - inv_d0;
+      U += 0.5f * t * t;
+      const float f = -t * inv * inv * inv;
+      Gx += f * ox; Gy += f * oy; Gz += f * oz;
+    }
+  }
+  pot[i] = U;
+  grad[3 * i] = Gx; grad[3 * i + 1] = Gy; grad[3 * i + 2] = Gz;
+}
+
 inline unsigned grid_for(long rows) { return (unsigned)((rows + kBlock - 1) / kBlock); }
 
 // float32 variant selection (A/B switch for profiling): MANIPULAPY_HIP_F32 = "packed" (default) | "scalar"
@@ -380,5 +408,14 @@ hipError_t mpk_cartesian_traj(hipStream_t s, const double* Xstart, const double*
                               float* pos, float* vel, float* acc, float* ori) {
   if (B <= 0 || Nt <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_cartesian_traj, dim3(grid_for(B * Nt)), dim3(kBlock), 0, s, Xstart, Xend, B, Nt, Tf, method, pos, vel, acc, ori);
+  return hipGetLastError();
+}
+
+hipError_t mpk_potential_field(hipStream_t s, const float* pos, const float* goal3_host, const float* obs, long P, long O,
+                               float influence, float* pot, float* grad) {
+  if (P <= 0) return hipSuccess;
+  const float inv = influence > 0.0f ? (float)(1.0 / (double)influence) : 0.0f;
+  hipLaunchKernelGGL(k_potential_field, dim3(grid_for(P)), dim3(kBlock), 0, s, pos, goal3_host[0], goal3_host[1], goal3_host[2], obs,
+                     P, O, inv, influence * influence, pot, grad);
   return hipGetLastError();
 }

@@ -29,7 +29,7 @@ from .backend import get_backend
 
 __all__ = ["KernelRegistration", "KernelRegistry", "execute_registered_kernel", "get_registered_kernel",
            "check_hip_availability", "get_context", "get_gpu_properties", "BackendNotSupportedError",
-           "trajectory_cpu", "HIP_DEVICE_ENV"]
+           "trajectory_cpu", "potential_field_cpu", "HIP_DEVICE_ENV"]
 
 HIP_DEVICE_ENV = "MANIPULAPY_HIP_DEVICE"
 
@@ -181,6 +181,31 @@ def trajectory_cpu(thetastart, thetaend, Tf: float, N: int, method: int) -> Tupl
     return pos, vel, acc
 
 
+def potential_field_cpu(positions, goal, obstacles, influence_distance: float):
+    """Fused attractive + repulsive potential field on the host (NumPy launcher of "potential_field.fused").
+
+    U = 1/2 |p - goal|^2 + sum over obstacles with 0 < d < d0 of 1/2 (1/d - 1/d0)^2, and its gradient; float32
+    arithmetic, zero-distance obstacles ignored (reference cuda_kernels/field_kernels.py:113-161)."""
+    p = np.ascontiguousarray(positions, dtype=np.float32).reshape(-1, 3)
+    g = np.ascontiguousarray(goal, dtype=np.float32).reshape(3)
+    o = np.ascontiguousarray(obstacles, dtype=np.float32).reshape(-1, 3)
+    diff = p - g
+    pot = np.float32(0.5) * np.einsum("ij,ij->i", diff, diff)
+    grad = diff.copy()
+    if o.shape[0]:
+        inv_d0 = np.float32(1.0 / influence_distance) if influence_distance > 0.0 else np.float32(0.0)
+        d0sq = np.float32(influence_distance * influence_distance)
+        rel = p[:, None, :] - o[None, :, :]                      # (P, O, 3)
+        d2 = np.einsum("poj,poj->po", rel, rel)
+        hit = (d2 > 0.0) & (d2 < d0sq)
+        inv = np.zeros_like(d2)
+        inv[hit] = np.float32(1.0) / np.sqrt(d2[hit])
+        t = np.where(hit, inv - inv_d0, np.float32(0.0)).astype(np.float32)
+        pot = pot + np.float32(0.5) * np.sum(t * t, axis=1, dtype=np.float32)
+        grad = grad + np.einsum("po,poj->pj", -t * inv * inv * inv, rel).astype(np.float32)
+    return pot.astype(np.float32), grad.astype(np.float32)
+
+
 # ------------------------------------------------------------------------------ launchers
 def _no_cpu(name: str) -> Callable[..., Any]:
     def launcher(*_a: Any, **_k: Any) -> Any:
@@ -245,6 +270,16 @@ def _launch_cartesian_gpu(Xstart, Xend, Tf, N, method):
     return get_context().cartesian_trajectory_host(Xstart, Xend, Tf, N, method)
 
 
+def _launch_potential_field_gpu(positions, goal, obstacles, influence_distance, use_pinned=True):
+    del use_pinned
+    return get_context().potential_field_host(positions, goal, obstacles, influence_distance)
+
+
+def _launch_potential_field_cpu(positions, goal, obstacles, influence_distance, use_pinned=True):
+    del use_pinned
+    return potential_field_cpu(positions, goal, obstacles, influence_distance)
+
+
 def _grid_1d(rows: int, block: int = 256):
     """Launch shape every kernel uses: one thread per (trajectory, timestep) row, 256-thread blocks
     (4 wavefronts of 64).  Replaces the CUDA block heuristics of reference registry.py:409-515."""
@@ -278,6 +313,10 @@ def _build_kernel_registry() -> KernelRegistry:
         cpu_fallback=trajectory_cpu, gpu_launcher=_launch_batch_trajectory_gpu,
         cpu_launcher=_launch_batch_trajectory_cpu,
         metadata={"family": "trajectory", "variant": "batch", "dimensions": 1}))
+    reg.register(KernelRegistration(
+        name="potential_field.fused", implementation="mp_potential_field_host_f32", launch_config=_grid_1d,
+        cpu_fallback=potential_field_cpu, gpu_launcher=_launch_potential_field_gpu, cpu_launcher=_launch_potential_field_cpu,
+        metadata={"family": "potential_field", "variant": "fused", "dimensions": 1}))
     for name, impl, gpu in (
         ("dynamics.inverse_trajectory", "mp_id_trajectory_host_f32 / _f64", _launch_id_gpu),
         ("dynamics.fused_trajectory_inverse", "mp_traj_id_fused_host_f32", _launch_fused_gpu),

@@ -310,6 +310,22 @@ def test_kernel_registry_semantics():
     assert entry.metadata["family"] == "trajectory" and entry.launch_config(1000) == ((4,), (256,))
 
 
+def test_potential_field_cpu_launcher_hand_checked():
+    """The reference's hand-checked fused-field values (tests/test_cuda_kernels_cpu.py:104-118) through the registry."""
+    positions = np.array([[0.0, 0.0, 0.0], [2.0, 0.0, 0.0]], dtype=np.float32)
+    goal = np.array([1.0, 0.0, 0.0], dtype=np.float32)
+    obstacles = np.array([[0.5, 0.0, 0.0]], dtype=np.float32)
+    pot, grad = mp.execute_registered_kernel("potential_field.fused", positions, goal, obstacles, 1.0)
+    assert pot.dtype == np.float32 and grad.shape == (2, 3)
+    np.testing.assert_allclose(pot, [1.0, 0.5])
+    np.testing.assert_allclose(grad, [[3.0, 0.0, 0.0], [1.0, 0.0, 0.0]])
+    # an obstacle exactly on a point is ignored; no obstacles -> attractive part only
+    pot, grad = registry.potential_field_cpu(positions, goal, positions[:1], 1.0)
+    np.testing.assert_allclose(pot[0], 0.5)
+    pot, grad = registry.potential_field_cpu(positions, goal, np.zeros((0, 3)), 1.0)
+    np.testing.assert_allclose(grad, positions - goal)
+
+
 def test_routing_predicate_and_execute(monkeypatch):
     """GPU launcher iff physical probe AND backend.gpu_capable, read live
     (reference registry.py:85-89, :729-732; tests/test_backend_dispatch.py:2545-2663)."""
