@@ -33,6 +33,9 @@ CONFIGS = {
     # name: (robot, B per GPU, N, dtype, what the step runs)
     "c2": dict(robot="ur5", B=4096, N=1000, dtype="f32", op="id",
                desc="UR5 6-DOF, B=4096 x N=1000, inverse_dynamics_trajectory fp32 (BASELINE configs[1])"),
+    "c2f": dict(robot="ur5", B=4096, N=1000, dtype="f32", op="fused",
+                desc="UR5 6-DOF, B=4096 x N=1000, joint_trajectory fused into inverse_dynamics_trajectory fp32: inputs are the "
+                     "(B,n) start/end pairs, only tau is written (4 B per joint-timestep) - reported separately from c2, never mixed"),
     "c3": dict(robot="iiwa14", B=65536, N=500, dtype="f64", op="fk_jac_id",
                desc="KUKA iiwa14 7-DOF, B=65536 x N=500, FK + Jacobian + ID fused fp64 (BASELINE configs[2])"),
     "c4": dict(robot="panda", B=32768, N=200, dtype="f32", op="id",
@@ -51,7 +54,18 @@ def algorithmic_bytes_per_row(cfg, n):
     w = 4 if cfg["dtype"] == "f32" else 8
     if cfg["op"] == "fd_traj":  # per timestep: in tau (n) + Ftip (6), out pos/vel/acc (3n float32)
         return (n + 6) * w + 3 * n * 4
+    if cfg["op"] == "fused":  # write tau only (the 2*n*4 B per TRAJECTORY of start/end are negligible)
+        return n * w
     return (4 * n) * w if cfg["op"] == "id" else (3 * n + n + 16 + 6 * n) * w
+
+
+def kernel_name(cfg):
+    spec = cfg.get("specialized")
+    return {"id": ("mp_spec_id_pk_f0" if cfg["dtype"] == "f32" else "mp_spec_id_d_f0") if spec else
+                  ("k_id_pk" if cfg["dtype"] == "f32" else "k_id"),
+            "fused": "mp_spec_traj_id_pk_f0" if spec else "k_traj_id_pk",
+            "fk_jac_id": "mp_spec_fk_jac_id_d_f0" if spec else "k_fk_jac_id",
+            "fd_traj": "mp_spec_fd_traj_f1" if spec else "k_fd_traj"}[cfg["op"]]
 
 
 def cpu_baseline(robot, q, qd, qdd, budget_s=12.0):
@@ -126,7 +140,7 @@ def bench_fd(args, cfg, info, hg, ctx, model, t, props):
                    "kernel_variant": "robot-specialised (hiprtc)" if cfg["specialized"] else "generic",
                    "sharding": f"batch axis over {world} rank(s), no collective in the timed step"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                     "traffic": None, "kernel": "k_fd_traj", "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                     "traffic": None, "kernel": kernel_name(cfg), "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes,
                      "note": "sequential in time: VALU-bound (mass matrix + solve per step), HBM line shown for reference"},
         "device": props["name"],
     }
@@ -197,7 +211,7 @@ def main():
         return bench_fd(args, cfg, info, hg, ctx, model, t, props)
 
     # ---- synthetic input, generated ON the device: start / end ~ U(joint limits), quintic, Tf = 2
-    cid = {"c2": 2, "c3": 3, "c4": 4}[args.config]
+    cid = {"c2": 2, "c2f": 2, "c3": 3, "c4": 4}[args.config]
     rng = np.random.default_rng(SEED + cid + 1000 * info.rank)
     lo, hi = t["joint_limits"][:, 0], t["joint_limits"][:, 1]
     start = rng.uniform(lo, hi, (B, n)).astype(np.float32)
@@ -226,6 +240,8 @@ def main():
     def step():
         if cfg["op"] == "id":
             ctx.id_trajectory(model, d_q, d_qd, d_qdd, rows, d_tau, dtype=dt_np)
+        elif cfg["op"] == "fused":
+            ctx.traj_id_fused(model, d_start, d_end, B, N, 2.0, 5, d_tau)
         else:
             ctx.fk_jac_id(model, d_q, d_qd, d_qdd, rows, d_T, d_J, d_tau, dtype=dt_np)
 
@@ -310,7 +326,7 @@ def main():
                    "sharding": f"batch axis over {world} rank(s), no collective in the timed step"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                     "kernel": "k_id" if cfg["op"] == "id" else "k_fk_jac_id", "kernel_ms": kern_ms,
+                     "kernel": kernel_name(cfg), "kernel_ms": kern_ms,
                      "kernel_ms_max_over_ranks": kern_ms_all, "algorithmic_bytes_per_launch": alg_bytes},
         "device": props["name"],
     }
