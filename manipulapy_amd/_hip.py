@@ -115,6 +115,16 @@ def load_library():
         if _lib is not None:
             return _lib
         path = lib_path()
+        if not os.path.exists(path) and path == DEFAULT_LIB:
+            # a fresh checkout: compile the native library in-tree (hipcc cross-compiles without a GPU)
+            try:
+                from .build import build as _build
+
+                _build(verbose=False)
+            except Exception as exc:
+                raise HipUnavailableError(
+                    f"{path} not found and building it failed ({exc}); run `python -m manipulapy_amd.build` "
+                    "(needs hipcc) - there is no CPU fallback for the HIP backend") from exc
         if not os.path.exists(path):
             raise HipUnavailableError(
                 f"{path} not found: build it with `python -m manipulapy_amd.build` (needs hipcc); "

@@ -20,6 +20,7 @@ What it does:
       trajectory_ur5.npz   : joint_trajectory / batch_joint_trajectory /
                              inverse_dynamics_trajectory / forward_dynamics_trajectory dumps
       cartesian_ur5.npz    : cartesian_trajectory dumps (`make_golden.py cartesian` regenerates only this)
+      urdf/<robot>.urdf    : kinematic + inertial skeletons of the four URDFs (`make_golden.py urdf`)
       reference_cpu_timings.json : cold-cache per-point timings of the reference
 
 Nothing from /root/reference is copied: the fixtures hold numbers only.
@@ -281,6 +282,37 @@ def dump_cartesian():
     np.savez(os.path.join(HERE, "cartesian_ur5.npz"), **d)
 
 
+def dump_urdfs():
+    """tests/golden/urdf/<robot>.urdf: the kinematic + inertial skeleton of the four benchmark robots' URDFs (robot
+    description DATA; number strings kept verbatim so the tables stay bit-identical).  Visual / collision geometry,
+    materials, mesh references, transmissions and gazebo blocks are dropped: manipulapy_amd.urdf never reads them."""
+    import xml.etree.ElementTree as ET
+
+    os.makedirs(os.path.join(HERE, "urdf"), exist_ok=True)
+    for robot in ROBOTS:
+        src = ET.parse(get_robot_urdf(robot)).getroot()
+        out = ET.Element("robot", {"name": src.get("name", robot)})
+        out.append(ET.Comment(f" kinematic + inertial skeleton of the {robot} description used by BASELINE configs; "
+                              "generated by tests/golden/make_golden.py urdf "))
+        for link in src.findall("link"):
+            le = ET.SubElement(out, "link", {"name": link.get("name")})
+            ine = link.find("inertial")
+            if ine is not None:
+                ie = ET.SubElement(le, "inertial")
+                for tag in ("origin", "mass", "inertia"):
+                    e = ine.find(tag)
+                    if e is not None:
+                        ET.SubElement(ie, tag, dict(e.attrib))
+        for joint in src.findall("joint"):
+            je = ET.SubElement(out, "joint", {"name": joint.get("name"), "type": joint.get("type", "fixed")})
+            for tag in ("origin", "parent", "child", "axis", "limit", "mimic"):
+                e = joint.find(tag)
+                if e is not None:
+                    ET.SubElement(je, tag, dict(e.attrib))
+        ET.indent(out, space="  ")
+        ET.ElementTree(out).write(os.path.join(HERE, "urdf", f"{robot}.urdf"), encoding="utf-8", xml_declaration=True)
+
+
 def time_reference():
     """Cold-cache single-thread timings of the reference's inverse_dynamics."""
     res = {"host": "build container", "cores_visible": os.cpu_count(), "threads_used": 1,
@@ -307,6 +339,10 @@ def time_reference():
 
 def main():
     assert os.environ.get("PYTHONHASHSEED") == "0"
+    if "urdf" in sys.argv[1:]:  # only (re)generate the URDF skeletons
+        dump_urdfs()
+        print("urdf skeletons dumped")
+        return
     if "cartesian" in sys.argv[1:]:  # only (re)generate the Cartesian-trajectory dump
         dump_cartesian()
         print("cartesian dumped")
@@ -318,6 +354,7 @@ def main():
         print(f"{robot}: n={n} dumped", flush=True)
     dump_trajectories()
     dump_cartesian()
+    dump_urdfs()
     print("trajectories dumped", flush=True)
     time_reference()
     print("timings dumped")
