@@ -117,9 +117,9 @@ const MpSpec* find_spec(mp_ctx* ctx, const mp_model* model) {
   auto it = ctx->specs.find(model->uid);
   return it == ctx->specs.end() ? nullptr : &it->second;
 }
-int launch_spec(mp_ctx* ctx, hipFunction_t fn, long threads, void** args) {
-  const unsigned grid = (unsigned)((threads + 255) / 256);
-  HIP_TRY(hipModuleLaunchKernel(fn, grid, 1, 1, 256, 1, 1, 0, ctx->compute, args, nullptr));
+int launch_spec(mp_ctx* ctx, hipFunction_t fn, long threads, void** args, unsigned block = 256) {
+  const unsigned grid = (unsigned)((threads + block - 1) / block);
+  HIP_TRY(hipModuleLaunchKernel(fn, grid, 1, 1, block, 1, 1, 0, ctx->compute, args, nullptr));
   return MP_OK;
 }
 
@@ -207,7 +207,7 @@ int launch_fkjid_spec(mp_ctx* ctx, const mp_model* model, const MpCall<double>& 
   if (!sp) return -1;
   MpCall<double> cc = c;
   void* args[] = {&cc, &q, &qd, &qdd, &T, &J, &tau, &rows};
-  return launch_spec(ctx, sp->fk_jac_id_d[ftip ? 1 : 0], rows, args);
+  return launch_spec(ctx, sp->fk_jac_id_d[ftip ? 1 : 0], rows, args, 64);  // one wave per block (per-wave LDS slice)
 }
 int launch_fkjid_spec(mp_ctx*, const mp_model*, const MpCall<float>&, bool, const float*, const float*, const float*, float*, float*,
                       float*, long) {

@@ -136,13 +136,17 @@ __global__ __launch_bounds__(kBlock, MP_PK_MINW) void k_traj_id_pk(const MpModel
 }
 
 // ------------------------------------------------------------- FK + space Jacobian + ID fused
+// one wave per block: the per-wave LDS staging slice (9 KiB) then never limits residency (a 256-thread block needs
+// 36 KiB, i.e. at most 4 blocks = 16 waves per CU, and blocks drain unevenly: 1.7 waves per SIMD measured)
+constexpr int kFkBlock = 64;
+
 template <typename T, int N, bool HAS_FTIP>
-__global__ __launch_bounds__(kBlock) void k_fk_jac_id(const MpModel<T> M, const MpCall<T> C, const T* __restrict__ q,
+__global__ __launch_bounds__(kFkBlock) void k_fk_jac_id(const MpModel<T> M, const MpCall<T> C, const T* __restrict__ q,
                                                       const T* __restrict__ qd, const T* __restrict__ qdd,
                                                       T* __restrict__ Tout, T* __restrict__ Jout,
                                                       T* __restrict__ tau, long rows) {
-  __shared__ __attribute__((aligned(16))) char lds[(kBlock / 64) * MP_WAVE_LDS_BYTES];  // one staging slice per wave
-  const long r = (long)blockIdx.x * kBlock + threadIdx.x;
+  __shared__ __attribute__((aligned(16))) char lds[(kFkBlock / 64) * MP_WAVE_LDS_BYTES];  // one staging slice per wave
+  const long r = (long)blockIdx.x * kFkBlock + threadIdx.x;
   mp_body_fk_jac_id<T, N, HAS_FTIP>(M, C, q, qd, qdd, Tout, Jout, tau, r, rows, lds + (threadIdx.x >> 6) * MP_WAVE_LDS_BYTES);
 }
 
@@ -354,8 +358,9 @@ hipError_t mpk_fk_jac_id(hipStream_t s, const MpModel<T>& M, const MpCall<T>& C,
                          const T* qdd, T* Tout, T* Jout, T* tau, long rows) {
   if (rows <= 0) return hipSuccess;
   MP_DISPATCH_N(M.n, {
-    if (ftip) hipLaunchKernelGGL((k_fk_jac_id<T, N, true>), dim3(grid_for(rows)), dim3(kBlock), 0, s, M, C, q, qd, qdd, Tout, Jout, tau, rows);
-    else hipLaunchKernelGGL((k_fk_jac_id<T, N, false>), dim3(grid_for(rows)), dim3(kBlock), 0, s, M, C, q, qd, qdd, Tout, Jout, tau, rows);
+    const unsigned gb = (unsigned)((rows + kFkBlock - 1) / kFkBlock);
+    if (ftip) hipLaunchKernelGGL((k_fk_jac_id<T, N, true>), dim3(gb), dim3(kFkBlock), 0, s, M, C, q, qd, qdd, Tout, Jout, tau, rows);
+    else hipLaunchKernelGGL((k_fk_jac_id<T, N, false>), dim3(gb), dim3(kFkBlock), 0, s, M, C, q, qd, qdd, Tout, Jout, tau, rows);
   })
   return hipGetLastError();
 }
