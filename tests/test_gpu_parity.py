@@ -597,3 +597,34 @@ def test_potential_field_kernel(ctx):
     np.testing.assert_allclose(g_gpu, g_cpu, rtol=2e-4, atol=2e-3 * float(np.abs(g_cpu).max()) * 1e-2)
     u0, g0 = ctx.potential_field_host(pos, goal, np.zeros((0, 3)), 0.6)
     np.testing.assert_allclose(g0, pos - goal, rtol=1e-6)
+
+
+def test_planner_fused_pipeline_with_limits_and_wrench(tables):
+    """batch_inverse_dynamics_trajectory (generation fused into inverse dynamics, specialised kernels through the
+    planner) == joint limits clip -> oracle inverse dynamics -> torque clip, with a tip wrench and an odd row count."""
+    import manipulapy_amd as mp
+
+    tab = tables["iiwa14"]
+    sm, dyn, lim = mp.load_robot("iiwa14")
+    tl = np.array([[-60.0, 55.0]] * 7)
+    rng = np.random.default_rng(21)
+    B, N = 3, 11  # 33 rows: odd
+    s = rng.uniform(lim[:, 0] - 0.3, lim[:, 1] + 0.3, (B, 7)).astype(np.float32)  # partly outside the limits -> clip
+    e = rng.uniform(lim[:, 0] - 0.3, lim[:, 1] + 0.3, (B, 7)).astype(np.float32)
+    F = np.array([1.0, -2.0, 0.5, 3.0, -1.5, 0.75])
+    g = np.array([0.0, 0.0, -9.81])
+    with mp.use_backend("hip"):
+        pl = mp.OptimizedTrajectoryPlanning(sm, None, dyn, lim, torque_limits=tl)
+        tau = pl.batch_inverse_dynamics_trajectory(s, e, 2.0, N, 5, g, F)
+        traj = pl.batch_joint_trajectory(s, e, 2.0, N, 5)
+        two = pl.inverse_dynamics_trajectory(traj["positions"].reshape(-1, 7), traj["velocities"].reshape(-1, 7),
+                                             traj["accelerations"].reshape(-1, 7), g, F)
+    assert tau.shape == (B, N, 7) and tau.dtype == np.float32
+    o = ref.batch_joint_trajectory(lim, s, e, 2.0, N, 5)
+    assert (o["positions"] <= lim[:, 1].astype(np.float32)).all() and (o["positions"] >= lim[:, 0].astype(np.float32)).all()
+    np.testing.assert_allclose(traj["positions"], o["positions"], rtol=2.5e-7, atol=1e-6)
+    want = ref.inverse_dynamics_trajectory(tab, o["positions"].reshape(-1, 7).astype(np.float64), o["velocities"].reshape(-1, 7).astype(np.float64),
+                                           o["accelerations"].reshape(-1, 7).astype(np.float64), g, F, torque_limits=tl, dtype=np.float64)
+    assert_f32(tau.reshape(-1, 7), want)
+    assert_f32(two, want)
+    assert tau.max() <= 55.0 and tau.min() >= -60.0
