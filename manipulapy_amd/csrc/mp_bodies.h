@@ -298,61 +298,158 @@ __device__ __forceinline__ void mp_body_traj_id_pk(const MT& M, const MpCall<flo
 // trajectory — semi-implicit Euler, `intRes` sub-steps of dt/intRes per outer step, joint-limit clip after
 // every sub-step, rows stored float32, the recorded acceleration is the last sub-step's, row 0 = initial
 // state with zero acceleration.  Time is sequential; trajectories are independent.  Body of k_fd_traj.
+//
+// I/O tiling.  A lane's rows are Nt * N * 4 bytes apart from its neighbour's, so a per-step access touches 64
+// different cache lines per array and uses N * 4 bytes of each; with >= 8 MB of such lines live per XCD the
+// 4 MB L2 evicts every line before the next step reuses it (PMC, config c5: 5.6 GB moved for 0.94 GB of
+// payload, the roll-out ran at the fabric's bandwidth).  Here each lane moves MP_FD_KS steps at a time: the
+// torque rows of a tile are fetched as one contiguous run per lane and parked in the lane's column of the
+// wave's LDS tile, the three output rows of every step are written to the same tile, and the tile leaves as
+// contiguous KS * N * 4-byte runs (whole 32-byte sectors) per lane and array.  The tile is laid out
+// [step][slot][joint][lane], so every LDS access is lane-contiguous (no bank conflicts) and a lane only ever
+// touches its own column — no barriers, and lanes past the batch end may simply return.
+constexpr int MP_FD_KS = 4;
+// Columns of one step of the tile (each column = 64 lanes x one dword).  float32: [0,N) torque, overwritten by the
+// position once the step has consumed it; [N,2N) velocity; [2N,3N) acceleration; the step's wrench (6 values, if
+// any) sits in [N,N+6) and is likewise consumed before the step's velocity / acceleration are written.
+// float64 inputs take two dwords per value and get their own columns after the three output slots.
+template <typename T, int N, bool HAS_FTIP>
+struct MpFdTile {
+  static constexpr int TW = (int)sizeof(T) / 4;  // dwords per input value
+  static constexpr int TAU0 = (TW == 1) ? 0 : 3 * N;
+  static constexpr int F0 = (TW == 1) ? N : 5 * N;
+  static constexpr int COLS32 = (HAS_FTIP && N + 6 > 3 * N) ? N + 6 : 3 * N;
+  static constexpr int COLS = (TW == 1) ? COLS32 : 5 * N + (HAS_FTIP ? 12 : 0);
+  static constexpr int STEP = COLS * 64;           // dwords per step
+  static constexpr int DWORDS = MP_FD_KS * STEP;   // per wave
+};
+typedef unsigned mp_io_u4 __attribute__((ext_vector_type(4)));
+
+// dword `d` of a lane's contiguous input run (rows of E values of TW dwords) -> tile dword index, lane offset excluded
+template <int E, int TW, int BASE, int STEP>
+__device__ __forceinline__ constexpr int mp_fd_in_slot(int d) {
+  const int s = d / (E * TW), rem = d % (E * TW), e = rem / TW, w = rem % TW;
+  return s * STEP + (BASE + w * E + e) * 64;
+}
+
+// global -> tile: MP_FD_KS rows (or `limit` dwords of them when VW == 1) of one lane's run
+template <int E, int TW, int BASE, int STEP, int VW>
+__device__ __forceinline__ void mp_fd_tile_in(const unsigned* __restrict__ g, int limit, unsigned* __restrict__ col) {
+  constexpr int TOTAL = MP_FD_KS * E * TW;
+#pragma unroll
+  for (int d = 0; d < TOTAL; d += VW) {
+    if constexpr (VW == 4) {
+      const mp_io_u4 v = *reinterpret_cast<const mp_io_u4*>(g + d);
+      col[mp_fd_in_slot<E, TW, BASE, STEP>(d)] = v.x;
+      col[mp_fd_in_slot<E, TW, BASE, STEP>(d + 1)] = v.y;
+      col[mp_fd_in_slot<E, TW, BASE, STEP>(d + 2)] = v.z;
+      col[mp_fd_in_slot<E, TW, BASE, STEP>(d + 3)] = v.w;
+    } else if (d < limit) {
+      col[mp_fd_in_slot<E, TW, BASE, STEP>(d)] = g[d];
+    }
+  }
+}
+
+// tile -> global: output slot `slot` (0 pos, 1 vel, 2 acc) of MP_FD_KS rows (or `limit` dwords when VW == 1)
+template <int N, int STEP, int VW>
+__device__ __forceinline__ void mp_fd_tile_out(float* __restrict__ gdst, int slot, int limit, const unsigned* __restrict__ col) {
+  constexpr int TOTAL = MP_FD_KS * N;
+  unsigned* g = reinterpret_cast<unsigned*>(gdst);
+#pragma unroll
+  for (int d = 0; d < TOTAL; d += VW) {
+    if constexpr (VW == 4) {
+      mp_io_u4 v;
+      v.x = col[((d) / N) * STEP + (slot * N + (d) % N) * 64];
+      v.y = col[((d + 1) / N) * STEP + (slot * N + (d + 1) % N) * 64];
+      v.z = col[((d + 2) / N) * STEP + (slot * N + (d + 2) % N) * 64];
+      v.w = col[((d + 3) / N) * STEP + (slot * N + (d + 3) % N) * 64];
+      *reinterpret_cast<mp_io_u4*>(g + d) = v;
+    } else if (d < limit) {
+      g[d] = col[(d / N) * STEP + (slot * N + d % N) * 64];
+    }
+  }
+}
+
+template <typename T, int TW>
+__device__ __forceinline__ T mp_fd_tile_get(const unsigned* __restrict__ cs, int c, int E) {
+  if constexpr (TW == 1) {
+    return (T)__builtin_bit_cast(float, cs[c * 64]);
+  } else {
+    const unsigned long long u = (unsigned long long)cs[c * 64] | ((unsigned long long)cs[(c + E) * 64] << 32);
+    return (T)__builtin_bit_cast(double, u);
+  }
+}
+
+// `lds` is this wave's tile (MpFdTile<T, N, HAS_FTIP>::DWORDS dwords), `lane` the lane index inside the wave
 template <typename T, int N, bool HAS_FTIP, typename MT>
 __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C, const T* __restrict__ theta0,
                                                 const T* __restrict__ dtheta0, const T* __restrict__ taumat,
                                                 const T* __restrict__ Ftipmat, long b, long Nt, T h, int intRes,
-                                                float* __restrict__ pos, float* __restrict__ vel, float* __restrict__ acc) {
+                                                float* __restrict__ pos, float* __restrict__ vel, float* __restrict__ acc,
+                                                unsigned* __restrict__ lds, int lane) {
+  using TL = MpFdTile<T, N, HAS_FTIP>;
+  constexpr int TW = TL::TW, STEP = TL::STEP;
+  unsigned* col = lds + lane;
   T q[N], qd[N];
   RunIO<T, N>::load(theta0, b, q);
   RunIO<T, N>::load(dtheta0, b, qd);
-  float o[N];
-#pragma unroll
-  for (int j = 0; j < N; ++j) o[j] = (float)q[j];
-  RunIO<float, N>::store(pos, b * Nt, o);
-#pragma unroll
-  for (int j = 0; j < N; ++j) o[j] = (float)qd[j];
-  RunIO<float, N>::store(vel, b * Nt, o);
-#pragma unroll
-  for (int j = 0; j < N; ++j) o[j] = 0.f;
-  RunIO<float, N>::store(acc, b * Nt, o);
-  // step i's torque / wrench rows are fetched one step ahead, so the (lane-strided, latency-bound) loads overlap
-  // the previous step's arithmetic instead of stalling the head of every iteration
-  T tau_n[N], F_n[6];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) F_n[k] = T(0);
-  if (Nt > 1) {
-    RunIO<T, N>::load(taumat, b * Nt + 1, tau_n);
-    if (HAS_FTIP) RunIO<T, 6>::load(Ftipmat, b * Nt + 1, F_n);
-  }
-  for (long i = 1; i < Nt; ++i) {
-    T tau[N], tn[3] = {T(0), T(0), T(0)}, tf[3] = {T(0), T(0), T(0)};
-#pragma unroll
-    for (int j = 0; j < N; ++j) tau[j] = tau_n[j];
-    if (HAS_FTIP) mp_wrench_to_frame1(M, F_n, tn, tf);
-    if (i + 1 < Nt) {
-      RunIO<T, N>::load(taumat, b * Nt + i + 1, tau_n);
-      if (HAS_FTIP) RunIO<T, 6>::load(Ftipmat, b * Nt + i + 1, F_n);
+  // 16-byte vector accesses need every lane's run to start on a 16-byte boundary (wave-uniform tests)
+  const bool vec_tau = ((Nt * N * (long)sizeof(T)) & 15) == 0, vec_out = ((Nt * N * 4) & 15) == 0;
+  const bool vec_f = ((Nt * 6 * (long)sizeof(T)) & 15) == 0;
+  for (long i0 = 0; i0 < Nt; i0 += MP_FD_KS) {
+    const long left = Nt - i0;
+    const int rows = left < MP_FD_KS ? (int)left : MP_FD_KS;
+    const bool full = rows == MP_FD_KS;
+    const long row0 = b * Nt + i0;
+    {
+      const unsigned* g = reinterpret_cast<const unsigned*>(taumat + row0 * N);
+      if (full && vec_tau) mp_fd_tile_in<N, TW, TL::TAU0, STEP, 4>(g, 0, col);
+      else mp_fd_tile_in<N, TW, TL::TAU0, STEP, 1>(g, rows * N * TW, col);
     }
-    T last[N];
+    if (HAS_FTIP) {
+      const unsigned* g = reinterpret_cast<const unsigned*>(Ftipmat + row0 * 6);
+      if (full && vec_f) mp_fd_tile_in<6, TW, TL::F0, STEP, 4>(g, 0, col);
+      else mp_fd_tile_in<6, TW, TL::F0, STEP, 1>(g, rows * 6 * TW, col);
+    }
+    for (int s = 0; s < rows; ++s) {
+      unsigned* cs = col + s * STEP;
+      T last[N];
 #pragma unroll
-    for (int j = 0; j < N; ++j) last[j] = T(0);
-    for (int s = 0; s < intRes; ++s) {
-      mp_forward_dynamics<T, N, HAS_FTIP>(M, C.a0, tn, tf, q, qd, tau, last);
+      for (int j = 0; j < N; ++j) last[j] = T(0);
+      if (i0 + s > 0) {
+        T tau[N], tn[3] = {T(0), T(0), T(0)}, tf[3] = {T(0), T(0), T(0)};
+#pragma unroll
+        for (int j = 0; j < N; ++j) tau[j] = mp_fd_tile_get<T, TW>(cs, TL::TAU0 + j, N);
+        if (HAS_FTIP) {
+          T F[6];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) F[k] = mp_fd_tile_get<T, TW>(cs, TL::F0 + k, 6);
+          mp_wrench_to_frame1(M, F, tn, tf);
+        }
+        for (int k = 0; k < intRes; ++k) {
+          mp_forward_dynamics<T, N, HAS_FTIP>(M, C.a0, tn, tf, q, qd, tau, last);
+#pragma unroll
+          for (int j = 0; j < N; ++j) {
+            qd[j] = qd[j] + last[j] * h;
+            q[j] = mp_clip(q[j] + qd[j] * h, M.qmin[j], M.qmax[j]);
+          }
+        }
+      }
 #pragma unroll
       for (int j = 0; j < N; ++j) {
-        qd[j] = qd[j] + last[j] * h;
-        q[j] = mp_clip(q[j] + qd[j] * h, M.qmin[j], M.qmax[j]);
+        cs[j * 64] = __builtin_bit_cast(unsigned, (float)q[j]);
+        cs[(N + j) * 64] = __builtin_bit_cast(unsigned, (float)qd[j]);
+        cs[(2 * N + j) * 64] = __builtin_bit_cast(unsigned, (float)last[j]);
       }
     }
-#pragma unroll
-    for (int j = 0; j < N; ++j) o[j] = (float)q[j];
-    RunIO<float, N>::store(pos, b * Nt + i, o);
-#pragma unroll
-    for (int j = 0; j < N; ++j) o[j] = (float)qd[j];
-    RunIO<float, N>::store(vel, b * Nt + i, o);
-#pragma unroll
-    for (int j = 0; j < N; ++j) o[j] = (float)last[j];
-    RunIO<float, N>::store(acc, b * Nt + i, o);
+    if (full && vec_out) {
+      mp_fd_tile_out<N, STEP, 4>(pos + row0 * N, 0, 0, col);
+      mp_fd_tile_out<N, STEP, 4>(vel + row0 * N, 1, 0, col);
+      mp_fd_tile_out<N, STEP, 4>(acc + row0 * N, 2, 0, col);
+    } else {
+      mp_fd_tile_out<N, STEP, 1>(pos + row0 * N, 0, rows * N, col);
+      mp_fd_tile_out<N, STEP, 1>(vel + row0 * N, 1, rows * N, col);
+      mp_fd_tile_out<N, STEP, 1>(acc + row0 * N, 2, rows * N, col);
+    }
   }
 }

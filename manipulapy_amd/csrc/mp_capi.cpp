@@ -292,7 +292,7 @@ int launch_fd_spec(mp_ctx* ctx, const mp_model* model, const MpCall<float>& c, c
   if (!sp) return -1;
   MpCall<float> cc = c;
   void* args[] = {&cc, &th0, &dth0, &taumat, &Fm, &B, &Nt, &h, &intRes, &pos, &vel, &acc};
-  return launch_spec(ctx, sp->fd_traj[Fm ? 1 : 0], B, args);
+  return launch_spec(ctx, sp->fd_traj[Fm ? 1 : 0], B, args, 64);  // one wave per block (per-wave LDS tile)
 }
 int launch_fd_spec(mp_ctx*, const mp_model*, const MpCall<double>&, const double*, const double*, const double*, const double*,
                    long, long, double, int, float*, float*, float*) {

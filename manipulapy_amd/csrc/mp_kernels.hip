@@ -186,14 +186,17 @@ __global__ __launch_bounds__(kBlock) void k_forward_dynamics(const MpModel<T> M,
   RunIO<T, N>::store(qdd, r, out);
 }
 
+// one wave per block: the roll-out's LDS tile is per wave and nothing is shared between waves
+constexpr int kFdBlock = 64;
 template <typename T, int N, bool HAS_FTIP>
-__global__ __launch_bounds__(kBlock) void k_fd_traj(const MpModel<T> M, const MpCall<T> C, const T* __restrict__ theta0,
-                                                    const T* __restrict__ dtheta0, const T* __restrict__ taumat,
-                                                    const T* __restrict__ Ftipmat, long B, long Nt, T h, int intRes,
-                                                    float* __restrict__ pos, float* __restrict__ vel, float* __restrict__ acc) {
-  const long b = (long)blockIdx.x * kBlock + threadIdx.x;
+__global__ __launch_bounds__(kFdBlock, (sizeof(T) == 4 ? 2 : 1)) void k_fd_traj(const MpModel<T> M, const MpCall<T> C, const T* __restrict__ theta0,
+                                                      const T* __restrict__ dtheta0, const T* __restrict__ taumat,
+                                                      const T* __restrict__ Ftipmat, long B, long Nt, T h, int intRes,
+                                                      float* __restrict__ pos, float* __restrict__ vel, float* __restrict__ acc) {
+  __shared__ unsigned lds[MpFdTile<T, N, HAS_FTIP>::DWORDS];
+  const long b = (long)blockIdx.x * kFdBlock + threadIdx.x;
   if (b >= B) return;
-  mp_body_fd_traj<T, N, HAS_FTIP>(M, C, theta0, dtheta0, taumat, Ftipmat, b, Nt, h, intRes, pos, vel, acc);
+  mp_body_fd_traj<T, N, HAS_FTIP>(M, C, theta0, dtheta0, taumat, Ftipmat, b, Nt, h, intRes, pos, vel, acc, lds, (int)threadIdx.x);
 }
 
 // ------------------------------------------------------------------- Cartesian straight-line path
@@ -398,8 +401,8 @@ hipError_t mpk_fd_traj(hipStream_t s, const MpModel<T>& M, const MpCall<T>& C, c
                        const T* taumat, const T* Ftipmat, long B, long Nt, T h, int intRes, float* pos, float* vel, float* acc) {
   if (B <= 0 || Nt <= 0) return hipSuccess;
   MP_DISPATCH_N(M.n, {
-    if (Ftipmat) hipLaunchKernelGGL((k_fd_traj<T, N, true>), dim3(grid_for(B)), dim3(kBlock), 0, s, M, C, theta0, dtheta0, taumat, Ftipmat, B, Nt, h, intRes, pos, vel, acc);
-    else hipLaunchKernelGGL((k_fd_traj<T, N, false>), dim3(grid_for(B)), dim3(kBlock), 0, s, M, C, theta0, dtheta0, taumat, Ftipmat, B, Nt, h, intRes, pos, vel, acc);
+    if (Ftipmat) hipLaunchKernelGGL((k_fd_traj<T, N, true>), dim3((unsigned)((B + kFdBlock - 1) / kFdBlock)), dim3(kFdBlock), 0, s, M, C, theta0, dtheta0, taumat, Ftipmat, B, Nt, h, intRes, pos, vel, acc);
+    else hipLaunchKernelGGL((k_fd_traj<T, N, false>), dim3((unsigned)((B + kFdBlock - 1) / kFdBlock)), dim3(kFdBlock), 0, s, M, C, theta0, dtheta0, taumat, Ftipmat, B, Nt, h, intRes, pos, vel, acc);
   })
   return hipGetLastError();
 }

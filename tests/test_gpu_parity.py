@@ -399,6 +399,45 @@ def test_forward_dynamics_trajectory_fixture_and_oracle(tables):
                 np.testing.assert_allclose(one[k], o[k], rtol=1e-5, atol=1e-5 * max(1.0, float(np.abs(o[k]).max())))
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_forward_dynamics_trajectory_tiles_and_alignment(tables, dtype):
+    """The roll-out kernel moves its rows in 4-step tiles with 16-byte vector accesses when every lane's run is
+    aligned: cover partial tiles (Nt not a multiple of 4), Nt = 1, unaligned runs (panda: n = 7, odd Nt), more than one
+    wave with a ragged last wave, generic and specialised kernels, with and without per-step wrenches."""
+    from manipulapy_amd import _hip
+
+    ctx = _hip.HipContext(0)
+    G0 = np.array([0.0, 0.0, -9.81])
+    try:
+        for robot, B in (("xarm6", 67), ("panda", 65)):
+            tab = tables[robot]
+            gen = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee, tab.joint_limits)
+            spec = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee, tab.joint_limits)
+            ctx.specialize(spec)
+            n = tab.n
+            for Nt in (1, 2, 3, 4, 5, 7, 8, 9):
+                rng = np.random.default_rng(100 + Nt)
+                th0 = rng.uniform(-0.5, 0.5, (B, n)); dth0 = rng.uniform(-0.2, 0.2, (B, n))
+                tm = rng.uniform(-1, 1, (B, Nt, n)); Fm = rng.uniform(-1, 1, (B, Nt, 6))
+                for wrench in (None, Fm):
+                    a = ctx.fd_trajectory_host(gen, th0, dth0, tm, G0, wrench, 0.01, 2, dtype=dtype)
+                    b = ctx.fd_trajectory_host(spec, th0, dth0, tm, G0, wrench, 0.01, 2, dtype=dtype)
+                    for x, y in zip(a, b):
+                        assert x.shape == (B, Nt, n) and np.isfinite(x).all()
+                        np.testing.assert_allclose(x, y, rtol=2e-4, atol=2e-4 * max(1.0, float(np.abs(x).max())))
+                    np.testing.assert_array_equal(a[2][:, 0], 0)
+                    np.testing.assert_array_equal(a[0][:, 0], th0.astype(dtype).astype(np.float32))
+                    for t in (0, B - 1):  # first lane of the first wave, last lane of the ragged wave
+                        o = ref.forward_dynamics_trajectory(tab, th0[t], dth0[t], tm[t], G0,
+                                                            np.zeros((Nt, 6)) if wrench is None else Fm[t], 0.01, 2,
+                                                            joint_limits=tab.joint_limits)
+                        tol = 1e-5 if dtype == np.float64 else 3e-4
+                        for k, name in enumerate(("positions", "velocities", "accelerations")):
+                            np.testing.assert_allclose(a[k][t], o[name], rtol=tol, atol=tol * max(1.0, float(np.abs(o[name]).max())))
+    finally:
+        ctx.destroy()
+
+
 @pytest.mark.parametrize("robot", ROBOTS)
 def test_specialised_kernels_match_generic_and_oracle(robot, tables, dyn_golden):
     """Run-time specialised float32 kernels (mp_model_specialize) vs the generic ones vs the oracle:
