@@ -390,6 +390,25 @@ class HipContext:
         F = _vec_or_none(Ftip, 6, "Ftip")
         _check(fn(self.handle, model.handle, _p(d_q), _p(d_qd), _p(d_qdd), int(rows), _dptr(g), _dptr(F), _p(d_T), _p(d_J), _p(d_tau)))
 
+    def mass_matrix(self, model, d_q, rows, d_M, dtype=np.float64):
+        fn = self.lib.mp_mass_matrix_f64 if np.dtype(dtype) == np.float64 else self.lib.mp_mass_matrix_f32
+        _check(fn(self.handle, model.handle, _p(d_q), int(rows), _p(d_M)))
+
+    def forward_dynamics(self, model, d_q, d_qd, d_tau, rows, d_qdd, g=None, Ftip=None, dtype=np.float64):
+        fn = self.lib.mp_forward_dynamics_f64 if np.dtype(dtype) == np.float64 else self.lib.mp_forward_dynamics_f32
+        g = _vec_or_none(g, 3, "g")
+        F = _vec_or_none(Ftip, 6, "Ftip")
+        _check(fn(self.handle, model.handle, _p(d_q), _p(d_qd), _p(d_tau), int(rows), _dptr(g), _dptr(F), _p(d_qdd)))
+
+    def cartesian_trajectory(self, d_Xstart, d_Xend, B, N, Tf, method, d_pos, d_vel, d_acc, d_orient):
+        _check(self.lib.mp_cartesian_trajectory_f32(self.handle, _p(d_Xstart), _p(d_Xend), int(B), int(N), float(Tf), int(method),
+                                                    _p(d_pos), _p(d_vel), _p(d_acc), _p(d_orient)))
+
+    def potential_field(self, d_positions, goal, d_obstacles, P, O, influence_distance, d_potential, d_gradient):
+        goal = np.ascontiguousarray(goal, dtype=np.float32).reshape(3)
+        _check(self.lib.mp_potential_field_f32(self.handle, _p(d_positions), _fptr(goal), _p(d_obstacles), int(P), int(O),
+                                               float(influence_distance), _p(d_potential), _p(d_gradient)))
+
     # ---- hot path on host arrays (what the registry's gpu launchers call; synchronous)
     def id_trajectory_host(self, model: HipModel, q, qd, qdd, g=None, Ftip=None, dtype=np.float32) -> np.ndarray:
         dtype = np.dtype(dtype)

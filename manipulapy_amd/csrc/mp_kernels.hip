@@ -151,11 +151,17 @@ __global__ __launch_bounds__(kFkBlock) void k_fk_jac_id(const MpModel<T> M, cons
 }
 
 // ------------------------------------------------------------- mass matrix / forward dynamics
+// one wave per block; the N x N rows leave through the wave-cooperative coalesced store (see mp_bodies.h)
 template <typename T, int N>
-__global__ __launch_bounds__(kBlock) void k_mass_matrix(const MpModel<T> M, const T* __restrict__ q, T* __restrict__ Mout,
-                                                        long rows) {
-  const long r = (long)blockIdx.x * kBlock + threadIdx.x;
-  if (r >= rows) return;
+__global__ __launch_bounds__(kFkBlock) void k_mass_matrix(const MpModel<T> M, const T* __restrict__ q, T* __restrict__ Mout,
+                                                          long rows) {
+  __shared__ __attribute__((aligned(16))) char lds[MP_WAVE_LDS_BYTES];
+  const int lane = (int)threadIdx.x;
+  const long row0 = (long)blockIdx.x * kFkBlock;
+  if (row0 >= rows) return;
+  const long left = rows - row0;
+  const int nvalid = left < 64 ? (int)left : 64;
+  const long r = lane < nvalid ? row0 + lane : rows - 1;  // out-of-range lanes recompute the last row, store nothing
   T a[N];
   RunIO<T, N>::load(q, r, a);
   MpJointState<T, N> js;
@@ -167,7 +173,7 @@ __global__ __launch_bounds__(kBlock) void k_mass_matrix(const MpModel<T> M, cons
   for (int i = 0; i < N; ++i)
 #pragma unroll
     for (int j = 0; j < N; ++j) flat[i * N + j] = Mq[i][j];
-  RunIO<T, N * N>::store(Mout, r, flat);
+  mp_wave_store_auto<T, N * N>(Mout, row0, lane, nvalid, flat, lds);
 }
 
 // qdd = forward_dynamics(q, qd, tau, g, Ftip) per row; Ftip is one wrench for every row (per-call constant)
@@ -375,7 +381,7 @@ template hipError_t mpk_fk_jac_id<double>(hipStream_t, const MpModel<double>&, c
 template <typename T>
 hipError_t mpk_mass_matrix(hipStream_t s, const MpModel<T>& M, const T* q, T* Mout, long rows) {
   if (rows <= 0) return hipSuccess;
-  MP_DISPATCH_N(M.n, { hipLaunchKernelGGL((k_mass_matrix<T, N>), dim3(grid_for(rows)), dim3(kBlock), 0, s, M, q, Mout, rows); })
+  MP_DISPATCH_N(M.n, { hipLaunchKernelGGL((k_mass_matrix<T, N>), dim3((unsigned)((rows + kFkBlock - 1) / kFkBlock)), dim3(kFkBlock), 0, s, M, q, Mout, rows); })
   return hipGetLastError();
 }
 template hipError_t mpk_mass_matrix<float>(hipStream_t, const MpModel<float>&, const float*, float*, long);

@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Time the secondary operators of the path on device-resident buffers (HIP events on the library's stream):
+mass matrix, forward dynamics, trajectory generation, Cartesian path, potential field.  One JSON line per
+operator: rows/s and algorithmic GB/s.  bench.py covers the headline configurations (c2..c5)."""
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import manipulapy_amd as mp  # noqa: E402
+from manipulapy_amd import _hip  # noqa: E402
+
+
+def timed(ctx, fn, steps=10, warmup=2):
+    for _ in range(warmup):
+        fn()
+    ctx.synchronize()
+    a, b = ctx.event(), ctx.event()
+    a.record()
+    for _ in range(steps):
+        fn()
+    b.record()
+    ctx.synchronize()
+    ms = b.elapsed_ms_since(a) / steps
+    a.destroy(); b.destroy()
+    return ms
+
+
+def main():
+    rows = int(os.environ.get("ROWS", 1 << 22))
+    ctx = _hip.HipContext(0)
+    rng = np.random.default_rng(0)
+    out = []
+    for robot in ("ur5", "iiwa14"):
+        sm, dyn, lim = mp.load_robot(robot)
+        model = _hip.HipModel(dyn.S_list, dyn.Mlist_per_link, dyn.Glist, sm.M_list, lim)
+        n = model.n
+        for dt in (np.float64, np.float32):
+            w = np.dtype(dt).itemsize
+            q = ctx.to_device(rng.uniform(-1, 1, (rows, n)).astype(dt))
+            qd = ctx.to_device(rng.uniform(-1, 1, (rows, n)).astype(dt))
+            tau = ctx.to_device(rng.uniform(-1, 1, (rows, n)).astype(dt))
+            M = ctx.alloc(rows * n * n * w)
+            qdd = ctx.alloc(rows * n * w)
+            ms = timed(ctx, lambda: ctx.mass_matrix(model, q, rows, M, dtype=dt))
+            by = rows * (n + n * n) * w
+            out.append(dict(op="mass_matrix", robot=robot, dtype=np.dtype(dt).name, rows=rows, ms=ms, rows_per_s=rows / ms * 1e3,
+                            alg_GBps=by / ms / 1e6))
+            ms = timed(ctx, lambda: ctx.forward_dynamics(model, q, qd, tau, rows, qdd, dtype=dt))
+            by = rows * 4 * n * w
+            out.append(dict(op="forward_dynamics", robot=robot, dtype=np.dtype(dt).name, rows=rows, ms=ms,
+                            rows_per_s=rows / ms * 1e3, alg_GBps=by / ms / 1e6))
+            for b in (q, qd, tau, M, qdd):
+                b.free()
+        # trajectory generation: B x N rows, three float32 outputs
+        B, N = 4096, 1000
+        st = ctx.to_device(rng.uniform(-1, 1, (B, n)).astype(np.float32))
+        en = ctx.to_device(rng.uniform(-1, 1, (B, n)).astype(np.float32))
+        o = [ctx.alloc(B * N * n * 4) for _ in range(3)]
+        ms = timed(ctx, lambda: ctx.batch_trajectory(model, st, en, B, N, 2.0, 5, *o))
+        out.append(dict(op="batch_trajectory", robot=robot, dtype="float32", rows=B * N, ms=ms, rows_per_s=B * N / ms * 1e3,
+                        alg_GBps=3 * B * N * n * 4 / ms / 1e6))
+        for b in (st, en, *o):
+            b.free()
+        model.destroy()
+    # Cartesian straight-line path
+    B, N = 4096, 1000
+    X = np.tile(np.eye(4), (B, 1, 1)); X[:, :3, 3] = rng.uniform(-1, 1, (B, 3))
+    Y = X.copy(); Y[:, :3, 3] += 0.3
+    dX, dY = ctx.to_device(X), ctx.to_device(Y)
+    o = [ctx.alloc(B * N * 3 * 4) for _ in range(3)] + [ctx.alloc(B * N * 9 * 4)]
+    ms = timed(ctx, lambda: ctx.cartesian_trajectory(dX, dY, B, N, 2.0, 5, *o))
+    out.append(dict(op="cartesian_trajectory", dtype="float32", rows=B * N, ms=ms, rows_per_s=B * N / ms * 1e3,
+                    alg_GBps=B * N * 18 * 4 / ms / 1e6))
+    for b in (dX, dY, *o):
+        b.free()
+    # potential field: P points x O obstacles
+    P, O = 1 << 22, 64
+    pos = ctx.to_device(rng.uniform(-2, 2, (P, 3)).astype(np.float32))
+    obs = ctx.to_device(rng.uniform(-2, 2, (O, 3)).astype(np.float32))
+    pot, grad = ctx.alloc(P * 4), ctx.alloc(P * 12)
+    ms = timed(ctx, lambda: ctx.potential_field(pos, [0.5, 0.5, 0.5], obs, P, O, 0.8, pot, grad))
+    out.append(dict(op="potential_field", dtype="float32", rows=P, obstacles=O, ms=ms, rows_per_s=P / ms * 1e3,
+                    alg_GBps=P * 28 / ms / 1e6, pair_per_s=P * O / ms * 1e3))
+    for r in out:
+        print(json.dumps(r))
+    ctx.destroy()
+
+
+if __name__ == "__main__":
+    main()
