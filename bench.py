@@ -91,6 +91,19 @@ def cpu_baseline(robot, q, qd, qdd, budget_s=12.0):
                       f"reference algorithm (the reference's own NumPy code runs ~40-80 ms per row, BASELINE.md)"}, tau
 
 
+def ramp(ctx, step, ms):
+    """Setup, untimed: keep the GPU busy with the step for `ms` milliseconds (clock / power ramp after the idle setup phase;
+    measured on c2: 0.080 ms per step right after start-up, 0.0747 ms once warm)."""
+    t0 = time.perf_counter()
+    n = 0
+    while (time.perf_counter() - t0) * 1e3 < ms and n < 100000:
+        for _ in range(8):
+            step()
+        ctx.synchronize()
+        n += 8
+    return n
+
+
 FTIP_REF = np.array([1.0, -2.0, 0.5, 3.0, -1.5, 0.75])  # the reference's own non-zero wrench (tests/test_dynamics_golden.py:145)
 
 
@@ -114,21 +127,23 @@ def bench_fd(args, cfg, info, hg, ctx, model, t, props):
     def step():
         ctx.fd_trajectory(model, d_th0, d_dth0, d_tau, d_F, B, N, g, 0.01, 1, d_pos, d_vel, d_acc, dtype=np.float32)
 
+    ramp(ctx, step, args.ramp_ms)
     for _ in range(args.warmup):
         step()
     ctx.synchronize()
-    ev = [(ctx.event(), ctx.event()) for _ in range(args.steps)]
+    a, b = ctx.event(), ctx.event()
     hg.barrier()
     ctx.synchronize()
     t0 = time.perf_counter()
+    a.record()
     for k in range(args.steps):
-        ev[k][0].record()
         step()
-        ev[k][1].record()
+    b.record()   # HIP events on the launch stream around the K launches of the timed region
     ctx.synchronize()
+    dt = time.perf_counter() - t0
     hg.barrier()
-    elapsed = hg.max(time.perf_counter() - t0)
-    kern_ms = float(np.mean([b.elapsed_ms_since(a) for a, b in ev]))
+    elapsed = hg.max(dt)
+    kern_ms = b.elapsed_ms_since(a) / args.steps   # average launch period = kernel duration + dispatch gap
     alg_bytes = algorithmic_bytes_per_row(cfg, n) * B * N
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
     result = {
@@ -141,9 +156,15 @@ def bench_fd(args, cfg, info, hg, ctx, model, t, props):
                    "sharding": f"batch axis over {world} rank(s), no collective in the timed step"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                      "traffic": None, "kernel": kernel_name(cfg), "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                     "kernel_ms_method": "HIP events on the launch stream around the K launches of the timed region, / K",
                      "note": "sequential in time: VALU-bound (mass matrix + solve per step), HBM line shown for reference"},
+        "setup": {"ramp_ms": args.ramp_ms, "what": "untimed launches before the W warm-up steps (clock ramp)"},
         "device": props["name"],
     }
+    traffic_file = os.path.join(ROOT, "profiles", f"traffic_{args.config}.json")
+    if os.path.exists(traffic_file):  # measured HBM bytes per launch from the rocprofv3 --pmc passes
+        with open(traffic_file) as f:
+            result["roofline"]["traffic"] = json.load(f).get("hbm_bytes_per_launch")
     if info.rank == 0 and world == 1 and not args.no_cpu_baseline:
         tab = ref.load_tables(os.path.join(ROOT, "tests", "golden", f"model_{cfg['robot']}.npz"))
         r0 = ref.forward_dynamics_trajectory(tab, th0[0].astype(np.float64), dth0[0].astype(np.float64), taumat[0, :12].astype(np.float64),
@@ -168,6 +189,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--launch", default="stream", choices=("stream", "graph"),
+                    help="stream: one host call per step; graph: the K timed steps captured into one hipGraph launch")
+    ap.add_argument("--event-stride", type=int, default=0,
+                    help="0: one HIP event pair around the whole timed region (default); S > 0: a pair around every S-th launch")
+    ap.add_argument("--ramp-ms", type=float, default=60.0,
+                    help="setup: run the step untimed for this long before the W warm-up steps so the GPU is at its sustained clocks")
     ap.add_argument("--no-gather", action="store_true", help="multi-GPU: skip the all-gather (compute-only figure)")
     ap.add_argument("--no-specialize", action="store_true", help="use the generic kernels (no run-time robot specialisation)")
     ap.add_argument("--B", type=int, default=0, help="experiments only: override the config's trajectories per GPU")
@@ -248,27 +275,62 @@ def main():
     def timed(fn_after_step=None):
         """W warm-up steps, then exactly K timed steps between barrier + device sync on both sides.
         Returns (max-over-ranks wall seconds, mean kernel ms from HIP events on the launch stream)."""
+        ramp(ctx, step, args.ramp_ms)
         for _ in range(args.warmup):
             step()
             if fn_after_step:
                 fn_after_step()
         ctx.synchronize()
-        ev = [(ctx.event(), ctx.event()) for _ in range(args.steps)]
+        if args.launch == "graph" and fn_after_step is None:
+            # the K launches of the timed region are captured once (hipGraph) and submitted as ONE graph launch: the
+            # queue then holds all K dispatch packets up front instead of receiving one per host call
+            with ctx.capture() as cap:
+                for _ in range(args.steps):
+                    step()
+            graph = cap.graph
+            graph.launch()   # untimed: first launch uploads the graph
+            ctx.synchronize()
+            a, b = ctx.event(), ctx.event()
+            hg.barrier()
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            a.record()
+            graph.launch()
+            b.record()       # HIP events on the launch stream around the K kernels of the timed region
+            ctx.synchronize()
+            dt = time.perf_counter() - t0
+            hg.barrier()
+            wall = hg.max(dt)
+            kms = b.elapsed_ms_since(a) / args.steps   # average launch period: kernel + any residual inter-kernel gap
+            a.destroy(); b.destroy(); graph.destroy()
+            return wall, kms
+        # HIP events on the launch stream around the K launches of the timed region: elapsed / K = the kernel's average
+        # launch period (duration + the ~2 us dispatch gap), an upper bound on its duration.  --event-stride S instead
+        # brackets every S-th launch with its own pair (isolated duration, but each pair costs a queue bubble).
+        stride = args.event_stride
+        ev = {k: (ctx.event(), ctx.event()) for k in range(0, args.steps, stride)} if stride > 0 else {}
+        a, b = ctx.event(), ctx.event()
         hg.barrier()
         ctx.synchronize()
         t0 = time.perf_counter()
+        a.record()
         for k in range(args.steps):
-            ev[k][0].record()
+            pair = ev.get(k)
+            if pair:
+                pair[0].record()
             step()
-            ev[k][1].record()   # HIP events on the launch stream bracket the dominant kernel alone
+            if pair:
+                pair[1].record()
             if fn_after_step:
                 fn_after_step()
+        b.record()
         ctx.synchronize()
+        dt = time.perf_counter() - t0
         hg.barrier()
-        wall = hg.max(time.perf_counter() - t0)
-        kms = float(np.mean([b.elapsed_ms_since(a) for a, b in ev]))
-        for a, b in ev:
-            a.destroy(); b.destroy()
+        wall = hg.max(dt)
+        kms = float(np.mean([y.elapsed_ms_since(x) for x, y in ev.values()])) if ev else b.elapsed_ms_since(a) / args.steps
+        for x, y in list(ev.values()) + [(a, b)]:
+            x.destroy(); y.destroy()
         return wall, kms
 
     # ---- the timed step: every rank evaluates its own shard; the path has no exchange step, so no collective
@@ -327,7 +389,12 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                      "kernel": kernel_name(cfg), "kernel_ms": kern_ms,
-                     "kernel_ms_max_over_ranks": kern_ms_all, "algorithmic_bytes_per_launch": alg_bytes},
+                     "kernel_ms_max_over_ranks": kern_ms_all, "algorithmic_bytes_per_launch": alg_bytes,
+                     "kernel_ms_method": ("HIP event pair around every %d-th launch of the timed region" % args.event_stride)
+                     if args.event_stride > 0 else
+                     "HIP events on the launch stream around the K launches of the timed region, / K (launch period: duration + dispatch gap)"},
+        "launch": "one hipGraph of K captured launches" if args.launch == "graph" else "one host call per step",
+        "setup": {"ramp_ms": args.ramp_ms, "what": "untimed launches before the W warm-up steps (clock ramp)"},
         "device": props["name"],
     }
     traffic_file = os.path.join(ROOT, "profiles", f"traffic_{args.config}.json")

@@ -42,6 +42,7 @@ extern "C" {
 typedef struct mp_ctx mp_ctx;     /* device context: device id, streams, device-buffer pool */
 typedef struct mp_model mp_model; /* compiled robot model (host object, passed to kernels by value) */
 typedef struct mp_event mp_event; /* HIP event on the context's compute stream */
+typedef struct mp_graph mp_graph; /* instantiated HIP graph captured from the context's compute stream */
 typedef struct mp_comm mp_comm;   /* RCCL communicator (one rank per process) */
 
 /* ---- library / device ----------------------------------------------------------------------- */
@@ -73,6 +74,18 @@ int mp_event_create(mp_ctx* ctx, mp_event** out);
 int mp_event_destroy(mp_event* ev);
 int mp_event_record(mp_ctx* ctx, mp_event* ev);   /* on the stream the kernels are launched on */
 int mp_event_elapsed_ms(mp_event* start, mp_event* stop, float* ms); /* synchronises on `stop` */
+
+/* ---- launch graphs ----------------------------------------------------------------------------
+ * Every device-pointer entry point below only enqueues kernels on the context's compute stream, so a sequence of
+ * them can be captured once and replayed with a single submission (hipGraph): between mp_graph_begin and
+ * mp_graph_end the calls are recorded instead of executed.  Replaying re-runs the same kernels on the same
+ * device pointers with the same per-call constants; the caller refreshes the buffers' contents in between.
+ * (The reference has no counterpart: its launchers pay one Numba dispatch per kernel, cuda_kernels/registry.py:828-867.)
+ * Not capturable: the *_host_* entry points, mp_malloc / mp_free, mp_model_specialize, mp_comm_*. */
+int mp_graph_begin(mp_ctx* ctx);
+int mp_graph_end(mp_ctx* ctx, mp_graph** out);
+int mp_graph_launch(mp_ctx* ctx, mp_graph* graph);   /* asynchronous, on the compute stream */
+int mp_graph_destroy(mp_graph* graph);
 
 /* ---- robot model ------------------------------------------------------------------------------
  * Inputs are the reference's constant tables (urdf/core.py:670-769; ManipulatorDynamics ctor,

@@ -59,6 +59,10 @@ SIGNATURES = {
     "mp_event_destroy": (ctypes.c_int, [_vp]),
     "mp_event_record": (ctypes.c_int, [_vp, _vp]),
     "mp_event_elapsed_ms": (ctypes.c_int, [_vp, _vp, ctypes.POINTER(ctypes.c_float)]),
+    "mp_graph_begin": (ctypes.c_int, [_vp]),
+    "mp_graph_end": (ctypes.c_int, [_vp, ctypes.POINTER(_vp)]),
+    "mp_graph_launch": (ctypes.c_int, [_vp, _vp]),
+    "mp_graph_destroy": (ctypes.c_int, [_vp]),
     "mp_model_create": (ctypes.c_int, [ctypes.c_int, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, ctypes.POINTER(_vp)]),
     "mp_model_destroy": (ctypes.c_int, [_vp]),
     "mp_model_dof": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int)]),
@@ -231,6 +235,40 @@ class HipEvent:
             self.handle = None
 
 
+class HipGraph:
+    """A captured sequence of device-pointer launches (mp_graph_*), replayed with one submission."""
+
+    def __init__(self, ctx: "HipContext", handle):
+        self.ctx, self.handle = ctx, handle
+
+    def launch(self) -> None:
+        _check(self.ctx.lib.mp_graph_launch(self.ctx.handle, self.handle))
+
+    def destroy(self) -> None:
+        if self.handle is not None:
+            self.ctx.lib.mp_graph_destroy(self.handle)
+            self.handle = None
+
+
+class _Capture:
+    def __init__(self, ctx: "HipContext"):
+        self.ctx, self.graph = ctx, None
+
+    def __enter__(self):
+        _check(self.ctx.lib.mp_graph_begin(self.ctx.handle))
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        p = _vp()
+        rc = self.ctx.lib.mp_graph_end(self.ctx.handle, ctypes.byref(p))
+        if exc_type is None:
+            _check(rc)
+            self.graph = HipGraph(self.ctx, p)
+        elif rc == 0:
+            self.ctx.lib.mp_graph_destroy(p)
+        return False
+
+
 class HipModel:
     """Compiled robot model (mp_model_create).  Host-only object: no GPU needed to build one."""
 
@@ -358,6 +396,10 @@ class HipContext:
 
     def event(self) -> HipEvent:
         return HipEvent(self)
+
+    def capture(self) -> _Capture:
+        """``with ctx.capture() as cap: <device-pointer launches>`` -> ``cap.graph`` (HipGraph)."""
+        return _Capture(self)
 
     def trim_pool(self) -> None:
         _check(self.lib.mp_pool_trim(self.handle))

@@ -33,6 +33,7 @@ struct mp_ctx {
   std::map<uint64_t, void*> dev_models;                // model uid -> float32 model resident on this device
   std::map<uint64_t, MpSpec> specs;                    // model uid -> specialised kernels (mp_model_specialize)
   int compute_units = 0;
+  bool capturing = false;                              // between mp_graph_begin and mp_graph_end
 };
 struct mp_model {
   MpModel<double> d;
@@ -41,6 +42,12 @@ struct mp_model {
 };
 struct mp_event {
   hipEvent_t ev = nullptr;
+  int device = -1;
+};
+
+struct mp_graph {
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
   int device = -1;
 };
 
@@ -442,6 +449,7 @@ int mp_malloc(mp_ctx* ctx, size_t bytes, void** d_ptr) {
   REQUIRE(ctx && d_ptr, "mp_malloc: null argument");
   *d_ptr = nullptr;
   if (int rc = bind(ctx)) return rc;
+  REQUIRE(!ctx->capturing, "mp_malloc: not allowed while a launch graph is being captured (mp_graph_begin)");
   if (bytes == 0) bytes = 16;
   bytes = (bytes + 255) & ~size_t(255);
   auto it = ctx->free_by_size.find(bytes);
@@ -540,6 +548,50 @@ int mp_event_elapsed_ms(mp_event* start, mp_event* stop, float* ms) {
   HIP_TRY(hipSetDevice(stop->device));
   HIP_TRY(hipEventSynchronize(stop->ev));
   HIP_TRY(hipEventElapsedTime(ms, start->ev, stop->ev));
+  return MP_OK;
+}
+
+// ----------------------------------------------------------------------------------------- graphs
+int mp_graph_begin(mp_ctx* ctx) {
+  REQUIRE(ctx, "mp_graph_begin: null context");
+  if (int rc = bind(ctx)) return rc;
+  REQUIRE(!ctx->capturing, "mp_graph_begin: a capture is already open on this context");
+  HIP_TRY(hipStreamBeginCapture(ctx->compute, hipStreamCaptureModeThreadLocal));
+  ctx->capturing = true;
+  return MP_OK;
+}
+int mp_graph_end(mp_ctx* ctx, mp_graph** out) {
+  REQUIRE(ctx && out, "mp_graph_end: null argument");
+  *out = nullptr;
+  if (int rc = bind(ctx)) return rc;
+  REQUIRE(ctx->capturing, "mp_graph_end: no capture is open on this context");
+  ctx->capturing = false;
+  hipGraph_t g = nullptr;
+  HIP_TRY(hipStreamEndCapture(ctx->compute, &g));
+  REQUIRE(g, "mp_graph_end: the capture was invalidated (a non-capturable call ran between begin and end)");
+  hipGraphExec_t ex = nullptr;
+  hipError_t he = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+  if (he != hipSuccess) { (void)hipGraphDestroy(g); return hip_err(he, "hipGraphInstantiate"); }
+  mp_graph* gr = new (std::nothrow) mp_graph;
+  if (!gr) { (void)hipGraphExecDestroy(ex); (void)hipGraphDestroy(g); }
+  REQUIRE(gr, "mp_graph_end: out of host memory");
+  gr->graph = g; gr->exec = ex; gr->device = ctx->device;
+  *out = gr;
+  return MP_OK;
+}
+int mp_graph_launch(mp_ctx* ctx, mp_graph* graph) {
+  REQUIRE(ctx && graph, "mp_graph_launch: null argument");
+  REQUIRE(graph->device == ctx->device, "mp_graph_launch: graph captured on device %d, context is on %d", graph->device, ctx->device);
+  if (int rc = bind(ctx)) return rc;
+  HIP_TRY(hipGraphLaunch(graph->exec, ctx->compute));
+  return MP_OK;
+}
+int mp_graph_destroy(mp_graph* graph) {
+  if (!graph) return MP_OK;
+  (void)hipSetDevice(graph->device);
+  (void)hipGraphExecDestroy(graph->exec);
+  (void)hipGraphDestroy(graph->graph);
+  delete graph;
   return MP_OK;
 }
 

@@ -521,6 +521,61 @@ def test_rccl_communicator_single_rank(ctx):
     d_s.free(); d_r.free()
 
 
+def test_launch_graph_replays_the_captured_calls(ctx, models, tables):
+    """mp_graph_*: a captured sequence (fp32 ID with a wrench, fp64 FK + Jacobian + ID, roll-out) replays on refreshed
+    inputs with the results of the direct calls; non-capturable calls are refused while a capture is open."""
+    from manipulapy_amd import _hip
+
+    tab, model = tables["ur5"], models["ur5"]
+    n, rows, B, Nt = tab.n, 515, 9, 6
+    rng = np.random.default_rng(3)
+    F = np.array([1.0, -2.0, 0.5, 3.0, -1.5, 0.75])
+
+    def inputs():
+        return [rng.uniform(-1, 1, (rows, n)) for _ in range(3)] + [rng.uniform(-0.3, 0.3, (B, n)), rng.uniform(-0.1, 0.1, (B, n)),
+                                                                    rng.uniform(-1, 1, (B, Nt, n))]
+
+    x = inputs()
+    d32 = [ctx.to_device(a.astype(np.float32)) for a in x[:3]]
+    d64 = [ctx.to_device(a) for a in x[:3]]
+    dfd = [ctx.to_device(a.astype(np.float32)) for a in x[3:]]
+    t32, t64 = ctx.alloc(rows * n * 4), ctx.alloc(rows * n * 8)
+    dT, dJ = ctx.alloc(rows * 16 * 8), ctx.alloc(rows * 6 * n * 8)
+    out = [ctx.alloc(B * Nt * n * 4) for _ in range(3)]
+    with ctx.capture() as cap:
+        ctx.id_trajectory(model, *d32, rows, t32, None, F)
+        ctx.fk_jac_id(model, *d64, rows, dT, dJ, t64)
+        ctx.fd_trajectory(model, dfd[0], dfd[1], dfd[2], None, B, Nt, None, 0.01, 1, *out, dtype=np.float32)
+        with pytest.raises(_hip.HipError, match="captured"):
+            ctx.alloc(64)
+    graph = cap.graph
+    ctx.synchronize()
+    for _ in range(2):  # replay on fresh contents of the same buffers
+        x = inputs()
+        for d, a in zip(d32, x[:3]):
+            d.upload(a.astype(np.float32))
+        for d, a in zip(d64, x[:3]):
+            d.upload(a)
+        for d, a in zip(dfd, x[3:]):
+            d.upload(a.astype(np.float32))
+        graph.launch()
+        ctx.synchronize()
+        np.testing.assert_array_equal(t32.download((rows, n), np.float32),
+                                      ctx.id_trajectory_host(model, *[a.astype(np.float32) for a in x[:3]], None, F))
+        Ts, Js, taus = ctx.fk_jac_id_host(model, *x[:3])
+        np.testing.assert_array_equal(dT.download((rows, 4, 4), np.float64), Ts)
+        np.testing.assert_array_equal(dJ.download((rows, 6, n), np.float64), Js)
+        np.testing.assert_array_equal(t64.download((rows, n), np.float64), taus)
+        want = ctx.fd_trajectory_host(model, *[a.astype(np.float32) for a in x[3:]], None, None, 0.01, 1, dtype=np.float32)
+        for o, w in zip(out, want):
+            np.testing.assert_array_equal(o.download((B, Nt, n), np.float32), w)
+        assert_f32(t32.download((rows, n), np.float32)[::50],
+                   ref.inverse_dynamics_trajectory(tab, x[0][::50], x[1][::50], x[2][::50], None, F, dtype=np.float64))
+    graph.destroy()
+    for b in d32 + d64 + dfd + [t32, t64, dT, dJ] + out:
+        b.free()
+
+
 @pytest.mark.parametrize("seed", [0, 2, 4, 5, 6, 8, 11, 16])
 def test_random_robots_on_gpu(seed, ctx):
     """Randomised chains (tests/test_random_robots.py) through the C ABI: generic fp64 / fp32 and specialised kernels."""
