@@ -164,7 +164,9 @@ def bench_fd(args, cfg, info, hg, ctx, model, t, props):
     traffic_file = os.path.join(ROOT, "profiles", f"traffic_{args.config}.json")
     if os.path.exists(traffic_file):  # measured HBM bytes per launch from the rocprofv3 --pmc passes
         with open(traffic_file) as f:
-            result["roofline"]["traffic"] = json.load(f).get("hbm_bytes_per_launch")
+            tf = json.load(f)
+        if tf.get("kernel") == result["roofline"]["kernel"]:  # counters were collected on this very kernel
+            result["roofline"]["traffic"] = tf.get("hbm_bytes_per_launch")
     if info.rank == 0 and world == 1 and not args.no_cpu_baseline:
         tab = ref.load_tables(os.path.join(ROOT, "tests", "golden", f"model_{cfg['robot']}.npz"))
         r0 = ref.forward_dynamics_trajectory(tab, th0[0].astype(np.float64), dth0[0].astype(np.float64), taumat[0, :12].astype(np.float64),
@@ -400,7 +402,9 @@ def main():
     traffic_file = os.path.join(ROOT, "profiles", f"traffic_{args.config}.json")
     if os.path.exists(traffic_file):  # measured HBM bytes per launch from the rocprofv3 --pmc passes
         with open(traffic_file) as f:
-            result["roofline"]["traffic"] = json.load(f).get("hbm_bytes_per_launch")
+            tf = json.load(f)
+        if tf.get("kernel") == result["roofline"]["kernel"]:  # counters were collected on this very kernel
+            result["roofline"]["traffic"] = tf.get("hbm_bytes_per_launch")
 
     if info.rank == 0 and world == 1 and not args.no_cpu_baseline:
         ns = rows  # the C oracle sizes its own sample from a time budget

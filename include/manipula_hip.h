@@ -68,6 +68,11 @@ int mp_pool_trim(mp_ctx* ctx);                    /* releases pooled buffers bac
 int mp_memcpy_h2d(mp_ctx* ctx, void* d_dst, const void* h_src, size_t bytes); /* synchronous */
 int mp_memcpy_d2h(mp_ctx* ctx, void* h_dst, const void* d_src, size_t bytes); /* synchronous */
 int mp_memset(mp_ctx* ctx, void* d_dst, int value, size_t bytes);
+/* page-locked host buffers (the reference's pinned staging, cuda_kernels/memory.py:12-50, handed to the caller): the
+ * *_host_* entry points below accept any host pointer; on buffers from mp_host_alloc the upload, the kernels and
+ * the download of a large call overlap chunk by chunk (pageable memory is staged by the runtime and serialises). */
+int mp_host_alloc(mp_ctx* ctx, size_t bytes, void** h_ptr);
+int mp_host_free(mp_ctx* ctx, void* h_ptr);
 
 /* ---- timing on the compute stream ------------------------------------------------------------ */
 int mp_event_create(mp_ctx* ctx, mp_event** out);

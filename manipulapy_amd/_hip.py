@@ -59,6 +59,8 @@ SIGNATURES = {
     "mp_event_destroy": (ctypes.c_int, [_vp]),
     "mp_event_record": (ctypes.c_int, [_vp, _vp]),
     "mp_event_elapsed_ms": (ctypes.c_int, [_vp, _vp, ctypes.POINTER(ctypes.c_float)]),
+    "mp_host_alloc": (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.POINTER(_vp)]),
+    "mp_host_free": (ctypes.c_int, [_vp, _vp]),
     "mp_graph_begin": (ctypes.c_int, [_vp]),
     "mp_graph_end": (ctypes.c_int, [_vp, ctypes.POINTER(_vp)]),
     "mp_graph_launch": (ctypes.c_int, [_vp, _vp]),
@@ -235,6 +237,33 @@ class HipEvent:
             self.handle = None
 
 
+class PinnedBuffer:
+    """Page-locked host memory (mp_host_alloc).  ``np.asarray(buf)`` / ``buf.array(shape, dtype)`` give NumPy views that
+    keep the allocation alive; on such arrays the *_host entry points overlap upload, kernels and download."""
+
+    def __init__(self, ctx: "HipContext", nbytes: int):
+        self.ctx, self.nbytes = ctx, int(nbytes)
+        p = _vp()
+        _check(ctx.lib.mp_host_alloc(ctx.handle, ctypes.c_size_t(self.nbytes), ctypes.byref(p)))
+        self.ptr = p.value
+        self.__array_interface__ = {"shape": (self.nbytes,), "typestr": "|u1", "data": (self.ptr, False), "version": 3}
+
+    def array(self, shape, dtype) -> np.ndarray:
+        a = np.asarray(self).view(np.dtype(dtype))
+        n = int(np.prod(shape))
+        if n > a.size:
+            raise ValueError("shape larger than the pinned buffer")
+        return a[:n].reshape(shape)
+
+    def __del__(self):
+        try:
+            if self.ptr and self.ctx.handle is not None:
+                self.ctx.lib.mp_host_free(self.ctx.handle, _vp(self.ptr))
+        except Exception:
+            pass
+        self.ptr = None
+
+
 class HipGraph:
     """A captured sequence of device-pointer launches (mp_graph_*), replayed with one submission."""
 
@@ -397,6 +426,12 @@ class HipContext:
     def event(self) -> HipEvent:
         return HipEvent(self)
 
+    def pinned_empty(self, shape, dtype=np.float32) -> np.ndarray:
+        """Uninitialised page-locked NumPy array (freed with its last view, or with the context)."""
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape))
+        return PinnedBuffer(self, max(1, n) * dtype.itemsize).array(shape, dtype)
+
     def capture(self) -> _Capture:
         """``with ctx.capture() as cap: <device-pointer launches>`` -> ``cap.graph`` (HipGraph)."""
         return _Capture(self)
@@ -452,14 +487,16 @@ class HipContext:
                                                float(influence_distance), _p(d_potential), _p(d_gradient)))
 
     # ---- hot path on host arrays (what the registry's gpu launchers call; synchronous)
-    def id_trajectory_host(self, model: HipModel, q, qd, qdd, g=None, Ftip=None, dtype=np.float32) -> np.ndarray:
+    def id_trajectory_host(self, model: HipModel, q, qd, qdd, g=None, Ftip=None, dtype=np.float32, out=None) -> np.ndarray:
+        """tau (rows, n) for host arrays.  `out`: optional C-contiguous array of q's shape and dtype to write into (a
+        reused or page-locked buffer, see `pinned_empty`); a fresh array is allocated otherwise."""
         dtype = np.dtype(dtype)
         q = _as_c(q, dtype, name="q")
         if q.ndim != 2 or q.shape[1] != model.n:
             raise ValueError(f"q must be (rows, {model.n}), got {q.shape}")
         qd = _as_c(qd, dtype, q.shape, "qd")
         qdd = _as_c(qdd, dtype, q.shape, "qdd")
-        tau = np.empty_like(q)
+        tau = _out_or_new(out, q.shape, dtype)
         g = _vec_or_none(g, 3, "g")
         F = _vec_or_none(Ftip, 6, "Ftip")
         if dtype == np.float32:
@@ -481,13 +518,13 @@ class HipContext:
                                                      float(Tf), int(method), _fptr(out[0]), _fptr(out[1]), _fptr(out[2])))
         return tuple(out)
 
-    def traj_id_fused_host(self, model: HipModel, start, end, Tf, N, method, g=None, Ftip=None) -> np.ndarray:
+    def traj_id_fused_host(self, model: HipModel, start, end, Tf, N, method, g=None, Ftip=None, out=None) -> np.ndarray:
         start = _as_c(start, np.float32, name="thetastart_batch")
         if start.ndim != 2 or start.shape[1] != model.n:
             raise ValueError(f"thetastart_batch must be (B, {model.n}), got {start.shape}")
         end = _as_c(end, np.float32, start.shape, "thetaend_batch")
         B = start.shape[0]
-        tau = np.zeros((B, int(N), model.n), dtype=np.float32)
+        tau = _out_or_new(out, (B, int(N), model.n), np.dtype(np.float32))
         g = _vec_or_none(g, 3, "g")
         F = _vec_or_none(Ftip, 6, "Ftip")
         _check(self.lib.mp_traj_id_fused_host_f32(self.handle, model.handle, _fptr(start), _fptr(end), B, int(N),
@@ -595,6 +632,15 @@ class HipContext:
 
     def comm_create(self, unique_id: bytes, nranks: int, rank: int) -> "HipComm":
         return HipComm(self, unique_id, nranks, rank)
+
+
+def _out_or_new(out, shape, dtype) -> np.ndarray:
+    if out is None:
+        return np.empty(shape, dtype=dtype)
+    if not isinstance(out, np.ndarray) or out.shape != tuple(shape) or out.dtype != dtype or not out.flags.c_contiguous \
+            or not out.flags.writeable:
+        raise ValueError(f"out must be a writeable C-contiguous {np.dtype(dtype).name} array of shape {tuple(shape)}")
+    return out
 
 
 def _p(buf):

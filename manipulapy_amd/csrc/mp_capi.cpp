@@ -27,7 +27,9 @@ struct MpSpec {  // run-time specialised kernels of one model on one device
 struct mp_ctx {
   int device = -1;
   hipStream_t compute = nullptr;
-  hipStream_t copy = nullptr;
+  hipStream_t copy = nullptr;      // host -> device leg of the chunked host-buffer pipeline
+  hipStream_t copy_out = nullptr;  // device -> host leg
+  std::map<void*, size_t> pinned;  // page-locked host buffers handed out by mp_host_alloc
   std::map<size_t, std::vector<void*>> free_by_size;  // pool: exact-size free lists
   std::map<void*, size_t> live;                        // every buffer handed out -> its size
   std::map<uint64_t, void*> dev_models;                // model uid -> float32 model resident on this device
@@ -108,6 +110,38 @@ struct Scratch {
     int rc = mp_malloc(ctx, bytes ? bytes : 16, p);
     if (rc == MP_OK) bufs.push_back(*p);
     return rc;
+  }
+};
+// rows per chunk of the host-buffer pipeline (MANIPULAPY_HIP_HOST_CHUNK_ROWS, default 512 Ki rows, kept even so that
+// only the last chunk can end on an odd row)
+int64_t host_chunk_rows() {
+  static const int64_t rows = [] {
+    const char* e = getenv("MANIPULAPY_HIP_HOST_CHUNK_ROWS");
+    long long v = e ? atoll(e) : 0;
+    if (v <= 0) v = 512 * 1024;
+    return (int64_t)((v + 1) & ~1LL);
+  }();
+  return rows;
+}
+// true when `p` is page-locked host memory the device can DMA directly (mp_host_alloc, hipHostMalloc, hipHostRegister)
+bool is_pinned_host(const void* p) {
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();  // an ordinary pageable pointer is reported as an error: clear it
+    return false;
+  }
+  return a.type == hipMemoryTypeHost;
+}
+
+// events of one pipelined call, destroyed on every exit path
+struct EventList {
+  std::vector<hipEvent_t> evs;
+  ~EventList() { for (hipEvent_t e : evs) (void)hipEventDestroy(e); }
+  int make(hipEvent_t* out) {
+    hipError_t he = hipEventCreateWithFlags(out, hipEventDisableTiming);
+    if (he != hipSuccess) return hip_err(he, "hipEventCreate");
+    evs.push_back(*out);
+    return MP_OK;
   }
 };
 #define H2D(dst, src, bytes) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->compute))
@@ -249,20 +283,62 @@ static int id_host_impl(const char* fn, mp_ctx* ctx, const mp_model* model, cons
   REQUIRE(rows >= 0, "%s: negative row count", fn);
   if (rows == 0) return MP_OK;
   REQUIRE(q && qd && qdd && tau, "%s: null host pointer", fn);
-  const size_t bytes = (size_t)rows * (size_t)model->d.n * sizeof(T);
+  const size_t row_b = (size_t)model->d.n * sizeof(T), bytes = (size_t)rows * row_b;
   Scratch sc(ctx);
   void *dq, *dqd, *dqdd, *dt;
   if (int rc = sc.get(bytes, &dq)) return rc;
   if (int rc = sc.get(bytes, &dqd)) return rc;
   if (int rc = sc.get(bytes, &dqdd)) return rc;
   if (int rc = sc.get(bytes, &dt)) return rc;
-  H2D(dq, q, bytes);
-  H2D(dqd, qd, bytes);
-  H2D(dqdd, qdd, bytes);
-  if (int rc = id_impl<T>(fn, ctx, model, (T*)dq, (T*)dqd, (T*)dqdd, rows, g, Ftip, (T*)dt)) return rc;
-  D2H(tau, dt, bytes);
-  HIP_TRY(hipStreamSynchronize(ctx->compute));
-  return MP_OK;
+  // Chunked three-stage pipeline: upload of chunk k+1 (copy stream), kernel of chunk k (compute stream) and download
+  // of chunk k-1 (copy-out stream) overlap; events order the stages of one chunk.  PCIe is full duplex, so with
+  // page-locked buffers the call costs about the upload alone.
+  // Pageable buffers are staged by the runtime on the calling thread, which serialises the stages anyway (measured:
+  // chunking then costs 8 %), so only page-locked calls are chunked.
+  const int64_t chunk = host_chunk_rows();
+  const bool pinned = is_pinned_host(q) && is_pinned_host(qd) && is_pinned_host(qdd) && is_pinned_host(tau);
+  const int64_t nchunks = pinned ? (rows + chunk - 1) / chunk : 1;
+  if (nchunks < 2) {
+    H2D(dq, q, bytes);
+    H2D(dqd, qd, bytes);
+    H2D(dqdd, qdd, bytes);
+    if (int rc = id_impl<T>(fn, ctx, model, (T*)dq, (T*)dqd, (T*)dqdd, rows, g, Ftip, (T*)dt)) {
+      (void)hipStreamSynchronize(ctx->compute);
+      return rc;
+    }
+    D2H(tau, dt, bytes);
+    HIP_TRY(hipStreamSynchronize(ctx->compute));
+    return MP_OK;
+  }
+  EventList ev;
+  auto pipeline = [&]() -> int {
+    for (int64_t k = 0; k < nchunks; ++k) {
+      const int64_t r0 = k * chunk, nr = std::min(chunk, rows - r0);
+      const size_t off = (size_t)r0 * row_b, nb = (size_t)nr * row_b;
+      hipEvent_t up = nullptr, done = nullptr;
+      if (int rc = ev.make(&up)) return rc;
+      if (int rc = ev.make(&done)) return rc;
+      HIP_TRY(hipMemcpyAsync((char*)dq + off, (const char*)q + off, nb, hipMemcpyHostToDevice, ctx->copy));
+      HIP_TRY(hipMemcpyAsync((char*)dqd + off, (const char*)qd + off, nb, hipMemcpyHostToDevice, ctx->copy));
+      HIP_TRY(hipMemcpyAsync((char*)dqdd + off, (const char*)qdd + off, nb, hipMemcpyHostToDevice, ctx->copy));
+      HIP_TRY(hipEventRecord(up, ctx->copy));
+      HIP_TRY(hipStreamWaitEvent(ctx->compute, up, 0));
+      if (int rc = id_impl<T>(fn, ctx, model, (T*)((char*)dq + off), (T*)((char*)dqd + off), (T*)((char*)dqdd + off), nr, g, Ftip,
+                              (T*)((char*)dt + off)))
+        return rc;
+      HIP_TRY(hipEventRecord(done, ctx->compute));
+      HIP_TRY(hipStreamWaitEvent(ctx->copy_out, done, 0));
+      HIP_TRY(hipMemcpyAsync((char*)tau + off, (const char*)dt + off, nb, hipMemcpyDeviceToHost, ctx->copy_out));
+    }
+    return MP_OK;
+  };
+  const int rc = pipeline();
+  // drain every stage before the scratch buffers return to the pool, also on the error path
+  (void)hipStreamSynchronize(ctx->copy);
+  (void)hipStreamSynchronize(ctx->compute);
+  hipError_t he = hipStreamSynchronize(ctx->copy_out);
+  if (rc == MP_OK && he != hipSuccess) return hip_err(he, "hipStreamSynchronize");
+  return rc;
 }
 
 template <typename T>
@@ -393,6 +469,7 @@ int mp_ctx_create(int device_id, mp_ctx** out) {
   }
   hipError_t e = hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy_out, hipStreamNonBlocking);
   if (e != hipSuccess) { delete c; return hip_err(e, "hipStreamCreate"); }
   *out = c;
   return MP_OK;
@@ -404,8 +481,10 @@ int mp_ctx_destroy(mp_ctx* ctx) {
   (void)hipDeviceSynchronize();
   for (auto& kv : ctx->specs) if (kv.second.mod) (void)hipModuleUnload(kv.second.mod);
   for (auto& kv : ctx->live) (void)hipFree(kv.first);
+  for (auto& kv : ctx->pinned) (void)hipHostFree(kv.first);
   if (ctx->compute) (void)hipStreamDestroy(ctx->compute);
   if (ctx->copy) (void)hipStreamDestroy(ctx->copy);
+  if (ctx->copy_out) (void)hipStreamDestroy(ctx->copy_out);
   delete ctx;
   return MP_OK;
 }
@@ -415,6 +494,7 @@ int mp_ctx_synchronize(mp_ctx* ctx) {
   if (int rc = bind(ctx)) return rc;
   HIP_TRY(hipStreamSynchronize(ctx->compute));
   HIP_TRY(hipStreamSynchronize(ctx->copy));
+  HIP_TRY(hipStreamSynchronize(ctx->copy_out));
   return MP_OK;
 }
 
@@ -491,6 +571,29 @@ int mp_pool_trim(mp_ctx* ctx) {
       ctx->live.erase(p);
     }
   ctx->free_by_size.clear();
+  return MP_OK;
+}
+
+// page-locked host memory: DMA reads / writes it directly, so the host-buffer entry points overlap upload, kernel
+// and download on such buffers (pageable buffers are staged by the runtime and serialise)
+int mp_host_alloc(mp_ctx* ctx, size_t bytes, void** h_ptr) {
+  REQUIRE(ctx && h_ptr, "mp_host_alloc: null argument");
+  *h_ptr = nullptr;
+  if (int rc = bind(ctx)) return rc;
+  void* p = nullptr;
+  HIP_TRY(hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault));
+  ctx->pinned[p] = bytes;
+  *h_ptr = p;
+  return MP_OK;
+}
+int mp_host_free(mp_ctx* ctx, void* h_ptr) {
+  REQUIRE(ctx, "mp_host_free: null context");
+  if (!h_ptr) return MP_OK;
+  auto it = ctx->pinned.find(h_ptr);
+  REQUIRE(it != ctx->pinned.end(), "mp_host_free: pointer %p was not allocated by mp_host_alloc on this context", h_ptr);
+  if (int rc = bind(ctx)) return rc;
+  HIP_TRY(hipHostFree(h_ptr));
+  ctx->pinned.erase(it);
   return MP_OK;
 }
 

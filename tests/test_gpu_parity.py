@@ -8,6 +8,8 @@ Tolerances (BASELINE.json north_star: 1e-6 rel fp64 / 1e-4 rel fp32 against the 
   fp32:  |d| <= 1e-4 * |ref| + 1e-4 * max|ref row|  — elementwise relative, with a floor tied to the
          row's own scale for near-zero components (float32 cancellation cannot be relative to ~0).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -15,6 +17,7 @@ from conftest import ROBOTS, golden_path
 from oracle import ref_numpy as ref
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 F64_RTOL, F64_ATOL = 1e-6, 1e-7
 F32_RTOL, F32_ROW = 1e-4, 1e-4
@@ -519,6 +522,53 @@ def test_rccl_communicator_single_rank(ctx):
     with pytest.raises(ValueError):
         ctx.comm_create(b"short", 1, 0)
     d_s.free(); d_r.free()
+
+
+def test_host_paths_pinned_pipelined_and_prefaulted(models, tables):
+    """The host-buffer ID entry point gives bit-identical results whether the arrays are pageable (single shot),
+    page-locked (chunked upload / kernel / download pipeline; chunk size forced small in the first pass so that several
+    chunks and an odd tail are exercised) or written into a caller-supplied `out`."""
+    import subprocess, sys, textwrap
+
+    code = textwrap.dedent("""
+        import numpy as np, sys
+        sys.path.insert(0, %r)
+        import manipulapy_amd as mp
+        from manipulapy_amd import _hip
+        ctx = _hip.HipContext(0)
+        sm, dyn, lim = mp.load_robot("ur5")
+        model = _hip.HipModel(dyn.S_list, dyn.Mlist_per_link, dyn.Glist, sm.M_list, lim)
+        rng = np.random.default_rng(9)
+        rows, n = 700001, 6          # odd -> one-row tail kernel in the last chunk
+        q, qd, qdd = (rng.uniform(-1, 1, (rows, n)).astype(np.float32) for _ in range(3))
+        want = ctx.id_trajectory_host(model, q, qd, qdd)
+        out = np.full((rows, n), np.nan, np.float32)
+        assert ctx.id_trajectory_host(model, q, qd, qdd, out=out) is out
+        np.testing.assert_array_equal(out, want)
+        pq, pqd, pqdd, pt = (ctx.pinned_empty((rows, n), np.float32) for _ in range(4))
+        pq[:], pqd[:], pqdd[:] = q, qd, qdd
+        pt[:] = np.nan
+        ctx.id_trajectory_host(model, pq, pqd, pqdd, out=pt)
+        np.testing.assert_array_equal(pt, want)
+        for bad in (np.empty((rows, n), np.float64), np.empty((rows - 1, n), np.float32), np.empty((n, rows), np.float32).T):
+            try:
+                ctx.id_trajectory_host(model, q, qd, qdd, out=bad)
+            except ValueError:
+                pass
+            else:
+                raise AssertionError("bad out accepted")
+        fused = ctx.traj_id_fused_host(model, q[:300], qd[:300], 2.0, 1201, 5)
+        pf = ctx.pinned_empty(fused.shape, np.float32)
+        ctx.traj_id_fused_host(model, q[:300], qd[:300], 2.0, 1201, 5, out=pf)
+        np.testing.assert_array_equal(pf, fused)
+        del pq, pqd, pqdd, pt, pf
+        ctx.destroy()
+        print("OK")
+    """ % ROOT)
+    for env_extra in ({"MANIPULAPY_HIP_HOST_CHUNK_ROWS": "100001"}, {}):
+        env = dict(os.environ, **env_extra)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_launch_graph_replays_the_captured_calls(ctx, models, tables):

@@ -84,6 +84,31 @@ def main():
     ms = timed(ctx, lambda: ctx.potential_field(pos, [0.5, 0.5, 0.5], obs, P, O, 0.8, pot, grad))
     out.append(dict(op="potential_field", dtype="float32", rows=P, obstacles=O, ms=ms, rows_per_s=P / ms * 1e3,
                     alg_GBps=P * 28 / ms / 1e6, pair_per_s=P * O / ms * 1e3))
+    # host-buffer entry points (PCIe inclusive): what a drop-in caller holding NumPy arrays sees
+    sm, dyn, lim = mp.load_robot("ur5")
+    model = _hip.HipModel(dyn.S_list, dyn.Mlist_per_link, dyn.Glist, sm.M_list, lim)
+    ctx.specialize(model)
+    B, N, n = 4096, 1000, 6
+    q, qd, qdd = (rng.uniform(-1, 1, (B * N, n)).astype(np.float32) for _ in range(3))
+    st, en = (rng.uniform(-1, 1, (B, n)).astype(np.float32) for _ in range(2))
+    import time
+    pq, pqd, pqdd, ptau = (ctx.pinned_empty((B * N, n), np.float32) for _ in range(4))
+    pq[:], pqd[:], pqdd[:] = q, qd, qdd
+    ptau3 = ctx.pinned_empty((B, N, n), np.float32)
+    reuse = np.empty((B * N, n), np.float32)
+    for name, fn, by in (("id_trajectory_host (pageable in, fresh out)", lambda: ctx.id_trajectory_host(model, q, qd, qdd), 16 * B * N * n),
+                         ("id_trajectory_host (pageable in, reused out)", lambda: ctx.id_trajectory_host(model, q, qd, qdd, out=reuse), 16 * B * N * n),
+                         ("id_trajectory_host (pinned in/out)", lambda: ctx.id_trajectory_host(model, pq, pqd, pqdd, out=ptau), 16 * B * N * n),
+                         ("traj_id_fused_host (fresh out)", lambda: ctx.traj_id_fused_host(model, st, en, 2.0, N, 5), 4 * B * N * n),
+                         ("traj_id_fused_host (pinned out)", lambda: ctx.traj_id_fused_host(model, st, en, 2.0, N, 5, out=ptau3), 4 * B * N * n)):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            fn()
+        ms = (time.perf_counter() - t0) / 5 * 1e3
+        out.append(dict(op=name, robot="ur5", dtype="float32", rows=B * N, ms=ms, rows_per_s=B * N / ms * 1e3,
+                        jt_per_s=B * N * n / ms * 1e3, pcie_GBps=by / ms / 1e6))
+    np.testing.assert_array_equal(ptau, reuse)
     for r in out:
         print(json.dumps(r))
     ctx.destroy()
