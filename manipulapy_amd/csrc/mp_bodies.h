@@ -313,45 +313,45 @@ constexpr int MP_FD_KS = 4;
 // position once the step has consumed it; [N,2N) velocity; [2N,3N) acceleration; the step's wrench (6 values, if
 // any) sits in [N,N+6) and is likewise consumed before the step's velocity / acceleration are written.
 // float64 inputs take two dwords per value and get their own columns after the three output slots.
-template <typename T, int N, bool HAS_FTIP>
+template <typename T, int N, bool HAS_FTIP, int W = 64>
 struct MpFdTile {
   static constexpr int TW = (int)sizeof(T) / 4;  // dwords per input value
   static constexpr int TAU0 = (TW == 1) ? 0 : 3 * N;
   static constexpr int F0 = (TW == 1) ? N : 5 * N;
   static constexpr int COLS32 = (HAS_FTIP && N + 6 > 3 * N) ? N + 6 : 3 * N;
   static constexpr int COLS = (TW == 1) ? COLS32 : 5 * N + (HAS_FTIP ? 12 : 0);
-  static constexpr int STEP = COLS * 64;           // dwords per step
+  static constexpr int STEP = COLS * W;            // dwords per step (W = trajectories per wave: 64, or 128 packed)
   static constexpr int DWORDS = MP_FD_KS * STEP;   // per wave
 };
 typedef unsigned mp_io_u4 __attribute__((ext_vector_type(4)));
 
 // dword `d` of a lane's contiguous input run (rows of E values of TW dwords) -> tile dword index, lane offset excluded
-template <int E, int TW, int BASE, int STEP>
+template <int E, int TW, int BASE, int STEP, int W>
 __device__ __forceinline__ constexpr int mp_fd_in_slot(int d) {
   const int s = d / (E * TW), rem = d % (E * TW), e = rem / TW, w = rem % TW;
-  return s * STEP + (BASE + w * E + e) * 64;
+  return s * STEP + (BASE + w * E + e) * W;
 }
 
-// global -> tile: MP_FD_KS rows (or `limit` dwords of them when VW == 1) of one lane's run
-template <int E, int TW, int BASE, int STEP, int VW>
+// global -> tile: MP_FD_KS rows (or `limit` dwords of them when VW == 1) of one trajectory's run
+template <int E, int TW, int BASE, int STEP, int W, int VW>
 __device__ __forceinline__ void mp_fd_tile_in(const unsigned* __restrict__ g, int limit, unsigned* __restrict__ col) {
   constexpr int TOTAL = MP_FD_KS * E * TW;
 #pragma unroll
   for (int d = 0; d < TOTAL; d += VW) {
     if constexpr (VW == 4) {
       const mp_io_u4 v = *reinterpret_cast<const mp_io_u4*>(g + d);
-      col[mp_fd_in_slot<E, TW, BASE, STEP>(d)] = v.x;
-      col[mp_fd_in_slot<E, TW, BASE, STEP>(d + 1)] = v.y;
-      col[mp_fd_in_slot<E, TW, BASE, STEP>(d + 2)] = v.z;
-      col[mp_fd_in_slot<E, TW, BASE, STEP>(d + 3)] = v.w;
+      col[mp_fd_in_slot<E, TW, BASE, STEP, W>(d)] = v.x;
+      col[mp_fd_in_slot<E, TW, BASE, STEP, W>(d + 1)] = v.y;
+      col[mp_fd_in_slot<E, TW, BASE, STEP, W>(d + 2)] = v.z;
+      col[mp_fd_in_slot<E, TW, BASE, STEP, W>(d + 3)] = v.w;
     } else if (d < limit) {
-      col[mp_fd_in_slot<E, TW, BASE, STEP>(d)] = g[d];
+      col[mp_fd_in_slot<E, TW, BASE, STEP, W>(d)] = g[d];
     }
   }
 }
 
 // tile -> global: output slot `slot` (0 pos, 1 vel, 2 acc) of MP_FD_KS rows (or `limit` dwords when VW == 1)
-template <int N, int STEP, int VW>
+template <int N, int STEP, int W, int VW>
 __device__ __forceinline__ void mp_fd_tile_out(float* __restrict__ gdst, int slot, int limit, const unsigned* __restrict__ col) {
   constexpr int TOTAL = MP_FD_KS * N;
   unsigned* g = reinterpret_cast<unsigned*>(gdst);
@@ -359,23 +359,23 @@ __device__ __forceinline__ void mp_fd_tile_out(float* __restrict__ gdst, int slo
   for (int d = 0; d < TOTAL; d += VW) {
     if constexpr (VW == 4) {
       mp_io_u4 v;
-      v.x = col[((d) / N) * STEP + (slot * N + (d) % N) * 64];
-      v.y = col[((d + 1) / N) * STEP + (slot * N + (d + 1) % N) * 64];
-      v.z = col[((d + 2) / N) * STEP + (slot * N + (d + 2) % N) * 64];
-      v.w = col[((d + 3) / N) * STEP + (slot * N + (d + 3) % N) * 64];
+      v.x = col[((d) / N) * STEP + (slot * N + (d) % N) * W];
+      v.y = col[((d + 1) / N) * STEP + (slot * N + (d + 1) % N) * W];
+      v.z = col[((d + 2) / N) * STEP + (slot * N + (d + 2) % N) * W];
+      v.w = col[((d + 3) / N) * STEP + (slot * N + (d + 3) % N) * W];
       *reinterpret_cast<mp_io_u4*>(g + d) = v;
     } else if (d < limit) {
-      g[d] = col[(d / N) * STEP + (slot * N + d % N) * 64];
+      g[d] = col[(d / N) * STEP + (slot * N + d % N) * W];
     }
   }
 }
 
-template <typename T, int TW>
+template <typename T, int TW, int W>
 __device__ __forceinline__ T mp_fd_tile_get(const unsigned* __restrict__ cs, int c, int E) {
   if constexpr (TW == 1) {
-    return (T)__builtin_bit_cast(float, cs[c * 64]);
+    return (T)__builtin_bit_cast(float, cs[c * W]);
   } else {
-    const unsigned long long u = (unsigned long long)cs[c * 64] | ((unsigned long long)cs[(c + E) * 64] << 32);
+    const unsigned long long u = (unsigned long long)cs[c * W] | ((unsigned long long)cs[(c + E) * W] << 32);
     return (T)__builtin_bit_cast(double, u);
   }
 }
@@ -403,13 +403,13 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
     const long row0 = b * Nt + i0;
     {
       const unsigned* g = reinterpret_cast<const unsigned*>(taumat + row0 * N);
-      if (full && vec_tau) mp_fd_tile_in<N, TW, TL::TAU0, STEP, 4>(g, 0, col);
-      else mp_fd_tile_in<N, TW, TL::TAU0, STEP, 1>(g, rows * N * TW, col);
+      if (full && vec_tau) mp_fd_tile_in<N, TW, TL::TAU0, STEP, 64, 4>(g, 0, col);
+      else mp_fd_tile_in<N, TW, TL::TAU0, STEP, 64, 1>(g, rows * N * TW, col);
     }
     if (HAS_FTIP) {
       const unsigned* g = reinterpret_cast<const unsigned*>(Ftipmat + row0 * 6);
-      if (full && vec_f) mp_fd_tile_in<6, TW, TL::F0, STEP, 4>(g, 0, col);
-      else mp_fd_tile_in<6, TW, TL::F0, STEP, 1>(g, rows * 6 * TW, col);
+      if (full && vec_f) mp_fd_tile_in<6, TW, TL::F0, STEP, 64, 4>(g, 0, col);
+      else mp_fd_tile_in<6, TW, TL::F0, STEP, 64, 1>(g, rows * 6 * TW, col);
     }
     for (int s = 0; s < rows; ++s) {
       unsigned* cs = col + s * STEP;
@@ -419,11 +419,11 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
       if (i0 + s > 0) {
         T tau[N], tn[3] = {T(0), T(0), T(0)}, tf[3] = {T(0), T(0), T(0)};
 #pragma unroll
-        for (int j = 0; j < N; ++j) tau[j] = mp_fd_tile_get<T, TW>(cs, TL::TAU0 + j, N);
+        for (int j = 0; j < N; ++j) tau[j] = mp_fd_tile_get<T, TW, 64>(cs, TL::TAU0 + j, N);
         if (HAS_FTIP) {
           T F[6];
 #pragma unroll
-          for (int k = 0; k < 6; ++k) F[k] = mp_fd_tile_get<T, TW>(cs, TL::F0 + k, 6);
+          for (int k = 0; k < 6; ++k) F[k] = mp_fd_tile_get<T, TW, 64>(cs, TL::F0 + k, 6);
           mp_wrench_to_frame1(M, F, tn, tf);
         }
         for (int k = 0; k < intRes; ++k) {
@@ -443,13 +443,133 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
       }
     }
     if (full && vec_out) {
-      mp_fd_tile_out<N, STEP, 4>(pos + row0 * N, 0, 0, col);
-      mp_fd_tile_out<N, STEP, 4>(vel + row0 * N, 1, 0, col);
-      mp_fd_tile_out<N, STEP, 4>(acc + row0 * N, 2, 0, col);
+      mp_fd_tile_out<N, STEP, 64, 4>(pos + row0 * N, 0, 0, col);
+      mp_fd_tile_out<N, STEP, 64, 4>(vel + row0 * N, 1, 0, col);
+      mp_fd_tile_out<N, STEP, 64, 4>(acc + row0 * N, 2, 0, col);
     } else {
-      mp_fd_tile_out<N, STEP, 1>(pos + row0 * N, 0, rows * N, col);
-      mp_fd_tile_out<N, STEP, 1>(vel + row0 * N, 1, rows * N, col);
-      mp_fd_tile_out<N, STEP, 1>(acc + row0 * N, 2, rows * N, col);
+      mp_fd_tile_out<N, STEP, 64, 1>(pos + row0 * N, 0, rows * N, col);
+      mp_fd_tile_out<N, STEP, 64, 1>(vel + row0 * N, 1, rows * N, col);
+      mp_fd_tile_out<N, STEP, 64, 1>(acc + row0 * N, 2, rows * N, col);
+    }
+  }
+}
+
+// float32, TWO trajectories per lane (packed v_pk_* math): lane `p` integrates trajectories 2p and 2p+1.  Same tile
+// as above with 128 columns per wave (column = lane + 64 * half); B odd: the last lane's second half recomputes its
+// first trajectory and stores nothing.
+template <int N, bool HAS_FTIP, typename MT>
+__device__ __forceinline__ void mp_body_fd_traj_pk(const MT& M, const MpCall<float>& C, const float* __restrict__ theta0,
+                                                   const float* __restrict__ dtheta0, const float* __restrict__ taumat,
+                                                   const float* __restrict__ Ftipmat, long p, long B, long Nt, float h,
+                                                   int intRes, float* __restrict__ pos, float* __restrict__ vel,
+                                                   float* __restrict__ acc, unsigned* __restrict__ lds, int lane) {
+  using TL = MpFdTile<float, N, HAS_FTIP, 128>;
+  constexpr int STEP = TL::STEP, W = 128;
+  const long b0 = 2 * p, b1v = 2 * p + 1;
+  const bool two = b1v < B;
+  const long b1 = two ? b1v : b0;
+  unsigned* col0 = lds + lane;
+  unsigned* col1 = col0 + 64;
+  mp_f2 q[N], qd[N];
+  {
+    float a[N], b[N];
+    RunIO<float, N>::load(theta0, b0, a);
+    RunIO<float, N>::load(theta0, b1, b);
+#pragma unroll
+    for (int j = 0; j < N; ++j) q[j] = (mp_f2){a[j], b[j]};
+    RunIO<float, N>::load(dtheta0, b0, a);
+    RunIO<float, N>::load(dtheta0, b1, b);
+#pragma unroll
+    for (int j = 0; j < N; ++j) qd[j] = (mp_f2){a[j], b[j]};
+  }
+  const bool vec_tau = ((Nt * N * 4) & 15) == 0, vec_f = ((Nt * 6 * 4) & 15) == 0;
+  const mp_f2 hh = (mp_f2){h, h};
+  for (long i0 = 0; i0 < Nt; i0 += MP_FD_KS) {
+    const long left = Nt - i0;
+    const int rows = left < MP_FD_KS ? (int)left : MP_FD_KS;
+    const bool full = rows == MP_FD_KS;
+    const long r0 = b0 * Nt + i0, r1 = b1 * Nt + i0;
+    {
+      const unsigned* g0 = reinterpret_cast<const unsigned*>(taumat + r0 * N);
+      const unsigned* g1 = reinterpret_cast<const unsigned*>(taumat + r1 * N);
+      if (full && vec_tau) {
+        mp_fd_tile_in<N, 1, TL::TAU0, STEP, W, 4>(g0, 0, col0);
+        mp_fd_tile_in<N, 1, TL::TAU0, STEP, W, 4>(g1, 0, col1);
+      } else {
+        mp_fd_tile_in<N, 1, TL::TAU0, STEP, W, 1>(g0, rows * N, col0);
+        mp_fd_tile_in<N, 1, TL::TAU0, STEP, W, 1>(g1, rows * N, col1);
+      }
+    }
+    if (HAS_FTIP) {
+      const unsigned* g0 = reinterpret_cast<const unsigned*>(Ftipmat + r0 * 6);
+      const unsigned* g1 = reinterpret_cast<const unsigned*>(Ftipmat + r1 * 6);
+      if (full && vec_f) {
+        mp_fd_tile_in<6, 1, TL::F0, STEP, W, 4>(g0, 0, col0);
+        mp_fd_tile_in<6, 1, TL::F0, STEP, W, 4>(g1, 0, col1);
+      } else {
+        mp_fd_tile_in<6, 1, TL::F0, STEP, W, 1>(g0, rows * 6, col0);
+        mp_fd_tile_in<6, 1, TL::F0, STEP, W, 1>(g1, rows * 6, col1);
+      }
+    }
+    for (int s = 0; s < rows; ++s) {
+      unsigned* c0 = col0 + s * STEP;
+      unsigned* c1 = col1 + s * STEP;
+      mp_f2 last[N];
+#pragma unroll
+      for (int j = 0; j < N; ++j) last[j] = (mp_f2){0.f, 0.f};
+      if (i0 + s > 0) {
+        mp_f2 tau[N], tn[3], tf[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { tn[k] = (mp_f2){0.f, 0.f}; tf[k] = (mp_f2){0.f, 0.f}; }
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+          tau[j] = (mp_f2){__builtin_bit_cast(float, c0[(TL::TAU0 + j) * W]), __builtin_bit_cast(float, c1[(TL::TAU0 + j) * W])};
+        if (HAS_FTIP) {
+          mp_f2 F[6];
+#pragma unroll
+          for (int k = 0; k < 6; ++k)
+            F[k] = (mp_f2){__builtin_bit_cast(float, c0[(TL::F0 + k) * W]), __builtin_bit_cast(float, c1[(TL::F0 + k) * W])};
+          mp_wrench_to_frame1(M, F, tn, tf);
+        }
+        for (int k = 0; k < intRes; ++k) {
+          mp_forward_dynamics<mp_f2, N, HAS_FTIP>(M, C.a0, tn, tf, q, qd, tau, last);
+#pragma unroll
+          for (int j = 0; j < N; ++j) {
+            qd[j] = qd[j] + last[j] * hh;
+            q[j] = mp_clip(q[j] + qd[j] * hh, M.qmin[j], M.qmax[j]);
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        // element copies first: __builtin_bit_cast applied directly to a vector-element lvalue (v.y) reads element 0
+        const float qx = q[j].x, qy = q[j].y, vx = qd[j].x, vy = qd[j].y, ax = last[j].x, ay = last[j].y;
+        c0[j * W] = __builtin_bit_cast(unsigned, qx);
+        c1[j * W] = __builtin_bit_cast(unsigned, qy);
+        c0[(N + j) * W] = __builtin_bit_cast(unsigned, vx);
+        c1[(N + j) * W] = __builtin_bit_cast(unsigned, vy);
+        c0[(2 * N + j) * W] = __builtin_bit_cast(unsigned, ax);
+        c1[(2 * N + j) * W] = __builtin_bit_cast(unsigned, ay);
+      }
+    }
+    if (full && vec_tau) {
+      mp_fd_tile_out<N, STEP, W, 4>(pos + r0 * N, 0, 0, col0);
+      mp_fd_tile_out<N, STEP, W, 4>(vel + r0 * N, 1, 0, col0);
+      mp_fd_tile_out<N, STEP, W, 4>(acc + r0 * N, 2, 0, col0);
+      if (two) {
+        mp_fd_tile_out<N, STEP, W, 4>(pos + r1 * N, 0, 0, col1);
+        mp_fd_tile_out<N, STEP, W, 4>(vel + r1 * N, 1, 0, col1);
+        mp_fd_tile_out<N, STEP, W, 4>(acc + r1 * N, 2, 0, col1);
+      }
+    } else {
+      mp_fd_tile_out<N, STEP, W, 1>(pos + r0 * N, 0, rows * N, col0);
+      mp_fd_tile_out<N, STEP, W, 1>(vel + r0 * N, 1, rows * N, col0);
+      mp_fd_tile_out<N, STEP, W, 1>(acc + r0 * N, 2, rows * N, col0);
+      if (two) {
+        mp_fd_tile_out<N, STEP, W, 1>(pos + r1 * N, 0, rows * N, col1);
+        mp_fd_tile_out<N, STEP, W, 1>(vel + r1 * N, 1, rows * N, col1);
+        mp_fd_tile_out<N, STEP, W, 1>(acc + r1 * N, 2, rows * N, col1);
+      }
     }
   }
 }

@@ -22,7 +22,7 @@
 struct MpSpec {  // run-time specialised kernels of one model on one device
   hipModule_t mod = nullptr;
   hipFunction_t id_pk[2] = {nullptr, nullptr}, traj_id_pk[2] = {nullptr, nullptr}, fd_traj[2] = {nullptr, nullptr};
-  hipFunction_t id_d[2] = {nullptr, nullptr}, fk_jac_id_d[2] = {nullptr, nullptr};
+  hipFunction_t id_d[2] = {nullptr, nullptr}, fk_jac_id_d[2] = {nullptr, nullptr}, fd_traj_pk[2] = {nullptr, nullptr};
 };
 struct mp_ctx {
   int device = -1;
@@ -375,6 +375,7 @@ int launch_fd_spec(mp_ctx* ctx, const mp_model* model, const MpCall<float>& c, c
   if (!sp) return -1;
   MpCall<float> cc = c;
   void* args[] = {&cc, &th0, &dth0, &taumat, &Fm, &B, &Nt, &h, &intRes, &pos, &vel, &acc};
+  if (mpk_fd_packed()) return launch_spec(ctx, sp->fd_traj_pk[Fm ? 1 : 0], (B + 1) / 2, args, 64);  // two trajectories per lane
   return launch_spec(ctx, sp->fd_traj[Fm ? 1 : 0], B, args, 64);  // one wave per block (per-wave LDS tile)
 }
 int launch_fd_spec(mp_ctx*, const mp_model*, const MpCall<double>&, const double*, const double*, const double*, const double*,
@@ -768,11 +769,11 @@ int mp_model_specialize(mp_ctx* ctx, const mp_model* model) {
   if (mp_jit_compile(model->f, model->d, &code, nullptr, &err)) return set_err(MP_ERR_UNSUPPORTED, "mp_model_specialize: %s", err.c_str());
   MpSpec sp;
   HIP_TRY(hipModuleLoadData(&sp.mod, code.data()));
-  const char* names[5][2] = {{"mp_spec_id_pk_f0", "mp_spec_id_pk_f1"}, {"mp_spec_traj_id_pk_f0", "mp_spec_traj_id_pk_f1"},
+  const char* names[6][2] = {{"mp_spec_id_pk_f0", "mp_spec_id_pk_f1"}, {"mp_spec_traj_id_pk_f0", "mp_spec_traj_id_pk_f1"},
                              {"mp_spec_fd_traj_f0", "mp_spec_fd_traj_f1"}, {"mp_spec_id_d_f0", "mp_spec_id_d_f1"},
-                             {"mp_spec_fk_jac_id_d_f0", "mp_spec_fk_jac_id_d_f1"}};
-  hipFunction_t* slots[5] = {sp.id_pk, sp.traj_id_pk, sp.fd_traj, sp.id_d, sp.fk_jac_id_d};
-  for (int k = 0; k < 5; ++k)
+                             {"mp_spec_fk_jac_id_d_f0", "mp_spec_fk_jac_id_d_f1"}, {"mp_spec_fd_traj_pk_f0", "mp_spec_fd_traj_pk_f1"}};
+  hipFunction_t* slots[6] = {sp.id_pk, sp.traj_id_pk, sp.fd_traj, sp.id_d, sp.fk_jac_id_d, sp.fd_traj_pk};
+  for (int k = 0; k < 6; ++k)
     for (int f = 0; f < 2; ++f) {
       hipError_t e = hipModuleGetFunction(&slots[k][f], sp.mod, names[k][f]);
       if (e != hipSuccess) { (void)hipModuleUnload(sp.mod); return hip_err(e, names[k][f]); }

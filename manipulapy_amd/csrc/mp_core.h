@@ -118,6 +118,9 @@ MP_HD mp_f2 mp_max(mp_f2 a, mp_f2 b) { return (a > b) ? a : b; }
 #endif
 MP_HD float mp_sqrt(float x) { return sqrtf(x); }
 MP_HD double mp_sqrt(double x) { return sqrt(x); }
+#if MP_HAS_PACKED
+MP_HD mp_f2 mp_sqrt(mp_f2 x) { return (mp_f2){sqrtf(x.x), sqrtf(x.y)}; }
+#endif
 // np.clip order: max with the lower bound first, then min with the upper bound
 template <typename T>
 MP_HD T mp_clip(T v, typename MpTraits<T>::S lo, typename MpTraits<T>::S hi) {
@@ -421,7 +424,7 @@ MP_HD void mp_spd_solve(T (&A)[N][N], T (&b)[N]) {
     T d = A[j][j];
 #pragma unroll
     for (int k = 0; k < j; ++k) d -= A[j][k] * A[j][k];
-    const T inv = T(1) / mp_sqrt(d);
+    const T inv = MpTraits<T>::splat(typename MpTraits<T>::S(1)) / mp_sqrt(d);
     A[j][j] = inv;  // store 1 / L_jj
 #pragma unroll
     for (int i = j + 1; i < N; ++i) {

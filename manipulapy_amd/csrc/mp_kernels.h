@@ -31,6 +31,7 @@ template <typename T>
 hipError_t mpk_forward_dynamics(hipStream_t s, const MpModel<T>& M, const MpCall<T>& C, bool ftip, const T* q, const T* qd,
                                 const T* tau, T* qdd, long rows);
 // Ftipmat == nullptr: no tip wrench.  h = dt / intRes.  Outputs are float32 (B, Nt, n).
+bool mpk_fd_packed();  // MANIPULAPY_HIP_FD=packed: float32 roll-outs with two trajectories per lane (measured slower; off by default)
 template <typename T>
 hipError_t mpk_fd_traj(hipStream_t s, const MpModel<T>& M, const MpCall<T>& C, const T* theta0, const T* dtheta0,
                        const T* taumat, const T* Ftipmat, long B, long Nt, T h, int intRes, float* pos, float* vel, float* acc);

@@ -205,6 +205,20 @@ __global__ __launch_bounds__(kFdBlock, (sizeof(T) == 4 ? 2 : 1)) void k_fd_traj(
   mp_body_fd_traj<T, N, HAS_FTIP>(M, C, theta0, dtheta0, taumat, Ftipmat, b, Nt, h, intRes, pos, vel, acc, lds, (int)threadIdx.x);
 }
 
+// float32, two trajectories per lane (packed math); the tile is twice as wide, so DOF 8 with wrenches is 60 KB
+template <int N, bool HAS_FTIP>
+__global__ __launch_bounds__(kFdBlock) void k_fd_traj_pk(const MpModel<float> M, const MpCall<float> C,
+                                                         const float* __restrict__ theta0, const float* __restrict__ dtheta0,
+                                                         const float* __restrict__ taumat, const float* __restrict__ Ftipmat,
+                                                         long B, long Nt, float h, int intRes, float* __restrict__ pos,
+                                                         float* __restrict__ vel, float* __restrict__ acc) {
+  __shared__ unsigned lds[MpFdTile<float, N, HAS_FTIP, 128>::DWORDS];
+  const long p = (long)blockIdx.x * kFdBlock + threadIdx.x;
+  if (2 * p >= B) return;
+  mp_body_fd_traj_pk<N, HAS_FTIP>(M, C, theta0, dtheta0, taumat, Ftipmat, p, B, Nt, h, intRes, pos, vel, acc, lds,
+                                  (int)threadIdx.x);
+}
+
 // ------------------------------------------------------------------- Cartesian straight-line path
 // one lane per (pose pair b, timestep i); outputs float32 (B,N,3) x3 and (B,N,3,3)
 __global__ __launch_bounds__(kBlock) void k_cartesian_traj(const double* __restrict__ Xstart, const double* __restrict__ Xend,
@@ -402,10 +416,39 @@ template hipError_t mpk_forward_dynamics<float>(hipStream_t, const MpModel<float
 template hipError_t mpk_forward_dynamics<double>(hipStream_t, const MpModel<double>&, const MpCall<double>&, bool,
                                                  const double*, const double*, const double*, double*, long);
 
+// roll-out variant for float32 (A/B switch): MANIPULAPY_HIP_FD = "scalar" (default: one trajectory per lane) | "packed"
+// (two per lane, v_pk_* math).  Measured on c5 and at B = 1 M: packed is 8-10 % SLOWER - it needs > 128 VGPRs, so one
+// wave per SIMD is resident and nothing hides the dependent-issue stalls of the packed pipeline (57 % VALU utilisation
+// against 90 % for the scalar kernel at two waves per SIMD), and the specialised scalar code folds constants into
+// v_fmamk / v_fmaak literals that packed instructions cannot take (1379 VALU per step vs 1870 per pair).
+bool mpk_fd_packed() {
+  static const bool packed = [] {
+    const char* e = getenv("MANIPULAPY_HIP_FD");
+    return e && e[0] == 'p';
+  }();
+  return packed;
+}
+
+static hipError_t fd_traj_pk(hipStream_t s, const MpModel<float>& M, const MpCall<float>& C, const float* theta0,
+                             const float* dtheta0, const float* taumat, const float* Ftipmat, long B, long Nt, float h,
+                             int intRes, float* pos, float* vel, float* acc) {
+  const unsigned grid = (unsigned)(((B + 1) / 2 + kFdBlock - 1) / kFdBlock);
+  MP_DISPATCH_N(M.n, {
+    if (Ftipmat) hipLaunchKernelGGL((k_fd_traj_pk<N, true>), dim3(grid), dim3(kFdBlock), 0, s, M, C, theta0, dtheta0, taumat, Ftipmat, B, Nt, h, intRes, pos, vel, acc);
+    else hipLaunchKernelGGL((k_fd_traj_pk<N, false>), dim3(grid), dim3(kFdBlock), 0, s, M, C, theta0, dtheta0, taumat, Ftipmat, B, Nt, h, intRes, pos, vel, acc);
+  })
+  return hipGetLastError();
+}
+static hipError_t fd_traj_pk(hipStream_t, const MpModel<double>&, const MpCall<double>&, const double*, const double*,
+                             const double*, const double*, long, long, double, int, float*, float*, float*) {
+  return hipErrorInvalidValue;  // never selected for float64
+}
+
 template <typename T>
 hipError_t mpk_fd_traj(hipStream_t s, const MpModel<T>& M, const MpCall<T>& C, const T* theta0, const T* dtheta0,
                        const T* taumat, const T* Ftipmat, long B, long Nt, T h, int intRes, float* pos, float* vel, float* acc) {
   if (B <= 0 || Nt <= 0) return hipSuccess;
+  if (sizeof(T) == 4 && mpk_fd_packed()) return fd_traj_pk(s, M, C, theta0, dtheta0, taumat, Ftipmat, B, Nt, h, intRes, pos, vel, acc);
   MP_DISPATCH_N(M.n, {
     if (Ftipmat) hipLaunchKernelGGL((k_fd_traj<T, N, true>), dim3((unsigned)((B + kFdBlock - 1) / kFdBlock)), dim3(kFdBlock), 0, s, M, C, theta0, dtheta0, taumat, Ftipmat, B, Nt, h, intRes, pos, vel, acc);
     else hipLaunchKernelGGL((k_fd_traj<T, N, false>), dim3((unsigned)((B + kFdBlock - 1) / kFdBlock)), dim3(kFdBlock), 0, s, M, C, theta0, dtheta0, taumat, Ftipmat, B, Nt, h, intRes, pos, vel, acc);

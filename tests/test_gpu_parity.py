@@ -524,6 +524,58 @@ def test_rccl_communicator_single_rank(ctx):
     d_s.free(); d_r.free()
 
 
+def test_forward_dynamics_trajectory_packed_variant(tables):
+    """MANIPULAPY_HIP_FD=packed (two trajectories per lane, off by default): same results as the default kernels to
+    float32 rounding and as the oracle, generic and specialised, odd batch, partial tiles, with and without wrenches."""
+    import subprocess, sys, textwrap
+
+    code = textwrap.dedent("""
+        import numpy as np, sys, os
+        sys.path.insert(0, %r)
+        import manipulapy_amd as mp
+        from manipulapy_amd import _hip
+        from oracle import ref_numpy as ref
+        tab = ref.load_tables(os.path.join(%r, "tests", "golden", "model_xarm6.npz"))
+        ctx = _hip.HipContext(0)
+        gen = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee, tab.joint_limits)
+        spec = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee, tab.joint_limits)
+        ctx.specialize(spec)
+        G0 = np.array([0.0, 0.0, -9.81])
+        B, n = 67, tab.n
+        out = {}
+        for Nt in (1, 3, 4, 9):
+            rng = np.random.default_rng(100 + Nt)
+            th0 = rng.uniform(-0.5, 0.5, (B, n)); dth0 = rng.uniform(-0.2, 0.2, (B, n))
+            tm = rng.uniform(-1, 1, (B, Nt, n)); Fm = rng.uniform(-1, 1, (B, Nt, 6))
+            for w, wrench in enumerate((None, Fm)):
+                a = ctx.fd_trajectory_host(gen, th0, dth0, tm, G0, wrench, 0.01, 2, dtype=np.float32)
+                b = ctx.fd_trajectory_host(spec, th0, dth0, tm, G0, wrench, 0.01, 2, dtype=np.float32)
+                for x, y in zip(a, b):
+                    np.testing.assert_allclose(x, y, rtol=2e-4, atol=2e-4 * max(1.0, float(np.abs(x).max())))
+                for t in (0, 1, B - 1):
+                    o = ref.forward_dynamics_trajectory(tab, th0[t], dth0[t], tm[t], G0, np.zeros((Nt, 6)) if wrench is None else Fm[t],
+                                                        0.01, 2, joint_limits=tab.joint_limits)
+                    for k, name in enumerate(("positions", "velocities", "accelerations")):
+                        np.testing.assert_allclose(a[k][t], o[name], rtol=3e-4, atol=3e-4 * max(1.0, float(np.abs(o[name]).max())))
+                out["%%d_%%d" %% (Nt, w)] = np.stack(a)
+        np.savez(sys.argv[1], **out)
+        print("OK")
+    """ % (ROOT, ROOT))
+    import tempfile
+
+    res = {}
+    with tempfile.TemporaryDirectory() as d:
+        for mode in ("packed", "scalar"):
+            path = os.path.join(d, mode + ".npz")
+            r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, MANIPULAPY_HIP_FD=mode), capture_output=True,
+                               text=True, timeout=900)
+            assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+            res[mode] = dict(np.load(path))
+    for k in res["packed"]:
+        x, y = res["packed"][k], res["scalar"][k]
+        assert np.abs(x - y).max() <= 2e-4 * max(1.0, float(np.abs(y).max())), k
+
+
 def test_singularity_and_workspace_against_oracle(tables, dyn_golden):
     """Singularity mirror (reference singularity/singularity_analysis.py): condition number / smallest singular value of
     the GPU Jacobians == NumPy on the oracle's Jacobians; batch == per-sample; Monte-Carlo workspace points == oracle FK."""
