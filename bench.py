@@ -345,6 +345,25 @@ def main():
     if world > 1 and not args.no_gather:
         allgather = {"bytes_per_rank": nb, "collective": "ncclAllGather (RCCL), one call per step after the kernel"}
 
+        def verify_gather(d_all):
+            """Rank 0 recomputes trajectory 0 of EVERY rank's shard (inputs are seeded per rank) with the same two kernels and
+            compares it bit for bit with what the all-gather delivered into that rank's slot."""
+            try:
+                ctx.synchronize()
+                for r in range(world):
+                    rr = np.random.default_rng(SEED + cid + 1000 * r)
+                    s0 = rr.uniform(lo, hi, (B, n)).astype(np.float32)[:1]
+                    e0 = rr.uniform(lo, hi, (B, n)).astype(np.float32)[:1]
+                    p, v, a = ctx.batch_trajectory_host(model, s0, e0, 2.0, N, 5)
+                    want = ctx.id_trajectory_host(model, p[0], v[0], a[0])
+                    got = np.empty((N, n), np.float32)
+                    _hip._check(ctx.lib.mp_memcpy_d2h(ctx.handle, got.ctypes.data, d_all.offset(r * nb), got.nbytes))
+                    if not np.array_equal(got, want):
+                        return f"mismatch in the slot of rank {r}: max abs diff {float(np.abs(got - want).max()):.3e}"
+                return True
+            except Exception as exc:
+                return f"not checked: {str(exc)[:200]}"
+
         def gather_phase():
             try:
                 uid = _hip.HipContext.comm_unique_id() if info.rank == 0 else None
@@ -356,6 +375,8 @@ def main():
                 allgather.update({"ms_per_step_with_allgather": ms_g,
                                   "value_with_allgather": rows * n * world * args.steps / wall_g,
                                   "busbw_GBps": nb * (world - 1) / max(ms_g - elapsed / args.steps * 1e3, 1e-6) / 1e6})
+                if info.rank == 0 and cfg["op"] == "id" and cfg["dtype"] == "f32":
+                    allgather["verified"] = verify_gather(d_tau_all)
                 comm.destroy()
             except Exception as exc:  # keep the compute line even if RCCL is unusable on this node
                 allgather["error"] = str(exc)[:300]
