@@ -72,7 +72,7 @@ int mp_memset(mp_ctx* ctx, void* d_dst, int value, size_t bytes);
  * *_host_* entry points below accept any host pointer; on buffers from mp_host_alloc the upload, the kernels and
  * the download of a large call overlap chunk by chunk (pageable memory is staged by the runtime and serialises). */
 int mp_host_alloc(mp_ctx* ctx, size_t bytes, void** h_ptr);
-int mp_host_free(mp_ctx* ctx, void* h_ptr);
+int mp_host_free(mp_ctx* ctx, void* h_ptr); /* ctx may be NULL: the buffer outlives the context that allocated it */
 
 /* ---- timing on the compute stream ------------------------------------------------------------ */
 int mp_event_create(mp_ctx* ctx, mp_event** out);

@@ -257,8 +257,8 @@ class PinnedBuffer:
 
     def __del__(self):
         try:
-            if self.ptr and self.ctx.handle is not None:
-                self.ctx.lib.mp_host_free(self.ctx.handle, _vp(self.ptr))
+            if self.ptr:  # valid with or without the allocating context: the buffer does not belong to it
+                self.ctx.lib.mp_host_free(None, _vp(self.ptr))
         except Exception:
             pass
         self.ptr = None

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -29,7 +30,6 @@ struct mp_ctx {
   hipStream_t compute = nullptr;
   hipStream_t copy = nullptr;      // host -> device leg of the chunked host-buffer pipeline
   hipStream_t copy_out = nullptr;  // device -> host leg
-  std::map<void*, size_t> pinned;  // page-locked host buffers handed out by mp_host_alloc
   std::map<size_t, std::vector<void*>> free_by_size;  // pool: exact-size free lists
   std::map<void*, size_t> live;                        // every buffer handed out -> its size
   std::map<uint64_t, void*> dev_models;                // model uid -> float32 model resident on this device
@@ -482,7 +482,6 @@ int mp_ctx_destroy(mp_ctx* ctx) {
   (void)hipDeviceSynchronize();
   for (auto& kv : ctx->specs) if (kv.second.mod) (void)hipModuleUnload(kv.second.mod);
   for (auto& kv : ctx->live) (void)hipFree(kv.first);
-  for (auto& kv : ctx->pinned) (void)hipHostFree(kv.first);
   if (ctx->compute) (void)hipStreamDestroy(ctx->compute);
   if (ctx->copy) (void)hipStreamDestroy(ctx->copy);
   if (ctx->copy_out) (void)hipStreamDestroy(ctx->copy_out);
@@ -576,25 +575,36 @@ int mp_pool_trim(mp_ctx* ctx) {
 }
 
 // page-locked host memory: DMA reads / writes it directly, so the host-buffer entry points overlap upload, kernel
-// and download on such buffers (pageable buffers are staged by the runtime and serialise)
+// and download on such buffers (pageable buffers are staged by the runtime and serialise).  The buffers are portable
+// (usable from every device) and outlive the context that allocated them: a caller may still hold views of one
+// when it destroys its context, so only mp_host_free releases them.
+namespace {
+std::mutex g_pinned_mu;
+std::map<void*, size_t> g_pinned;
+}  // namespace
 int mp_host_alloc(mp_ctx* ctx, size_t bytes, void** h_ptr) {
   REQUIRE(ctx && h_ptr, "mp_host_alloc: null argument");
   *h_ptr = nullptr;
   if (int rc = bind(ctx)) return rc;
   void* p = nullptr;
-  HIP_TRY(hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault));
-  ctx->pinned[p] = bytes;
+  HIP_TRY(hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocPortable));
+  {
+    std::lock_guard<std::mutex> lk(g_pinned_mu);
+    g_pinned[p] = bytes;
+  }
   *h_ptr = p;
   return MP_OK;
 }
 int mp_host_free(mp_ctx* ctx, void* h_ptr) {
-  REQUIRE(ctx, "mp_host_free: null context");
+  (void)ctx;  // may be null or already destroyed: the buffer does not belong to a context
   if (!h_ptr) return MP_OK;
-  auto it = ctx->pinned.find(h_ptr);
-  REQUIRE(it != ctx->pinned.end(), "mp_host_free: pointer %p was not allocated by mp_host_alloc on this context", h_ptr);
-  if (int rc = bind(ctx)) return rc;
+  {
+    std::lock_guard<std::mutex> lk(g_pinned_mu);
+    auto it = g_pinned.find(h_ptr);
+    REQUIRE(it != g_pinned.end(), "mp_host_free: pointer %p was not allocated by mp_host_alloc", h_ptr);
+    g_pinned.erase(it);
+  }
   HIP_TRY(hipHostFree(h_ptr));
-  ctx->pinned.erase(it);
   return MP_OK;
 }
 

@@ -654,8 +654,11 @@ def test_host_paths_pinned_pipelined_and_prefaulted(models, tables):
         pf = ctx.pinned_empty(fused.shape, np.float32)
         ctx.traj_id_fused_host(model, q[:300], qd[:300], 2.0, 1201, 5, out=pf)
         np.testing.assert_array_equal(pf, fused)
-        del pq, pqd, pqdd, pt, pf
-        ctx.destroy()
+        del pq, pqd, pqdd
+        ctx.destroy()                       # page-locked arrays outlive the context that allocated them
+        np.testing.assert_array_equal(pt, want)
+        np.testing.assert_array_equal(pf, fused)
+        del pt, pf
         print("OK")
     """ % ROOT)
     for env_extra in ({"MANIPULAPY_HIP_HOST_CHUNK_ROWS": "100001"}, {}):
