@@ -40,6 +40,9 @@ CONFIGS = {
                desc="KUKA iiwa14 7-DOF, B=65536 x N=500, FK + Jacobian + ID fused fp64 (BASELINE configs[2])"),
     "c4": dict(robot="panda", B=32768, N=200, dtype="f32", op="id",
                desc="Franka Panda (8 DOF as the reference parses it), B=32768/GPU x N=200, ID fp32 (BASELINE configs[3] per-GPU shard)"),
+    "c4s": dict(robot="panda7", B=32768, N=200, dtype="f32", op="id",
+                desc="Franka Panda, the 7 arm joints only (first-seven-joint truncation of the reference's 8-joint tables), "
+                     "B=32768/GPU x N=200, ID fp32 - the 7-DOF reading of BASELINE configs[3]"),
     "c5": dict(robot="xarm6", B=131072, N=100, dtype="f32", op="fd_traj",
                desc="xArm6 (6 DOF; the reference ships no xArm7), gravity + per-step Ftip, B=131072/GPU x N=100, mass matrix + "
                     "forward-dynamics roll-out fp32, dt=0.01 intRes=1 (BASELINE configs[4] per-GPU shard)"),
@@ -68,6 +71,16 @@ def kernel_name(cfg):
             "fd_traj": "mp_spec_fd_traj_f1" if spec else "k_fd_traj"}[cfg["op"]]
 
 
+def oracle_tables(ref, robot):
+    """The oracle's view of the tables bench.py runs on (fixtures, or a derived robot such as the 7-joint Panda)."""
+    from manipulapy_amd import robots
+
+    t = robots.robot_tables(robot)
+    return ref.RobotTables(S=t["S_list"].astype(np.float64), M_ee=t["M_ee"].astype(np.float64), G=t["Glist"].astype(np.float64),
+                           Mcom=t["Mlist_per_link"].astype(np.float64), joint_limits=t["joint_limits"].astype(np.float64),
+                           B=t["B_list"].astype(np.float64), name=robot)
+
+
 def cpu_baseline(robot, q, qd, qdd, budget_s=12.0):
     """The CPU oracle — the reference's algorithm (1 + 2n mass matrices per point, finite-difference Coriolis)
     restated in C (oracle/oracle.c, pinned to the reference's golden vectors) — timed on this box's host
@@ -75,7 +88,7 @@ def cpu_baseline(robot, q, qd, qdd, budget_s=12.0):
     from oracle import c_oracle
     from oracle import ref_numpy as ref
 
-    tab = ref.load_tables(os.path.join(ROOT, "tests", "golden", f"model_{robot}.npz"))
+    tab = oracle_tables(ref, robot)
     n = tab.n
     q, qd, qdd = (np.ascontiguousarray(x, dtype=np.float64) for x in (q, qd, qdd))
     probe = min(2048, q.shape[0])
@@ -168,7 +181,7 @@ def bench_fd(args, cfg, info, hg, ctx, model, t, props):
         if tf.get("kernel") == result["roofline"]["kernel"]:  # counters were collected on this very kernel
             result["roofline"]["traffic"] = tf.get("hbm_bytes_per_launch")
     if info.rank == 0 and world == 1 and not args.no_cpu_baseline:
-        tab = ref.load_tables(os.path.join(ROOT, "tests", "golden", f"model_{cfg['robot']}.npz"))
+        tab = oracle_tables(ref, cfg["robot"])
         r0 = ref.forward_dynamics_trajectory(tab, th0[0].astype(np.float64), dth0[0].astype(np.float64), taumat[0, :12].astype(np.float64),
                                              g, Fm[0, :12].astype(np.float64), 0.01, 1)  # first 12 steps of trajectory 0
         tc = time.perf_counter()
@@ -240,7 +253,7 @@ def main():
         return bench_fd(args, cfg, info, hg, ctx, model, t, props)
 
     # ---- synthetic input, generated ON the device: start / end ~ U(joint limits), quintic, Tf = 2
-    cid = {"c2": 2, "c2f": 2, "c3": 3, "c4": 4}[args.config]
+    cid = {"c2": 2, "c2f": 2, "c3": 3, "c4": 4, "c4s": 4}[args.config]
     rng = np.random.default_rng(SEED + cid + 1000 * info.rank)
     lo, hi = t["joint_limits"][:, 0], t["joint_limits"][:, 1]
     start = rng.uniform(lo, hi, (B, n)).astype(np.float32)

@@ -15,12 +15,24 @@ import numpy as np
 
 _DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 ROBOTS = ("ur5", "iiwa14", "panda", "xarm6")
+# "panda7": the 7 arm joints of the Panda.  The reference parses the packaged Panda URDF as EIGHT actuated joints (the
+# arm + one prismatic finger joint), which is what "panda" reproduces; BASELINE names a 7-DOF Panda, so the
+# first-seven-joint truncation of the same tables is offered next to it.  Tables only: it has
+# no URDF of its own.
+DERIVED = {"panda7": ("panda", 7)}
 
 
 def robot_tables(name: str) -> Dict[str, np.ndarray]:
     """S_list (6,n), M_ee (4,4), Glist (n,6,6), Mlist_per_link (n,4,4), joint_limits (n,2), B_list (6,n)."""
+    if name in DERIVED:
+        base, n = DERIVED[name]
+        t = robot_tables(base)
+        return {"S_list": np.ascontiguousarray(t["S_list"][:, :n]), "B_list": np.ascontiguousarray(t["B_list"][:, :n]),
+                "M_ee": t["M_ee"], "Glist": np.ascontiguousarray(t["Glist"][:n]),
+                "Mlist_per_link": np.ascontiguousarray(t["Mlist_per_link"][:n]),
+                "joint_limits": np.ascontiguousarray(t["joint_limits"][:n])}
     if name not in ROBOTS:
-        raise KeyError(f"unknown robot {name!r}; available: {', '.join(ROBOTS)}")
+        raise KeyError(f"unknown robot {name!r}; available: {', '.join(ROBOTS + tuple(DERIVED))}")
     z = np.load(os.path.join(_DATA, f"model_{name}.npz"))
     return {k: z[k] for k in ("S_list", "B_list", "M_ee", "Glist", "Mlist_per_link", "joint_limits")}
 

@@ -576,6 +576,36 @@ def test_forward_dynamics_trajectory_packed_variant(tables):
         assert np.abs(x - y).max() <= 2e-4 * max(1.0, float(np.abs(y).max())), k
 
 
+def test_seven_joint_panda_truncation(ctx):
+    """"panda7" = the first seven joints of the reference's 8-joint Panda tables (the 7-DOF reading of BASELINE configs[3]):
+    generic and specialised kernels against the oracle on the truncated tables, fp64 and fp32, with a wrench."""
+    import manipulapy_amd as mp
+    from manipulapy_amd import _hip
+
+    t = mp.robot_tables("panda7")
+    assert t["S_list"].shape == (6, 7) and t["Glist"].shape == (7, 6, 6)
+    tab = ref.RobotTables(S=t["S_list"], M_ee=t["M_ee"], G=t["Glist"], Mcom=t["Mlist_per_link"], joint_limits=t["joint_limits"])
+    gen = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee, tab.joint_limits)
+    spec = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee, tab.joint_limits)
+    ctx.specialize(spec)
+    rng = np.random.default_rng(77)
+    rows = 24
+    q = rng.uniform(tab.joint_limits[:, 0], tab.joint_limits[:, 1], (rows, 7))
+    qd, qdd = rng.uniform(-1, 1, (rows, 7)), rng.uniform(-2, 2, (rows, 7))
+    F = np.array([1.0, -2.0, 0.5, 3.0, -1.5, 0.75])
+    for wrench in (None, F):
+        want = ref.inverse_dynamics_trajectory(tab, q, qd, qdd, None, wrench, dtype=np.float64)
+        for m in (gen, spec):
+            assert_f64(ctx.id_trajectory_host(m, q, qd, qdd, None, wrench, dtype=np.float64), want)
+            assert_f32(ctx.id_trajectory_host(m, q.astype(np.float32), qd.astype(np.float32), qdd.astype(np.float32), None, wrench), want)
+    Ts, Js, _ = ctx.fk_jac_id_host(spec, q[:4])
+    for i in range(4):
+        assert_f64(Ts[i], ref.fk_space(tab, q[i]))
+        assert_f64(Js[i], ref.jacobian_space(tab, q[i]))
+    with pytest.raises(KeyError):
+        mp.robot_tables("panda6")
+
+
 def test_singularity_and_workspace_against_oracle(tables, dyn_golden):
     """Singularity mirror (reference singularity/singularity_analysis.py): condition number / smallest singular value of
     the GPU Jacobians == NumPy on the oracle's Jacobians; batch == per-sample; Monte-Carlo workspace points == oracle FK."""
