@@ -36,6 +36,7 @@ struct mp_ctx {
   std::map<uint64_t, MpSpec> specs;                    // model uid -> specialised kernels (mp_model_specialize)
   int compute_units = 0;
   bool capturing = false;                              // between mp_graph_begin and mp_graph_end
+  std::recursive_mutex mu;                             // serialises the entry points of this context (CTX_ENTER)
 };
 struct mp_model {
   MpModel<double> d;
@@ -89,6 +90,14 @@ int bind(mp_ctx* ctx) {
   HIP_TRY(hipSetDevice(ctx->device));
   return MP_OK;
 }
+// Every entry point that touches a context starts with CTX_ENTER: it serialises the callers of one context (the pool,
+// the specialisation table and the capture flag are plain containers; ctypes releases the GIL during a call, so
+// Python threads sharing a planner do arrive concurrently - the reference runs its planners from several threads in
+// tests/test_trajectory_planning.py:1375) and binds the calling thread to the context's device.  Recursive: the
+// host-buffer entry points call the device-pointer ones.
+#define CTX_ENTER(ctx)                                         \
+  std::lock_guard<std::recursive_mutex> ctx_lock_((ctx)->mu);  \
+  if (int rc_enter_ = bind(ctx)) return rc_enter_
 template <typename T> const MpModel<T>& pick(const mp_model* m);
 template <> const MpModel<float>& pick<float>(const mp_model* m) { return m->f; }
 template <> const MpModel<double>& pick<double>(const mp_model* m) { return m->d; }
@@ -230,7 +239,7 @@ template <typename T>
 static int id_impl(const char* fn, mp_ctx* ctx, const mp_model* model, const T* d_q, const T* d_qd, const T* d_qdd,
                    int64_t rows, const double* g, const double* Ftip, T* d_tau) {
   REQUIRE(ctx && model, "%s: null context or model", fn);
-  if (int rc = bind(ctx)) return rc;
+  CTX_ENTER(ctx);
   REQUIRE(rows >= 0, "%s: negative row count %lld", fn, (long long)rows);
   if (rows == 0) return MP_OK;
   REQUIRE(d_q && d_qd && d_qdd && d_tau, "%s: null device pointer", fn);
@@ -259,7 +268,7 @@ template <typename T>
 static int fkjid_impl(const char* fn, mp_ctx* ctx, const mp_model* model, const T* d_q, const T* d_qd, const T* d_qdd,
                       int64_t rows, const double* g, const double* Ftip, T* d_T, T* d_J, T* d_tau) {
   REQUIRE(ctx && model, "%s: null context or model", fn);
-  if (int rc = bind(ctx)) return rc;
+  CTX_ENTER(ctx);
   REQUIRE(rows >= 0, "%s: negative row count %lld", fn, (long long)rows);
   if (rows == 0) return MP_OK;
   REQUIRE(d_q, "%s: null d_q", fn);
@@ -279,7 +288,7 @@ template <typename T>
 static int id_host_impl(const char* fn, mp_ctx* ctx, const mp_model* model, const T* q, const T* qd, const T* qdd,
                         int64_t rows, const double* g, const double* Ftip, T* tau) {
   REQUIRE(ctx && model, "%s: null context or model", fn);
-  if (int rc = bind(ctx)) return rc;
+  CTX_ENTER(ctx);
   REQUIRE(rows >= 0, "%s: negative row count", fn);
   if (rows == 0) return MP_OK;
   REQUIRE(q && qd && qdd && tau, "%s: null host pointer", fn);
@@ -344,7 +353,7 @@ static int id_host_impl(const char* fn, mp_ctx* ctx, const mp_model* model, cons
 template <typename T>
 static int mm_impl(const char* fn, mp_ctx* ctx, const mp_model* model, const T* d_q, int64_t rows, T* d_M) {
   REQUIRE(ctx && model, "%s: null context or model", fn);
-  if (int rc = bind(ctx)) return rc;
+  CTX_ENTER(ctx);
   REQUIRE(rows >= 0, "%s: negative row count", fn);
   if (rows == 0) return MP_OK;
   REQUIRE(d_q && d_M, "%s: null device pointer", fn);
@@ -357,7 +366,7 @@ template <typename T>
 static int fdyn_impl(const char* fn, mp_ctx* ctx, const mp_model* model, const T* d_q, const T* d_qd, const T* d_tau,
                      int64_t rows, const double* g, const double* Ftip, T* d_qdd) {
   REQUIRE(ctx && model, "%s: null context or model", fn);
-  if (int rc = bind(ctx)) return rc;
+  CTX_ENTER(ctx);
   REQUIRE(rows >= 0, "%s: negative row count", fn);
   if (rows == 0) return MP_OK;
   REQUIRE(d_q && d_qd && d_tau && d_qdd, "%s: null device pointer", fn);
@@ -388,7 +397,7 @@ static int fdtraj_impl(const char* fn, mp_ctx* ctx, const mp_model* model, const
                        const T* d_taumat, const T* d_Ftipmat, int64_t B, int64_t N, const double* g, double dt, int intRes,
                        float* d_pos, float* d_vel, float* d_acc) {
   REQUIRE(ctx && model, "%s: null context or model", fn);
-  if (int rc = bind(ctx)) return rc;
+  CTX_ENTER(ctx);
   REQUIRE(B >= 0 && N >= 0, "%s: negative B or N", fn);
   REQUIRE(intRes >= 0, "%s: negative intRes", fn);
   if (B == 0 || N == 0) return MP_OK;
@@ -410,7 +419,7 @@ static int fdtraj_host_impl(const char* fn, mp_ctx* ctx, const mp_model* model, 
                             const T* taumat, const T* Ftipmat, int64_t B, int64_t N, const double* g, double dt, int intRes,
                             float* pos, float* vel, float* acc) {
   REQUIRE(ctx && model, "%s: null context or model", fn);
-  if (int rc = bind(ctx)) return rc;
+  CTX_ENTER(ctx);
   REQUIRE(B >= 0 && N >= 0, "%s: negative B or N", fn);
   if (B == 0 || N == 0) return MP_OK;
   REQUIRE(theta0 && dtheta0 && taumat && pos && vel && acc, "%s: null host pointer", fn);
@@ -491,7 +500,7 @@ int mp_ctx_destroy(mp_ctx* ctx) {
 
 int mp_ctx_synchronize(mp_ctx* ctx) {
   REQUIRE(ctx, "mp_ctx_synchronize: null context");
-  if (int rc = bind(ctx)) return rc;
+  CTX_ENTER(ctx);
   HIP_TRY(hipStreamSynchronize(ctx->compute));
   HIP_TRY(hipStreamSynchronize(ctx->copy));
   HIP_TRY(hipStreamSynchronize(ctx->copy_out));
@@ -510,7 +519,7 @@ int mp_ctx_properties(mp_ctx* ctx, char* name, size_t name_len, int* compute_uni
 
 int mp_selftest(mp_ctx* ctx) {
   REQUIRE(ctx, "mp_selftest: null context");
-  if (int rc = bind(ctx)) return rc;
+  CTX_ENTER(ctx);
   Scratch sc(ctx);
   void* d = nullptr;
   if (int rc = sc.get(64 * sizeof(int), &d)) return rc;
@@ -528,7 +537,7 @@ int mp_selftest(mp_ctx* ctx) {
 int mp_malloc(mp_ctx* ctx, size_t bytes, void** d_ptr) {
   REQUIRE(ctx && d_ptr, "mp_malloc: null argument");
   *d_ptr = nullptr;
-  if (int rc = bind(ctx)) return rc;
+  CTX_ENTER(ctx);
   REQUIRE(!ctx->capturing, "mp_malloc: not allowed while a launch graph is being captured (mp_graph_begin)");
   if (bytes == 0) bytes = 16;
   bytes = (bytes + 255) & ~size_t(255);
@@ -554,6 +563,7 @@ int mp_malloc(mp_ctx* ctx, size_t bytes, void** d_ptr) {
 int mp_free(mp_ctx* ctx, void* d_ptr) {
   REQUIRE(ctx, "mp_free: null context");
   if (!d_ptr) return MP_OK;
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   auto it = ctx->live.find(d_ptr);
   REQUIRE(it != ctx->live.end(), "mp_free: pointer %p was not allocated by this context", d_ptr);
   ctx->free_by_size[it->second].push_back(d_ptr);
@@ -562,7 +572,7 @@ int mp_free(mp_ctx* ctx, void* d_ptr) {
 
 int mp_pool_trim(mp_ctx* ctx) {
   REQUIRE(ctx, "mp_pool_trim: null context");
-  if (int rc = bind(ctx)) return rc;
+  CTX_ENTER(ctx);
   (void)hipStreamSynchronize(ctx->compute);
   (void)hipStreamSynchronize(ctx->copy);
   for (auto& kv : ctx->free_by_size)
@@ -585,7 +595,7 @@ std::map<void*, size_t> g_pinned;
 int mp_host_alloc(mp_ctx* ctx, size_t bytes, void** h_ptr) {
   REQUIRE(ctx && h_ptr, "mp_host_alloc: null argument");
   *h_ptr = nullptr;
-  if (int rc = bind(ctx)) return rc;
+  CTX_ENTER(ctx);
   void* p = nullptr;
   HIP_TRY(hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocPortable));
   {
@@ -611,7 +621,7 @@ int mp_host_free(mp_ctx* ctx, void* h_ptr) {
 int mp_memcpy_h2d(mp_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
   REQUIRE(ctx && (bytes == 0 || (d_dst && h_src)), "mp_memcpy_h2d: null argument");
   if (bytes == 0) return MP_OK;
-  if (int rc = bind(ctx)) return rc;
+  CTX_ENTER(ctx);
   HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->compute));
   HIP_TRY(hipStreamSynchronize(ctx->compute));
   return MP_OK;
@@ -619,7 +629,7 @@ int mp_memcpy_h2d(mp_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
 int mp_memcpy_d2h(mp_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
   REQUIRE(ctx && (bytes == 0 || (h_dst && d_src)), "mp_memcpy_d2h: null argument");
   if (bytes == 0) return MP_OK;
-  if (int rc = bind(ctx)) return rc;
+  CTX_ENTER(ctx);
   HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->compute));
   HIP_TRY(hipStreamSynchronize(ctx->compute));
   return MP_OK;
@@ -627,7 +637,7 @@ int mp_memcpy_d2h(mp_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
 int mp_memset(mp_ctx* ctx, void* d_dst, int value, size_t bytes) {
   REQUIRE(ctx && (bytes == 0 || d_dst), "mp_memset: null argument");
   if (bytes == 0) return MP_OK;
-  if (int rc = bind(ctx)) return rc;
+  CTX_ENTER(ctx);
   HIP_TRY(hipMemsetAsync(d_dst, value, bytes, ctx->compute));
   return MP_OK;
 }
@@ -635,7 +645,7 @@ int mp_memset(mp_ctx* ctx, void* d_dst, int value, size_t bytes) {
 // ----------------------------------------------------------------------------------------- events
 int mp_event_create(mp_ctx* ctx, mp_event** out) {
   REQUIRE(ctx && out, "mp_event_create: null argument");
-  if (int rc = bind(ctx)) return rc;
+  CTX_ENTER(ctx);
   mp_event* e = new (std::nothrow) mp_event;
   REQUIRE(e, "mp_event_create: out of host memory");
   e->device = ctx->device;
@@ -653,7 +663,7 @@ int mp_event_destroy(mp_event* ev) {
 }
 int mp_event_record(mp_ctx* ctx, mp_event* ev) {
   REQUIRE(ctx && ev, "mp_event_record: null argument");
-  if (int rc = bind(ctx)) return rc;
+  CTX_ENTER(ctx);
   HIP_TRY(hipEventRecord(ev->ev, ctx->compute));
   return MP_OK;
 }
@@ -668,7 +678,7 @@ int mp_event_elapsed_ms(mp_event* start, mp_event* stop, float* ms) {
 // ----------------------------------------------------------------------------------------- graphs
 int mp_graph_begin(mp_ctx* ctx) {
   REQUIRE(ctx, "mp_graph_begin: null context");
-  if (int rc = bind(ctx)) return rc;
+  CTX_ENTER(ctx);
   REQUIRE(!ctx->capturing, "mp_graph_begin: a capture is already open on this context");
   HIP_TRY(hipStreamBeginCapture(ctx->compute, hipStreamCaptureModeThreadLocal));
   ctx->capturing = true;
@@ -677,7 +687,7 @@ int mp_graph_begin(mp_ctx* ctx) {
 int mp_graph_end(mp_ctx* ctx, mp_graph** out) {
   REQUIRE(ctx && out, "mp_graph_end: null argument");
   *out = nullptr;
-  if (int rc = bind(ctx)) return rc;
+  CTX_ENTER(ctx);
   REQUIRE(ctx->capturing, "mp_graph_end: no capture is open on this context");
   ctx->capturing = false;
   hipGraph_t g = nullptr;
@@ -696,7 +706,7 @@ int mp_graph_end(mp_ctx* ctx, mp_graph** out) {
 int mp_graph_launch(mp_ctx* ctx, mp_graph* graph) {
   REQUIRE(ctx && graph, "mp_graph_launch: null argument");
   REQUIRE(graph->device == ctx->device, "mp_graph_launch: graph captured on device %d, context is on %d", graph->device, ctx->device);
-  if (int rc = bind(ctx)) return rc;
+  CTX_ENTER(ctx);
   HIP_TRY(hipGraphLaunch(graph->exec, ctx->compute));
   return MP_OK;
 }
@@ -767,13 +777,14 @@ int mp_model_specialize_compile(const mp_model* model, size_t* code_bytes, int* 
 }
 int mp_model_is_specialized(mp_ctx* ctx, const mp_model* model, int* yes) {
   REQUIRE(ctx && model && yes, "mp_model_is_specialized: null argument");
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   *yes = ctx->specs.count(model->uid) ? 1 : 0;
   return MP_OK;
 }
 int mp_model_specialize(mp_ctx* ctx, const mp_model* model) {
   REQUIRE(ctx && model, "mp_model_specialize: null argument");
+  CTX_ENTER(ctx);
   if (ctx->specs.count(model->uid)) return MP_OK;
-  if (int rc = bind(ctx)) return rc;
   std::vector<char> code;
   std::string err;
   if (mp_jit_compile(model->f, model->d, &code, nullptr, &err)) return set_err(MP_ERR_UNSUPPORTED, "mp_model_specialize: %s", err.c_str());
@@ -810,7 +821,7 @@ int mp_model_fk_host(const mp_model* model, const double* q, double* T) {
 // ---------------------------------------------------------------------- hot path, device pointers
 #define CHECK_COMMON(fn)                                              \
   REQUIRE(ctx && model, fn ": null context or model");                \
-  if (int rc_ = bind(ctx)) return rc_;
+  CTX_ENTER(ctx);
 
 int mp_batch_trajectory_f32(mp_ctx* ctx, const mp_model* model, const float* d_start, const float* d_end, int64_t B,
                             int64_t N, double Tf, int method, float* d_pos, float* d_vel, float* d_acc) {
@@ -1028,7 +1039,7 @@ int mp_forward_dynamics_host_f64(mp_ctx* ctx, const mp_model* model, const doubl
 int mp_cartesian_trajectory_f32(mp_ctx* ctx, const double* d_Xstart, const double* d_Xend, int64_t B, int64_t N, double Tf,
                                 int method, float* d_pos, float* d_vel, float* d_acc, float* d_orient) {
   REQUIRE(ctx, "mp_cartesian_trajectory_f32: null context");
-  if (int rc = bind(ctx)) return rc;
+  CTX_ENTER(ctx);
   REQUIRE(B >= 0 && N >= 0, "mp_cartesian_trajectory_f32: negative B or N");
   if (B == 0 || N == 0) return MP_OK;
   REQUIRE(N >= 2, "mp_cartesian_trajectory_f32: N = 1 divides by zero (Tf / (N - 1))");
@@ -1040,7 +1051,7 @@ int mp_cartesian_trajectory_f32(mp_ctx* ctx, const double* d_Xstart, const doubl
 int mp_cartesian_trajectory_host_f32(mp_ctx* ctx, const double* Xstart, const double* Xend, int64_t B, int64_t N, double Tf,
                                      int method, float* pos, float* vel, float* acc, float* orient) {
   REQUIRE(ctx, "mp_cartesian_trajectory_host_f32: null context");
-  if (int rc = bind(ctx)) return rc;
+  CTX_ENTER(ctx);
   REQUIRE(B >= 0 && N >= 0, "mp_cartesian_trajectory_host_f32: negative B or N");
   if (B == 0 || N == 0) return MP_OK;
   REQUIRE(Xstart && Xend && pos && vel && acc && orient, "mp_cartesian_trajectory_host_f32: null host pointer");
@@ -1067,7 +1078,7 @@ int mp_cartesian_trajectory_host_f32(mp_ctx* ctx, const double* Xstart, const do
 int mp_potential_field_f32(mp_ctx* ctx, const float* d_positions, const float* goal, const float* d_obstacles, int64_t P,
                            int64_t O, float influence_distance, float* d_potential, float* d_gradient) {
   REQUIRE(ctx, "mp_potential_field_f32: null context");
-  if (int rc = bind(ctx)) return rc;
+  CTX_ENTER(ctx);
   REQUIRE(P >= 0 && O >= 0, "mp_potential_field_f32: negative P or O");
   if (P == 0) return MP_OK;
   REQUIRE(d_positions && goal && d_potential && d_gradient && (O == 0 || d_obstacles), "mp_potential_field_f32: null pointer");
@@ -1077,7 +1088,7 @@ int mp_potential_field_f32(mp_ctx* ctx, const float* d_positions, const float* g
 int mp_potential_field_host_f32(mp_ctx* ctx, const float* positions, const float* goal, const float* obstacles, int64_t P,
                                 int64_t O, float influence_distance, float* potential, float* gradient) {
   REQUIRE(ctx, "mp_potential_field_host_f32: null context");
-  if (int rc = bind(ctx)) return rc;
+  CTX_ENTER(ctx);
   REQUIRE(P >= 0 && O >= 0, "mp_potential_field_host_f32: negative P or O");
   if (P == 0) return MP_OK;
   REQUIRE(positions && goal && potential && gradient && (O == 0 || obstacles), "mp_potential_field_host_f32: null pointer");

@@ -606,6 +606,47 @@ def test_seven_joint_panda_truncation(ctx):
         mp.robot_tables("panda6")
 
 
+def test_planner_shared_by_threads(tables):
+    """One planner, one context, eight Python threads (the reference drives a planner from several threads in
+    tests/test_trajectory_planning.py:1375; ctypes releases the GIL, so the calls really overlap): every thread gets the
+    result a lone caller gets."""
+    import threading
+
+    import manipulapy_amd as mp
+
+    sm, dyn, lim = mp.load_robot("ur5")
+    with mp.use_backend("hip"):
+        pl = mp.OptimizedTrajectoryPlanning(sm, None, dyn, lim)
+        rng = np.random.default_rng(11)
+        jobs = []
+        for k in range(8):
+            a, b = rng.uniform(-1, 1, (2, 6))
+            tr = pl.joint_trajectory(a, b, 2.0, 300 + 2 * k, 5)
+            tau = pl.inverse_dynamics_trajectory(tr["positions"], tr["velocities"], tr["accelerations"])
+            bt = pl.batch_inverse_dynamics_trajectory(np.stack([a, b]), np.stack([b, a]), 2.0, 64 + k, 3)
+            jobs.append((a, b, 300 + 2 * k, 64 + k, tau, bt))
+        errors = []
+
+        def work(k):
+            try:
+                a, b, N, Nb, tau, bt = jobs[k]
+                for _ in range(6):
+                    tr = pl.joint_trajectory(a, b, 2.0, N, 5)
+                    got = pl.inverse_dynamics_trajectory(tr["positions"], tr["velocities"], tr["accelerations"])
+                    np.testing.assert_array_equal(got, tau)
+                    np.testing.assert_array_equal(pl.batch_inverse_dynamics_trajectory(np.stack([a, b]), np.stack([b, a]), 2.0, Nb, 3), bt)
+                    np.testing.assert_allclose(dyn.mass_matrix(a), dyn.mass_matrix(a), rtol=0, atol=0)
+            except Exception as exc:  # noqa: BLE001
+                errors.append(f"thread {k}: {exc!r}"[:500])
+
+        threads = [threading.Thread(target=work, args=(k,)) for k in range(8)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=300)
+        assert not errors, errors
+
+
 def test_singularity_and_workspace_against_oracle(tables, dyn_golden):
     """Singularity mirror (reference singularity/singularity_analysis.py): condition number / smallest singular value of
     the GPU Jacobians == NumPy on the oracle's Jacobians; batch == per-sample; Monte-Carlo workspace points == oracle FK."""
