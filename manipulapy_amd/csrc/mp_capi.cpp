@@ -16,6 +16,7 @@
 
 #include "../../include/manipula_hip.h"
 #include "mp_jit.h"
+#include "mp_ik.h"
 #include "mp_kernels.h"
 #include "mp_model_compile.h"
 
@@ -1104,6 +1105,69 @@ int mp_potential_field_host_f32(mp_ctx* ctx, const float* positions, const float
   if (int rc = mp_potential_field_f32(ctx, (float*)dp, goal, (float*)dob, P, O, influence_distance, (float*)du, (float*)dg)) return rc;
   D2H(potential, du, (size_t)P * sizeof(float));
   D2H(gradient, dg, pb);
+  HIP_TRY(hipStreamSynchronize(ctx->compute));
+  return MP_OK;
+}
+
+static int ik_params(const char* fn, const mp_model* model, const double* joint_limits, double eomg, double ev, int max_iterations,
+                     double damping, double step_cap, double w_o, double w_p, uint32_t seed, MpIkParams* P) {
+  REQUIRE(max_iterations >= 1, "%s: max_iterations must be at least 1 (got %d)", fn, max_iterations);
+  REQUIRE(eomg > 0 && ev > 0 && damping >= 0 && step_cap > 0, "%s: eomg, ev, step_cap must be positive and damping non-negative", fn);
+  P->eomg = eomg; P->ev = ev; P->damping = damping; P->step_cap = step_cap; P->w_o = w_o; P->w_p = w_p;
+  P->max_iterations = max_iterations; P->seed = seed;
+  const int n = model->d.n;
+  for (int j = 0; j < MP_MAX_DOF; ++j) {
+    P->lo[j] = (j < n && joint_limits) ? joint_limits[2 * j] : -HUGE_VAL;
+    P->hi[j] = (j < n && joint_limits) ? joint_limits[2 * j + 1] : HUGE_VAL;
+    REQUIRE(!(P->lo[j] > P->hi[j]), "%s: joint %d has lower limit above upper limit", fn, j);
+  }
+  return MP_OK;
+}
+
+int mp_inverse_kinematics_f64(mp_ctx* ctx, const mp_model* model, const double* d_T_desired, const double* d_theta0, int64_t B,
+                              const double* joint_limits, double eomg, double ev, int max_iterations, double damping,
+                              double step_cap, double weight_orientation, double weight_position, uint32_t seed,
+                              double* d_theta, int32_t* d_success, int32_t* d_iterations, int32_t* d_restarts) {
+  CHECK_COMMON("mp_inverse_kinematics_f64");
+  REQUIRE(B >= 0, "mp_inverse_kinematics_f64: negative problem count");
+  if (B == 0) return MP_OK;
+  REQUIRE(d_T_desired && d_theta0 && d_theta && d_success && d_iterations && d_restarts, "mp_inverse_kinematics_f64: null device pointer");
+  REQUIRE(aligned16(d_T_desired) && aligned16(d_theta0) && aligned16(d_theta), "mp_inverse_kinematics_f64: device pointers must be 16-byte aligned");
+  MpIkParams P;
+  if (int rc = ik_params("mp_inverse_kinematics_f64", model, joint_limits, eomg, ev, max_iterations, damping, step_cap,
+                         weight_orientation, weight_position, seed, &P))
+    return rc;
+  HIP_TRY(mpk_ik(ctx->compute, model->d, P, d_T_desired, d_theta0, (long)B, d_theta, d_success, d_iterations, d_restarts));
+  return MP_OK;
+}
+
+int mp_inverse_kinematics_host_f64(mp_ctx* ctx, const mp_model* model, const double* T_desired, const double* theta0, int64_t B,
+                                   const double* joint_limits, double eomg, double ev, int max_iterations, double damping,
+                                   double step_cap, double weight_orientation, double weight_position, uint32_t seed,
+                                   double* theta, int32_t* success, int32_t* iterations, int32_t* restarts) {
+  CHECK_COMMON("mp_inverse_kinematics_host_f64");
+  REQUIRE(B >= 0, "mp_inverse_kinematics_host_f64: negative problem count");
+  if (B == 0) return MP_OK;
+  REQUIRE(T_desired && theta0 && theta && success && iterations && restarts, "mp_inverse_kinematics_host_f64: null host pointer");
+  const size_t tb = (size_t)B * 16 * sizeof(double), qb = (size_t)B * (size_t)model->d.n * sizeof(double), ib = (size_t)B * sizeof(int32_t);
+  Scratch sc(ctx);
+  void *dT, *d0, *dq, *dok, *dit, *drs;
+  if (int rc = sc.get(tb, &dT)) return rc;
+  if (int rc = sc.get(qb, &d0)) return rc;
+  if (int rc = sc.get(qb, &dq)) return rc;
+  if (int rc = sc.get(ib, &dok)) return rc;
+  if (int rc = sc.get(ib, &dit)) return rc;
+  if (int rc = sc.get(ib, &drs)) return rc;
+  H2D(dT, T_desired, tb);
+  H2D(d0, theta0, qb);
+  if (int rc = mp_inverse_kinematics_f64(ctx, model, (double*)dT, (double*)d0, B, joint_limits, eomg, ev, max_iterations, damping,
+                                         step_cap, weight_orientation, weight_position, seed, (double*)dq, (int32_t*)dok,
+                                         (int32_t*)dit, (int32_t*)drs))
+    return rc;
+  D2H(theta, dq, qb);
+  D2H(success, dok, ib);
+  D2H(iterations, dit, ib);
+  D2H(restarts, drs, ib);
   HIP_TRY(hipStreamSynchronize(ctx->compute));
   return MP_OK;
 }

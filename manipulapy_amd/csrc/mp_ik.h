@@ -1,0 +1,153 @@
+// Batched damped-least-squares inverse kinematics: one lane solves one pose target.
+//
+// Follows the reference's iterative_inverse_kinematics with its default flags (kinematics/ik.py:39-311; adaptive
+// tuning and backtracking off): geometric error (:88-140), damped step (:142-162), step cap (:243-246), joint-limit
+// projection (:164-180), best-solution tracking (:196-203, :273-280), stagnation restart (:205-213), iteration
+// count convention (k + 1 on convergence, max_iterations + 1 on exhaustion: the for / else at :267-269).
+//
+// The step: the reference forms  V diag(s / (s^2 + lambda^2 + 1e-12)) U^T e  from an SVD of J.  That vector equals
+// J^T (J J^T + (lambda^2 + 1e-12) I)^-1 e, a 6 x 6 SPD system solved here with the in-register Cholesky of mp_core.h -
+// no SVD on the device.  With lambda >= 1e-6 the system is well conditioned in float64.
+//
+// The stagnation restart adds 0.1 * N(0, 1) noise to the best configuration.  The reference draws it from NumPy's
+// GLOBAL random stream, so its own runs are not reproducible across call orders; here the noise comes from a counter
+// hash of (seed, problem index, restart number, joint) - same distribution, reproducible, not the same numbers.
+#pragma once
+
+#include "mp_core.h"
+
+struct MpIkParams {
+  double eomg, ev, damping, step_cap, w_o, w_p;
+  int max_iterations;
+  unsigned seed;
+  double lo[MP_MAX_DOF], hi[MP_MAX_DOF];
+};
+
+// 6-vector [angular, space frame; linear], rotation angle and translation norm between two poses (4x4 row-major)
+MP_HD void mp_ik_error(const double (&Tc)[16], const double (&Td)[16], double (&V)[6], double& rot_err, double& trans_err) {
+  const double px = Td[3] - Tc[3], py = Td[7] - Tc[7], pz = Td[11] - Tc[11];
+  trans_err = sqrt(px * px + py * py + pz * pz);
+  double E[9];  // Rc^T Rd
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) E[3 * r + c] = Tc[r] * Td[c] + Tc[4 + r] * Td[4 + c] + Tc[8 + r] * Td[8 + c];
+  double cs = 0.5 * (E[0] + E[4] + E[8] - 1.0);
+  cs = cs < -1.0 ? -1.0 : (cs > 1.0 ? 1.0 : cs);
+  const double angle = acos(cs);
+  rot_err = angle;  // acos >= 0
+  const double vee[3] = {E[7] - E[5], E[2] - E[6], E[3] - E[1]};
+  double w[3];
+  if (angle < 1e-6) {
+    w[0] = 0.5 * vee[0]; w[1] = 0.5 * vee[1]; w[2] = 0.5 * vee[2];
+  } else if (fabs(angle - 3.14159265358979323846) < 1e-6) {
+    const int idx = (E[0] >= E[4] && E[0] >= E[8]) ? 0 : (E[4] >= E[8] ? 1 : 2);  // first maximum of the diagonal
+    w[0] = idx == 0 ? angle : 0.0; w[1] = idx == 1 ? angle : 0.0; w[2] = idx == 2 ? angle : 0.0;
+  } else {
+    const double k = angle / (2.0 * sin(angle) + 1e-10);
+    w[0] = k * vee[0]; w[1] = k * vee[1]; w[2] = k * vee[2];
+  }
+#pragma unroll
+  for (int r = 0; r < 3; ++r) V[r] = Tc[4 * r] * w[0] + Tc[4 * r + 1] * w[1] + Tc[4 * r + 2] * w[2];
+  V[3] = px; V[4] = py; V[5] = pz;
+}
+
+// standard normal from a counter (splitmix64 finaliser + Box-Muller); only the restart path uses it
+MP_HD double mp_ik_normal(unsigned seed, long problem, int restart, int joint) {
+  unsigned long long x = (unsigned long long)seed * 0x9E3779B97F4A7C15ull + (unsigned long long)problem * 0xBF58476D1CE4E5B9ull +
+                         (unsigned long long)(restart * 64 + joint) * 0x94D049BB133111EBull;
+  unsigned long long u[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    x += 0x9E3779B97F4A7C15ull;
+    unsigned long long z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    u[i] = z ^ (z >> 31);
+  }
+  const double a = ((double)(u[0] >> 11) + 1.0) * (1.0 / 9007199254740993.0);  // (0, 1)
+  const double b = (double)(u[1] >> 11) * (1.0 / 9007199254740992.0);
+  return sqrt(-2.0 * log(a)) * cos(6.283185307179586476925 * b);
+}
+
+// theta: in = initial guess, out = solution.  Returns the reference's iteration count; sets success / restarts.
+template <int N, typename MT>
+MP_HD int mp_ik_solve(const MT& M, const MpIkParams& P, const double (&Td)[16], long problem, double (&theta)[N], int& success,
+                      int& restarts) {
+  double best[N], best_err = HUGE_VAL, cur_err = HUGE_VAL;
+#pragma unroll
+  for (int j = 0; j < N; ++j) best[j] = theta[j];
+  int stall = 0, k = 0;
+  success = 0;
+  restarts = 0;
+  const double lam = P.damping * P.damping + 1e-12;
+  for (k = 0; k < P.max_iterations; ++k) {
+    MpJointState<double, N> js;
+    mp_joint_state<double, N>(M, theta, js);
+    double Tc[16], J[6 * N], V[6], rot, tr;
+    mp_fk_jac<double, N, true>(M, js, Tc, J);
+    mp_ik_error(Tc, Td, V, rot, tr);
+    cur_err = rot + tr;
+    if (rot < P.eomg && tr < P.ev) { success = 1; break; }
+    if (cur_err < best_err) {
+      best_err = cur_err;
+      stall = 0;
+#pragma unroll
+      for (int j = 0; j < N; ++j) best[j] = theta[j];
+    } else {
+      ++stall;
+    }
+    if (stall > 20) {
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        const double t = best[j] + 0.1 * mp_ik_normal(P.seed, problem, restarts, j);
+        theta[j] = t < P.lo[j] ? P.lo[j] : (t > P.hi[j] ? P.hi[j] : t);
+      }
+      stall = 0;
+      ++restarts;
+      continue;
+    }
+    double A[6][6], y[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      y[r] = V[r] * (r < 3 ? P.w_o : P.w_p);
+#pragma unroll
+      for (int c = 0; c <= r; ++c) {
+        double s = (r == c) ? lam : 0.0;
+#pragma unroll
+        for (int j = 0; j < N; ++j) s += J[r * N + j] * J[c * N + j];
+        A[r][c] = s;
+        A[c][r] = s;
+      }
+    }
+    mp_spd_solve<double, 6>(A, y);
+    double d[N], nd = 0.0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      double s = 0.0;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) s += J[r * N + j] * y[r];
+      d[j] = s;
+      nd += s * s;
+    }
+    nd = sqrt(nd);
+    const double scale = nd > P.step_cap ? P.step_cap / nd : 1.0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const double t = theta[j] + d[j] * scale;
+      theta[j] = t < P.lo[j] ? P.lo[j] : (t > P.hi[j] ? P.hi[j] : t);
+    }
+  }
+  // k == max_iterations after exhaustion, matching the reference's `else: k += 1`
+  if (!success && best_err < cur_err) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) theta[j] = best[j];
+    MpJointState<double, N> js;
+    mp_joint_state<double, N>(M, theta, js);
+    double Tc[16], J[6 * N], V[6], rot, tr;
+    mp_fk_jac<double, N, false>(M, js, Tc, J);
+    mp_ik_error(Tc, Td, V, rot, tr);
+    success = (rot < P.eomg && tr < P.ev) ? 1 : 0;
+  }
+  return k + 1;
+}

@@ -43,3 +43,9 @@ hipError_t mpk_cartesian_traj(hipStream_t s, const double* Xstart, const double*
 // Fused attractive + repulsive potential and gradient at P points against O obstacles (float32); goal on the host.
 hipError_t mpk_potential_field(hipStream_t s, const float* pos, const float* goal3_host, const float* obs, long P, long O,
                                float influence, float* pot, float* grad);
+
+// B damped-least-squares inverse-kinematics problems (csrc/mp_ik.h): Tdes (B,4,4), theta0 / theta (B,n) float64
+struct MpIkParams;
+hipError_t mpk_ik(hipStream_t s, const MpModel<double>& M, const MpIkParams& P, const double* Tdes, const double* theta0, long B,
+                  double* theta, int* success, int* iterations, int* restarts);
+

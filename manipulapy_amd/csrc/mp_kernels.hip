@@ -11,6 +11,7 @@
 #include <cstdlib>
 
 #include "mp_bodies.h"
+#include "mp_ik.h"
 #include "mp_kernels.h"
 
 namespace {
@@ -267,6 +268,27 @@ __global__ __launch_bounds__(kBlock) void k_potential_field(const float* __restr
   grad[3 * i] = Gx; grad[3 * i + 1] = Gy; grad[3 * i + 2] = Gz;
 }
 
+// ------------------------------------------------------------------- batched inverse kinematics
+// one lane per pose target; lanes of a wave leave the iteration loop at different counts (the wave runs as long as
+// its slowest problem).  float64 throughout: the reference's default tolerances are 1e-6 rad / 1e-6 m.
+template <int N>
+__global__ __launch_bounds__(kBlock) void k_ik(const MpModel<double> M, const MpIkParams P, const double* __restrict__ Tdes,
+                                               const double* __restrict__ theta0, long B, double* __restrict__ theta,
+                                               int* __restrict__ success, int* __restrict__ iterations,
+                                               int* __restrict__ restarts) {
+  const long b = (long)blockIdx.x * kBlock + threadIdx.x;
+  if (b >= B) return;
+  double Td[16], q[N];
+  RunIO<double, 16>::load(Tdes, b, Td);
+  RunIO<double, N>::load(theta0, b, q);
+  int ok = 0, rs = 0;
+  const int it = mp_ik_solve<N>(M, P, Td, b, q, ok, rs);
+  RunIO<double, N>::store(theta, b, q);
+  success[b] = ok;
+  iterations[b] = it;
+  restarts[b] = rs;
+}
+
 inline unsigned grid_for(long rows) { return (unsigned)((rows + kBlock - 1) / kBlock); }
 
 // float32 variant selection (A/B switch for profiling): MANIPULAPY_HIP_F32 = "packed" (default) | "scalar"
@@ -465,6 +487,13 @@ hipError_t mpk_cartesian_traj(hipStream_t s, const double* Xstart, const double*
                               float* pos, float* vel, float* acc, float* ori) {
   if (B <= 0 || Nt <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_cartesian_traj, dim3(grid_for(B * Nt)), dim3(kBlock), 0, s, Xstart, Xend, B, Nt, Tf, method, pos, vel, acc, ori);
+  return hipGetLastError();
+}
+
+hipError_t mpk_ik(hipStream_t s, const MpModel<double>& M, const MpIkParams& P, const double* Tdes, const double* theta0, long B,
+                  double* theta, int* success, int* iterations, int* restarts) {
+  if (B <= 0) return hipSuccess;
+  MP_DISPATCH_N(M.n, { hipLaunchKernelGGL((k_ik<N>), dim3(grid_for(B)), dim3(kBlock), 0, s, M, P, Tdes, theta0, B, theta, success, iterations, restarts); })
   return hipGetLastError();
 }
 

@@ -254,6 +254,10 @@ def _launch_fk_jac_gpu(model, q, qd=None, qdd=None, g=None, Ftip=None, want_T=Tr
     return get_context().fk_jac_id_host(model, q, qd, qdd, g, Ftip, want_T, want_J)
 
 
+def _launch_ik_gpu(model, T_desired, theta0, **kw):
+    return get_context().inverse_kinematics_host(model, T_desired, theta0, **kw)
+
+
 def _launch_mass_matrix_gpu(model, q):
     return get_context().mass_matrix_host(model, q)
 
@@ -321,6 +325,7 @@ def _build_kernel_registry() -> KernelRegistry:
         ("dynamics.inverse_trajectory", "mp_id_trajectory_host_f32 / _f64", _launch_id_gpu),
         ("dynamics.fused_trajectory_inverse", "mp_traj_id_fused_host_f32", _launch_fused_gpu),
         ("kinematics.fk_jacobian", "mp_fk_jac_id_host_f64", _launch_fk_jac_gpu),
+        ("kinematics.inverse", "mp_inverse_kinematics_host_f64", _launch_ik_gpu),
         ("dynamics.mass_matrix", "mp_mass_matrix_host_f64", _launch_mass_matrix_gpu),
         ("dynamics.forward", "mp_forward_dynamics_host_f64", _launch_forward_dynamics_gpu),
         ("dynamics.forward_trajectory", "mp_fd_trajectory_host_f32 / _f64", _launch_fd_trajectory_gpu),

@@ -450,3 +450,67 @@ def forward_dynamics_trajectory(tab, theta0, dtheta0, taumat, g, Ftipmat, dt, in
         V.append(qd.astype(np.float32))
         A.append(np.asarray(last, dtype=np.float32))
     return {"positions": np.stack(P), "velocities": np.stack(V), "accelerations": np.stack(A)}
+
+# --------------------------------------------------------------------------- inverse kinematics
+def ik_geometric_error(T_curr, T_target):
+    """kinematics/ik.py:88-140 — 6-vector [angular (space frame); linear], rotation angle, translation norm."""
+    pos_err = T_target[:3, 3] - T_curr[:3, 3]
+    trans_err = np.linalg.norm(pos_err)
+    R_curr, R_target = T_curr[:3, :3], T_target[:3, :3]
+    R_err = R_curr.T @ R_target
+    angle = np.arccos(np.clip((np.trace(R_err) - 1) / 2, -1, 1))
+    rot_err = abs(angle)
+    vee = np.array([R_err[2, 1] - R_err[1, 2], R_err[0, 2] - R_err[2, 0], R_err[1, 0] - R_err[0, 1]])
+    if angle < 1e-6:
+        omega = vee / 2
+    elif abs(angle - np.pi) < 1e-6:
+        omega = angle * np.eye(3)[int(np.argmax(np.diag(R_err)))]
+    else:
+        omega = angle * vee / (2 * np.sin(angle) + 1e-10)
+    return np.concatenate((R_curr @ omega, pos_err)), rot_err, trans_err
+
+
+def iterative_inverse_kinematics(tab, T_desired, theta0, eomg=1e-6, ev=1e-6, max_iterations=10000, damping=2e-2, step_cap=0.3,
+                                 weight_orientation=1.0, weight_position=1.0, joint_limits=None, rng=None):
+    """kinematics/ik.py:39-311 with the default flags (adaptive_tuning = backtracking = False): damped least squares
+    through the damped pseudo-inverse  V diag(s / (s^2 + lambda^2 + 1e-12)) U^T  (:142-162), step cap (:243-246),
+    joint-limit projection (:164-180), best-solution tracking (:196-203, :273-280) and the stagnation restart
+    (:205-213: after more than 20 iterations without a new best, restart from best + 0.1 randn).  The restart draws from
+    `rng.standard_normal` here (NumPy's global stream in the reference; pass np.random.RandomState(seed) seeded like the
+    caller seeded np.random to reproduce a reference run).  Returns (theta, success, iterations, restarts)."""
+    lim = np.asarray(tab.joint_limits if joint_limits is None else joint_limits, dtype=np.float64)
+    lower, upper = lim[:, 0], lim[:, 1]
+    theta = np.array(theta0, dtype=np.float64)
+    T_desired = np.asarray(T_desired, dtype=np.float64)
+    best_theta, best_error, stall, restarts = theta.copy(), np.inf, 0, 0
+    W = np.array([weight_orientation] * 3 + [weight_position] * 3)
+    success, k, current_error = False, -1, np.inf
+    for k in range(max_iterations):
+        V, rot_err, trans_err = ik_geometric_error(fk_space(tab, theta), T_desired)
+        current_error = rot_err + trans_err
+        if rot_err < eomg and trans_err < ev:
+            success = True
+            break
+        if current_error < best_error:
+            best_error, best_theta, stall = current_error, theta.copy(), 0
+        else:
+            stall += 1
+        if stall > 20:
+            noise = (rng.standard_normal(theta.shape[0]) if rng is not None else np.random.randn(theta.shape[0]))
+            theta = np.minimum(np.maximum(best_theta + 0.1 * noise, lower), upper)
+            stall, restarts = 0, restarts + 1
+            continue
+        J = jacobian_space(tab, theta)
+        U, s, Vt = np.linalg.svd(J, full_matrices=False)
+        delta = Vt.T @ ((s / (s ** 2 + damping ** 2 + 1e-12)) * (U.T @ (V * W)))
+        nd = np.linalg.norm(delta)
+        if nd > step_cap:
+            delta = delta * (step_cap / nd)
+        theta = np.minimum(np.maximum(theta + delta, lower), upper)
+    else:
+        k += 1
+    if not success and best_error < current_error:
+        theta = best_theta
+        _, rot_err, trans_err = ik_geometric_error(fk_space(tab, theta), T_desired)
+        success = bool(rot_err < eomg and trans_err < ev)
+    return theta, bool(success), k + 1, restarts

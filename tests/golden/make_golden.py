@@ -20,6 +20,7 @@ What it does:
       trajectory_ur5.npz   : joint_trajectory / batch_joint_trajectory /
                              inverse_dynamics_trajectory / forward_dynamics_trajectory dumps
       cartesian_ur5.npz    : cartesian_trajectory dumps (`make_golden.py cartesian` regenerates only this)
+      ik.npz               : iterative_inverse_kinematics dumps, 10 problems per robot (`make_golden.py ik`)
       urdf/<robot>.urdf    : kinematic + inertial skeletons of the four URDFs (`make_golden.py urdf`)
       reference_cpu_timings.json : cold-cache per-point timings of the reference
 
@@ -282,6 +283,43 @@ def dump_cartesian():
     np.savez(os.path.join(HERE, "cartesian_ur5.npz"), **d)
 
 
+def dump_ik():
+    """iterative_inverse_kinematics (kinematics/ik.py:39-311) with its default flags, for the four robots: targets are
+    FK of random in-limit configurations, initial guesses are that configuration plus a perturbation (small: converges in
+    a few steps; large: tens of iterations, step cap + joint-limit clip active), plus one unreachable target per robot
+    that exhausts a small iteration budget without ever stalling for 20 iterations (so the reference's random
+    restart, which draws from NumPy's global stream, never fires and the dump is deterministic)."""
+    d = {}
+    for r, robot in enumerate(ROBOTS):
+        proc, sm, dyn = build(robot)
+        n = sm.S_list.shape[1]
+        lims = finite_limits(sm, n)
+        rng = np.random.default_rng(SEED + 500 + r)
+        T_des, th0, th, ok, it, params = [], [], [], [], [], []
+        for case in range(10):
+            q_true = rng.uniform(0.6 * lims[:, 0], 0.6 * lims[:, 1])
+            T = np.asarray(sm.forward_kinematics(q_true), dtype=np.float64)
+            spread = (0.05, 0.3, 0.8)[case % 3]
+            q0 = np.clip(q_true + rng.uniform(-spread, spread, n), lims[:, 0], lims[:, 1])
+            kw = dict(eomg=1e-6, ev=1e-6, max_iterations=400, damping=2e-2, step_cap=0.3)
+            if case == 9:  # unreachable: 3 m away, tiny budget
+                T = T.copy(); T[:3, 3] += np.array([3.0, 0.0, 0.0])
+                kw["max_iterations"] = 15
+            if case in (4, 7):  # non-default weights / damping / cap
+                kw.update(damping=5e-2, step_cap=0.15, weight_orientation=0.5, weight_position=2.0)
+            np.random.seed(1234)
+            sol, success, iters = sm.iterative_inverse_kinematics(T, q0, **kw)
+            T_des.append(T); th0.append(q0); th.append(np.asarray(sol, dtype=np.float64)); ok.append(bool(success)); it.append(int(iters))
+            params.append([kw["eomg"], kw["ev"], kw["max_iterations"], kw["damping"], kw["step_cap"],
+                           kw.get("weight_orientation", 1.0), kw.get("weight_position", 1.0)])
+        d[f"{robot}_T_desired"] = np.stack(T_des); d[f"{robot}_theta0"] = np.stack(th0); d[f"{robot}_theta"] = np.stack(th)
+        d[f"{robot}_success"] = np.array(ok); d[f"{robot}_iterations"] = np.array(it); d[f"{robot}_params"] = np.array(params)
+        d[f"{robot}_joint_limits"] = np.array([[-np.inf if lo is None else lo, np.inf if hi is None else hi]
+                                              for lo, hi in sm.joint_limits], dtype=np.float64)
+        print(robot, "ik:", ok, it, flush=True)
+    np.savez(os.path.join(HERE, "ik.npz"), **d)
+
+
 def dump_urdfs():
     """tests/golden/urdf/<robot>.urdf: the kinematic + inertial skeleton of the four benchmark robots' URDFs (robot
     description DATA; number strings kept verbatim so the tables stay bit-identical).  Visual / collision geometry,
@@ -343,6 +381,10 @@ def main():
         dump_urdfs()
         print("urdf skeletons dumped")
         return
+    if "ik" in sys.argv[1:]:  # only (re)generate the inverse-kinematics dump
+        dump_ik()
+        print("ik dumped")
+        return
     if "cartesian" in sys.argv[1:]:  # only (re)generate the Cartesian-trajectory dump
         dump_cartesian()
         print("cartesian dumped")
@@ -354,6 +396,7 @@ def main():
         print(f"{robot}: n={n} dumped", flush=True)
     dump_trajectories()
     dump_cartesian()
+    dump_ik()
     dump_urdfs()
     print("trajectories dumped", flush=True)
     time_reference()

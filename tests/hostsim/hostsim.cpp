@@ -4,6 +4,7 @@
 #include <cstring>
 
 #include "../../manipulapy_amd/csrc/mp_core.h"
+#include "../../manipulapy_amd/csrc/mp_ik.h"
 #include "../../manipulapy_amd/csrc/mp_model_compile.h"
 
 namespace {
@@ -196,4 +197,36 @@ extern "C" int hostsim_cartesian(const double* Xs, const double* Xe, long N, dou
     for (int k = 0; k < 9; ++k) ori[i * 9 + k] = o[k];
   }
   return 0;
+}
+
+// inverse kinematics (mp_ik_solve), `rows` independent problems: params = {eomg, ev, max_iterations, damping, step_cap, w_o, w_p}
+namespace {
+template <int N>
+void run_ik(const MpModel<double>& M, const MpIkParams& P, long rows, const double* Td, const double* th0, double* th, int* ok,
+            int* iters, int* restarts) {
+  for (long r = 0; r < rows; ++r) {
+    double T[16], q[N];
+    for (int k = 0; k < 16; ++k) T[k] = Td[r * 16 + k];
+    for (int j = 0; j < N; ++j) q[j] = th0[r * N + j];
+    iters[r] = mp_ik_solve<N>(M, P, T, r, q, ok[r], restarts[r]);
+    for (int j = 0; j < N; ++j) th[r * N + j] = q[j];
+  }
+}
+}  // namespace
+extern "C" int hostsim_ik(int n, const double* S, const double* Mcom, const double* G, const double* M_ee, const double* limits,
+                          const double* params, long rows, const double* Td, const double* th0, double* th, int* ok, int* iters,
+                          int* restarts, char* err, long errlen) {
+  MpModel<double> Md;
+  int rc = mp_compile_model(n, S, Mcom, G, M_ee, nullptr, nullptr, &Md, err, (size_t)errlen);
+  if (rc) return rc;
+  MpIkParams P;
+  P.eomg = params[0]; P.ev = params[1]; P.max_iterations = (int)params[2]; P.damping = params[3]; P.step_cap = params[4];
+  P.w_o = params[5]; P.w_p = params[6]; P.seed = 1234u;
+  for (int j = 0; j < MP_MAX_DOF; ++j) { P.lo[j] = j < n ? limits[2 * j] : -HUGE_VAL; P.hi[j] = j < n ? limits[2 * j + 1] : HUGE_VAL; }
+  switch (n) {
+#define CASE(N) case N: run_ik<N>(Md, P, rows, Td, th0, th, ok, iters, restarts); return 0;
+    CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
+#undef CASE
+  }
+  return 1;
 }

@@ -647,6 +647,60 @@ def test_planner_shared_by_threads(tables):
         assert not errors, errors
 
 
+@pytest.mark.parametrize("robot", ROBOTS)
+def test_inverse_kinematics_against_reference_runs_and_oracle(robot, tables):
+    """Batched IK kernel (mp_inverse_kinematics_*) against the reference's own iterative_inverse_kinematics runs
+    (tests/golden/ik.npz: quick / slow convergence, non-default weights, unreachable target) and, on a larger random batch,
+    against the pinned oracle; single-target API == batch API; solutions reproduce the target pose."""
+    import manipulapy_amd as mp
+    from manipulapy_amd import _hip
+
+    z = np.load(golden_path("ik.npz"))
+    tab = tables[robot]
+    lim = z[f"{robot}_joint_limits"]
+    sm, _, _ = mp.load_robot(robot)
+    sm.joint_limits = [(None if not np.isfinite(lo) else float(lo), None if not np.isfinite(hi) else float(hi)) for lo, hi in lim]
+    with mp.use_backend("hip"):
+        for i in range(10):
+            p = z[f"{robot}_params"][i]
+            th, ok, it = sm.iterative_inverse_kinematics(z[f"{robot}_T_desired"][i], z[f"{robot}_theta0"][i], eomg=p[0], ev=p[1],
+                                                         max_iterations=int(p[2]), damping=p[3], step_cap=p[4],
+                                                         weight_orientation=p[5], weight_position=p[6])
+            want_ok, want_it = bool(z[f"{robot}_success"][i]), int(z[f"{robot}_iterations"][i])
+            assert ok == want_ok and abs(it - want_it) <= (1 if want_ok else 0), (robot, i, ok, it, want_it)
+            np.testing.assert_allclose(th, z[f"{robot}_theta"][i], rtol=0, atol=1e-6 if want_ok else 1e-5)
+        # a batch of fresh problems: targets = FK of in-limit configurations, guesses nearby
+        rng = np.random.default_rng(31)
+        B = 200
+        fin = np.where(np.isfinite(lim), lim, np.array([-np.pi, np.pi]))
+        q_true = rng.uniform(0.6 * fin[:, 0], 0.6 * fin[:, 1], (B, tab.n))
+        T = np.stack([ref.fk_space(tab, q) for q in q_true])
+        q0 = np.clip(q_true + rng.uniform(-0.3, 0.3, (B, tab.n)), fin[:, 0], fin[:, 1])
+        th, ok, it = sm.batch_inverse_kinematics(T, q0, max_iterations=300)
+        assert ok.mean() > 0.5
+        for b in np.flatnonzero(ok)[:40]:
+            Tb = ref.fk_space(tab, th[b])
+            _, rot, tr = ref.ik_geometric_error(Tb, T[b])
+            assert rot < 1e-6 and tr < 1e-6
+        for b in range(0, B, 25):
+            o_th, o_ok, o_it, o_rs = ref.iterative_inverse_kinematics(tab, T[b], q0[b], max_iterations=300, joint_limits=lim,
+                                                                      rng=np.random.RandomState(0))
+            if o_rs == 0:  # restarts use different random streams by design
+                assert o_ok == ok[b] and abs(o_it - it[b]) <= 1
+                np.testing.assert_allclose(th[b], o_th, rtol=0, atol=1e-6 if o_ok else 1e-5)
+        with pytest.raises(NotImplementedError):
+            sm.iterative_inverse_kinematics(T[0], q0[0], adaptive_tuning=True)
+    ctx = _hip.HipContext(0)
+    try:
+        m = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee)
+        with pytest.raises(_hip.HipError):
+            ctx.inverse_kinematics_host(m, T[:2], q0[:2], max_iterations=0)
+        e = ctx.inverse_kinematics_host(m, T[:0], q0[:0])
+        assert e[0].shape == (0, tab.n)
+    finally:
+        ctx.destroy()
+
+
 def test_singularity_and_workspace_against_oracle(tables, dyn_golden):
     """Singularity mirror (reference singularity/singularity_analysis.py): condition number / smallest singular value of
     the GPU Jacobians == NumPy on the oracle's Jacobians; batch == per-sample; Monte-Carlo workspace points == oracle FK."""

@@ -116,7 +116,7 @@ def hostsim():
     """g++ build of the SAME templates the kernels instantiate (tests/hostsim/hostsim.cpp)."""
     src = os.path.join(ROOT, "tests", "hostsim", "hostsim.cpp")
     out = os.path.join(ROOT, "tests", "hostsim", "libmp_hostsim.so")
-    deps = [src] + [os.path.join(ROOT, "manipulapy_amd", "csrc", f) for f in ("mp_core.h", "mp_model.h", "mp_model_compile.cpp", "mp_model_compile.h")]
+    deps = [src] + [os.path.join(ROOT, "manipulapy_amd", "csrc", f) for f in ("mp_core.h", "mp_ik.h", "mp_model.h", "mp_model_compile.cpp", "mp_model_compile.h")]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
         subprocess.run([HOST_CXX, "-O2", "-std=c++17", "-ffp-contract=fast", "-shared", "-fPIC", "-o", out, src,
                         os.path.join(ROOT, "manipulapy_amd", "csrc", "mp_model_compile.cpp")], check=True)
@@ -156,8 +156,23 @@ def hostsim():
                                    *[o.ctypes.data_as(fp) for o in out])
         assert rc == 0
         return out
+    def ik(tab, limits, params, Td, th0):
+        c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        P = lambda a: a.ctypes.data_as(dp)
+        ip = ctypes.POINTER(ctypes.c_int)
+        S, Mc, G, Me, lim, par, Td, th0 = c(tab.S), c(tab.Mcom), c(tab.G), c(tab.M_ee), c(limits), c(params), c(Td), c(th0)
+        rows = Td.shape[0]
+        th = np.zeros((rows, tab.n))
+        ok, it, rs = (np.zeros(rows, dtype=np.int32) for _ in range(3))
+        err = ctypes.create_string_buffer(256)
+        rc = lib.hostsim_ik(tab.n, P(S), P(Mc), P(G), P(Me), P(lim), P(par), ctypes.c_long(rows), P(Td), P(th0), P(th),
+                            ok.ctypes.data_as(ip), it.ctypes.data_as(ip), rs.ctypes.data_as(ip), err, ctypes.c_long(256))
+        assert rc == 0, err.value
+        return th, ok.astype(bool), it, rs
+
     run.fd = fd
     run.cartesian = cartesian
+    run.ik = ik
     return run
 
 
@@ -296,7 +311,7 @@ def test_kernel_registry_semantics():
     for v in ("auto", "auto_tune", "standard", "vectorized", "memory_optimized", "warp_optimized", "cache_friendly"):
         assert f"trajectory.{v}" in names
     for n in ("trajectory.batch", "dynamics.inverse_trajectory", "dynamics.fused_trajectory_inverse", "kinematics.fk_jacobian",
-              "dynamics.mass_matrix", "dynamics.forward", "dynamics.forward_trajectory", "trajectory.cartesian"):
+              "dynamics.mass_matrix", "dynamics.forward", "dynamics.forward_trajectory", "trajectory.cartesian", "kinematics.inverse"):
         assert n in names
     with pytest.raises(KeyError, match="Available kernels: dynamics.forward, dynamics.forward_trajectory"):
         mp.get_registered_kernel("trajectory.nope")
@@ -431,3 +446,23 @@ def test_two_process_gloo_shard_and_gather(tmp_path):
     z = np.load(out)
     np.testing.assert_array_equal(z["gathered"], z["single"])
     assert z["world"] == 2 and abs(float(z["max_val"]) - 1.0) < 1e-12
+
+
+@pytest.mark.parametrize("robot", ROBOTS)
+def test_device_inverse_kinematics_on_host(robot, hostsim, tables):
+    """mp_ik_solve (csrc/mp_ik.h) compiled for the host against the reference's own iterative_inverse_kinematics runs
+    (tests/golden/ik.npz): same success flags, same iteration counts (the Cholesky step equals the reference's damped
+    pseudo-inverse step to rounding; a count may move by one where a tolerance test is decided in the last bits), same
+    solution for the converged problems, no stagnation restart on any fixture."""
+    z = np.load(golden_path("ik.npz"))
+    tab = tables[robot]
+    lim = z[f"{robot}_joint_limits"]
+    for i in range(10):
+        th, ok, it, rs = hostsim.ik(tab, lim, z[f"{robot}_params"][i], z[f"{robot}_T_desired"][i:i + 1], z[f"{robot}_theta0"][i:i + 1])
+        want_ok, want_it = bool(z[f"{robot}_success"][i]), int(z[f"{robot}_iterations"][i])
+        assert rs[0] == 0
+        assert ok[0] == want_ok, (robot, i)
+        assert abs(int(it[0]) - want_it) <= (1 if want_ok else 0), (robot, i, it[0], want_it)
+        tol = 1e-6 if want_ok else 1e-5  # an exhausted run is 400 accumulated steps of a different (equivalent) solve
+        np.testing.assert_allclose(th[0], z[f"{robot}_theta"][i], rtol=0, atol=tol, err_msg=f"{robot} case {i}")
+

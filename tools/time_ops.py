@@ -84,6 +84,28 @@ def main():
     ms = timed(ctx, lambda: ctx.potential_field(pos, [0.5, 0.5, 0.5], obs, P, O, 0.8, pot, grad))
     out.append(dict(op="potential_field", dtype="float32", rows=P, obstacles=O, ms=ms, rows_per_s=P / ms * 1e3,
                     alg_GBps=P * 28 / ms / 1e6, pair_per_s=P * O / ms * 1e3))
+    # batched inverse kinematics: targets reachable by construction, guesses 0.3 rad away
+    from oracle import ref_numpy as ref
+    for robot in ("ur5", "iiwa14"):
+        sm, dyn, lim = mp.load_robot(robot)
+        model = _hip.HipModel(dyn.S_list, dyn.Mlist_per_link, dyn.Glist, sm.M_list, lim)
+        n, B = model.n, 1 << 18
+        lim = np.asarray(lim, dtype=np.float64)
+        q_true = rng.uniform(0.6 * lim[:, 0], 0.6 * lim[:, 1], (B, n))
+        dq, dT = ctx.to_device(q_true), ctx.alloc(B * 128)
+        ctx.fk_jac_id(model, dq, None, None, B, dT, None, None)
+        q0 = np.clip(q_true + rng.uniform(-0.3, 0.3, (B, n)), lim[:, 0], lim[:, 1])
+        d0, dth = ctx.to_device(q0), ctx.alloc(B * n * 8)
+        dok, dit, drs = ctx.alloc(B * 4), ctx.alloc(B * 4), ctx.alloc(B * 4)
+        ms = timed(ctx, lambda: ctx.inverse_kinematics(model, dT, d0, B, dth, dok, dit, drs, joint_limits=lim, max_iterations=200),
+                   steps=3, warmup=1)
+        ok = dok.download((B,), np.int32); it = dit.download((B,), np.int32)
+        out.append(dict(op="inverse_kinematics", robot=robot, dtype="float64", problems=B, ms=ms, problems_per_s=B / ms * 1e3,
+                        success_rate=float(ok.mean()), mean_iterations=float(it.mean()), max_iterations=int(it.max()),
+                        iterations_per_s=float(it.sum()) / ms * 1e3))
+        for b in (dq, dT, d0, dth, dok, dit, drs):
+            b.free()
+        model.destroy()
     # host-buffer entry points (PCIe inclusive): what a drop-in caller holding NumPy arrays sees
     sm, dyn, lim = mp.load_robot("ur5")
     model = _hip.HipModel(dyn.S_list, dyn.Mlist_per_link, dyn.Glist, sm.M_list, lim)
