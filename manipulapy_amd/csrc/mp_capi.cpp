@@ -37,6 +37,7 @@ struct mp_ctx {
   std::map<uint64_t, MpSpec> specs;                    // model uid -> specialised kernels (mp_model_specialize)
   int compute_units = 0;
   bool capturing = false;                              // between mp_graph_begin and mp_graph_end
+  void* queue_counter = nullptr;                       // 8-byte work-queue head of the IK kernel (lazily allocated)
   std::recursive_mutex mu;                             // serialises the entry points of this context (CTX_ENTER)
 };
 struct mp_model {
@@ -492,6 +493,7 @@ int mp_ctx_destroy(mp_ctx* ctx) {
   (void)hipDeviceSynchronize();
   for (auto& kv : ctx->specs) if (kv.second.mod) (void)hipModuleUnload(kv.second.mod);
   for (auto& kv : ctx->live) (void)hipFree(kv.first);
+  if (ctx->queue_counter) (void)hipFree(ctx->queue_counter);
   if (ctx->compute) (void)hipStreamDestroy(ctx->compute);
   if (ctx->copy) (void)hipStreamDestroy(ctx->copy);
   if (ctx->copy_out) (void)hipStreamDestroy(ctx->copy_out);
@@ -1137,7 +1139,12 @@ int mp_inverse_kinematics_f64(mp_ctx* ctx, const mp_model* model, const double* 
   if (int rc = ik_params("mp_inverse_kinematics_f64", model, joint_limits, eomg, ev, max_iterations, damping, step_cap,
                          weight_orientation, weight_position, seed, &P))
     return rc;
-  HIP_TRY(mpk_ik(ctx->compute, model->d, P, d_T_desired, d_theta0, (long)B, d_theta, d_success, d_iterations, d_restarts));
+  if (!ctx->queue_counter) {
+    REQUIRE(!ctx->capturing, "mp_inverse_kinematics_f64: first use allocates; call it once before capturing a launch graph");
+    HIP_TRY(hipMalloc(&ctx->queue_counter, 256));
+  }
+  HIP_TRY(mpk_ik(ctx->compute, model->d, P, d_T_desired, d_theta0, (long)B, d_theta, d_success, d_iterations, d_restarts,
+                 (unsigned long long*)ctx->queue_counter, ctx->compute_units));
   return MP_OK;
 }
 

@@ -70,84 +70,118 @@ MP_HD double mp_ik_normal(unsigned seed, long problem, int restart, int joint) {
   return sqrt(-2.0 * log(a)) * cos(6.283185307179586476925 * b);
 }
 
+// Per-problem state of the iteration, so that a lane can interleave "fetch the next problem" with "advance the current
+// one" (the work-queue kernel) instead of idling until the slowest problem of its wave is done.
+template <int N>
+struct MpIkState {
+  double theta[N], best[N], Td[16];
+  double best_err, cur_err;
+  int stall, k, restarts, success;
+  long problem;
+};
+
+template <int N>
+MP_HD void mp_ik_begin(MpIkState<N>& S, long problem) {
+#pragma unroll
+  for (int j = 0; j < N; ++j) S.best[j] = S.theta[j];
+  S.best_err = HUGE_VAL;
+  S.cur_err = HUGE_VAL;
+  S.stall = 0; S.k = 0; S.restarts = 0; S.success = 0;
+  S.problem = problem;
+}
+
+// One trip of the reference's loop (kinematics/ik.py:182-269).  Returns true when the problem is finished; S.theta is
+// then the answer, S.success the flag and S.k + 1 the reference's iteration count.
+template <int N, typename MT>
+MP_HD bool mp_ik_iterate(const MT& M, const MpIkParams& P, MpIkState<N>& S) {
+  if (S.k >= P.max_iterations) {  // exhausted (the for / else): fall back to the best configuration seen (:273-280)
+    if (S.best_err < S.cur_err) {
+#pragma unroll
+      for (int j = 0; j < N; ++j) S.theta[j] = S.best[j];
+      MpJointState<double, N> js;
+      mp_joint_state<double, N>(M, S.theta, js);
+      double Tc[16], J[6 * N], V[6], rot, tr;
+      mp_fk_jac<double, N, false>(M, js, Tc, J);
+      mp_ik_error(Tc, S.Td, V, rot, tr);
+      S.success = (rot < P.eomg && tr < P.ev) ? 1 : 0;
+    }
+    return true;
+  }
+  MpJointState<double, N> js;
+  mp_joint_state<double, N>(M, S.theta, js);
+  double Tc[16], J[6 * N], V[6], rot, tr;
+  mp_fk_jac<double, N, true>(M, js, Tc, J);
+  mp_ik_error(Tc, S.Td, V, rot, tr);
+  S.cur_err = rot + tr;
+  if (rot < P.eomg && tr < P.ev) { S.success = 1; return true; }
+  if (S.cur_err < S.best_err) {
+    S.best_err = S.cur_err;
+    S.stall = 0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) S.best[j] = S.theta[j];
+  } else {
+    ++S.stall;
+  }
+  if (S.stall > 20) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const double t = S.best[j] + 0.1 * mp_ik_normal(P.seed, S.problem, S.restarts, j);
+      S.theta[j] = t < P.lo[j] ? P.lo[j] : (t > P.hi[j] ? P.hi[j] : t);
+    }
+    S.stall = 0;
+    ++S.restarts;
+    ++S.k;
+    return false;
+  }
+  const double lam = P.damping * P.damping + 1e-12;
+  double A[6][6], y[6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    y[r] = V[r] * (r < 3 ? P.w_o : P.w_p);
+#pragma unroll
+    for (int c = 0; c <= r; ++c) {
+      double s = (r == c) ? lam : 0.0;
+#pragma unroll
+      for (int j = 0; j < N; ++j) s += J[r * N + j] * J[c * N + j];
+      A[r][c] = s;
+      A[c][r] = s;
+    }
+  }
+  mp_spd_solve<double, 6>(A, y);
+  double d[N], nd = 0.0;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    double s = 0.0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) s += J[r * N + j] * y[r];
+    d[j] = s;
+    nd += s * s;
+  }
+  nd = sqrt(nd);
+  const double scale = nd > P.step_cap ? P.step_cap / nd : 1.0;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const double t = S.theta[j] + d[j] * scale;
+    S.theta[j] = t < P.lo[j] ? P.lo[j] : (t > P.hi[j] ? P.hi[j] : t);
+  }
+  ++S.k;
+  return false;
+}
+
 // theta: in = initial guess, out = solution.  Returns the reference's iteration count; sets success / restarts.
 template <int N, typename MT>
 MP_HD int mp_ik_solve(const MT& M, const MpIkParams& P, const double (&Td)[16], long problem, double (&theta)[N], int& success,
                       int& restarts) {
-  double best[N], best_err = HUGE_VAL, cur_err = HUGE_VAL;
+  MpIkState<N> S;
 #pragma unroll
-  for (int j = 0; j < N; ++j) best[j] = theta[j];
-  int stall = 0, k = 0;
-  success = 0;
-  restarts = 0;
-  const double lam = P.damping * P.damping + 1e-12;
-  for (k = 0; k < P.max_iterations; ++k) {
-    MpJointState<double, N> js;
-    mp_joint_state<double, N>(M, theta, js);
-    double Tc[16], J[6 * N], V[6], rot, tr;
-    mp_fk_jac<double, N, true>(M, js, Tc, J);
-    mp_ik_error(Tc, Td, V, rot, tr);
-    cur_err = rot + tr;
-    if (rot < P.eomg && tr < P.ev) { success = 1; break; }
-    if (cur_err < best_err) {
-      best_err = cur_err;
-      stall = 0;
+  for (int j = 0; j < N; ++j) S.theta[j] = theta[j];
 #pragma unroll
-      for (int j = 0; j < N; ++j) best[j] = theta[j];
-    } else {
-      ++stall;
-    }
-    if (stall > 20) {
+  for (int k = 0; k < 16; ++k) S.Td[k] = Td[k];
+  mp_ik_begin(S, problem);
+  while (!mp_ik_iterate<N>(M, P, S)) {}
 #pragma unroll
-      for (int j = 0; j < N; ++j) {
-        const double t = best[j] + 0.1 * mp_ik_normal(P.seed, problem, restarts, j);
-        theta[j] = t < P.lo[j] ? P.lo[j] : (t > P.hi[j] ? P.hi[j] : t);
-      }
-      stall = 0;
-      ++restarts;
-      continue;
-    }
-    double A[6][6], y[6];
-#pragma unroll
-    for (int r = 0; r < 6; ++r) {
-      y[r] = V[r] * (r < 3 ? P.w_o : P.w_p);
-#pragma unroll
-      for (int c = 0; c <= r; ++c) {
-        double s = (r == c) ? lam : 0.0;
-#pragma unroll
-        for (int j = 0; j < N; ++j) s += J[r * N + j] * J[c * N + j];
-        A[r][c] = s;
-        A[c][r] = s;
-      }
-    }
-    mp_spd_solve<double, 6>(A, y);
-    double d[N], nd = 0.0;
-#pragma unroll
-    for (int j = 0; j < N; ++j) {
-      double s = 0.0;
-#pragma unroll
-      for (int r = 0; r < 6; ++r) s += J[r * N + j] * y[r];
-      d[j] = s;
-      nd += s * s;
-    }
-    nd = sqrt(nd);
-    const double scale = nd > P.step_cap ? P.step_cap / nd : 1.0;
-#pragma unroll
-    for (int j = 0; j < N; ++j) {
-      const double t = theta[j] + d[j] * scale;
-      theta[j] = t < P.lo[j] ? P.lo[j] : (t > P.hi[j] ? P.hi[j] : t);
-    }
-  }
-  // k == max_iterations after exhaustion, matching the reference's `else: k += 1`
-  if (!success && best_err < cur_err) {
-#pragma unroll
-    for (int j = 0; j < N; ++j) theta[j] = best[j];
-    MpJointState<double, N> js;
-    mp_joint_state<double, N>(M, theta, js);
-    double Tc[16], J[6 * N], V[6], rot, tr;
-    mp_fk_jac<double, N, false>(M, js, Tc, J);
-    mp_ik_error(Tc, Td, V, rot, tr);
-    success = (rot < P.eomg && tr < P.ev) ? 1 : 0;
-  }
-  return k + 1;
+  for (int j = 0; j < N; ++j) theta[j] = S.theta[j];
+  success = S.success;
+  restarts = S.restarts;
+  return S.k + 1;
 }

@@ -46,6 +46,7 @@ hipError_t mpk_potential_field(hipStream_t s, const float* pos, const float* goa
 
 // B damped-least-squares inverse-kinematics problems (csrc/mp_ik.h): Tdes (B,4,4), theta0 / theta (B,n) float64
 struct MpIkParams;
+// queue_counter: 8 bytes of device memory owned by the caller (zeroed here on the stream before the launch)
 hipError_t mpk_ik(hipStream_t s, const MpModel<double>& M, const MpIkParams& P, const double* Tdes, const double* theta0, long B,
-                  double* theta, int* success, int* iterations, int* restarts);
+                  double* theta, int* success, int* iterations, int* restarts, unsigned long long* queue_counter, int compute_units);
 

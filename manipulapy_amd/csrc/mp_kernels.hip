@@ -269,24 +269,36 @@ __global__ __launch_bounds__(kBlock) void k_potential_field(const float* __restr
 }
 
 // ------------------------------------------------------------------- batched inverse kinematics
-// one lane per pose target; lanes of a wave leave the iteration loop at different counts (the wave runs as long as
-// its slowest problem).  float64 throughout: the reference's default tolerances are 1e-6 rad / 1e-6 m.
+// Work queue: a lane that finishes its pose target takes the next unsolved one from a global counter instead of idling
+// until the slowest problem of its wave is done (iteration counts vary from a handful to max_iterations; with one
+// fixed problem per lane nearly every wave contains a straggler).  Every trip of the loop either fetches a problem or
+// advances one by a single iteration, so the lanes of a wave keep executing the same code on different problems.
+// Exit: the counter passes B for every lane eventually (it only grows), so every wave drains.  float64 throughout: the
+// reference's default tolerances are 1e-6 rad / 1e-6 m.
 template <int N>
 __global__ __launch_bounds__(kBlock) void k_ik(const MpModel<double> M, const MpIkParams P, const double* __restrict__ Tdes,
                                                const double* __restrict__ theta0, long B, double* __restrict__ theta,
                                                int* __restrict__ success, int* __restrict__ iterations,
-                                               int* __restrict__ restarts) {
-  const long b = (long)blockIdx.x * kBlock + threadIdx.x;
-  if (b >= B) return;
-  double Td[16], q[N];
-  RunIO<double, 16>::load(Tdes, b, Td);
-  RunIO<double, N>::load(theta0, b, q);
-  int ok = 0, rs = 0;
-  const int it = mp_ik_solve<N>(M, P, Td, b, q, ok, rs);
-  RunIO<double, N>::store(theta, b, q);
-  success[b] = ok;
-  iterations[b] = it;
-  restarts[b] = rs;
+                                               int* __restrict__ restarts, unsigned long long* __restrict__ next) {
+  MpIkState<N> S;
+  bool have = false;
+  for (;;) {
+    if (!have) {
+      const long b = (long)atomicAdd(next, 1ull);
+      if (b >= B) break;
+      RunIO<double, 16>::load(Tdes, b, S.Td);
+      RunIO<double, N>::load(theta0, b, S.theta);
+      mp_ik_begin(S, b);
+      have = true;
+    }
+    if (mp_ik_iterate<N>(M, P, S)) {
+      RunIO<double, N>::store(theta, S.problem, S.theta);
+      success[S.problem] = S.success;
+      iterations[S.problem] = S.k + 1;
+      restarts[S.problem] = S.restarts;
+      have = false;
+    }
+  }
 }
 
 inline unsigned grid_for(long rows) { return (unsigned)((rows + kBlock - 1) / kBlock); }
@@ -491,9 +503,14 @@ hipError_t mpk_cartesian_traj(hipStream_t s, const double* Xstart, const double*
 }
 
 hipError_t mpk_ik(hipStream_t s, const MpModel<double>& M, const MpIkParams& P, const double* Tdes, const double* theta0, long B,
-                  double* theta, int* success, int* iterations, int* restarts) {
+                  double* theta, int* success, int* iterations, int* restarts, unsigned long long* queue_counter, int compute_units) {
   if (B <= 0) return hipSuccess;
-  MP_DISPATCH_N(M.n, { hipLaunchKernelGGL((k_ik<N>), dim3(grid_for(B)), dim3(kBlock), 0, s, M, P, Tdes, theta0, B, theta, success, iterations, restarts); })
+  hipError_t e = hipMemsetAsync(queue_counter, 0, sizeof(unsigned long long), s);
+  if (e != hipSuccess) return e;
+  // resident lanes only (two 256-thread blocks per CU; fp64 IK needs > 128 VGPRs): the queue feeds them
+  const long want = (B + kBlock - 1) / kBlock, cap = 2L * (compute_units > 0 ? compute_units : 256);
+  const unsigned grid = (unsigned)(want < cap ? want : cap);
+  MP_DISPATCH_N(M.n, { hipLaunchKernelGGL((k_ik<N>), dim3(grid), dim3(kBlock), 0, s, M, P, Tdes, theta0, B, theta, success, iterations, restarts, queue_counter); })
   return hipGetLastError();
 }
 
