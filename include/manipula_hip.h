@@ -197,14 +197,15 @@ int mp_potential_field_f32(mp_ctx* ctx, const float* d_positions, const float* g
                            int64_t O, float influence_distance, float* d_potential, float* d_gradient);
 
 /* Batched inverse kinematics: B independent pose targets (B,4,4) from initial guesses (B,n), float64.  One lane runs
- * the reference's damped-least-squares iteration (kinematics/ik.py:39-311, default flags: no adaptive tuning, no
- * backtracking) for one target: geometric error, damped step through a 6x6 Cholesky (== the reference's damped
+ * the reference's damped-least-squares iteration (kinematics/ik.py:39-311; adaptive_tuning / backtracking select its two options, default off: no adaptive tuning, no
+ * backtracking unless asked for) for one target: geometric error, damped step through a 6x6 Cholesky (== the reference's damped
  * pseudo-inverse), step cap, joint-limit projection (joint_limits: host (n,2), +-inf = open, NULL = all open), best
  * solution tracking, stagnation restart (counter-hashed noise seeded by `seed`; the reference draws from NumPy's
  * global stream).  iterations follows the reference's count (k + 1, or max_iterations + 1 when exhausted). */
 int mp_inverse_kinematics_f64(mp_ctx* ctx, const mp_model* model, const double* d_T_desired, const double* d_theta0, int64_t B,
                               const double* joint_limits, double eomg, double ev, int max_iterations, double damping,
-                              double step_cap, double weight_orientation, double weight_position, uint32_t seed,
+                              double step_cap, double weight_orientation, double weight_position, int adaptive_tuning, int backtracking,
+                              uint32_t seed,
                               double* d_theta, int32_t* d_success, int32_t* d_iterations, int32_t* d_restarts);
 
 /* ---- hot path, host pointers (what a Python gpu_launcher calls): H2D, launch, D2H, synchronise - */
@@ -239,7 +240,8 @@ int mp_potential_field_host_f32(mp_ctx* ctx, const float* positions, const float
 
 int mp_inverse_kinematics_host_f64(mp_ctx* ctx, const mp_model* model, const double* T_desired, const double* theta0, int64_t B,
                                    const double* joint_limits, double eomg, double ev, int max_iterations, double damping,
-                                   double step_cap, double weight_orientation, double weight_position, uint32_t seed,
+                                   double step_cap, double weight_orientation, double weight_position, int adaptive_tuning, int backtracking,
+                              uint32_t seed,
                                    double* theta, int32_t* success, int32_t* iterations, int32_t* restarts);
 
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI (new; the reference is single-device) ------

@@ -61,8 +61,8 @@ SIGNATURES = {
     "mp_event_elapsed_ms": (ctypes.c_int, [_vp, _vp, ctypes.POINTER(ctypes.c_float)]),
     "mp_host_alloc": (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.POINTER(_vp)]),
     "mp_host_free": (ctypes.c_int, [_vp, _vp]),
-    "mp_inverse_kinematics_f64": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int64, _c_dp, ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_uint32, _vp, _vp, _vp, _vp]),
-    "mp_inverse_kinematics_host_f64": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int64, _c_dp, ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_uint32, _vp, _vp, _vp, _vp]),
+    "mp_inverse_kinematics_f64": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int64, _c_dp, ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, _vp, _vp, _vp, _vp]),
+    "mp_inverse_kinematics_host_f64": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int64, _c_dp, ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, _vp, _vp, _vp, _vp]),
     "mp_graph_begin": (ctypes.c_int, [_vp]),
     "mp_graph_end": (ctypes.c_int, [_vp, ctypes.POINTER(_vp)]),
     "mp_graph_launch": (ctypes.c_int, [_vp, _vp]),
@@ -576,7 +576,7 @@ class HipContext:
 
     def inverse_kinematics_host(self, model: HipModel, T_desired, theta0, joint_limits=None, eomg=1e-6, ev=1e-6,
                                 max_iterations=10000, damping=2e-2, step_cap=0.3, weight_orientation=1.0, weight_position=1.0,
-                                seed=1234):
+                                adaptive_tuning=False, backtracking=False, seed=1234):
         """B damped-least-squares IK problems in one launch: T_desired (B,4,4), theta0 (B,n) ->
         (theta (B,n) float64, success (B,) bool, iterations (B,) int32, restarts (B,) int32).
         joint_limits: (n,2) with +-inf / None for open ends, or None for no limits."""
@@ -594,17 +594,19 @@ class HipContext:
         ok, it, rs = (np.zeros(B, dtype=np.int32) for _ in range(3))
         _check(self.lib.mp_inverse_kinematics_host_f64(
             self.handle, model.handle, _dptr(T), _dptr(th0), B, _dptr(lim), float(eomg), float(ev), int(max_iterations), float(damping),
-            float(step_cap), float(weight_orientation), float(weight_position), int(seed) & 0xFFFFFFFF, _dptr(th),
+            float(step_cap), float(weight_orientation), float(weight_position), int(bool(adaptive_tuning)), int(bool(backtracking)),
+            int(seed) & 0xFFFFFFFF, _dptr(th),
             ok.ctypes.data_as(_vp), it.ctypes.data_as(_vp), rs.ctypes.data_as(_vp)))
         return th, ok.astype(bool), it, rs
 
     def inverse_kinematics(self, model, d_T_desired, d_theta0, B, d_theta, d_success, d_iterations, d_restarts, joint_limits=None,
                            eomg=1e-6, ev=1e-6, max_iterations=10000, damping=2e-2, step_cap=0.3, weight_orientation=1.0,
-                           weight_position=1.0, seed=1234):
+                           weight_position=1.0, adaptive_tuning=False, backtracking=False, seed=1234):
         lim = None if joint_limits is None else np.ascontiguousarray(joint_limits, dtype=np.float64)
         _check(self.lib.mp_inverse_kinematics_f64(
             self.handle, model.handle, _p(d_T_desired), _p(d_theta0), int(B), _dptr(lim), float(eomg), float(ev), int(max_iterations),
-            float(damping), float(step_cap), float(weight_orientation), float(weight_position), int(seed) & 0xFFFFFFFF, _p(d_theta),
+            float(damping), float(step_cap), float(weight_orientation), float(weight_position), int(bool(adaptive_tuning)),
+            int(bool(backtracking)), int(seed) & 0xFFFFFFFF, _p(d_theta),
             _p(d_success), _p(d_iterations), _p(d_restarts)))
 
     def mass_matrix_host(self, model: HipModel, q) -> np.ndarray:

@@ -1112,11 +1112,13 @@ int mp_potential_field_host_f32(mp_ctx* ctx, const float* positions, const float
 }
 
 static int ik_params(const char* fn, const mp_model* model, const double* joint_limits, double eomg, double ev, int max_iterations,
-                     double damping, double step_cap, double w_o, double w_p, uint32_t seed, MpIkParams* P) {
+                     double damping, double step_cap, double w_o, double w_p, int adaptive, int backtracking, uint32_t seed,
+                     MpIkParams* P) {
   REQUIRE(max_iterations >= 1, "%s: max_iterations must be at least 1 (got %d)", fn, max_iterations);
   REQUIRE(eomg > 0 && ev > 0 && damping >= 0 && step_cap > 0, "%s: eomg, ev, step_cap must be positive and damping non-negative", fn);
   P->eomg = eomg; P->ev = ev; P->damping = damping; P->step_cap = step_cap; P->w_o = w_o; P->w_p = w_p;
   P->max_iterations = max_iterations; P->seed = seed;
+  P->adaptive_tuning = adaptive ? 1 : 0; P->backtracking = backtracking ? 1 : 0;
   const int n = model->d.n;
   for (int j = 0; j < MP_MAX_DOF; ++j) {
     P->lo[j] = (j < n && joint_limits) ? joint_limits[2 * j] : -HUGE_VAL;
@@ -1128,7 +1130,8 @@ static int ik_params(const char* fn, const mp_model* model, const double* joint_
 
 int mp_inverse_kinematics_f64(mp_ctx* ctx, const mp_model* model, const double* d_T_desired, const double* d_theta0, int64_t B,
                               const double* joint_limits, double eomg, double ev, int max_iterations, double damping,
-                              double step_cap, double weight_orientation, double weight_position, uint32_t seed,
+                              double step_cap, double weight_orientation, double weight_position, int adaptive_tuning, int backtracking,
+                              uint32_t seed,
                               double* d_theta, int32_t* d_success, int32_t* d_iterations, int32_t* d_restarts) {
   CHECK_COMMON("mp_inverse_kinematics_f64");
   REQUIRE(B >= 0, "mp_inverse_kinematics_f64: negative problem count");
@@ -1137,7 +1140,7 @@ int mp_inverse_kinematics_f64(mp_ctx* ctx, const mp_model* model, const double* 
   REQUIRE(aligned16(d_T_desired) && aligned16(d_theta0) && aligned16(d_theta), "mp_inverse_kinematics_f64: device pointers must be 16-byte aligned");
   MpIkParams P;
   if (int rc = ik_params("mp_inverse_kinematics_f64", model, joint_limits, eomg, ev, max_iterations, damping, step_cap,
-                         weight_orientation, weight_position, seed, &P))
+                         weight_orientation, weight_position, adaptive_tuning, backtracking, seed, &P))
     return rc;
   if (!ctx->queue_counter) {
     REQUIRE(!ctx->capturing, "mp_inverse_kinematics_f64: first use allocates; call it once before capturing a launch graph");
@@ -1150,7 +1153,8 @@ int mp_inverse_kinematics_f64(mp_ctx* ctx, const mp_model* model, const double* 
 
 int mp_inverse_kinematics_host_f64(mp_ctx* ctx, const mp_model* model, const double* T_desired, const double* theta0, int64_t B,
                                    const double* joint_limits, double eomg, double ev, int max_iterations, double damping,
-                                   double step_cap, double weight_orientation, double weight_position, uint32_t seed,
+                                   double step_cap, double weight_orientation, double weight_position, int adaptive_tuning, int backtracking,
+                              uint32_t seed,
                                    double* theta, int32_t* success, int32_t* iterations, int32_t* restarts) {
   CHECK_COMMON("mp_inverse_kinematics_host_f64");
   REQUIRE(B >= 0, "mp_inverse_kinematics_host_f64: negative problem count");
@@ -1168,7 +1172,8 @@ int mp_inverse_kinematics_host_f64(mp_ctx* ctx, const mp_model* model, const dou
   H2D(dT, T_desired, tb);
   H2D(d0, theta0, qb);
   if (int rc = mp_inverse_kinematics_f64(ctx, model, (double*)dT, (double*)d0, B, joint_limits, eomg, ev, max_iterations, damping,
-                                         step_cap, weight_orientation, weight_position, seed, (double*)dq, (int32_t*)dok,
+                                         step_cap, weight_orientation, weight_position, adaptive_tuning, backtracking, seed, (double*)dq,
+                                         (int32_t*)dok,
                                          (int32_t*)dit, (int32_t*)drs))
     return rc;
   D2H(theta, dq, qb);

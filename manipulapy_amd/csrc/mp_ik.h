@@ -1,9 +1,10 @@
 // Batched damped-least-squares inverse kinematics: one lane solves one pose target.
 //
-// Follows the reference's iterative_inverse_kinematics with its default flags (kinematics/ik.py:39-311; adaptive
-// tuning and backtracking off): geometric error (:88-140), damped step (:142-162), step cap (:243-246), joint-limit
-// projection (:164-180), best-solution tracking (:196-203, :273-280), stagnation restart (:205-213), iteration
-// count convention (k + 1 on convergence, max_iterations + 1 on exhaustion: the for / else at :267-269).
+// Follows the reference's iterative_inverse_kinematics (kinematics/ik.py:39-311): geometric error (:88-140), damped
+// step (:142-162), step cap (:243-246), joint-limit projection (:164-180), best-solution tracking (:196-203,
+// :273-280), stagnation restart (:205-213), the optional Levenberg-Marquardt style adaptive damping / step cap
+// (:215-231) and the optional five-scale line search (:248-265), iteration count convention (k + 1 on convergence,
+// max_iterations + 1 on exhaustion: the for / else at :267-269).
 //
 // The step: the reference forms  V diag(s / (s^2 + lambda^2 + 1e-12)) U^T e  from an SVD of J.  That vector equals
 // J^T (J J^T + (lambda^2 + 1e-12) I)^-1 e, a 6 x 6 SPD system solved here with the in-register Cholesky of mp_core.h -
@@ -20,6 +21,7 @@ struct MpIkParams {
   double eomg, ev, damping, step_cap, w_o, w_p;
   int max_iterations;
   unsigned seed;
+  int adaptive_tuning, backtracking;
   double lo[MP_MAX_DOF], hi[MP_MAX_DOF];
 };
 
@@ -76,12 +78,14 @@ template <int N>
 struct MpIkState {
   double theta[N], best[N], Td[16];
   double best_err, cur_err;
+  double damping, step_cap, nu, prev_err;  // the adaptive-tuning state (constant when the option is off)
   int stall, k, restarts, success;
   long problem;
 };
 
 template <int N>
-MP_HD void mp_ik_begin(MpIkState<N>& S, long problem) {
+MP_HD void mp_ik_begin(MpIkState<N>& S, const MpIkParams& P, long problem) {
+  S.damping = P.damping; S.step_cap = P.step_cap; S.nu = 2.0; S.prev_err = HUGE_VAL;
 #pragma unroll
   for (int j = 0; j < N; ++j) S.best[j] = S.theta[j];
   S.best_err = HUGE_VAL;
@@ -129,11 +133,27 @@ MP_HD bool mp_ik_iterate(const MT& M, const MpIkParams& P, MpIkState<N>& S) {
       S.theta[j] = t < P.lo[j] ? P.lo[j] : (t > P.hi[j] ? P.hi[j] : t);
     }
     S.stall = 0;
+    S.damping = P.damping;  // the restart resets the damping and its growth factor, not the step cap (:209-212)
+    S.nu = 2.0;
     ++S.restarts;
     ++S.k;
     return false;
   }
-  const double lam = P.damping * P.damping + 1e-12;
+  if (P.adaptive_tuning && S.k > 0) {
+    if (S.cur_err < S.prev_err * 0.75) {  // good progress: towards Newton
+      S.damping = fmax(1e-6, S.damping / 3.0);
+      S.step_cap = fmin(P.step_cap * 1.5, S.step_cap * 1.2);
+      S.nu = 2.0;
+    } else if (S.cur_err < S.prev_err * 0.95) {
+      S.damping = fmax(1e-6, S.damping / 1.5);
+    } else if (S.cur_err > S.prev_err) {  // got worse: towards gradient descent
+      S.damping = fmin(0.5, S.damping * S.nu);
+      S.nu = fmin(S.nu * 1.5, 8.0);
+      S.step_cap = fmax(0.01, S.step_cap * 0.7);
+    }
+  }
+  S.prev_err = S.cur_err;
+  const double lam = S.damping * S.damping + 1e-12;
   double A[6][6], y[6];
 #pragma unroll
   for (int r = 0; r < 6; ++r) {
@@ -158,11 +178,46 @@ MP_HD bool mp_ik_iterate(const MT& M, const MpIkParams& P, MpIkState<N>& S) {
     nd += s * s;
   }
   nd = sqrt(nd);
-  const double scale = nd > P.step_cap ? P.step_cap / nd : 1.0;
+  const double scale = nd > S.step_cap ? S.step_cap / nd : 1.0;
+  if (P.backtracking) {  // try five scales of the step, keep the best pose error (:248-265)
+    const double scales[5] = {1.0, 0.5, 0.25, 0.125, 0.75};
+    double keep[N], keep_err = S.cur_err;
 #pragma unroll
-  for (int j = 0; j < N; ++j) {
-    const double t = S.theta[j] + d[j] * scale;
-    S.theta[j] = t < P.lo[j] ? P.lo[j] : (t > P.hi[j] ? P.hi[j] : t);
+    for (int j = 0; j < N; ++j) keep[j] = S.theta[j];
+    for (int c = 0; c < 5; ++c) {
+      double cand[N];
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        const double t = S.theta[j] + scales[c] * (d[j] * scale);
+        cand[j] = t < P.lo[j] ? P.lo[j] : (t > P.hi[j] ? P.hi[j] : t);
+      }
+      MpJointState<double, N> jc;
+      mp_joint_state<double, N>(M, cand, jc);
+      double Tt[16], Jt[6 * N], Vt[6], rt, tt;
+      mp_fk_jac<double, N, false>(M, jc, Tt, Jt);
+      mp_ik_error(Tt, S.Td, Vt, rt, tt);
+      if (rt + tt < keep_err) {
+        keep_err = rt + tt;
+#pragma unroll
+        for (int j = 0; j < N; ++j) keep[j] = cand[j];
+      }
+    }
+    if (keep_err < S.cur_err * 1.1) {
+#pragma unroll
+      for (int j = 0; j < N; ++j) S.theta[j] = keep[j];
+    } else {  // every scale failed by more than 10 %: a small step anyway
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        const double t = S.theta[j] + 0.1 * (d[j] * scale);
+        S.theta[j] = t < P.lo[j] ? P.lo[j] : (t > P.hi[j] ? P.hi[j] : t);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const double t = S.theta[j] + d[j] * scale;
+      S.theta[j] = t < P.lo[j] ? P.lo[j] : (t > P.hi[j] ? P.hi[j] : t);
+    }
   }
   ++S.k;
   return false;
@@ -177,7 +232,7 @@ MP_HD int mp_ik_solve(const MT& M, const MpIkParams& P, const double (&Td)[16], 
   for (int j = 0; j < N; ++j) S.theta[j] = theta[j];
 #pragma unroll
   for (int k = 0; k < 16; ++k) S.Td[k] = Td[k];
-  mp_ik_begin(S, problem);
+  mp_ik_begin(S, P, problem);
   while (!mp_ik_iterate<N>(M, P, S)) {}
 #pragma unroll
   for (int j = 0; j < N; ++j) theta[j] = S.theta[j];

@@ -288,7 +288,7 @@ __global__ __launch_bounds__(kBlock) void k_ik(const MpModel<double> M, const Mp
       if (b >= B) break;
       RunIO<double, 16>::load(Tdes, b, S.Td);
       RunIO<double, N>::load(theta0, b, S.theta);
-      mp_ik_begin(S, b);
+      mp_ik_begin(S, P, b);
       have = true;
     }
     if (mp_ik_iterate<N>(M, P, S)) {

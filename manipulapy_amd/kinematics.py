@@ -111,29 +111,30 @@ class SerialManipulator:
     # ---- inverse kinematics (reference kinematics/ik.py:39-311)
     def batch_inverse_kinematics(self, T_desired_batch, thetalist0_batch, eomg: float = 1e-6, ev: float = 1e-6,
                                  max_iterations: int = 10000, damping: float = 2e-2, step_cap: float = 0.3,
-                                 weight_orientation: float = 1.0, weight_position: float = 1.0, seed: int = 1234):
+                                 weight_orientation: float = 1.0, weight_position: float = 1.0, adaptive_tuning: bool = False,
+                                 backtracking: bool = False, seed: int = 1234):
         """B pose targets (B,4,4) from B initial guesses (B,n), one kernel launch, one lane per target:
         (theta (B,n), success (B,) bool, iterations (B,) int).  Each problem runs the reference's damped-least-squares
-        iteration with its default flags; `self.joint_limits` is the projection box (None = open end)."""
+        iteration (optionally with its adaptive damping and its five-scale line search); `self.joint_limits` is the
+        projection box (None = open end)."""
         theta, ok, it, _ = execute_registered_kernel(
             "kinematics.inverse", self._kin_model(), T_desired_batch, thetalist0_batch, joint_limits=self.joint_limits, eomg=eomg,
             ev=ev, max_iterations=max_iterations, damping=damping, step_cap=step_cap, weight_orientation=weight_orientation,
-            weight_position=weight_position, seed=seed)
+            weight_position=weight_position, adaptive_tuning=adaptive_tuning, backtracking=backtracking, seed=seed)
         return theta, ok, it
 
     def iterative_inverse_kinematics(self, T_desired, thetalist0, eomg: float = 1e-6, ev: float = 1e-6, max_iterations: int = 10000,
                                      plot_residuals: bool = False, damping: float = 2e-2, step_cap: float = 0.3,
                                      png_name: str = "ik_residuals.png", weight_orientation: float = 1.0,
                                      weight_position: float = 1.0, adaptive_tuning: bool = False, backtracking: bool = False):
-        """(theta, success, iterations) for one target — the reference's signature; the options that change the iteration
-        (adaptive_tuning, backtracking) and the residual plot are not implemented and raise."""
-        if adaptive_tuning or backtracking or plot_residuals:
-            raise NotImplementedError("adaptive_tuning / backtracking / plot_residuals are not part of the batched kernel")
+        """(theta, success, iterations) for one target — the reference's signature; only the residual plot is missing."""
+        if plot_residuals:
+            raise NotImplementedError("plot_residuals is not part of the batched kernel")
         T = np.asarray(T_desired, dtype=np.float64)
         if T.shape != (4, 4):
             raise ValueError(f"T_desired must be (4, 4), got {T.shape}")
         th, ok, it = self.batch_inverse_kinematics(T[None], np.asarray(thetalist0, dtype=np.float64)[None], eomg, ev, max_iterations,
-                                                   damping, step_cap, weight_orientation, weight_position)
+                                                   damping, step_cap, weight_orientation, weight_position, adaptive_tuning, backtracking)
         return th[0], bool(ok[0]), int(it[0])
 
     def end_effector_velocity(self, thetalist, dthetalist, frame: str = "space") -> np.ndarray:

@@ -471,19 +471,23 @@ def ik_geometric_error(T_curr, T_target):
 
 
 def iterative_inverse_kinematics(tab, T_desired, theta0, eomg=1e-6, ev=1e-6, max_iterations=10000, damping=2e-2, step_cap=0.3,
-                                 weight_orientation=1.0, weight_position=1.0, joint_limits=None, rng=None):
-    """kinematics/ik.py:39-311 with the default flags (adaptive_tuning = backtracking = False): damped least squares
-    through the damped pseudo-inverse  V diag(s / (s^2 + lambda^2 + 1e-12)) U^T  (:142-162), step cap (:243-246),
-    joint-limit projection (:164-180), best-solution tracking (:196-203, :273-280) and the stagnation restart
-    (:205-213: after more than 20 iterations without a new best, restart from best + 0.1 randn).  The restart draws from
+                                 weight_orientation=1.0, weight_position=1.0, joint_limits=None, rng=None, adaptive_tuning=False,
+                                 backtracking=False):
+    """kinematics/ik.py:39-311: damped least squares through the damped pseudo-inverse
+    V diag(s / (s^2 + lambda^2 + 1e-12)) U^T  (:142-162), step cap (:243-246), joint-limit projection (:164-180),
+    best-solution tracking (:196-203, :273-280), the stagnation restart (:205-213: after more than 20 iterations without
+    a new best, restart from best + 0.1 randn, damping and its growth factor reset), the optional adaptive damping /
+    step cap (:215-231) and the optional five-scale line search (:248-265).  The restart draws from
     `rng.standard_normal` here (NumPy's global stream in the reference; pass np.random.RandomState(seed) seeded like the
     caller seeded np.random to reproduce a reference run).  Returns (theta, success, iterations, restarts)."""
     lim = np.asarray(tab.joint_limits if joint_limits is None else joint_limits, dtype=np.float64)
     lower, upper = lim[:, 0], lim[:, 1]
+    clip = lambda th: np.minimum(np.maximum(th, lower), upper)
     theta = np.array(theta0, dtype=np.float64)
     T_desired = np.asarray(T_desired, dtype=np.float64)
     best_theta, best_error, stall, restarts = theta.copy(), np.inf, 0, 0
     W = np.array([weight_orientation] * 3 + [weight_position] * 3)
+    damping_local, step_cap_local, nu, prev_error = damping, step_cap, 2.0, np.inf
     success, k, current_error = False, -1, np.inf
     for k in range(max_iterations):
         V, rot_err, trans_err = ik_geometric_error(fk_space(tab, theta), T_desired)
@@ -497,16 +501,37 @@ def iterative_inverse_kinematics(tab, T_desired, theta0, eomg=1e-6, ev=1e-6, max
             stall += 1
         if stall > 20:
             noise = (rng.standard_normal(theta.shape[0]) if rng is not None else np.random.randn(theta.shape[0]))
-            theta = np.minimum(np.maximum(best_theta + 0.1 * noise, lower), upper)
-            stall, restarts = 0, restarts + 1
+            theta = clip(best_theta + 0.1 * noise)
+            damping_local, stall, nu, restarts = damping, 0, 2.0, restarts + 1
             continue
+        if adaptive_tuning and k > 0:
+            if current_error < prev_error * 0.75:
+                damping_local = max(1e-6, damping_local / 3)
+                step_cap_local = min(step_cap * 1.5, step_cap_local * 1.2)
+                nu = 2.0
+            elif current_error < prev_error * 0.95:
+                damping_local = max(1e-6, damping_local / 1.5)
+            elif current_error > prev_error:
+                damping_local = min(5e-1, damping_local * nu)
+                nu = min(nu * 1.5, 8)
+                step_cap_local = max(0.01, step_cap_local * 0.7)
+        prev_error = current_error
         J = jacobian_space(tab, theta)
         U, s, Vt = np.linalg.svd(J, full_matrices=False)
-        delta = Vt.T @ ((s / (s ** 2 + damping ** 2 + 1e-12)) * (U.T @ (V * W)))
+        delta = Vt.T @ ((s / (s ** 2 + damping_local ** 2 + 1e-12)) * (U.T @ (V * W)))
         nd = np.linalg.norm(delta)
-        if nd > step_cap:
-            delta = delta * (step_cap / nd)
-        theta = np.minimum(np.maximum(theta + delta, lower), upper)
+        if nd > step_cap_local:
+            delta = delta * (step_cap_local / nd)
+        if backtracking:
+            keep, keep_err = theta, current_error
+            for scale in (1.0, 0.5, 0.25, 0.125, 0.75):
+                cand = clip(theta + scale * delta)
+                _, r_try, t_try = ik_geometric_error(fk_space(tab, cand), T_desired)
+                if r_try + t_try < keep_err:
+                    keep, keep_err = cand, r_try + t_try
+            theta = keep if keep_err < current_error * 1.1 else clip(theta + 0.1 * delta)
+        else:
+            theta = clip(theta + delta)
     else:
         k += 1
     if not success and best_error < current_error:

@@ -307,11 +307,18 @@ def dump_ik():
                 kw["max_iterations"] = 15
             if case in (4, 7):  # non-default weights / damping / cap
                 kw.update(damping=5e-2, step_cap=0.15, weight_orientation=0.5, weight_position=2.0)
+            if case in (2, 5, 9):  # the two options robust_inverse_kinematics switches on
+                kw.update(adaptive_tuning=True, backtracking=True)
+            if case == 3:
+                kw.update(adaptive_tuning=True)
+            if case == 6:
+                kw.update(backtracking=True)
             np.random.seed(1234)
             sol, success, iters = sm.iterative_inverse_kinematics(T, q0, **kw)
             T_des.append(T); th0.append(q0); th.append(np.asarray(sol, dtype=np.float64)); ok.append(bool(success)); it.append(int(iters))
             params.append([kw["eomg"], kw["ev"], kw["max_iterations"], kw["damping"], kw["step_cap"],
-                           kw.get("weight_orientation", 1.0), kw.get("weight_position", 1.0)])
+                           kw.get("weight_orientation", 1.0), kw.get("weight_position", 1.0),
+                           float(kw.get("adaptive_tuning", False)), float(kw.get("backtracking", False))])
         d[f"{robot}_T_desired"] = np.stack(T_des); d[f"{robot}_theta0"] = np.stack(th0); d[f"{robot}_theta"] = np.stack(th)
         d[f"{robot}_success"] = np.array(ok); d[f"{robot}_iterations"] = np.array(it); d[f"{robot}_params"] = np.array(params)
         d[f"{robot}_joint_limits"] = np.array([[-np.inf if lo is None else lo, np.inf if hi is None else hi]

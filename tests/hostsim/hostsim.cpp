@@ -199,7 +199,8 @@ extern "C" int hostsim_cartesian(const double* Xs, const double* Xe, long N, dou
   return 0;
 }
 
-// inverse kinematics (mp_ik_solve), `rows` independent problems: params = {eomg, ev, max_iterations, damping, step_cap, w_o, w_p}
+// inverse kinematics (mp_ik_solve), `rows` independent problems:
+// params = {eomg, ev, max_iterations, damping, step_cap, w_o, w_p, adaptive_tuning, backtracking}
 namespace {
 template <int N>
 void run_ik(const MpModel<double>& M, const MpIkParams& P, long rows, const double* Td, const double* th0, double* th, int* ok,
@@ -222,6 +223,7 @@ extern "C" int hostsim_ik(int n, const double* S, const double* Mcom, const doub
   MpIkParams P;
   P.eomg = params[0]; P.ev = params[1]; P.max_iterations = (int)params[2]; P.damping = params[3]; P.step_cap = params[4];
   P.w_o = params[5]; P.w_p = params[6]; P.seed = 1234u;
+  P.adaptive_tuning = params[7] != 0.0; P.backtracking = params[8] != 0.0;
   for (int j = 0; j < MP_MAX_DOF; ++j) { P.lo[j] = j < n ? limits[2 * j] : -HUGE_VAL; P.hi[j] = j < n ? limits[2 * j + 1] : HUGE_VAL; }
   switch (n) {
 #define CASE(N) case N: run_ik<N>(Md, P, rows, Td, th0, th, ok, iters, restarts); return 0;

@@ -647,6 +647,15 @@ def test_planner_shared_by_threads(tables):
         assert not errors, errors
 
 
+def _restarted(tab, z, robot, i):
+    """True when the reference run of fixture `i` went through a stagnation restart (its noise is NumPy's, the device's is
+    a counter hash, so such a run is only comparable through the oracle)."""
+    p = z[f"{robot}_params"][i]
+    return ref.iterative_inverse_kinematics(tab, z[f"{robot}_T_desired"][i], z[f"{robot}_theta0"][i], p[0], p[1], int(p[2]), p[3], p[4],
+                                            p[5], p[6], joint_limits=z[f"{robot}_joint_limits"], rng=np.random.RandomState(1234),
+                                            adaptive_tuning=bool(p[7]), backtracking=bool(p[8]))[3] > 0
+
+
 @pytest.mark.parametrize("robot", ROBOTS)
 def test_inverse_kinematics_against_reference_runs_and_oracle(robot, tables):
     """Batched IK kernel (mp_inverse_kinematics_*) against the reference's own iterative_inverse_kinematics runs
@@ -665,8 +674,11 @@ def test_inverse_kinematics_against_reference_runs_and_oracle(robot, tables):
             p = z[f"{robot}_params"][i]
             th, ok, it = sm.iterative_inverse_kinematics(z[f"{robot}_T_desired"][i], z[f"{robot}_theta0"][i], eomg=p[0], ev=p[1],
                                                          max_iterations=int(p[2]), damping=p[3], step_cap=p[4],
-                                                         weight_orientation=p[5], weight_position=p[6])
+                                                         weight_orientation=p[5], weight_position=p[6],
+                                                         adaptive_tuning=bool(p[7]), backtracking=bool(p[8]))
             want_ok, want_it = bool(z[f"{robot}_success"][i]), int(z[f"{robot}_iterations"][i])
+            if _restarted(tab, z, robot, i):
+                continue
             assert ok == want_ok and abs(it - want_it) <= (1 if want_ok else 0), (robot, i, ok, it, want_it)
             np.testing.assert_allclose(th, z[f"{robot}_theta"][i], rtol=0, atol=1e-6 if want_ok else 1e-5)
         # a batch of fresh problems: targets = FK of in-limit configurations, guesses nearby
@@ -689,7 +701,7 @@ def test_inverse_kinematics_against_reference_runs_and_oracle(robot, tables):
                 assert o_ok == ok[b] and abs(o_it - it[b]) <= 1
                 np.testing.assert_allclose(th[b], o_th, rtol=0, atol=1e-6 if o_ok else 1e-5)
         with pytest.raises(NotImplementedError):
-            sm.iterative_inverse_kinematics(T[0], q0[0], adaptive_tuning=True)
+            sm.iterative_inverse_kinematics(T[0], q0[0], plot_residuals=True)
     ctx = _hip.HipContext(0)
     try:
         m = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee)
