@@ -12,7 +12,8 @@
 //
 // The stagnation restart adds 0.1 * N(0, 1) noise to the best configuration.  The reference draws it from NumPy's
 // GLOBAL random stream, so its own runs are not reproducible across call orders; here the noise comes from a counter
-// hash of (seed, problem index, restart number, joint) - same distribution, reproducible, not the same numbers.
+// hash of (seed, the problem's own content: target position + initial guess, restart number, joint) - same
+// distribution, reproducible, the same for a problem wherever it sits in a batch, not NumPy's numbers.
 #pragma once
 
 #include "mp_core.h"
@@ -55,8 +56,8 @@ MP_HD void mp_ik_error(const double (&Tc)[16], const double (&Td)[16], double (&
 }
 
 // standard normal from a counter (splitmix64 finaliser + Box-Muller); only the restart path uses it
-MP_HD double mp_ik_normal(unsigned seed, long problem, int restart, int joint) {
-  unsigned long long x = (unsigned long long)seed * 0x9E3779B97F4A7C15ull + (unsigned long long)problem * 0xBF58476D1CE4E5B9ull +
+MP_HD double mp_ik_normal(unsigned seed, unsigned long long key, int restart, int joint) {
+  unsigned long long x = (unsigned long long)seed * 0x9E3779B97F4A7C15ull + key * 0xBF58476D1CE4E5B9ull +
                          (unsigned long long)(restart * 64 + joint) * 0x94D049BB133111EBull;
   unsigned long long u[2];
 #pragma unroll
@@ -80,18 +81,24 @@ struct MpIkState {
   double best_err, cur_err;
   double damping, step_cap, nu, prev_err;  // the adaptive-tuning state (constant when the option is off)
   int stall, k, restarts, success;
-  long problem;
+  unsigned long long key;  // content hash of the problem: keys the restart noise
 };
 
+// S.theta (initial guess) and S.Td (target) must be set
 template <int N>
-MP_HD void mp_ik_begin(MpIkState<N>& S, const MpIkParams& P, long problem) {
+MP_HD void mp_ik_begin(MpIkState<N>& S, const MpIkParams& P) {
+  unsigned long long h = 0xCBF29CE484222325ull;  // FNV-1a over the bit patterns of the target position and the guess
+#pragma unroll
+  for (int k = 0; k < 3; ++k) h = (h ^ __builtin_bit_cast(unsigned long long, S.Td[4 * k + 3])) * 0x100000001B3ull;
+#pragma unroll
+  for (int j = 0; j < N; ++j) h = (h ^ __builtin_bit_cast(unsigned long long, S.theta[j])) * 0x100000001B3ull;
+  S.key = h;
   S.damping = P.damping; S.step_cap = P.step_cap; S.nu = 2.0; S.prev_err = HUGE_VAL;
 #pragma unroll
   for (int j = 0; j < N; ++j) S.best[j] = S.theta[j];
   S.best_err = HUGE_VAL;
   S.cur_err = HUGE_VAL;
   S.stall = 0; S.k = 0; S.restarts = 0; S.success = 0;
-  S.problem = problem;
 }
 
 // One trip of the reference's loop (kinematics/ik.py:182-269).  Returns true when the problem is finished; S.theta is
@@ -129,7 +136,7 @@ MP_HD bool mp_ik_iterate(const MT& M, const MpIkParams& P, MpIkState<N>& S) {
   if (S.stall > 20) {
 #pragma unroll
     for (int j = 0; j < N; ++j) {
-      const double t = S.best[j] + 0.1 * mp_ik_normal(P.seed, S.problem, S.restarts, j);
+      const double t = S.best[j] + 0.1 * mp_ik_normal(P.seed, S.key, S.restarts, j);
       S.theta[j] = t < P.lo[j] ? P.lo[j] : (t > P.hi[j] ? P.hi[j] : t);
     }
     S.stall = 0;
@@ -225,14 +232,13 @@ MP_HD bool mp_ik_iterate(const MT& M, const MpIkParams& P, MpIkState<N>& S) {
 
 // theta: in = initial guess, out = solution.  Returns the reference's iteration count; sets success / restarts.
 template <int N, typename MT>
-MP_HD int mp_ik_solve(const MT& M, const MpIkParams& P, const double (&Td)[16], long problem, double (&theta)[N], int& success,
-                      int& restarts) {
+MP_HD int mp_ik_solve(const MT& M, const MpIkParams& P, const double (&Td)[16], double (&theta)[N], int& success, int& restarts) {
   MpIkState<N> S;
 #pragma unroll
   for (int j = 0; j < N; ++j) S.theta[j] = theta[j];
 #pragma unroll
   for (int k = 0; k < 16; ++k) S.Td[k] = Td[k];
-  mp_ik_begin(S, P, problem);
+  mp_ik_begin(S, P);
   while (!mp_ik_iterate<N>(M, P, S)) {}
 #pragma unroll
   for (int j = 0; j < N; ++j) theta[j] = S.theta[j];

@@ -282,20 +282,21 @@ __global__ __launch_bounds__(kBlock) void k_ik(const MpModel<double> M, const Mp
                                                int* __restrict__ restarts, unsigned long long* __restrict__ next) {
   MpIkState<N> S;
   bool have = false;
+  long row = 0;
   for (;;) {
     if (!have) {
-      const long b = (long)atomicAdd(next, 1ull);
-      if (b >= B) break;
-      RunIO<double, 16>::load(Tdes, b, S.Td);
-      RunIO<double, N>::load(theta0, b, S.theta);
-      mp_ik_begin(S, P, b);
+      row = (long)atomicAdd(next, 1ull);
+      if (row >= B) break;
+      RunIO<double, 16>::load(Tdes, row, S.Td);
+      RunIO<double, N>::load(theta0, row, S.theta);
+      mp_ik_begin(S, P);
       have = true;
     }
     if (mp_ik_iterate<N>(M, P, S)) {
-      RunIO<double, N>::store(theta, S.problem, S.theta);
-      success[S.problem] = S.success;
-      iterations[S.problem] = S.k + 1;
-      restarts[S.problem] = S.restarts;
+      RunIO<double, N>::store(theta, row, S.theta);
+      success[row] = S.success;
+      iterations[row] = S.k + 1;
+      restarts[row] = S.restarts;
       have = false;
     }
   }

@@ -1,0 +1,74 @@
+"""Initial guesses for inverse kinematics, for one target or a batch (reference kinematics/ik_helpers.py).
+
+`workspace_heuristic_guess` (:28-114), `random_in_limits` (:179-212), `midpoint_of_limits` (:215-246) with the same
+formulas and the same use of NumPy's global random stream (one `np.random.uniform` per joint, in joint order), so that a
+caller who seeds `np.random` gets the guesses the reference would draw.  The batched forms exist because every attempt
+of a multi-start solve is just another row of one inverse-kinematics launch.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+Limits = Sequence[Tuple[Optional[float], Optional[float]]]
+
+__all__ = ["workspace_heuristic_guess", "random_in_limits", "midpoint_of_limits", "clip_to_limits"]
+
+
+def clip_to_limits(theta: np.ndarray, joint_limits: Limits) -> np.ndarray:
+    """Project onto the joint-limit box; None leaves an end open (reference ik_helpers.py:407-446)."""
+    theta = np.asarray(theta, dtype=np.float64)
+    n = theta.shape[-1]
+    lo = np.array([-np.inf if (i >= len(joint_limits) or joint_limits[i][0] is None) else joint_limits[i][0] for i in range(n)])
+    hi = np.array([np.inf if (i >= len(joint_limits) or joint_limits[i][1] is None) else joint_limits[i][1] for i in range(n)])
+    return np.minimum(np.maximum(theta, lo), hi)
+
+
+def workspace_heuristic_guess(T_desired, n_joints: int, joint_limits: Limits) -> np.ndarray:
+    """Geometric guess: joint 1 from the target's azimuth, joint 2 from its elevation, joint 3 = pi / 4, joints 4-6 from the
+    ZYZ-like angles of the target rotation.  T_desired (4,4) -> (n,), or (B,4,4) -> (B,n)."""
+    T = np.asarray(T_desired, dtype=np.float64)
+    single = T.ndim == 2
+    T = T[None] if single else T
+    B = T.shape[0]
+    th = np.zeros((B, n_joints))
+    p, R = T[:, :3, 3], T[:, :3, :3]
+    if n_joints >= 1:
+        th[:, 0] = np.arctan2(p[:, 1], p[:, 0])
+    if n_joints >= 2:
+        r_xy = np.sqrt(p[:, 0] ** 2 + p[:, 1] ** 2)
+        th[:, 1] = np.where(r_xy > 1e-6, np.arctan2(p[:, 2], r_xy), 0.0)
+    if n_joints >= 3:
+        th[:, 2] = np.pi / 4
+    if n_joints > 3:
+        generic = np.abs(R[:, 2, 2]) < 0.9999
+        th[:, 3] = np.where(generic, np.arctan2(R[:, 1, 2], R[:, 0, 2]), np.arctan2(R[:, 1, 0], R[:, 0, 0]))
+        if n_joints >= 5:
+            th[:, 4] = np.where(generic, np.arccos(np.clip(R[:, 2, 2], -1, 1)), 0.0)
+        if n_joints >= 6:
+            th[:, 5] = np.where(generic, np.arctan2(R[:, 2, 1], -R[:, 2, 0]), 0.0)
+    th = clip_to_limits(th, joint_limits)
+    return th[0] if single else th
+
+
+def random_in_limits(joint_limits: Limits, count: Optional[int] = None) -> np.ndarray:
+    """Uniform inside the limits (open ends: a pi-wide band next to the closed end, or [-pi, pi]); draws from NumPy's
+    global stream joint by joint, row by row.  count=None -> (n,), else (count, n)."""
+    rows = 1 if count is None else int(count)
+    out = np.empty((rows, len(joint_limits)))
+    for r in range(rows):
+        for j, (mn, mx) in enumerate(joint_limits):
+            if mn is not None and mx is not None:
+                out[r, j] = np.random.uniform(mn, mx)
+            elif mn is not None:
+                out[r, j] = mn + np.random.uniform(0, np.pi)
+            elif mx is not None:
+                out[r, j] = mx - np.random.uniform(0, np.pi)
+            else:
+                out[r, j] = np.random.uniform(-np.pi, np.pi)
+    return out[0] if count is None else out
+
+
+def midpoint_of_limits(joint_limits: Limits) -> np.ndarray:
+    return np.array([(mn + mx) / 2.0 if mn is not None and mx is not None else 0.0 for mn, mx in joint_limits], dtype=np.float64)

@@ -137,6 +137,71 @@ class SerialManipulator:
                                                    damping, step_cap, weight_orientation, weight_position, adaptive_tuning, backtracking)
         return th[0], bool(ok[0]), int(it[0])
 
+    # the (initial guess, damping, step cap) ladder of the reference's robust solver (kinematics/ik.py:505-516)
+    _ROBUST_STRATEGIES = (("workspace_heuristic", 0.02, 0.3), ("midpoint", 0.02, 0.3), ("workspace_heuristic", 0.01, 0.4),
+                          ("random", 0.02, 0.3), ("random", 0.03, 0.25), ("midpoint", 0.01, 0.4), ("random", 0.015, 0.35),
+                          ("random", 0.025, 0.3), ("workspace_heuristic", 0.03, 0.25), ("random", 0.02, 0.35))
+
+    def batch_robust_inverse_kinematics(self, T_desired_batch, max_attempts: int = 10, eomg: float = 2e-3, ev: float = 2e-3,
+                                        max_iterations: int = 5000):
+        """Multi-start IK for B targets (reference kinematics/ik.py:477-598, one target per call there): up to ten
+        attempts per target, each with its own initial guess, damping and step cap, adaptive tuning and backtracking on.
+        The reference runs the attempts one after the other and stops at the first success; here all attempts of all
+        targets are rows of a few launches (one per distinct damping / step-cap pair) and the winner is picked afterwards
+        in the same order, so the answer is the sequential one.  Random guesses are drawn from NumPy's global stream in
+        attempt order, target by target.  Returns (theta (B,n), success (B,), total_iterations (B,), strategy list)."""
+        from . import ik_helpers
+
+        T = np.asarray(T_desired_batch, dtype=np.float64)
+        if T.ndim != 3 or T.shape[1:] != (4, 4):
+            raise ValueError(f"T_desired_batch must be (B, 4, 4), got {T.shape}")
+        B, n = T.shape[0], self.S_list.shape[1]
+        plan = self._ROBUST_STRATEGIES[:max(0, min(int(max_attempts), len(self._ROBUST_STRATEGIES)))]
+        A = len(plan)
+        guesses = np.zeros((B, A, n))
+        heur, mid = ik_helpers.workspace_heuristic_guess(T, n, self.joint_limits), ik_helpers.midpoint_of_limits(self.joint_limits)
+        for b in range(B):
+            for a, (name, _, _) in enumerate(plan):
+                guesses[b, a] = heur[b] if name == "workspace_heuristic" else mid if name == "midpoint" else \
+                    ik_helpers.random_in_limits(self.joint_limits)
+        theta_all, ok_all, it_all = np.zeros((B, A, n)), np.zeros((B, A), dtype=bool), np.zeros((B, A), dtype=np.int64)
+        for damping, cap in sorted({(d, c) for _, d, c in plan}):
+            cols = [a for a, (_, d, c) in enumerate(plan) if (d, c) == (damping, cap)]
+            th, ok, it = self.batch_inverse_kinematics(np.repeat(T, len(cols), axis=0), guesses[:, cols].reshape(-1, n), eomg, ev,
+                                                       max_iterations, damping, cap, adaptive_tuning=True, backtracking=True)
+            theta_all[:, cols], ok_all[:, cols], it_all[:, cols] = th.reshape(B, len(cols), n), ok.reshape(B, -1), it.reshape(B, -1)
+        theta, success, total, names = np.zeros((B, n)), np.zeros(B, dtype=bool), np.zeros(B, dtype=np.int64), []
+        err = None
+        for b in range(B):
+            wins = np.flatnonzero(ok_all[b])
+            if wins.size:
+                a = int(wins[0])
+                theta[b], success[b], total[b] = theta_all[b, a], True, it_all[b, :a + 1].sum()
+                names.append(plan[a][0])
+                continue
+            if A == 0:
+                theta[b] = mid
+                names.append("none")
+                continue
+            if err is None:  # pose error of every failed attempt: one batched FK (reference :567-585)
+                Tc = np.asarray(self.forward_kinematics(theta_all.reshape(-1, n))).reshape(B, A, 4, 4)
+                pos = np.linalg.norm(Tc[..., :3, 3] - T[:, None, :3, 3], axis=-1)
+                tr = np.einsum("baij,bij->ba", Tc[..., :3, :3], T[:, :3, :3])  # trace(Rc^T Rd)
+                err = pos + np.arccos(np.clip((tr - 1) / 2, -1, 1))
+            a = int(np.argmin(err[b]))  # first minimum == the reference's strict "<" update order
+            theta[b], total[b] = theta_all[b, a], it_all[b].sum()
+            names.append(plan[a][0])
+        return theta, success, total, names
+
+    def robust_inverse_kinematics(self, T_desired, max_attempts: int = 10, eomg: float = 2e-3, ev: float = 2e-3,
+                                  max_iterations: int = 5000, verbose: bool = False):
+        """(theta, success, total_iterations, winning_strategy) — the reference's signature for one target."""
+        th, ok, it, names = self.batch_robust_inverse_kinematics(np.asarray(T_desired, dtype=np.float64)[None], max_attempts, eomg, ev,
+                                                                 max_iterations)
+        if verbose:
+            print(f"robust IK: {'success' if ok[0] else 'failed'} with '{names[0]}' after {int(it[0])} iterations")
+        return th[0], bool(ok[0]), int(it[0]), names[0]
+
     def end_effector_velocity(self, thetalist, dthetalist, frame: str = "space") -> np.ndarray:
         """reference kinematics/velocity.py:35-60."""
         return self.jacobian(thetalist, frame=frame) @ np.asarray(dthetalist, dtype=np.float64)

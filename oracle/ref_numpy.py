@@ -539,3 +539,76 @@ def iterative_inverse_kinematics(tab, T_desired, theta0, eomg=1e-6, ev=1e-6, max
         _, rot_err, trans_err = ik_geometric_error(fk_space(tab, theta), T_desired)
         success = bool(rot_err < eomg and trans_err < ev)
     return theta, bool(success), k + 1, restarts
+
+
+# initial guesses (kinematics/ik_helpers.py:28-114, :179-212, :215-246); limits as (n,2) with +-inf for open ends
+def ik_workspace_heuristic_guess(T, n, lim):
+    a = np.zeros(n)
+    p, R = T[:3, 3], T[:3, :3]
+    if n >= 1:
+        a[0] = np.arctan2(p[1], p[0])
+    if n >= 2:
+        r = np.sqrt(p[0] ** 2 + p[1] ** 2)
+        a[1] = np.arctan2(p[2], r) if r > 1e-6 else 0.0
+    if n >= 3:
+        a[2] = np.pi / 4
+    if n > 3:
+        if abs(R[2, 2]) < 0.9999:
+            if n >= 5:
+                a[4] = np.arccos(np.clip(R[2, 2], -1, 1))
+            a[3] = np.arctan2(R[1, 2], R[0, 2])
+            if n >= 6:
+                a[5] = np.arctan2(R[2, 1], -R[2, 0])
+        else:
+            a[3] = np.arctan2(R[1, 0], R[0, 0])
+    return np.minimum(np.maximum(a, lim[:, 0]), lim[:, 1])
+
+
+def ik_random_in_limits(lim):
+    out = []
+    for mn, mx in lim:
+        if np.isfinite(mn) and np.isfinite(mx):
+            out.append(np.random.uniform(mn, mx))
+        elif np.isfinite(mn):
+            out.append(mn + np.random.uniform(0, np.pi))
+        elif np.isfinite(mx):
+            out.append(mx - np.random.uniform(0, np.pi))
+        else:
+            out.append(np.random.uniform(-np.pi, np.pi))
+    return np.array(out)
+
+
+def ik_midpoint_of_limits(lim):
+    return np.array([(mn + mx) / 2.0 if np.isfinite(mn) and np.isfinite(mx) else 0.0 for mn, mx in lim])
+
+
+ROBUST_STRATEGIES = (("workspace_heuristic", 0.02, 0.3), ("midpoint", 0.02, 0.3), ("workspace_heuristic", 0.01, 0.4),
+                     ("random", 0.02, 0.3), ("random", 0.03, 0.25), ("midpoint", 0.01, 0.4), ("random", 0.015, 0.35),
+                     ("random", 0.025, 0.3), ("workspace_heuristic", 0.03, 0.25), ("random", 0.02, 0.35))
+
+
+def robust_inverse_kinematics(tab, T_desired, joint_limits, max_attempts=10, eomg=2e-3, ev=2e-3, max_iterations=5000):
+    """kinematics/ik.py:477-598 — sequential multi-start over ROBUST_STRATEGIES with adaptive tuning and backtracking, first
+    success wins, otherwise the attempt with the smallest pose error.  Uses NumPy's GLOBAL random stream for the random
+    guesses and the restarts, exactly like the reference (seed np.random before calling to reproduce one of its runs).
+    Returns (theta, success, total_iterations, strategy, total_restarts)."""
+    lim = np.asarray(joint_limits, dtype=np.float64)
+    n = tab.n
+    best_theta, best_error, total, winner, restarts = None, np.inf, 0, "none", 0
+    for name, damping, cap in ROBUST_STRATEGIES[:min(max_attempts, len(ROBUST_STRATEGIES))]:
+        theta0 = (ik_workspace_heuristic_guess(T_desired, n, lim) if name == "workspace_heuristic"
+                  else ik_midpoint_of_limits(lim) if name == "midpoint" else ik_random_in_limits(lim))
+        theta, ok, it, rs = iterative_inverse_kinematics(tab, T_desired, theta0, eomg, ev, max_iterations, damping, cap,
+                                                         joint_limits=lim, adaptive_tuning=True, backtracking=True)
+        total += it
+        restarts += rs
+        if ok:
+            return theta, True, total, name, restarts
+        Tc = fk_space(tab, theta)
+        err = np.linalg.norm(Tc[:3, 3] - T_desired[:3, 3]) + np.arccos(np.clip((np.trace(Tc[:3, :3].T @ T_desired[:3, :3]) - 1) / 2, -1, 1))
+        if err < best_error:
+            best_error, best_theta, winner = err, theta.copy(), name
+    if best_theta is None:
+        best_theta = ik_midpoint_of_limits(lim)
+    return best_theta, False, total, winner, restarts
+

@@ -324,6 +324,20 @@ def dump_ik():
         d[f"{robot}_joint_limits"] = np.array([[-np.inf if lo is None else lo, np.inf if hi is None else hi]
                                               for lo, hi in sm.joint_limits], dtype=np.float64)
         print(robot, "ik:", ok, it, flush=True)
+        # robust_inverse_kinematics (kinematics/ik.py:477-598): multi-start, adaptive tuning + backtracking, np.random guesses
+        Tr, thr, okr, itr, names = [], [], [], [], []
+        for case in range(4):
+            q_true = rng.uniform(0.8 * lims[:, 0], 0.8 * lims[:, 1])
+            T = np.asarray(sm.forward_kinematics(q_true), dtype=np.float64)
+            if case == 3:
+                T = T.copy(); T[:3, 3] += np.array([2.5, 0.0, 0.0])  # unreachable: every attempt fails
+            np.random.seed(4321 + case)
+            sol, success, iters, name = sm.robust_inverse_kinematics(T, max_attempts=10 if case < 3 else 4, max_iterations=300)
+            Tr.append(T); thr.append(np.asarray(sol, dtype=np.float64)); okr.append(bool(success)); itr.append(int(iters)); names.append(name)
+        d[f"{robot}_robust_T_desired"] = np.stack(Tr); d[f"{robot}_robust_theta"] = np.stack(thr)
+        d[f"{robot}_robust_success"] = np.array(okr); d[f"{robot}_robust_iterations"] = np.array(itr)
+        d[f"{robot}_robust_strategy"] = np.array(names)
+        print(robot, "robust ik:", okr, itr, names, flush=True)
     np.savez(os.path.join(HERE, "ik.npz"), **d)
 
 

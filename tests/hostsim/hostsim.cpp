@@ -209,7 +209,7 @@ void run_ik(const MpModel<double>& M, const MpIkParams& P, long rows, const doub
     double T[16], q[N];
     for (int k = 0; k < 16; ++k) T[k] = Td[r * 16 + k];
     for (int j = 0; j < N; ++j) q[j] = th0[r * N + j];
-    iters[r] = mp_ik_solve<N>(M, P, T, r, q, ok[r], restarts[r]);
+    iters[r] = mp_ik_solve<N>(M, P, T, q, ok[r], restarts[r]);
     for (int j = 0; j < N; ++j) th[r * N + j] = q[j];
   }
 }

@@ -713,6 +713,46 @@ def test_inverse_kinematics_against_reference_runs_and_oracle(robot, tables):
         ctx.destroy()
 
 
+@pytest.mark.parametrize("robot", ROBOTS)
+def test_robust_inverse_kinematics_against_reference_runs(robot, tables):
+    """Multi-start IK: every attempt of every target is a row of a few launches; the winner is picked in the reference's
+    order.  Against the reference's own runs (np.random seeded identically; runs whose attempts went through a stagnation
+    restart are only checked for success, their noise differs by design); batch == per-target."""
+    import manipulapy_amd as mp
+
+    z = np.load(golden_path("ik.npz"))
+    tab = tables[robot]
+    lim = z[f"{robot}_joint_limits"]
+    sm, _, _ = mp.load_robot(robot)
+    sm.joint_limits = [(None if not np.isfinite(lo) else float(lo), None if not np.isfinite(hi) else float(hi)) for lo, hi in lim]
+    with mp.use_backend("hip"):
+        for case in range(4):
+            T = z[f"{robot}_robust_T_desired"][case]
+            np.random.seed(4321 + case)
+            _, o_ok, o_total, o_name, o_restarts = ref.robust_inverse_kinematics(tab, T, lim, max_attempts=10 if case < 3 else 4,
+                                                                               max_iterations=300)
+            np.random.seed(4321 + case)
+            th, ok, total, name = sm.robust_inverse_kinematics(T, max_attempts=10 if case < 3 else 4, max_iterations=300)
+            want_ok = bool(z[f"{robot}_robust_success"][case])
+            if o_restarts == 0:
+                assert ok == want_ok and name == str(z[f"{robot}_robust_strategy"][case]), (robot, case, ok, name)
+                assert abs(total - int(z[f"{robot}_robust_iterations"][case])) <= 2
+                np.testing.assert_allclose(th, z[f"{robot}_robust_theta"][case], rtol=0, atol=2e-3 if want_ok else 1e-4)
+            if ok:
+                _, rot, tr = ref.ik_geometric_error(ref.fk_space(tab, th), T)
+                assert rot < 2e-3 and tr < 2e-3
+        Tb = z[f"{robot}_robust_T_desired"][:3]
+        np.random.seed(99)
+        th_b, ok_b, it_b, names_b = sm.batch_robust_inverse_kinematics(Tb, max_attempts=3, max_iterations=300)
+        assert th_b.shape == (3, tab.n) and len(names_b) == 3
+        for b in range(3):  # no random guess among the first three strategies, and the restart noise is keyed by the problem's
+            th1, ok1, it1, n1 = sm.robust_inverse_kinematics(Tb[b], max_attempts=3, max_iterations=300)  # content: batch == single
+            np.testing.assert_array_equal(th1, th_b[b])
+            assert (ok1, it1, n1) == (bool(ok_b[b]), int(it_b[b]), names_b[b])
+        e = sm.batch_robust_inverse_kinematics(Tb[:1], max_attempts=0)
+        assert not e[1][0] and e[3] == ["none"]
+
+
 def test_singularity_and_workspace_against_oracle(tables, dyn_golden):
     """Singularity mirror (reference singularity/singularity_analysis.py): condition number / smallest singular value of
     the GPU Jacobians == NumPy on the oracle's Jacobians; batch == per-sample; Monte-Carlo workspace points == oracle FK."""
