@@ -97,3 +97,40 @@ def test_random_chain_matches_oracle(seed, hostsim):  # noqa: F811
     for r in range(rows):
         want = ref.inverse_dynamics(tab, q[r], qd[r], qdd[r], g, F)
         assert np.abs(t32[r] - want).max() <= 2e-4 * max(1.0, np.abs(want).max())
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_chain_forward_dynamics_and_ik(seed, hostsim):  # noqa: F811
+    """Forward dynamics (bias recursion + CRBA + Cholesky) and the IK iteration on the same randomised chains: FD against
+    the oracle's solve(M, tau - c - g - J^T F); IK (plain, and with adaptive tuning + backtracking) against the oracle's
+    restatement of the reference loop on reachable targets — same flag, same count (+-1), same solution."""
+    rng = np.random.default_rng(5000 + seed)
+    n = int(rng.integers(2, 9))
+    tab = random_robot(rng, n, FLAVOURS[seed % len(FLAVOURS)])
+    prismatic = np.abs(tab.S[:3]).sum(axis=0) == 0
+    rows = 2
+    q = rng.uniform(-2.0, 2.0, (rows, n))
+    q[:, prismatic] *= 0.1
+    qd, tau = rng.uniform(-1, 1, (rows, n)), rng.uniform(-5, 5, (rows, n))
+    g, F = np.array([0.4, -0.3, -9.81]), rng.uniform(-3, 3, 6)
+    for r in range(rows):
+        qdd = hostsim.fd(tab, 1, 1, q[r:r + 1], qd[r:r + 1], tau[r:r + 1], g, F, outshape=(1, n))
+        want = ref.forward_dynamics(tab, q[r], qd[r], tau[r], g, F)
+        np.testing.assert_allclose(qdd[0], want, rtol=2e-5, atol=2e-5 * max(1.0, np.abs(want).max()))  # the oracle's own FD noise x M^-1
+    lim = np.tile([-2.5, 2.5], (n, 1)).astype(float)
+    lim[prismatic] = [-0.4, 0.4]
+    for case in range(3):
+        q_true = rng.uniform(0.7 * lim[:, 0], 0.7 * lim[:, 1])
+        T = ref.fk_space(tab, q_true)
+        q0 = np.clip(q_true + rng.uniform(-0.2, 0.2, n) * np.where(prismatic, 0.2, 1.0), lim[:, 0], lim[:, 1])
+        for adaptive, backtrack in ((False, False), (True, True)):
+            params = [1e-6, 1e-6, 150, 2e-2, 0.3, 1.0, 1.0, float(adaptive), float(backtrack)]
+            th, ok, it, rs = hostsim.ik(tab, lim, params, T[None], q0[None])
+            o_th, o_ok, o_it, o_rs = ref.iterative_inverse_kinematics(tab, T, q0, 1e-6, 1e-6, 150, 2e-2, 0.3, joint_limits=lim,
+                                                                      rng=np.random.RandomState(0), adaptive_tuning=adaptive,
+                                                                      backtracking=backtrack)
+            if o_rs or rs[0]:
+                continue  # restart noise differs by design
+            assert bool(ok[0]) == o_ok and abs(int(it[0]) - o_it) <= 1, (seed, case, adaptive, ok[0], it[0], o_ok, o_it)
+            np.testing.assert_allclose(th[0], o_th, rtol=0, atol=1e-6 if o_ok else 1e-4)
+
