@@ -73,14 +73,15 @@ __global__ __launch_bounds__(kBlock) void k_traj_id(const MpModel<float> M, cons
 
 // ------------------------------------------------- float32, two rows per lane (packed v_pk_* math)
 // Lane t owns rows 2t and 2t+1 — one contiguous 2*N*4-byte run per array, so the loads/stores are
-// also twice as wide per lane.  The launcher sends an odd trailing row to the one-row-per-lane kernel.
+// also twice as wide per lane.  A lane's two rows are `p` and `p + pairs` (the two halves of the batch), so each half is
+// streamed in one-row-per-lane runs.  The launcher sends an odd trailing row to the one-row-per-lane kernel.
 template <int N, bool HAS_FTIP>
 __global__ __launch_bounds__(MP_PK_BLOCK, MP_PK_MINW) void k_id_pk(const MpModel<float> M, const MpCall<float> C,
                                                      const float* __restrict__ q, const float* __restrict__ qd,
                                                      const float* __restrict__ qdd, float* __restrict__ tau, long pairs) {
   const long p = (long)blockIdx.x * MP_PK_BLOCK + threadIdx.x;
   if (p >= pairs) return;
-  mp_body_id_pk<N, HAS_FTIP>(M, C, q, qd, qdd, tau, p);
+  mp_body_id_pk_split<N, HAS_FTIP>(M, C, q, qd, qdd, tau, p, pairs);  // rows p and p + pairs
 }
 
 // Persistent form of k_id_pk: a fixed grid walks the pairs with a grid stride and keeps the NEXT
