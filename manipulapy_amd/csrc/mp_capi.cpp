@@ -25,6 +25,7 @@ struct MpSpec {  // run-time specialised kernels of one model on one device
   hipModule_t mod = nullptr;
   hipFunction_t id_pk[2] = {nullptr, nullptr}, traj_id_pk[2] = {nullptr, nullptr}, fd_traj[2] = {nullptr, nullptr};
   hipFunction_t id_d[2] = {nullptr, nullptr}, fk_jac_id_d[2] = {nullptr, nullptr}, fd_traj_pk[2] = {nullptr, nullptr};
+  hipFunction_t ik = nullptr;
 };
 struct mp_ctx {
   int device = -1;
@@ -802,6 +803,10 @@ int mp_model_specialize(mp_ctx* ctx, const mp_model* model) {
       hipError_t e = hipModuleGetFunction(&slots[k][f], sp.mod, names[k][f]);
       if (e != hipSuccess) { (void)hipModuleUnload(sp.mod); return hip_err(e, names[k][f]); }
     }
+  {
+    hipError_t e = hipModuleGetFunction(&sp.ik, sp.mod, "mp_spec_ik");
+    if (e != hipSuccess) { (void)hipModuleUnload(sp.mod); return hip_err(e, "mp_spec_ik"); }
+  }
   ctx->specs[model->uid] = sp;
   return MP_OK;
 }
@@ -1145,6 +1150,18 @@ int mp_inverse_kinematics_f64(mp_ctx* ctx, const mp_model* model, const double* 
   if (!ctx->queue_counter) {
     REQUIRE(!ctx->capturing, "mp_inverse_kinematics_f64: first use allocates; call it once before capturing a launch graph");
     HIP_TRY(hipMalloc(&ctx->queue_counter, 256));
+  }
+  if (const MpSpec* sp = find_spec(ctx, model)) {  // this robot's constants baked in (mp_model_specialize)
+    for (int j = 0; j < MP_MAX_DOF; ++j) {  // the specialised build assumes finite arithmetic: open limits become huge ones
+      if (!(P.lo[j] > -1e300)) P.lo[j] = -1e300;
+      if (!(P.hi[j] < 1e300)) P.hi[j] = 1e300;
+    }
+    HIP_TRY(hipMemsetAsync(ctx->queue_counter, 0, sizeof(unsigned long long), ctx->compute));
+    long nb = (long)B;
+    void* counter = ctx->queue_counter;
+    void* args[] = {&P, &d_T_desired, &d_theta0, &nb, &d_theta, &d_success, &d_iterations, &d_restarts, &counter};
+    const long want = (nb + 255) / 256, cap = 2L * (ctx->compute_units > 0 ? ctx->compute_units : 256);
+    return launch_spec(ctx, sp->ik, (want < cap ? want : cap) * 256, args);
   }
   HIP_TRY(mpk_ik(ctx->compute, model->d, P, d_T_desired, d_theta0, (long)B, d_theta, d_success, d_iterations, d_restarts,
                  (unsigned long long*)ctx->queue_counter, ctx->compute_units));

@@ -18,6 +18,10 @@
 
 #include "mp_core.h"
 
+// "no error measured yet": a large finite number, not infinity - the run-time specialised build compiles with
+// -ffinite-math-only, under which comparisons against an infinite constant are not dependable
+#define MP_IK_BIG 1e300
+
 struct MpIkParams {
   double eomg, ev, damping, step_cap, w_o, w_p;
   int max_iterations;
@@ -93,11 +97,11 @@ MP_HD void mp_ik_begin(MpIkState<N>& S, const MpIkParams& P) {
 #pragma unroll
   for (int j = 0; j < N; ++j) h = (h ^ __builtin_bit_cast(unsigned long long, S.theta[j])) * 0x100000001B3ull;
   S.key = h;
-  S.damping = P.damping; S.step_cap = P.step_cap; S.nu = 2.0; S.prev_err = HUGE_VAL;
+  S.damping = P.damping; S.step_cap = P.step_cap; S.nu = 2.0; S.prev_err = MP_IK_BIG;
 #pragma unroll
   for (int j = 0; j < N; ++j) S.best[j] = S.theta[j];
-  S.best_err = HUGE_VAL;
-  S.cur_err = HUGE_VAL;
+  S.best_err = MP_IK_BIG;
+  S.cur_err = MP_IK_BIG;
   S.stall = 0; S.k = 0; S.restarts = 0; S.success = 0;
 }
 

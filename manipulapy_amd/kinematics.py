@@ -7,6 +7,8 @@ plotting and the other concerns of the reference class are out of scope (SURVEY 
 """
 from __future__ import annotations
 
+import os
+
 from typing import List, Optional, Tuple
 
 import numpy as np
@@ -117,8 +119,16 @@ class SerialManipulator:
         (theta (B,n), success (B,) bool, iterations (B,) int).  Each problem runs the reference's damped-least-squares
         iteration (optionally with its adaptive damping and its five-scale line search); `self.joint_limits` is the
         projection box (None = open end)."""
+        model = self._kin_model()
+        if np.shape(T_desired_batch)[0] >= 16384 and os.environ.get("MANIPULAPY_HIP_SPECIALIZE", "1") != "0":
+            try:  # big batch: the ~2 s (first time; cached on disk) of baking this robot's constants in pays for itself
+                from .registry import get_context
+
+                get_context().specialize(model)
+            except Exception:  # no hiprtc: the generic kernel serves
+                pass
         theta, ok, it, _ = execute_registered_kernel(
-            "kinematics.inverse", self._kin_model(), T_desired_batch, thetalist0_batch, joint_limits=self.joint_limits, eomg=eomg,
+            "kinematics.inverse", model, T_desired_batch, thetalist0_batch, joint_limits=self.joint_limits, eomg=eomg,
             ev=ev, max_iterations=max_iterations, damping=damping, step_cap=step_cap, weight_orientation=weight_orientation,
             weight_position=weight_position, adaptive_tuning=adaptive_tuning, backtracking=backtracking, seed=seed)
         return theta, ok, it

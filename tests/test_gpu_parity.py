@@ -705,6 +705,17 @@ def test_inverse_kinematics_against_reference_runs_and_oracle(robot, tables):
     ctx = _hip.HipContext(0)
     try:
         m = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee)
+        # run-time specialised kernel (this robot's constants baked in) == generic kernel, also with the options on
+        ms = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee)
+        ctx.specialize(ms)
+        for kw in (dict(), dict(adaptive_tuning=True, backtracking=True)):
+            a = ctx.inverse_kinematics_host(m, T, q0, lim, max_iterations=300, **kw)
+            b = ctx.inverse_kinematics_host(ms, T, q0, lim, max_iterations=300, **kw)
+            same = (a[3] == 0) & (b[3] == 0)  # no restart on either side
+            assert same.sum() > B // 2
+            assert (a[1][same] == b[1][same]).mean() > 0.98 and (np.abs(a[2][same] - b[2][same]) <= 1).mean() > 0.95
+            both = same & a[1] & b[1]
+            assert np.abs(a[0][both] - b[0][both]).max() < 1e-5
         with pytest.raises(_hip.HipError):
             ctx.inverse_kinematics_host(m, T[:2], q0[:2], max_iterations=0)
         e = ctx.inverse_kinematics_host(m, T[:0], q0[:0])

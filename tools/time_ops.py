@@ -103,6 +103,13 @@ def main():
         out.append(dict(op="inverse_kinematics", robot=robot, dtype="float64", problems=B, ms=ms, problems_per_s=B / ms * 1e3,
                         success_rate=float(ok.mean()), mean_iterations=float(it.mean()), max_iterations=int(it.max()),
                         iterations_per_s=float(it.sum()) / ms * 1e3))
+        ctx.specialize(model)
+        ms = timed(ctx, lambda: ctx.inverse_kinematics(model, dT, d0, B, dth, dok, dit, drs, joint_limits=lim, max_iterations=200),
+                   steps=3, warmup=1)
+        ok = dok.download((B,), np.int32); it = dit.download((B,), np.int32)
+        out.append(dict(op="inverse_kinematics (specialised)", robot=robot, dtype="float64", problems=B, ms=ms,
+                        problems_per_s=B / ms * 1e3, success_rate=float(ok.mean()), mean_iterations=float(it.mean()),
+                        iterations_per_s=float(it.sum()) / ms * 1e3))
         for b in (dq, dT, d0, dth, dok, dit, drs):
             b.free()
         model.destroy()
