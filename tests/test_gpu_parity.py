@@ -940,6 +940,43 @@ def test_random_robots_on_gpu(seed, ctx):
     assert np.abs(s32[:9] - want).max() <= 2e-4 * scale
     np.testing.assert_allclose(s64[:9], want, rtol=1e-6, atol=1e-6 * scale)
     assert np.abs(s32 - t32).max() <= 2e-4 * scale
+    # mass matrix, forward dynamics, roll-out (every DOF has its own LDS tile shape) and IK on the same chain
+    gen = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee, tab.joint_limits)
+    M = ctx.mass_matrix_host(gen, q[:5])
+    for r in range(5):
+        np.testing.assert_allclose(M[r], ref.mass_matrix(tab, q[r]), rtol=1e-8, atol=1e-9)
+    tau_in = rng.uniform(-3, 3, (rows, n))
+    qdd_fd = ctx.forward_dynamics_host(gen, q[:3], qd[:3], tau_in[:3], g, F)
+    for r in range(3):
+        w = ref.forward_dynamics(tab, q[r], qd[r], tau_in[r], g, F)
+        np.testing.assert_allclose(qdd_fd[r], w, rtol=2e-5, atol=2e-5 * max(1.0, float(np.abs(w).max())))
+    B, Nt = 66, 6
+    th0 = q[:B % rows + 1][:1].repeat(B, axis=0) * rng.uniform(0.2, 1.0, (B, 1)); dth0 = rng.uniform(-0.2, 0.2, (B, n))
+    tm, Fm = rng.uniform(-1, 1, (B, Nt, n)), rng.uniform(-1, 1, (B, Nt, 6))
+    for dt_ in (np.float64, np.float32):
+        for wrench in (None, Fm):
+            a = ctx.fd_trajectory_host(gen, th0, dth0, tm, g, wrench, 0.005, 1, dtype=dt_)
+            b = ctx.fd_trajectory_host(m, th0, dth0, tm, g, wrench, 0.005, 1, dtype=dt_)  # m is specialised
+            o = ref.forward_dynamics_trajectory(tab, th0[B - 1], dth0[B - 1], tm[B - 1], g, np.zeros((Nt, 6)) if wrench is None else Fm[B - 1],
+                                                0.005, 1, joint_limits=tab.joint_limits)
+            tol = 2e-5 if dt_ == np.float64 else 1e-3
+            for k, name in enumerate(("positions", "velocities", "accelerations")):
+                sc = max(1.0, float(np.abs(o[name]).max()))
+                np.testing.assert_allclose(a[k][B - 1], o[name], rtol=tol, atol=tol * sc)
+                assert np.abs(a[k] - b[k]).max() <= (1e-6 if dt_ == np.float64 else 1e-3) * max(1.0, float(np.abs(a[k]).max()))
+    prismatic = np.abs(tab.S[:3]).sum(axis=0) == 0
+    lim = np.tile([-2.5, 2.5], (n, 1)).astype(float)
+    lim[prismatic] = [-0.4, 0.4]
+    q_true = rng.uniform(0.7 * lim[:, 0], 0.7 * lim[:, 1], (6, n))
+    Tt = np.stack([ref.fk_space(tab, x) for x in q_true])
+    q0 = np.clip(q_true + rng.uniform(-0.2, 0.2, (6, n)) * np.where(prismatic, 0.2, 1.0), lim[:, 0], lim[:, 1])
+    th, ok, it, rs = ctx.inverse_kinematics_host(gen, Tt, q0, lim, max_iterations=150)
+    for b in range(6):
+        o_th, o_ok, o_it, o_rs = ref.iterative_inverse_kinematics(tab, Tt[b], q0[b], max_iterations=150, joint_limits=lim,
+                                                                  rng=np.random.RandomState(0))
+        if o_rs == 0 and rs[b] == 0:
+            assert bool(ok[b]) == o_ok and abs(int(it[b]) - o_it) <= 1
+            np.testing.assert_allclose(th[b], o_th, rtol=0, atol=1e-6 if o_ok else 1e-4)
 
 
 def test_cartesian_trajectory_on_gpu(ctx):
