@@ -104,6 +104,19 @@ def cpu_baseline(robot, q, qd, qdd, budget_s=12.0):
                       f"reference algorithm (the reference's own NumPy code runs ~40-80 ms per row, BASELINE.md)"}, tau
 
 
+def emit(result):
+    """The ONE JSON line, as the last line of stdout: native libraries (RCCL prints a version banner) write through C stdio,
+    which is block-buffered on a pipe and would otherwise land after an early Python print when the process exits."""
+    import ctypes
+
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    print(json.dumps(result), flush=True)
+
+
 def ramp(ctx, step, ms):
     """Setup, untimed: keep the GPU busy with the step for `ms` milliseconds (clock / power ramp after the idle setup phase;
     measured on c2: 0.080 ms per step right after start-up, 0.0747 ms once warm)."""
@@ -193,7 +206,7 @@ def bench_fd(args, cfg, info, hg, ctx, model, t, props):
                                   "sample": f"11 integration steps of one trajectory, {dtc:.1f} s, single thread, NumPy oracle"}
         result["parity_sample"] = {"rows": 12, "max_abs_err": float(np.abs(pos[0, :12] - r0["positions"]).max())}
     if info.rank == 0:
-        print(json.dumps(result), flush=True)
+        emit(result)
     ctx.destroy()
 
 
@@ -287,16 +300,17 @@ def main():
         else:
             ctx.fk_jac_id(model, d_q, d_qd, d_qdd, rows, d_T, d_J, d_tau, dtype=dt_np)
 
-    def timed(fn_after_step=None):
+    def timed(fn_after_step=None, step_fn=None):
         """W warm-up steps, then exactly K timed steps between barrier + device sync on both sides.
         Returns (max-over-ranks wall seconds, mean kernel ms from HIP events on the launch stream)."""
+        do = step_fn or step
         ramp(ctx, step, args.ramp_ms)
         for _ in range(args.warmup):
-            step()
+            do()
             if fn_after_step:
                 fn_after_step()
         ctx.synchronize()
-        if args.launch == "graph" and fn_after_step is None:
+        if args.launch == "graph" and fn_after_step is None and step_fn is None:
             # the K launches of the timed region are captured once (hipGraph) and submitted as ONE graph launch: the
             # queue then holds all K dispatch packets up front instead of receiving one per host call
             with ctx.capture() as cap:
@@ -333,7 +347,7 @@ def main():
             pair = ev.get(k)
             if pair:
                 pair[0].record()
-            step()
+            do()
             if pair:
                 pair[1].record()
             if fn_after_step:
@@ -355,7 +369,8 @@ def main():
     # ---- multi-GPU only: the RCCL all-gather that reassembles the sharded torque history on every GPU,
     #      measured as a second timed loop (step + all-gather) and reported next to `value`
     allgather = None
-    if world > 1 and not args.no_gather:
+    # MANIPULAPY_BENCH_FORCE_GATHER=1 runs the phase on a single GPU too (a one-rank communicator): exercises this code path
+    if (world > 1 or os.environ.get("MANIPULAPY_BENCH_FORCE_GATHER") == "1") and not args.no_gather:
         allgather = {"bytes_per_rank": nb, "collective": "ncclAllGather (RCCL), one call per step after the kernel"}
 
         def verify_gather(d_all):
@@ -390,6 +405,35 @@ def main():
                                   "busbw_GBps": nb * (world - 1) / max(ms_g - elapsed / args.steps * 1e3, 1e-6) / 1e6})
                 if info.rank == 0 and cfg["op"] == "id" and cfg["dtype"] == "f32":
                     allgather["verified"] = verify_gather(d_tau_all)
+                if cfg["op"] == "id":
+                    # the same reassembly overlapped with compute: the shard is evaluated in 4 chunks straight into this
+                    # rank's slot of the gathered buffer; after each chunk's kernel its bytes travel to every peer
+                    # (grouped ncclSend / ncclRecv on the communicator's stream) while the next chunk's kernel runs
+                    try:
+                        ctx.memset(d_tau_all, 0, nb * world)
+                        chunks = 4
+                        rc = ((rows // chunks) + 1) & ~1  # even, so only the last chunk can end on an odd row
+                        row_b = n * wbytes
+
+                        def step_overlapped():
+                            for r0 in range(0, rows, rc):
+                                nr = min(rc, rows - r0)
+                                off = r0 * row_b
+                                ctx.id_trajectory(model, d_q.offset(off), d_qd.offset(off), d_qdd.offset(off), nr,
+                                                  d_tau_all.offset(info.rank * nb + off), dtype=dt_np)
+                                comm.exchange_chunk(d_tau_all, nb, off, nr * row_b)
+                            comm.join()
+
+                        wall_o, _ = timed(step_fn=step_overlapped)
+                        ms_o = wall_o / args.steps * 1e3
+                        allgather["overlapped"] = {"chunks": chunks, "ms_per_step": ms_o,
+                                                   "value": rows * n * world * args.steps / wall_o,
+                                                   "how": "per chunk: kernel on the compute stream, then grouped ncclSend/ncclRecv "
+                                                          "to every peer on the communicator's stream"}
+                        if info.rank == 0 and cfg["dtype"] == "f32":
+                            allgather["overlapped"]["verified"] = verify_gather(d_tau_all)
+                    except Exception as exc:
+                        allgather["overlapped"] = {"error": str(exc)[:300]}
                 comm.destroy()
             except Exception as exc:  # keep the compute line even if RCCL is unusable on this node
                 allgather["error"] = str(exc)[:300]
@@ -458,7 +502,7 @@ def main():
     if allgather is not None:
         result["allgather"] = allgather
     if info.rank == 0:
-        print(json.dumps(result), flush=True)
+        emit(result)
     if hung:
         os._exit(0)  # a stuck collective cannot be cancelled from Python
     ctx.destroy()

@@ -254,6 +254,15 @@ int mp_comm_destroy(mp_comm* comm);
 /* d_recv (nranks * bytes_per_rank) <- every rank's d_send (bytes_per_rank); enqueued on the compute
  * stream after the kernels already queued there. */
 int mp_comm_allgather(mp_comm* comm, const void* d_send, void* d_recv, size_t bytes_per_rank);
+/* The same reassembly, overlapped with compute.  d_all holds nranks slots of bytes_per_rank; a rank writes ITS slot
+ * chunk by chunk with ordinary launches on the compute stream (output pointer = slot + offset) and, after the launches
+ * of a chunk, calls mp_comm_exchange_chunk: the bytes [offset, offset + nbytes) of its slot go to every peer, every
+ * peer's same range arrives in that peer's slot (one ncclSend + ncclRecv per peer in a group: xGMI is point to point),
+ * on the communicator's own stream, ordered behind the compute stream's tail - so the kernels of the next chunk run
+ * beside the exchange.  Every rank must issue the same sequence of chunks.  mp_comm_join makes the compute stream
+ * wait for all exchanges issued so far (call it before anything reads d_all). */
+int mp_comm_exchange_chunk(mp_comm* comm, void* d_all, size_t bytes_per_rank, size_t offset, size_t nbytes);
+int mp_comm_join(mp_comm* comm);
 
 #ifdef __cplusplus
 }

@@ -106,6 +106,8 @@ SIGNATURES = {
     "mp_comm_create": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint8), ctypes.c_int, ctypes.c_int, ctypes.POINTER(_vp)]),
     "mp_comm_destroy": (ctypes.c_int, [_vp]),
     "mp_comm_allgather": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t]),
+    "mp_comm_exchange_chunk": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t]),
+    "mp_comm_join": (ctypes.c_int, [_vp]),
 }
 
 _lib = None
@@ -425,6 +427,10 @@ class HipContext:
         host = np.ascontiguousarray(host)
         return DeviceBuffer(self, host.nbytes).upload(host)
 
+    def memset(self, buf, value: int, nbytes: int) -> None:
+        """Asynchronous byte fill on the compute stream."""
+        _check(self.lib.mp_memset(self.handle, _p(buf), int(value), ctypes.c_size_t(int(nbytes))))
+
     def event(self) -> HipEvent:
         return HipEvent(self)
 
@@ -701,6 +707,16 @@ class HipComm:
 
     def allgather(self, d_send, d_recv, bytes_per_rank: int) -> None:
         _check(self.ctx.lib.mp_comm_allgather(self.handle, _p(d_send), _p(d_recv), ctypes.c_size_t(int(bytes_per_rank))))
+
+    def exchange_chunk(self, d_all, bytes_per_rank: int, offset: int, nbytes: int) -> None:
+        """Bytes [offset, offset + nbytes) of this rank's slot of `d_all` (just written on the compute stream) go to every
+        peer, the peers' same range arrives in their slots, on the communicator's own stream (overlaps later kernels)."""
+        _check(self.ctx.lib.mp_comm_exchange_chunk(self.handle, _p(d_all), ctypes.c_size_t(int(bytes_per_rank)),
+                                                   ctypes.c_size_t(int(offset)), ctypes.c_size_t(int(nbytes))))
+
+    def join(self) -> None:
+        """The compute stream waits for every exchange issued so far."""
+        _check(self.ctx.lib.mp_comm_join(self.handle))
 
     def destroy(self) -> None:
         if self.handle is not None:

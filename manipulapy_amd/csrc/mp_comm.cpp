@@ -24,6 +24,10 @@ struct Api {
   int (*CommInitRank)(Comm*, int, UniqueId, int) = nullptr;
   int (*CommDestroy)(Comm) = nullptr;
   int (*AllGather)(const void*, void*, size_t, int, Comm, hipStream_t) = nullptr;
+  int (*Send)(const void*, size_t, int, int, Comm, hipStream_t) = nullptr;
+  int (*Recv)(void*, size_t, int, int, Comm, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
 };
 Api g_api;
@@ -48,7 +52,12 @@ int load_api() {
   a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
   a.AllGather = reinterpret_cast<decltype(a.AllGather)>(dlsym(h, "ncclAllGather"));
   a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
-  if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllGather || !a.GetErrorString)
+  a.Send = reinterpret_cast<decltype(a.Send)>(dlsym(h, "ncclSend"));
+  a.Recv = reinterpret_cast<decltype(a.Recv)>(dlsym(h, "ncclRecv"));
+  a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(dlsym(h, "ncclGroupStart"));
+  a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
+  if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllGather || !a.GetErrorString || !a.Send || !a.Recv ||
+      !a.GroupStart || !a.GroupEnd)
     return fail("librccl.so", "missing nccl* symbol");
   g_api = a;
   return MP_OK;
@@ -60,6 +69,7 @@ struct mp_comm {
   mp_ctx* ctx = nullptr;
   Comm comm = nullptr;
   int nranks = 0, rank = 0;
+  hipStream_t stream = nullptr;  // the exchanges of mp_comm_exchange_chunk run here, beside the compute stream
 };
 
 extern "C" {
@@ -86,12 +96,18 @@ int mp_comm_create(mp_ctx* ctx, const uint8_t id[MP_UNIQUE_ID_BYTES], int nranks
   UniqueId u;
   std::memcpy(u.internal, id, MP_UNIQUE_ID_BYTES);
   if (int rc = g_api.CommInitRank(&c->comm, nranks, u, rank)) { delete c; return nccl_fail("ncclCommInitRank", rc); }
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    (void)g_api.CommDestroy(c->comm);
+    delete c;
+    return mp_set_error(MP_ERR_HIP, "mp_comm_create: hipStreamCreate failed");
+  }
   *out = c;
   return MP_OK;
 }
 
 int mp_comm_destroy(mp_comm* comm) {
   if (!comm) return MP_OK;
+  if (comm->stream) { (void)hipStreamSynchronize(comm->stream); (void)hipStreamDestroy(comm->stream); }
   if (comm->comm && g_api.CommDestroy) (void)g_api.CommDestroy(comm->comm);
   delete comm;
   return MP_OK;
@@ -105,6 +121,46 @@ int mp_comm_allgather(mp_comm* comm, const void* d_send, void* d_recv, size_t by
   if (int rc = g_api.AllGather(d_send, d_recv, bytes_per_rank, 0, comm->comm, mp_ctx_compute_stream(comm->ctx)))
     return nccl_fail("ncclAllGather", rc);
   return MP_OK;
+}
+
+// order stream `after` behind everything queued so far on stream `before`
+static int chain(hipStream_t before, hipStream_t after, const char* fn) {
+  hipEvent_t ev = nullptr;
+  if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return mp_set_error(MP_ERR_HIP, fn);
+  hipError_t e = hipEventRecord(ev, before);
+  if (e == hipSuccess) e = hipStreamWaitEvent(after, ev, 0);
+  (void)hipEventDestroy(ev);  // released by the runtime once the recorded work has completed
+  return e == hipSuccess ? MP_OK : mp_set_error(MP_ERR_HIP, fn);
+}
+
+int mp_comm_exchange_chunk(mp_comm* comm, void* d_all, size_t bytes_per_rank, size_t offset, size_t nbytes) {
+  if (!comm || !d_all) return mp_set_error(MP_ERR_INVALID, "mp_comm_exchange_chunk: null argument");
+  if (offset + nbytes > bytes_per_rank) return mp_set_error(MP_ERR_INVALID, "mp_comm_exchange_chunk: chunk exceeds the per-rank slot");
+  if (nbytes == 0) return MP_OK;
+  if (hipSetDevice(mp_ctx_device(comm->ctx)) != hipSuccess) return mp_set_error(MP_ERR_HIP, "mp_comm_exchange_chunk: hipSetDevice failed");
+  // the chunk was produced by kernels already queued on the compute stream: the exchange starts when they are done,
+  // on its own stream, so the kernels of the NEXT chunk run beside it
+  if (int rc = chain(mp_ctx_compute_stream(comm->ctx), comm->stream, "mp_comm_exchange_chunk: event chain failed")) return rc;
+  if (comm->nranks == 1) return MP_OK;
+  char* base = static_cast<char*>(d_all);
+  if (int rc = g_api.GroupStart()) return nccl_fail("ncclGroupStart", rc);
+  int err = 0;
+  for (int p = 0; p < comm->nranks && !err; ++p) {
+    if (p == comm->rank) continue;
+    // xGMI is point to point: one send and one receive per peer, all seven links busy at once (no ring)
+    err = g_api.Send(base + (size_t)comm->rank * bytes_per_rank + offset, nbytes, 0, p, comm->comm, comm->stream);
+    if (!err) err = g_api.Recv(base + (size_t)p * bytes_per_rank + offset, nbytes, 0, p, comm->comm, comm->stream);
+  }
+  const int end = g_api.GroupEnd();
+  if (err) return nccl_fail("ncclSend / ncclRecv", err);
+  if (end) return nccl_fail("ncclGroupEnd", end);
+  return MP_OK;
+}
+
+int mp_comm_join(mp_comm* comm) {
+  if (!comm) return mp_set_error(MP_ERR_INVALID, "mp_comm_join: null communicator");
+  if (hipSetDevice(mp_ctx_device(comm->ctx)) != hipSuccess) return mp_set_error(MP_ERR_HIP, "mp_comm_join: hipSetDevice failed");
+  return chain(comm->stream, mp_ctx_compute_stream(comm->ctx), "mp_comm_join: event chain failed");
 }
 
 }  // extern "C"

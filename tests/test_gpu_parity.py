@@ -524,6 +524,41 @@ def test_rccl_communicator_single_rank(ctx):
     d_s.free(); d_r.free()
 
 
+def test_overlapped_chunk_exchange_single_rank(ctx, models, tables):
+    """mp_comm_exchange_chunk / mp_comm_join with nranks = 1: the shard is evaluated chunk by chunk straight into its slot of
+    the gathered buffer, each chunk followed by its exchange on the communicator's stream; after the join the buffer holds
+    what one plain launch produces.  (With one rank the exchange has no peers: this covers the stream / event chaining and
+    the argument checks; the peer traffic itself needs a multi-GPU node.)"""
+    from manipulapy_amd import _hip
+
+    tab, model = tables["ur5"], models["ur5"]
+    n, rows = tab.n, 100001
+    rng = np.random.default_rng(21)
+    q, qd, qdd = (rng.uniform(-1, 1, (rows, n)).astype(np.float32) for _ in range(3))
+    d_q, d_qd, d_qdd = ctx.to_device(q), ctx.to_device(qd), ctx.to_device(qdd)
+    nb = rows * n * 4
+    d_all = ctx.alloc(nb)
+    ctx.memset(d_all, 0xFF, nb)
+    comm = ctx.comm_create(_hip.HipContext.comm_unique_id(), 1, 0)
+    rc = ((rows // 4) + 1) & ~1
+    for r0 in range(0, rows, rc):
+        nr, off = min(rc, rows - r0), r0 * n * 4
+        ctx.id_trajectory(model, d_q.offset(off), d_qd.offset(off), d_qdd.offset(off), nr, d_all.offset(off))
+        comm.exchange_chunk(d_all, nb, off, nr * n * 4)
+    comm.join()
+    ctx.synchronize()
+    got = d_all.download((rows, n), np.float32)
+    # chunk boundaries change which rows share a lane, not the per-row arithmetic beyond float32 rounding of the packed pairs
+    want = ctx.id_trajectory_host(model, q, qd, qdd)
+    assert np.isfinite(got).all()
+    assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max()
+    with pytest.raises(_hip.HipError):
+        comm.exchange_chunk(d_all, nb, nb - 8, 16)
+    comm.destroy()
+    for b in (d_q, d_qd, d_qdd, d_all):
+        b.free()
+
+
 def test_forward_dynamics_trajectory_packed_variant(tables):
     """MANIPULAPY_HIP_FD=packed (two trajectories per lane, off by default): same results as the default kernels to
     float32 rounding and as the oracle, generic and specialised, odd batch, partial tiles, with and without wrenches."""
