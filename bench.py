@@ -66,7 +66,7 @@ def kernel_name(cfg):
     spec = cfg.get("specialized")
     return {"id": ("mp_spec_id_pk_f0" if cfg["dtype"] == "f32" else "mp_spec_id_d_f0") if spec else
                   ("k_id_pk" if cfg["dtype"] == "f32" else "k_id"),
-            "fused": "mp_spec_traj_id_pk_f0" if spec else "k_traj_id_pk",
+            "fused": "mp_spec_traj_id_pk_f0" if spec else "k_traj_id_pk_tab",
             "fk_jac_id": "mp_spec_fk_jac_id_d_f0" if spec else "k_fk_jac_id",
             "fd_traj": "mp_spec_fd_traj_f1" if spec else "k_fd_traj"}[cfg["op"]]
 

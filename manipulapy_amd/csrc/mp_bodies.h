@@ -324,6 +324,56 @@ __device__ __forceinline__ void mp_body_traj_id_pk(const MT& M, const MpCall<flo
   store_pair<N>(tau, p, tq);
 }
 
+// The same with the time scaling taken from a per-call table (s, s', s'' per timestep, three doubles each, written by
+// k_time_table with exactly the arithmetic of traj_row) and with both rows of the lane in ONE trajectory: timesteps t0
+// and t1 = t0 + ceil(Nt / 2).  Per pair this removes the eleven float64 divisions and the 64-bit row -> (trajectory,
+// timestep) division of the form above (293 float64 + ~100 integer instructions of 1006), loads the end points once,
+// and stores tau in one-row-per-lane runs.  `valid1` is false for the unpaired middle row of an odd Nt.
+template <int N, bool HAS_FTIP, typename MT>
+__device__ __forceinline__ void mp_body_traj_id_pk_tab(const MT& M, const MpCall<float>& C, const float* __restrict__ start,
+                                                       const float* __restrict__ end, long b, long t0, long t1, bool valid1,
+                                                       long Nt, const double* __restrict__ tab, float* __restrict__ tau) {
+  float a[N], e[N];
+  RunIO<float, N>::load(start, b, a);
+  RunIO<float, N>::load(end, b, e);
+  const double s0 = tab[3 * t0], sd0 = tab[3 * t0 + 1], sdd0 = tab[3 * t0 + 2];
+  const double s1 = tab[3 * t1], sd1 = tab[3 * t1 + 1], sdd1 = tab[3 * t1 + 2];
+  mp_f2 qq[N], qd[N], qdd[N], tq[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const double d = (double)(e[j] - a[j]);  // float32 difference first, as the reference types it
+    qq[j] = (mp_f2){mp_clip((float)(s0 * d + (double)a[j]), M.qmin[j], M.qmax[j]),
+                    mp_clip((float)(s1 * d + (double)a[j]), M.qmin[j], M.qmax[j])};
+    qd[j] = (mp_f2){(float)(sd0 * d), (float)(sd1 * d)};
+    qdd[j] = (mp_f2){(float)(sdd0 * d), (float)(sdd1 * d)};
+  }
+  MpJointState<mp_f2, N> js;
+  mp_joint_state<mp_f2, N>(M, qq, js);
+  mp_rnea<mp_f2, N, HAS_FTIP>(M, C, js, qd, qdd, tq);
+  float lo[N], hi[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const mp_f2 c = mp_clip(tq[j], M.taumin[j], M.taumax[j]);
+    lo[j] = c.x; hi[j] = c.y;
+  }
+  RunIO<float, N>::store(tau, b * Nt + t0, lo);
+  if (valid1) RunIO<float, N>::store(tau, b * Nt + t1, hi);
+}
+
+// lane -> (trajectory, timestep pair) for the kernel above: `bpt` blocks of `block` lanes per trajectory
+__device__ __forceinline__ bool mp_traj_pair(unsigned block_idx, unsigned lane, unsigned block, unsigned bpt, long Nt, long& b,
+                                             long& t0, long& t1, bool& valid1) {
+  const unsigned bb = block_idx / bpt;  // block-uniform: a scalar division
+  const long half = (Nt + 1) / 2;
+  t0 = (long)(block_idx - bb * bpt) * block + lane;
+  if (t0 >= half) return false;
+  b = bb;
+  t1 = t0 + half;
+  valid1 = t1 < Nt;
+  if (!valid1) t1 = t0;  // the duplicate is computed and dropped
+  return true;
+}
+
 // forward_dynamics_trajectory (reference planning/trajectory_dynamics.py:580-708): one lane integrates one
 // trajectory — semi-implicit Euler, `intRes` sub-steps of dt/intRes per outer step, joint-limit clip after
 // every sub-step, rows stored float32, the recorded acceleration is the last sub-step's, row 0 = initial

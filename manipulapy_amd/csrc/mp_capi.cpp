@@ -39,6 +39,10 @@ struct mp_ctx {
   int compute_units = 0;
   bool capturing = false;                              // between mp_graph_begin and mp_graph_end
   void* queue_counter = nullptr;                       // 8-byte work-queue head of the IK kernel (lazily allocated)
+  double* time_tab = nullptr;                          // per-timestep time-scaling table of the fused kernels
+  long tab_cap = 0, tab_Nt = -1;                       // its capacity in timesteps / the call it currently holds
+  double tab_Tf = 0;
+  int tab_method = 0;
   std::recursive_mutex mu;                             // serialises the entry points of this context (CTX_ENTER)
 };
 struct mp_model {
@@ -495,6 +499,7 @@ int mp_ctx_destroy(mp_ctx* ctx) {
   for (auto& kv : ctx->specs) if (kv.second.mod) (void)hipModuleUnload(kv.second.mod);
   for (auto& kv : ctx->live) (void)hipFree(kv.first);
   if (ctx->queue_counter) (void)hipFree(ctx->queue_counter);
+  if (ctx->time_tab) (void)hipFree(ctx->time_tab);
   if (ctx->compute) (void)hipStreamDestroy(ctx->compute);
   if (ctx->copy) (void)hipStreamDestroy(ctx->copy);
   if (ctx->copy_out) (void)hipStreamDestroy(ctx->copy_out);
@@ -863,14 +868,34 @@ int mp_traj_id_fused_f32(mp_ctx* ctx, const mp_model* model, const float* d_star
   MpCall<float> c;
   make_call<float>(model, g, Ftip, &c);
   const bool ftip = any_nonzero(Ftip);
-  const long rows = (long)B * (long)N, pairs = rows / 2;
-  const MpSpec* sp = find_spec(ctx, model);
-  if (sp && pairs > 0 && rows == 2 * pairs) {  // an odd total falls through to the generic kernels
-    long np = pairs, nt = (long)N;
-    void* args[] = {&c, &d_start, &d_end, &np, &nt, &Tf, &method, &d_tau};
-    return launch_spec(ctx, sp->traj_id_pk[ftip ? 1 : 0], pairs, args);
+  if (!mpk_packed_f32()) {  // MANIPULAPY_HIP_F32=scalar: the one-row-per-lane kernel, time scaling computed per row
+    HIP_TRY(mpk_traj_id(ctx->compute, model->f, c, ftip, d_start, d_end, (long)B, (long)N, Tf, method, d_tau));
+    return MP_OK;
   }
-  HIP_TRY(mpk_traj_id(ctx->compute, model->f, c, ftip, d_start, d_end, (long)B, (long)N, Tf, method, d_tau));
+  // per-timestep table of (s, s', s''): rebuilt on the stream only when (N, Tf, method) differ from the last call
+  if (ctx->tab_cap < (long)N) {
+    REQUIRE(!ctx->capturing, "mp_traj_id_fused_f32: the first call for this N allocates; run it once before capturing a launch graph");
+    HIP_TRY(hipStreamSynchronize(ctx->compute));  // earlier kernels may still read the old table
+    if (ctx->time_tab) (void)hipFree(ctx->time_tab);
+    ctx->time_tab = nullptr; ctx->tab_cap = 0; ctx->tab_Nt = -1;
+    HIP_TRY(hipMalloc((void**)&ctx->time_tab, (size_t)N * 3 * sizeof(double)));
+    ctx->tab_cap = (long)N;
+  }
+  if (ctx->capturing || ctx->tab_Nt != (long)N || ctx->tab_Tf != Tf || ctx->tab_method != method) {
+    HIP_TRY(mpk_time_table(ctx->compute, ctx->time_tab, (long)N, Tf, method));
+    ctx->tab_Nt = (long)N; ctx->tab_Tf = Tf; ctx->tab_method = method;
+    // a captured launch only RECORDS the table kernel (it becomes part of the graph, so replays are self-contained);
+    // the table itself is not written now, so the next ordinary call must rebuild it
+    if (ctx->capturing) ctx->tab_Nt = -1;
+  }
+  if (const MpSpec* sp = find_spec(ctx, model)) {
+    long nt = (long)N;
+    unsigned bpt = mpk_traj_blocks_per_trajectory(nt);
+    const double* tab = ctx->time_tab;
+    void* args[] = {&c, &d_start, &d_end, &nt, &bpt, &tab, &d_tau};
+    return launch_spec(ctx, sp->traj_id_pk[ftip ? 1 : 0], (long)B * bpt * 256, args);
+  }
+  HIP_TRY(mpk_traj_id_tab(ctx->compute, model->f, c, ftip, d_start, d_end, (long)B, (long)N, ctx->time_tab, d_tau));
   return MP_OK;
 }
 

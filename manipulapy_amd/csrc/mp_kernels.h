@@ -50,3 +50,11 @@ struct MpIkParams;
 hipError_t mpk_ik(hipStream_t s, const MpModel<double>& M, const MpIkParams& P, const double* Tdes, const double* theta0, long B,
                   double* theta, int* success, int* iterations, int* restarts, unsigned long long* queue_counter, int compute_units);
 
+// table-driven fused generation + ID (float32): `tab` = 3 doubles per timestep written by mpk_time_table for the same
+// (Nt, Tf, method); one lane takes timesteps t and t + ceil(Nt / 2) of one trajectory
+bool mpk_packed_f32();  // false under MANIPULAPY_HIP_F32=scalar
+hipError_t mpk_time_table(hipStream_t s, double* tab, long Nt, double Tf, int method);
+unsigned mpk_traj_blocks_per_trajectory(long Nt);
+hipError_t mpk_traj_id_tab(hipStream_t s, const MpModel<float>& M, const MpCall<float>& C, bool ftip, const float* start,
+                           const float* end, long B, long Nt, const double* tab, float* tau);
+

@@ -137,6 +137,28 @@ __global__ __launch_bounds__(kBlock, MP_PK_MINW) void k_traj_id_pk(const MpModel
   mp_body_traj_id_pk<N, HAS_FTIP>(M, C, start, end, p, Nt, Tf, method, tau);
 }
 
+// per-call table of the time scaling, three doubles per timestep: exactly traj_row's arithmetic, once per timestep
+// instead of once per row
+__global__ __launch_bounds__(kBlock) void k_time_table(double* __restrict__ tab, long Nt, double Tf, int method) {
+  const long t = (long)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= Nt) return;
+  const double tt = (double)t * (Tf / (double)(Nt - 1));
+  double s, sd, sdd;
+  mp_time_scaling(method, tt / Tf, Tf, s, sd, sdd);
+  tab[3 * t] = s; tab[3 * t + 1] = sd; tab[3 * t + 2] = sdd;
+}
+
+template <int N, bool HAS_FTIP>
+__global__ __launch_bounds__(kBlock, MP_PK_MINW) void k_traj_id_pk_tab(const MpModel<float> M, const MpCall<float> C,
+                                                              const float* __restrict__ start, const float* __restrict__ end,
+                                                              long Nt, unsigned bpt, const double* __restrict__ tab,
+                                                              float* __restrict__ tau) {
+  long b, t0, t1;
+  bool valid1;
+  if (!mp_traj_pair(blockIdx.x, threadIdx.x, kBlock, bpt, Nt, b, t0, t1, valid1)) return;
+  mp_body_traj_id_pk_tab<N, HAS_FTIP>(M, C, start, end, b, t0, t1, valid1, Nt, tab, tau);
+}
+
 // ------------------------------------------------------------- FK + space Jacobian + ID fused
 // one wave per block: the per-wave LDS staging slice (9 KiB) then never limits residency (a 256-thread block needs
 // 36 KiB, i.e. at most 4 blocks = 16 waves per CU, and blocks drain unevenly: 1.7 waves per SIMD measured)
@@ -386,6 +408,29 @@ hipError_t mpk_batch_traj(hipStream_t s, const MpModel<float>& M, const float* s
   if (rows <= 0) return hipSuccess;
   MP_DISPATCH_N(M.n, {
     hipLaunchKernelGGL((k_batch_traj<N>), dim3(grid_for(rows)), dim3(kBlock), 0, s, M, start, end, B, Nt, Tf, method, pos, vel, acc);
+  })
+  return hipGetLastError();
+}
+
+bool mpk_packed_f32() { return use_packed_f32(); }
+
+hipError_t mpk_time_table(hipStream_t s, double* tab, long Nt, double Tf, int method) {
+  if (Nt <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_time_table, dim3(grid_for(Nt)), dim3(kBlock), 0, s, tab, Nt, Tf, method);
+  return hipGetLastError();
+}
+
+// blocks per trajectory of the table-driven fused kernels (block = 256 lanes, ceil(Nt / 2) lanes per trajectory)
+unsigned mpk_traj_blocks_per_trajectory(long Nt) { return (unsigned)(((Nt + 1) / 2 + kBlock - 1) / kBlock); }
+
+hipError_t mpk_traj_id_tab(hipStream_t s, const MpModel<float>& M, const MpCall<float>& C, bool ftip, const float* start,
+                           const float* end, long B, long Nt, const double* tab, float* tau) {
+  if (B <= 0 || Nt <= 0) return hipSuccess;
+  const unsigned bpt = mpk_traj_blocks_per_trajectory(Nt);
+  const unsigned grid = (unsigned)(B * bpt);
+  MP_DISPATCH_N(M.n, {
+    if (ftip) hipLaunchKernelGGL((k_traj_id_pk_tab<N, true>), dim3(grid), dim3(kBlock), 0, s, M, C, start, end, Nt, bpt, tab, tau);
+    else hipLaunchKernelGGL((k_traj_id_pk_tab<N, false>), dim3(grid), dim3(kBlock), 0, s, M, C, start, end, Nt, bpt, tab, tau);
   })
   return hipGetLastError();
 }
