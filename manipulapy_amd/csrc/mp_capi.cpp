@@ -43,6 +43,8 @@ struct mp_ctx {
   long tab_cap = 0, tab_Nt = -1;                       // its capacity in timesteps / the call it currently holds
   double tab_Tf = 0;
   int tab_method = 0;
+  bool tab_volatile = false;                           // a launch graph holds a table kernel: never trust the cache again
+  std::vector<void*> retired_tabs;                     // outgrown tables that captured graphs may still reference
   std::recursive_mutex mu;                             // serialises the entry points of this context (CTX_ENTER)
 };
 struct mp_model {
@@ -500,6 +502,7 @@ int mp_ctx_destroy(mp_ctx* ctx) {
   for (auto& kv : ctx->live) (void)hipFree(kv.first);
   if (ctx->queue_counter) (void)hipFree(ctx->queue_counter);
   if (ctx->time_tab) (void)hipFree(ctx->time_tab);
+  for (void* p : ctx->retired_tabs) (void)hipFree(p);
   if (ctx->compute) (void)hipStreamDestroy(ctx->compute);
   if (ctx->copy) (void)hipStreamDestroy(ctx->copy);
   if (ctx->copy_out) (void)hipStreamDestroy(ctx->copy_out);
@@ -876,17 +879,19 @@ int mp_traj_id_fused_f32(mp_ctx* ctx, const mp_model* model, const float* d_star
   if (ctx->tab_cap < (long)N) {
     REQUIRE(!ctx->capturing, "mp_traj_id_fused_f32: the first call for this N allocates; run it once before capturing a launch graph");
     HIP_TRY(hipStreamSynchronize(ctx->compute));  // earlier kernels may still read the old table
-    if (ctx->time_tab) (void)hipFree(ctx->time_tab);
+    if (ctx->time_tab && ctx->tab_volatile) ctx->retired_tabs.push_back(ctx->time_tab);  // a launch graph still points at it
+    else if (ctx->time_tab) (void)hipFree(ctx->time_tab);
     ctx->time_tab = nullptr; ctx->tab_cap = 0; ctx->tab_Nt = -1;
     HIP_TRY(hipMalloc((void**)&ctx->time_tab, (size_t)N * 3 * sizeof(double)));
     ctx->tab_cap = (long)N;
   }
-  if (ctx->capturing || ctx->tab_Nt != (long)N || ctx->tab_Tf != Tf || ctx->tab_method != method) {
+  // A captured call RECORDS its table kernel (the graph is self-contained), and every later replay rewrites the shared
+  // table behind the cache's back - so once a capture has happened on this context the cache is off for good: every
+  // call then writes its own table first (one extra ~2 us kernel, stream-ordered before the kernel that reads it).
+  if (ctx->capturing) ctx->tab_volatile = true;
+  if (ctx->tab_volatile || ctx->tab_Nt != (long)N || ctx->tab_Tf != Tf || ctx->tab_method != method) {
     HIP_TRY(mpk_time_table(ctx->compute, ctx->time_tab, (long)N, Tf, method));
     ctx->tab_Nt = (long)N; ctx->tab_Tf = Tf; ctx->tab_method = method;
-    // a captured launch only RECORDS the table kernel (it becomes part of the graph, so replays are self-contained);
-    // the table itself is not written now, so the next ordinary call must rebuild it
-    if (ctx->capturing) ctx->tab_Nt = -1;
   }
   if (const MpSpec* sp = find_spec(ctx, model)) {
     long nt = (long)N;

@@ -943,6 +943,23 @@ def test_launch_graph_replays_the_captured_calls(ctx, models, tables):
     graph.destroy()
     for b in d32 + d64 + dfd + [t32, t64, dT, dJ] + out:
         b.free()
+    # the fused generation + ID call keeps a per-context time-scaling table keyed by (N, Tf, method): a captured call
+    # carries its own table kernel, so a replay is right even after other calls have rewritten the table
+    Bf, Nf = 7, 33
+    st, en = rng.uniform(-1, 1, (Bf, n)).astype(np.float32), rng.uniform(-1, 1, (Bf, n)).astype(np.float32)
+    d_st, d_en, d_t = ctx.to_device(st), ctx.to_device(en), ctx.alloc(Bf * Nf * n * 4)
+    want = ctx.traj_id_fused_host(model, st, en, 2.0, Nf, 5)   # also sizes the table before the capture
+    with ctx.capture() as cap:
+        ctx.traj_id_fused(model, d_st, d_en, Bf, Nf, 2.0, 5, d_t)
+    other = ctx.traj_id_fused_host(model, st, en, 3.5, Nf, 3)  # different Tf / method: rewrites the table
+    assert np.abs(other - want).max() > 1e-3
+    cap.graph.launch()
+    ctx.synchronize()
+    np.testing.assert_array_equal(d_t.download((Bf, Nf, n), np.float32), want)
+    np.testing.assert_array_equal(ctx.traj_id_fused_host(model, st, en, 3.5, Nf, 3), other)  # and the cache is not left stale
+    cap.graph.destroy()
+    for b in (d_st, d_en, d_t):
+        b.free()
 
 
 @pytest.mark.parametrize("seed", [0, 2, 4, 5, 6, 8, 11, 16])
