@@ -79,36 +79,50 @@ MP_HD double mp_ik_normal(unsigned seed, unsigned long long key, int restart, in
 
 // Per-problem state of the iteration, so that a lane can interleave "fetch the next problem" with "advance the current
 // one" (the work-queue kernel) instead of idling until the slowest problem of its wave is done.
+// (The target pose is NOT part of the state: it is re-read from memory every trip - 96 bytes against ~2000
+// instructions - which keeps 32 VGPRs free; the kernel is register-bound.)
 template <int N>
 struct MpIkState {
-  double theta[N], best[N], Td[16];
+  double theta[N], best[N];
   double best_err, cur_err;
   double damping, step_cap, nu, prev_err;  // the adaptive-tuning state (constant when the option is off)
-  int stall, k, restarts, success;
-  unsigned long long key;  // content hash of the problem: keys the restart noise
+  int stall, k, restarts;
 };
+// (Nor are the success flag - it is the return value of the finishing trip - and the restart-noise key, which is
+// re-hashed from memory on the rare restart: the specialised 6-DOF kernel sits exactly at the 256-VGPR line.)
 
-// S.theta (initial guess) and S.Td (target) must be set
+// content hash of a problem (target position + initial guess): keys the restart noise
+template <int N>
+MP_HD unsigned long long mp_ik_key(const double* Td, const double* theta0) {
+  unsigned long long h = 0xCBF29CE484222325ull;  // FNV-1a over the bit patterns
+#pragma unroll
+  for (int k = 0; k < 3; ++k) h = (h ^ __builtin_bit_cast(unsigned long long, Td[4 * k + 3])) * 0x100000001B3ull;
+#pragma unroll
+  for (int j = 0; j < N; ++j) h = (h ^ __builtin_bit_cast(unsigned long long, theta0[j])) * 0x100000001B3ull;
+  return h;
+}
+
+// S.theta (initial guess) must be set
 template <int N>
 MP_HD void mp_ik_begin(MpIkState<N>& S, const MpIkParams& P) {
-  unsigned long long h = 0xCBF29CE484222325ull;  // FNV-1a over the bit patterns of the target position and the guess
-#pragma unroll
-  for (int k = 0; k < 3; ++k) h = (h ^ __builtin_bit_cast(unsigned long long, S.Td[4 * k + 3])) * 0x100000001B3ull;
-#pragma unroll
-  for (int j = 0; j < N; ++j) h = (h ^ __builtin_bit_cast(unsigned long long, S.theta[j])) * 0x100000001B3ull;
-  S.key = h;
   S.damping = P.damping; S.step_cap = P.step_cap; S.nu = 2.0; S.prev_err = MP_IK_BIG;
 #pragma unroll
   for (int j = 0; j < N; ++j) S.best[j] = S.theta[j];
   S.best_err = MP_IK_BIG;
   S.cur_err = MP_IK_BIG;
-  S.stall = 0; S.k = 0; S.restarts = 0; S.success = 0;
+  S.stall = 0; S.k = 0; S.restarts = 0;
 }
 
-// One trip of the reference's loop (kinematics/ik.py:182-269).  Returns true when the problem is finished; S.theta is
-// then the answer, S.success the flag and S.k + 1 the reference's iteration count.
+// One trip of the reference's loop (kinematics/ik.py:182-269).  Returns 0 while the problem is running, 1 when it finished
+// without meeting the tolerances, 2 when it finished successfully; S.theta is then the answer and S.k + 1 the reference's
+// iteration count.  Tdp = the target pose, theta0 = the problem's initial guess (both re-read from memory when needed).
 template <int N, typename MT>
-MP_HD bool mp_ik_iterate(const MT& M, const MpIkParams& P, MpIkState<N>& S) {
+MP_HD int mp_ik_iterate(const MT& M, const MpIkParams& P, MpIkState<N>& S, const double* __restrict__ Tdp,
+                        const double* __restrict__ theta0) {
+  double Td[16];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) Td[k] = Tdp[k];  // the last row of a pose is never read
+  Td[12] = 0.0; Td[13] = 0.0; Td[14] = 0.0; Td[15] = 1.0;
   if (S.k >= P.max_iterations) {  // exhausted (the for / else): fall back to the best configuration seen (:273-280)
     if (S.best_err < S.cur_err) {
 #pragma unroll
@@ -117,18 +131,18 @@ MP_HD bool mp_ik_iterate(const MT& M, const MpIkParams& P, MpIkState<N>& S) {
       mp_joint_state<double, N>(M, S.theta, js);
       double Tc[16], J[6 * N], V[6], rot, tr;
       mp_fk_jac<double, N, false>(M, js, Tc, J);
-      mp_ik_error(Tc, S.Td, V, rot, tr);
-      S.success = (rot < P.eomg && tr < P.ev) ? 1 : 0;
+      mp_ik_error(Tc, Td, V, rot, tr);
+      return (rot < P.eomg && tr < P.ev) ? 2 : 1;
     }
-    return true;
+    return 1;
   }
   MpJointState<double, N> js;
   mp_joint_state<double, N>(M, S.theta, js);
   double Tc[16], J[6 * N], V[6], rot, tr;
   mp_fk_jac<double, N, true>(M, js, Tc, J);
-  mp_ik_error(Tc, S.Td, V, rot, tr);
+  mp_ik_error(Tc, Td, V, rot, tr);
   S.cur_err = rot + tr;
-  if (rot < P.eomg && tr < P.ev) { S.success = 1; return true; }
+  if (rot < P.eomg && tr < P.ev) return 2;
   if (S.cur_err < S.best_err) {
     S.best_err = S.cur_err;
     S.stall = 0;
@@ -138,9 +152,10 @@ MP_HD bool mp_ik_iterate(const MT& M, const MpIkParams& P, MpIkState<N>& S) {
     ++S.stall;
   }
   if (S.stall > 20) {
+    const unsigned long long key = mp_ik_key<N>(Tdp, theta0);
 #pragma unroll
     for (int j = 0; j < N; ++j) {
-      const double t = S.best[j] + 0.1 * mp_ik_normal(P.seed, S.key, S.restarts, j);
+      const double t = S.best[j] + 0.1 * mp_ik_normal(P.seed, key, S.restarts, j);
       S.theta[j] = t < P.lo[j] ? P.lo[j] : (t > P.hi[j] ? P.hi[j] : t);
     }
     S.stall = 0;
@@ -148,7 +163,7 @@ MP_HD bool mp_ik_iterate(const MT& M, const MpIkParams& P, MpIkState<N>& S) {
     S.nu = 2.0;
     ++S.restarts;
     ++S.k;
-    return false;
+    return 0;
   }
   if (P.adaptive_tuning && S.k > 0) {
     if (S.cur_err < S.prev_err * 0.75) {  // good progress: towards Newton
@@ -206,7 +221,7 @@ MP_HD bool mp_ik_iterate(const MT& M, const MpIkParams& P, MpIkState<N>& S) {
       mp_joint_state<double, N>(M, cand, jc);
       double Tt[16], Jt[6 * N], Vt[6], rt, tt;
       mp_fk_jac<double, N, false>(M, jc, Tt, Jt);
-      mp_ik_error(Tt, S.Td, Vt, rt, tt);
+      mp_ik_error(Tt, Td, Vt, rt, tt);
       if (rt + tt < keep_err) {
         keep_err = rt + tt;
 #pragma unroll
@@ -231,22 +246,22 @@ MP_HD bool mp_ik_iterate(const MT& M, const MpIkParams& P, MpIkState<N>& S) {
     }
   }
   ++S.k;
-  return false;
+  return 0;
 }
 
 // theta: in = initial guess, out = solution.  Returns the reference's iteration count; sets success / restarts.
 template <int N, typename MT>
 MP_HD int mp_ik_solve(const MT& M, const MpIkParams& P, const double (&Td)[16], double (&theta)[N], int& success, int& restarts) {
   MpIkState<N> S;
+  double theta0[N];
 #pragma unroll
-  for (int j = 0; j < N; ++j) S.theta[j] = theta[j];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) S.Td[k] = Td[k];
+  for (int j = 0; j < N; ++j) { S.theta[j] = theta[j]; theta0[j] = theta[j]; }
   mp_ik_begin(S, P);
-  while (!mp_ik_iterate<N>(M, P, S)) {}
+  int done;
+  while (!(done = mp_ik_iterate<N>(M, P, S, Td, theta0))) {}
 #pragma unroll
   for (int j = 0; j < N; ++j) theta[j] = S.theta[j];
-  success = S.success;
+  success = done == 2 ? 1 : 0;
   restarts = S.restarts;
   return S.k + 1;
 }

@@ -310,14 +310,13 @@ __global__ __launch_bounds__(kBlock) void k_ik(const MpModel<double> M, const Mp
     if (!have) {
       row = (long)atomicAdd(next, 1ull);
       if (row >= B) break;
-      RunIO<double, 16>::load(Tdes, row, S.Td);
       RunIO<double, N>::load(theta0, row, S.theta);
       mp_ik_begin(S, P);
       have = true;
     }
-    if (mp_ik_iterate<N>(M, P, S)) {
+    if (const int done = mp_ik_iterate<N>(M, P, S, Tdes + row * 16, theta0 + row * N)) {
       RunIO<double, N>::store(theta, row, S.theta);
-      success[row] = S.success;
+      success[row] = done == 2 ? 1 : 0;
       iterations[row] = S.k + 1;
       restarts[row] = S.restarts;
       have = false;
