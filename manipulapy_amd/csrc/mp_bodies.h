@@ -97,6 +97,19 @@ __device__ __forceinline__ void mp_body_id(const MT& M, const MpCall<T>& C, cons
   RunIO<T, N>::store(tau, r, t);
 }
 
+// qdd for row `r` = forward_dynamics(q, qd, tau, g, F) with one wrench for every row: the body of k_forward_dynamics
+template <typename T, int N, bool HAS_FTIP, typename MT>
+__device__ __forceinline__ void mp_body_fd(const MT& M, const MpCall<T>& C, const T* __restrict__ q, const T* __restrict__ qd,
+                                           const T* __restrict__ tau, T* __restrict__ qdd, long r) {
+  T a[N], b[N], t[N], out[N];
+  RunIO<T, N>::load(q, r, a);
+  RunIO<T, N>::load(qd, r, b);
+  RunIO<T, N>::load(tau, r, t);
+  const T tn[3] = {C.F1n[0], C.F1n[1], C.F1n[2]}, tf[3] = {C.F1f[0], C.F1f[1], C.F1f[2]};
+  mp_forward_dynamics<T, N, HAS_FTIP>(M, C.a0, tn, tf, a, b, t, out);
+  RunIO<T, N>::store(qdd, r, out);
+}
+
 // ------------------------------------------------------------- wave-cooperative coalesced stores
 // A lane that owns a long output run (T: 128 B, J: 336 B at n = 7, float64) and stores it directly issues
 // 16-byte stores that are 128 / 336 bytes apart across lanes: every store instruction touches 64 different

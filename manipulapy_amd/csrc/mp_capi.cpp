@@ -26,6 +26,7 @@ struct MpSpec {  // run-time specialised kernels of one model on one device
   hipFunction_t id_pk[2] = {nullptr, nullptr}, traj_id_pk[2] = {nullptr, nullptr}, fd_traj[2] = {nullptr, nullptr};
   hipFunction_t id_d[2] = {nullptr, nullptr}, fk_jac_id_d[2] = {nullptr, nullptr}, fd_traj_pk[2] = {nullptr, nullptr};
   hipFunction_t ik = nullptr;
+  hipFunction_t fd_s[2] = {nullptr, nullptr}, fd_d[2] = {nullptr, nullptr};  // forward dynamics per row, float32 / float64
 };
 struct mp_ctx {
   int device = -1;
@@ -382,7 +383,13 @@ static int fdyn_impl(const char* fn, mp_ctx* ctx, const mp_model* model, const T
   REQUIRE(aligned16(d_q) && aligned16(d_qd) && aligned16(d_tau) && aligned16(d_qdd), "%s: device pointers must be 16-byte aligned", fn);
   MpCall<T> c;
   make_call<T>(model, g, Ftip, &c);
-  HIP_TRY(mpk_forward_dynamics<T>(ctx->compute, pick<T>(model), c, any_nonzero(Ftip), d_q, d_qd, d_tau, d_qdd, (long)rows));
+  const bool ftip = any_nonzero(Ftip);
+  if (const MpSpec* sp = find_spec(ctx, model)) {
+    long nr = (long)rows;
+    void* args[] = {&c, &d_q, &d_qd, &d_tau, &d_qdd, &nr};
+    return launch_spec(ctx, (sizeof(T) == 4 ? sp->fd_s : sp->fd_d)[ftip ? 1 : 0], nr, args);
+  }
+  HIP_TRY(mpk_forward_dynamics<T>(ctx->compute, pick<T>(model), c, ftip, d_q, d_qd, d_tau, d_qdd, (long)rows));
   return MP_OK;
 }
 
@@ -802,11 +809,12 @@ int mp_model_specialize(mp_ctx* ctx, const mp_model* model) {
   if (mp_jit_compile(model->f, model->d, &code, nullptr, &err)) return set_err(MP_ERR_UNSUPPORTED, "mp_model_specialize: %s", err.c_str());
   MpSpec sp;
   HIP_TRY(hipModuleLoadData(&sp.mod, code.data()));
-  const char* names[6][2] = {{"mp_spec_id_pk_f0", "mp_spec_id_pk_f1"}, {"mp_spec_traj_id_pk_f0", "mp_spec_traj_id_pk_f1"},
+  const char* names[8][2] = {{"mp_spec_id_pk_f0", "mp_spec_id_pk_f1"}, {"mp_spec_traj_id_pk_f0", "mp_spec_traj_id_pk_f1"},
                              {"mp_spec_fd_traj_f0", "mp_spec_fd_traj_f1"}, {"mp_spec_id_d_f0", "mp_spec_id_d_f1"},
-                             {"mp_spec_fk_jac_id_d_f0", "mp_spec_fk_jac_id_d_f1"}, {"mp_spec_fd_traj_pk_f0", "mp_spec_fd_traj_pk_f1"}};
-  hipFunction_t* slots[6] = {sp.id_pk, sp.traj_id_pk, sp.fd_traj, sp.id_d, sp.fk_jac_id_d, sp.fd_traj_pk};
-  for (int k = 0; k < 6; ++k)
+                             {"mp_spec_fk_jac_id_d_f0", "mp_spec_fk_jac_id_d_f1"}, {"mp_spec_fd_traj_pk_f0", "mp_spec_fd_traj_pk_f1"},
+                             {"mp_spec_fd_s_f0", "mp_spec_fd_s_f1"}, {"mp_spec_fd_d_f0", "mp_spec_fd_d_f1"}};
+  hipFunction_t* slots[8] = {sp.id_pk, sp.traj_id_pk, sp.fd_traj, sp.id_d, sp.fk_jac_id_d, sp.fd_traj_pk, sp.fd_s, sp.fd_d};
+  for (int k = 0; k < 8; ++k)
     for (int f = 0; f < 2; ++f) {
       hipError_t e = hipModuleGetFunction(&slots[k][f], sp.mod, names[k][f]);
       if (e != hipSuccess) { (void)hipModuleUnload(sp.mod); return hip_err(e, names[k][f]); }

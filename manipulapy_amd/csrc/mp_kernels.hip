@@ -207,13 +207,7 @@ __global__ __launch_bounds__(kBlock) void k_forward_dynamics(const MpModel<T> M,
                                                              T* __restrict__ qdd, long rows) {
   const long r = (long)blockIdx.x * kBlock + threadIdx.x;
   if (r >= rows) return;
-  T a[N], b[N], t[N], out[N];
-  RunIO<T, N>::load(q, r, a);
-  RunIO<T, N>::load(qd, r, b);
-  RunIO<T, N>::load(tau, r, t);
-  const T tn[3] = {C.F1n[0], C.F1n[1], C.F1n[2]}, tf[3] = {C.F1f[0], C.F1f[1], C.F1f[2]};
-  mp_forward_dynamics<T, N, HAS_FTIP>(M, C.a0, tn, tf, a, b, t, out);
-  RunIO<T, N>::store(qdd, r, out);
+  mp_body_fd<T, N, HAS_FTIP>(M, C, q, qd, tau, qdd, r);
 }
 
 // one wave per block: the roll-out's LDS tile is per wave and nothing is shared between waves

@@ -18,6 +18,8 @@ analytic recursion does not need) and no legacy (Mlist_per_link=None) approximat
 """
 from __future__ import annotations
 
+import os
+
 from typing import Optional
 
 import numpy as np
@@ -54,15 +56,28 @@ class ManipulatorDynamics(SerialManipulator):
         return _hip.HipModel(self.S_list, np.asarray(self.Mlist_per_link), np.asarray(self.Glist), self._M_ee,
                              joint_limits, torque_limits)
 
+    def _model_for(self, rows: int) -> _hip.HipModel:
+        """The shared model; for big batches it is specialised first (~2 s once, cached on disk: the per-row forward
+        dynamics kernel runs 3x faster with this robot's constants baked in)."""
+        model = self.hip_model()
+        if rows >= 16384 and os.environ.get("MANIPULAPY_HIP_SPECIALIZE", "1") != "0":
+            try:
+                from .registry import get_context
+
+                get_context().specialize(model)
+            except Exception:  # no hiprtc: the generic kernels serve
+                pass
+        return model
+
     def _id(self, q, qd, qdd, g, Ftip) -> np.ndarray:
-        return execute_registered_kernel("dynamics.inverse_trajectory", self.hip_model(), q, qd, qdd, g, Ftip,
+        return execute_registered_kernel("dynamics.inverse_trajectory", self._model_for(np.shape(q)[0]), q, qd, qdd, g, Ftip,
                                          dtype=np.float64)
 
     # ---- public API
     def mass_matrix(self, thetalist) -> np.ndarray:
         """(n, n) mass matrix, or (rows, n, n) for a 2-D `thetalist`."""
         q = np.atleast_2d(np.asarray(thetalist, dtype=np.float64))
-        M = execute_registered_kernel("dynamics.mass_matrix", self.hip_model(), q)
+        M = execute_registered_kernel("dynamics.mass_matrix", self._model_for(q.shape[0]), q)
         return M if np.ndim(thetalist) == 2 else M[0]
 
     def velocity_quadratic_forces(self, thetalist, dthetalist) -> np.ndarray:
@@ -87,7 +102,7 @@ class ManipulatorDynamics(SerialManipulator):
         q = np.atleast_2d(np.asarray(thetalist, dtype=np.float64))
         qd = np.atleast_2d(np.asarray(dthetalist, dtype=np.float64))
         tau = np.atleast_2d(np.asarray(taulist, dtype=np.float64))
-        qdd = execute_registered_kernel("dynamics.forward", self.hip_model(), q, qd, tau, g, Ftip)
+        qdd = execute_registered_kernel("dynamics.forward", self._model_for(q.shape[0]), q, qd, tau, g, Ftip)
         return qdd if np.ndim(thetalist) == 2 else qdd[0]
 
     def partial_derivative(self, i: int, j: int, k: int, thetalist, epsilon: float = 1e-6) -> float:

@@ -470,6 +470,15 @@ def test_specialised_kernels_match_generic_and_oracle(robot, tables, dyn_golden)
             want = ref.inverse_dynamics_trajectory(tab, q[idx].astype(np.float64), qd[idx].astype(np.float64),
                                                    qdd[idx].astype(np.float64), None, wrench, dtype=np.float64)
             assert_f32(b[idx], want)
+        # per-row forward dynamics: specialised float64 kernel vs generic and oracle (the host entry point is float64)
+        for wrench in (None, F):
+            tq = rng.uniform(-5, 5, (rows, tab.n))
+            a = ctx.forward_dynamics_host(gen, q[:64].astype(np.float64), qd[:64].astype(np.float64), tq[:64], None, wrench)
+            b = ctx.forward_dynamics_host(spec, q[:64].astype(np.float64), qd[:64].astype(np.float64), tq[:64], None, wrench)
+            np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-9 * max(1.0, float(np.abs(a).max())))
+            w0 = ref.forward_dynamics(tab, q[0].astype(np.float64), qd[0].astype(np.float64), tq[0], np.array([0, 0, -9.81]),
+                                      np.zeros(6) if wrench is None else wrench)
+            np.testing.assert_allclose(b[0], w0, rtol=2e-5, atol=2e-5 * max(1.0, float(np.abs(w0).max())))
         # golden rows
         zero = [i for i in range(len(z["thetas"])) if not z["ftips"][i].any()]
         t = ctx.id_trajectory_host(spec, z["thetas"][zero], z["dthetas"][zero], z["ddthetas"][zero], z["g"], None)

@@ -52,6 +52,12 @@ def main():
             by = rows * 4 * n * w
             out.append(dict(op="forward_dynamics", robot=robot, dtype=np.dtype(dt).name, rows=rows, ms=ms,
                             rows_per_s=rows / ms * 1e3, alg_GBps=by / ms / 1e6))
+            spec = _hip.HipModel(dyn.S_list, dyn.Mlist_per_link, dyn.Glist, sm.M_list, lim)
+            ctx.specialize(spec)
+            ms = timed(ctx, lambda: ctx.forward_dynamics(spec, q, qd, tau, rows, qdd, dtype=dt))
+            out.append(dict(op="forward_dynamics (specialised)", robot=robot, dtype=np.dtype(dt).name, rows=rows, ms=ms,
+                            rows_per_s=rows / ms * 1e3, alg_GBps=by / ms / 1e6))
+            spec.destroy()
             for b in (q, qd, tau, M, qdd):
                 b.free()
         # trajectory generation: B x N rows, three float32 outputs
