@@ -612,11 +612,8 @@ MP_HD void mp_rot_times_exp3(const double (&Rs)[9], const double (&w)[3], double
 // One timestep `i` of N between the poses Xs, Xe (4x4 row-major): position, velocity, acceleration, orientation.
 // Positions / orientations: cubic for method 3, QUINTIC for anything else; velocities / accelerations: cubic (3),
 // quintic (5), zero otherwise — the reference's two code paths differ and both are reproduced.
-MP_HD void mp_cartesian_point(const double (&Xs)[16], const double (&Xe)[16], long i, long N, double Tf, int method,
-                              float (&pos)[3], float (&vel)[3], float (&acc)[3], float (&ori)[9]) {
-  const double timegap = Tf / ((double)N - 1.0);
-  const double x = (timegap * (double)i) / Tf;
-  const double s = (method == 3) ? 3.0 * x * x - 2.0 * x * x * x : 10.0 * x * x * x - 15.0 * x * x * x * x + 6.0 * x * x * x * x * x;
+// the rotation part that does not depend on the timestep: w = log(Rs^T Re)
+MP_HD void mp_cartesian_prepare(const double (&Xs)[16], const double (&Xe)[16], double (&w)[3]) {
   const double Rs[9] = {Xs[0], Xs[1], Xs[2], Xs[4], Xs[5], Xs[6], Xs[8], Xs[9], Xs[10]};
   const double Re[9] = {Xe[0], Xe[1], Xe[2], Xe[4], Xe[5], Xe[6], Xe[8], Xe[9], Xe[10]};
   double D[9];  // Rs^T Re
@@ -624,20 +621,36 @@ MP_HD void mp_cartesian_point(const double (&Xs)[16], const double (&Xe)[16], lo
   for (int r = 0; r < 3; ++r)
 #pragma unroll
     for (int c = 0; c < 3; ++c) D[3 * r + c] = Rs[r] * Re[c] + Rs[3 + r] * Re[3 + c] + Rs[6 + r] * Re[6 + c];
-  double w[3], O[9];
   mp_log3(D, w);
+}
+
+// timestep `i` given the prepared rotation vector: Rs (3x3 row-major), ps / pe = start / end positions
+MP_HD void mp_cartesian_eval(const double (&Rs)[9], const double (&ps)[3], const double (&pe)[3], const double (&w)[3], long i,
+                             long N, double Tf, int method, float (&pos)[3], float (&vel)[3], float (&acc)[3], float (&ori)[9]) {
+  const double timegap = Tf / ((double)N - 1.0);
+  const double x = (timegap * (double)i) / Tf;
+  const double s = (method == 3) ? 3.0 * x * x - 2.0 * x * x * x : 10.0 * x * x * x - 15.0 * x * x * x * x + 6.0 * x * x * x * x * x;
   const double ws[3] = {w[0] * s, w[1] * s, w[2] * s};
+  double O[9];
   mp_rot_times_exp3(Rs, ws, O);
 #pragma unroll
   for (int k = 0; k < 9; ++k) ori[k] = (float)O[k];
   const double tau = ((double)i * (Tf / (double)(N - 1))) / Tf;
   double s2, sd, sdd;
   mp_time_scaling(method, tau, Tf, s2, sd, sdd);
-  const double ps[3] = {Xs[3], Xs[7], Xs[11]}, pe[3] = {Xe[3], Xe[7], Xe[11]};
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     pos[k] = (float)(s * pe[k] + (1.0 - s) * ps[k]);
     vel[k] = (float)(sd * (pe[k] - ps[k]));
     acc[k] = (float)(sdd * (pe[k] - ps[k]));
   }
+}
+
+MP_HD void mp_cartesian_point(const double (&Xs)[16], const double (&Xe)[16], long i, long N, double Tf, int method,
+                              float (&pos)[3], float (&vel)[3], float (&acc)[3], float (&ori)[9]) {
+  double w[3];
+  mp_cartesian_prepare(Xs, Xe, w);
+  const double Rs[9] = {Xs[0], Xs[1], Xs[2], Xs[4], Xs[5], Xs[6], Xs[8], Xs[9], Xs[10]};
+  const double ps[3] = {Xs[3], Xs[7], Xs[11]}, pe[3] = {Xe[3], Xe[7], Xe[11]};
+  mp_cartesian_eval(Rs, ps, pe, w, i, N, Tf, method, pos, vel, acc, ori);
 }

@@ -238,19 +238,41 @@ __global__ __launch_bounds__(kFdBlock) void k_fd_traj_pk(const MpModel<float> M,
 }
 
 // ------------------------------------------------------------------- Cartesian straight-line path
-// one lane per (pose pair b, timestep i); outputs float32 (B,N,3) x3 and (B,N,3,3)
+// one lane per (pose pair b, timestep i); outputs float32 (B,N,3) x3 and (B,N,3,3).
+// `bpt` blocks of 256 timesteps per pose pair: the pair's rotation logarithm (acos, the half-turn branches) is worked
+// out once per block by lane 0 and broadcast through LDS together with the start rotation and the end points, so a lane
+// neither reloads two 4x4 poses nor repeats the logarithm, and there is no row -> (pair, timestep) division
 __global__ __launch_bounds__(kBlock) void k_cartesian_traj(const double* __restrict__ Xstart, const double* __restrict__ Xend,
-                                                           long B, long Nt, double Tf, int method, float* __restrict__ pos,
+                                                           long Nt, unsigned bpt, double Tf, int method, float* __restrict__ pos,
                                                            float* __restrict__ vel, float* __restrict__ acc,
                                                            float* __restrict__ ori) {
-  const long r = (long)blockIdx.x * kBlock + threadIdx.x;
-  if (r >= B * Nt) return;
-  const long b = r / Nt, i = r - b * Nt;
-  double Xs[16], Xe[16];
-  RunIO<double, 16>::load(Xstart, b, Xs);
-  RunIO<double, 16>::load(Xend, b, Xe);
+  __shared__ double sh[18];  // w (3), Rs (9), ps (3), pe (3)
+  const unsigned bb = blockIdx.x / bpt;
+  const long b = bb, i = (long)(blockIdx.x - bb * bpt) * kBlock + threadIdx.x;
+  if (threadIdx.x == 0) {
+    double Xs[16], Xe[16], w[3];
+    RunIO<double, 16>::load(Xstart, b, Xs);
+    RunIO<double, 16>::load(Xend, b, Xe);
+    mp_cartesian_prepare(Xs, Xe, w);
+    sh[0] = w[0]; sh[1] = w[1]; sh[2] = w[2];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) sh[3 + 3 * r + c] = Xs[4 * r + c];
+      sh[12 + r] = Xs[4 * r + 3];
+      sh[15 + r] = Xe[4 * r + 3];
+    }
+  }
+  __syncthreads();
+  if (i >= Nt) return;
+  double w[3], Rs[9], ps[3], pe[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { w[k] = sh[k]; ps[k] = sh[12 + k]; pe[k] = sh[15 + k]; }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) Rs[k] = sh[3 + k];
   float p[3], v[3], a[3], o[9];
-  mp_cartesian_point(Xs, Xe, i, Nt, Tf, method, p, v, a, o);
+  mp_cartesian_eval(Rs, ps, pe, w, i, Nt, Tf, method, p, v, a, o);
+  const long r = b * Nt + i;
 #pragma unroll
   for (int k = 0; k < 3; ++k) { pos[r * 3 + k] = p[k]; vel[r * 3 + k] = v[k]; acc[r * 3 + k] = a[k]; }
 #pragma unroll
@@ -538,7 +560,8 @@ template hipError_t mpk_fd_traj<double>(hipStream_t, const MpModel<double>&, con
 hipError_t mpk_cartesian_traj(hipStream_t s, const double* Xstart, const double* Xend, long B, long Nt, double Tf, int method,
                               float* pos, float* vel, float* acc, float* ori) {
   if (B <= 0 || Nt <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_cartesian_traj, dim3(grid_for(B * Nt)), dim3(kBlock), 0, s, Xstart, Xend, B, Nt, Tf, method, pos, vel, acc, ori);
+  const unsigned bpt = (unsigned)((Nt + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(k_cartesian_traj, dim3((unsigned)(B * bpt)), dim3(kBlock), 0, s, Xstart, Xend, Nt, bpt, Tf, method, pos, vel, acc, ori);
   return hipGetLastError();
 }
 
