@@ -9,7 +9,9 @@ mass matrix and an inverse-dynamics call per sample.  Inverse dynamics is affine
         qdd_cmd = qdd_d + Kp e + Ki int(e) + Kd de,
 
 which is what runs here — for a single sample or for a whole batch of (rows, n) samples in one launch.
-The PID / adaptive / Kalman controllers of the reference are single-sample host loops and stay out of scope.
+The reference's other model-based laws (PD / PID, PD + feed-forward, joint- and Cartesian-space PD, robust and adaptive
+control) are the same inverse-dynamics / FK / Jacobian calls plus host arithmetic and are mirrored below; the Kalman filter,
+the tuning helpers and the response metrics are single-sample host loops and stay out of scope.
 """
 from __future__ import annotations
 
@@ -49,6 +51,85 @@ class ManipulatorController:
         """inverse_dynamics at the desired state (reference control/computed_torque.py:93-124); 2-D inputs batch."""
         return self._id(np.asarray(desired_position, dtype=np.float64), np.asarray(desired_velocity, dtype=np.float64),
                         np.asarray(desired_acceleration, dtype=np.float64), g, Ftip)
+
+    # ---- the other model-based laws of the reference: each is inverse dynamics plus host arithmetic, so a (rows, n)
+    #      batch of samples is one launch (control/pid.py, control/computed_torque.py, control/robust_adaptive.py)
+    @staticmethod
+    def pd_control(desired_position, desired_velocity, current_position, current_velocity, Kp, Kd) -> np.ndarray:
+        """Kp e + Kd de (reference control/pid.py:17-52)."""
+        e = np.asarray(desired_position, dtype=np.float64) - np.asarray(current_position, dtype=np.float64)
+        de = np.asarray(desired_velocity, dtype=np.float64) - np.asarray(current_velocity, dtype=np.float64)
+        return np.asarray(Kp) * e + np.asarray(Kd) * de
+
+    def pid_control(self, thetalistd, dthetalistd, thetalist, dthetalist, dt, Kp, Ki, Kd, i_clamp: Optional[float] = None) -> np.ndarray:
+        """Kp e + Ki int(e) + Kd de with the controller's integral state (reference control/pid.py:54-118)."""
+        q = np.asarray(thetalist, dtype=np.float64)
+        if i_clamp is not None and (not np.isfinite(i_clamp) or i_clamp <= 0):
+            raise ValueError("i_clamp must be a positive finite number")
+        if self.eint is None or self.eint.shape != q.shape:
+            self.eint = np.zeros(q.shape)
+        e = np.asarray(thetalistd, dtype=np.float64) - q
+        self.eint = self.eint + e * dt
+        if i_clamp is not None:
+            self.eint = np.clip(self.eint, -i_clamp, i_clamp)
+        de = np.asarray(dthetalistd, dtype=np.float64) - np.asarray(dthetalist, dtype=np.float64)
+        return np.asarray(Kp) * e + np.asarray(Ki) * self.eint + np.asarray(Kd) * de
+
+    def pd_feedforward_control(self, desired_position, desired_velocity, desired_acceleration, current_position, current_velocity,
+                               Kp, Kd, g, Ftip) -> np.ndarray:
+        """PD on the error + inverse dynamics at the desired state (reference control/computed_torque.py:134-178)."""
+        return (self.pd_control(desired_position, desired_velocity, current_position, current_velocity, Kp, Kd)
+                + self.feedforward_control(desired_position, desired_velocity, desired_acceleration, g, Ftip))
+
+    @staticmethod
+    def enforce_limits(thetalist, dthetalist, tau, joint_limits, torque_limits):
+        """Clip angles and torques to their limits; velocities pass through (reference control/computed_torque.py:181-211)."""
+        jl, tl = np.asarray(joint_limits, dtype=np.float64), np.asarray(torque_limits, dtype=np.float64)
+        return (np.clip(np.asarray(thetalist, dtype=np.float64), jl[:, 0], jl[:, 1]), np.asarray(dthetalist, dtype=np.float64),
+                np.clip(np.asarray(tau, dtype=np.float64), tl[:, 0], tl[:, 1]))
+
+    @staticmethod
+    def joint_space_control(desired_joint_angles, current_joint_angles, current_joint_velocities, Kp, Kd) -> np.ndarray:
+        """Kp (qd - q) - Kd qdot (reference control/computed_torque.py:214-245)."""
+        e = np.asarray(desired_joint_angles, dtype=np.float64) - np.asarray(current_joint_angles, dtype=np.float64)
+        return np.asarray(Kp) * e - np.asarray(Kd) * np.asarray(current_joint_velocities, dtype=np.float64)
+
+    def cartesian_space_control(self, desired_position, current_joint_angles, current_joint_velocities, Kp, Kd) -> np.ndarray:
+        """J_v^T (Kp (x_d - x) - Kd J_v qdot), J_v = the linear rows of the space Jacobian as the reference slices them
+        (control/computed_torque.py:248-296: rows 0..2).  2-D joint states batch: FK + Jacobian of all rows in one launch."""
+        q = np.asarray(current_joint_angles, dtype=np.float64)
+        single = q.ndim == 1
+        q2, qd2 = np.atleast_2d(q), np.atleast_2d(np.asarray(current_joint_velocities, dtype=np.float64))
+        xd = np.atleast_2d(np.asarray(desired_position, dtype=np.float64))
+        T = np.asarray(self.dynamics.forward_kinematics(q2))
+        Jv = np.asarray(self.dynamics.jacobian(q2))[:, :3, :]
+        e = xd - T[:, :3, 3]
+        xdot = np.einsum("rij,rj->ri", Jv, qd2)
+        Kp, Kd = np.asarray(Kp, dtype=np.float64), np.asarray(Kd, dtype=np.float64)
+        kp = e @ Kp.T if Kp.ndim == 2 else Kp * e
+        kd = xdot @ Kd.T if Kd.ndim == 2 else Kd * xdot
+        tau = np.einsum("rij,ri->rj", Jv, kp - kd)
+        return tau[0] if single else tau
+
+    def robust_control(self, thetalist, dthetalist, ddthetalist, g, Ftip, disturbance_estimate, adaptation_gain) -> np.ndarray:
+        """M qdd + c + g + J^T Ftip + gain * disturbance estimate (reference control/robust_adaptive.py:17-66): the first four
+        terms ARE inverse dynamics, so this is one launch plus an addition."""
+        q = np.asarray(thetalist, dtype=np.float64)
+        return (self._id(q, np.asarray(dthetalist, dtype=np.float64), np.asarray(ddthetalist, dtype=np.float64), g, Ftip)
+                + np.asarray(adaptation_gain, dtype=np.float64) * np.asarray(disturbance_estimate, dtype=np.float64))
+
+    def adaptive_control(self, thetalist, dthetalist, ddthetalist, g, Ftip, measurement_error, adaptation_gain) -> np.ndarray:
+        """Inverse dynamics + the running parameter estimate, updated by gain * measurement error on every call
+        (reference control/robust_adaptive.py:69-131; single sample, as there: the estimate is controller state)."""
+        q = np.asarray(thetalist, dtype=np.float64)
+        if q.ndim != 1:
+            raise ValueError("adaptive_control keeps one parameter estimate: call it per sample")
+        if getattr(self, "parameter_estimate", None) is None:
+            self.parameter_estimate = np.zeros(q.shape[0])
+        gamma = float(np.asarray(adaptation_gain, dtype=np.float64).reshape(-1)[0])
+        self.parameter_estimate = self.parameter_estimate + gamma * np.asarray(measurement_error, dtype=np.float64).reshape(-1)
+        return (self._id(q, np.asarray(dthetalist, dtype=np.float64), np.asarray(ddthetalist, dtype=np.float64), g, Ftip)
+                + self.parameter_estimate)
 
     def _id(self, q, qd, qdd, g, Ftip):
         single = q.ndim == 1

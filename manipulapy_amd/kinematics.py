@@ -212,6 +212,32 @@ class SerialManipulator:
             print(f"robust IK: {'success' if ok[0] else 'failed'} with '{names[0]}' after {int(it[0])} iterations")
         return th[0], bool(ok[0]), int(it[0]), names[0]
 
+    def end_effector_pose(self, thetalist) -> np.ndarray:
+        """[x, y, z, roll, pitch, yaw]: position and ZYX Euler angles of the end effector (reference kinematics/fk.py:88-104,
+        utils/so3.py:240-251); (rows, 6) for a 2-D `thetalist`."""
+        T = np.asarray(self.forward_kinematics(np.atleast_2d(np.asarray(thetalist, dtype=np.float64))))
+        R = T[:, :3, :3]
+        sy = np.sqrt(R[:, 0, 0] ** 2 + R[:, 1, 0] ** 2)
+        pitch = np.arctan2(-R[:, 2, 0], sy)
+        regular = np.stack((np.arctan2(R[:, 2, 1], R[:, 2, 2]), pitch, np.arctan2(R[:, 1, 0], R[:, 0, 0])), axis=1)
+        singular = np.stack((np.arctan2(-R[:, 1, 2], R[:, 1, 1]), pitch, sy * 0), axis=1)
+        out = np.concatenate((T[:, :3, 3], np.where((sy < 1e-6)[:, None], singular, regular)), axis=1)
+        return out if np.ndim(thetalist) == 2 else out[0]
+
+    def joint_velocity(self, thetalist, V_ee, frame: str = "space") -> np.ndarray:
+        """pinv(J) V_ee (reference kinematics/velocity.py:65-89); 2-D inputs batch."""
+        if frame not in ("space", "body"):
+            raise ValueError("Invalid frame specified. Choose 'space' or 'body'.")
+        J = np.asarray(self.jacobian(thetalist, frame=frame))
+        V = np.asarray(V_ee, dtype=np.float64)
+        return np.einsum("...ij,...j->...i", np.linalg.pinv(J), V)
+
+    def update_state(self, joint_positions, joint_velocities=None) -> None:
+        """reference kinematics/serial_manipulator.py:125-145."""
+        self.joint_positions = np.asarray(joint_positions)
+        self.joint_velocities = (np.asarray(joint_velocities) if joint_velocities is not None
+                                 else np.zeros(self.joint_positions.shape, dtype=self.joint_positions.dtype))
+
     def end_effector_velocity(self, thetalist, dthetalist, frame: str = "space") -> np.ndarray:
         """reference kinematics/velocity.py:35-60."""
         return self.jacobian(thetalist, frame=frame) @ np.asarray(dthetalist, dtype=np.float64)

@@ -273,6 +273,18 @@ class OptimizedTrajectoryPlanning:
         j = (a[1:] - a[:-1]) / dt
         return v, a, j
 
+    def reset_performance_stats(self) -> None:
+        """reference planning/trajectory_planning.py:489-500."""
+        self.performance_stats = {"gpu_calls": 0, "cpu_calls": 0, "total_gpu_time": 0.0, "total_cpu_time": 0.0,
+                                  "memory_transfers": 0, "kernel_launches": 0, "speedup_achieved": 0.0, "best_kernel_used": "none"}
+
+    def cleanup_gpu_memory(self) -> None:
+        """Return the context's pooled device buffers to the driver (reference planning/trajectory_planning.py:502-524)."""
+        if self._gpu_routed():
+            ctx = _reg.get_context()
+            ctx.synchronize()
+            ctx.trim_pool()
+
     def get_performance_stats(self) -> Dict[str, float]:
         return dict(self.performance_stats)
 

@@ -21,6 +21,7 @@ What it does:
                              inverse_dynamics_trajectory / forward_dynamics_trajectory dumps
       cartesian_ur5.npz    : cartesian_trajectory dumps (`make_golden.py cartesian` regenerates only this)
       ik.npz               : iterative_inverse_kinematics dumps, 10 problems per robot (`make_golden.py ik`)
+      control_ur5.npz      : ManipulatorController laws on UR5 (`make_golden.py control`)
       urdf/<robot>.urdf    : kinematic + inertial skeletons of the four URDFs (`make_golden.py urdf`)
       reference_cpu_timings.json : cold-cache per-point timings of the reference
 
@@ -341,6 +342,49 @@ def dump_ik():
     np.savez(os.path.join(HERE, "ik.npz"), **d)
 
 
+def dump_control():
+    """ManipulatorController laws (control/pid.py, computed_torque.py, robust_adaptive.py) on UR5, two consecutive calls each
+    where the controller carries state (integral, parameter estimate)."""
+    from ManipulaPy.control import ManipulatorController
+
+    proc, sm, dyn = build("ur5")
+    rng = np.random.default_rng(SEED + 600)
+    n = 6
+    d = {}
+    u = lambda lo, hi, *shape: rng.uniform(lo, hi, shape if shape else (n,))
+    st = {k: u(-1, 1) for k in ("qd_des", "q", "dq_des", "dq", "ddq_des", "ddq")}
+    st.update(Kp=u(5, 50), Ki=u(0.1, 2), Kd=u(0.5, 5), x_des=u(-0.5, 0.5, 3), Kp3=u(5, 50, 3), Kd3=u(0.5, 5, 3),
+              Kp33=u(-5, 5, 3, 3), Kd33=u(-1, 1, 3, 3), dist=u(-1, 1), gain=u(0.1, 2), merr=u(-0.1, 0.1),
+              jl=np.stack([u(-2, -0.2), u(0.2, 2)], axis=1), tl=np.stack([u(-30, -5), u(5, 30)], axis=1), tau_in=u(-60, 60))
+    d.update({f"in_{k}": v for k, v in st.items()})
+    c = ManipulatorController(dyn)
+    d["pd"] = np.asarray(c.pd_control(st["qd_des"], st["dq_des"], st["q"], st["dq"], st["Kp"], st["Kd"]))
+    d["pid_1"] = np.asarray(c.pid_control(st["qd_des"], st["dq_des"], st["q"], st["dq"], 0.01, st["Kp"], st["Ki"], st["Kd"]))
+    d["pid_2"] = np.asarray(c.pid_control(st["qd_des"], st["dq_des"], st["q"], st["dq"], 0.01, st["Kp"], st["Ki"], st["Kd"], i_clamp=0.015))
+    d["pdff"] = np.asarray(c.pd_feedforward_control(st["qd_des"], st["dq_des"], st["ddq_des"], st["q"], st["dq"], st["Kp"], st["Kd"], G_VEC, FTIP_REF))
+    lim = c.enforce_limits(st["q"], st["dq"], st["tau_in"], st["jl"], st["tl"])
+    d["lim_q"], d["lim_dq"], d["lim_tau"] = (np.asarray(x) for x in lim)
+    d["jsc"] = np.asarray(c.joint_space_control(st["qd_des"], st["q"], st["dq"], st["Kp"], st["Kd"]))
+    d["csc_vec"] = np.asarray(c.cartesian_space_control(st["x_des"], st["q"], st["dq"], st["Kp3"], st["Kd3"]))
+    d["csc_mat"] = np.asarray(c.cartesian_space_control(st["x_des"], st["q"], st["dq"], st["Kp33"], st["Kd33"]))
+    d["robust"] = np.asarray(c.robust_control(st["q"], st["dq"], st["ddq"], G_VEC, FTIP_REF, st["dist"], st["gain"]))
+    c2 = ManipulatorController(dyn)
+    d["adaptive_1"] = np.asarray(c2.adaptive_control(st["q"], st["dq"], st["ddq"], G_VEC, FTIP_REF, st["merr"], 0.7))
+    d["adaptive_2"] = np.asarray(c2.adaptive_control(st["q"], st["dq"], st["ddq"], G_VEC, FTIP_REF, st["merr"], 0.7))
+    c3 = ManipulatorController(dyn)
+    d["ctc_1"] = np.asarray(c3.computed_torque_control(st["qd_des"], st["dq_des"], st["ddq_des"], st["q"], st["dq"], G_VEC, 0.01, st["Kp"], st["Ki"], st["Kd"]))
+    d["ctc_2"] = np.asarray(c3.computed_torque_control(st["qd_des"], st["dq_des"], st["ddq_des"], st["q"], st["dq"], G_VEC, 0.01, st["Kp"], st["Ki"], st["Kd"]))
+    d["ff"] = np.asarray(c3.feedforward_control(st["qd_des"], st["dq_des"], st["ddq_des"], G_VEC, FTIP_REF))
+    # small kinematics helpers of SerialManipulator (kinematics/fk.py:88-104, kinematics/velocity.py:65-89)
+    qs = rng.uniform(-2, 2, (6, n))
+    Vs = rng.uniform(-1, 1, (6, 6))
+    d["kin_q"], d["kin_V"] = qs, Vs
+    d["kin_pose"] = np.stack([np.asarray(sm.end_effector_pose(q)) for q in qs])
+    d["kin_jvel_space"] = np.stack([np.asarray(sm.joint_velocity(q, V)) for q, V in zip(qs, Vs)])
+    d["kin_jvel_body"] = np.stack([np.asarray(sm.joint_velocity(q, V, frame="body")) for q, V in zip(qs, Vs)])
+    np.savez(os.path.join(HERE, "control_ur5.npz"), **d)
+
+
 def dump_urdfs():
     """tests/golden/urdf/<robot>.urdf: the kinematic + inertial skeleton of the four benchmark robots' URDFs (robot
     description DATA; number strings kept verbatim so the tables stay bit-identical).  Visual / collision geometry,
@@ -402,6 +446,10 @@ def main():
         dump_urdfs()
         print("urdf skeletons dumped")
         return
+    if "control" in sys.argv[1:]:  # only (re)generate the controller dump
+        dump_control()
+        print("control dumped")
+        return
     if "ik" in sys.argv[1:]:  # only (re)generate the inverse-kinematics dump
         dump_ik()
         print("ik dumped")
@@ -418,6 +466,7 @@ def main():
     dump_trajectories()
     dump_cartesian()
     dump_ik()
+    dump_control()
     dump_urdfs()
     print("trajectories dumped", flush=True)
     time_reference()

@@ -1072,6 +1072,66 @@ def test_cartesian_trajectory_on_gpu(ctx):
         assert pl.cartesian_trajectory(z["Xstart"], z["generic_Xend"], 2.0, 0, 5)["orientations"].shape == (0, 3, 3)
 
 
+def test_controller_laws_against_reference_runs():
+    """Every mirrored ManipulatorController law against the reference's own outputs (tests/golden/control_ur5.npz), including
+    the stateful second calls (integral, parameter estimate); 2-D inputs batch and agree with the per-sample calls."""
+    import manipulapy_amd as mp
+
+    z = np.load(golden_path("control_ur5.npz"))
+    i = lambda k: z[f"in_{k}"]
+    g, F = np.array([0.0, 0.0, -9.81]), np.array([1.0, -2.0, 0.5, 3.0, -1.5, 0.75])
+    _, dyn, _ = mp.load_robot("ur5")
+    tol = dict(rtol=1e-6, atol=1e-6)
+    with mp.use_backend("hip"):
+        c = mp.ManipulatorController(dyn)
+        np.testing.assert_allclose(c.pd_control(i("qd_des"), i("dq_des"), i("q"), i("dq"), i("Kp"), i("Kd")), z["pd"], rtol=1e-12)
+        np.testing.assert_allclose(c.pid_control(i("qd_des"), i("dq_des"), i("q"), i("dq"), 0.01, i("Kp"), i("Ki"), i("Kd")), z["pid_1"], rtol=1e-12)
+        np.testing.assert_allclose(c.pid_control(i("qd_des"), i("dq_des"), i("q"), i("dq"), 0.01, i("Kp"), i("Ki"), i("Kd"), i_clamp=0.015),
+                                   z["pid_2"], rtol=1e-12)
+        np.testing.assert_allclose(c.pd_feedforward_control(i("qd_des"), i("dq_des"), i("ddq_des"), i("q"), i("dq"), i("Kp"), i("Kd"), g, F),
+                                   z["pdff"], **tol)
+        lq, ldq, lt = c.enforce_limits(i("q"), i("dq"), i("tau_in"), i("jl"), i("tl"))
+        np.testing.assert_array_equal(lq, z["lim_q"]); np.testing.assert_array_equal(ldq, z["lim_dq"]); np.testing.assert_array_equal(lt, z["lim_tau"])
+        np.testing.assert_allclose(c.joint_space_control(i("qd_des"), i("q"), i("dq"), i("Kp"), i("Kd")), z["jsc"], rtol=1e-12)
+        np.testing.assert_allclose(c.cartesian_space_control(i("x_des"), i("q"), i("dq"), i("Kp3"), i("Kd3")), z["csc_vec"], **tol)
+        np.testing.assert_allclose(c.cartesian_space_control(i("x_des"), i("q"), i("dq"), i("Kp33"), i("Kd33")), z["csc_mat"], **tol)
+        np.testing.assert_allclose(c.robust_control(i("q"), i("dq"), i("ddq"), g, F, i("dist"), i("gain")), z["robust"], **tol)
+        c2 = mp.ManipulatorController(dyn)
+        np.testing.assert_allclose(c2.adaptive_control(i("q"), i("dq"), i("ddq"), g, F, i("merr"), 0.7), z["adaptive_1"], **tol)
+        np.testing.assert_allclose(c2.adaptive_control(i("q"), i("dq"), i("ddq"), g, F, i("merr"), 0.7), z["adaptive_2"], **tol)
+        c3 = mp.ManipulatorController(dyn)
+        for k in ("ctc_1", "ctc_2"):
+            np.testing.assert_allclose(c3.computed_torque_control(i("qd_des"), i("dq_des"), i("ddq_des"), i("q"), i("dq"), g, 0.01, i("Kp"), i("Ki"),
+                                                                  i("Kd")), z[k], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(c3.feedforward_control(i("qd_des"), i("dq_des"), i("ddq_des"), g, F), z["ff"], **tol)
+        # batches: 2-D states == the per-sample calls
+        rng = np.random.default_rng(5)
+        Q, dQ, ddQ = rng.uniform(-1, 1, (3, 5, 6))
+        X = rng.uniform(-0.5, 0.5, (5, 3))
+        rb = c.robust_control(Q, dQ, ddQ, g, F, i("dist"), i("gain"))
+        cb = c.cartesian_space_control(X, Q, dQ, i("Kp33"), i("Kd33"))
+        for r in range(5):
+            np.testing.assert_allclose(rb[r], c.robust_control(Q[r], dQ[r], ddQ[r], g, F, i("dist"), i("gain")), rtol=1e-12, atol=1e-12)
+            np.testing.assert_allclose(cb[r], c.cartesian_space_control(X[r], Q[r], dQ[r], i("Kp33"), i("Kd33")), rtol=1e-12, atol=1e-12)
+        with pytest.raises(ValueError):
+            c.adaptive_control(Q, dQ, ddQ, g, F, i("merr"), 0.7)
+        # the small kinematics helpers: pose as [p; ZYX Euler], joint velocity through pinv(J); batch == per sample
+        sm, _, _ = mp.load_robot("ur5")
+        np.testing.assert_allclose(sm.end_effector_pose(z["kin_q"]), z["kin_pose"], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(sm.end_effector_pose(z["kin_q"][2]), z["kin_pose"][2], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(sm.joint_velocity(z["kin_q"], z["kin_V"]), z["kin_jvel_space"], rtol=1e-6, atol=1e-8)
+        np.testing.assert_allclose(sm.joint_velocity(z["kin_q"][1], z["kin_V"][1], frame="body"), z["kin_jvel_body"][1], rtol=1e-6, atol=1e-8)
+        sm.update_state(z["kin_q"][0])
+        assert sm.joint_velocities.shape == (6,) and not sm.joint_velocities.any()
+        pl = mp.OptimizedTrajectoryPlanning(sm, None, dyn, i("jl"))
+        pl.batch_inverse_dynamics_trajectory(Q, dQ, 2.0, 16, 5)
+        assert pl.get_performance_stats()["gpu_calls"] == 1
+        pl.reset_performance_stats()
+        assert pl.get_performance_stats()["gpu_calls"] == 0
+        pl.cleanup_gpu_memory()
+        pl.batch_inverse_dynamics_trajectory(Q, dQ, 2.0, 16, 5)  # still works after the pool was trimmed
+
+
 def test_computed_torque_control_batched(tables):
     """Computed-torque control as one inverse-dynamics evaluation vs the reference's formula
     M (Kp e + Ki eint + Kd de) + ID(q, qd, qdd_d, g, 0) evaluated with the CPU oracle."""
