@@ -13,7 +13,8 @@ import numpy as np
 
 Limits = Sequence[Tuple[Optional[float], Optional[float]]]
 
-__all__ = ["workspace_heuristic_guess", "random_in_limits", "midpoint_of_limits", "clip_to_limits"]
+__all__ = ["workspace_heuristic_guess", "random_in_limits", "midpoint_of_limits", "clip_to_limits", "extrapolate_from_current",
+           "IKInitialGuessCache", "se3_log_vector"]
 
 
 def clip_to_limits(theta: np.ndarray, joint_limits: Limits) -> np.ndarray:
@@ -72,3 +73,89 @@ def random_in_limits(joint_limits: Limits, count: Optional[int] = None) -> np.nd
 
 def midpoint_of_limits(joint_limits: Limits) -> np.ndarray:
     return np.array([(mn + mx) / 2.0 if mn is not None and mx is not None else 0.0 for mn, mx in joint_limits], dtype=np.float64)
+
+
+def _so3_log_matrix(R: np.ndarray) -> np.ndarray:
+    """Phi = log(R) as a skew matrix, with the reference's conventions (utils/so3.py:172-191): theta / (2 sin theta)
+    (R - R^T) away from the ends, the Taylor form near the identity, the symmetric-part axis near a half turn."""
+    cs = min(1.0, max(-1.0, 0.5 * (np.trace(R) - 1.0)))
+    vee = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    sn = 0.5 * np.sqrt(max(float(vee @ vee), 1e-300))
+    theta = np.arctan2(sn, cs)
+    if theta > np.pi - 1e-2:
+        sym = 0.5 * (R + R.T) - cs * np.eye(3)
+        if sym[2, 2] >= 1e-6:
+            col, ref_s = sym[:, 2], vee[2]
+        elif sym[1, 1] >= 1e-6:
+            col, ref_s = sym[:, 1], vee[1]
+        else:
+            col, ref_s = sym[:, 0], vee[0]
+        w = (theta if ref_s >= 0.0 else -theta) * col / np.sqrt(max(float(col @ col), 1e-24))
+    else:
+        u = 1.0 - cs
+        coef = 1.0 + u / 3.0 + 4.0 * u * u / 45.0 if cs > 1.0 - 5e-5 else np.arccos(cs) / np.sqrt(1.0 - cs * cs)
+        w = 0.5 * coef * vee
+    return np.array([[0.0, -w[2], w[1]], [w[2], 0.0, -w[0]], [-w[1], w[0], 0.0]])
+
+
+def se3_log_vector(T) -> np.ndarray:
+    """[rotation vector; theta G^-1 p] of a homogeneous transform: the six-vector the reference obtains from
+    se3ToVec(MatrixLog6(T)) (utils/se3.py:55-115), with  theta G^-1 = I - Phi / 2 + a(theta^2) Phi^2,
+    a = (1 - theta sin theta / (2 (1 - cos theta))) / theta^2  and its four-term series below theta^2 = 1e-2."""
+    T = np.asarray(T, dtype=np.float64)
+    phi = _so3_log_matrix(T[:3, :3])
+    t2 = float(np.sum(phi * phi)) / 2.0
+    if t2 < 1e-2:
+        a = 1.0 / 12 + t2 / 720 + t2 ** 2 / 30240 + t2 ** 3 / 1209600
+    else:
+        th = np.sqrt(t2)
+        a = (1.0 - th * np.sin(th) / max(2.0 * (1.0 - np.cos(th)), 1e-300)) / (th * th)
+    Ginv = np.eye(3) - 0.5 * phi + a * (phi @ phi)
+    return np.concatenate((np.array([phi[2, 1], phi[0, 2], phi[1, 0]]), Ginv @ T[:3, 3]))
+
+
+def extrapolate_from_current(theta_current, T_current, T_desired, jacobian_func, joint_limits: Limits, alpha: float = 0.5) -> np.ndarray:
+    """theta + alpha pinv(J(theta)) log6(T_desired T_current^-1), clipped (reference kinematics/ik_helpers.py:116-176)."""
+    theta = np.asarray(theta_current, dtype=np.float64)
+    V = se3_log_vector(np.asarray(T_desired, dtype=np.float64) @ np.linalg.inv(np.asarray(T_current, dtype=np.float64)))
+    J = np.asarray(jacobian_func(theta), dtype=np.float64)
+    return clip_to_limits(theta + alpha * (np.linalg.pinv(J) @ V), joint_limits)
+
+
+class IKInitialGuessCache:
+    """(pose, solution, residual) triples of solved IK problems; `get_nearest` proposes an initial guess for a new target
+    from the k closest cached poses (reference kinematics/ik_helpers.py:249-405: FIFO eviction, distance = position error +
+    0.1 Frobenius rotation error + 0.2 residual, the best entry itself when its residual is below 1e-3, else the mean)."""
+
+    def __init__(self, max_size: int = 100) -> None:
+        self.cache: List[tuple] = []
+        self.max_size = max_size
+
+    def add(self, T, theta, residual: Optional[float] = None) -> None:
+        self.cache.append((np.array(T, dtype=np.float64), np.array(theta, dtype=np.float64), None if residual is None else float(residual)))
+        if len(self.cache) > self.max_size:
+            self.cache.pop(0)
+
+    def get_nearest(self, T_desired, k: int = 3, joint_limits: Optional[Limits] = None) -> Optional[np.ndarray]:
+        if not self.cache:
+            return None
+        Td = np.asarray(T_desired, dtype=np.float64)
+        scored = sorted(((self._pose_distance(Td, T) + 0.2 * (0.0 if r is None else r), 0.0 if r is None else r, th)
+                         for T, th, r in self.cache), key=lambda x: x[0])
+        near = scored[:min(k, len(scored))]
+        best_quality, best_theta = near[0][1], near[0][2].copy()
+        avg = best_theta.copy() if best_quality < 1e-3 else np.mean([e[2] for e in near], axis=0)
+        if joint_limits is not None:
+            avg, best_theta = clip_to_limits(avg, joint_limits), clip_to_limits(best_theta, joint_limits)
+        return best_theta if np.linalg.norm(avg - best_theta) < 1e-6 else avg
+
+    def clear(self) -> None:
+        self.cache.clear()
+
+    def size(self) -> int:
+        return len(self.cache)
+
+    @staticmethod
+    def _pose_distance(T1, T2) -> float:
+        return float(np.linalg.norm(T1[:3, 3] - T2[:3, 3]) + 0.1 * np.linalg.norm(T1[:3, :3] - T2[:3, :3], "fro"))
+

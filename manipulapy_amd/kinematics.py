@@ -147,6 +147,61 @@ class SerialManipulator:
                                                    damping, step_cap, weight_orientation, weight_position, adaptive_tuning, backtracking)
         return th[0], bool(ok[0]), int(it[0])
 
+    def smart_inverse_kinematics(self, T_desired, strategy: str = "workspace_heuristic", theta_current=None, T_current=None, cache=None,
+                                 eomg: float = 1e-6, ev: float = 1e-6, max_iterations: int = 10000, plot_residuals: bool = False,
+                                 damping: float = 2e-2, step_cap: float = 0.3, png_name: str = "ik_residuals.png",
+                                 weight_orientation: float = 1.0, weight_position: float = 1.0, adaptive_tuning: bool = True,
+                                 backtracking: bool = True, auto_fallback: bool = True):
+        """IK from a strategy-chosen initial guess, with up to four fallback starts (midpoint, three random) when the first
+        attempt fails (reference kinematics/ik.py:327-475).  Returns (theta, success, iterations summed over the attempts)."""
+        from . import ik_helpers
+
+        valid = ["workspace_heuristic", "extrapolate", "cached", "random", "midpoint"]
+        if strategy not in valid:
+            raise ValueError(f"Unknown strategy '{strategy}'. Choose from: {valid}")
+        T = np.asarray(T_desired, dtype=np.float64)
+        n = len(self.joint_limits)
+
+        def guess(name):
+            if name == "workspace_heuristic":
+                return ik_helpers.workspace_heuristic_guess(T, n, self.joint_limits)
+            if name == "extrapolate":
+                if theta_current is None or T_current is None:
+                    return None
+                return ik_helpers.extrapolate_from_current(theta_current, T_current, T, lambda th: self.jacobian(th, frame="space"),
+                                                           self.joint_limits, alpha=0.5)
+            if name == "cached":
+                return None if cache is None else cache.get_nearest(T, k=3, joint_limits=self.joint_limits)
+            if name == "random":
+                return ik_helpers.random_in_limits(self.joint_limits)
+            return ik_helpers.midpoint_of_limits(self.joint_limits)
+
+        def attempt(theta0):
+            return self.iterative_inverse_kinematics(T, theta0, eomg, ev, max_iterations, plot_residuals, damping, step_cap, png_name,
+                                                     weight_orientation, weight_position, adaptive_tuning, backtracking)
+
+        def pose_error(theta):
+            Tc = np.asarray(self.forward_kinematics(theta))
+            tr = np.trace(Tc[:3, :3].T @ T[:3, :3])
+            return float(np.linalg.norm(Tc[:3, 3] - T[:3, 3]) + np.arccos(np.clip((tr - 1) / 2, -1, 1)))
+
+        theta0 = guess(strategy)
+        if theta0 is None:
+            theta0 = guess("workspace_heuristic")
+        theta, ok, iters = attempt(theta0)
+        if ok or not auto_fallback:
+            return theta, ok, iters
+        total, best_theta, best_err = iters, theta, pose_error(theta)
+        for name in ("midpoint", "random", "random", "random"):
+            th, ok, it = attempt(guess(name))
+            total += it
+            if ok:
+                return th, True, total
+            err = pose_error(th)
+            if err < best_err:
+                best_err, best_theta = err, th
+        return best_theta, False, total
+
     # the (initial guess, damping, step cap) ladder of the reference's robust solver (kinematics/ik.py:505-516)
     _ROBUST_STRATEGIES = (("workspace_heuristic", 0.02, 0.3), ("midpoint", 0.02, 0.3), ("workspace_heuristic", 0.01, 0.4),
                           ("random", 0.02, 0.3), ("random", 0.03, 0.25), ("midpoint", 0.01, 0.4), ("random", 0.015, 0.35),

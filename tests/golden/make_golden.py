@@ -339,6 +339,52 @@ def dump_ik():
         d[f"{robot}_robust_success"] = np.array(okr); d[f"{robot}_robust_iterations"] = np.array(itr)
         d[f"{robot}_robust_strategy"] = np.array(names)
         print(robot, "robust ik:", okr, itr, names, flush=True)
+        if robot == "ur5":  # smart_inverse_kinematics + its helpers (kinematics/ik.py:327-475, kinematics/ik_helpers.py)
+            from ManipulaPy import utils as ref_utils
+            from ManipulaPy.kinematics import ik_helpers as ref_h
+
+            def rot(axis, ang):
+                axis = np.asarray(axis, float) / np.linalg.norm(axis)
+                K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+                return np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * (K @ K)
+
+            Ts = []
+            for axis, ang in (([1, 2, 3], 0.7), ([0, 1, 1], 1e-5), ([1, -1, 0.5], 0.05), ([0, 0, 1], 2.5), ([1, 0, 0], np.pi - 1e-3),
+                              ([1, 2, -1], np.pi), ([0, 0, 1], 0.0)):
+                T = np.eye(4); T[:3, :3] = rot(axis, ang); T[:3, 3] = rng.uniform(-0.5, 0.5, 3)
+                Ts.append(T)
+            d["log6_T"] = np.stack(Ts)
+            d["log6_V"] = np.stack([np.asarray(ref_utils.se3ToVec(ref_utils.MatrixLog6(T))) for T in Ts])
+            qc = rng.uniform(0.5 * lims[:, 0], 0.5 * lims[:, 1], (4, n))
+            qn = qc + rng.uniform(-0.15, 0.15, (4, n))
+            Tc = np.stack([np.asarray(sm.forward_kinematics(q)) for q in qc]); Tn = np.stack([np.asarray(sm.forward_kinematics(q)) for q in qn])
+            d["ext_theta"], d["ext_Tc"], d["ext_Tn"] = qc, Tc, Tn
+            d["ext_guess"] = np.stack([np.asarray(ref_h.extrapolate_from_current(qc[i], Tc[i], Tn[i], lambda th: sm.jacobian(th, frame="space"),
+                                                                             sm.joint_limits, alpha=0.5)) for i in range(4)])
+            cache = ref_h.IKInitialGuessCache(max_size=3)
+            for i in range(4):  # the first entry is evicted
+                cache.add(Tc[i], qc[i], residual=[None, 0.5, 1e-4, 0.02][i])
+            d["cache_query"] = Tn
+            d["cache_out"] = np.stack([np.asarray(cache.get_nearest(Tn[i], k=3, joint_limits=sm.joint_limits)) for i in range(4)])
+            smart = {}
+            for j, strat in enumerate(("workspace_heuristic", "midpoint", "extrapolate", "cached", "random")):
+                np.random.seed(777 + j)
+                kw = dict(max_iterations=250)
+                if strat == "extrapolate":
+                    kw.update(theta_current=qc[1], T_current=Tc[1])
+                if strat == "cached":
+                    kw.update(cache=cache)
+                th_s, ok_s, it_s = sm.smart_inverse_kinematics(Tn[1], strategy=strat, **kw)
+                smart[strat] = (np.asarray(th_s, dtype=np.float64), bool(ok_s), int(it_s))
+                print("smart", strat, ok_s, it_s, flush=True)
+            d["smart_target"] = Tn[1]
+            for k_, (th_s, ok_s, it_s) in smart.items():
+                d[f"smart_{k_}_theta"], d[f"smart_{k_}_success"], d[f"smart_{k_}_iterations"] = th_s, np.array(ok_s), np.array(it_s)
+            np.random.seed(4242)
+            Tbad = Tn[2].copy(); Tbad[:3, 3] += np.array([2.5, 0, 0])
+            th_s, ok_s, it_s = sm.smart_inverse_kinematics(Tbad, max_iterations=40)
+            d["smart_unreachable_target"], d["smart_unreachable_theta"] = Tbad, np.asarray(th_s, dtype=np.float64)
+            d["smart_unreachable_success"], d["smart_unreachable_iterations"] = np.array(bool(ok_s)), np.array(int(it_s))
     np.savez(os.path.join(HERE, "ik.npz"), **d)
 
 

@@ -808,6 +808,42 @@ def test_robust_inverse_kinematics_against_reference_runs(robot, tables):
         assert not e[1][0] and e[3] == ["none"]
 
 
+def test_smart_inverse_kinematics_against_reference_runs(tables):
+    """smart_inverse_kinematics (strategy-chosen initial guess + fallback starts) on the reference's own problems: the
+    deterministic strategy (extrapolate: 7 iterations, no restart) reproduces the reference run; the long multi-attempt
+    runs go through stagnation restarts whose noise differs by design, so they are checked for a valid outcome."""
+    import manipulapy_amd as mp
+    from manipulapy_amd import ik_helpers as h
+
+    z = np.load(golden_path("ik.npz"))
+    tab = tables["ur5"]
+    sm, _, _ = mp.load_robot("ur5")
+    sm.joint_limits = [(float(a), float(b)) for a, b in z["ur5_joint_limits"]]
+    T = z["smart_target"]
+    with mp.use_backend("hip"):
+        th, ok, it = sm.smart_inverse_kinematics(T, strategy="extrapolate", theta_current=z["ext_theta"][1], T_current=z["ext_Tc"][1],
+                                                 max_iterations=250)
+        assert ok == bool(z["smart_extrapolate_success"]) and abs(it - int(z["smart_extrapolate_iterations"])) <= 1
+        np.testing.assert_allclose(th, z["smart_extrapolate_theta"], rtol=0, atol=1e-6)
+        cache = h.IKInitialGuessCache(max_size=3)
+        for i in range(4):
+            cache.add(z["ext_Tc"][i], z["ext_theta"][i], residual=[None, 0.5, 1e-4, 0.02][i])
+        for strat, kw in (("workspace_heuristic", {}), ("midpoint", {}), ("cached", {"cache": cache}), ("random", {})):
+            np.random.seed(5)
+            th, ok, it = sm.smart_inverse_kinematics(T, strategy=strat, max_iterations=250, **kw)
+            assert it >= 1 and th.shape == (6,)
+            if ok:
+                _, rot, tr = ref.ik_geometric_error(ref.fk_space(tab, th), T)
+                assert rot < 1e-6 and tr < 1e-6
+        th, ok, it = sm.smart_inverse_kinematics(z["smart_unreachable_target"], max_iterations=40)
+        assert not ok and it == int(z["smart_unreachable_iterations"])  # five exhausted attempts of 41
+        th1, ok1, it1 = sm.smart_inverse_kinematics(T, strategy="extrapolate", max_iterations=250)  # missing inputs -> heuristic guess
+        th2, ok2, it2 = sm.smart_inverse_kinematics(T, strategy="workspace_heuristic", max_iterations=250, auto_fallback=False)
+        assert it1 >= it2
+        with pytest.raises(ValueError):
+            sm.smart_inverse_kinematics(T, strategy="nope")
+
+
 def test_singularity_and_workspace_against_oracle(tables, dyn_golden):
     """Singularity mirror (reference singularity/singularity_analysis.py): condition number / smallest singular value of
     the GPU Jacobians == NumPy on the oracle's Jacobians; batch == per-sample; Monte-Carlo workspace points == oracle FK."""

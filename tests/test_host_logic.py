@@ -481,3 +481,35 @@ def test_device_inverse_kinematics_on_host(robot, hostsim, tables):
         tol = 1e-6 if want_ok else 1e-5  # an exhausted run is 400 accumulated steps of a different (equivalent) solve
         np.testing.assert_allclose(th[0], z[f"{robot}_theta"][i], rtol=0, atol=tol, err_msg=f"{robot} case {i}")
 
+
+def test_ik_helpers_match_reference(tables):
+    """manipulapy_amd.ik_helpers against the reference's own outputs (tests/golden/ik.npz): the se(3) logarithm over generic,
+    tiny, near-pi and exact half-turn rotations, the extrapolated initial guess, the nearest-solution cache (eviction,
+    residual weighting, best-entry shortcut), and the closed-form guesses."""
+    from manipulapy_amd import ik_helpers as h
+
+    z = np.load(golden_path("ik.npz"))
+    tab = tables["ur5"]
+    lim = [(float(a), float(b)) for a, b in z["ur5_joint_limits"]]
+    for T, V in zip(z["log6_T"], z["log6_V"]):
+        np.testing.assert_allclose(h.se3_log_vector(T), V, rtol=1e-9, atol=1e-9)
+    for i in range(4):
+        g = h.extrapolate_from_current(z["ext_theta"][i], z["ext_Tc"][i], z["ext_Tn"][i], lambda th: ref.jacobian_space(tab, th), lim, alpha=0.5)
+        np.testing.assert_allclose(g, z["ext_guess"][i], rtol=1e-8, atol=1e-9)
+    cache = h.IKInitialGuessCache(max_size=3)
+    for i in range(4):
+        cache.add(z["ext_Tc"][i], z["ext_theta"][i], residual=[None, 0.5, 1e-4, 0.02][i])
+    assert cache.size() == 3
+    for i in range(4):
+        np.testing.assert_allclose(cache.get_nearest(z["cache_query"][i], k=3, joint_limits=lim), z["cache_out"][i], rtol=1e-12, atol=1e-12)
+    cache.clear()
+    assert cache.get_nearest(z["cache_query"][0]) is None
+    T = z["ur5_robust_T_desired"][0]
+    np.testing.assert_allclose(h.workspace_heuristic_guess(T, 6, lim), ref.ik_workspace_heuristic_guess(T, 6, np.array(lim)), rtol=0, atol=0)
+    np.testing.assert_allclose(h.workspace_heuristic_guess(np.stack([T, T]), 6, lim)[1], h.workspace_heuristic_guess(T, 6, lim))
+    np.testing.assert_array_equal(h.midpoint_of_limits([(-1.0, 3.0), (None, 2.0)]), [1.0, 0.0])
+    np.random.seed(3)
+    a = h.random_in_limits(lim)
+    np.random.seed(3)
+    np.testing.assert_array_equal(a, ref.ik_random_in_limits(np.array(lim)))
+
