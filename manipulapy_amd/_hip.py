@@ -539,7 +539,11 @@ class HipContext:
                                                   float(Tf), int(method), _dptr(g), _dptr(F), _fptr(tau)))
         return tau
 
-    def fk_jac_id_host(self, model: HipModel, q, qd=None, qdd=None, g=None, Ftip=None, want_T=True, want_J=True):
+    def fk_jac_id_host(self, model: HipModel, q, qd=None, qdd=None, g=None, Ftip=None, want_T=True, want_J=True, out_T=None,
+                       out_J=None, out_tau=None):
+        """(T (rows,4,4), J (rows,6,n), tau (rows,n)) float64; an output that was not asked for is None.  out_*: arrays to
+        write into (reused or page-locked, see `pinned_empty`): with page-locked inputs and outputs a large call is chunked
+        and its upload, kernels and download overlap."""
         q = _as_c(q, np.float64, name="q")
         if q.ndim != 2 or q.shape[1] != model.n:
             raise ValueError(f"q must be (rows, {model.n}), got {q.shape}")
@@ -547,9 +551,10 @@ class HipContext:
         want_tau = qd is not None and qdd is not None
         qd = _as_c(qd, np.float64, q.shape, "qd") if want_tau else None
         qdd = _as_c(qdd, np.float64, q.shape, "qdd") if want_tau else None
-        T = np.zeros((rows, 4, 4)) if want_T else None
-        J = np.zeros((rows, 6, model.n)) if want_J else None
-        tau = np.zeros((rows, model.n)) if want_tau else None
+        f64 = np.dtype(np.float64)
+        T = _out_or_new(out_T, (rows, 4, 4), f64) if want_T else None
+        J = _out_or_new(out_J, (rows, 6, model.n), f64) if want_J else None
+        tau = _out_or_new(out_tau, (rows, model.n), f64) if want_tau else None
         g = _vec_or_none(g, 3, "g")
         F = _vec_or_none(Ftip, 6, "Ftip")
         _check(self.lib.mp_fk_jac_id_host_f64(self.handle, model.handle, _dptr(q), _dptr(qd), _dptr(qdd), rows,

@@ -294,6 +294,40 @@ static int fkjid_impl(const char* fn, mp_ctx* ctx, const mp_model* model, const 
   return MP_OK;
 }
 
+// Chunked three-stage pipeline over `rows` rows in chunks of `chunk`: `up(r0, nr)` queues the uploads of a chunk on the
+// copy stream, `run(r0, nr)` launches its kernels on the compute stream, `down(r0, nr)` queues its downloads on the
+// copy-out stream; events order the stages of one chunk, so the upload of chunk k+1, the kernels of chunk k and the
+// download of chunk k-1 overlap (PCIe is full duplex: with page-locked buffers a call costs about its larger
+// direction).  Every stage is drained before returning, also on the error path.
+template <class Up, class Run, class Down>
+static int host_pipeline(mp_ctx* ctx, int64_t rows, int64_t chunk, Up up, Run run, Down down) {
+  EventList ev;
+  auto body = [&]() -> int {
+    for (int64_t r0 = 0; r0 < rows; r0 += chunk) {
+      const int64_t nr = std::min(chunk, rows - r0);
+      hipEvent_t uploaded = nullptr, done = nullptr;
+      if (int rc = ev.make(&uploaded)) return rc;
+      if (int rc = ev.make(&done)) return rc;
+      if (int rc = up(r0, nr)) return rc;
+      HIP_TRY(hipEventRecord(uploaded, ctx->copy));
+      HIP_TRY(hipStreamWaitEvent(ctx->compute, uploaded, 0));
+      if (int rc = run(r0, nr)) return rc;
+      HIP_TRY(hipEventRecord(done, ctx->compute));
+      HIP_TRY(hipStreamWaitEvent(ctx->copy_out, done, 0));
+      if (int rc = down(r0, nr)) return rc;
+    }
+    return MP_OK;
+  };
+  const int rc = body();
+  (void)hipStreamSynchronize(ctx->copy);
+  (void)hipStreamSynchronize(ctx->compute);
+  const hipError_t he = hipStreamSynchronize(ctx->copy_out);
+  if (rc == MP_OK && he != hipSuccess) return hip_err(he, "hipStreamSynchronize");
+  return rc;
+}
+#define UP(dst, src, bytes) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->copy))
+#define DOWN(dst, src, bytes) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->copy_out))
+
 template <typename T>
 static int id_host_impl(const char* fn, mp_ctx* ctx, const mp_model* model, const T* q, const T* qd, const T* qdd,
                         int64_t rows, const double* g, const double* Ftip, T* tau) {
@@ -329,35 +363,25 @@ static int id_host_impl(const char* fn, mp_ctx* ctx, const mp_model* model, cons
     HIP_TRY(hipStreamSynchronize(ctx->compute));
     return MP_OK;
   }
-  EventList ev;
-  auto pipeline = [&]() -> int {
-    for (int64_t k = 0; k < nchunks; ++k) {
-      const int64_t r0 = k * chunk, nr = std::min(chunk, rows - r0);
-      const size_t off = (size_t)r0 * row_b, nb = (size_t)nr * row_b;
-      hipEvent_t up = nullptr, done = nullptr;
-      if (int rc = ev.make(&up)) return rc;
-      if (int rc = ev.make(&done)) return rc;
-      HIP_TRY(hipMemcpyAsync((char*)dq + off, (const char*)q + off, nb, hipMemcpyHostToDevice, ctx->copy));
-      HIP_TRY(hipMemcpyAsync((char*)dqd + off, (const char*)qd + off, nb, hipMemcpyHostToDevice, ctx->copy));
-      HIP_TRY(hipMemcpyAsync((char*)dqdd + off, (const char*)qdd + off, nb, hipMemcpyHostToDevice, ctx->copy));
-      HIP_TRY(hipEventRecord(up, ctx->copy));
-      HIP_TRY(hipStreamWaitEvent(ctx->compute, up, 0));
-      if (int rc = id_impl<T>(fn, ctx, model, (T*)((char*)dq + off), (T*)((char*)dqd + off), (T*)((char*)dqdd + off), nr, g, Ftip,
-                              (T*)((char*)dt + off)))
-        return rc;
-      HIP_TRY(hipEventRecord(done, ctx->compute));
-      HIP_TRY(hipStreamWaitEvent(ctx->copy_out, done, 0));
-      HIP_TRY(hipMemcpyAsync((char*)tau + off, (const char*)dt + off, nb, hipMemcpyDeviceToHost, ctx->copy_out));
-    }
-    return MP_OK;
-  };
-  const int rc = pipeline();
-  // drain every stage before the scratch buffers return to the pool, also on the error path
-  (void)hipStreamSynchronize(ctx->copy);
-  (void)hipStreamSynchronize(ctx->compute);
-  hipError_t he = hipStreamSynchronize(ctx->copy_out);
-  if (rc == MP_OK && he != hipSuccess) return hip_err(he, "hipStreamSynchronize");
-  return rc;
+  char *cq = (char*)dq, *cqd = (char*)dqd, *cqdd = (char*)dqdd, *ct = (char*)dt;
+  return host_pipeline(
+      ctx, rows, chunk,
+      [&](int64_t r0, int64_t nr) -> int {
+        const size_t off = (size_t)r0 * row_b, nb = (size_t)nr * row_b;
+        UP(cq + off, (const char*)q + off, nb);
+        UP(cqd + off, (const char*)qd + off, nb);
+        UP(cqdd + off, (const char*)qdd + off, nb);
+        return MP_OK;
+      },
+      [&](int64_t r0, int64_t nr) -> int {
+        const size_t off = (size_t)r0 * row_b;
+        return id_impl<T>(fn, ctx, model, (T*)(cq + off), (T*)(cqd + off), (T*)(cqdd + off), nr, g, Ftip, (T*)(ct + off));
+      },
+      [&](int64_t r0, int64_t nr) -> int {
+        const size_t off = (size_t)r0 * row_b;
+        DOWN((char*)tau + off, ct + off, (size_t)nr * row_b);
+        return MP_OK;
+      });
 }
 
 template <typename T>
@@ -982,20 +1006,53 @@ int mp_fk_jac_id_host_f64(mp_ctx* ctx, const mp_model* model, const double* q, c
   if (rows == 0) return MP_OK;
   REQUIRE(q && (T || J || tau), "mp_fk_jac_id_host_f64: q and at least one output are required");
   REQUIRE(!tau || (qd && qdd), "mp_fk_jac_id_host_f64: tau requested without qd / qdd");
-  const size_t n = (size_t)model->d.n, rb = (size_t)rows * n * sizeof(double);
+  const size_t n = (size_t)model->d.n, row_b = n * sizeof(double), rb = (size_t)rows * row_b;
   Scratch sc(ctx);
   void *dq = nullptr, *dqd = nullptr, *dqdd = nullptr, *dT = nullptr, *dJ = nullptr, *dt = nullptr;
   if (int rc = sc.get(rb, &dq)) return rc;
-  H2D(dq, q, rb);
   if (tau) {
     if (int rc = sc.get(rb, &dqd)) return rc;
     if (int rc = sc.get(rb, &dqdd)) return rc;
     if (int rc = sc.get(rb, &dt)) return rc;
-    H2D(dqd, qd, rb);
-    H2D(dqdd, qdd, rb);
   }
   if (T) if (int rc = sc.get((size_t)rows * 16 * sizeof(double), &dT)) return rc;
   if (J) if (int rc = sc.get(rb * 6, &dJ)) return rc;
+  // page-locked arrays throughout and more than one chunk: upload, kernels and the (much larger) download overlap
+  const int64_t chunk = host_chunk_rows();
+  const bool pinned = is_pinned_host(q) && (!tau || (is_pinned_host(qd) && is_pinned_host(qdd) && is_pinned_host(tau))) &&
+                      (!T || is_pinned_host(T)) && (!J || is_pinned_host(J));
+  if (pinned && rows > chunk) {
+    char *cq = (char*)dq, *cqd = (char*)dqd, *cqdd = (char*)dqdd, *ct = (char*)dt, *cT = (char*)dT, *cJ = (char*)dJ;
+    return host_pipeline(
+        ctx, rows, chunk,
+        [&](int64_t r0, int64_t nr) -> int {
+          const size_t off = (size_t)r0 * row_b, nb = (size_t)nr * row_b;
+          UP(cq + off, (const char*)q + off, nb);
+          if (tau) {
+            UP(cqd + off, (const char*)qd + off, nb);
+            UP(cqdd + off, (const char*)qdd + off, nb);
+          }
+          return MP_OK;
+        },
+        [&](int64_t r0, int64_t nr) -> int {
+          const size_t off = (size_t)r0 * row_b;
+          return mp_fk_jac_id_f64(ctx, model, (double*)(cq + off), tau ? (double*)(cqd + off) : nullptr,
+                                  tau ? (double*)(cqdd + off) : nullptr, nr, g, Ftip, T ? (double*)(cT + (size_t)r0 * 128) : nullptr,
+                                  J ? (double*)(cJ + off * 6) : nullptr, tau ? (double*)(ct + off) : nullptr);
+        },
+        [&](int64_t r0, int64_t nr) -> int {
+          const size_t off = (size_t)r0 * row_b, nb = (size_t)nr * row_b;
+          if (T) DOWN((char*)T + (size_t)r0 * 128, cT + (size_t)r0 * 128, (size_t)nr * 128);
+          if (J) DOWN((char*)J + off * 6, cJ + off * 6, nb * 6);
+          if (tau) DOWN((char*)tau + off, ct + off, nb);
+          return MP_OK;
+        });
+  }
+  H2D(dq, q, rb);
+  if (tau) {
+    H2D(dqd, qd, rb);
+    H2D(dqdd, qdd, rb);
+  }
   if (int rc = mp_fk_jac_id_f64(ctx, model, (double*)dq, (double*)dqd, (double*)dqdd, rows, g, Ftip, (double*)dT,
                                 (double*)dJ, (double*)dt))
     return rc;

@@ -922,6 +922,19 @@ def test_host_paths_pinned_pipelined_and_prefaulted(models, tables):
         pf = ctx.pinned_empty(fused.shape, np.float32)
         ctx.traj_id_fused_host(model, q[:300], qd[:300], 2.0, 1201, 5, out=pf)
         np.testing.assert_array_equal(pf, fused)
+        # FK + Jacobian + ID through the same pipeline: page-locked in / out, several chunks, == the pageable call
+        q64, qd64, qdd64 = q[:300001].astype(np.float64), qd[:300001].astype(np.float64), qdd[:300001].astype(np.float64)
+        Tw, Jw, tw = ctx.fk_jac_id_host(model, q64, qd64, qdd64)
+        pin = lambda a: (lambda b: (b.__setitem__(slice(None), a), b)[1])(ctx.pinned_empty(a.shape, np.float64))
+        pq64, pqd64, pqdd64 = pin(q64), pin(qd64), pin(qdd64)
+        oT, oJ, ot = ctx.pinned_empty(Tw.shape, np.float64), ctx.pinned_empty(Jw.shape, np.float64), ctx.pinned_empty(tw.shape, np.float64)
+        rT, rJ, rt = ctx.fk_jac_id_host(model, pq64, pqd64, pqdd64, out_T=oT, out_J=oJ, out_tau=ot)
+        assert rT is oT and rJ is oJ and rt is ot
+        np.testing.assert_array_equal(oT, Tw); np.testing.assert_array_equal(oJ, Jw); np.testing.assert_array_equal(ot, tw)
+        rT2, rJ2, rt2 = ctx.fk_jac_id_host(model, pq64, want_T=True, want_J=False, out_T=oT)   # FK only, pinned, chunked
+        assert rJ2 is None and rt2 is None
+        np.testing.assert_array_equal(oT, Tw)
+        del pq64, pqd64, pqdd64, oT, oJ, ot, rT, rJ, rt, rT2
         del pq, pqd, pqdd
         ctx.destroy()                       # page-locked arrays outlive the context that allocated them
         np.testing.assert_array_equal(pt, want)

@@ -144,6 +144,20 @@ def main():
         out.append(dict(op=name, robot="ur5", dtype="float32", rows=B * N, ms=ms, rows_per_s=B * N / ms * 1e3,
                         jt_per_s=B * N * n / ms * 1e3, pcie_GBps=by / ms / 1e6))
     np.testing.assert_array_equal(ptau, reuse)
+    # FK + Jacobian of 2 M configurations back to the host: 36 B up, 464 B down per row
+    R = 1 << 21
+    q64 = rng.uniform(-1, 1, (R, n))
+    pq64 = ctx.pinned_empty((R, n), np.float64); pq64[:] = q64
+    oT, oJ = ctx.pinned_empty((R, 4, 4), np.float64), ctx.pinned_empty((R, 6, n), np.float64)
+    for name, fn in (("fk_jac_host (pageable in, fresh out)", lambda: ctx.fk_jac_id_host(model, q64)),
+                     ("fk_jac_host (pinned in/out)", lambda: ctx.fk_jac_id_host(model, pq64, out_T=oT, out_J=oJ))):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            fn()
+        ms = (time.perf_counter() - t0) / 3 * 1e3
+        out.append(dict(op=name, robot="ur5", dtype="float64", rows=R, ms=ms, rows_per_s=R / ms * 1e3,
+                        pcie_GBps=R * (n * 8 + 128 + 48 * n) / ms / 1e6))
     for r in out:
         print(json.dumps(r))
     ctx.destroy()
