@@ -296,7 +296,7 @@ __global__ __launch_bounds__(kBlock) void k_potential_field(const float* __restr
     const float ox = px - obs[3 * o], oy = py - obs[3 * o + 1], oz = pz - obs[3 * o + 2];
     const float d2 = ox * ox + oy * oy + oz * oz;
     if (d2 > 0.0f && d2 < d0sq) {
-      const float inv = 1.0f / sqrtf(d2);
+      const float inv = __builtin_amdgcn_rsqf(d2);  // v_rsq_f32, 1 ulp: the divide-after-sqrt sequence it replaces is ~15 instructions of ~40
       const float t = inv - inv_d0;
       U += 0.5f * t * t;
       const float f = -t * inv * inv * inv;
