@@ -91,7 +91,6 @@ def main():
     out.append(dict(op="potential_field", dtype="float32", rows=P, obstacles=O, ms=ms, rows_per_s=P / ms * 1e3,
                     alg_GBps=P * 28 / ms / 1e6, pair_per_s=P * O / ms * 1e3))
     # batched inverse kinematics: targets reachable by construction, guesses 0.3 rad away
-    from oracle import ref_numpy as ref
     for robot in ("ur5", "iiwa14"):
         sm, dyn, lim = mp.load_robot(robot)
         model = _hip.HipModel(dyn.S_list, dyn.Mlist_per_link, dyn.Glist, sm.M_list, lim)
