@@ -14,6 +14,7 @@ from .dynamics import ManipulatorDynamics
 from .planning import OptimizedTrajectoryPlanning, TrajectoryPlanning
 from .control import ManipulatorController
 from .singularity import Singularity
+from . import ik_helpers, utils
 from .robots import load_robot, robot_tables, robot_urdf
 from .urdf import URDFToSerialManipulator
 
@@ -21,5 +22,5 @@ __version__ = "0.1.0"
 __all__ = ["ArrayBackend", "HipBackend", "NumpyBackend", "get_backend", "get_registered", "register", "set_backend",
            "use_backend", "BackendNotSupportedError", "KernelRegistration", "KernelRegistry", "check_hip_availability",
            "execute_registered_kernel", "get_context", "get_gpu_properties", "get_registered_kernel",
-           "SerialManipulator", "ManipulatorDynamics", "OptimizedTrajectoryPlanning", "TrajectoryPlanning", "ManipulatorController", "Singularity",
+           "SerialManipulator", "ManipulatorDynamics", "OptimizedTrajectoryPlanning", "TrajectoryPlanning", "ManipulatorController", "Singularity", "ik_helpers", "utils",
            "load_robot", "robot_tables", "robot_urdf", "URDFToSerialManipulator"]

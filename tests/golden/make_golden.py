@@ -22,6 +22,7 @@ What it does:
       cartesian_ur5.npz    : cartesian_trajectory dumps (`make_golden.py cartesian` regenerates only this)
       ik.npz               : iterative_inverse_kinematics dumps, 10 problems per robot (`make_golden.py ik`)
       control_ur5.npz      : ManipulatorController laws on UR5 (`make_golden.py control`)
+      utils.npz            : every public ManipulaPy.utils function on generic and branch-switching inputs (`make_golden.py utils`)
       urdf/<robot>.urdf    : kinematic + inertial skeletons of the four URDFs (`make_golden.py urdf`)
       reference_cpu_timings.json : cold-cache per-point timings of the reference
 
@@ -431,6 +432,70 @@ def dump_control():
     np.savez(os.path.join(HERE, "control_ur5.npz"), **d)
 
 
+def dump_utils():
+    """ManipulaPy.utils (so3 / se3 / screw / time_scaling): every public function on generic inputs and on the inputs where its
+    branches switch (identity, tiny angles on both sides of each Taylor band, near-pi, exact half turns about several axes,
+    Euler gimbal lock, prismatic screws)."""
+    from ManipulaPy import utils as U
+
+    rng = np.random.default_rng(SEED + 700)
+
+    def rot(axis, ang):
+        axis = np.asarray(axis, float) / np.linalg.norm(axis)
+        K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+        return np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * (K @ K)
+
+    angles = [0.0, 1e-9, 5e-7, 2e-6, 1e-4, 9e-3, 1.1e-2, 0.09, 0.11, 0.7, 2.5, np.pi - 2e-2, np.pi - 5e-3, np.pi - 1e-7, np.pi]
+    axes = [[0, 0, 1], [1, 0, 0], [0, 1, 0], [1, 2, 3], [1, -1, 0.5], [-2, 0.1, 0.3]]
+    Rs = np.stack([rot(axes[(i + j) % len(axes)], a) for i, a in enumerate(angles) for j in range(2)])
+    d = {"R": Rs}
+    d["MatrixLog3"] = np.stack([np.asarray(U.MatrixLog3(R)) for R in Rs])
+    ax_ang = [U.rotation_logm(R) for R in Rs]
+    d["rotation_logm_axis"] = np.stack([np.asarray(a) for a, _ in ax_ang]); d["rotation_logm_angle"] = np.array([float(t) for _, t in ax_ang])
+    d["euler"] = np.stack([np.asarray(U.rotation_matrix_to_euler_angles(R)) for R in Rs])
+    gimbal = rot([0, 1, 0], np.pi / 2) @ rot([1, 0, 0], 0.3)
+    d["R_gimbal"], d["euler_gimbal"] = gimbal, np.asarray(U.rotation_matrix_to_euler_angles(gimbal))
+    eul = rng.uniform(-170, 170, (5, 3))
+    d["euler_deg"], d["euler_to_R"] = eul, np.stack([np.asarray(U.euler_to_rotation_matrix(e)) for e in eul])
+    ws = np.stack([np.asarray(ax, float) / np.linalg.norm(ax) * a for ax in axes[:4] for a in (0.0, 5e-3, 1.5e-2, 0.8, 3.0)])
+    d["w"] = ws
+    d["MatrixExp3"] = np.stack([np.asarray(U.MatrixExp3(U.VecToso3(w))) for w in ws])
+    d["skew"] = np.stack([np.asarray(U.skew_symmetric(w)) for w in ws])
+    Vs = np.concatenate([ws, rng.uniform(-1, 1, ws.shape)], axis=1)
+    d["V"] = Vs
+    d["VecTose3"] = np.stack([np.asarray(U.VecTose3(V)) for V in Vs])
+    d["MatrixExp6"] = np.stack([np.asarray(U.MatrixExp6(U.VecTose3(V))) for V in Vs])
+    Ts = []
+    for R in Rs:
+        T = np.eye(4); T[:3, :3] = R; T[:3, 3] = rng.uniform(-0.6, 0.6, 3)
+        Ts.append(T)
+    Ts = np.stack(Ts)
+    d["T"] = Ts
+    d["MatrixLog6"] = np.stack([np.asarray(U.MatrixLog6(T)) for T in Ts])
+    d["logm"] = np.stack([np.asarray(U.logm(T)) for T in Ts])
+    d["se3ToVec"] = np.stack([np.asarray(U.se3ToVec(U.MatrixLog6(T))) for T in Ts])
+    d["logm_to_twist"] = np.stack([np.asarray(U.logm_to_twist(U.MatrixLog6(T))) for T in Ts])
+    d["TransInv"] = np.stack([np.asarray(U.TransInv(T)) for T in Ts])
+    d["adjoint"] = np.stack([np.asarray(U.adjoint_transform(T)) for T in Ts])
+    S = np.stack([np.concatenate([np.asarray(ax, float) / np.linalg.norm(ax), rng.uniform(-1, 1, 3)]) for ax in axes] +
+                 [np.array([0, 0, 0, 0.6, 0, 0.8])])
+    th = rng.uniform(-3, 3, len(S))
+    d["S"], d["theta"] = S, th
+    d["transform_from_twist"] = np.stack([np.asarray(U.transform_from_twist(s, t)) for s, t in zip(S, th)])
+    Slist = S.T  # (6, n)
+    d["extract_r_list"] = np.asarray(U.extract_r_list(Slist))
+    d["extract_omega_list"] = np.asarray(U.extract_omega_list(Slist))
+    om, rr = Slist[:3, :], np.asarray(U.extract_r_list(Slist)).T
+    d["screw_in_omega"], d["screw_in_r"] = om, rr
+    d["extract_screw_list"] = np.asarray(U.extract_screw_list(om, rr))
+    d["extract_screw_list_flat"] = np.asarray(U.extract_screw_list(om.reshape(-1), rr.reshape(-1)))
+    d["extract_screw_list_bcast"] = np.asarray(U.extract_screw_list(om, rr[:, :1]))
+    tt = np.linspace(0, 2.0, 9)
+    d["t"] = tt
+    d["cubic"] = np.array([U.CubicTimeScaling(2.0, t) for t in tt]); d["quintic"] = np.array([U.QuinticTimeScaling(2.0, t) for t in tt])
+    np.savez(os.path.join(HERE, "utils.npz"), **d)
+
+
 def dump_urdfs():
     """tests/golden/urdf/<robot>.urdf: the kinematic + inertial skeleton of the four benchmark robots' URDFs (robot
     description DATA; number strings kept verbatim so the tables stay bit-identical).  Visual / collision geometry,
@@ -492,6 +557,10 @@ def main():
         dump_urdfs()
         print("urdf skeletons dumped")
         return
+    if "utils" in sys.argv[1:]:  # only (re)generate the utils dump
+        dump_utils()
+        print("utils dumped")
+        return
     if "control" in sys.argv[1:]:  # only (re)generate the controller dump
         dump_control()
         print("control dumped")
@@ -513,6 +582,7 @@ def main():
     dump_cartesian()
     dump_ik()
     dump_control()
+    dump_utils()
     dump_urdfs()
     print("trajectories dumped", flush=True)
     time_reference()

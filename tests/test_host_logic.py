@@ -513,3 +513,54 @@ def test_ik_helpers_match_reference(tables):
     np.random.seed(3)
     np.testing.assert_array_equal(a, ref.ik_random_in_limits(np.array(lim)))
 
+
+def test_utils_match_reference():
+    """manipulapy_amd.utils against the reference's own outputs for every public function (tests/golden/utils.npz): generic
+    inputs plus the ones where branches switch - identity, both sides of each Taylor band, near-pi, exact half turns about
+    several axes, gimbal lock, prismatic screws, the reshaping / broadcasting rules of extract_screw_list."""
+    from manipulapy_amd import utils as U
+
+    z = np.load(golden_path("utils.npz"))
+    tol = dict(rtol=1e-10, atol=1e-12)
+    for i, R in enumerate(z["R"]):
+        np.testing.assert_allclose(U.MatrixLog3(R), z["MatrixLog3"][i], err_msg=f"MatrixLog3 {i}", **tol)
+        axis, ang = U.rotation_logm(R)
+        np.testing.assert_allclose(axis, z["rotation_logm_axis"][i], err_msg=f"rotation_logm axis {i}", **tol)
+        assert abs(ang - z["rotation_logm_angle"][i]) < 1e-12
+        np.testing.assert_allclose(U.rotation_matrix_to_euler_angles(R), z["euler"][i], **tol)
+    np.testing.assert_allclose(U.rotation_matrix_to_euler_angles(z["R_gimbal"]), z["euler_gimbal"], **tol)
+    for e, R in zip(z["euler_deg"], z["euler_to_R"]):
+        np.testing.assert_allclose(U.euler_to_rotation_matrix(e), R, **tol)
+    for i, w in enumerate(z["w"]):
+        np.testing.assert_array_equal(U.skew_symmetric(w), z["skew"][i])
+        np.testing.assert_allclose(U.MatrixExp3(U.VecToso3(w)), z["MatrixExp3"][i], **tol)
+        np.testing.assert_allclose(U.skew_symmetric_to_vector(U.skew_symmetric(w)), w, rtol=0, atol=0)
+    for i, V in enumerate(z["V"]):
+        np.testing.assert_array_equal(U.VecTose3(V), z["VecTose3"][i])
+        np.testing.assert_allclose(U.MatrixExp6(U.VecTose3(V)), z["MatrixExp6"][i], **tol)
+    for i, T in enumerate(z["T"]):
+        np.testing.assert_allclose(U.MatrixLog6(T), z["MatrixLog6"][i], err_msg=f"MatrixLog6 {i}", **tol)
+        np.testing.assert_allclose(U.logm(T), z["logm"][i], **tol)
+        np.testing.assert_allclose(U.se3ToVec(U.MatrixLog6(T)), z["se3ToVec"][i], **tol)
+        np.testing.assert_allclose(U.logm_to_twist(U.MatrixLog6(T)), z["logm_to_twist"][i], **tol)
+        np.testing.assert_allclose(U.TransInv(T), z["TransInv"][i], **tol)
+        np.testing.assert_allclose(U.adjoint_transform(T), z["adjoint"][i], **tol)
+        R, p = U.TransToRp(T)
+        np.testing.assert_array_equal(R, T[:3, :3]); np.testing.assert_array_equal(p, T[:3, 3])
+    for s_, t_, T in zip(z["S"], z["theta"], z["transform_from_twist"]):
+        np.testing.assert_allclose(U.transform_from_twist(s_, t_), T, **tol)
+    Slist = z["S"].T
+    np.testing.assert_allclose(U.extract_r_list(Slist), z["extract_r_list"], **tol)
+    np.testing.assert_array_equal(U.extract_omega_list(Slist), z["extract_omega_list"])
+    np.testing.assert_allclose(U.extract_screw_list(z["screw_in_omega"], z["screw_in_r"]), z["extract_screw_list"], **tol)
+    np.testing.assert_allclose(U.extract_screw_list(z["screw_in_omega"].reshape(-1), z["screw_in_r"].reshape(-1)), z["extract_screw_list_flat"], **tol)
+    np.testing.assert_allclose(U.extract_screw_list(z["screw_in_omega"], z["screw_in_r"][:, :1]), z["extract_screw_list_bcast"], **tol)
+    assert U.extract_screw_list(None, z["screw_in_r"]) is None and U.extract_r_list(None).size == 0
+    with pytest.raises(ValueError):
+        U.extract_screw_list(np.zeros((3, 2)), np.zeros((3, 3)))
+    np.testing.assert_allclose([U.CubicTimeScaling(2.0, t) for t in z["t"]], z["cubic"], rtol=1e-15)
+    np.testing.assert_allclose([U.QuinticTimeScaling(2.0, t) for t in z["t"]], z["quintic"], rtol=1e-15)
+    assert U.NearZero(1e-7) and not U.NearZero(1e-5)
+    with pytest.raises(ValueError):
+        U.se3ToVec(np.zeros((3, 3)))
+
