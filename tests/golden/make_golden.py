@@ -490,6 +490,16 @@ def dump_utils():
     d["extract_screw_list"] = np.asarray(U.extract_screw_list(om, rr))
     d["extract_screw_list_flat"] = np.asarray(U.extract_screw_list(om.reshape(-1), rr.reshape(-1)))
     d["extract_screw_list_bcast"] = np.asarray(U.extract_screw_list(om, rr[:, :1]))
+    # joint-space potential field (potential_field/fields.py:35-160)
+    from ManipulaPy.potential_field import PotentialField
+    pf = PotentialField(attractive_gain=1.3, repulsive_gain=80.0, influence_distance=0.6)
+    qpf, goal = rng.uniform(-1, 1, 6), rng.uniform(-1, 1, 6)
+    obstacles = [qpf + rng.uniform(-0.2, 0.2, 6), qpf + rng.uniform(-1.5, 1.5, 6), qpf.copy(), qpf + rng.uniform(-0.1, 0.1, 6)]
+    d["pf_q"], d["pf_goal"], d["pf_obstacles"] = qpf, goal, np.stack(obstacles)
+    d["pf_attractive"] = np.asarray(pf.compute_attractive_potential(qpf, goal))
+    d["pf_repulsive"] = np.asarray(pf.compute_repulsive_potential(qpf, obstacles))
+    d["pf_gradient"] = np.asarray(pf.compute_gradient(qpf, goal, obstacles))
+    d["pf_gradient_free"] = np.asarray(pf.compute_gradient(qpf, goal, []))
     tt = np.linspace(0, 2.0, 9)
     d["t"] = tt
     d["cubic"] = np.array([U.CubicTimeScaling(2.0, t) for t in tt]); d["quintic"] = np.array([U.QuinticTimeScaling(2.0, t) for t in tt])

@@ -563,4 +563,14 @@ def test_utils_match_reference():
     assert U.NearZero(1e-7) and not U.NearZero(1e-5)
     with pytest.raises(ValueError):
         U.se3ToVec(np.zeros((3, 3)))
+    # joint-space potential field: in-range, out-of-range and coincident obstacles
+    from manipulapy_amd.potential_field import PotentialField
+
+    pf = PotentialField(attractive_gain=1.3, repulsive_gain=80.0, influence_distance=0.6)
+    obs = list(z["pf_obstacles"])
+    np.testing.assert_allclose(pf.compute_attractive_potential(z["pf_q"], z["pf_goal"]), z["pf_attractive"], rtol=1e-12)
+    np.testing.assert_allclose(pf.compute_repulsive_potential(z["pf_q"], obs), z["pf_repulsive"], rtol=1e-12)
+    np.testing.assert_allclose(pf.compute_gradient(z["pf_q"], z["pf_goal"], obs), z["pf_gradient"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(pf.compute_gradient(z["pf_q"], z["pf_goal"], []), z["pf_gradient_free"], rtol=1e-12)
+    assert pf.compute_repulsive_potential(z["pf_q"], []) == 0
 
