@@ -10,8 +10,9 @@ mass matrix and an inverse-dynamics call per sample.  Inverse dynamics is affine
 
 which is what runs here — for a single sample or for a whole batch of (rows, n) samples in one launch.
 The reference's other model-based laws (PD / PID, PD + feed-forward, joint- and Cartesian-space PD, robust and adaptive
-control) are the same inverse-dynamics / FK / Jacobian calls plus host arithmetic and are mirrored below; the Kalman filter,
-the tuning helpers and the response metrics are single-sample host loops and stay out of scope.
+control, the Kalman filter on [q; qd]) are the same inverse- / forward-dynamics / FK / Jacobian calls plus host arithmetic and
+are mirrored below, with the step-response metrics and the Ziegler-Nichols gain formulas; the closed-loop gain sweep
+(`find_ultimate_gain_and_period`) and the response plot stay out of scope.
 """
 from __future__ import annotations
 
@@ -130,6 +131,107 @@ class ManipulatorController:
         self.parameter_estimate = self.parameter_estimate + gamma * np.asarray(measurement_error, dtype=np.float64).reshape(-1)
         return (self._id(q, np.asarray(dthetalist, dtype=np.float64), np.asarray(ddthetalist, dtype=np.float64), g, Ftip)
                 + self.parameter_estimate)
+
+    # ---- Kalman filter on the joint state [q; qd] (reference control/kalman.py): the prediction integrates forward dynamics
+    def kalman_filter_predict(self, thetalist, dthetalist, taulist, g, Ftip, dt, Q) -> None:
+        q, qd = np.asarray(thetalist, dtype=np.float64), np.asarray(dthetalist, dtype=np.float64)
+        Q = np.asarray(Q, dtype=np.float64)
+        x = getattr(self, "x_hat", None)
+        n2 = x.shape[0] if x is not None else 2 * len(q)
+        if Q.shape != (n2, n2):
+            raise ValueError(f"Q must have shape ({n2}, {n2}), got {Q.shape}")
+        if x is None:
+            x = np.concatenate((q, qd))
+        n = len(q)
+        qdd = np.asarray(self.dynamics.forward_dynamics(x[:n], x[n:], np.asarray(taulist, dtype=np.float64), g, Ftip))
+        x_pred = np.concatenate((x[:n] + x[n:] * dt, qdd * dt + x[n:]))
+        P = getattr(self, "P", None)
+        if P is None:
+            P = np.eye(len(x_pred))
+        self.P = P + Q  # F = I
+        self.x_hat = x_pred
+
+    def kalman_filter_update(self, z, R) -> None:
+        x = getattr(self, "x_hat", None)
+        if x is None:
+            raise ValueError("kalman_filter_update called before kalman_filter_predict; x_hat has not been initialized")
+        n = x.shape[0]
+        P = getattr(self, "P", None)
+        if P is None or getattr(P, "shape", None) != (n, n):
+            raise ValueError(f"P must be initialized with shape ({n}, {n}) before update; got {None if P is None else P.shape}")
+        z, R = np.asarray(z, dtype=np.float64), np.asarray(R, dtype=np.float64)
+        if z.shape != (n,):
+            raise ValueError(f"z must have shape ({n},) to match x_hat, got {z.shape}")
+        if R.shape != (n, n):
+            raise ValueError(f"R must have shape ({n}, {n}), got {R.shape}")
+        K = P @ np.linalg.inv(P + R)  # H = I
+        self.x_hat = x + K @ (z - x)
+        self.P = (np.eye(n) - K) @ P
+
+    def kalman_filter_control(self, thetalistd, dthetalistd, thetalist, dthetalist, taulist, g, Ftip, dt, Q, R):
+        """One predict + update cycle on the measured state; returns the filtered (q, qd) (reference control/kalman.py:131-170)."""
+        q, qd = np.asarray(thetalist, dtype=np.float64), np.asarray(dthetalist, dtype=np.float64)
+        self.kalman_filter_predict(q, qd, taulist, g, Ftip, dt, Q)
+        self.kalman_filter_update(np.concatenate((q, qd)), R)
+        return self.x_hat[:len(q)], self.x_hat[len(q):]
+
+    # ---- step-response metrics and Ziegler-Nichols gains (reference control/metrics.py; plotting and the gain sweep stay out)
+    @staticmethod
+    def calculate_rise_time(time, response, set_point: float) -> float:
+        """Time between the first samples at or above 10 % and 90 % of the set point; inf if either is never reached."""
+        time, response = np.asarray(time), np.asarray(response)
+        lo, hi = response >= 0.1 * set_point, response >= 0.9 * set_point
+        if not lo.any() or not hi.any():
+            return float("inf")
+        return float(time[int(np.argmax(hi))] - time[int(np.argmax(lo))])
+
+    @staticmethod
+    def calculate_percent_overshoot(response, set_point: float) -> float:
+        if set_point == 0:
+            return 0.0
+        return float((np.amax(np.asarray(response)) - set_point) / set_point * 100)
+
+    @staticmethod
+    def calculate_settling_time(time, response, set_point: float, tolerance: float = 0.02) -> float:
+        """First time after which the response stays inside |set_point| * tolerance of the set point; inf if it never does."""
+        time, response = np.asarray(time), np.asarray(response)
+        inside = np.abs(response - set_point) <= abs(set_point) * tolerance
+        if not inside.any():
+            return float("inf")
+        outside = np.flatnonzero(~inside)
+        last = int(outside[-1]) if outside.size else -1
+        if last == len(inside) - 1:
+            return float("inf")
+        return float(time[last + 1])
+
+    @staticmethod
+    def calculate_steady_state_error(response, set_point: float) -> float:
+        return float(np.asarray(response)[-1] - set_point)
+
+    @staticmethod
+    def ziegler_nichols_tuning(Ku, Tu, kind: str = "PID"):
+        """(Kp, Ki, Kd) from the ultimate gain / period: P 0.5 Ku; PI 0.45 Ku, 1.2 Ku / Tu; PID 0.6 Ku, 2 Kp / Tu, Kp Tu / 8."""
+        Ku = np.asarray(Ku, dtype=float)
+        kind = kind.upper()
+        if kind == "P":
+            Kp, Ki, Kd = 0.50 * Ku, 0.0 * Ku, 0.0 * Ku
+        else:
+            Tu = np.asarray(Tu, dtype=float)
+            if not np.all(np.isfinite(Tu)) or np.any(Tu <= 0):
+                raise ValueError(f"Tu (ultimate period) must be positive and finite, got Tu={Tu!r}.")
+            if kind == "PI":
+                Kp, Ki, Kd = 0.45 * Ku, 1.2 * Ku / Tu, 0.0 * Ku
+            elif kind == "PID":
+                Kp = 0.60 * Ku
+                Ki, Kd = 2.0 * Kp / Tu, 0.125 * Kp * Tu
+            else:
+                raise ValueError("kind must be 'P', 'PI' or 'PID'")
+        if Ku.size == 1:
+            return float(Kp), float(Ki), float(Kd)
+        return Kp, Ki, Kd
+
+    def tune_controller(self, Ku, Tu, kind: str = "PID"):
+        return self.ziegler_nichols_tuning(Ku, Tu, kind)
 
     def _id(self, q, qd, qdd, g, Ftip):
         single = q.ndim == 1

@@ -422,6 +422,24 @@ def dump_control():
     d["ctc_1"] = np.asarray(c3.computed_torque_control(st["qd_des"], st["dq_des"], st["ddq_des"], st["q"], st["dq"], G_VEC, 0.01, st["Kp"], st["Ki"], st["Kd"]))
     d["ctc_2"] = np.asarray(c3.computed_torque_control(st["qd_des"], st["dq_des"], st["ddq_des"], st["q"], st["dq"], G_VEC, 0.01, st["Kp"], st["Ki"], st["Kd"]))
     d["ff"] = np.asarray(c3.feedforward_control(st["qd_des"], st["dq_des"], st["ddq_des"], G_VEC, FTIP_REF))
+    # Kalman filter (control/kalman.py) and response metrics / Ziegler-Nichols (control/metrics.py)
+    ck = ManipulatorController(dyn)
+    Qn, Rn = np.eye(12) * 1e-3, np.eye(12) * 1e-2
+    tau_k = u(-5, 5)
+    kal = []
+    for step in range(3):
+        qf, dqf = ck.kalman_filter_control(st["qd_des"], st["dq_des"], st["q"] + 0.01 * step, st["dq"], tau_k, G_VEC, FTIP_REF, 0.01, Qn, Rn)
+        kal.append(np.concatenate((np.asarray(qf), np.asarray(dqf))))
+    d["kalman_tau"], d["kalman_x"], d["kalman_P"] = tau_k, np.stack(kal), np.asarray(ck.P)
+    tt_ = np.linspace(0, 5, 251)
+    resp = 1.0 - np.exp(-1.2 * tt_) * np.cos(4.0 * tt_)
+    d["metric_t"], d["metric_y"] = tt_, resp
+    d["metric_values"] = np.array([c.calculate_rise_time(tt_, resp, 1.0), c.calculate_percent_overshoot(resp, 1.0),
+                                   c.calculate_settling_time(tt_, resp, 1.0), c.calculate_settling_time(tt_, resp, 1.0, 0.2),
+                                   c.calculate_steady_state_error(resp, 1.0), c.calculate_rise_time(tt_, resp, 5.0),
+                                   c.calculate_settling_time(tt_, resp * 0 + 3, 1.0)])
+    d["zn"] = np.array([list(c.ziegler_nichols_tuning(8.0, 0.5, k)) for k in ("P", "PI", "PID")])
+    d["zn_vec"] = np.stack([np.asarray(x) for x in c.ziegler_nichols_tuning(np.array([8.0, 4.0]), np.array([0.5, 0.25]), "PID")])
     # small kinematics helpers of SerialManipulator (kinematics/fk.py:88-104, kinematics/velocity.py:65-89)
     qs = rng.uniform(-2, 2, (6, n))
     Vs = rng.uniform(-1, 1, (6, 6))

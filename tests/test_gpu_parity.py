@@ -1164,6 +1164,24 @@ def test_controller_laws_against_reference_runs():
             np.testing.assert_allclose(cb[r], c.cartesian_space_control(X[r], Q[r], dQ[r], i("Kp33"), i("Kd33")), rtol=1e-12, atol=1e-12)
         with pytest.raises(ValueError):
             c.adaptive_control(Q, dQ, ddQ, g, F, i("merr"), 0.7)
+        # Kalman filter on [q; qd] (prediction = forward dynamics on the GPU), three consecutive cycles; metrics; Z-N gains
+        ck = mp.ManipulatorController(dyn)
+        for step in range(3):
+            qf, dqf = ck.kalman_filter_control(i("qd_des"), i("dq_des"), i("q") + 0.01 * step, i("dq"), z["kalman_tau"], g, F, 0.01,
+                                               np.eye(12) * 1e-3, np.eye(12) * 1e-2)
+            np.testing.assert_allclose(np.concatenate((qf, dqf)), z["kalman_x"][step], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(ck.P, z["kalman_P"], rtol=1e-10, atol=1e-12)
+        with pytest.raises(ValueError):
+            mp.ManipulatorController(dyn).kalman_filter_update(np.zeros(12), np.eye(12))
+        t_, y_ = z["metric_t"], z["metric_y"]
+        got = [c.calculate_rise_time(t_, y_, 1.0), c.calculate_percent_overshoot(y_, 1.0), c.calculate_settling_time(t_, y_, 1.0),
+               c.calculate_settling_time(t_, y_, 1.0, 0.2), c.calculate_steady_state_error(y_, 1.0), c.calculate_rise_time(t_, y_, 5.0),
+               c.calculate_settling_time(t_, y_ * 0 + 3, 1.0)]
+        np.testing.assert_allclose(got, z["metric_values"], rtol=1e-12)
+        np.testing.assert_allclose([list(c.ziegler_nichols_tuning(8.0, 0.5, k)) for k in ("P", "PI", "PID")], z["zn"], rtol=1e-12)
+        np.testing.assert_allclose(np.stack(c.tune_controller(np.array([8.0, 4.0]), np.array([0.5, 0.25]), "PID")), z["zn_vec"], rtol=1e-12)
+        with pytest.raises(ValueError):
+            c.ziegler_nichols_tuning(1.0, 0.0, "PID")
         # the small kinematics helpers: pose as [p; ZYX Euler], joint velocity through pinv(J); batch == per sample
         sm, _, _ = mp.load_robot("ur5")
         np.testing.assert_allclose(sm.end_effector_pose(z["kin_q"]), z["kin_pose"], rtol=1e-9, atol=1e-9)
