@@ -94,6 +94,9 @@ __device__ __forceinline__ void mp_body_id(const MT& M, const MpCall<T>& C, cons
   mp_rnea<T, N, HAS_FTIP>(M, C, js, b, c, t);
 #pragma unroll
   for (int j = 0; j < N; ++j) t[j] = mp_clip(t[j], M.taumin[j], M.taumax[j]);
+  MpBad<T> bad;  // a NaN / inf anywhere in the row's inputs -> a NaN row, as the reference returns (mp_core.h)
+  bad.add(a); bad.add(b); bad.add(c);
+  mp_poison_if(bad.any(), t);
   RunIO<T, N>::store(tau, r, t);
 }
 
@@ -107,6 +110,9 @@ __device__ __forceinline__ void mp_body_fd(const MT& M, const MpCall<T>& C, cons
   RunIO<T, N>::load(tau, r, t);
   const T tn[3] = {C.F1n[0], C.F1n[1], C.F1n[2]}, tf[3] = {C.F1f[0], C.F1f[1], C.F1f[2]};
   mp_forward_dynamics<T, N, HAS_FTIP>(M, C.a0, tn, tf, a, b, t, out);
+  MpBad<T> bad;
+  bad.add(a); bad.add(b); bad.add(t);
+  mp_poison_if(bad.any(), out);
   RunIO<T, N>::store(qdd, r, out);
 }
 
@@ -233,9 +239,13 @@ __device__ __forceinline__ void mp_body_fk_jac_id(const MT& M, const MpCall<T>& 
   RunIO<T, N>::load(q, rr, a);
   MpJointState<T, N> js;
   mp_joint_state<T, N>(M, a, js);
+  MpBad<T> bad;
+  bad.add(a);
   if (Tout != nullptr || Jout != nullptr) {
     T TT[16], JJ[6 * N];
     mp_fk_jac<T, N, true>(M, js, TT, JJ);
+    mp_poison_if(bad.any(), TT);
+    mp_poison_if(bad.any(), JJ);
     if (Tout != nullptr) mp_wave_store_auto<T, 16>(Tout, row0, lane, nvalid, TT, lds);
     if (Jout != nullptr) mp_wave_store_auto<T, 6 * N>(Jout, row0, lane, nvalid, JJ, lds);
   }
@@ -246,6 +256,8 @@ __device__ __forceinline__ void mp_body_fk_jac_id(const MT& M, const MpCall<T>& 
     mp_rnea<T, N, HAS_FTIP>(M, C, js, b, c, t);
 #pragma unroll
     for (int j = 0; j < N; ++j) t[j] = mp_clip(t[j], M.taumin[j], M.taumax[j]);
+    bad.add(b); bad.add(c);
+    mp_poison_if(bad.any(), t);
     if (valid) RunIO<T, N>::store(tau, r, t);
   }
 }
@@ -259,10 +271,15 @@ __device__ __forceinline__ void load_pair(const float* __restrict__ base, long p
   for (int j = 0; j < N; ++j) v[j] = (mp_f2){f[j], f[N + j]};
 }
 template <int N>
-__device__ __forceinline__ void store_pair(float* __restrict__ base, long pair, const mp_f2 (&v)[N]) {
+__device__ __forceinline__ void store_pair(float* __restrict__ base, long pair, const mp_f2 (&v)[N], const MpBad<mp_f2>& bad) {
   float f[2 * N];
+  const bool bx = bad.x.any(), by = bad.y.any();
 #pragma unroll
-  for (int j = 0; j < N; ++j) { f[j] = v[j].x; f[N + j] = v[j].y; }
+  for (int j = 0; j < N; ++j) {
+    f[j] = v[j].x; f[N + j] = v[j].y;
+    mp_poison_if(bx, f[j]);
+    mp_poison_if(by, f[N + j]);
+  }
   RunIO<float, 2 * N>::store(base, pair, f);
 }
 
@@ -279,9 +296,11 @@ __device__ __forceinline__ void mp_body_id_pk(const MT& M, const MpCall<float>& 
   MpJointState<mp_f2, N> js;
   mp_joint_state<mp_f2, N>(M, a, js);
   mp_rnea<mp_f2, N, HAS_FTIP>(M, C, js, b, c, t);
+  MpBad<mp_f2> bad;
+  bad.add(a); bad.add(b); bad.add(c);
 #pragma unroll
   for (int j = 0; j < N; ++j) t[j] = mp_clip(t[j], M.taumin[j], M.taumax[j]);
-  store_pair<N>(tau, p, t);
+  store_pair<N>(tau, p, t, bad);
 }
 
 // The same for the rows `p` and `p + stride` (instead of the adjacent 2p, 2p+1): each half of the batch is then read
@@ -304,12 +323,16 @@ __device__ __forceinline__ void mp_body_id_pk_split(const MT& M, const MpCall<fl
   MpJointState<mp_f2, N> js;
   mp_joint_state<mp_f2, N>(M, v[0], js);
   mp_rnea<mp_f2, N, HAS_FTIP>(M, C, js, v[1], v[2], t);
+  MpBad<mp_f2> bad;
+  bad.add(v[0]); bad.add(v[1]); bad.add(v[2]);
   float lo[N], hi[N];
 #pragma unroll
   for (int j = 0; j < N; ++j) {
     const mp_f2 c = mp_clip(t[j], M.taumin[j], M.taumax[j]);
     lo[j] = c.x; hi[j] = c.y;
   }
+  mp_poison_if(bad.x.any(), lo);
+  mp_poison_if(bad.y.any(), hi);
   RunIO<float, N>::store(tau, p, lo);
   RunIO<float, N>::store(tau, p + stride, hi);
 }
@@ -332,9 +355,11 @@ __device__ __forceinline__ void mp_body_traj_id_pk(const MT& M, const MpCall<flo
   MpJointState<mp_f2, N> js;
   mp_joint_state<mp_f2, N>(M, qq, js);
   mp_rnea<mp_f2, N, HAS_FTIP>(M, C, js, qd, qdd, tq);
+  MpBad<mp_f2> bad;  // a non-finite end point makes the generated row non-finite
+  bad.add(qq); bad.add(qd); bad.add(qdd);
 #pragma unroll
   for (int j = 0; j < N; ++j) tq[j] = mp_clip(tq[j], M.taumin[j], M.taumax[j]);
-  store_pair<N>(tau, p, tq);
+  store_pair<N>(tau, p, tq, bad);
 }
 
 // The same with the time scaling taken from a per-call table (s, s', s'' per timestep, three doubles each, written by
@@ -363,12 +388,16 @@ __device__ __forceinline__ void mp_body_traj_id_pk_tab(const MT& M, const MpCall
   MpJointState<mp_f2, N> js;
   mp_joint_state<mp_f2, N>(M, qq, js);
   mp_rnea<mp_f2, N, HAS_FTIP>(M, C, js, qd, qdd, tq);
+  MpBad<mp_f2> bad;  // a non-finite end point makes the generated row non-finite
+  bad.add(qq); bad.add(qd); bad.add(qdd);
   float lo[N], hi[N];
 #pragma unroll
   for (int j = 0; j < N; ++j) {
     const mp_f2 c = mp_clip(tq[j], M.taumin[j], M.taumax[j]);
     lo[j] = c.x; hi[j] = c.y;
   }
+  mp_poison_if(bad.x.any(), lo);
+  mp_poison_if(bad.y.any(), hi);
   RunIO<float, N>::store(tau, b * Nt + t0, lo);
   if (valid1) RunIO<float, N>::store(tau, b * Nt + t1, hi);
 }
@@ -486,6 +515,11 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
   T q[N], qd[N];
   RunIO<T, N>::load(theta0, b, q);
   RunIO<T, N>::load(dtheta0, b, qd);
+  // Sticky non-finite verdict (running maxima of the bit patterns, mp_core.h): the initial state, every torque / wrench
+  // row consumed and the integrated velocity feed it; from the first step at which it trips, the trajectory's rows are
+  // NaN, as in the reference, whose state stays non-finite once it is (row 0 is the initial state as given).
+  MpBad<T> bad;
+  bad.add(q); bad.add(qd);
   // 16-byte vector accesses need every lane's run to start on a 16-byte boundary (wave-uniform tests)
   const bool vec_tau = ((Nt * N * (long)sizeof(T)) & 15) == 0, vec_out = ((Nt * N * 4) & 15) == 0;
   const bool vec_f = ((Nt * 6 * (long)sizeof(T)) & 15) == 0;
@@ -513,10 +547,12 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
         T tau[N], tn[3] = {T(0), T(0), T(0)}, tf[3] = {T(0), T(0), T(0)};
 #pragma unroll
         for (int j = 0; j < N; ++j) tau[j] = mp_fd_tile_get<T, TW, 64>(cs, TL::TAU0 + j, N);
+        bad.add(tau);
         if (HAS_FTIP) {
           T F[6];
 #pragma unroll
           for (int k = 0; k < 6; ++k) F[k] = mp_fd_tile_get<T, TW, 64>(cs, TL::F0 + k, 6);
+          bad.add(F);
           mp_wrench_to_frame1(M, F, tn, tf);
         }
         for (int k = 0; k < intRes; ++k) {
@@ -527,12 +563,14 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
             q[j] = mp_clip(q[j] + qd[j] * h, M.qmin[j], M.qmax[j]);
           }
         }
+        bad.add(qd);
       }
+      const bool poison = (i0 + s > 0) && bad.any();
 #pragma unroll
       for (int j = 0; j < N; ++j) {
-        cs[j * 64] = __builtin_bit_cast(unsigned, (float)q[j]);
-        cs[(N + j) * 64] = __builtin_bit_cast(unsigned, (float)qd[j]);
-        cs[(2 * N + j) * 64] = __builtin_bit_cast(unsigned, (float)last[j]);
+        cs[j * 64] = poison ? 0x7fc00000u : __builtin_bit_cast(unsigned, (float)q[j]);
+        cs[(N + j) * 64] = poison ? 0x7fc00000u : __builtin_bit_cast(unsigned, (float)qd[j]);
+        cs[(2 * N + j) * 64] = poison ? 0x7fc00000u : __builtin_bit_cast(unsigned, (float)last[j]);
       }
     }
     if (full && vec_out) {
@@ -575,6 +613,8 @@ __device__ __forceinline__ void mp_body_fd_traj_pk(const MT& M, const MpCall<flo
 #pragma unroll
     for (int j = 0; j < N; ++j) qd[j] = (mp_f2){a[j], b[j]};
   }
+  MpBad<mp_f2> bad;  // sticky non-finite verdict per trajectory, see mp_body_fd_traj
+  bad.add(q); bad.add(qd);
   const bool vec_tau = ((Nt * N * 4) & 15) == 0, vec_f = ((Nt * 6 * 4) & 15) == 0;
   const mp_f2 hh = (mp_f2){h, h};
   for (long i0 = 0; i0 < Nt; i0 += MP_FD_KS) {
@@ -617,11 +657,13 @@ __device__ __forceinline__ void mp_body_fd_traj_pk(const MT& M, const MpCall<flo
 #pragma unroll
         for (int j = 0; j < N; ++j)
           tau[j] = (mp_f2){__builtin_bit_cast(float, c0[(TL::TAU0 + j) * W]), __builtin_bit_cast(float, c1[(TL::TAU0 + j) * W])};
+        bad.add(tau);
         if (HAS_FTIP) {
           mp_f2 F[6];
 #pragma unroll
           for (int k = 0; k < 6; ++k)
             F[k] = (mp_f2){__builtin_bit_cast(float, c0[(TL::F0 + k) * W]), __builtin_bit_cast(float, c1[(TL::F0 + k) * W])};
+          bad.add(F);
           mp_wrench_to_frame1(M, F, tn, tf);
         }
         for (int k = 0; k < intRes; ++k) {
@@ -632,17 +674,19 @@ __device__ __forceinline__ void mp_body_fd_traj_pk(const MT& M, const MpCall<flo
             q[j] = mp_clip(q[j] + qd[j] * hh, M.qmin[j], M.qmax[j]);
           }
         }
+        bad.add(qd);
       }
+      const bool px = (i0 + s > 0) && bad.x.any(), py = (i0 + s > 0) && bad.y.any();
 #pragma unroll
       for (int j = 0; j < N; ++j) {
         // element copies first: __builtin_bit_cast applied directly to a vector-element lvalue (v.y) reads element 0
         const float qx = q[j].x, qy = q[j].y, vx = qd[j].x, vy = qd[j].y, ax = last[j].x, ay = last[j].y;
-        c0[j * W] = __builtin_bit_cast(unsigned, qx);
-        c1[j * W] = __builtin_bit_cast(unsigned, qy);
-        c0[(N + j) * W] = __builtin_bit_cast(unsigned, vx);
-        c1[(N + j) * W] = __builtin_bit_cast(unsigned, vy);
-        c0[(2 * N + j) * W] = __builtin_bit_cast(unsigned, ax);
-        c1[(2 * N + j) * W] = __builtin_bit_cast(unsigned, ay);
+        c0[j * W] = px ? 0x7fc00000u : __builtin_bit_cast(unsigned, qx);
+        c1[j * W] = py ? 0x7fc00000u : __builtin_bit_cast(unsigned, qy);
+        c0[(N + j) * W] = px ? 0x7fc00000u : __builtin_bit_cast(unsigned, vx);
+        c1[(N + j) * W] = py ? 0x7fc00000u : __builtin_bit_cast(unsigned, vy);
+        c0[(2 * N + j) * W] = px ? 0x7fc00000u : __builtin_bit_cast(unsigned, ax);
+        c1[(2 * N + j) * W] = py ? 0x7fc00000u : __builtin_bit_cast(unsigned, ay);
       }
     }
     if (full && vec_tau) {

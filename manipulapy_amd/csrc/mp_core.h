@@ -149,6 +149,61 @@ MP_HD T mp_clip(T v, typename MpTraits<T>::S lo, typename MpTraits<T>::S hi) {
   return mp_min(mp_max(v, MpTraits<T>::splat(lo)), MpTraits<T>::splat(hi));
 }
 
+// ------------------------------------------------------------------------------ non-finite inputs
+// The reference hands back a non-finite row wherever a row's inputs hold a NaN or an infinity (NumPy raises nothing, so
+// its try / except never fires; tests/golden/nonfinite.npz) and leaves every other row alone.  The robot-specialised
+// kernels are compiled with -ffinite-math-only (that is what lets `x * 0` fold away, mp_jit.cpp), under which
+// floating-point arithmetic may launder a NaN and a floating-point NaN test folds to false - so the guard works on the
+// BIT PATTERNS with integer instructions, and the row is poisoned with integer selects on its way to memory.
+// A value is non-finite iff its exponent field is all ones: for the raw (high) word b that is  b >= POS as a signed
+// integer (positive values) or b >= NEG as an unsigned one (negative values) - two running maxima, which the compiler
+// folds into v_max3_i32 / v_max3_u32: one instruction per value checked.
+MP_HD int mp_hi_word(float x) { return __builtin_bit_cast(int, x); }
+MP_HD int mp_hi_word(double x) { return (int)(__builtin_bit_cast(long long, x) >> 32); }
+template <typename T> struct MpBadBits;
+template <> struct MpBadBits<float> { static constexpr int POS = 0x7f800000; static constexpr unsigned NEG = 0xff800000u; };
+template <> struct MpBadBits<double> { static constexpr int POS = 0x7ff00000; static constexpr unsigned NEG = 0xfff00000u; };
+
+template <typename T>
+struct MpBad {  // T = float / double
+  int ms = 0;
+  unsigned mu = 0;
+  MP_HD void add(T v) {
+    const int b = mp_hi_word(v);
+    ms = b > ms ? b : ms;
+    mu = (unsigned)b > mu ? (unsigned)b : mu;
+  }
+  template <int N> MP_HD void add(const T (&v)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) add(v[i]);
+  }
+  MP_HD bool any() const { return ms >= MpBadBits<T>::POS || mu >= MpBadBits<T>::NEG; }
+};
+MP_HD void mp_poison_if(bool bad, float& v) {
+  const unsigned b = __builtin_bit_cast(unsigned, v);
+  v = __builtin_bit_cast(float, bad ? 0x7fc00000u : b);
+}
+MP_HD void mp_poison_if(bool bad, double& v) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+  v = __builtin_bit_cast(double, bad ? 0x7ff8000000000000ull : b);
+}
+#if MP_HAS_PACKED
+template <>
+struct MpBad<mp_f2> {  // one verdict per packed row
+  MpBad<float> x, y;
+  MP_HD void add(mp_f2 v) { x.add(v.x); y.add(v.y); }
+  template <int N> MP_HD void add(const mp_f2 (&v)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) add(v[i]);
+  }
+};
+#endif
+template <typename T, int N>
+MP_HD void mp_poison_if(bool bad, T (&v)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) mp_poison_if(bad, v[i]);
+}
+
 // ------------------------------------------------------------------------------ axis-aligned steps
 // Motion vector (w, v), parent -> child coordinates, child pose in parent = (E, r):
 //     w' = E^T w,  v' = E^T (v + w x r).

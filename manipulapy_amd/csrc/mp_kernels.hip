@@ -68,6 +68,9 @@ __global__ __launch_bounds__(kBlock) void k_traj_id(const MpModel<float> M, cons
   mp_rnea<float, N, HAS_FTIP>(M, C, js, v, a, tq);
 #pragma unroll
   for (int j = 0; j < N; ++j) tq[j] = mp_clip(tq[j], M.taumin[j], M.taumax[j]);
+  MpBad<float> bad;
+  bad.add(p); bad.add(v); bad.add(a);
+  mp_poison_if(bad.any(), tq);
   RunIO<float, N>::store(tau, r, tq);
 }
 
@@ -120,9 +123,11 @@ __global__ __launch_bounds__(kBlock, MP_PK_MINW) void k_id_pk_persist(const MpMo
     MpJointState<mp_f2, N> js;
     mp_joint_state<mp_f2, N>(*Mc, a, js);
     mp_rnea<mp_f2, N, HAS_FTIP>(*Mc, C, js, b, c, t);
+    MpBad<mp_f2> bad;
+    bad.add(a); bad.add(b); bad.add(c);
 #pragma unroll
     for (int j = 0; j < N; ++j) t[j] = mp_clip(t[j], Mc->taumin[j], Mc->taumax[j]);
-    store_pair<N>(tau, p, t);
+    store_pair<N>(tau, p, t, bad);
     if (!more) break;
     p = pn;
   }
@@ -197,6 +202,9 @@ __global__ __launch_bounds__(kFkBlock) void k_mass_matrix(const MpModel<T> M, co
   for (int i = 0; i < N; ++i)
 #pragma unroll
     for (int j = 0; j < N; ++j) flat[i * N + j] = Mq[i][j];
+  MpBad<T> bad;
+  bad.add(a);
+  mp_poison_if(bad.any(), flat);
   mp_wave_store_auto<T, N * N>(Mout, row0, lane, nvalid, flat, lds);
 }
 

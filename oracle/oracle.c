@@ -214,3 +214,123 @@ int oracle_mass_matrix_rows(int n, const double* S, const double* Mcom, const do
   for (long r = 0; r < rows; ++r) mass_matrix_gravity(n, S, Mcom, G, M_ee, q + r * n, g0, M + r * n * n, 0);
   return 0;
 }
+
+/* np.linalg.solve (LAPACK dgesv: LU with partial pivoting), as dynamics/id_fd.py:82 calls it */
+static int lu_solve(int n, double* A /*n x n, destroyed*/, double* b /*n, in: rhs, out: x*/) {
+  for (int k = 0; k < n; ++k) {
+    int p = k;
+    double best = fabs(A[k * n + k]);
+    for (int i = k + 1; i < n; ++i)
+      if (fabs(A[i * n + k]) > best) { best = fabs(A[i * n + k]); p = i; }
+    if (best == 0.0) return -1;
+    if (p != k) {
+      for (int j = 0; j < n; ++j) { const double t = A[k * n + j]; A[k * n + j] = A[p * n + j]; A[p * n + j] = t; }
+      const double t = b[k]; b[k] = b[p]; b[p] = t;
+    }
+    for (int i = k + 1; i < n; ++i) {
+      const double f = A[i * n + k] / A[k * n + k];
+      A[i * n + k] = f;
+      for (int j = k + 1; j < n; ++j) A[i * n + j] -= f * A[k * n + j];
+      b[i] -= f * b[k];
+    }
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    double s = b[i];
+    for (int j = i + 1; j < n; ++j) s -= A[i * n + j] * b[j];
+    b[i] = s / A[i * n + i];
+  }
+  return 0;
+}
+
+/* dynamics/id_fd.py:71-83 — qdd = solve(M, tau - c - g - Js^T Ftip).  c + g + Js^T Ftip is the inverse
+ * dynamics at zero acceleration (id_fd.py:37-48 with ddtheta = 0), M comes from the same mass_matrix. */
+static int forward_dynamics_row(int n, const double* S, const double* Mcom, const double* G, const double* M_ee,
+                                const double* th, const double* dth, const double* tau, const double* g, const double* F,
+                                double* qdd) {
+  double M[MAXN * MAXN], bias[MAXN], zero[MAXN] = {0};
+  const double g0[3] = {0, 0, 0};
+  inverse_dynamics_row(n, S, Mcom, G, M_ee, th, dth, zero, g, F, bias);
+  mass_matrix_gravity(n, S, Mcom, G, M_ee, th, g0, M, 0);
+  for (int i = 0; i < n; ++i) qdd[i] = tau[i] - bias[i];
+  return lu_solve(n, M, qdd);
+}
+
+int oracle_forward_dynamics_rows(int n, const double* S, const double* Mcom, const double* G, const double* M_ee,
+                                 const double* q, const double* qd, const double* tau, const double* g, const double* Ftip,
+                                 long rows, double* qdd) {
+  if (n < 1 || n > MAXN) return -1;
+  for (long r = 0; r < rows; ++r)
+    if (forward_dynamics_row(n, S, Mcom, G, M_ee, q + r * n, qd + r * n, tau + r * n, g, Ftip, qdd + r * n)) return -2;
+  return 0;
+}
+
+/* planning/trajectory_dynamics.py:580-708 — B independent roll-outs (the reference integrates one; the batch is a
+ * loop over them): semi-implicit Euler, intRes sub-steps of dt / intRes, q clipped to the float32 joint limits after
+ * every sub-step, row 0 = initial state with zero acceleration, taumat[i] / Ftipmat[i] drive step i, rows stored
+ * float32, the recorded acceleration is the last sub-step's.
+ * state_f32 = 0: the state is float64 (what the reference does with float64 inputs — THE parity oracle, SURVEY
+ *   §0.5d); state_f32 = 1: the state is rounded to float32 after every update exactly as NumPy types it with
+ *   float32 inputs (dtheta: float64 sum cast back; theta: float32 product and sum), while the dynamics are still
+ *   evaluated in float64 — a diagnostic that separates state rounding from arithmetic error (the reference itself
+ *   would do its trigonometry and the 1e-6 finite difference in float32 there, which is numerically meaningless).
+ * lim: (n, 2) float64 holding float32-representable limits.  Ftipmat may be NULL (zero wrench).
+ * OpenMP over trajectories.  Returns threads used, < 0 on error. */
+int oracle_fd_trajectory(int n, const double* S, const double* Mcom, const double* G, const double* M_ee, const double* lim,
+                         const double* theta0, const double* dtheta0, const double* taumat, const double* g,
+                         const double* Ftipmat, long B, long Nt, double dt, int intRes, int state_f32, float* pos, float* vel,
+                         float* acc, int nthreads) {
+  if (n < 1 || n > MAXN || Nt < 1 || intRes < 1) return -1;
+  int used = 1, fail = 0;
+  const double h = dt / intRes;
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel
+  {
+#pragma omp single
+    used = omp_get_num_threads();
+#pragma omp for schedule(dynamic, 1)
+#endif
+    for (long b = 0; b < B; ++b) {
+      double q[MAXN], qd[MAXN], qdd[MAXN], F0[6] = {0};
+      for (int j = 0; j < n; ++j) {
+        q[j] = state_f32 ? (double)(float)theta0[b * n + j] : theta0[b * n + j];
+        qd[j] = state_f32 ? (double)(float)dtheta0[b * n + j] : dtheta0[b * n + j];
+        pos[(b * Nt) * n + j] = (float)q[j];
+        vel[(b * Nt) * n + j] = (float)qd[j];
+        acc[(b * Nt) * n + j] = 0.0f;
+      }
+      for (long i = 1; i < Nt; ++i) {
+        const double* tau = taumat + (b * Nt + i) * n;
+        const double* F = Ftipmat ? Ftipmat + (b * Nt + i) * 6 : F0;
+        for (int j = 0; j < n; ++j) qdd[j] = 0.0;
+        for (int k = 0; k < intRes; ++k) {
+          if (forward_dynamics_row(n, S, Mcom, G, M_ee, q, qd, tau, g, F, qdd)) { fail = 1; break; }
+          for (int j = 0; j < n; ++j) {
+            if (state_f32) {
+              const float v = (float)(qd[j] + qdd[j] * h);            /* float32 + float64 -> float64, cast back */
+              const float hf = (float)h;
+              volatile float prod = v * hf;                            /* float32 array * python float -> float32 */
+              float p = (float)q[j] + prod;
+              const float lo = (float)lim[2 * j], hi = (float)lim[2 * j + 1];
+              p = p < lo ? lo : (p > hi ? hi : p);
+              qd[j] = v; q[j] = p;
+            } else {
+              qd[j] = qd[j] + qdd[j] * h;
+              double p = q[j] + qd[j] * h;
+              p = p < lim[2 * j] ? lim[2 * j] : (p > lim[2 * j + 1] ? lim[2 * j + 1] : p);
+              q[j] = p;
+            }
+          }
+        }
+        for (int j = 0; j < n; ++j) {
+          pos[(b * Nt + i) * n + j] = (float)q[j];
+          vel[(b * Nt + i) * n + j] = (float)qd[j];
+          acc[(b * Nt + i) * n + j] = (float)qdd[j];
+        }
+      }
+    }
+#ifdef _OPENMP
+  }
+#endif
+  return fail ? -2 : used;
+}

@@ -612,3 +612,28 @@ def robust_inverse_kinematics(tab, T_desired, joint_limits, max_attempts=10, eom
         best_theta = ik_midpoint_of_limits(lim)
     return best_theta, False, total, winner, restarts
 
+
+# --------------------------------------------------------------------------- fused potential field
+def potential_field(positions, goal, obstacles, influence_distance):
+    """cuda_kernels/field_kernels.py:113-161 (`potential_field_cpu_fallback`) — attractive 0.5 |p - goal|^2 plus, for every
+    obstacle with 0 < d^2 < influence^2, 0.5 (1/d - 1/influence)^2; gradient (p - goal) - (1/d - 1/influence) / d^3 (p - obstacle).
+    float32 throughout, obstacles accumulated in order; a zero distance contributes nothing."""
+    pos = np.ascontiguousarray(positions, dtype=np.float32).reshape(-1, 3)
+    goal = np.ascontiguousarray(goal, dtype=np.float32).reshape(3)
+    obs = np.ascontiguousarray(obstacles, dtype=np.float32).reshape(-1, 3)
+    diff = pos - goal
+    pot = np.float32(0.5) * np.sum(diff * diff, axis=1)
+    grad = diff.copy()
+    inv_infl = np.float32(1.0 / influence_distance) if influence_distance > 0.0 else np.float32(0.0)
+    infl2 = np.float32(influence_distance * influence_distance)
+    for o in obs:
+        od = pos - o
+        d2 = np.sum(od * od, axis=1)
+        m = (d2 > 0.0) & (d2 < infl2)
+        if not m.any():
+            continue
+        inv = np.float32(1.0) / np.sqrt(d2[m])
+        term = inv - inv_infl
+        pot[m] += np.float32(0.5) * term * term
+        grad[m] += (-term * inv * inv * inv)[:, None] * od[m]
+    return pot.astype(np.float32), grad.astype(np.float32)

@@ -579,6 +579,116 @@ def time_reference():
         json.dump(res, f, indent=1)
 
 
+
+def rollout_workload(rng, sm, dyn, B, N, n):
+    """A roll-out that stays finite for a full second: torques that hold the start configuration against gravity plus a
+    small disturbance, small per-step wrenches.  (SURVEY §8d's c5 inputs - a free-falling arm with a 3 N / 0.75 N.m tip
+    wrench on a 8e-5 kg.m^2 wrist - overflow to inf within ~20 steps of dt = 0.01 in the reference itself.)"""
+    th0 = rng.uniform(-0.5, 0.5, (B, n))
+    dth0 = rng.uniform(-0.2, 0.2, (B, n))
+    hold = np.array([np.asarray(dyn.inverse_dynamics(th0[b], np.zeros(n), np.zeros(n), G_VEC, np.zeros(6))) for b in range(B)])
+    taumat = hold[:, None, :] + rng.uniform(-1, 1, (B, N, n)) * 0.001
+    Ftipmat = rng.uniform(-1, 1, (B, N, 6)) * 0.02
+    return th0, dth0, taumat, Ftipmat
+
+
+def dump_rollout100():
+    """forward_dynamics_trajectory at config c5's own horizon: xarm6, N = 100, dt = 0.01, intRes = 1, per-step wrench,
+    float64 inputs, 3 trajectories; plus one at dt = 0.001 / intRes = 2."""
+    from ManipulaPy.planning import OptimizedTrajectoryPlanning
+
+    proc, sm, dyn = build("xarm6")
+    n = sm.S_list.shape[1]
+    lims = finite_limits(sm, n)
+    planner = OptimizedTrajectoryPlanning(sm, get_robot_urdf("xarm6"), dyn, lims.tolist(), use_cuda=False)
+    rng = np.random.default_rng(SEED + 700)
+    B, N = 3, 100
+    th0, dth0, taumat, Ftipmat = rollout_workload(rng, sm, dyn, B, N, n)
+    d = {"joint_limits": lims, "theta0": th0, "dtheta0": dth0, "taumat": taumat, "Ftipmat": Ftipmat, "g": G_VEC,
+         "dt": np.float64(0.01), "intRes": np.int64(1)}
+    out = {k: [] for k in ("positions", "velocities", "accelerations")}
+    for b in range(B):
+        clear_caches(dyn)
+        r = planner.forward_dynamics_trajectory(th0[b], dth0[b], taumat[b], G_VEC, Ftipmat[b], 0.01, 1)
+        for k in out:
+            out[k].append(np.asarray(r[k]))
+        print("rollout100", b, float(np.abs(out["velocities"][-1]).max()), flush=True)
+    for k in out:
+        d[k] = np.stack(out[k])
+    clear_caches(dyn)
+    r = planner.forward_dynamics_trajectory(th0[0], dth0[0], taumat[0, :40], G_VEC, Ftipmat[0, :40], 0.001, 2)
+    for k in out:
+        d["fine_" + k] = np.asarray(r[k])
+    np.savez(os.path.join(HERE, "fd_rollout100_xarm6.npz"), **d)
+
+
+def dump_nonfinite():
+    """What the reference returns for rows that contain NaN / inf (planning/trajectory_dynamics.py:345-358 catches
+    exceptions only - NumPy raises none here, so such rows come back non-finite, not zero)."""
+    from ManipulaPy.planning import OptimizedTrajectoryPlanning
+
+    proc, sm, dyn = build("ur5")
+    n = sm.S_list.shape[1]
+    lims = finite_limits(sm, n)
+    planner = OptimizedTrajectoryPlanning(sm, get_robot_urdf("ur5"), dyn, lims.tolist(), use_cuda=False)
+    rng = np.random.default_rng(SEED + 800)
+    R = 12
+    q = rng.uniform(-1, 1, (R, n)); qd = rng.uniform(-1, 1, (R, n)); qdd = rng.uniform(-1, 1, (R, n))
+    q[1, 0] = np.nan; q[2, n - 1] = np.inf; qd[3, 2] = np.nan; qd[4, 0] = -np.inf; qdd[5, n - 1] = np.nan; qdd[6, 3] = np.inf
+    q[7, 3] = np.nan; qd[7, 1] = np.inf
+    clear_caches(dyn)
+    tau = np.asarray(planner.inverse_dynamics_trajectory(q, qd, qdd, G_VEC, FTIP_REF))
+    d = {"id_q": q, "id_qd": qd, "id_qdd": qdd, "id_ftip": FTIP_REF, "id_tau": tau, "joint_limits": lims}
+    print("nonfinite ID rows:", (~np.isfinite(tau)).all(axis=1).astype(int), (~np.isfinite(tau)).any(axis=1).astype(int))
+    # roll-out whose torque row 5 holds a NaN (xarm6): rows 0..4 finite, rows 5.. non-finite
+    proc, sm, dyn = build("xarm6")
+    n = sm.S_list.shape[1]
+    lims6 = finite_limits(sm, n)
+    planner = OptimizedTrajectoryPlanning(sm, get_robot_urdf("xarm6"), dyn, lims6.tolist(), use_cuda=False)
+    th0, dth0, taumat, Ftipmat = rollout_workload(rng, sm, dyn, 1, 10, n)
+    taumat[0, 5, 2] = np.nan
+    clear_caches(dyn)
+    r = planner.forward_dynamics_trajectory(th0[0], dth0[0], taumat[0], G_VEC, Ftipmat[0], 0.01, 1)
+    d.update(fd_joint_limits=lims6, fd_theta0=th0[0], fd_dtheta0=dth0[0], fd_taumat=taumat[0], fd_Ftipmat=Ftipmat[0],
+             fd_positions=np.asarray(r["positions"]), fd_velocities=np.asarray(r["velocities"]),
+             fd_accelerations=np.asarray(r["accelerations"]))
+    print("nonfinite FD rows (pos / vel / acc):", *[np.isfinite(np.asarray(r[k])).all(axis=1).astype(int) for k in ("positions", "velocities", "accelerations")])
+    np.savez(os.path.join(HERE, "nonfinite.npz"), **d)
+
+
+def dump_field():
+    """potential_field_cpu_fallback (cuda_kernels/field_kernels.py:113-161): 1200 points x 37 obstacles, including points
+    that coincide with an obstacle (zero distance: skipped), points on / outside the influence sphere, a point at the
+    goal, and the hand-checked case of tests/test_cuda_kernels_cpu.py:104-118."""
+    from ManipulaPy.cuda_kernels.field_kernels import potential_field_cpu_fallback
+
+    rng = np.random.default_rng(SEED + 900)
+    P, K = 1200, 37
+    obstacles = rng.uniform(-1.0, 1.0, (K, 3)).astype(np.float32)
+    goal = np.array([0.4, -0.3, 0.6], dtype=np.float32)
+    pos = rng.uniform(-1.2, 1.2, (P, 3)).astype(np.float32)
+    pos[:K] = obstacles                                   # zero distance to one obstacle each
+    pos[K] = goal                                         # at the goal
+    infl = 0.35
+    for i in range(20):                                   # exactly on / just inside / just outside the influence sphere
+        u = rng.normal(size=3); u /= np.linalg.norm(u)
+        pos[K + 1 + i] = (obstacles[i].astype(np.float64) + u * infl * (1.0, 1.0 - 1e-6, 1.0 + 1e-6, 0.999)[i % 4]).astype(np.float32)
+    for i in range(20):                                   # very close to an obstacle (large 1/d^3 factors)
+        u = rng.normal(size=3); u /= np.linalg.norm(u)
+        pos[K + 21 + i] = (obstacles[i].astype(np.float64) + u * (1e-3, 1e-2, 5e-2, 1e-4)[i % 4]).astype(np.float32)
+    d = {"positions": pos, "goal": goal, "obstacles": obstacles}
+    for tag, dist in (("d035", infl), ("d100", 1.0), ("d000", 0.0)):
+        pot, grad = potential_field_cpu_fallback(pos, goal, obstacles, dist)
+        d[f"{tag}_influence"] = np.float64(dist)
+        d[f"{tag}_potential"], d[f"{tag}_gradient"] = pot, grad
+    pot, grad = potential_field_cpu_fallback(pos, goal, np.zeros((0, 3), dtype=np.float32), 0.5)   # no obstacles
+    d["noobs_potential"], d["noobs_gradient"] = pot, grad
+    hp = np.array([[0.0, 0.0, 0.0], [2.0, 0.0, 0.0]], dtype=np.float32)
+    pot, grad = potential_field_cpu_fallback(hp, np.array([1.0, 0.0, 0.0], dtype=np.float32), np.array([[0.5, 0.0, 0.0]], dtype=np.float32), 1.0)
+    d["hand_positions"], d["hand_potential"], d["hand_gradient"] = hp, pot, grad
+    np.savez(os.path.join(HERE, "potential_field.npz"), **d)
+
+
 def main():
     assert os.environ.get("PYTHONHASHSEED") == "0"
     if "urdf" in sys.argv[1:]:  # only (re)generate the URDF skeletons
@@ -597,6 +707,11 @@ def main():
         dump_ik()
         print("ik dumped")
         return
+    for name, fn in (("rollout100", dump_rollout100), ("nonfinite", dump_nonfinite), ("field", dump_field)):
+        if name in sys.argv[1:]:
+            fn()
+            print(name, "dumped")
+            return
     if "cartesian" in sys.argv[1:]:  # only (re)generate the Cartesian-trajectory dump
         dump_cartesian()
         print("cartesian dumped")
@@ -612,6 +727,9 @@ def main():
     dump_control()
     dump_utils()
     dump_urdfs()
+    dump_rollout100()
+    dump_nonfinite()
+    dump_field()
     print("trajectories dumped", flush=True)
     time_reference()
     print("timings dumped")

@@ -2,6 +2,7 @@
 planner plumbing on the NumPy backend, the model compiler + device math (host instantiation) against
 the oracle, and the multi-process sharding logic over gloo.  No compute call reaches a GPU here."""
 import ctypes
+import json
 import os
 import re
 import subprocess
@@ -460,6 +461,26 @@ def test_two_process_gloo_shard_and_gather(tmp_path):
     z = np.load(out)
     np.testing.assert_array_equal(z["gathered"], z["single"])
     assert z["world"] == 2 and abs(float(z["max_val"]) - 1.0) < 1e-12
+
+
+def test_bench_self_launches_one_worker_per_gpu():
+    """`python bench.py --gpus 2` as ONE command (the way the driver starts the scaling runs): the launcher spawns two
+    fresh workers with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*, they meet over gloo, rank 0's JSON line is relayed and
+    the exit code is the workers'.  Dry run = everything up to the first HIP call (there is no GPU here)."""
+    env = dict(os.environ, PYTHONPATH=ROOT, MANIPULAPY_BENCH_DRYRUN="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = json.loads(res.stdout.strip().splitlines()[-1])
+    assert line["dryrun"] and line["n_gpus"] == 2 and line["max_rank_seen"] == 1.0 and line["broadcast_ok"]
+    # a worker that fails makes the launcher fail: without the dry-run flag the first HIP call raises on this box
+    if not os.path.exists("/dev/kfd"):
+        env.pop("MANIPULAPY_BENCH_DRYRUN")
+        res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                             capture_output=True, text=True, timeout=300)
+        assert res.returncode != 0
 
 
 @pytest.mark.parametrize("robot", ROBOTS)
