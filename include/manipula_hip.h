@@ -10,7 +10,8 @@
  * Conventions
  *   - every function returns int: 0 = MP_OK, otherwise an MP_ERR_* code; mp_last_error() returns
  *     the thread-local message of the last failure on the calling thread.  There is NO CPU fallback
- *     anywhere behind this ABI: without a usable GPU the compute calls fail with MP_ERR_HIP.
+ *     anywhere behind this ABI: without a usable GPU the compute calls that take an mp_ctx fail with MP_ERR_HIP
+ *     (the *_cpu twins at the end are separate entry points a caller selects explicitly).
  *   - arrays are C-contiguous (row-major), exactly the shapes the reference's Python API uses;
  *     "d_" parameters are device pointers obtained from mp_malloc (16-byte aligned), "h_" or
  *     unprefixed pointers are host memory owned by the caller.
@@ -60,6 +61,16 @@ int mp_ctx_properties(mp_ctx* ctx, char* name, size_t name_len, int* compute_uni
  * Replaces the reference's device self-test kernel, cuda_kernels/_runtime.py:127-138. */
 int mp_selftest(mp_ctx* ctx);
 
+/* Profiling (replaces the reference's profile_start / profile_stop hooks, planning/trajectory_planning.py:295-296, and
+ * the timing part of its performance_stats): while on, every device-pointer entry point (and so every *_host one)
+ * brackets what it enqueues with a timed HIP event pair on the compute stream and an roctx range named after the
+ * entry point (visible to rocprofv3 --marker-trace).  mp_ctx_profile waits for the pairs recorded since the last
+ * read and returns the accumulated kernel milliseconds, the number of timed calls and the last call's milliseconds
+ * (any output may be NULL); reset != 0 zeroes the accumulators afterwards.  Off by default; not active while a launch
+ * graph is being captured. */
+int mp_ctx_set_profiling(mp_ctx* ctx, int on);
+int mp_ctx_profile(mp_ctx* ctx, double* kernel_ms_total, int64_t* timed_calls, double* kernel_ms_last, int reset);
+
 /* ---- device memory (pooled per context; replaces _GlobalCudaMemoryPool, cuda_kernels/memory.py:55-118,
  *      and the pinned-H2D helper _h2d_pinned, cuda_kernels/memory.py:12-50) ----------------------- */
 int mp_malloc(mp_ctx* ctx, size_t bytes, void** d_ptr);
@@ -101,6 +112,7 @@ int mp_graph_destroy(mp_graph* graph);
  *   planner stores them (:218).  No device is needed: the model is host data. */
 int mp_model_create(int n, const double* S, const double* Mcom, const double* G, const double* M_ee,
                     const double* joint_limits, const double* torque_limits, mp_model** out);
+/* Also releases what every live context holds for the model (specialised code object, device-resident copy). */
 int mp_model_destroy(mp_model* model);
 int mp_model_dof(const mp_model* model, int* n);
 /* Compiled per-joint parameters, 16 doubles per joint (see csrc/mp_model.h): for inspection/tests. */
@@ -243,6 +255,34 @@ int mp_inverse_kinematics_host_f64(mp_ctx* ctx, const mp_model* model, const dou
                                    double step_cap, double weight_orientation, double weight_position, int adaptive_tuning, int backtracking,
                               uint32_t seed,
                                    double* theta, int32_t* success, int32_t* iterations, int32_t* restarts);
+
+/* ---- CPU twins (csrc/mp_cpu.cpp): what the kernel registry's cpu_launcher of each operation calls ----------------
+ * The reference routes every registered operation through `gpu_launcher if _cuda_routing_enabled() else cpu_launcher`
+ * (cuda_kernels/registry.py:85-89) and its planner mixins pick _*_cpu when _should_use_gpu is false
+ * (planning/trajectory_dynamics.py:84-90, :414-423); its CPU launchers are NumPy code (dynamics/id_fd.py:16-83,
+ * kinematics/fk.py:39-86, kinematics/jacobian.py:39-93, dynamics/mass_matrix.py:16-99,
+ * planning/trajectory_dynamics.py:308-380, :580-708, planning/trajectory.py:676-737).  These entry points evaluate the
+ * same per-row templates the HIP kernels instantiate, on host arrays, over `nthreads` host threads (0 = all cores, or
+ * MANIPULAPY_CPU_THREADS).  No context and no GPU are involved; they are selected by the routing rule (NumPy backend
+ * active / use_cuda=False), never as a fallback of a failing GPU call.  Same argument meaning as the *_host forms. */
+int mp_cpu_threads(int64_t items); /* threads a call over `items` rows would use */
+int mp_id_trajectory_cpu_f32(const mp_model* model, const float* q, const float* qd, const float* qdd, int64_t rows,
+                             const double* g, const double* Ftip, float* tau, int nthreads);
+int mp_id_trajectory_cpu_f64(const mp_model* model, const double* q, const double* qd, const double* qdd, int64_t rows,
+                             const double* g, const double* Ftip, double* tau, int nthreads);
+int mp_fk_jac_id_cpu_f64(const mp_model* model, const double* q, const double* qd, const double* qdd, int64_t rows,
+                         const double* g, const double* Ftip, double* T, double* J, double* tau, int nthreads);
+int mp_mass_matrix_cpu_f64(const mp_model* model, const double* q, int64_t rows, double* M, int nthreads);
+int mp_forward_dynamics_cpu_f64(const mp_model* model, const double* q, const double* qd, const double* tau, int64_t rows,
+                                const double* g, const double* Ftip, double* qdd, int nthreads);
+int mp_fd_trajectory_cpu_f32(const mp_model* model, const float* theta0, const float* dtheta0, const float* taumat,
+                             const float* Ftipmat, int64_t B, int64_t N, const double* g, double dt, int intRes, float* pos,
+                             float* vel, float* acc, int nthreads);
+int mp_fd_trajectory_cpu_f64(const mp_model* model, const double* theta0, const double* dtheta0, const double* taumat,
+                             const double* Ftipmat, int64_t B, int64_t N, const double* g, double dt, int intRes, float* pos,
+                             float* vel, float* acc, int nthreads);
+int mp_cartesian_trajectory_cpu_f32(const double* Xstart, const double* Xend, int64_t B, int64_t N, double Tf, int method,
+                                    float* pos, float* vel, float* acc, float* orient, int nthreads);
 
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI (new; the reference is single-device) ------
  * Trajectory batches are sharded over ranks with no exchange during compute; the only collective is

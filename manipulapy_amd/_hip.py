@@ -49,6 +49,8 @@ SIGNATURES = {
     "mp_ctx_synchronize": (ctypes.c_int, [_vp]),
     "mp_ctx_properties": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint64)]),
     "mp_selftest": (ctypes.c_int, [_vp]),
+    "mp_ctx_set_profiling": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "mp_ctx_profile": (ctypes.c_int, [_vp, _c_dp, ctypes.POINTER(ctypes.c_int64), _c_dp, ctypes.c_int]),
     "mp_malloc": (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.POINTER(_vp)]),
     "mp_free": (ctypes.c_int, [_vp, _vp]),
     "mp_pool_trim": (ctypes.c_int, [_vp]),
@@ -102,6 +104,15 @@ SIGNATURES = {
     "mp_id_trajectory_host_f64": (ctypes.c_int, [_vp, _vp, _c_dp, _c_dp, _c_dp, _i64, _c_dp, _c_dp, _c_dp]),
     "mp_traj_id_fused_host_f32": (ctypes.c_int, [_vp, _vp, _c_fp, _c_fp, _i64, _i64, ctypes.c_double, ctypes.c_int, _c_dp, _c_dp, _c_fp]),
     "mp_fk_jac_id_host_f64": (ctypes.c_int, [_vp, _vp, _c_dp, _c_dp, _c_dp, _i64, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp]),
+    "mp_cpu_threads": (ctypes.c_int, [_i64]),
+    "mp_id_trajectory_cpu_f32": (ctypes.c_int, [_vp, _c_fp, _c_fp, _c_fp, _i64, _c_dp, _c_dp, _c_fp, ctypes.c_int]),
+    "mp_id_trajectory_cpu_f64": (ctypes.c_int, [_vp, _c_dp, _c_dp, _c_dp, _i64, _c_dp, _c_dp, _c_dp, ctypes.c_int]),
+    "mp_fk_jac_id_cpu_f64": (ctypes.c_int, [_vp, _c_dp, _c_dp, _c_dp, _i64, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, ctypes.c_int]),
+    "mp_mass_matrix_cpu_f64": (ctypes.c_int, [_vp, _c_dp, _i64, _c_dp, ctypes.c_int]),
+    "mp_forward_dynamics_cpu_f64": (ctypes.c_int, [_vp, _c_dp, _c_dp, _c_dp, _i64, _c_dp, _c_dp, _c_dp, ctypes.c_int]),
+    "mp_fd_trajectory_cpu_f32": (ctypes.c_int, [_vp, _c_fp, _c_fp, _c_fp, _c_fp, _i64, _i64, _c_dp, ctypes.c_double, ctypes.c_int, _c_fp, _c_fp, _c_fp, ctypes.c_int]),
+    "mp_fd_trajectory_cpu_f64": (ctypes.c_int, [_vp, _c_dp, _c_dp, _c_dp, _c_dp, _i64, _i64, _c_dp, ctypes.c_double, ctypes.c_int, _c_fp, _c_fp, _c_fp, ctypes.c_int]),
+    "mp_cartesian_trajectory_cpu_f32": (ctypes.c_int, [_c_dp, _c_dp, _i64, _i64, ctypes.c_double, ctypes.c_int, _c_fp, _c_fp, _c_fp, _c_fp, ctypes.c_int]),
     "mp_comm_unique_id": (ctypes.c_int, [ctypes.POINTER(ctypes.c_uint8)]),
     "mp_comm_create": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint8), ctypes.c_int, ctypes.c_int, ctypes.POINTER(_vp)]),
     "mp_comm_destroy": (ctypes.c_int, [_vp]),
@@ -362,6 +373,11 @@ class HipModel:
         assert o * w + head == nb.value, (o * w + head, nb.value)
         return d
 
+    def joint_limits_f32(self) -> np.ndarray:
+        """(n, 2) float32 joint limits exactly as the kernels clip against them (+-inf where the model is unbounded)."""
+        b = self.blob(np.float32)
+        return np.stack([b["qmin"][:self.n], b["qmax"][:self.n]], axis=1).astype(np.float32)
+
     def fk_host(self, q) -> np.ndarray:
         q = _as_c(q, np.float64, (self.n,), "q")
         T = np.zeros((4, 4))
@@ -419,6 +435,17 @@ class HipContext:
         yes = ctypes.c_int(0)
         _check(self.lib.mp_model_is_specialized(self.handle, model.handle, ctypes.byref(yes)))
         return bool(yes.value)
+
+    def set_profiling(self, on: bool = True) -> None:
+        """Timed HIP event pair + roctx range around every entry point's launches (mp_ctx_set_profiling)."""
+        _check(self.lib.mp_ctx_set_profiling(self.handle, int(bool(on))))
+
+    def profile(self, reset: bool = False) -> dict:
+        """{"kernel_ms_total", "timed_calls", "kernel_ms_last"} since profiling was switched on (or the last reset);
+        waits for the launches recorded so far."""
+        tot, last, calls = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_int64(0)
+        _check(self.lib.mp_ctx_profile(self.handle, ctypes.byref(tot), ctypes.byref(calls), ctypes.byref(last), int(bool(reset))))
+        return {"kernel_ms_total": float(tot.value), "timed_calls": int(calls.value), "kernel_ms_last": float(last.value)}
 
     def alloc(self, nbytes: int) -> DeviceBuffer:
         return DeviceBuffer(self, nbytes)
@@ -680,6 +707,98 @@ class HipContext:
 
     def comm_create(self, unique_id: bytes, nranks: int, rank: int) -> "HipComm":
         return HipComm(self, unique_id, nranks, rank)
+
+
+# --------------------------------------------------------------------------- CPU twins (csrc/mp_cpu.cpp)
+# Host arrays in, host arrays out, no context: the registry's cpu_launchers (reference cuda_kernels/registry.py:85-89).
+def _ptr(a, dtype):
+    if a is None:
+        return None
+    return a.ctypes.data_as(_c_fp if dtype == np.float32 else _c_dp)
+
+
+def cpu_id_trajectory(model: "HipModel", q, qd, qdd, g=None, Ftip=None, dtype=np.float32, nthreads: int = 0) -> np.ndarray:
+    lib = load_library()
+    q = _as_c(q, dtype, name="q")
+    if q.ndim != 2 or q.shape[1] != model.n:
+        raise ValueError(f"q must be (rows, {model.n}); got {q.shape}")
+    qd, qdd = _as_c(qd, dtype, q.shape, "qd"), _as_c(qdd, dtype, q.shape, "qdd")
+    tau = np.empty_like(q)
+    fn = lib.mp_id_trajectory_cpu_f32 if dtype == np.float32 else lib.mp_id_trajectory_cpu_f64
+    _check(fn(model.handle, _ptr(q, dtype), _ptr(qd, dtype), _ptr(qdd, dtype), q.shape[0], _dptr(_vec_or_none(g, 3, "g")),
+              _dptr(_vec_or_none(Ftip, 6, "Ftip")), _ptr(tau, dtype), int(nthreads)))
+    return tau
+
+
+def cpu_fk_jac_id(model: "HipModel", q, qd=None, qdd=None, g=None, Ftip=None, want_T=True, want_J=True, nthreads: int = 0):
+    lib = load_library()
+    q = _as_c(q, np.float64, name="q")
+    if q.ndim != 2 or q.shape[1] != model.n:
+        raise ValueError(f"q must be (rows, {model.n}); got {q.shape}")
+    rows, n = q.shape
+    want_tau = qd is not None and qdd is not None
+    qd = _as_c(qd, np.float64, q.shape, "qd") if want_tau else None
+    qdd = _as_c(qdd, np.float64, q.shape, "qdd") if want_tau else None
+    T = np.empty((rows, 4, 4)) if want_T else None
+    J = np.empty((rows, 6, n)) if want_J else None
+    tau = np.empty((rows, n)) if want_tau else None
+    if not (want_T or want_J or want_tau):
+        raise ValueError("at least one output is required")
+    _check(lib.mp_fk_jac_id_cpu_f64(model.handle, _dptr(q), _dptr(qd), _dptr(qdd), rows, _dptr(_vec_or_none(g, 3, "g")),
+                                    _dptr(_vec_or_none(Ftip, 6, "Ftip")), _dptr(T), _dptr(J), _dptr(tau), int(nthreads)))
+    return T, J, tau
+
+
+def cpu_mass_matrix(model: "HipModel", q, nthreads: int = 0) -> np.ndarray:
+    q = _as_c(q, np.float64, name="q")
+    if q.ndim != 2 or q.shape[1] != model.n:
+        raise ValueError(f"q must be (rows, {model.n}); got {q.shape}")
+    M = np.empty((q.shape[0], model.n, model.n))
+    _check(load_library().mp_mass_matrix_cpu_f64(model.handle, _dptr(q), q.shape[0], _dptr(M), int(nthreads)))
+    return M
+
+
+def cpu_forward_dynamics(model: "HipModel", q, qd, tau, g=None, Ftip=None, nthreads: int = 0) -> np.ndarray:
+    q = _as_c(q, np.float64, name="q")
+    if q.ndim != 2 or q.shape[1] != model.n:
+        raise ValueError(f"q must be (rows, {model.n}); got {q.shape}")
+    qd, tau = _as_c(qd, np.float64, q.shape, "qd"), _as_c(tau, np.float64, q.shape, "tau")
+    out = np.empty_like(q)
+    _check(load_library().mp_forward_dynamics_cpu_f64(model.handle, _dptr(q), _dptr(qd), _dptr(tau), q.shape[0],
+                                                      _dptr(_vec_or_none(g, 3, "g")), _dptr(_vec_or_none(Ftip, 6, "Ftip")), _dptr(out),
+                                                      int(nthreads)))
+    return out
+
+
+def cpu_fd_trajectory(model: "HipModel", theta0, dtheta0, taumat, g, Ftipmat, dt, intRes, dtype=np.float64, nthreads: int = 0):
+    lib = load_library()
+    tm = _as_c(taumat, dtype, name="taumat")
+    if tm.ndim != 3 or tm.shape[2] != model.n:
+        raise ValueError(f"taumat must be (B, N, {model.n}); got {tm.shape}")
+    B, N, n = tm.shape
+    th, dth = _as_c(theta0, dtype, (B, n), "theta0"), _as_c(dtheta0, dtype, (B, n), "dtheta0")
+    Fm = None if Ftipmat is None else _as_c(Ftipmat, dtype, (B, N, 6), "Ftipmat")
+    out = [np.empty((B, N, n), dtype=np.float32) for _ in range(3)]
+    fn = lib.mp_fd_trajectory_cpu_f32 if dtype == np.float32 else lib.mp_fd_trajectory_cpu_f64
+    _check(fn(model.handle, _ptr(th, dtype), _ptr(dth, dtype), _ptr(tm, dtype), _ptr(Fm, dtype), B, N, _dptr(_vec_or_none(g, 3, "g")),
+              float(dt), int(intRes), _fptr(out[0]), _fptr(out[1]), _fptr(out[2]), int(nthreads)))
+    return out[0], out[1], out[2]
+
+
+def cpu_cartesian_trajectory(Xstart, Xend, Tf, N, method, nthreads: int = 0):
+    Xs = _as_c(Xstart, np.float64, name="Xstart")
+    if Xs.ndim != 3 or Xs.shape[1:] != (4, 4):
+        raise ValueError(f"Xstart must be (B, 4, 4); got {Xs.shape}")
+    Xe = _as_c(Xend, np.float64, Xs.shape, "Xend")
+    B, N = Xs.shape[0], int(N)
+    out = [np.empty((B, N, 3), dtype=np.float32) for _ in range(3)] + [np.empty((B, N, 3, 3), dtype=np.float32)]
+    _check(load_library().mp_cartesian_trajectory_cpu_f32(_dptr(Xs), _dptr(Xe), B, N, float(Tf), int(method), *[_fptr(o) for o in out],
+                                                          int(nthreads)))
+    return tuple(out)
+
+
+def cpu_threads(items: int = 1 << 30) -> int:
+    return int(load_library().mp_cpu_threads(int(items)))
 
 
 def _out_or_new(out, shape, dtype) -> np.ndarray:

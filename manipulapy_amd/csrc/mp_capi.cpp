@@ -3,7 +3,10 @@
 // model handles, argument validation and the host-pointer convenience wrappers.
 #include <hip/hip_runtime_api.h>
 
+#include <dlfcn.h>
+
 #include <atomic>
+#include <set>
 #include <cstdarg>
 #include <cstdlib>
 #include <cstdio>
@@ -19,6 +22,7 @@
 #include "mp_ik.h"
 #include "mp_kernels.h"
 #include "mp_model_compile.h"
+#include "mp_handles.h"
 
 // ------------------------------------------------------------------------------------- objects
 struct MpSpec {  // run-time specialised kernels of one model on one device
@@ -47,11 +51,13 @@ struct mp_ctx {
   bool tab_volatile = false;                           // a launch graph holds a table kernel: never trust the cache again
   std::vector<void*> retired_tabs;                     // outgrown tables that captured graphs may still reference
   std::recursive_mutex mu;                             // serialises the entry points of this context (CTX_ENTER)
-};
-struct mp_model {
-  MpModel<double> d;
-  MpModel<float> f;
-  uint64_t uid;  // never reused, so a context's device copies cannot alias a destroyed model
+  // profiling (mp_ctx_set_profiling): every device-pointer entry point brackets its launches with a timed HIP event pair
+  // on the compute stream and an roctx range; the pairs are resolved when the figures are read (mp_ctx_profile)
+  bool profiling = false;
+  struct Pending { hipEvent_t a, b; };
+  std::vector<Pending> prof_pending;
+  double prof_total_ms = 0, prof_last_ms = 0;
+  long long prof_launches = 0;
 };
 struct mp_event {
   hipEvent_t ev = nullptr;
@@ -108,6 +114,54 @@ int bind(mp_ctx* ctx) {
 #define CTX_ENTER(ctx)                                         \
   std::lock_guard<std::recursive_mutex> ctx_lock_((ctx)->mu);  \
   if (int rc_enter_ = bind(ctx)) return rc_enter_
+// every live context, so that mp_model_destroy can drop the per-context state of a model (specialised code object,
+// device-resident copy) instead of leaving it to mp_ctx_destroy
+std::mutex g_ctxs_mu;
+std::set<mp_ctx*> g_ctxs;
+
+// roctx ranges (rocprofv3 --marker-trace shows them): libroctx64 is dlopen'd on first use only, absent = no ranges
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    for (const char* name : {"libroctx64.so.4", "libroctx64.so", "/opt/rocm/lib/libroctx64.so"}) {
+      if (void* h = dlopen(name, RTLD_NOW | RTLD_LOCAL)) {
+        push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+        pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        if (push && pop) return;
+        push = nullptr; pop = nullptr;
+      }
+    }
+  }
+};
+const Roctx& roctx() { static const Roctx r; return r; }
+
+// Scope of one device-pointer entry point when the context profiles: an roctx range named after the entry point and a
+// timed HIP event pair around whatever it enqueues on the compute stream (the replacement of the reference's
+// profile_start / CUDA profiler hooks, planning/trajectory_planning.py:295-296, cuda_kernels/_runtime.py).
+struct KernelScope {
+  mp_ctx* ctx;
+  hipEvent_t a = nullptr, b = nullptr;
+  bool ranged = false;
+  KernelScope(mp_ctx* c, const char* name) : ctx(c) {
+    if (!c->profiling || c->capturing) return;
+    if (roctx().push) { roctx().push(name); ranged = true; }
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess || hipEventRecord(a, c->compute) != hipSuccess) {
+      if (a) (void)hipEventDestroy(a);
+      if (b) (void)hipEventDestroy(b);
+      a = b = nullptr;
+    }
+  }
+  ~KernelScope() {
+    if (a && b) {
+      if (hipEventRecord(b, ctx->compute) == hipSuccess) ctx->prof_pending.push_back({a, b});
+      else { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
+    }
+    if (ranged) roctx().pop();
+  }
+};
+#define PROFILE_SCOPE(ctx, name) KernelScope kernel_scope_((ctx), (name))
+
 template <typename T> const MpModel<T>& pick(const mp_model* m);
 template <> const MpModel<float>& pick<float>(const mp_model* m) { return m->f; }
 template <> const MpModel<double>& pick<double>(const mp_model* m) { return m->d; }
@@ -131,14 +185,15 @@ struct Scratch {
     return rc;
   }
 };
-// rows per chunk of the host-buffer pipeline (MANIPULAPY_HIP_HOST_CHUNK_ROWS, default 512 Ki rows, kept even so that
-// only the last chunk can end on an odd row)
+// rows per chunk of the host-buffer pipeline (MANIPULAPY_HIP_HOST_CHUNK_ROWS, default 512 Ki rows), rounded up to a
+// multiple of 4: every chunk then starts on a 16-byte boundary for any row size (4 rows x n x 4 bytes), which the
+// device-pointer entry points require, and only the last chunk can end on an odd row
 int64_t host_chunk_rows() {
   static const int64_t rows = [] {
     const char* e = getenv("MANIPULAPY_HIP_HOST_CHUNK_ROWS");
     long long v = e ? atoll(e) : 0;
     if (v <= 0) v = 512 * 1024;
-    return (int64_t)((v + 1) & ~1LL);
+    return (int64_t)((v + 3) & ~3LL);
   }();
   return rows;
 }
@@ -257,6 +312,7 @@ static int id_impl(const char* fn, mp_ctx* ctx, const mp_model* model, const T* 
           "%s: device pointers must be 16-byte aligned", fn);
   MpCall<T> c;
   make_call<T>(model, g, Ftip, &c);
+  PROFILE_SCOPE(ctx, fn);
   return launch_id(ctx, model, c, any_nonzero(Ftip), d_q, d_qd, d_qdd, d_tau, (long)rows);
 }
 
@@ -288,6 +344,7 @@ static int fkjid_impl(const char* fn, mp_ctx* ctx, const mp_model* model, const 
           "%s: device pointers must be 16-byte aligned", fn);
   MpCall<T> c;
   make_call<T>(model, g, Ftip, &c);
+  PROFILE_SCOPE(ctx, fn);
   const int src = launch_fkjid_spec(ctx, model, c, any_nonzero(Ftip), d_q, d_qd, d_qdd, d_T, d_J, d_tau, (long)rows);
   if (src >= 0) return src;
   HIP_TRY(mpk_fk_jac_id<T>(ctx->compute, pick<T>(model), c, any_nonzero(Ftip), d_q, d_qd, d_qdd, d_T, d_J, d_tau, (long)rows));
@@ -303,6 +360,14 @@ template <class Up, class Run, class Down>
 static int host_pipeline(mp_ctx* ctx, int64_t rows, int64_t chunk, Up up, Run run, Down down) {
   EventList ev;
   auto body = [&]() -> int {
+    // The scratch blocks of this call come from the pool, whose reuse is ordered with respect to the COMPUTE stream
+    // only: work still pending there (an asynchronous device-pointer call whose buffer the caller has already freed)
+    // must finish before the copy streams may overwrite a recycled block.
+    hipEvent_t tail = nullptr;
+    if (int rc = ev.make(&tail)) return rc;
+    HIP_TRY(hipEventRecord(tail, ctx->compute));
+    HIP_TRY(hipStreamWaitEvent(ctx->copy, tail, 0));
+    HIP_TRY(hipStreamWaitEvent(ctx->copy_out, tail, 0));
     for (int64_t r0 = 0; r0 < rows; r0 += chunk) {
       const int64_t nr = std::min(chunk, rows - r0);
       hipEvent_t uploaded = nullptr, done = nullptr;
@@ -392,6 +457,7 @@ static int mm_impl(const char* fn, mp_ctx* ctx, const mp_model* model, const T* 
   if (rows == 0) return MP_OK;
   REQUIRE(d_q && d_M, "%s: null device pointer", fn);
   REQUIRE(aligned16(d_q) && aligned16(d_M), "%s: device pointers must be 16-byte aligned", fn);
+  PROFILE_SCOPE(ctx, fn);
   HIP_TRY(mpk_mass_matrix<T>(ctx->compute, pick<T>(model), d_q, d_M, (long)rows));
   return MP_OK;
 }
@@ -408,6 +474,7 @@ static int fdyn_impl(const char* fn, mp_ctx* ctx, const mp_model* model, const T
   MpCall<T> c;
   make_call<T>(model, g, Ftip, &c);
   const bool ftip = any_nonzero(Ftip);
+  PROFILE_SCOPE(ctx, fn);
   if (const MpSpec* sp = find_spec(ctx, model)) {
     long nr = (long)rows;
     void* args[] = {&c, &d_q, &d_qd, &d_tau, &d_qdd, &nr};
@@ -447,6 +514,7 @@ static int fdtraj_impl(const char* fn, mp_ctx* ctx, const mp_model* model, const
   MpCall<T> c;
   make_call<T>(model, g, nullptr, &c);
   const T h = intRes > 0 ? (T)(dt / intRes) : (T)0;
+  PROFILE_SCOPE(ctx, fn);
   const int src = launch_fd_spec(ctx, model, c, d_theta0, d_dtheta0, d_taumat, d_Ftipmat, (long)B, (long)N, h, intRes, d_pos, d_vel, d_acc);
   if (src >= 0) return src;  // a specialised kernel exists for this model: launched (0) or failed (error code)
   HIP_TRY(mpk_fd_traj<T>(ctx->compute, pick<T>(model), c, d_theta0, d_dtheta0, d_taumat, d_Ftipmat, (long)B, (long)N, h, intRes,
@@ -521,14 +589,23 @@ int mp_ctx_create(int device_id, mp_ctx** out) {
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy_out, hipStreamNonBlocking);
   if (e != hipSuccess) { delete c; return hip_err(e, "hipStreamCreate"); }
+  {
+    std::lock_guard<std::mutex> lk(g_ctxs_mu);
+    g_ctxs.insert(c);
+  }
   *out = c;
   return MP_OK;
 }
 
 int mp_ctx_destroy(mp_ctx* ctx) {
   if (!ctx) return MP_OK;
+  {
+    std::lock_guard<std::mutex> lk(g_ctxs_mu);
+    g_ctxs.erase(ctx);
+  }
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
+  for (auto& pe : ctx->prof_pending) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
   for (auto& kv : ctx->specs) if (kv.second.mod) (void)hipModuleUnload(kv.second.mod);
   for (auto& kv : ctx->live) (void)hipFree(kv.first);
   if (ctx->queue_counter) (void)hipFree(ctx->queue_counter);
@@ -538,6 +615,34 @@ int mp_ctx_destroy(mp_ctx* ctx) {
   if (ctx->copy) (void)hipStreamDestroy(ctx->copy);
   if (ctx->copy_out) (void)hipStreamDestroy(ctx->copy_out);
   delete ctx;
+  return MP_OK;
+}
+
+int mp_ctx_set_profiling(mp_ctx* ctx, int on) {
+  REQUIRE(ctx, "mp_ctx_set_profiling: null context");
+  CTX_ENTER(ctx);
+  ctx->profiling = on != 0;
+  return MP_OK;
+}
+
+int mp_ctx_profile(mp_ctx* ctx, double* kernel_ms_total, int64_t* timed_calls, double* kernel_ms_last, int reset) {
+  REQUIRE(ctx, "mp_ctx_profile: null context");
+  CTX_ENTER(ctx);
+  for (auto& pe : ctx->prof_pending) {  // resolve the event pairs recorded since the last read
+    float ms = 0.f;
+    if (hipEventSynchronize(pe.b) == hipSuccess && hipEventElapsedTime(&ms, pe.a, pe.b) == hipSuccess) {
+      ctx->prof_total_ms += ms;
+      ctx->prof_last_ms = ms;
+      ctx->prof_launches += 1;
+    }
+    (void)hipEventDestroy(pe.a);
+    (void)hipEventDestroy(pe.b);
+  }
+  ctx->prof_pending.clear();
+  if (kernel_ms_total) *kernel_ms_total = ctx->prof_total_ms;
+  if (timed_calls) *timed_calls = ctx->prof_launches;
+  if (kernel_ms_last) *kernel_ms_last = ctx->prof_last_ms;
+  if (reset) { ctx->prof_total_ms = 0; ctx->prof_last_ms = 0; ctx->prof_launches = 0; }
   return MP_OK;
 }
 
@@ -784,6 +889,25 @@ int mp_model_create(int n, const double* S, const double* Mcom, const double* G,
   return MP_OK;
 }
 int mp_model_destroy(mp_model* model) {
+  if (!model) return MP_OK;
+  // drop what the live contexts hold for this model: its specialised code object and its device-resident copy
+  std::lock_guard<std::mutex> lk(g_ctxs_mu);
+  for (mp_ctx* ctx : g_ctxs) {
+    std::lock_guard<std::recursive_mutex> cl(ctx->mu);
+    auto sp = ctx->specs.find(model->uid);
+    auto dm = ctx->dev_models.find(model->uid);
+    if (sp == ctx->specs.end() && dm == ctx->dev_models.end()) continue;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->compute);  // a launch of this model's kernels may still be in flight
+    if (sp != ctx->specs.end()) {
+      if (sp->second.mod) (void)hipModuleUnload(sp->second.mod);
+      ctx->specs.erase(sp);
+    }
+    if (dm != ctx->dev_models.end()) {
+      (void)mp_free(ctx, dm->second);
+      ctx->dev_models.erase(dm);
+    }
+  }
   delete model;
   return MP_OK;
 }
@@ -879,6 +1003,7 @@ int mp_batch_trajectory_f32(mp_ctx* ctx, const mp_model* model, const float* d_s
   REQUIRE(d_start && d_end && d_pos && d_vel && d_acc, "mp_batch_trajectory_f32: null device pointer");
   REQUIRE(aligned16(d_start) && aligned16(d_end) && aligned16(d_pos) && aligned16(d_vel) && aligned16(d_acc),
           "mp_batch_trajectory_f32: device pointers must be 16-byte aligned");
+  PROFILE_SCOPE(ctx, "mp_batch_trajectory_f32");
   HIP_TRY(mpk_batch_traj(ctx->compute, model->f, d_start, d_end, (long)B, (long)N, Tf, method, d_pos, d_vel, d_acc));
   return MP_OK;
 }
@@ -903,6 +1028,7 @@ int mp_traj_id_fused_f32(mp_ctx* ctx, const mp_model* model, const float* d_star
   MpCall<float> c;
   make_call<float>(model, g, Ftip, &c);
   const bool ftip = any_nonzero(Ftip);
+  PROFILE_SCOPE(ctx, "mp_traj_id_fused_f32");
   if (!mpk_packed_f32()) {  // MANIPULAPY_HIP_F32=scalar: the one-row-per-lane kernel, time scaling computed per row
     HIP_TRY(mpk_traj_id(ctx->compute, model->f, c, ftip, d_start, d_end, (long)B, (long)N, Tf, method, d_tau));
     return MP_OK;

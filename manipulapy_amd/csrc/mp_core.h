@@ -143,6 +143,22 @@ MP_HD double mp_sqrt(double x) { return sqrt(x); }
 #if MP_HAS_PACKED
 MP_HD mp_f2 mp_sqrt(mp_f2 x) { return (mp_f2){sqrtf(x.x), sqrtf(x.y)}; }
 #endif
+// 1 / sqrt(x) for the Cholesky pivots.  float32 on the device: v_rsq_f32 (1 ulp) plus one Newton step, 5 instructions
+// where the IEEE sqrt followed by the IEEE divide expands to ~20 (v_sqrt + fix-up, v_div_scale x 2, v_rcp, four FMAs,
+// v_div_fmas, v_div_fixup); the result is within 1 ulp of the correctly rounded quotient.  float64 keeps sqrt + divide.
+MP_HD float mp_rsqrt(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const float y = __builtin_amdgcn_rsqf(x);
+  const float e = fmaf(-(x * y), y, 1.0f);  // 1 - x y^2
+  return fmaf(0.5f * y, e, y);
+#else
+  return 1.0f / sqrtf(x);
+#endif
+}
+MP_HD double mp_rsqrt(double x) { return 1.0 / sqrt(x); }
+#if MP_HAS_PACKED
+MP_HD mp_f2 mp_rsqrt(mp_f2 x) { return (mp_f2){mp_rsqrt(x.x), mp_rsqrt(x.y)}; }
+#endif
 // np.clip order: max with the lower bound first, then min with the upper bound
 template <typename T>
 MP_HD T mp_clip(T v, typename MpTraits<T>::S lo, typename MpTraits<T>::S hi) {
@@ -501,7 +517,7 @@ MP_HD void mp_spd_solve(T (&A)[N][N], T (&b)[N]) {
     T d = A[j][j];
 #pragma unroll
     for (int k = 0; k < j; ++k) d -= A[j][k] * A[j][k];
-    const T inv = MpTraits<T>::splat(typename MpTraits<T>::S(1)) / mp_sqrt(d);
+    const T inv = mp_rsqrt(d);
     A[j][j] = inv;  // store 1 / L_jj
 #pragma unroll
     for (int i = j + 1; i < N; ++i) {

@@ -1,0 +1,314 @@
+// CPU twins of the hot-path entry points (include/manipula_hip.h, "*_cpu"): the SAME per-row templates the HIP
+// kernels instantiate (mp_core.h), compiled for the host and run over the rows by a small std::thread pool.
+// They are what the kernel registry's cpu_launchers call when the reference's own routing rule sends an operation to
+// the CPU (NumPy backend active, or use_cuda=False): reference cuda_kernels/registry.py:85-89 picks
+// `gpu_launcher if _cuda_routing_enabled() else cpu_launcher`.  They are NOT a fallback of the GPU path - a failing
+// or missing GPU under the "hip" backend raises - and they are the product's own analytic recursion, not the test
+// suite's restatement of the reference's 1 + 2n mass-matrix algorithm.  No HIP call is made here.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "../../include/manipula_hip.h"
+#include "mp_core.h"
+#include "mp_handles.h"
+#include "mp_model_compile.h"
+
+namespace {
+const double kG[3] = {0.0, 0.0, -9.81};
+
+int fail(const char* msg) { return mp_set_error(MP_ERR_INVALID, msg); }
+
+int thread_count(int64_t items, int64_t grain, int nthreads) {
+  int want = nthreads;
+  if (want <= 0) {
+    if (const char* e = getenv("MANIPULAPY_CPU_THREADS")) want = atoi(e);
+    if (want <= 0) want = (int)std::thread::hardware_concurrency();
+    if (want <= 0) want = 1;
+  }
+  const int64_t by_work = (items + grain - 1) / grain;
+  return (int)std::max<int64_t>(1, std::min<int64_t>(want, by_work));
+}
+
+// fn(lo, hi) over [0, items) in contiguous slices, one per thread; small inputs stay on the calling thread
+template <class F>
+int parallel_for(int64_t items, int64_t grain, int nthreads, F fn) {
+  const int T = thread_count(items, grain, nthreads);
+  if (T <= 1) { fn((int64_t)0, items); return 1; }
+  std::vector<std::thread> pool;
+  pool.reserve(T - 1);
+  const int64_t per = (items + T - 1) / T;
+  for (int t = 1; t < T; ++t) {
+    const int64_t lo = std::min(items, t * per), hi = std::min(items, lo + per);
+    if (lo < hi) pool.emplace_back([=] { fn(lo, hi); });
+  }
+  fn((int64_t)0, std::min(items, per));
+  for (auto& th : pool) th.join();
+  return T;
+}
+
+bool any_nonzero(const double* F) {
+  if (!F) return false;
+  for (int k = 0; k < 6; ++k)
+    if (F[k] != 0.0) return true;
+  return false;
+}
+
+template <typename T> const MpModel<T>& pick(const mp_model* m);
+template <> const MpModel<float>& pick<float>(const mp_model* m) { return m->f; }
+template <> const MpModel<double>& pick<double>(const mp_model* m) { return m->d; }
+
+template <typename T>
+MpCall<T> make_call(const mp_model* m, const double* g, const double* Ftip) {
+  MpCall<double> cd;
+  mp_make_call(m->d, g ? g : kG, Ftip, &cd);
+  MpCall<T> c;
+  mp_call_cast(cd, &c);
+  return c;
+}
+
+#define MP_CPU_DISPATCH(n, ...)                                  \
+  switch (n) {                                                   \
+    case 1: { constexpr int N = 1; __VA_ARGS__; } break;         \
+    case 2: { constexpr int N = 2; __VA_ARGS__; } break;         \
+    case 3: { constexpr int N = 3; __VA_ARGS__; } break;         \
+    case 4: { constexpr int N = 4; __VA_ARGS__; } break;         \
+    case 5: { constexpr int N = 5; __VA_ARGS__; } break;         \
+    case 6: { constexpr int N = 6; __VA_ARGS__; } break;         \
+    case 7: { constexpr int N = 7; __VA_ARGS__; } break;         \
+    case 8: { constexpr int N = 8; __VA_ARGS__; } break;         \
+    default: return fail("dof outside 1..8");                    \
+  }
+
+// ---- one row of FK / Jacobian / inverse dynamics: the body of k_fk_jac_id / k_id on the host
+template <typename T, int N, bool F>
+void rows_fk_jac_id(const MpModel<T>& M, const MpCall<T>& C, const T* q, const T* qd, const T* qdd, T* Tout, T* Jout, T* tau,
+                    int64_t lo, int64_t hi) {
+  for (int64_t r = lo; r < hi; ++r) {
+    T a[N];
+    for (int j = 0; j < N; ++j) a[j] = q[r * N + j];
+    MpJointState<T, N> js;
+    mp_joint_state<T, N>(M, a, js);
+    MpBad<T> bad;
+    bad.add(a);
+    if (Tout || Jout) {
+      T TT[16], JJ[6 * N];
+      mp_fk_jac<T, N, true>(M, js, TT, JJ);
+      mp_poison_if(bad.any(), TT);
+      mp_poison_if(bad.any(), JJ);
+      if (Tout) std::memcpy(Tout + r * 16, TT, sizeof TT);
+      if (Jout) std::memcpy(Jout + r * 6 * N, JJ, sizeof JJ);
+    }
+    if (tau) {
+      T b[N], c[N], t[N];
+      for (int j = 0; j < N; ++j) { b[j] = qd[r * N + j]; c[j] = qdd[r * N + j]; }
+      mp_rnea<T, N, F>(M, C, js, b, c, t);
+      for (int j = 0; j < N; ++j) t[j] = mp_clip(t[j], M.taumin[j], M.taumax[j]);
+      bad.add(b); bad.add(c);
+      mp_poison_if(bad.any(), t);
+      std::memcpy(tau + r * N, t, sizeof t);
+    }
+  }
+}
+
+template <typename T>
+int fk_jac_id_cpu(const char* fn, const mp_model* model, const T* q, const T* qd, const T* qdd, int64_t rows, const double* g,
+                  const double* Ftip, T* Tout, T* Jout, T* tau, int nthreads) {
+  if (!model) return fail("null model");
+  if (rows < 0) return fail("negative row count");
+  if (rows == 0) return MP_OK;
+  if (!q || !(Tout || Jout || tau) || (tau && !(qd && qdd))) return fail(fn);
+  const MpModel<T>& M = pick<T>(model);
+  const MpCall<T> C = make_call<T>(model, g, Ftip);
+  const bool ftip = any_nonzero(Ftip);
+  MP_CPU_DISPATCH(M.n, {
+    parallel_for(rows, 256, nthreads, [&](int64_t lo, int64_t hi) {
+      if (ftip) rows_fk_jac_id<T, N, true>(M, C, q, qd, qdd, Tout, Jout, tau, lo, hi);
+      else rows_fk_jac_id<T, N, false>(M, C, q, qd, qdd, Tout, Jout, tau, lo, hi);
+    });
+  })
+  return MP_OK;
+}
+
+// ---- mass matrix / forward dynamics per row
+template <typename T, int N>
+void rows_mass_matrix(const MpModel<T>& M, const T* q, T* out, int64_t lo, int64_t hi) {
+  for (int64_t r = lo; r < hi; ++r) {
+    T a[N];
+    for (int j = 0; j < N; ++j) a[j] = q[r * N + j];
+    MpJointState<T, N> js;
+    mp_joint_state<T, N>(M, a, js);
+    T Mq[N][N];
+    mp_mass_matrix_crba<T, N>(M, js, Mq);
+    MpBad<T> bad;
+    bad.add(a);
+    for (int i = 0; i < N; ++i) {
+      mp_poison_if(bad.any(), Mq[i]);
+      std::memcpy(out + (r * N + i) * N, Mq[i], sizeof Mq[i]);
+    }
+  }
+}
+
+template <typename T, int N, bool F>
+void rows_forward_dynamics(const MpModel<T>& M, const MpCall<T>& C, const T* q, const T* qd, const T* tau, T* qdd, int64_t lo,
+                           int64_t hi) {
+  const T tn[3] = {C.F1n[0], C.F1n[1], C.F1n[2]}, tf[3] = {C.F1f[0], C.F1f[1], C.F1f[2]};
+  for (int64_t r = lo; r < hi; ++r) {
+    T a[N], b[N], t[N], o[N];
+    for (int j = 0; j < N; ++j) { a[j] = q[r * N + j]; b[j] = qd[r * N + j]; t[j] = tau[r * N + j]; }
+    mp_forward_dynamics<T, N, F>(M, C.a0, tn, tf, a, b, t, o);
+    MpBad<T> bad;
+    bad.add(a); bad.add(b); bad.add(t);
+    mp_poison_if(bad.any(), o);
+    std::memcpy(qdd + r * N, o, sizeof o);
+  }
+}
+
+// ---- forward_dynamics_trajectory: the body of k_fd_traj for trajectories [lo, hi)
+template <typename T, int N, bool F>
+void rollouts(const MpModel<T>& M, const MpCall<T>& C, const T* theta0, const T* dtheta0, const T* taumat, const T* Ftipmat,
+              int64_t Nt, T h, int intRes, float* pos, float* vel, float* acc, int64_t lo, int64_t hi) {
+  const float nanf_ = __builtin_bit_cast(float, 0x7fc00000u);
+  for (int64_t b = lo; b < hi; ++b) {
+    T q[N], qd[N];
+    for (int j = 0; j < N; ++j) { q[j] = theta0[b * N + j]; qd[j] = dtheta0[b * N + j]; }
+    MpBad<T> bad;
+    bad.add(q); bad.add(qd);
+    for (int64_t i = 0; i < Nt; ++i) {
+      T last[N];
+      for (int j = 0; j < N; ++j) last[j] = T(0);
+      if (i > 0) {
+        T tau[N], tn[3] = {T(0), T(0), T(0)}, tf[3] = {T(0), T(0), T(0)};
+        for (int j = 0; j < N; ++j) tau[j] = taumat[(b * Nt + i) * N + j];
+        bad.add(tau);
+        if (F) {
+          T W[6];
+          for (int k = 0; k < 6; ++k) W[k] = Ftipmat[(b * Nt + i) * 6 + k];
+          bad.add(W);
+          mp_wrench_to_frame1(M, W, tn, tf);
+        }
+        for (int k = 0; k < intRes; ++k) {
+          mp_forward_dynamics<T, N, F>(M, C.a0, tn, tf, q, qd, tau, last);
+          for (int j = 0; j < N; ++j) {
+            qd[j] = qd[j] + last[j] * h;
+            q[j] = mp_clip(q[j] + qd[j] * h, M.qmin[j], M.qmax[j]);
+          }
+        }
+        bad.add(qd);
+      }
+      const bool poison = i > 0 && bad.any();
+      for (int j = 0; j < N; ++j) {
+        const int64_t o = (b * Nt + i) * N + j;
+        pos[o] = poison ? nanf_ : (float)q[j];
+        vel[o] = poison ? nanf_ : (float)qd[j];
+        acc[o] = poison ? nanf_ : (float)last[j];
+      }
+    }
+  }
+}
+
+template <typename T>
+int fd_trajectory_cpu(const mp_model* model, const T* theta0, const T* dtheta0, const T* taumat, const T* Ftipmat, int64_t B,
+                      int64_t Nt, const double* g, double dt, int intRes, float* pos, float* vel, float* acc, int nthreads) {
+  if (!model) return fail("null model");
+  if (B < 0 || Nt < 0) return fail("negative trajectory / step count");
+  if (B == 0 || Nt == 0) return MP_OK;
+  if (intRes < 1) return fail("intRes must be >= 1");
+  if (!theta0 || !dtheta0 || !taumat || !pos || !vel || !acc) return fail("null pointer");
+  const MpModel<T>& M = pick<T>(model);
+  const MpCall<T> C = make_call<T>(model, g, nullptr);
+  const T h = (T)(dt / intRes);
+  MP_CPU_DISPATCH(M.n, {
+    parallel_for(B, 1, nthreads, [&](int64_t lo, int64_t hi) {
+      if (Ftipmat) rollouts<T, N, true>(M, C, theta0, dtheta0, taumat, Ftipmat, Nt, h, intRes, pos, vel, acc, lo, hi);
+      else rollouts<T, N, false>(M, C, theta0, dtheta0, taumat, Ftipmat, Nt, h, intRes, pos, vel, acc, lo, hi);
+    });
+  })
+  return MP_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int mp_cpu_threads(int64_t items) { return thread_count(items, 1, 0); }
+
+int mp_id_trajectory_cpu_f32(const mp_model* model, const float* q, const float* qd, const float* qdd, int64_t rows,
+                             const double* g, const double* Ftip, float* tau, int nthreads) {
+  if (rows > 0 && !tau) return fail("mp_id_trajectory_cpu_f32: null tau");
+  return fk_jac_id_cpu<float>("mp_id_trajectory_cpu_f32: null pointer", model, q, qd, qdd, rows, g, Ftip, nullptr, nullptr, tau, nthreads);
+}
+int mp_id_trajectory_cpu_f64(const mp_model* model, const double* q, const double* qd, const double* qdd, int64_t rows,
+                             const double* g, const double* Ftip, double* tau, int nthreads) {
+  if (rows > 0 && !tau) return fail("mp_id_trajectory_cpu_f64: null tau");
+  return fk_jac_id_cpu<double>("mp_id_trajectory_cpu_f64: null pointer", model, q, qd, qdd, rows, g, Ftip, nullptr, nullptr, tau, nthreads);
+}
+int mp_fk_jac_id_cpu_f64(const mp_model* model, const double* q, const double* qd, const double* qdd, int64_t rows,
+                         const double* g, const double* Ftip, double* T, double* J, double* tau, int nthreads) {
+  return fk_jac_id_cpu<double>("mp_fk_jac_id_cpu_f64: null pointer / no output / tau without qd, qdd", model, q, qd, qdd, rows, g,
+                               Ftip, T, J, tau, nthreads);
+}
+
+int mp_mass_matrix_cpu_f64(const mp_model* model, const double* q, int64_t rows, double* Mout, int nthreads) {
+  if (!model) return fail("mp_mass_matrix_cpu_f64: null model");
+  if (rows < 0) return fail("mp_mass_matrix_cpu_f64: negative row count");
+  if (rows == 0) return MP_OK;
+  if (!q || !Mout) return fail("mp_mass_matrix_cpu_f64: null pointer");
+  const MpModel<double>& M = model->d;
+  MP_CPU_DISPATCH(M.n, { parallel_for(rows, 256, nthreads, [&](int64_t lo, int64_t hi) { rows_mass_matrix<double, N>(M, q, Mout, lo, hi); }); })
+  return MP_OK;
+}
+
+int mp_forward_dynamics_cpu_f64(const mp_model* model, const double* q, const double* qd, const double* tau, int64_t rows,
+                                const double* g, const double* Ftip, double* qdd, int nthreads) {
+  if (!model) return fail("mp_forward_dynamics_cpu_f64: null model");
+  if (rows < 0) return fail("mp_forward_dynamics_cpu_f64: negative row count");
+  if (rows == 0) return MP_OK;
+  if (!q || !qd || !tau || !qdd) return fail("mp_forward_dynamics_cpu_f64: null pointer");
+  const MpModel<double>& M = model->d;
+  const MpCall<double> C = make_call<double>(model, g, Ftip);
+  const bool ftip = any_nonzero(Ftip);
+  MP_CPU_DISPATCH(M.n, {
+    parallel_for(rows, 128, nthreads, [&](int64_t lo, int64_t hi) {
+      if (ftip) rows_forward_dynamics<double, N, true>(M, C, q, qd, tau, qdd, lo, hi);
+      else rows_forward_dynamics<double, N, false>(M, C, q, qd, tau, qdd, lo, hi);
+    });
+  })
+  return MP_OK;
+}
+
+int mp_fd_trajectory_cpu_f32(const mp_model* model, const float* theta0, const float* dtheta0, const float* taumat,
+                             const float* Ftipmat, int64_t B, int64_t N, const double* g, double dt, int intRes, float* pos,
+                             float* vel, float* acc, int nthreads) {
+  return fd_trajectory_cpu<float>(model, theta0, dtheta0, taumat, Ftipmat, B, N, g, dt, intRes, pos, vel, acc, nthreads);
+}
+int mp_fd_trajectory_cpu_f64(const mp_model* model, const double* theta0, const double* dtheta0, const double* taumat,
+                             const double* Ftipmat, int64_t B, int64_t N, const double* g, double dt, int intRes, float* pos,
+                             float* vel, float* acc, int nthreads) {
+  return fd_trajectory_cpu<double>(model, theta0, dtheta0, taumat, Ftipmat, B, N, g, dt, intRes, pos, vel, acc, nthreads);
+}
+
+int mp_cartesian_trajectory_cpu_f32(const double* Xstart, const double* Xend, int64_t B, int64_t N, double Tf, int method,
+                                    float* pos, float* vel, float* acc, float* orient, int nthreads) {
+  if (B < 0 || N < 0) return fail("mp_cartesian_trajectory_cpu_f32: negative count");
+  if (B == 0 || N == 0) return MP_OK;
+  if (N < 2) return fail("mp_cartesian_trajectory_cpu_f32: N must be >= 2");
+  if (!Xstart || !Xend || !pos || !vel || !acc || !orient) return fail("mp_cartesian_trajectory_cpu_f32: null pointer");
+  parallel_for(B * N, 512, nthreads, [&](int64_t lo, int64_t hi) {
+    for (int64_t r = lo; r < hi; ++r) {
+      const int64_t b = r / N, i = r - b * N;
+      double A[16], E[16];
+      std::memcpy(A, Xstart + b * 16, sizeof A);
+      std::memcpy(E, Xend + b * 16, sizeof E);
+      float p[3], v[3], a[3], o[9];
+      mp_cartesian_point(A, E, (long)i, (long)N, Tf, method, p, v, a, o);
+      std::memcpy(pos + r * 3, p, sizeof p); std::memcpy(vel + r * 3, v, sizeof v); std::memcpy(acc + r * 3, a, sizeof a);
+      std::memcpy(orient + r * 9, o, sizeof o);
+    }
+  });
+  return MP_OK;
+}
+
+}  // extern "C"

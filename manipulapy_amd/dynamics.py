@@ -3,7 +3,8 @@
 Same constructor signature (dynamics/manipulator_dynamics.py:43-86) and the same public methods:
 mass_matrix (mass_matrix.py:16-99), velocity_quadratic_forces / gravity_forces (forces.py:26-133),
 inverse_dynamics / forward_dynamics (id_fd.py:16-83), partial_derivative (forces.py:16-24).
-Every method evaluates a HIP kernel through the kernel registry (float64):
+Every method runs a registered operation through the kernel registry (float64): its HIP kernel with the "hip" backend
+active, its CPU launcher (the C ABI's *_cpu twin, same per-row code) with the NumPy backend active:
 
     inverse_dynamics(q, qd, qdd, g, F)      "dynamics.inverse_trajectory"   ID(q, qd, qdd, g, F)
     gravity_forces(q, g)                    "dynamics.inverse_trajectory"   ID(q, 0, 0, g, 0)
@@ -18,8 +19,8 @@ analytic recursion does not need) and no legacy (Mlist_per_link=None) approximat
 """
 from __future__ import annotations
 
+import logging
 import os
-
 from typing import Optional
 
 import numpy as np
@@ -30,6 +31,8 @@ from .registry import execute_registered_kernel
 
 __all__ = ["ManipulatorDynamics"]
 
+logger = logging.getLogger("ManipulaPy.dynamics")
+
 _ZERO3 = np.zeros(3)
 
 
@@ -39,6 +42,7 @@ class ManipulatorDynamics(SerialManipulator):
         self.Glist = Glist
         self.Mlist_per_link = Mlist_per_link
         self._dyn_model: Optional[_hip.HipModel] = None
+        self._spec_tried = False
 
     # ---- compiled model
     def hip_model(self, joint_limits=None, torque_limits=None) -> _hip.HipModel:
@@ -60,13 +64,15 @@ class ManipulatorDynamics(SerialManipulator):
         """The shared model; for big batches it is specialised first (~2 s once, cached on disk: the per-row forward
         dynamics kernel runs 3x faster with this robot's constants baked in)."""
         model = self.hip_model()
-        if rows >= 16384 and os.environ.get("MANIPULAPY_HIP_SPECIALIZE", "1") != "0":
-            try:
-                from .registry import get_context
+        if rows >= 16384 and os.environ.get("MANIPULAPY_HIP_SPECIALIZE", "1") != "0" and not self._spec_tried:
+            from .registry import _hip_routing_enabled, get_context
 
-                get_context().specialize(model)
-            except Exception:  # no hiprtc: the generic kernels serve
-                pass
+            if _hip_routing_enabled():
+                self._spec_tried = True
+                try:
+                    get_context().specialize(model)
+                except _hip.HipError as exc:  # e.g. no hiprtc on this machine: the generic GPU kernels serve
+                    logger.warning("kernel specialisation unavailable (%s); using the generic kernels", exc)
         return model
 
     def _id(self, q, qd, qdd, g, Ftip) -> np.ndarray:

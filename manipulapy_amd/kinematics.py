@@ -7,6 +7,7 @@ plotting and the other concerns of the reference class are out of scope (SURVEY 
 """
 from __future__ import annotations
 
+import logging
 import os
 
 from typing import List, Optional, Tuple
@@ -121,12 +122,13 @@ class SerialManipulator:
         projection box (None = open end)."""
         model = self._kin_model()
         if np.shape(T_desired_batch)[0] >= 16384 and os.environ.get("MANIPULAPY_HIP_SPECIALIZE", "1") != "0":
-            try:  # big batch: the ~2 s (first time; cached on disk) of baking this robot's constants in pays for itself
-                from .registry import get_context
+            from .registry import _hip_routing_enabled, get_context
 
-                get_context().specialize(model)
-            except Exception:  # no hiprtc: the generic kernel serves
-                pass
+            if _hip_routing_enabled():  # big batch: the ~2 s (first time; cached on disk) of baking this robot's constants in pays for itself
+                try:
+                    get_context().specialize(model)
+                except _hip.HipError as exc:  # e.g. no hiprtc on this machine: the generic GPU kernel serves
+                    logging.getLogger("ManipulaPy.kinematics").warning("kernel specialisation unavailable (%s); using the generic kernel", exc)
         theta, ok, it, _ = execute_registered_kernel(
             "kinematics.inverse", model, T_desired_batch, thetalist0_batch, joint_limits=self.joint_limits, eomg=eomg,
             ev=ev, max_iterations=max_iterations, damping=damping, step_cap=step_cap, weight_orientation=weight_orientation,

@@ -12,9 +12,13 @@ clipping, default gravity / zero wrench.
 What is different, on purpose:
   * a failing GPU launch raises instead of silently recomputing on the CPU
     (reference planning/trajectory.py:270-274, trajectory_dynamics.py:292-302);
-  * the dynamics have no CPU twin here: with the NumPy backend (or use_cuda=False)
-    inverse_dynamics_trajectory raises BackendNotSupportedError — the reference remains the CPU
-    implementation; trajectory GENERATION does have its NumPy path (BASELINE config 0);
+  * with the NumPy backend active (or use_cuda=False) every operation runs its registered CPU launcher
+    (NumPy for trajectory generation, the C ABI's *_cpu twins for the dynamics), as the reference's
+    planner runs its _*_cpu methods; with the "hip" backend active and no usable GPU it raises instead
+    of quietly computing on the host;
+  * with the "hip" backend the dynamics always go to the device (the reference applies its work
+    threshold to them too; a launch costs microseconds here, so the threshold only steers trajectory
+    generation, whose NumPy path is BASELINE config 0);
   * collision avoidance is absent (host-only, mesh-dependent, a no-op without meshes — SURVEY §8c);
   * `batch_inverse_dynamics_trajectory` is new: joint_trajectory -> inverse_dynamics_trajectory fused
     on the device for B start/end pairs; `batch_forward_dynamics_trajectory` is new: B roll-outs of
@@ -57,6 +61,7 @@ class OptimizedTrajectoryPlanning:
         self.performance_stats = {"gpu_calls": 0, "cpu_calls": 0, "total_gpu_time": 0.0, "total_cpu_time": 0.0,
                                   "memory_transfers": 0, "kernel_launches": 0, "speedup_achieved": 0.0,
                                   "best_kernel_used": "none"}
+        self.performance_stats.update({"gpu_kernel_ms_total": 0.0, "gpu_kernel_ms_last": 0.0, "gpu_timed_calls": 0})
         del auto_optimize, memory_pool_size_mb  # CUDA-environment knobs with no HIP counterpart
 
         physical = _reg.check_hip_availability()
@@ -78,6 +83,10 @@ class OptimizedTrajectoryPlanning:
         else:
             self.cpu_threshold = int(cuda_threshold)
         self._model = None
+        # reference planning/trajectory_planning.py:295-296 (profile_start): here a timed HIP event pair and an roctx
+        # range around every launch of the context, read back into performance_stats after each GPU call
+        if self.enable_profiling and self.cuda_available and self._gpu_routed():
+            _reg.get_context().set_profiling(True)
 
     # ------------------------------------------------------------------ plumbing
     def _hip_model(self):
@@ -115,8 +124,28 @@ class OptimizedTrajectoryPlanning:
         if kind == "gpu":
             self.performance_stats["kernel_launches"] += 1
             self.performance_stats["best_kernel_used"] = "hip"
+            if self.enable_profiling:
+                p = _reg.get_context().profile()
+                self.performance_stats.update({"gpu_kernel_ms_total": p["kernel_ms_total"], "gpu_kernel_ms_last": p["kernel_ms_last"],
+                                               "gpu_timed_calls": p["timed_calls"]})
         else:
             self._last_cpu_time = dt
+
+    def _dispatch(self, name: str, *args, **kwargs):
+        """Run a registered operation where the routing rule sends it: the GPU launcher when the "hip" backend is active
+        and a device is there, otherwise the CPU launcher (NumPy backend, or this planner pinned to the CPU with
+        use_cuda=False).  "hip" backend without a usable device: raises (registry._refuse_silent_cpu)."""
+        entry = _reg.get_registered_kernel(name)
+        t0 = time.time()
+        if self._gpu_routed():
+            out = entry.gpu_launcher(*args, **kwargs)
+            self._count("gpu", t0)
+        else:
+            if not self._forced_cpu:
+                _reg._refuse_silent_cpu(name)
+            out = entry.cpu_launcher(*args, **kwargs)
+            self._count("cpu", t0)
+        return out
 
     def _clip_positions(self, pos: np.ndarray) -> np.ndarray:
         return np.clip(pos, self.joint_limits[:, 0], self.joint_limits[:, 1])
@@ -179,11 +208,7 @@ class OptimizedTrajectoryPlanning:
 
     def batch_cartesian_trajectory(self, Xstart_batch, Xend_batch, Tf, N, method) -> Dict[str, np.ndarray]:
         """B pose pairs (B, 4, 4) in one launch -> (B, N, 3) / (B, N, 3, 3) float32 arrays.  New."""
-        t0 = time.time()
-        if not self._gpu_routed():
-            _reg.get_registered_kernel("trajectory.cartesian").cpu_launcher()  # raises BackendNotSupportedError
-        pos, vel, acc, ori = _reg.execute_registered_kernel("trajectory.cartesian", Xstart_batch, Xend_batch, Tf, int(N), int(method))
-        self._count("gpu", t0)
+        pos, vel, acc, ori = self._dispatch("trajectory.cartesian", Xstart_batch, Xend_batch, Tf, int(N), int(method))
         b = get_backend()
         return {"positions": b.asarray(pos), "velocities": b.asarray(vel), "accelerations": b.asarray(acc),
                 "orientations": b.asarray(ori)}
@@ -204,13 +229,9 @@ class OptimizedTrajectoryPlanning:
             raise ValueError(f"trajectories must be (N, n); got {q.shape}")
         if q.shape[0] == 0:
             return np.zeros(q.shape, dtype=np.float32)
-        t0 = time.time()
-        if not self._gpu_routed():
-            _reg.get_registered_kernel("dynamics.inverse_trajectory").cpu_launcher()  # raises BackendNotSupportedError
         dtype = np.float64 if q.dtype == np.float64 else np.float32
-        tau = _reg.execute_registered_kernel("dynamics.inverse_trajectory", self._hip_model(), q, dthetalist_trajectory,
-                                             ddthetalist_trajectory, gravity_vector, Ftip, dtype=dtype)
-        self._count("gpu", t0)
+        tau = self._dispatch("dynamics.inverse_trajectory", self._hip_model(), q, dthetalist_trajectory,
+                             ddthetalist_trajectory, gravity_vector, Ftip, dtype=dtype)
         return get_backend().asarray(tau.astype(np.float32, copy=False))
 
     def batch_inverse_dynamics_trajectory(self, thetastart_batch, thetaend_batch, Tf, N, method, gravity_vector=None,
@@ -223,12 +244,8 @@ class OptimizedTrajectoryPlanning:
             raise ValueError(f"start/end batches must both be (B, n); got {sb.shape} and {eb.shape}")
         if sb.shape[0] == 0:
             return np.zeros((0, int(N), sb.shape[1]), dtype=np.float32)
-        t0 = time.time()
-        if not self._gpu_routed():
-            _reg.get_registered_kernel("dynamics.fused_trajectory_inverse").cpu_launcher()
-        tau = _reg.execute_registered_kernel("dynamics.fused_trajectory_inverse", self._hip_model(), sb, eb, Tf, int(N),
-                                             int(method), gravity_vector, Ftip)
-        self._count("gpu", t0)
+        tau = self._dispatch("dynamics.fused_trajectory_inverse", self._hip_model(), sb, eb, Tf, int(N), int(method),
+                             gravity_vector, Ftip)
         return get_backend().asarray(tau)
 
     def forward_dynamics_trajectory(self, thetalist, dthetalist, taumat, g, Ftipmat, dt, intRes) -> Dict[str, np.ndarray]:
@@ -253,14 +270,10 @@ class OptimizedTrajectoryPlanning:
         if th.ndim != 2:
             raise ValueError(f"initial states must be (B, n); got {th.shape}")
         dtype = np.float32 if th.dtype == np.float32 else np.float64
-        t0 = time.time()
-        if not self._gpu_routed():
-            _reg.get_registered_kernel("dynamics.forward_trajectory").cpu_launcher()  # raises BackendNotSupportedError
         if g is None:
             g = np.array([0.0, 0.0, -9.81])
-        pos, vel, acc = _reg.execute_registered_kernel("dynamics.forward_trajectory", self._hip_model(), th, dtheta0_batch,
-                                                       taumat_batch, g, Ftipmat_batch, dt, int(intRes), dtype=dtype)
-        self._count("gpu", t0)
+        pos, vel, acc = self._dispatch("dynamics.forward_trajectory", self._hip_model(), th, dtheta0_batch, taumat_batch, g,
+                                       Ftipmat_batch, dt, int(intRes), dtype=dtype)
         b = get_backend()
         return {"positions": b.asarray(pos), "velocities": b.asarray(vel), "accelerations": b.asarray(acc)}
 
@@ -276,7 +289,10 @@ class OptimizedTrajectoryPlanning:
     def reset_performance_stats(self) -> None:
         """reference planning/trajectory_planning.py:489-500."""
         self.performance_stats = {"gpu_calls": 0, "cpu_calls": 0, "total_gpu_time": 0.0, "total_cpu_time": 0.0,
-                                  "memory_transfers": 0, "kernel_launches": 0, "speedup_achieved": 0.0, "best_kernel_used": "none"}
+                                  "memory_transfers": 0, "kernel_launches": 0, "speedup_achieved": 0.0, "best_kernel_used": "none",
+                                  "gpu_kernel_ms_total": 0.0, "gpu_kernel_ms_last": 0.0, "gpu_timed_calls": 0}
+        if self.enable_profiling and self._gpu_routed():
+            _reg.get_context().profile(reset=True)
 
     def cleanup_gpu_memory(self) -> None:
         """Return the context's pooled device buffers to the driver (reference planning/trajectory_planning.py:502-524)."""
@@ -286,7 +302,20 @@ class OptimizedTrajectoryPlanning:
             ctx.trim_pool()
 
     def get_performance_stats(self) -> Dict[str, float]:
-        return dict(self.performance_stats)
+        """reference planning/trajectory_planning.py:440-487: the counters plus averages, GPU share, overall speed-up and
+        the EWMA adaptation of the CPU / GPU work threshold (kept within the reference's [50, 5000] band)."""
+        stats = dict(self.performance_stats)
+        stats["avg_gpu_time"] = stats["total_gpu_time"] / stats["gpu_calls"] if stats["gpu_calls"] > 0 else 0.0
+        stats["avg_cpu_time"] = stats["total_cpu_time"] / stats["cpu_calls"] if stats["cpu_calls"] > 0 else 0.0
+        total = stats["gpu_calls"] + stats["cpu_calls"]
+        stats["gpu_usage_percent"] = stats["gpu_calls"] / total * 100 if total > 0 else 0.0
+        stats["overall_speedup"] = (stats["total_cpu_time"] / stats["total_gpu_time"]
+                                    if stats["total_gpu_time"] > 0 and stats["total_cpu_time"] > 0 else 0.0)
+        if stats["avg_gpu_time"] > 0 and stats["avg_cpu_time"] > 0:
+            ratio = stats["avg_cpu_time"] / stats["avg_gpu_time"]
+            self.cpu_threshold = int(0.9 * self.cpu_threshold + 0.1 * ratio * self.cpu_threshold)
+            self.cpu_threshold = max(50, min(self.cpu_threshold, 5000))
+        return stats
 
 
 TrajectoryPlanning = OptimizedTrajectoryPlanning  # alias kept by the reference (planning/__init__.py)

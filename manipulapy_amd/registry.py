@@ -10,9 +10,11 @@ Reference semantics kept:
 
 Deliberate difference: the reference's GPU launchers swallow every exception and return the CPU
 result (trajectory_kernels.py:1083-1086).  Here a GPU launcher that fails RAISES — a silent CPU
-recompute would make every parity/throughput claim about the HIP path meaningless.  Operations
-that have no NumPy implementation in this build (the dynamics) raise `BackendNotSupportedError` from
-their cpu_launcher instead of computing on the host.
+recompute would make every parity/throughput claim about the HIP path meaningless.  The CPU
+launchers (NumPy for trajectory generation and the potential field, the C ABI's *_cpu twins for the
+dynamics / kinematics) are reached only through the routing rule above, i.e. with the NumPy backend
+active; with the "hip" backend active and no usable device `execute` raises instead of computing on
+the host.  Batched IK has no CPU launcher (`BackendNotSupportedError`).
 """
 from __future__ import annotations
 
@@ -75,8 +77,10 @@ class KernelRegistry:
 
     def execute(self, name: str, *args: Any, **kwargs: Any) -> Any:
         entry = self.get(name)
-        launcher = entry.gpu_launcher if _hip_routing_enabled() else entry.cpu_launcher
-        return launcher(*args, **kwargs)
+        if _hip_routing_enabled():
+            return entry.gpu_launcher(*args, **kwargs)
+        _refuse_silent_cpu(name)
+        return entry.cpu_launcher(*args, **kwargs)
 
 
 # ------------------------------------------------------------------------------ device probe / ctx
@@ -102,6 +106,16 @@ def check_hip_availability() -> bool:
                 except _hip.HipUnavailableError:
                     _probe_result = False
         return _probe_result
+
+
+def _refuse_silent_cpu(name: str) -> None:
+    """The CPU launchers serve the NumPy backend.  With the "hip" backend ACTIVE and no usable device the reference's rule
+    would quietly hand the work to the CPU; here that is an error (a GPU box whose HIP path is broken must not pass as
+    working), unless the caller pinned the CPU on purpose with MANIPULAPY_FORCE_CPU=1 (reference tests/conftest.py:85)."""
+    if getattr(get_backend(), "gpu_capable", False) and os.environ.get("MANIPULAPY_FORCE_CPU") != "1":
+        raise _hip.HipUnavailableError(
+            f"'{name}': the 'hip' backend is active but no MI355X is usable in this process; refusing to compute on the CPU "
+            "silently (select the NumPy backend, or set MANIPULAPY_FORCE_CPU=1, to run the CPU launchers on purpose)")
 
 
 def _reset_probe_for_tests(value: Optional[bool] = None) -> None:
@@ -211,9 +225,47 @@ def _no_cpu(name: str) -> Callable[..., Any]:
     def launcher(*_a: Any, **_k: Any) -> Any:
         raise BackendNotSupportedError(
             f"'{name}' exists only on the HIP path of manipulapy_amd: it needs set_backend('hip') AND a "
-            "visible MI355X (no CPU twin is shipped; the reference's NumPy backend remains the CPU "
-            "implementation)")
+            "visible MI355X (no CPU twin is shipped for this operation)")
     return launcher
+
+
+# CPU launchers of the dynamics / kinematics operations: the C ABI's *_cpu twins (csrc/mp_cpu.cpp - the same per-row
+# templates the kernels instantiate, on host threads).  The registry picks them by the reference's rule (NumPy backend
+# active, registry.py:85-89); they are never a fallback of a failing GPU launch.
+def _launch_id_cpu(model, q, qd, qdd, g=None, Ftip=None, dtype=np.float32):
+    return _hip.cpu_id_trajectory(model, q, qd, qdd, g, Ftip, dtype=dtype)
+
+
+def _launch_fused_cpu(model, start_batch, end_batch, Tf, N, method, g=None, Ftip=None):
+    """joint_trajectory -> inverse_dynamics_trajectory for B start / end pairs: NumPy generation (the reference's own
+    CPU arithmetic, float32 rows, positions clipped to the model's float32 joint limits) then the float32 CPU twin."""
+    sb = np.asarray(start_batch, dtype=np.float32)
+    pos, vel, acc = trajectory_cpu(sb, np.asarray(end_batch, dtype=np.float32), float(Tf), int(N), int(method))
+    lim = model.joint_limits_f32()
+    pos = np.clip(pos, lim[:, 0], lim[:, 1])
+    n = sb.shape[1]
+    tau = _hip.cpu_id_trajectory(model, pos.reshape(-1, n), vel.reshape(-1, n), acc.reshape(-1, n), g, Ftip, dtype=np.float32)
+    return tau.reshape(sb.shape[0], int(N), n)
+
+
+def _launch_fk_jac_cpu(model, q, qd=None, qdd=None, g=None, Ftip=None, want_T=True, want_J=True):
+    return _hip.cpu_fk_jac_id(model, q, qd, qdd, g, Ftip, want_T, want_J)
+
+
+def _launch_mass_matrix_cpu(model, q):
+    return _hip.cpu_mass_matrix(model, q)
+
+
+def _launch_forward_dynamics_cpu(model, q, qd, tau, g=None, Ftip=None):
+    return _hip.cpu_forward_dynamics(model, q, qd, tau, g, Ftip)
+
+
+def _launch_fd_trajectory_cpu(model, theta0, dtheta0, taumat, g, Ftipmat, dt, intRes, dtype=np.float64):
+    return _hip.cpu_fd_trajectory(model, theta0, dtheta0, taumat, g, Ftipmat, dt, intRes, dtype=dtype)
+
+
+def _launch_cartesian_cpu(Xstart, Xend, Tf, N, method):
+    return _hip.cpu_cartesian_trajectory(Xstart, Xend, Tf, N, method)
 
 
 def _launch_trajectory_gpu(model, thetastart, thetaend, Tf, N, method, use_pinned=True, *, variant="auto",
@@ -321,19 +373,19 @@ def _build_kernel_registry() -> KernelRegistry:
         name="potential_field.fused", implementation="mp_potential_field_host_f32", launch_config=_grid_1d,
         cpu_fallback=potential_field_cpu, gpu_launcher=_launch_potential_field_gpu, cpu_launcher=_launch_potential_field_cpu,
         metadata={"family": "potential_field", "variant": "fused", "dimensions": 1}))
-    for name, impl, gpu in (
-        ("dynamics.inverse_trajectory", "mp_id_trajectory_host_f32 / _f64", _launch_id_gpu),
-        ("dynamics.fused_trajectory_inverse", "mp_traj_id_fused_host_f32", _launch_fused_gpu),
-        ("kinematics.fk_jacobian", "mp_fk_jac_id_host_f64", _launch_fk_jac_gpu),
-        ("kinematics.inverse", "mp_inverse_kinematics_host_f64", _launch_ik_gpu),
-        ("dynamics.mass_matrix", "mp_mass_matrix_host_f64", _launch_mass_matrix_gpu),
-        ("dynamics.forward", "mp_forward_dynamics_host_f64", _launch_forward_dynamics_gpu),
-        ("dynamics.forward_trajectory", "mp_fd_trajectory_host_f32 / _f64", _launch_fd_trajectory_gpu),
-        ("trajectory.cartesian", "mp_cartesian_trajectory_host_f32", _launch_cartesian_gpu),
+    for name, impl, gpu, cpu in (
+        ("dynamics.inverse_trajectory", "mp_id_trajectory_host_f32 / _f64", _launch_id_gpu, _launch_id_cpu),
+        ("dynamics.fused_trajectory_inverse", "mp_traj_id_fused_host_f32", _launch_fused_gpu, _launch_fused_cpu),
+        ("kinematics.fk_jacobian", "mp_fk_jac_id_host_f64", _launch_fk_jac_gpu, _launch_fk_jac_cpu),
+        ("kinematics.inverse", "mp_inverse_kinematics_host_f64", _launch_ik_gpu, None),
+        ("dynamics.mass_matrix", "mp_mass_matrix_host_f64", _launch_mass_matrix_gpu, _launch_mass_matrix_cpu),
+        ("dynamics.forward", "mp_forward_dynamics_host_f64", _launch_forward_dynamics_gpu, _launch_forward_dynamics_cpu),
+        ("dynamics.forward_trajectory", "mp_fd_trajectory_host_f32 / _f64", _launch_fd_trajectory_gpu, _launch_fd_trajectory_cpu),
+        ("trajectory.cartesian", "mp_cartesian_trajectory_host_f32", _launch_cartesian_gpu, _launch_cartesian_cpu),
     ):
         reg.register(KernelRegistration(
-            name=name, implementation=impl, launch_config=_grid_1d, cpu_fallback=None, gpu_launcher=gpu,
-            cpu_launcher=_no_cpu(name), metadata={"family": name.split(".")[0], "variant": "hip", "dimensions": 1}))
+            name=name, implementation=impl, launch_config=_grid_1d, cpu_fallback=cpu, gpu_launcher=gpu,
+            cpu_launcher=cpu or _no_cpu(name), metadata={"family": name.split(".")[0], "variant": "hip", "dimensions": 1}))
     return reg
 
 

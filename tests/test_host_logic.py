@@ -45,14 +45,118 @@ def test_no_gpu_means_loud_failure_not_fallback():
     with pytest.raises(_hip.HipUnavailableError):
         _hip.HipContext(0)
     sm, dyn, lim = mp.load_robot("ur5")
-    with mp.use_backend("hip"):
-        with pytest.raises(mp.BackendNotSupportedError):
+    with mp.use_backend("hip"):  # "hip" selected, no device: every operation refuses instead of running its CPU launcher
+        with pytest.raises(_hip.HipUnavailableError):
             dyn.mass_matrix(np.zeros(6))
+        with pytest.raises(_hip.HipUnavailableError):
+            sm.forward_kinematics(np.zeros(6))
         pl = mp.OptimizedTrajectoryPlanning(sm, None, dyn, lim)
-        with pytest.raises(mp.BackendNotSupportedError):
+        with pytest.raises(_hip.HipUnavailableError):
             pl.inverse_dynamics_trajectory(np.zeros((3, 6)), np.zeros((3, 6)), np.zeros((3, 6)))
+        with pytest.raises(_hip.HipUnavailableError):
+            pl.forward_dynamics_trajectory(np.zeros(6), np.zeros(6), np.zeros((3, 6)), None, None, 0.01, 1)
         with pytest.raises(RuntimeError):
             mp.OptimizedTrajectoryPlanning(sm, None, dyn, lim, use_cuda=True)
+        with pytest.raises(mp.BackendNotSupportedError):  # batched IK has no CPU launcher at all
+            mp.get_registered_kernel("kinematics.inverse").cpu_launcher()
+
+
+# ----------------------------------------------------------------------------- CPU twins behind the same ABI
+@pytest.mark.parametrize("robot", ROBOTS)
+def test_cpu_twins_match_reference_goldens(robot, tables, dyn_golden):
+    """The C ABI's *_cpu entry points (csrc/mp_cpu.cpp: the kernels' per-row templates on host threads) against the
+    reference's outputs at the reference's own tolerances (tests/test_dynamics_golden.py:77-83) - the same fixtures the
+    GPU parity tests use, through the NumPy backend's routing."""
+    tab, z = tables[robot], dyn_golden[robot]
+    m = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee, tab.joint_limits)
+    K, n = len(z["thetas"]), tab.n
+    M = _hip.cpu_mass_matrix(m, z["thetas"])
+    np.testing.assert_allclose(M, z["mass_matrix"], rtol=1e-7, atol=1e-9)
+    T, J, _ = _hip.cpu_fk_jac_id(m, z["thetas"])
+    np.testing.assert_allclose(T, z["fk_space"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(J, z["jac_space"], rtol=1e-9, atol=1e-9)
+    for i in range(K):  # per-row wrench
+        a = (z["thetas"][i:i + 1], z["dthetas"][i:i + 1], z["ddthetas"][i:i + 1], z["g"], z["ftips"][i])
+        tau = _hip.cpu_id_trajectory(m, *a, dtype=np.float64)
+        np.testing.assert_allclose(tau[0], z["inverse_dynamics"][i], rtol=1e-6, atol=1e-7)
+        _, _, tau2 = _hip.cpu_fk_jac_id(m, *a, want_T=False, want_J=False)
+        np.testing.assert_array_equal(tau2, tau)
+        t32 = _hip.cpu_id_trajectory(m, *a, dtype=np.float32)
+        assert np.abs(t32[0] - z["inverse_dynamics"][i]).max() <= 1e-4 * np.abs(z["inverse_dynamics"][i]).max() + 1e-5
+        qdd = _hip.cpu_forward_dynamics(m, z["thetas"][i:i + 1], z["dthetas"][i:i + 1], z["inverse_dynamics"][i:i + 1], z["g"], z["ftips"][i])
+        np.testing.assert_allclose(qdd[0], z["ddthetas"][i], rtol=1e-6, atol=1e-6)
+    zero = np.zeros_like(z["thetas"])
+    np.testing.assert_allclose(_hip.cpu_id_trajectory(m, z["thetas"], zero, zero, z["g"], None, dtype=np.float64), z["gravity_forces"],
+                               rtol=1e-7, atol=1e-8)
+    np.testing.assert_allclose(_hip.cpu_id_trajectory(m, z["thetas"], z["dthetas"], zero, np.zeros(3), None, dtype=np.float64),
+                               z["velocity_quadratic_forces"], rtol=1e-6, atol=1e-7)
+    # threads: one thread and many give the same bits (rows are independent)
+    big = np.tile(z["thetas"], (40, 1))
+    a1 = _hip.cpu_id_trajectory(m, big, big * 0.3, big * -0.2, dtype=np.float64, nthreads=1)
+    a8 = _hip.cpu_id_trajectory(m, big, big * 0.3, big * -0.2, dtype=np.float64, nthreads=8)
+    np.testing.assert_array_equal(a1, a8)
+
+
+def test_numpy_backend_computes_through_the_cpu_twins(tables, dyn_golden):
+    """Default (NumPy) backend: SerialManipulator / ManipulatorDynamics / the planner compute (the reference computes there
+    too: kinematics/fk.py:39-86, dynamics/id_fd.py:16-83, planning/trajectory_dynamics.py:308-380, :580-708)."""
+    assert not mp.get_backend().gpu_capable
+    z = dyn_golden["ur5"]
+    sm, dyn, lim = mp.load_robot("ur5")
+    i = 7
+    np.testing.assert_allclose(dyn.mass_matrix(z["thetas"][i]), z["mass_matrix"][i], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(dyn.inverse_dynamics(z["thetas"][i], z["dthetas"][i], z["ddthetas"][i], z["g"], z["ftips"][i]),
+                               z["inverse_dynamics"][i], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(dyn.gravity_forces(z["thetas"][i], z["g"]), z["gravity_forces"][i], rtol=1e-7, atol=1e-8)
+    np.testing.assert_allclose(dyn.forward_dynamics(z["thetas"][i], z["dthetas"][i], z["inverse_dynamics"][i], z["g"], z["ftips"][i]),
+                               z["ddthetas"][i], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(sm.forward_kinematics(z["thetas"][i]), z["fk_space"][i], atol=1e-9)
+    np.testing.assert_allclose(sm.jacobian(z["thetas"][i]), z["jac_space"][i], atol=1e-9)
+    np.testing.assert_allclose(sm.jacobian(z["thetas"][i], frame="body"), z["jac_body"][i], atol=1e-9)
+    t = np.load(golden_path("trajectory_ur5.npz"))
+    pl = mp.OptimizedTrajectoryPlanning(sm, None, dyn, t["joint_limits"])
+    tau = pl.inverse_dynamics_trajectory(t["idt_q"], t["idt_qd"], t["idt_qdd"])
+    assert tau.dtype == np.float32
+    np.testing.assert_allclose(tau, t["idt_tau_f32"], rtol=1e-5, atol=1e-5)
+    pl2 = mp.OptimizedTrajectoryPlanning(sm, None, dyn, t["joint_limits"], torque_limits=t["idt_torque_limits"])
+    np.testing.assert_allclose(pl2.inverse_dynamics_trajectory(t["idt_q"][:16], t["idt_qd"][:16], t["idt_qdd"][:16], None, t["idt_ftip"]),
+                               t["idt_tau_f32_clip_ftip"], rtol=1e-5, atol=1e-5)
+    assert pl.performance_stats["cpu_calls"] == 1 and pl.performance_stats["gpu_calls"] == 0
+    # fused generation + inverse dynamics == the two-step pipeline, bit for bit on the CPU path
+    s, e = t["batch_start"], t["batch_end"]
+    fused = pl.batch_inverse_dynamics_trajectory(s, e, 2.0, 16, 5)
+    r = pl.batch_joint_trajectory(s, e, 2.0, 16, 5)
+    two = pl.inverse_dynamics_trajectory(r["positions"].reshape(-1, 6), r["velocities"].reshape(-1, 6), r["accelerations"].reshape(-1, 6))
+    np.testing.assert_array_equal(fused.reshape(-1, 6), two)
+    # roll-out (xarm6): the reference's N = 8 / intRes = 2 dump and its N = 100 dump
+    sm6, dyn6, _ = mp.load_robot("xarm6")
+    f = np.load(golden_path("fd_trajectory_xarm6.npz"))
+    pl6 = mp.OptimizedTrajectoryPlanning(sm6, None, dyn6, f["joint_limits"])
+    r = pl6.forward_dynamics_trajectory(f["theta0"], f["dtheta0"], f["taumat"], f["g"], f["Ftipmat"], float(f["dt"]), int(f["intRes"]))
+    for k in ("positions", "velocities", "accelerations"):
+        assert r[k].dtype == np.float32
+        np.testing.assert_allclose(r[k], f[k], rtol=2e-6, atol=2e-6 * max(1.0, float(np.abs(f[k]).max())))
+    f = np.load(golden_path("fd_rollout100_xarm6.npz"))
+    rb = pl6.batch_forward_dynamics_trajectory(f["theta0"], f["dtheta0"], f["taumat"], f["g"], f["Ftipmat"], 0.01, 1)
+    for k, tol in (("positions", 1e-6), ("velocities", 2e-6), ("accelerations", 1e-5)):
+        assert np.abs(rb[k] - f[k]).max() <= tol * np.abs(f[k]).max(), k
+    r32 = pl6.batch_forward_dynamics_trajectory(f["theta0"].astype(np.float32), f["dtheta0"].astype(np.float32),
+                                                f["taumat"].astype(np.float32), f["g"], f["Ftipmat"].astype(np.float32), 0.01, 1)
+    for k in ("positions", "velocities", "accelerations"):
+        assert np.abs(r32[k] - f[k]).max() <= 1e-4 * np.abs(f[k]).max(), k   # north_star's float32 bound at N = 100
+    # Cartesian path
+    c = np.load(golden_path("cartesian_ur5.npz"))
+    got = pl.cartesian_trajectory(c["Xstart"], c["generic_Xend"], 2.0, 21, 5)
+    for k in ("positions", "velocities", "accelerations", "orientations"):
+        np.testing.assert_allclose(got[k], c[f"generic_m5_{k}"], rtol=2e-6, atol=2e-6)
+    # the non-finite row contract holds on the CPU twins too
+    nf = np.load(golden_path("nonfinite.npz"))
+    tau = mp.OptimizedTrajectoryPlanning(sm, None, dyn, nf["joint_limits"]).inverse_dynamics_trajectory(nf["id_q"], nf["id_qd"], nf["id_qdd"], None, nf["id_ftip"])
+    np.testing.assert_array_equal(np.isfinite(tau), np.isfinite(nf["id_tau"]))
+    pl7 = mp.OptimizedTrajectoryPlanning(sm6, None, dyn6, nf["fd_joint_limits"])
+    r = pl7.forward_dynamics_trajectory(nf["fd_theta0"], nf["fd_dtheta0"], nf["fd_taumat"], None, nf["fd_Ftipmat"], 0.01, 1)
+    for k in ("positions", "velocities", "accelerations"):
+        np.testing.assert_array_equal(np.isfinite(r[k]), np.isfinite(nf["fd_" + k]))
 
 
 def test_product_never_imports_the_oracle():
@@ -372,6 +476,11 @@ def test_routing_predicate_and_execute(monkeypatch):
         assert registry._hip_routing_enabled(False) is False  # explicit physical override
     monkeypatch.setattr(registry, "_probe_result", False)
     with mp.use_backend("hip"):
+        # "hip" selected but no usable device: the reference would run the CPU launcher; here that is refused (a GPU box
+        # with a broken HIP path must not pass as working) unless the CPU was pinned on purpose
+        with pytest.raises(_hip.HipUnavailableError):
+            reg.execute("t.op")
+        monkeypatch.setenv("MANIPULAPY_FORCE_CPU", "1")
         assert reg.execute("t.op") == "C"
     assert calls == ["cpu", "gpu", "cpu"]
 
@@ -395,7 +504,7 @@ def test_gpu_launcher_errors_propagate(monkeypatch):
 
 
 # ----------------------------------------------------------------------------- planner on the NumPy backend
-def test_planner_numpy_backend_config0():
+def test_planner_numpy_backend_config0(tables):
     """BASELINE config 0: UR5 quintic joint_trajectory N=1000 on the NumPy CPU backend (plumbing)."""
     z = np.load(golden_path("trajectory_ur5.npz"))
     sm, dyn, lim = mp.load_robot("ur5")
@@ -421,8 +530,14 @@ def test_planner_numpy_backend_config0():
     assert pl.performance_stats["cpu_calls"] == 3 and pl.performance_stats["gpu_calls"] == 0
     v, a, j = pl.calculate_derivatives(r["positions"], 0.002)
     assert v.shape == (999, 6) and a.shape == (998, 6) and j.shape == (997, 6)
-    with pytest.raises(mp.BackendNotSupportedError):
-        pl.inverse_dynamics_trajectory(r["positions"], r["velocities"], r["accelerations"])
+    # use_cuda=False: the dynamics run their CPU launcher (the reference's _inverse_dynamics_cpu role), float32 rows
+    tau = pl.inverse_dynamics_trajectory(r["positions"][:64], r["velocities"][:64], r["accelerations"][:64])
+    want = ref.inverse_dynamics_trajectory(tables["ur5"], r["positions"][:64].astype(np.float64), r["velocities"][:64].astype(np.float64),
+                                           r["accelerations"][:64].astype(np.float64), dtype=np.float64)
+    assert tau.dtype == np.float32 and np.abs(tau - want).max() <= 1e-4 * np.abs(want).max()
+    assert pl.performance_stats["cpu_calls"] == 4
+    st = pl.get_performance_stats()   # reference planning/trajectory_planning.py:440-487
+    assert st["gpu_usage_percent"] == 0.0 and st["avg_cpu_time"] > 0 and st["overall_speedup"] == 0.0
     with pytest.raises(KeyError):
         with mp.use_backend("hip"):
             registry._reset_probe_for_tests(True)
@@ -461,6 +576,21 @@ def test_two_process_gloo_shard_and_gather(tmp_path):
     z = np.load(out)
     np.testing.assert_array_equal(z["gathered"], z["single"])
     assert z["world"] == 2 and abs(float(z["max_val"]) - 1.0) < 1e-12
+
+
+def test_potential_field_cpu_launcher_against_reference_dump():
+    """The NumPy launcher of "potential_field.fused" (registry.potential_field_cpu) vs the reference's
+    potential_field_cpu_fallback dump (tests/golden/potential_field.npz)."""
+    from manipulapy_amd import registry
+
+    z = np.load(golden_path("potential_field.npz"))
+    for tag in ("d035", "d100", "d000"):
+        u, g = registry.potential_field_cpu(z["positions"], z["goal"], z["obstacles"], float(z[f"{tag}_influence"]))
+        np.testing.assert_allclose(u, z[f"{tag}_potential"], rtol=2e-6, atol=1e-9)
+        scale = np.abs(z[f"{tag}_gradient"]).max(axis=1, keepdims=True)
+        assert (np.abs(g - z[f"{tag}_gradient"]) <= 2e-6 * scale + 1e-9).all(), tag
+    u, g = registry.potential_field_cpu(z["positions"], z["goal"], np.zeros((0, 3)), 0.5)
+    np.testing.assert_array_equal(u, z["noobs_potential"]); np.testing.assert_array_equal(g, z["noobs_gradient"])
 
 
 def test_bench_self_launches_one_worker_per_gpu():
