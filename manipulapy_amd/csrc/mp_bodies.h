@@ -4,6 +4,25 @@
 #pragma once
 
 #include "mp_core.h"
+#include "mp_pair.h"
+
+// float32 forward dynamics: the pair-native recursion of mp_pair.h (one trajectory fills both halves of the packed
+// float32 instructions) unless MP_FD_PAIR=0 selects the scalar recursion of mp_core.h (A/B measurements); float64 always
+// takes the scalar one.
+#ifndef MP_FD_PAIR
+#define MP_FD_PAIR 1
+#endif
+template <typename T, int N, bool HAS_FTIP, typename MT>
+MP_HD void mp_forward_dynamics_auto(const MT& M, const typename MpTraits<T>::S (&a0)[3], const T (&tipn)[3], const T (&tipf)[3],
+                                    const T (&q)[N], const T (&qd)[N], const T (&tau)[N], T (&qdd)[N]) {
+#if MP_HAS_PACKED && MP_FD_PAIR
+  if constexpr (sizeof(T) == 4 && sizeof(typename MpTraits<T>::S) == 4 && N >= 2) {
+    mp_p_forward_dynamics<N, HAS_FTIP>(M, a0, tipn, tipf, q, qd, tau, qdd);
+    return;
+  }
+#endif
+  mp_forward_dynamics<T, N, HAS_FTIP>(M, a0, tipn, tipf, q, qd, tau, qdd);
+}
 
 // ---- widest legal vector type for a run of COUNT elements of T whose start is COUNT*sizeof(T)-strided
 template <typename T, int BYTES> struct VecOf;
@@ -109,7 +128,7 @@ __device__ __forceinline__ void mp_body_fd(const MT& M, const MpCall<T>& C, cons
   RunIO<T, N>::load(qd, r, b);
   RunIO<T, N>::load(tau, r, t);
   const T tn[3] = {C.F1n[0], C.F1n[1], C.F1n[2]}, tf[3] = {C.F1f[0], C.F1f[1], C.F1f[2]};
-  mp_forward_dynamics<T, N, HAS_FTIP>(M, C.a0, tn, tf, a, b, t, out);
+  mp_forward_dynamics_auto<T, N, HAS_FTIP>(M, C.a0, tn, tf, a, b, t, out);
   MpBad<T> bad;
   bad.add(a); bad.add(b); bad.add(t);
   mp_poison_if(bad.any(), out);
@@ -556,7 +575,7 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
           mp_wrench_to_frame1(M, F, tn, tf);
         }
         for (int k = 0; k < intRes; ++k) {
-          mp_forward_dynamics<T, N, HAS_FTIP>(M, C.a0, tn, tf, q, qd, tau, last);
+          mp_forward_dynamics_auto<T, N, HAS_FTIP>(M, C.a0, tn, tf, q, qd, tau, last);
 #pragma unroll
           for (int j = 0; j < N; ++j) {
             qd[j] = qd[j] + last[j] * h;
