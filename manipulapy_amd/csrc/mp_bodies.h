@@ -6,11 +6,14 @@
 #include "mp_core.h"
 #include "mp_pair.h"
 
-// float32 forward dynamics: the pair-native recursion of mp_pair.h (one trajectory fills both halves of the packed
-// float32 instructions) unless MP_FD_PAIR=0 selects the scalar recursion of mp_core.h (A/B measurements); float64 always
-// takes the scalar one.
+// float32 forward dynamics: the scalar recursion of mp_core.h; MP_FD_PAIR=1 selects the pair-native one of mp_pair.h (one
+// trajectory fills both halves of the packed float32 instructions).  Measured on MI355X (tools/ab_c5.sh, config c5): the
+// pair form executes 18 % fewer VALU instructions per step (1153 vs 1412) and is 1-3 % SLOWER - tools/ubench_issue2.hip
+// shows why: on gfx950 a v_pk_fma_f32 occupies the SIMD for ~4 cycles, a scalar v_fma_f32 / v_fmac / v_mul for ~2, so a
+// packed instruction buys no arithmetic throughput, and its constant pairs cost two s_mov_b32 each on top.  Kept as a
+// measured negative result (and as the host-tested second implementation of the same recursion).
 #ifndef MP_FD_PAIR
-#define MP_FD_PAIR 1
+#define MP_FD_PAIR 0
 #endif
 template <typename T, int N, bool HAS_FTIP, typename MT>
 MP_HD void mp_forward_dynamics_auto(const MT& M, const typename MpTraits<T>::S (&a0)[3], const T (&tipn)[3], const T (&tipf)[3],
