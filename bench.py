@@ -63,10 +63,13 @@ def algorithmic_bytes_per_row(cfg, n):
 
 
 def kernel_name(cfg):
+    """The dominant kernel of the step (must match what the launcher picks: csrc/mp_capi.cpp spec_scalar_f32)."""
     spec = cfg.get("specialized")
-    return {"id": ("mp_spec_id_pk_f0" if cfg["dtype"] == "f32" else "mp_spec_id_d_f0") if spec else
+    forced = os.environ.get("MANIPULAPY_HIP_F32", "")[:1]
+    scalar = forced == "s" or (forced != "p" and cfg.get("dof", 0) % 2 == 0)   # specialised float32: one row per lane for even DOF
+    return {"id": (("mp_spec_id_s_f0" if scalar else "mp_spec_id_pk_f0") if cfg["dtype"] == "f32" else "mp_spec_id_d_f0") if spec else
                   ("k_id_pk" if cfg["dtype"] == "f32" else "k_id"),
-            "fused": "mp_spec_traj_id_pk_f0" if spec else "k_traj_id_pk_tab",
+            "fused": ("mp_spec_traj_id_s_f0" if forced == "s" else "mp_spec_traj_id_pk_f0") if spec else "k_traj_id_pk_tab",
             "fk_jac_id": "mp_spec_fk_jac_id_d_f0" if spec else "k_fk_jac_id",
             "fd_traj": "mp_spec_fd_traj_f1" if spec else "k_fd_traj"}[cfg["op"]]
 
@@ -404,6 +407,7 @@ def main():
     if not args.no_specialize:
         ctx.specialize(model)  # setup, untimed: hiprtc build of this robot's kernels (cached on disk)
     cfg["specialized"] = ctx.is_specialized(model)
+    cfg["dof"] = n
 
     if cfg["op"] == "fd_traj":
         return bench_fd(args, cfg, info, hg, ctx, model, t, props)

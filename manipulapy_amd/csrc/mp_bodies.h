@@ -424,6 +424,35 @@ __device__ __forceinline__ void mp_body_traj_id_pk_tab(const MT& M, const MpCall
   if (valid1) RunIO<float, N>::store(tau, b * Nt + t1, hi);
 }
 
+// One timestep per lane (scalar float32 arithmetic): on gfx950 a scalar v_fma_f32 occupies the SIMD for ~2 cycles, a
+// packed one for ~4 (tools/ubench_issue2.hip), so for the VALU-bound fused kernel one row per lane is the faster form.
+template <int N, bool HAS_FTIP, typename MT>
+__device__ __forceinline__ void mp_body_traj_id_tab(const MT& M, const MpCall<float>& C, const float* __restrict__ start,
+                                                    const float* __restrict__ end, long b, long t, long Nt,
+                                                    const double* __restrict__ tab, float* __restrict__ tau) {
+  float a[N], e[N];
+  RunIO<float, N>::load(start, b, a);
+  RunIO<float, N>::load(end, b, e);
+  const double s0 = tab[3 * t], sd0 = tab[3 * t + 1], sdd0 = tab[3 * t + 2];
+  float qq[N], qd[N], qdd[N], tq[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const double d = (double)(e[j] - a[j]);  // float32 difference first, as the reference types it
+    qq[j] = mp_clip((float)(s0 * d + (double)a[j]), M.qmin[j], M.qmax[j]);
+    qd[j] = (float)(sd0 * d);
+    qdd[j] = (float)(sdd0 * d);
+  }
+  MpJointState<float, N> js;
+  mp_joint_state<float, N>(M, qq, js);
+  mp_rnea<float, N, HAS_FTIP>(M, C, js, qd, qdd, tq);
+#pragma unroll
+  for (int j = 0; j < N; ++j) tq[j] = mp_clip(tq[j], M.taumin[j], M.taumax[j]);
+  MpBad<float> bad;  // a non-finite end point makes the generated row non-finite
+  bad.add(qq); bad.add(qd); bad.add(qdd);
+  mp_poison_if(bad.any(), tq);
+  RunIO<float, N>::store(tau, b * Nt + t, tq);
+}
+
 // lane -> (trajectory, timestep pair) for the kernel above: `bpt` blocks of `block` lanes per trajectory
 __device__ __forceinline__ bool mp_traj_pair(unsigned block_idx, unsigned lane, unsigned block, unsigned bpt, long Nt, long& b,
                                              long& t0, long& t1, bool& valid1) {

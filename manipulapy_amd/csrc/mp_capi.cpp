@@ -31,6 +31,8 @@ struct MpSpec {  // run-time specialised kernels of one model on one device
   hipFunction_t id_d[2] = {nullptr, nullptr}, fk_jac_id_d[2] = {nullptr, nullptr}, fd_traj_pk[2] = {nullptr, nullptr};
   hipFunction_t ik = nullptr;
   hipFunction_t fd_s[2] = {nullptr, nullptr}, fd_d[2] = {nullptr, nullptr};  // forward dynamics per row, float32 / float64
+  hipFunction_t id_s[2] = {nullptr, nullptr};                                  // inverse dynamics, float32, one row per lane
+  hipFunction_t traj_id_s[2] = {nullptr, nullptr};                             // generation fused into it, one timestep per lane
 };
 struct mp_ctx {
   int device = -1;
@@ -227,6 +229,18 @@ bool specialize_enabled() {
   static const bool on = [] { const char* e = getenv("MANIPULAPY_HIP_SPECIALIZE"); return !(e && e[0] == '0'); }();
   return on;
 }
+// Which float32 form the robot-specialised inverse-dynamics kernels take.  MANIPULAPY_HIP_F32 = "scalar" | "packed" forces
+// one; by default the scalar one-row-per-lane form (v_fma_f32: ~2 cycles per wave instruction on gfx950, the packed forms ~4;
+// measured c2 +5 %, c4 +7.5 %) except for odd joint counts, whose 4 n-byte rows only allow dword accesses and measure
+// 4 % better two rows per lane (c4s, n = 7).
+bool spec_scalar_f32(int n) {
+  static const int forced = [] {
+    const char* e = getenv("MANIPULAPY_HIP_F32");
+    return !e ? 0 : (e[0] == 's' ? 1 : (e[0] == 'p' ? 2 : 0));
+  }();
+  if (forced) return forced == 1;
+  return (n & 1) == 0;
+}
 const MpSpec* find_spec(mp_ctx* ctx, const mp_model* model) {
   if (!specialize_enabled()) return nullptr;
   auto it = ctx->specs.find(model->uid);
@@ -271,6 +285,11 @@ int launch_id(mp_ctx* ctx, const mp_model* model, const MpCall<float>& c, bool f
               const float* qdd, float* tau, long rows) {
   const long pairs = rows / 2;
   if (const MpSpec* sp = find_spec(ctx, model)) {
+    if (spec_scalar_f32(model->d.n)) {  // one row per lane
+      MpCall<float> cc = c;
+      void* args[] = {&cc, &q, &qd, &qdd, &tau, &rows};
+      return launch_spec(ctx, sp->id_s[ftip ? 1 : 0], rows, args);
+    }
     if (pairs > 0) {
       MpCall<float> cc = c;
       long np = pairs;
@@ -957,12 +976,14 @@ int mp_model_specialize(mp_ctx* ctx, const mp_model* model) {
   if (mp_jit_compile(model->f, model->d, &code, nullptr, &err)) return set_err(MP_ERR_UNSUPPORTED, "mp_model_specialize: %s", err.c_str());
   MpSpec sp;
   HIP_TRY(hipModuleLoadData(&sp.mod, code.data()));
-  const char* names[8][2] = {{"mp_spec_id_pk_f0", "mp_spec_id_pk_f1"}, {"mp_spec_traj_id_pk_f0", "mp_spec_traj_id_pk_f1"},
+  const char* names[10][2] = {{"mp_spec_id_pk_f0", "mp_spec_id_pk_f1"}, {"mp_spec_traj_id_pk_f0", "mp_spec_traj_id_pk_f1"},
                              {"mp_spec_fd_traj_f0", "mp_spec_fd_traj_f1"}, {"mp_spec_id_d_f0", "mp_spec_id_d_f1"},
                              {"mp_spec_fk_jac_id_d_f0", "mp_spec_fk_jac_id_d_f1"}, {"mp_spec_fd_traj_pk_f0", "mp_spec_fd_traj_pk_f1"},
-                             {"mp_spec_fd_s_f0", "mp_spec_fd_s_f1"}, {"mp_spec_fd_d_f0", "mp_spec_fd_d_f1"}};
-  hipFunction_t* slots[8] = {sp.id_pk, sp.traj_id_pk, sp.fd_traj, sp.id_d, sp.fk_jac_id_d, sp.fd_traj_pk, sp.fd_s, sp.fd_d};
-  for (int k = 0; k < 8; ++k)
+                             {"mp_spec_fd_s_f0", "mp_spec_fd_s_f1"}, {"mp_spec_fd_d_f0", "mp_spec_fd_d_f1"},
+                             {"mp_spec_id_s_f0", "mp_spec_id_s_f1"}, {"mp_spec_traj_id_s_f0", "mp_spec_traj_id_s_f1"}};
+  hipFunction_t* slots[10] = {sp.id_pk, sp.traj_id_pk, sp.fd_traj, sp.id_d, sp.fk_jac_id_d, sp.fd_traj_pk, sp.fd_s, sp.fd_d, sp.id_s,
+                              sp.traj_id_s};
+  for (int k = 0; k < 10; ++k)
     for (int f = 0; f < 2; ++f) {
       hipError_t e = hipModuleGetFunction(&slots[k][f], sp.mod, names[k][f]);
       if (e != hipSuccess) { (void)hipModuleUnload(sp.mod); return hip_err(e, names[k][f]); }
@@ -1029,7 +1050,7 @@ int mp_traj_id_fused_f32(mp_ctx* ctx, const mp_model* model, const float* d_star
   make_call<float>(model, g, Ftip, &c);
   const bool ftip = any_nonzero(Ftip);
   PROFILE_SCOPE(ctx, "mp_traj_id_fused_f32");
-  if (!mpk_packed_f32()) {  // MANIPULAPY_HIP_F32=scalar: the one-row-per-lane kernel, time scaling computed per row
+  if (!mpk_packed_f32() && !find_spec(ctx, model)) {  // MANIPULAPY_HIP_F32=scalar, generic: one row per lane, time scaling per row
     HIP_TRY(mpk_traj_id(ctx->compute, model->f, c, ftip, d_start, d_end, (long)B, (long)N, Tf, method, d_tau));
     return MP_OK;
   }
@@ -1053,8 +1074,13 @@ int mp_traj_id_fused_f32(mp_ctx* ctx, const mp_model* model, const float* d_star
   }
   if (const MpSpec* sp = find_spec(ctx, model)) {
     long nt = (long)N;
-    unsigned bpt = mpk_traj_blocks_per_trajectory(nt);
     const double* tab = ctx->time_tab;
+    if (!mpk_packed_f32()) {  // MANIPULAPY_HIP_F32=scalar: one timestep per lane (measured slower: c2f 0.063 vs 0.054 ms)
+      unsigned bpt = (unsigned)((nt + 255) / 256);
+      void* args[] = {&c, &d_start, &d_end, &nt, &bpt, &tab, &d_tau};
+      return launch_spec(ctx, sp->traj_id_s[ftip ? 1 : 0], (long)B * bpt * 256, args);
+    }
+    unsigned bpt = mpk_traj_blocks_per_trajectory(nt);
     void* args[] = {&c, &d_start, &d_end, &nt, &bpt, &tab, &d_tau};
     return launch_spec(ctx, sp->traj_id_pk[ftip ? 1 : 0], (long)B * bpt * 256, args);
   }

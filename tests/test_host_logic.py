@@ -205,7 +205,7 @@ def test_kernel_specialiser_generates_and_compiles_without_a_gpu(tables, tmp_pat
     m = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee, tab.joint_limits)
     src = m.specialize_source()
     assert "static constexpr MpModel<float> kM = {6," in src and 'extern "C" __global__' in src
-    for name in ("mp_spec_id_pk_f0", "mp_spec_id_pk_f1", "mp_spec_traj_id_pk_f0", "mp_spec_fd_traj_f1"):
+    for name in ("mp_spec_id_pk_f0", "mp_spec_id_pk_f1", "mp_spec_id_s_f0", "mp_spec_traj_id_s_f1", "mp_spec_traj_id_pk_f0", "mp_spec_fd_traj_f1"):
         assert name in src
     assert "e-10f" not in src and "e-17f" not in src  # URDF dust is snapped to exact zeros
     assert "inf" not in src.lower().replace("__builtin_inff", "")  # infinite limits are emitted as +-3e38
