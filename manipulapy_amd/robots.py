@@ -1,10 +1,10 @@
 """Robot model tables for the benchmark robots.
 
 The reference builds these tables from URDFs (urdf_processor.py:82-138 -> urdf/core.py:670-769).
-`manipulapy_amd.urdf` reads any URDF the same way; this module additionally ships the tables of the four
-configuration robots as small .npz fixtures captured from the reference (tests/golden/make_golden.py,
-numbers only) — the pin the URDF reader is tested against, and what bench.py loads — next to the four
-URDF files themselves (tests/golden/urdf/, robot description data).
+`manipulapy_amd.urdf` reads any URDF the same way; this module additionally ships, under manipulapy_amd/data/, the
+tables of the four configuration robots as small .npz files captured from the reference (tests/golden/make_golden.py,
+numbers only) — the pin the URDF reader is tested against, and what bench.py loads — next to the four URDF files
+themselves (data/urdf/, robot description data).
 """
 from __future__ import annotations
 
@@ -13,7 +13,7 @@ from typing import Dict, Tuple
 
 import numpy as np
 
-_DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
 ROBOTS = ("ur5", "iiwa14", "panda", "xarm6")
 # "panda7": the 7 arm joints of the Panda.  The reference parses the packaged Panda URDF as EIGHT actuated joints (the
 # arm + one prismatic finger joint), which is what "panda" reproduces; BASELINE names a 7-DOF Panda, so the

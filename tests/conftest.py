@@ -20,7 +20,12 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with gpurun)")
 
 
+PKG_DATA = os.path.join(ROOT, "manipulapy_amd", "data")  # model tables + URDFs of the benchmark robots ship with the package
+
+
 def golden_path(name):
+    if name.startswith("model_") and name.endswith(".npz"):
+        return os.path.join(PKG_DATA, name)
     return os.path.join(GOLDEN, name)
 
 

@@ -23,7 +23,8 @@ What it does:
       ik.npz               : iterative_inverse_kinematics dumps, 10 problems per robot (`make_golden.py ik`)
       control_ur5.npz      : ManipulatorController laws on UR5 (`make_golden.py control`)
       utils.npz            : every public ManipulaPy.utils function on generic and branch-switching inputs (`make_golden.py utils`)
-      urdf/<robot>.urdf    : kinematic + inertial skeletons of the four URDFs (`make_golden.py urdf`)
+      (manipulapy_amd/data/) model_<robot>.npz, urdf/<robot>.urdf : the four benchmark robots' tables and URDF skeletons
+      urdf_suite.npz + urdf_suite/*.urdf : reference tables for all 28 database robots + the reference's URDF test fixtures
       reference_cpu_timings.json : cold-cache per-point timings of the reference
 
 Nothing from /root/reference is copied: the fixtures hold numbers only.
@@ -37,6 +38,7 @@ import tempfile
 import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+PKG_DATA = os.path.join(os.path.dirname(os.path.dirname(HERE)), "manipulapy_amd", "data")  # what the product ships
 REF = "/root/reference"
 SEED = 20260705  # same seed the reference's golden test uses (tests/test_dynamics_golden.py:53)
 
@@ -113,7 +115,7 @@ def dump_model(robot, proc, sm, dyn):
     ee = getattr(proc.robot, "end_effector_link", None)
     ee_name = getattr(ee, "name", str(ee))
     np.savez(
-        os.path.join(HERE, f"model_{robot}.npz"),
+        os.path.join(PKG_DATA, f"model_{robot}.npz"),
         n=np.int64(n),
         S_list=np.asarray(sm.S_list, dtype=np.float64),
         B_list=np.asarray(sm.B_list, dtype=np.float64),
@@ -524,35 +526,98 @@ def dump_utils():
     np.savez(os.path.join(HERE, "utils.npz"), **d)
 
 
-def dump_urdfs():
-    """tests/golden/urdf/<robot>.urdf: the kinematic + inertial skeleton of the four benchmark robots' URDFs (robot
-    description DATA; number strings kept verbatim so the tables stay bit-identical).  Visual / collision geometry,
-    materials, mesh references, transmissions and gazebo blocks are dropped: manipulapy_amd.urdf never reads them."""
+def write_skeleton(src_path, dst_path, label):
+    """The kinematic + inertial skeleton of a URDF (robot description DATA; number strings kept verbatim so the tables stay
+    bit-identical).  Visual / collision geometry, materials, mesh references, transmissions and gazebo blocks are dropped:
+    manipulapy_amd.urdf never reads them."""
     import xml.etree.ElementTree as ET
 
-    os.makedirs(os.path.join(HERE, "urdf"), exist_ok=True)
-    for robot in ROBOTS:
-        src = ET.parse(get_robot_urdf(robot)).getroot()
-        out = ET.Element("robot", {"name": src.get("name", robot)})
-        out.append(ET.Comment(f" kinematic + inertial skeleton of the {robot} description used by BASELINE configs; "
-                              "generated by tests/golden/make_golden.py urdf "))
-        for link in src.findall("link"):
-            le = ET.SubElement(out, "link", {"name": link.get("name")})
-            ine = link.find("inertial")
-            if ine is not None:
-                ie = ET.SubElement(le, "inertial")
-                for tag in ("origin", "mass", "inertia"):
-                    e = ine.find(tag)
-                    if e is not None:
-                        ET.SubElement(ie, tag, dict(e.attrib))
-        for joint in src.findall("joint"):
-            je = ET.SubElement(out, "joint", {"name": joint.get("name"), "type": joint.get("type", "fixed")})
-            for tag in ("origin", "parent", "child", "axis", "limit", "mimic"):
-                e = joint.find(tag)
+    src = ET.parse(src_path).getroot()
+    out = ET.Element("robot", {"name": src.get("name", label)})
+    out.append(ET.Comment(f" kinematic + inertial skeleton of the {label} description; generated by tests/golden/make_golden.py "))
+    for link in src.findall("link"):
+        le = ET.SubElement(out, "link", {"name": link.get("name")})
+        ine = link.find("inertial")
+        if ine is not None:
+            ie = ET.SubElement(le, "inertial")
+            for tag in ("origin", "mass", "inertia"):
+                e = ine.find(tag)
                 if e is not None:
-                    ET.SubElement(je, tag, dict(e.attrib))
-        ET.indent(out, space="  ")
-        ET.ElementTree(out).write(os.path.join(HERE, "urdf", f"{robot}.urdf"), encoding="utf-8", xml_declaration=True)
+                    ET.SubElement(ie, tag, dict(e.attrib))
+    for joint in src.findall("joint"):
+        je = ET.SubElement(out, "joint", {"name": joint.get("name"), "type": joint.get("type", "fixed")})
+        for tag in ("origin", "parent", "child", "axis", "limit", "mimic"):
+            e = joint.find(tag)
+            if e is not None:
+                ET.SubElement(je, tag, dict(e.attrib))
+    ET.indent(out, space="  ")
+    ET.ElementTree(out).write(dst_path, encoding="utf-8", xml_declaration=True)
+
+
+def dump_urdfs():
+    """manipulapy_amd/data/urdf/<robot>.urdf: skeletons of the four benchmark robots' URDFs (shipped with the package)."""
+    os.makedirs(os.path.join(PKG_DATA, "urdf"), exist_ok=True)
+    for robot in ROBOTS:
+        write_skeleton(get_robot_urdf(robot), os.path.join(PKG_DATA, "urdf", f"{robot}.urdf"), robot)
+
+
+def dump_urdf_suite():
+    """Reference tables for EVERY robot of the reference's database (ManipulaPy_data/__init__.py:44-310, 28 entries: UR3/5/10
+    + e-series, Panda, iiwa7/14, Gen3, Jaco, Fanuc, CRX, IRB2400, xArm6 with and without gripper, Robotiq grippers) and for the
+    URDF fixtures of the reference's own tests (tests/urdf_fixtures/: simple_arm, prismatic_joint, branched,
+    continuous_joints, mimic_joints, multi_root, primitives, transmissions): urdf_suite/<name>.urdf skeletons +
+    urdf_suite.npz with S_list, B_list, M, Glist, Mlist_per_link, joint limits, end-effector name, for the default
+    (seed-pinned) end effector and, for branching trees, for every other leaf as tip_link."""
+    from ManipulaPy.ManipulaPy_data import ROBOT_DATABASE
+    from ManipulaPy.urdf import URDF
+
+    out_dir = os.path.join(HERE, "urdf_suite")
+    os.makedirs(out_dir, exist_ok=True)
+    d, names = {}, []
+    sources = {name: get_robot_urdf(name) for name in ROBOT_DATABASE}
+    fx = os.path.join(REF, "tests", "urdf_fixtures")
+    for f in ("simple_arm", "prismatic_joint", "branched", "continuous_joints", "mimic_joints", "multi_root", "primitives", "transmissions"):
+        sources["fixture_" + f] = os.path.join(fx, f + ".urdf")
+    for name, path in sources.items():
+        try:
+            proc = URDFToSerialManipulator(path, load_meshes=False)
+        except Exception as exc:  # the reference itself rejects the file: record that
+            d[f"{name}__error"] = np.array(type(exc).__name__ + ": " + str(exc)[:160])
+            write_skeleton(path, os.path.join(out_dir, f"{name}.urdf"), name)
+            names.append(name)
+            print(f"urdf suite: {name}: reference raises {type(exc).__name__}", flush=True)
+            continue
+        sm, dyn = proc.serial_manipulator, proc.dynamics
+        n = sm.S_list.shape[1]
+        ee = proc.robot.end_effector_link.name
+        d[f"{name}__S"] = np.asarray(sm.S_list, dtype=np.float64); d[f"{name}__B"] = np.asarray(sm.B_list, dtype=np.float64)
+        d[f"{name}__M"] = np.asarray(sm.M_list, dtype=np.float64); d[f"{name}__G"] = np.asarray(dyn.Glist, dtype=np.float64)
+        d[f"{name}__Mcom"] = np.asarray(dyn.Mlist_per_link, dtype=np.float64)
+        d[f"{name}__limits"] = np.array([[np.nan if lo is None else lo, np.nan if hi is None else hi] for lo, hi in proc.robot_data["joint_limits"]], dtype=np.float64)
+        d[f"{name}__ee"] = np.array(ee)
+        d[f"{name}__joint_names"] = np.array([j.name for j in proc.robot.actuated_joints])
+        # every other leaf link as an explicit tip (branching trees: grippers, the branched fixture)
+        robot = URDF.load(path, backend="builtin", load_meshes=False)
+        leaves = [l for l in getattr(robot, "_end_link_names", []) if l != ee]
+        for k, leaf in enumerate(sorted(leaves)[:3]):
+            prm = robot.extract_screw_axes(tip_link=leaf)
+            d[f"{name}__tip{k}_name"] = np.array(leaf)
+            d[f"{name}__tip{k}_M"] = np.asarray(prm["M"], dtype=np.float64)
+            d[f"{name}__tip{k}_B"] = np.asarray(prm["B_list"], dtype=np.float64)
+        # a few reference dynamics values, so the suite also pins tables -> physics for robots outside the benchmark four
+        rng = np.random.default_rng(SEED + 1000 + len(names))
+        lim = finite_limits(sm, n)
+        th = rng.uniform(lim[:, 0], lim[:, 1]); dth = rng.uniform(-1, 1, n); ddth = rng.uniform(-1, 1, n)
+        d[f"{name}__theta"], d[f"{name}__dtheta"], d[f"{name}__ddtheta"] = th, dth, ddth
+        if n <= 8:
+            clear_caches(dyn)
+            d[f"{name}__tau"] = np.asarray(dyn.inverse_dynamics(th, dth, ddth, G_VEC, FTIP_REF))
+            d[f"{name}__T"] = np.asarray(sm.forward_kinematics(th))
+        write_skeleton(path, os.path.join(out_dir, f"{name}.urdf"), name)
+        names.append(name)
+        print(f"urdf suite: {name}: n={n} ee={ee} leaves={len(leaves) + 1}", flush=True)
+    d["names"] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, "urdf_suite.npz"), **d)
 
 
 def time_reference():
@@ -707,7 +772,7 @@ def main():
         dump_ik()
         print("ik dumped")
         return
-    for name, fn in (("rollout100", dump_rollout100), ("nonfinite", dump_nonfinite), ("field", dump_field)):
+    for name, fn in (("rollout100", dump_rollout100), ("nonfinite", dump_nonfinite), ("field", dump_field), ("urdf_suite", dump_urdf_suite)):
         if name in sys.argv[1:]:
             fn()
             print(name, "dumped")
@@ -730,6 +795,7 @@ def main():
     dump_rollout100()
     dump_nonfinite()
     dump_field()
+    dump_urdf_suite()
     print("trajectories dumped", flush=True)
     time_reference()
     print("timings dumped")

@@ -581,7 +581,7 @@ def test_forward_dynamics_trajectory_packed_variant(tables):
         import manipulapy_amd as mp
         from manipulapy_amd import _hip
         from oracle import ref_numpy as ref
-        tab = ref.load_tables(os.path.join(%r, "tests", "golden", "model_xarm6.npz"))
+        tab = ref.load_tables(os.path.join(%r, "manipulapy_amd", "data", "model_xarm6.npz"))
         ctx = _hip.HipContext(0)
         gen = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee, tab.joint_limits)
         spec = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee, tab.joint_limits)
@@ -1535,3 +1535,36 @@ def test_planner_profiling_specialised_dispatch_and_model_release(tables):
         b = ctx.id_trajectory_host(m2, q, q * 0.1, q * -0.2, dtype=np.float32)   # generic kernel
         assert np.abs(a - b).max() <= 2e-4 * np.abs(b).max()
         del handle
+
+
+def test_urdf_to_kernel_for_the_reference_robot_database():
+    """URDF file -> manipulapy_amd.URDFToSerialManipulator -> OptimizedTrajectoryPlanning.inverse_dynamics_trajectory /
+    SerialManipulator.forward_kinematics on the GPU, against the REFERENCE's torques and poses for the same URDF
+    (tests/golden/urdf_suite.npz: all robots of the reference's database with <= 8 joints - UR, Panda, iiwa, Gen3,
+    Fanuc, CRX, IRB2400, xArm6 + gripper, Robotiq - and its URDF test fixtures incl. the branched tree, the prismatic
+    chain, mimic and continuous joints); float64 and float32 kernels."""
+    import manipulapy_amd as mp
+
+    z = np.load(golden_path("urdf_suite.npz"))
+    g, F = np.array([0.0, 0.0, -9.81]), np.array([1.0, -2.0, 0.5, 3.0, -1.5, 0.75])
+    done = 0
+    with mp.use_backend("hip"):
+        for name in [str(n) for n in z["names"]]:
+            if f"{name}__tau" not in z.files:
+                continue   # the Jaco arms with their three-finger hands have 9 / 10 actuated joints (MP_MAX_DOF = 8)
+            proc = mp.URDFToSerialManipulator(golden_path(os.path.join("urdf_suite", f"{name}.urdf")), tip_link=str(z[f"{name}__ee"]))
+            n = proc.robot_data["actuated_joints_num"]
+            th, dth, ddth, want = z[f"{name}__theta"], z[f"{name}__dtheta"], z[f"{name}__ddtheta"], z[f"{name}__tau"]
+            lim = np.array([[-10.0, 10.0]] * n)   # wide limits: the planner must not clip this check's configuration
+            pl = mp.OptimizedTrajectoryPlanning(proc.serial_manipulator, None, proc.dynamics, lim)
+            rows = 130
+            q = np.tile(th, (rows, 1)); qd = np.tile(dth, (rows, 1)); qdd = np.tile(ddth, (rows, 1))
+            t64 = pl.inverse_dynamics_trajectory(q, qd, qdd, g, F)            # float64 kernel, float32 rows as the reference stores them
+            assert t64.dtype == np.float32 and t64.shape == (rows, n)
+            np.testing.assert_allclose(t64, np.tile(want, (rows, 1)), rtol=2e-6, atol=2e-6 * max(1.0, float(np.abs(want).max())), err_msg=name)
+            t32 = pl.inverse_dynamics_trajectory(q.astype(np.float32), qd.astype(np.float32), qdd.astype(np.float32), g, F)
+            assert_f32(t32, np.tile(want, (rows, 1)))
+            np.testing.assert_allclose(proc.serial_manipulator.forward_kinematics(th), z[f"{name}__T"], atol=1e-10, err_msg=name)
+            np.testing.assert_allclose(proc.dynamics.inverse_dynamics(th, dth, ddth, g, F), want, rtol=1e-6, atol=1e-7, err_msg=name)
+            done += 1
+    assert done >= 30

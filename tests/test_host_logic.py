@@ -402,6 +402,93 @@ def test_urdf_reader_reproduces_reference_tables(robot):
                                                                "panda": "panda_rightfinger", "xarm6": "link6"}[robot]
 
 
+def _suite():
+    z = np.load(golden_path("urdf_suite.npz"))
+    return z, [str(n) for n in z["names"]]
+
+
+def test_urdf_reader_reproduces_the_reference_on_its_whole_robot_database():
+    """manipulapy_amd.urdf.extract_tables vs the tables the reference derives (urdf/core.py:670-769) for ALL 28 robots of
+    its database (ManipulaPy_data/__init__.py:44-310: UR3/5/10 + e-series, Panda, iiwa7/14, Gen3, Jaco 6/7-DOF with
+    three-finger hands, Fanuc LR Mate / M-16iB / CRX, ABB IRB2400, xArm6 with and without gripper, Robotiq 2F-85/140)
+    and for the URDF fixtures of its own tests (tests/urdf_fixtures: simple_arm, prismatic_joint, branched,
+    continuous_joints, mimic_joints, multi_root, primitives, transmissions).  Covers fixed joints carrying inertia
+    mid-chain, branching trees with an explicit tip_link, prismatic-first chains, mimic joints, continuous joints
+    without limits, links without <inertial>.  S, G, Mlist_per_link and the limits bit for bit; M / B (which go through
+    the end-effector choice and a 4x4 inverse) to 1e-12."""
+    from manipulapy_amd.urdf import extract_tables
+
+    z, names = _suite()
+    assert len(names) == 36 and sum(1 for n in names if not n.startswith("fixture_")) == 28
+    checked_tips = 0
+    for name in names:
+        path = golden_path(os.path.join("urdf_suite", f"{name}.urdf"))
+        assert f"{name}__error" not in z.files, name
+        t = extract_tables(path, tip_link=str(z[f"{name}__ee"]))
+        n = z[f"{name}__S"].shape[1]
+        assert t["S_list"].shape == (6, n), name
+        np.testing.assert_array_equal(t["S_list"], z[f"{name}__S"], err_msg=name)
+        np.testing.assert_array_equal(t["G_list"], z[f"{name}__G"], err_msg=name)
+        np.testing.assert_array_equal(t["Mlist_per_link"], z[f"{name}__Mcom"], err_msg=name)
+        np.testing.assert_allclose(t["M"], z[f"{name}__M"], rtol=0, atol=1e-14, err_msg=name)
+        np.testing.assert_allclose(t["B_list"], z[f"{name}__B"], rtol=0, atol=1e-12, err_msg=name)
+        # (the reference's `actuated_joints` list is ordered by XML position, its screw columns by the BFS: same set)
+        assert sorted(t["joint_names"]) == sorted(str(j) for j in z[f"{name}__joint_names"]), name
+        lim = z[f"{name}__limits"]
+        mine = np.asarray(t["joint_limits"], dtype=float)
+        np.testing.assert_array_equal(mine[~np.isnan(lim)], lim[~np.isnan(lim)], err_msg=name)
+        k = 0
+        while f"{name}__tip{k}_name" in z.files:   # every other leaf of a branching tree as an explicit tip_link
+            tk = extract_tables(path, tip_link=str(z[f"{name}__tip{k}_name"]))
+            np.testing.assert_allclose(tk["M"], z[f"{name}__tip{k}_M"], rtol=0, atol=1e-14, err_msg=f"{name} tip {k}")
+            np.testing.assert_allclose(tk["B_list"], z[f"{name}__tip{k}_B"], rtol=0, atol=1e-12, err_msg=f"{name} tip {k}")
+            np.testing.assert_array_equal(tk["S_list"], t["S_list"])   # the screws do not depend on the tip
+            checked_tips += 1
+            k += 1
+    assert checked_tips >= 30
+
+
+def test_urdf_suite_tables_give_the_reference_dynamics_on_the_cpu_path():
+    """URDF -> URDFToSerialManipulator -> SerialManipulator / ManipulatorDynamics (NumPy backend: the C ABI's CPU
+    launchers) vs the reference's forward kinematics and inverse dynamics at a random configuration with gravity and a
+    tip wrench, for every suite robot with at most 8 joints whose tables the model compiler accepts; plus the cases of
+    reference tests/test_urdf_accuracy.py that need no PyBullet (mass matrix symmetric positive definite on simple_arm,
+    :426-460; SE(3) home pose and unit screw axes on UR5, :563-590; prismatic chain moves linearly, :603-645)."""
+    z, names = _suite()
+    g, F = np.array([0.0, 0.0, -9.81]), np.array([1.0, -2.0, 0.5, 3.0, -1.5, 0.75])
+    done, rejected = 0, []
+    for name in names:
+        if f"{name}__tau" not in z.files:
+            continue
+        path = golden_path(os.path.join("urdf_suite", f"{name}.urdf"))
+        proc = mp.URDFToSerialManipulator(path, tip_link=str(z[f"{name}__ee"]))
+        th, dth, ddth = z[f"{name}__theta"], z[f"{name}__dtheta"], z[f"{name}__ddtheta"]
+        try:
+            proc.dynamics.hip_model()
+        except _hip.HipError as exc:   # e.g. massless links (G = eye(6) placeholders are fine; a zero mass is not SPD)
+            rejected.append((name, str(exc)[:80]))
+            continue
+        np.testing.assert_allclose(proc.serial_manipulator.forward_kinematics(th), z[f"{name}__T"], atol=1e-10, err_msg=name)
+        tau = proc.dynamics.inverse_dynamics(th, dth, ddth, g, F)
+        np.testing.assert_allclose(tau, z[f"{name}__tau"], rtol=1e-6, atol=1e-6, err_msg=name)
+        done += 1
+    assert done >= 28, (done, rejected)
+    proc = mp.URDFToSerialManipulator(golden_path(os.path.join("urdf_suite", "fixture_simple_arm.urdf")))
+    rng = np.random.default_rng(42)
+    for _ in range(20):
+        M = proc.dynamics.mass_matrix(rng.uniform(-np.pi, np.pi, 2))
+        assert np.linalg.norm(M - M.T) < 1e-10 and (np.linalg.eigvalsh(M) > 0).all()
+    t = proc.tables
+    ur5 = mp.URDFToSerialManipulator(golden_path(os.path.join("urdf_suite", "ur5.urdf"))).tables
+    R = ur5["M"][:3, :3]
+    np.testing.assert_allclose(R @ R.T, np.eye(3), atol=1e-10); np.testing.assert_allclose(np.linalg.det(R), 1.0, atol=1e-10)
+    np.testing.assert_allclose(np.linalg.norm(ur5["S_list"][:3], axis=0), 1.0, atol=1e-10)
+    pr = mp.URDFToSerialManipulator(golden_path(os.path.join("urdf_suite", "fixture_prismatic_joint.urdf")))
+    T = pr.serial_manipulator.forward_kinematics(np.array([0.05, 0.03, 0.1]))
+    np.testing.assert_allclose(T[:3, 3], [0.05, 0.03, 0.045 + 0.035 + 0.015 + 0.1], atol=1e-10)
+    np.testing.assert_allclose(T[:3, :3], np.eye(3), atol=1e-12)
+
+
 def test_urdf_processor_mirror_and_errors(tmp_path):
     proc = mp.URDFToSerialManipulator(mp.robot_urdf("panda"), tip_link="panda_leftfinger")
     assert proc.robot_data["actuated_joints_num"] == 8  # 7 arm joints + one finger; the mimic finger is excluded
