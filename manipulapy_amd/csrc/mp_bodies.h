@@ -523,6 +523,31 @@ __device__ __forceinline__ void mp_fd_tile_in(const unsigned* __restrict__ g, in
   }
 }
 
+// The same in two halves, for the software-pipelined vector path: the global loads of the NEXT tile are issued into
+// registers while the current tile is being integrated (their latency - microseconds, with only one other wave on the
+// SIMD to cover it - used to be exposed at every tile boundary: SQ_WAIT_ANY was 22 % of the wave cycles of config c5),
+// and are parked in the tile only once the current tile's rows have left it.
+template <int E, int TW>
+struct MpFdPrefetch {
+  static constexpr int NV = MP_FD_KS * E * TW / 4;  // 16-byte vectors per tile and lane
+  mp_io_u4 v[NV];
+};
+template <int E, int TW>
+__device__ __forceinline__ void mp_fd_tile_load(const unsigned* __restrict__ g, MpFdPrefetch<E, TW>& r) {
+#pragma unroll
+  for (int k = 0; k < MpFdPrefetch<E, TW>::NV; ++k) r.v[k] = *reinterpret_cast<const mp_io_u4*>(g + 4 * k);
+}
+template <int E, int TW, int BASE, int STEP, int W>
+__device__ __forceinline__ void mp_fd_tile_park(const MpFdPrefetch<E, TW>& r, unsigned* __restrict__ col) {
+#pragma unroll
+  for (int k = 0; k < MpFdPrefetch<E, TW>::NV; ++k) {
+    col[mp_fd_in_slot<E, TW, BASE, STEP, W>(4 * k)] = r.v[k].x;
+    col[mp_fd_in_slot<E, TW, BASE, STEP, W>(4 * k + 1)] = r.v[k].y;
+    col[mp_fd_in_slot<E, TW, BASE, STEP, W>(4 * k + 2)] = r.v[k].z;
+    col[mp_fd_in_slot<E, TW, BASE, STEP, W>(4 * k + 3)] = r.v[k].w;
+  }
+}
+
 // tile -> global: output slot `slot` (0 pos, 1 vel, 2 acc) of MP_FD_KS rows (or `limit` dwords when VW == 1)
 template <int N, int STEP, int W, int VW>
 __device__ __forceinline__ void mp_fd_tile_out(float* __restrict__ gdst, int slot, int limit, const unsigned* __restrict__ col) {
@@ -574,19 +599,35 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
   // 16-byte vector accesses need every lane's run to start on a 16-byte boundary (wave-uniform tests)
   const bool vec_tau = ((Nt * N * (long)sizeof(T)) & 15) == 0, vec_out = ((Nt * N * 4) & 15) == 0;
   const bool vec_f = ((Nt * 6 * (long)sizeof(T)) & 15) == 0;
+  // software pipeline of the vector path: `pre_*` hold the inputs of the tile about to start (loaded one tile ahead)
+  constexpr bool PIPE = (MP_FD_KS * N * TW) % 4 == 0 && (MP_FD_KS * 6 * TW) % 4 == 0;
+  MpFdPrefetch<N, TW> pre_tau;
+  MpFdPrefetch<6, TW> pre_f;
+  bool have_tau = false, have_f = false;
   for (long i0 = 0; i0 < Nt; i0 += MP_FD_KS) {
     const long left = Nt - i0;
     const int rows = left < MP_FD_KS ? (int)left : MP_FD_KS;
     const bool full = rows == MP_FD_KS;
     const long row0 = b * Nt + i0;
+    const bool next_full = left >= 2 * MP_FD_KS;  // the tile after this one is a whole tile
     {
       const unsigned* g = reinterpret_cast<const unsigned*>(taumat + row0 * N);
-      if (full && vec_tau) mp_fd_tile_in<N, TW, TL::TAU0, STEP, 64, 4>(g, 0, col);
+      if (PIPE && full && vec_tau) {
+        if (!have_tau) mp_fd_tile_load<N, TW>(g, pre_tau);
+        mp_fd_tile_park<N, TW, TL::TAU0, STEP, 64>(pre_tau, col);
+        have_tau = next_full;
+        if (next_full) mp_fd_tile_load<N, TW>(g + MP_FD_KS * N * TW, pre_tau);
+      } else if (full && vec_tau) mp_fd_tile_in<N, TW, TL::TAU0, STEP, 64, 4>(g, 0, col);
       else mp_fd_tile_in<N, TW, TL::TAU0, STEP, 64, 1>(g, rows * N * TW, col);
     }
     if (HAS_FTIP) {
       const unsigned* g = reinterpret_cast<const unsigned*>(Ftipmat + row0 * 6);
-      if (full && vec_f) mp_fd_tile_in<6, TW, TL::F0, STEP, 64, 4>(g, 0, col);
+      if (PIPE && full && vec_f) {
+        if (!have_f) mp_fd_tile_load<6, TW>(g, pre_f);
+        mp_fd_tile_park<6, TW, TL::F0, STEP, 64>(pre_f, col);
+        have_f = next_full;
+        if (next_full) mp_fd_tile_load<6, TW>(g + MP_FD_KS * 6 * TW, pre_f);
+      } else if (full && vec_f) mp_fd_tile_in<6, TW, TL::F0, STEP, 64, 4>(g, 0, col);
       else mp_fd_tile_in<6, TW, TL::F0, STEP, 64, 1>(g, rows * 6 * TW, col);
     }
     for (int s = 0; s < rows; ++s) {
