@@ -523,10 +523,11 @@ __device__ __forceinline__ void mp_fd_tile_in(const unsigned* __restrict__ g, in
   }
 }
 
-// The same in two halves, for the software-pipelined vector path: the global loads of the NEXT tile are issued into
-// registers while the current tile is being integrated (their latency - microseconds, with only one other wave on the
-// SIMD to cover it - used to be exposed at every tile boundary: SQ_WAIT_ANY was 22 % of the wave cycles of config c5),
-// and are parked in the tile only once the current tile's rows have left it.
+// The same in two halves, for an optional software-pipelined vector path (MP_FD_PREFETCH): the global loads of the NEXT
+// tile are issued into registers while the current tile is being integrated and parked in the tile only once the
+// current tile's rows have left it.  SQ_WAIT_ANY is 22 % of the wave cycles of config c5, but hiding these loads did
+// not shorten the kernel (it holds ~1.9 GHz there against 2.3 GHz in the streaming kernels: the roll-out is limited by
+// what the chip's power management lets the vector units do, not by exposed latency), so it is off by default.
 template <int E, int TW>
 struct MpFdPrefetch {
   static constexpr int NV = MP_FD_KS * E * TW / 4;  // 16-byte vectors per tile and lane
@@ -600,7 +601,11 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
   const bool vec_tau = ((Nt * N * (long)sizeof(T)) & 15) == 0, vec_out = ((Nt * N * 4) & 15) == 0;
   const bool vec_f = ((Nt * 6 * (long)sizeof(T)) & 15) == 0;
   // software pipeline of the vector path: `pre_*` hold the inputs of the tile about to start (loaded one tile ahead)
+#if defined(MP_FD_PREFETCH)  // opt-in: measured neutral on config c5 (tools/ab_c5.sh, five interleaved rounds: 0.642 vs 0.633 ms)
   constexpr bool PIPE = (MP_FD_KS * N * TW) % 4 == 0 && (MP_FD_KS * 6 * TW) % 4 == 0;
+#else
+  constexpr bool PIPE = false;
+#endif
   MpFdPrefetch<N, TW> pre_tau;
   MpFdPrefetch<6, TW> pre_f;
   bool have_tau = false, have_f = false;
