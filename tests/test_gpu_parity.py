@@ -1537,7 +1537,7 @@ def test_planner_profiling_specialised_dispatch_and_model_release(tables):
         del handle
 
 
-def test_urdf_to_kernel_for_the_reference_robot_database():
+def test_urdf_to_kernel_for_the_reference_robot_database(monkeypatch):
     """URDF file -> manipulapy_amd.URDFToSerialManipulator -> OptimizedTrajectoryPlanning.inverse_dynamics_trajectory /
     SerialManipulator.forward_kinematics on the GPU, against the REFERENCE's torques and poses for the same URDF
     (tests/golden/urdf_suite.npz: all robots of the reference's database with <= 8 joints - UR, Panda, iiwa, Gen3,
@@ -1545,6 +1545,7 @@ def test_urdf_to_kernel_for_the_reference_robot_database():
     chain, mimic and continuous joints); float64 and float32 kernels."""
     import manipulapy_amd as mp
 
+    monkeypatch.setenv("MANIPULAPY_HIP_SPECIALIZE", "0")   # 34 robots x ~2 s of hiprtc each buys nothing here: generic kernels
     z = np.load(golden_path("urdf_suite.npz"))
     g, F = np.array([0.0, 0.0, -9.81]), np.array([1.0, -2.0, 0.5, 3.0, -1.5, 0.75])
     done = 0
