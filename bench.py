@@ -683,6 +683,10 @@ def main():
                                       "sample": f"not measured: {str(exc)[:200]}"}
     if allgather is not None:
         result["allgather"] = allgather
+        # the three figures of an N > 1 line side by side: `value` is compute only (the timed step has no collective)
+        result["value_with_allgather"] = allgather.get("value_with_allgather")
+        result["value_overlapped"] = (allgather.get("overlapped") or {}).get("value")
+        result["verified"] = bool(allgather.get("verified") is True and (allgather.get("overlapped") or {}).get("verified", True) is True)
     if info.rank == 0:
         emit(result)
     if hung:

@@ -302,6 +302,10 @@ int mp_comm_allgather(mp_comm* comm, const void* d_send, void* d_recv, size_t by
  * beside the exchange.  Every rank must issue the same sequence of chunks.  mp_comm_join makes the compute stream
  * wait for all exchanges issued so far (call it before anything reads d_all). */
 int mp_comm_exchange_chunk(mp_comm* comm, void* d_all, size_t bytes_per_rank, size_t offset, size_t nbytes);
+/* Buffer lifetime: mp_free hands a buffer back to the pool immediately, and the pool orders reuse with respect to the
+ * context's COMPUTE stream only.  A buffer a communicator is still reading or writing on its own stream (after
+ * mp_comm_exchange_chunk) must therefore not be freed before mp_comm_join (mp_comm_allgather runs on the compute
+ * stream and needs no join). */
 int mp_comm_join(mp_comm* comm);
 
 #ifdef __cplusplus

@@ -107,8 +107,11 @@ class SerialManipulator:
             raise ValueError("Invalid frame specified. Choose 'space' or 'body'.")
         self._require_consistent_B(frame)
         T, J = self._space_fk_jac(thetalist, want_T=(frame == "body"), want_J=True)
-        if frame == "body":  # J_b = Ad(T_sb^-1) J_s
-            J = np.stack([_adjoint(np.linalg.inv(T[i])) @ J[i] for i in range(J.shape[0])])
+        if frame == "body":  # J_b = Ad(T_sb^-1) J_s = [[R^T, 0], [-R^T [p], R^T]] J_s, all rows at once
+            Rt = np.swapaxes(T[:, :3, :3], 1, 2)
+            Jw, Jv = J[:, :3, :], J[:, 3:, :]
+            pxJw = np.cross(T[:, :3, 3][:, :, None], Jw, axis=1)       # [p] Jw, column by column
+            J = np.concatenate([Rt @ Jw, Rt @ (Jv - pxJw)], axis=1)
         return J if np.ndim(thetalist) == 2 else J[0]
 
     # ---- inverse kinematics (reference kinematics/ik.py:39-311)
