@@ -524,10 +524,8 @@ __device__ __forceinline__ void mp_fd_tile_in(const unsigned* __restrict__ g, in
 }
 
 // The same in two halves, for an optional software-pipelined vector path (MP_FD_PREFETCH): the global loads of the NEXT
-// tile are issued into registers while the current tile is being integrated and parked in the tile only once the
-// current tile's rows have left it.  SQ_WAIT_ANY is 22 % of the wave cycles of config c5, but hiding these loads did
-// not shorten the kernel (it holds ~1.9 GHz there against 2.3 GHz in the streaming kernels: the roll-out is limited by
-// what the chip's power management lets the vector units do, not by exposed latency), so it is off by default.
+// tile are issued into registers right before the current tile's rows are flushed and are parked in the tile once those
+// rows have left it.
 template <int E, int TW>
 struct MpFdPrefetch {
   static constexpr int NV = MP_FD_KS * E * TW / 4;  // 16-byte vectors per tile and lane
@@ -569,6 +567,64 @@ __device__ __forceinline__ void mp_fd_tile_out(float* __restrict__ gdst, int slo
   }
 }
 
+// tile -> global, WAVE-COOPERATIVE: the three output arrays of a whole tile leave in flat chunk order.  A trajectory's
+// rows of the tile are one contiguous run of MP_FD_KS * N floats per array (96 bytes at n = 6) and the runs of neighbouring
+// lanes are Nt * N * 4 bytes apart; stored lane by lane (mp_fd_tile_out) every store instruction scatters 64 16-byte pieces
+// over 64 different lines and each line is assembled from six instructions - measured, that output path cost 0.22 ms of
+// the 0.65 ms of config c5 (a build without it: 0.37 ms; without any tile I/O: 0.30 ms).  Here chunk f = k * 64 + lane of
+// the wave's 64 runs belongs to trajectory f / C, 16-byte piece f % C (C = pieces per run), so consecutive lanes write
+// consecutive 16-byte pieces of one run: a store instruction covers ~11 whole runs instead of 64 fragments.  The chunk ->
+// (trajectory, piece) split is the same for every tile and array: it is worked out once (`MpFdFlat`).
+template <int N>
+struct MpFdFlat {
+  static constexpr int C = MP_FD_KS * N / 4;      // 16-byte pieces per run (MP_FD_KS = 4: N of them)
+  static constexpr int NK = C;                     // store instructions per array: 64 * C chunks / 64 lanes
+  int lane;
+  // trajectory (lane column) and piece of this lane's chunk k - recomputed where used (a division by a constant) rather
+  // than carried in 2 NK registers through the integration steps
+  __device__ __forceinline__ int t(int k) const { return (int)((unsigned)(k * 64 + lane) / (unsigned)C); }
+  __device__ __forceinline__ int c(int k) const { return (k * 64 + lane) - t(k) * C; }
+};
+template <int N>
+__device__ __forceinline__ void mp_fd_flat_init(MpFdFlat<N>& F, int lane) { F.lane = lane; }
+// `lds` = the wave's tile base (lane offset NOT applied), `run0` = float index of (trajectory b0, step i0, joint 0),
+// `pitch` = floats between the runs of neighbouring trajectories (Nt * N), `nvalid` = trajectories of this wave inside the
+// batch.  An array's LDS reads are issued before its first store (every chunk's column exists: f < 64 C gives t < 64), so the
+// wave waits for the LDS once per array and tile, and a whole wave stores without per-chunk branches.
+template <int N, int STEP>
+__device__ __forceinline__ void mp_fd_tile_out_flat(float* __restrict__ pos, float* __restrict__ vel, float* __restrict__ acc,
+                                                    long run0, long pitch, int nvalid, const MpFdFlat<N>& F,
+                                                    const unsigned* __restrict__ lds) {
+  constexpr int NK = MpFdFlat<N>::NK;
+  float* const arr[3] = {pos, vel, acc};
+  // one array at a time: its NK x 4 LDS reads are issued together (one LDS round trip), then its NK stores; holding all
+  // three arrays' chunks at once (72 registers + 18 addresses) pushed the kernel past 256 VGPRs into scratch
+#pragma unroll
+  for (int slot = 0; slot < 3; ++slot) {
+    mp_io_u4 v[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      const int t = F.t(k), c = F.c(k);
+      unsigned e[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = 4 * c + i, s = r / N, j = r - s * N;  // run index -> (step, joint)
+        e[i] = lds[s * STEP + (slot * N + j) * 64 + t];
+      }
+      v[k].x = e[0]; v[k].y = e[1]; v[k].z = e[2]; v[k].w = e[3];
+    }
+    float* const base = arr[slot] + run0;
+    if (nvalid == 64) {
+#pragma unroll
+      for (int k = 0; k < NK; ++k) *reinterpret_cast<mp_io_u4*>(base + (long)F.t(k) * pitch + 4 * F.c(k)) = v[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < NK; ++k)
+        if (F.t(k) < nvalid) *reinterpret_cast<mp_io_u4*>(base + (long)F.t(k) * pitch + 4 * F.c(k)) = v[k];
+    }
+  }
+}
+
 template <typename T, int TW, int W>
 __device__ __forceinline__ T mp_fd_tile_get(const unsigned* __restrict__ cs, int c, int E) {
   if constexpr (TW == 1) {
@@ -583,15 +639,24 @@ __device__ __forceinline__ T mp_fd_tile_get(const unsigned* __restrict__ cs, int
 template <typename T, int N, bool HAS_FTIP, typename MT>
 __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C, const T* __restrict__ theta0,
                                                 const T* __restrict__ dtheta0, const T* __restrict__ taumat,
-                                                const T* __restrict__ Ftipmat, long b, long Nt, T h, int intRes,
+                                                const T* __restrict__ Ftipmat, long bl, long B, long Nt, T h, int intRes,
                                                 float* __restrict__ pos, float* __restrict__ vel, float* __restrict__ acc,
                                                 unsigned* __restrict__ lds, int lane) {
   using TL = MpFdTile<T, N, HAS_FTIP>;
   constexpr int TW = TL::TW, STEP = TL::STEP;
+  // EVERY lane of the wave runs this body (the flat stores are wave-cooperative): lanes past the batch integrate the
+  // last trajectory again and store nothing
+  const long b0 = bl - lane;                       // the wave's first trajectory (wave-uniform)
+  if (b0 >= B) return;
+  const bool in_batch = bl < B;
+  const long b = in_batch ? bl : B - 1;
+  const int nvalid = (B - b0) < 64 ? (int)(B - b0) : 64;
   unsigned* col = lds + lane;
   T q[N], qd[N];
   RunIO<T, N>::load(theta0, b, q);
   RunIO<T, N>::load(dtheta0, b, qd);
+  MpFdFlat<N> flat;
+  mp_fd_flat_init<N>(flat, lane);
   // Sticky non-finite verdict (running maxima of the bit patterns, mp_core.h): the initial state, every torque / wrench
   // row consumed and the integrated velocity feed it; from the first step at which it trips, the trajectory's rows are
   // NaN, as in the reference, whose state stays non-finite once it is (row 0 is the initial state as given).
@@ -601,7 +666,8 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
   const bool vec_tau = ((Nt * N * (long)sizeof(T)) & 15) == 0, vec_out = ((Nt * N * 4) & 15) == 0;
   const bool vec_f = ((Nt * 6 * (long)sizeof(T)) & 15) == 0;
   // software pipeline of the vector path: `pre_*` hold the inputs of the tile about to start (loaded one tile ahead)
-#if defined(MP_FD_PREFETCH)  // opt-in: measured neutral on config c5 (tools/ab_c5.sh, five interleaved rounds: 0.642 vs 0.633 ms)
+#if defined(MP_FD_PREFETCH)  // opt-in: measured neutral on config c5 in every form tried (issued at the tile top, or right
+  // before the flush; both arrays, or the torques only so that nothing spills): 0.587-0.607 ms median against 0.587-0.601
   constexpr bool PIPE = (MP_FD_KS * N * TW) % 4 == 0 && (MP_FD_KS * 6 * TW) % 4 == 0;
 #else
   constexpr bool PIPE = false;
@@ -615,13 +681,13 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
     const bool full = rows == MP_FD_KS;
     const long row0 = b * Nt + i0;
     const bool next_full = left >= 2 * MP_FD_KS;  // the tile after this one is a whole tile
+#if !defined(MP_FD_EXP_NOIN)  // (experiments: MP_FD_EXP_NOIN / MP_FD_EXP_NOOUT build kernels without the input / output half of the tile I/O)
     {
       const unsigned* g = reinterpret_cast<const unsigned*>(taumat + row0 * N);
       if (PIPE && full && vec_tau) {
         if (!have_tau) mp_fd_tile_load<N, TW>(g, pre_tau);
         mp_fd_tile_park<N, TW, TL::TAU0, STEP, 64>(pre_tau, col);
-        have_tau = next_full;
-        if (next_full) mp_fd_tile_load<N, TW>(g + MP_FD_KS * N * TW, pre_tau);
+        have_tau = false;
       } else if (full && vec_tau) mp_fd_tile_in<N, TW, TL::TAU0, STEP, 64, 4>(g, 0, col);
       else mp_fd_tile_in<N, TW, TL::TAU0, STEP, 64, 1>(g, rows * N * TW, col);
     }
@@ -630,11 +696,11 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
       if (PIPE && full && vec_f) {
         if (!have_f) mp_fd_tile_load<6, TW>(g, pre_f);
         mp_fd_tile_park<6, TW, TL::F0, STEP, 64>(pre_f, col);
-        have_f = next_full;
-        if (next_full) mp_fd_tile_load<6, TW>(g + MP_FD_KS * 6 * TW, pre_f);
+        have_f = false;
       } else if (full && vec_f) mp_fd_tile_in<6, TW, TL::F0, STEP, 64, 4>(g, 0, col);
       else mp_fd_tile_in<6, TW, TL::F0, STEP, 64, 1>(g, rows * 6 * TW, col);
     }
+#endif
     for (int s = 0; s < rows; ++s) {
       unsigned* cs = col + s * STEP;
       T last[N];
@@ -643,12 +709,22 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
       if (i0 + s > 0) {
         T tau[N], tn[3] = {T(0), T(0), T(0)}, tf[3] = {T(0), T(0), T(0)};
 #pragma unroll
-        for (int j = 0; j < N; ++j) tau[j] = mp_fd_tile_get<T, TW, 64>(cs, TL::TAU0 + j, N);
+        for (int j = 0; j < N; ++j)
+#if defined(MP_FD_EXP_NOIN)
+          tau[j] = q[j] * T(1e-3);
+#else
+          tau[j] = mp_fd_tile_get<T, TW, 64>(cs, TL::TAU0 + j, N);
+#endif
         bad.add(tau);
         if (HAS_FTIP) {
           T F[6];
 #pragma unroll
-          for (int k = 0; k < 6; ++k) F[k] = mp_fd_tile_get<T, TW, 64>(cs, TL::F0 + k, 6);
+          for (int k = 0; k < 6; ++k)
+#if defined(MP_FD_EXP_NOIN)
+            F[k] = qd[k % N] * T(1e-3);
+#else
+            F[k] = mp_fd_tile_get<T, TW, 64>(cs, TL::F0 + k, 6);
+#endif
           bad.add(F);
           mp_wrench_to_frame1(M, F, tn, tf);
         }
@@ -663,6 +739,9 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
         bad.add(qd);
       }
       const bool poison = (i0 + s > 0) && bad.any();
+#if defined(MP_FD_EXP_NOOUT)
+      if (i0 + s + 1 == Nt)
+#endif
 #pragma unroll
       for (int j = 0; j < N; ++j) {
         cs[j * 64] = poison ? 0x7fc00000u : __builtin_bit_cast(unsigned, (float)q[j]);
@@ -670,7 +749,34 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
         cs[(2 * N + j) * 64] = poison ? 0x7fc00000u : __builtin_bit_cast(unsigned, (float)last[j]);
       }
     }
+#if defined(MP_FD_EXP_NOOUT)
+    if (i0 + MP_FD_KS < Nt) continue;
+#endif
+    // the NEXT tile's torque / wrench rows are requested now, so that their latency (microseconds under load, with one
+    // other wave on the SIMD to cover it) runs beside the flush of this tile's rows; they wait in registers only across
+    // the flush - held across the integration steps they pushed the kernel past 256 VGPRs
+    if (PIPE && next_full) {
+      if (vec_tau) { mp_fd_tile_load<N, TW>(reinterpret_cast<const unsigned*>(taumat + (row0 + MP_FD_KS) * N), pre_tau); have_tau = true; }
+#if !defined(MP_FD_PREFETCH_TAU_ONLY)
+      if (HAS_FTIP && vec_f) { mp_fd_tile_load<6, TW>(reinterpret_cast<const unsigned*>(Ftipmat + (row0 + MP_FD_KS) * 6), pre_f); have_f = true; }
+#endif
+    }
+#if !defined(MP_FD_LANE_STORES)  // (A/B switch: MP_FD_LANE_STORES keeps the lane-by-lane stores)
     if (full && vec_out) {
+      // the tile was written column by column (each lane its own); the flat stores read across columns
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const long run0 = (b0 * Nt + i0) * N;
+      mp_fd_tile_out_flat<N, STEP>(pos, vel, acc, run0, Nt * N, nvalid, flat, lds);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the next tile's inputs overwrite these columns
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else
+#endif
+    if (!in_batch) {
+      // partial / unaligned tiles leave lane by lane: lanes past the batch have nothing to store
+    } else if (full && vec_out) {
       mp_fd_tile_out<N, STEP, 64, 4>(pos + row0 * N, 0, 0, col);
       mp_fd_tile_out<N, STEP, 64, 4>(vel + row0 * N, 1, 0, col);
       mp_fd_tile_out<N, STEP, 64, 4>(acc + row0 * N, 2, 0, col);
