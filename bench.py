@@ -361,6 +361,7 @@ def main():
     ap.add_argument("--no-specialize", action="store_true", help="use the generic kernels (no run-time robot specialisation)")
     ap.add_argument("--B", type=int, default=0, help="experiments only: override the config's trajectories per GPU")
     ap.add_argument("--N", type=int, default=0, help="experiments only: override the config's timesteps")
+    ap.add_argument("--robot", default="", help="experiments only: override the config's robot")
     ap.add_argument("--input-sets", type=int, default=0,
                     help="distinct input/output sets the steps rotate over (0 = enough for > 1.1 GB in flight, so no step can "
                          "be served from the 256 MB Infinity Cache)")
@@ -387,9 +388,9 @@ def main():
         return
 
     cfg = dict(CONFIGS[args.config])
-    if args.B or args.N:
-        cfg["B"], cfg["N"] = args.B or cfg["B"], args.N or cfg["N"]
-        cfg["desc"] += f" [OVERRIDDEN: B={cfg['B']} N={cfg['N']}]"
+    if args.B or args.N or args.robot:
+        cfg["B"], cfg["N"], cfg["robot"] = args.B or cfg["B"], args.N or cfg["N"], args.robot or cfg["robot"]
+        cfg["desc"] += f" [OVERRIDDEN: B={cfg['B']} N={cfg['N']} robot={cfg['robot']}]"
     t = robots.robot_tables(cfg["robot"])
     n = t["S_list"].shape[1]
     B, N = cfg["B"], cfg["N"]

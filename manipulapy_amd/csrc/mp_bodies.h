@@ -523,9 +523,9 @@ __device__ __forceinline__ void mp_fd_tile_in(const unsigned* __restrict__ g, in
   }
 }
 
-// The same in two halves, for an optional software-pipelined vector path (MP_FD_PREFETCH): the global loads of the NEXT
-// tile are issued into registers right before the current tile's rows are flushed and are parked in the tile once those
-// rows have left it.
+// The same in two halves, for the optional pipelined vector path (MP_FD_PREFETCH): the global loads of the NEXT tile are
+// issued into registers and waited for right before the current tile's rows are flushed, and parked in the tile once
+// those rows have left it (see "Optional order of the tile boundary" in mp_body_fd_traj).
 template <int E, int TW>
 struct MpFdPrefetch {
   static constexpr int NV = MP_FD_KS * E * TW / 4;  // 16-byte vectors per tile and lane
@@ -535,6 +535,12 @@ template <int E, int TW>
 __device__ __forceinline__ void mp_fd_tile_load(const unsigned* __restrict__ g, MpFdPrefetch<E, TW>& r) {
 #pragma unroll
   for (int k = 0; k < MpFdPrefetch<E, TW>::NV; ++k) r.v[k] = *reinterpret_cast<const mp_io_u4*>(g + 4 * k);
+}
+// make the wave wait for the loads of `r` HERE (an empty asm that consumes every register)
+template <int E, int TW>
+__device__ __forceinline__ void mp_fd_tile_arrive(MpFdPrefetch<E, TW>& r) {
+#pragma unroll
+  for (int k = 0; k < MpFdPrefetch<E, TW>::NV; ++k) asm volatile("" : "+v"(r.v[k]));
 }
 template <int E, int TW, int BASE, int STEP, int W>
 __device__ __forceinline__ void mp_fd_tile_park(const MpFdPrefetch<E, TW>& r, unsigned* __restrict__ col) {
@@ -635,13 +641,36 @@ __device__ __forceinline__ T mp_fd_tile_get(const unsigned* __restrict__ cs, int
   }
 }
 
+// Staggered tile phases (MP_FD_STAGGER, off: measured 10 % SLOWER).  Every wave executes the same instructions, so all
+// 2048 waves of a launch reach their tile boundary together: the memory system idles through four integration steps and
+// then takes 64 KB from every wave at once while the vector units wait (config c5: 0.305 ms of arithmetic + 0.065 ms for
+// the inputs + 0.24 ms for the outputs add up to the 0.61 ms of the whole kernel; during the boundaries the memory system
+// moves ~7 TB/s).  Letting a wave start with a SHORT first tile of MP_FD_KS - stagger rows (stagger from the bits of the
+// block index that differ between the waves sharing a CU; later tiles must still start on a 16-byte boundary of every
+// lane's run, so the stagger is a multiple of 1 step for N % 4 == 0, 2 for other even N, none for odd N) spreads the
+// boundaries over the steps - and costs 0.683 against 0.621 ms: a wave computing beside a partner that sits in its
+// boundary issues at the single-wave rate, and the bursts of pure stores followed by pure loads that the lock step
+// produces are what the HBM likes.  Kept as a measured negative result.
+template <int N>
+__device__ __forceinline__ int mp_fd_first_rows(unsigned block) {
+#if !defined(MP_FD_STAGGER)
+  (void)block;
+  return MP_FD_KS;
+#else
+  constexpr int ALIGN = (N % 4 == 0) ? 1 : (N % 2 == 0) ? 2 : MP_FD_KS;
+  // blocks go to the 8 XCDs round-robin; inside an XCD either CU by CU or round-robin over its 32 CUs: bits 3.. and 8..
+  const int want = (int)(((block >> 3) ^ (block >> 8)) & (MP_FD_KS - 1));
+  return MP_FD_KS - (want / ALIGN) * ALIGN;
+#endif
+}
+
 // `lds` is this wave's tile (MpFdTile<T, N, HAS_FTIP>::DWORDS dwords), `lane` the lane index inside the wave
 template <typename T, int N, bool HAS_FTIP, typename MT>
 __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C, const T* __restrict__ theta0,
                                                 const T* __restrict__ dtheta0, const T* __restrict__ taumat,
                                                 const T* __restrict__ Ftipmat, long bl, long B, long Nt, T h, int intRes,
                                                 float* __restrict__ pos, float* __restrict__ vel, float* __restrict__ acc,
-                                                unsigned* __restrict__ lds, int lane) {
+                                                unsigned* __restrict__ lds, int lane, int first_rows = MP_FD_KS) {
   using TL = MpFdTile<T, N, HAS_FTIP>;
   constexpr int TW = TL::TW, STEP = TL::STEP;
   // EVERY lane of the wave runs this body (the flat stores are wave-cooperative): lanes past the batch integrate the
@@ -666,8 +695,8 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
   const bool vec_tau = ((Nt * N * (long)sizeof(T)) & 15) == 0, vec_out = ((Nt * N * 4) & 15) == 0;
   const bool vec_f = ((Nt * 6 * (long)sizeof(T)) & 15) == 0;
   // software pipeline of the vector path: `pre_*` hold the inputs of the tile about to start (loaded one tile ahead)
-#if defined(MP_FD_PREFETCH)  // opt-in: measured neutral on config c5 in every form tried (issued at the tile top, or right
-  // before the flush; both arrays, or the torques only so that nothing spills): 0.587-0.607 ms median against 0.587-0.601
+#if defined(MP_FD_PREFETCH)  // opt-in: measured neutral (tools/ab_c5.sh, tools/ab_c5_cycles.sh: the waves' s_waitcnt share drops
+  // from 26 % to 18 % of their cycles and their issue stalls rise from 21 % to 31 %; kernel cycles 1.43 M vs 1.40 M)
   constexpr bool PIPE = (MP_FD_KS * N * TW) % 4 == 0 && (MP_FD_KS * 6 * TW) % 4 == 0;
 #else
   constexpr bool PIPE = false;
@@ -675,12 +704,13 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
   MpFdPrefetch<N, TW> pre_tau;
   MpFdPrefetch<6, TW> pre_f;
   bool have_tau = false, have_f = false;
-  for (long i0 = 0; i0 < Nt; i0 += MP_FD_KS) {
+  int tile_rows = first_rows;  // the first tile may be short (staggered phases); the others hold MP_FD_KS rows
+  for (long i0 = 0; i0 < Nt; i0 += tile_rows, tile_rows = MP_FD_KS) {
     const long left = Nt - i0;
-    const int rows = left < MP_FD_KS ? (int)left : MP_FD_KS;
+    const int rows = left < tile_rows ? (int)left : tile_rows;
     const bool full = rows == MP_FD_KS;
     const long row0 = b * Nt + i0;
-    const bool next_full = left >= 2 * MP_FD_KS;  // the tile after this one is a whole tile
+    const bool next_full = left - rows >= MP_FD_KS;  // the tile after this one is a whole tile
 #if !defined(MP_FD_EXP_NOIN)  // (experiments: MP_FD_EXP_NOIN / MP_FD_EXP_NOOUT build kernels without the input / output half of the tile I/O)
     {
       const unsigned* g = reinterpret_cast<const unsigned*>(taumat + row0 * N);
@@ -750,16 +780,19 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
       }
     }
 #if defined(MP_FD_EXP_NOOUT)
-    if (i0 + MP_FD_KS < Nt) continue;
+    if (i0 + rows < Nt) continue;
 #endif
-    // the NEXT tile's torque / wrench rows are requested now, so that their latency (microseconds under load, with one
-    // other wave on the SIMD to cover it) runs beside the flush of this tile's rows; they wait in registers only across
-    // the flush - held across the integration steps they pushed the kernel past 256 VGPRs
+    // Optional order of the tile boundary (MP_FD_PREFETCH).  Loads and stores share one counter (vmcnt) on gfx950 and
+    // complete out of order with respect to each other, so a wave that waits for a load while stores are in flight is
+    // made to wait for EVERY store too (the compiler emits vmcnt(0)): "flush this tile's rows, then fetch the next tile's
+    // torques / wrenches" drains 18 stores at every boundary.  With this switch the next tile's rows are requested FIRST
+    // and waited for before the first store is issued; the stores that follow are never waited for.  The rows wait in
+    // registers across the flush only.
     if (PIPE && next_full) {
-      if (vec_tau) { mp_fd_tile_load<N, TW>(reinterpret_cast<const unsigned*>(taumat + (row0 + MP_FD_KS) * N), pre_tau); have_tau = true; }
-#if !defined(MP_FD_PREFETCH_TAU_ONLY)
-      if (HAS_FTIP && vec_f) { mp_fd_tile_load<6, TW>(reinterpret_cast<const unsigned*>(Ftipmat + (row0 + MP_FD_KS) * 6), pre_f); have_f = true; }
-#endif
+      if (vec_tau) { mp_fd_tile_load<N, TW>(reinterpret_cast<const unsigned*>(taumat + (row0 + rows) * N), pre_tau); have_tau = true; }
+      if (HAS_FTIP && vec_f) { mp_fd_tile_load<6, TW>(reinterpret_cast<const unsigned*>(Ftipmat + (row0 + rows) * 6), pre_f); have_f = true; }
+      if (have_tau) mp_fd_tile_arrive<N, TW>(pre_tau);
+      if (have_f) mp_fd_tile_arrive<6, TW>(pre_f);
     }
 #if !defined(MP_FD_LANE_STORES)  // (A/B switch: MP_FD_LANE_STORES keeps the lane-by-lane stores)
     if (full && vec_out) {
@@ -768,7 +801,11 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       const long run0 = (b0 * Nt + i0) * N;
-      mp_fd_tile_out_flat<N, STEP>(pos, vel, acc, run0, Nt * N, nvalid, flat, lds);
+      // the chunk -> (trajectory, piece) split is the same for every tile; recomputing it from an opaque copy of the lane
+      // index keeps the compiler from hoisting a dozen per-lane 64-bit offsets out of the time loop (they were spilled)
+      MpFdFlat<N> fl = flat;
+      asm volatile("" : "+v"(fl.lane));
+      mp_fd_tile_out_flat<N, STEP>(pos, vel, acc, run0, Nt * N, nvalid, fl, lds);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the next tile's inputs overwrite these columns
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

@@ -227,7 +227,8 @@ __global__ __launch_bounds__(kFdBlock, (sizeof(T) == 4 ? 2 : 1)) void k_fd_traj(
                                                       float* __restrict__ pos, float* __restrict__ vel, float* __restrict__ acc) {
   __shared__ unsigned lds[MpFdTile<T, N, HAS_FTIP>::DWORDS];
   const long b = (long)blockIdx.x * kFdBlock + threadIdx.x;  // lanes past the batch stay (wave-cooperative stores)
-  mp_body_fd_traj<T, N, HAS_FTIP>(M, C, theta0, dtheta0, taumat, Ftipmat, b, B, Nt, h, intRes, pos, vel, acc, lds, (int)threadIdx.x);
+  mp_body_fd_traj<T, N, HAS_FTIP>(M, C, theta0, dtheta0, taumat, Ftipmat, b, B, Nt, h, intRes, pos, vel, acc, lds, (int)threadIdx.x,
+                                  mp_fd_first_rows<N>(blockIdx.x));
 }
 
 // float32, two trajectories per lane (packed math); the tile is twice as wide, so DOF 8 with wrenches is 60 KB
