@@ -622,7 +622,13 @@ __device__ __forceinline__ void mp_fd_tile_out_flat(float* __restrict__ pos, flo
     float* const base = arr[slot] + run0;
     if (nvalid == 64) {
 #pragma unroll
-      for (int k = 0; k < NK; ++k) *reinterpret_cast<mp_io_u4*>(base + (long)F.t(k) * pitch + 4 * F.c(k)) = v[k];
+      for (int k = 0; k < NK; ++k) {
+#if defined(MP_FD_NT_STORES)  // experiment: streaming (non-temporal) stores for the output rows
+        __builtin_nontemporal_store(v[k], reinterpret_cast<mp_io_u4*>(base + (long)F.t(k) * pitch + 4 * F.c(k)));
+#else
+        *reinterpret_cast<mp_io_u4*>(base + (long)F.t(k) * pitch + 4 * F.c(k)) = v[k];
+#endif
+      }
     } else {
 #pragma unroll
       for (int k = 0; k < NK; ++k)
@@ -658,8 +664,12 @@ __device__ __forceinline__ int mp_fd_first_rows(unsigned block) {
   return MP_FD_KS;
 #else
   constexpr int ALIGN = (N % 4 == 0) ? 1 : (N % 2 == 0) ? 2 : MP_FD_KS;
-  // blocks go to the 8 XCDs round-robin; inside an XCD either CU by CU or round-robin over its 32 CUs: bits 3.. and 8..
-  const int want = (int)(((block >> 3) ^ (block >> 8)) & (MP_FD_KS - 1));
+  // which bit of the block index separates the two waves that share a SIMD depends on the dispatcher's placement
+  // (blocks go to the 8 XCDs round-robin; inside an XCD either CU by CU or round-robin over its 32 CUs): experiment knob
+#if !defined(MP_FD_STAGGER_SHIFT)
+#define MP_FD_STAGGER_SHIFT 5
+#endif
+  const int want = (int)((block >> MP_FD_STAGGER_SHIFT) & 1u) * (MP_FD_KS / 2);
   return MP_FD_KS - (want / ALIGN) * ALIGN;
 #endif
 }
@@ -704,6 +714,12 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
   MpFdPrefetch<N, TW> pre_tau;
   MpFdPrefetch<6, TW> pre_f;
   bool have_tau = false, have_f = false;
+#if defined(MP_FD_STAGGER_SLEEP)  // experiment: the phase shift as an initial delay instead of a short first tile
+  if (first_rows != MP_FD_KS) {
+    for (int k = 0; k < MP_FD_STAGGER_SLEEP; ++k) __builtin_amdgcn_s_sleep(127);  // 127 x 64 cycles each
+    first_rows = MP_FD_KS;
+  }
+#endif
   int tile_rows = first_rows;  // the first tile may be short (staggered phases); the others hold MP_FD_KS rows
   for (long i0 = 0; i0 < Nt; i0 += tile_rows, tile_rows = MP_FD_KS) {
     const long left = Nt - i0;
