@@ -270,6 +270,10 @@ class OptimizedTrajectoryPlanning:
         if th.ndim != 2:
             raise ValueError(f"initial states must be (B, n); got {th.shape}")
         dtype = np.float32 if th.dtype == np.float32 else np.float64
+        if int(intRes) == 0:
+            raise ZeroDivisionError("float division by zero")  # dt_step = dt / intRes, as in the reference (:627)
+        if int(intRes) < 0:
+            raise ValueError("intRes must be positive")
         if g is None:
             g = np.array([0.0, 0.0, -9.81])
         pos, vel, acc = self._dispatch("dynamics.forward_trajectory", self._hip_model(), th, dtheta0_batch, taumat_batch, g,
