@@ -728,7 +728,37 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
     const long row0 = b * Nt + i0;
     const bool next_full = left - rows >= MP_FD_KS;  // the tile after this one is a whole tile
 #if !defined(MP_FD_EXP_NOIN)  // (experiments: MP_FD_EXP_NOIN / MP_FD_EXP_NOOUT build kernels without the input / output half of the tile I/O)
+#if defined(MP_FD_IN2)
+    // Experiment (off: 0.648 against 0.613 ms): inputs fetched for TWO tiles at a time (192-byte runs at n = 6 instead of
+    // 96-byte ones).  A lane's run starts wherever the previous one ended, so every 128-byte line that straddles two
+    // fetches is read twice (the lines of one fetch do not survive in L2 until the next: one open line per trajectory and
+    // array is 33 MB); halving the number of fetches halves the straddles.  The second tile's rows wait in registers (48
+    // of them, 227 VGPRs in all) across the four steps of the first.  The re-reads it saves are Infinity-Cache hits; the
+    // 24 loads per lane issued at once and the registers cost more than they return.
+    if (!PIPE && full && vec_tau && (!HAS_FTIP || vec_f)) {
+      if (have_tau) {  // second tile of a pair: its rows are in the registers
+        mp_fd_tile_park<N, TW, TL::TAU0, STEP, 64>(pre_tau, col);
+        if (HAS_FTIP) mp_fd_tile_park<6, TW, TL::F0, STEP, 64>(pre_f, col);
+        have_tau = false;
+      } else {
+        MpFdPrefetch<N, TW> now_tau;
+        MpFdPrefetch<6, TW> now_f;
+        const unsigned* gt = reinterpret_cast<const unsigned*>(taumat + row0 * N);
+        const unsigned* gf = HAS_FTIP ? reinterpret_cast<const unsigned*>(Ftipmat + row0 * 6) : nullptr;
+        mp_fd_tile_load<N, TW>(gt, now_tau);
+        if (HAS_FTIP) mp_fd_tile_load<6, TW>(gf, now_f);
+        if (next_full) {
+          mp_fd_tile_load<N, TW>(gt + MP_FD_KS * N * TW, pre_tau);
+          if (HAS_FTIP) mp_fd_tile_load<6, TW>(gf + MP_FD_KS * 6 * TW, pre_f);
+          have_tau = true;
+        }
+        mp_fd_tile_park<N, TW, TL::TAU0, STEP, 64>(now_tau, col);
+        if (HAS_FTIP) mp_fd_tile_park<6, TW, TL::F0, STEP, 64>(now_f, col);
+      }
+    } else
+#endif
     {
+      {
       const unsigned* g = reinterpret_cast<const unsigned*>(taumat + row0 * N);
       if (PIPE && full && vec_tau) {
         if (!have_tau) mp_fd_tile_load<N, TW>(g, pre_tau);
@@ -745,6 +775,7 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
         have_f = false;
       } else if (full && vec_f) mp_fd_tile_in<6, TW, TL::F0, STEP, 64, 4>(g, 0, col);
       else mp_fd_tile_in<6, TW, TL::F0, STEP, 64, 1>(g, rows * 6 * TW, col);
+    }
     }
 #endif
     for (int s = 0; s < rows; ++s) {
