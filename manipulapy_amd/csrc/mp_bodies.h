@@ -623,7 +623,10 @@ __device__ __forceinline__ void mp_fd_tile_out_flat(float* __restrict__ pos, flo
     if (nvalid == 64) {
 #pragma unroll
       for (int k = 0; k < NK; ++k) {
-#if defined(MP_FD_NT_STORES)  // experiment: streaming (non-temporal) stores for the output rows
+#if defined(MP_FD_EXP_NOSTORE)  // experiment: everything of the flush except the global stores themselves
+        asm volatile("" :: "v"(v[k]));
+        if (F.lane == 999) *reinterpret_cast<mp_io_u4*>(base + (long)F.t(k) * pitch + 4 * F.c(k)) = v[k];
+#elif defined(MP_FD_NT_STORES)  // experiment: streaming (non-temporal) stores for the output rows
         __builtin_nontemporal_store(v[k], reinterpret_cast<mp_io_u4*>(base + (long)F.t(k) * pitch + 4 * F.c(k)));
 #else
         *reinterpret_cast<mp_io_u4*>(base + (long)F.t(k) * pitch + 4 * F.c(k)) = v[k];
