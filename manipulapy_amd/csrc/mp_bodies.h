@@ -493,7 +493,14 @@ struct MpFdTile {
   static constexpr int F0 = (TW == 1) ? N : 5 * N;
   static constexpr int COLS32 = (HAS_FTIP && N + 6 > 3 * N) ? N + 6 : 3 * N;
   static constexpr int COLS = (TW == 1) ? COLS32 : 5 * N + (HAS_FTIP ? 12 : 0);
-  static constexpr int STEP = COLS * W;            // dwords per step (W = trajectories per wave: 64, or 128 packed)
+  // Row stride in dwords.  A row holds one value of the W trajectories of the wave; the 64-wide tile pads it by one
+  // dword: the flat stores read ACROSS rows (six lanes share a trajectory column and take different rows), which at a
+  // stride of 64 dwords puts all six on one LDS bank (PMC: 60 % of the LDS cycles of config c5 were bank conflicts).
+#if !defined(MP_FD_ROW_PAD)
+#define MP_FD_ROW_PAD 1
+#endif
+  static constexpr int RS = W + (W == 64 ? MP_FD_ROW_PAD : 0);
+  static constexpr int STEP = COLS * RS;           // dwords per step (W = trajectories per wave: 64, or 128 packed)
   static constexpr int DWORDS = MP_FD_KS * STEP;   // per wave
 };
 typedef unsigned mp_io_u4 __attribute__((ext_vector_type(4)));
@@ -597,11 +604,15 @@ __device__ __forceinline__ void mp_fd_flat_init(MpFdFlat<N>& F, int lane) { F.la
 // `pitch` = floats between the runs of neighbouring trajectories (Nt * N), `nvalid` = trajectories of this wave inside the
 // batch.  An array's LDS reads are issued before its first store (every chunk's column exists: f < 64 C gives t < 64), so the
 // wave waits for the LDS once per array and tile, and a whole wave stores without per-chunk branches.
-template <int N, int STEP>
+// `hold`: whole-64-byte-block mode (see MpFdCarry): the tail of a run that ends inside a 64-byte block is NOT stored (its
+// owner lane keeps it and stores it right before the next tile's run, which completes the block); `pm` = bytes between
+// the runs of neighbouring trajectories mod 64, `e_end` = byte offset of the END of trajectory b0's run mod 64.
+template <int N, int STEP, int RS>
 __device__ __forceinline__ void mp_fd_tile_out_flat(float* __restrict__ pos, float* __restrict__ vel, float* __restrict__ acc,
                                                     long run0, long pitch, int nvalid, const MpFdFlat<N>& F,
-                                                    const unsigned* __restrict__ lds) {
+                                                    const unsigned* __restrict__ lds, bool hold = false, int pm = 0, int e_end = 0) {
   constexpr int NK = MpFdFlat<N>::NK;
+  constexpr int RUN_BYTES = MP_FD_KS * N * 4;
   float* const arr[3] = {pos, vel, acc};
   // one array at a time: its NK x 4 LDS reads are issued together (one LDS round trip), then its NK stores; holding all
   // three arrays' chunks at once (72 registers + 18 addresses) pushed the kernel past 256 VGPRs into scratch
@@ -615,12 +626,19 @@ __device__ __forceinline__ void mp_fd_tile_out_flat(float* __restrict__ pos, flo
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int r = 4 * c + i, s = r / N, j = r - s * N;  // run index -> (step, joint)
-        e[i] = lds[s * STEP + (slot * N + j) * 64 + t];
+        e[i] = lds[s * STEP + (slot * N + j) * RS + t];
       }
       v[k].x = e[0]; v[k].y = e[1]; v[k].z = e[2]; v[k].w = e[3];
     }
     float* const base = arr[slot] + run0;
-    if (nvalid == 64) {
+    if (hold) {
+#pragma unroll
+      for (int k = 0; k < NK; ++k) {
+        const int t = F.t(k), c = F.c(k);
+        const int tail = (t * pm + e_end) & 63;  // bytes of trajectory t's run past its last whole 64-byte block
+        if (t < nvalid && 16 * c < RUN_BYTES - tail) *reinterpret_cast<mp_io_u4*>(base + (long)t * pitch + 4 * c) = v[k];
+      }
+    } else if (nvalid == 64) {
 #pragma unroll
       for (int k = 0; k < NK; ++k) {
 #if defined(MP_FD_EXP_NOSTORE)  // experiment: everything of the flush except the global stores themselves
@@ -638,6 +656,53 @@ __device__ __forceinline__ void mp_fd_tile_out_flat(float* __restrict__ pos, flo
         if (F.t(k) < nvalid) *reinterpret_cast<mp_io_u4*>(base + (long)F.t(k) * pitch + 4 * F.c(k)) = v[k];
     }
   }
+}
+
+// Whole 64-byte blocks.  A trajectory's rows of one tile are a run of MP_FD_KS * N * 4 bytes (96 at n = 6) that starts where
+// the previous tile's run ended, so at n = 6 every second run ends 32 bytes into a 64-byte block: written as it comes, the
+// block reaches the L2 in two parts four steps (~20 us) apart, is evicted in between (one open block per trajectory and
+// array is far more than the L2s hold) and goes to memory as two partial writes.  tools/ubench_c5io.hip, the kernel's
+// tile I/O around a stand-in for the arithmetic: 0.589 ms written as it comes, 0.472 ms when only whole 64-byte blocks
+// are written.  So the tail of a run that ends inside a block is held back: the owner lane reads it out of its own tile
+// column into registers (`v`: the last CP 16-byte pieces of each array's run) and stores it right before the next tile's
+// flat stores deliver the rest of the block.  Tails are multiples of 16 bytes (the vector path needs 16-byte aligned runs);
+// with an even n and a row pitch that is a multiple of 32 bytes they are 0 or 32 bytes (CP = 2), otherwise up to 48 (CP = 3).
+template <int N>
+struct MpFdCarry {
+  static constexpr int CP = (N % 2 == 0) ? 2 : 3;
+  static constexpr int C = MP_FD_KS * N / 4;  // 16-byte pieces per run
+  static constexpr bool ENABLED = C > CP;     // not for 1 - 3 joints: their runs are no longer than a tail
+  mp_io_u4 v[3][CP];
+  int bytes;  // of this lane's trajectory: how much of the previous tile's run is still to be written
+};
+// the tile still holds the run: keep its last CP pieces (own column, no bank conflicts)
+template <int N, int STEP, int RS>
+__device__ __forceinline__ void mp_fd_carry_keep(MpFdCarry<N>& K, const unsigned* __restrict__ col) {
+  constexpr int CP = MpFdCarry<N>::CP, C = MpFdCarry<N>::C;
+#pragma unroll
+  for (int slot = 0; slot < 3; ++slot)
+#pragma unroll
+    for (int q = 0; q < CP; ++q) {
+      unsigned e[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = 4 * (C - CP + q) + i, s = r / N, j = r - s * N;
+        e[i] = col[s * STEP + (slot * N + j) * RS];
+      }
+      K.v[slot][q].x = e[0]; K.v[slot][q].y = e[1]; K.v[slot][q].z = e[2]; K.v[slot][q].w = e[3];
+    }
+}
+// `run` = float index of this lane's run of the CURRENT tile; the pieces kept end right before it
+template <int N>
+__device__ __forceinline__ void mp_fd_carry_store(const MpFdCarry<N>& K, float* __restrict__ pos, float* __restrict__ vel,
+                                                  float* __restrict__ acc, long run) {
+  constexpr int CP = MpFdCarry<N>::CP;
+  float* const arr[3] = {pos, vel, acc};
+#pragma unroll
+  for (int slot = 0; slot < 3; ++slot)
+#pragma unroll
+    for (int q = 0; q < CP; ++q)
+      if ((CP - q) * 16 <= K.bytes) *reinterpret_cast<mp_io_u4*>(arr[slot] + run - 4 * (CP - q)) = K.v[slot][q];
 }
 
 template <typename T, int TW, int W>
@@ -685,7 +750,7 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
                                                 float* __restrict__ pos, float* __restrict__ vel, float* __restrict__ acc,
                                                 unsigned* __restrict__ lds, int lane, int first_rows = MP_FD_KS) {
   using TL = MpFdTile<T, N, HAS_FTIP>;
-  constexpr int TW = TL::TW, STEP = TL::STEP;
+  constexpr int TW = TL::TW, STEP = TL::STEP, RS = TL::RS;
   // EVERY lane of the wave runs this body (the flat stores are wave-cooperative): lanes past the batch integrate the
   // last trajectory again and store nothing
   const long b0 = bl - lane;                       // the wave's first trajectory (wave-uniform)
@@ -707,6 +772,18 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
   // 16-byte vector accesses need every lane's run to start on a 16-byte boundary (wave-uniform tests)
   const bool vec_tau = ((Nt * N * (long)sizeof(T)) & 15) == 0, vec_out = ((Nt * N * 4) & 15) == 0;
   const bool vec_f = ((Nt * 6 * (long)sizeof(T)) & 15) == 0;
+  // whole-64-byte-block output (MpFdCarry): the arrays start on a block boundary, tails come in the sizes the carry holds
+#if defined(MP_FD_NO_BLOCK64)  // A/B switch
+  const bool block64 = false;
+#else
+  const bool block64 = vec_out && MpFdCarry<N>::ENABLED &&
+                       (((unsigned long long)pos | (unsigned long long)vel | (unsigned long long)acc) & 63ull) == 0 &&
+                       (N % 2 != 0 || ((Nt * N * 4) & 31) == 0) &&
+                       !((MP_FD_KS * N * 4) % 64 == 0 && ((Nt * N * 4) & 63) == 0);  // runs that are whole blocks anyway (n = 4, 8)
+#endif
+  const int pitch_mod = (int)((Nt * N * 4) & 63);
+  MpFdCarry<N> carry;
+  carry.bytes = 0;
   // software pipeline of the vector path: `pre_*` hold the inputs of the tile about to start (loaded one tile ahead)
 #if defined(MP_FD_PREFETCH)  // opt-in: measured neutral (tools/ab_c5.sh, tools/ab_c5_cycles.sh: the waves' s_waitcnt share drops
   // from 26 % to 18 % of their cycles and their issue stalls rise from 21 % to 31 %; kernel cycles 1.43 M vs 1.40 M)
@@ -717,11 +794,47 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
   MpFdPrefetch<N, TW> pre_tau;
   MpFdPrefetch<6, TW> pre_f;
   bool have_tau = false, have_f = false;
+#if defined(MP_FD_STAGGER_HW)
+  // Experiment: phases by HARDWARE placement.  The two waves that share a SIMD stay in phase (a lone wave issues at half
+  // rate), the phase comes from where the wave landed: MP_FD_STAGGER_HW phases, field MP_FD_STAGGER_HW_FIELD of HW_ID
+  // (0: CU_ID bits [11:8], 1: SIMD_ID [5:4], 2: SE_ID [15:13]), MP_FD_STAGGER_HW_SLEEP x 64 x 16 cycles per phase step.
+  {
+#if !defined(MP_FD_STAGGER_HW_FIELD)
+#define MP_FD_STAGGER_HW_FIELD 0
+#endif
+#if !defined(MP_FD_STAGGER_HW_SLEEP)
+#define MP_FD_STAGGER_HW_SLEEP 4
+#endif
+    constexpr int kReg = MP_FD_STAGGER_HW_FIELD == 0 ? ((3 << 11) | (8 << 6) | 4)
+                         : MP_FD_STAGGER_HW_FIELD == 1 ? ((1 << 11) | (4 << 6) | 4) : ((2 << 11) | (13 << 6) | 4);
+    const unsigned where = __builtin_amdgcn_s_getreg(kReg);
+    const int ph = (int)(where % (unsigned)(MP_FD_STAGGER_HW));
+    for (int k = 0; k < ph * MP_FD_STAGGER_HW_SLEEP; ++k) __builtin_amdgcn_s_sleep(16);
+  }
+#endif
 #if defined(MP_FD_STAGGER_SLEEP)  // experiment: the phase shift as an initial delay instead of a short first tile
   if (first_rows != MP_FD_KS) {
     for (int k = 0; k < MP_FD_STAGGER_SLEEP; ++k) __builtin_amdgcn_s_sleep(127);  // 127 x 64 cycles each
     first_rows = MP_FD_KS;
   }
+#endif
+#if defined(MP_FD_EXP_TIMING)  // experiment: per-wave cycle totals of the tile phases, left in acc row 1 of the wave's first trajectory
+  unsigned long long tm_in = 0, tm_cmp = 0, tm_out = 0, tm_mark = __builtin_readcyclecounter();
+  const unsigned long long tm_start = tm_mark;
+#define MP_FD_TICK(acc_) do { const unsigned long long now_ = __builtin_readcyclecounter(); acc_ += now_ - tm_mark; tm_mark = now_; } while (0)
+#else
+#define MP_FD_TICK(acc_) do { } while (0)
+#endif
+#if !defined(MP_FD_PRIO)
+#define MP_FD_PRIO 3
+#endif
+#if MP_FD_PRIO
+  // Issue priority.  The two waves of a SIMD are not served alike: the arbiter takes the older one (wave slot 0) first, which
+  // then runs at the speed of a lone wave and finishes 25 % early, leaving its partner to integrate the rest alone
+  // (tools/c5_phase_times.py).  MP_FD_PRIO & 1: the favoured wave alternates tile by tile (s_setprio from tile index ^ wave
+  // slot); & 2: tile boundaries (loads, flat stores) run at the highest priority, so their memory requests leave early.
+  const unsigned wave_slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1u;
+  unsigned tile_no = 0;
 #endif
   int tile_rows = first_rows;  // the first tile may be short (staggered phases); the others hold MP_FD_KS rows
   for (long i0 = 0; i0 < Nt; i0 += tile_rows, tile_rows = MP_FD_KS) {
@@ -740,8 +853,8 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
     // 24 loads per lane issued at once and the registers cost more than they return.
     if (!PIPE && full && vec_tau && (!HAS_FTIP || vec_f)) {
       if (have_tau) {  // second tile of a pair: its rows are in the registers
-        mp_fd_tile_park<N, TW, TL::TAU0, STEP, 64>(pre_tau, col);
-        if (HAS_FTIP) mp_fd_tile_park<6, TW, TL::F0, STEP, 64>(pre_f, col);
+        mp_fd_tile_park<N, TW, TL::TAU0, STEP, RS>(pre_tau, col);
+        if (HAS_FTIP) mp_fd_tile_park<6, TW, TL::F0, STEP, RS>(pre_f, col);
         have_tau = false;
       } else {
         MpFdPrefetch<N, TW> now_tau;
@@ -755,8 +868,8 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
           if (HAS_FTIP) mp_fd_tile_load<6, TW>(gf + MP_FD_KS * 6 * TW, pre_f);
           have_tau = true;
         }
-        mp_fd_tile_park<N, TW, TL::TAU0, STEP, 64>(now_tau, col);
-        if (HAS_FTIP) mp_fd_tile_park<6, TW, TL::F0, STEP, 64>(now_f, col);
+        mp_fd_tile_park<N, TW, TL::TAU0, STEP, RS>(now_tau, col);
+        if (HAS_FTIP) mp_fd_tile_park<6, TW, TL::F0, STEP, RS>(now_f, col);
       }
     } else
 #endif
@@ -765,21 +878,30 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
       const unsigned* g = reinterpret_cast<const unsigned*>(taumat + row0 * N);
       if (PIPE && full && vec_tau) {
         if (!have_tau) mp_fd_tile_load<N, TW>(g, pre_tau);
-        mp_fd_tile_park<N, TW, TL::TAU0, STEP, 64>(pre_tau, col);
+        mp_fd_tile_park<N, TW, TL::TAU0, STEP, RS>(pre_tau, col);
         have_tau = false;
-      } else if (full && vec_tau) mp_fd_tile_in<N, TW, TL::TAU0, STEP, 64, 4>(g, 0, col);
-      else mp_fd_tile_in<N, TW, TL::TAU0, STEP, 64, 1>(g, rows * N * TW, col);
+      } else if (full && vec_tau) mp_fd_tile_in<N, TW, TL::TAU0, STEP, RS, 4>(g, 0, col);
+      else mp_fd_tile_in<N, TW, TL::TAU0, STEP, RS, 1>(g, rows * N * TW, col);
     }
     if (HAS_FTIP) {
       const unsigned* g = reinterpret_cast<const unsigned*>(Ftipmat + row0 * 6);
       if (PIPE && full && vec_f) {
         if (!have_f) mp_fd_tile_load<6, TW>(g, pre_f);
-        mp_fd_tile_park<6, TW, TL::F0, STEP, 64>(pre_f, col);
+        mp_fd_tile_park<6, TW, TL::F0, STEP, RS>(pre_f, col);
         have_f = false;
-      } else if (full && vec_f) mp_fd_tile_in<6, TW, TL::F0, STEP, 64, 4>(g, 0, col);
-      else mp_fd_tile_in<6, TW, TL::F0, STEP, 64, 1>(g, rows * 6 * TW, col);
+      } else if (full && vec_f) mp_fd_tile_in<6, TW, TL::F0, STEP, RS, 4>(g, 0, col);
+      else mp_fd_tile_in<6, TW, TL::F0, STEP, RS, 1>(g, rows * 6 * TW, col);
     }
     }
+#endif
+#if defined(MP_FD_EXP_TIMING)
+    __builtin_amdgcn_s_waitcnt(0);  // everything the input half issued has landed
+#endif
+    MP_FD_TICK(tm_in);
+#if MP_FD_PRIO
+    if ((MP_FD_PRIO & 1) && ((tile_no ^ wave_slot) & 1u)) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+    ++tile_no;
 #endif
     for (int s = 0; s < rows; ++s) {
       unsigned* cs = col + s * STEP;
@@ -793,7 +915,7 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
 #if defined(MP_FD_EXP_NOIN)
           tau[j] = q[j] * T(1e-3);
 #else
-          tau[j] = mp_fd_tile_get<T, TW, 64>(cs, TL::TAU0 + j, N);
+          tau[j] = mp_fd_tile_get<T, TW, RS>(cs, TL::TAU0 + j, N);
 #endif
         bad.add(tau);
         if (HAS_FTIP) {
@@ -803,7 +925,7 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
 #if defined(MP_FD_EXP_NOIN)
             F[k] = qd[k % N] * T(1e-3);
 #else
-            F[k] = mp_fd_tile_get<T, TW, 64>(cs, TL::F0 + k, 6);
+            F[k] = mp_fd_tile_get<T, TW, RS>(cs, TL::F0 + k, 6);
 #endif
           bad.add(F);
           mp_wrench_to_frame1(M, F, tn, tf);
@@ -824,13 +946,17 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
 #endif
 #pragma unroll
       for (int j = 0; j < N; ++j) {
-        cs[j * 64] = poison ? 0x7fc00000u : __builtin_bit_cast(unsigned, (float)q[j]);
-        cs[(N + j) * 64] = poison ? 0x7fc00000u : __builtin_bit_cast(unsigned, (float)qd[j]);
-        cs[(2 * N + j) * 64] = poison ? 0x7fc00000u : __builtin_bit_cast(unsigned, (float)last[j]);
+        cs[j * RS] = poison ? 0x7fc00000u : __builtin_bit_cast(unsigned, (float)q[j]);
+        cs[(N + j) * RS] = poison ? 0x7fc00000u : __builtin_bit_cast(unsigned, (float)qd[j]);
+        cs[(2 * N + j) * RS] = poison ? 0x7fc00000u : __builtin_bit_cast(unsigned, (float)last[j]);
       }
     }
 #if defined(MP_FD_EXP_NOOUT)
     if (i0 + rows < Nt) continue;
+#endif
+    MP_FD_TICK(tm_cmp);
+#if MP_FD_PRIO
+    if (MP_FD_PRIO & 2) __builtin_amdgcn_s_setprio(3);
 #endif
     // Optional order of the tile boundary (MP_FD_PREFETCH).  Loads and stores share one counter (vmcnt) on gfx950 and
     // complete out of order with respect to each other, so a wave that waits for a load while stores are in flight is
@@ -855,7 +981,16 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
       // index keeps the compiler from hoisting a dozen per-lane 64-bit offsets out of the time loop (they were spilled)
       MpFdFlat<N> fl = flat;
       asm volatile("" : "+v"(fl.lane));
-      mp_fd_tile_out_flat<N, STEP>(pos, vel, acc, run0, Nt * N, nvalid, fl, lds);
+      const bool hold = block64 && next_full;  // the next tile is a whole tile: it completes the blocks this one leaves open
+      const int e_end = (int)(((i0 + MP_FD_KS) * N * 4) & 63);
+      if constexpr (MpFdCarry<N>::ENABLED) {
+        if (block64 && in_batch && carry.bytes > 0) mp_fd_carry_store<N>(carry, pos, vel, acc, row0 * N);
+      }
+      mp_fd_tile_out_flat<N, STEP, RS>(pos, vel, acc, run0, Nt * N, nvalid, fl, lds, hold, pitch_mod, e_end);
+      if constexpr (MpFdCarry<N>::ENABLED) {
+        carry.bytes = hold ? ((fl.lane * pitch_mod + e_end) & 63) : 0;
+        if (hold) mp_fd_carry_keep<N, STEP, RS>(carry, col);
+      }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the next tile's inputs overwrite these columns
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -864,15 +999,32 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
     if (!in_batch) {
       // partial / unaligned tiles leave lane by lane: lanes past the batch have nothing to store
     } else if (full && vec_out) {
-      mp_fd_tile_out<N, STEP, 64, 4>(pos + row0 * N, 0, 0, col);
-      mp_fd_tile_out<N, STEP, 64, 4>(vel + row0 * N, 1, 0, col);
-      mp_fd_tile_out<N, STEP, 64, 4>(acc + row0 * N, 2, 0, col);
+      mp_fd_tile_out<N, STEP, RS, 4>(pos + row0 * N, 0, 0, col);
+      mp_fd_tile_out<N, STEP, RS, 4>(vel + row0 * N, 1, 0, col);
+      mp_fd_tile_out<N, STEP, RS, 4>(acc + row0 * N, 2, 0, col);
     } else {
-      mp_fd_tile_out<N, STEP, 64, 1>(pos + row0 * N, 0, rows * N, col);
-      mp_fd_tile_out<N, STEP, 64, 1>(vel + row0 * N, 1, rows * N, col);
-      mp_fd_tile_out<N, STEP, 64, 1>(acc + row0 * N, 2, rows * N, col);
+      mp_fd_tile_out<N, STEP, RS, 1>(pos + row0 * N, 0, rows * N, col);
+      mp_fd_tile_out<N, STEP, RS, 1>(vel + row0 * N, 1, rows * N, col);
+      mp_fd_tile_out<N, STEP, RS, 1>(acc + row0 * N, 2, rows * N, col);
     }
+#if defined(MP_FD_EXP_TIMING)
+#if MP_FD_EXP_TIMING > 1
+    __builtin_amdgcn_s_waitcnt(0);  // > 1: the stores are waited for here, so their completion is booked to the flush
+#endif
+#endif
+    MP_FD_TICK(tm_out);
   }
+#if defined(MP_FD_EXP_TIMING)
+  __builtin_amdgcn_s_waitcnt(0);
+  if (lane == 0 && Nt > 2) {
+    float* dbg = acc + (b0 * Nt + 1) * N;
+    dbg[0] = (float)tm_in; dbg[1] = (float)tm_cmp; dbg[2] = (float)tm_out;
+    dbg[3] = (float)(__builtin_readcyclecounter() - tm_start);
+    dbg[4] = (float)(tm_start & 0xffffff);
+    // where the wave ran: HW_ID bits [15:0] (wave, SIMD, pipe, CU, SH, SE) + XCC_ID bits [3:0] << 16
+    dbg[5] = (float)((__builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4) & 0xffffu) | ((__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 0xfu) << 16));
+  }
+#endif
 }
 
 // float32, TWO trajectories per lane (packed v_pk_* math): lane `p` integrates trajectories 2p and 2p+1.  Same tile
