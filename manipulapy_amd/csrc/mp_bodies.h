@@ -604,6 +604,28 @@ __device__ __forceinline__ void mp_fd_flat_init(MpFdFlat<N>& F, int lane) { F.la
 // `pitch` = floats between the runs of neighbouring trajectories (Nt * N), `nvalid` = trajectories of this wave inside the
 // batch.  An array's LDS reads are issued before its first store (every chunk's column exists: f < 64 C gives t < 64), so the
 // wave waits for the LDS once per array and tile, and a whole wave stores without per-chunk branches.
+// Whole 64-byte blocks.  A trajectory's rows of one tile are a run of MP_FD_KS * N * 4 bytes (96 at n = 6) that starts where
+// the previous tile's run ended, so at n = 6 every second run ends 32 bytes into a 64-byte block: written as it comes, the
+// block reaches the L2 in two parts four steps (~20 us) apart, is evicted in between (one open block per trajectory and
+// array is far more than the L2s hold) and goes to memory as two partial writes.  tools/ubench_c5io.hip, the kernel's
+// tile I/O around a stand-in for the arithmetic: 0.589 ms written as it comes, 0.472 ms when only whole 64-byte blocks
+// are written.  So the tail of a run that ends inside a block is held back: the owner lane reads it out of its own tile
+// column into registers (`v`: the last CP 16-byte pieces of each array's run) and stores it right before the next tile's
+// flat stores deliver the rest of the block.  Tails are multiples of 16 bytes (the vector path needs 16-byte aligned runs);
+// with an even n and a row pitch that is a multiple of 32 bytes they are 0 or 32 bytes (CP = 2), otherwise up to 48 (CP = 3).
+#if !defined(MP_FD_BLOCK)
+#define MP_FD_BLOCK 64  // (128: whole lines - tails up to 96 bytes per array, 72 registers at n = 6; measured)
+#endif
+template <int N>
+struct MpFdCarry {
+  static constexpr int BLOCK = MP_FD_BLOCK, MASK = BLOCK - 1;
+  static constexpr int C = MP_FD_KS * N / 4;  // 16-byte pieces per run
+  static constexpr int CP_WANT = (N % 2 == 0) ? (BLOCK - 32) / 16 : (BLOCK - 16) / 16;  // largest tail, in pieces
+  static constexpr int CP = CP_WANT < C ? CP_WANT : C;                                   // (a tail is never longer than a run)
+  static constexpr bool ENABLED = BLOCK == 64 ? (C > CP) : (C >= 4 && MP_FD_KS * N * 4 <= BLOCK);  // 64: not for 1 - 3 joints
+  mp_io_u4 v[3][CP];
+  int bytes;  // of this lane's trajectory: how much of the previous tile's run is still to be written
+};
 // `hold`: whole-64-byte-block mode (see MpFdCarry): the tail of a run that ends inside a 64-byte block is NOT stored (its
 // owner lane keeps it and stores it right before the next tile's run, which completes the block); `pm` = bytes between
 // the runs of neighbouring trajectories mod 64, `e_end` = byte offset of the END of trajectory b0's run mod 64.
@@ -635,7 +657,7 @@ __device__ __forceinline__ void mp_fd_tile_out_flat(float* __restrict__ pos, flo
 #pragma unroll
       for (int k = 0; k < NK; ++k) {
         const int t = F.t(k), c = F.c(k);
-        const int tail = (t * pm + e_end) & 63;  // bytes of trajectory t's run past its last whole 64-byte block
+        const int tail = (t * pm + e_end) & MpFdCarry<N>::MASK;  // bytes of trajectory t's run past its last whole block
         if (t < nvalid && 16 * c < RUN_BYTES - tail) *reinterpret_cast<mp_io_u4*>(base + (long)t * pitch + 4 * c) = v[k];
       }
     } else if (nvalid == 64) {
@@ -658,23 +680,6 @@ __device__ __forceinline__ void mp_fd_tile_out_flat(float* __restrict__ pos, flo
   }
 }
 
-// Whole 64-byte blocks.  A trajectory's rows of one tile are a run of MP_FD_KS * N * 4 bytes (96 at n = 6) that starts where
-// the previous tile's run ended, so at n = 6 every second run ends 32 bytes into a 64-byte block: written as it comes, the
-// block reaches the L2 in two parts four steps (~20 us) apart, is evicted in between (one open block per trajectory and
-// array is far more than the L2s hold) and goes to memory as two partial writes.  tools/ubench_c5io.hip, the kernel's
-// tile I/O around a stand-in for the arithmetic: 0.589 ms written as it comes, 0.472 ms when only whole 64-byte blocks
-// are written.  So the tail of a run that ends inside a block is held back: the owner lane reads it out of its own tile
-// column into registers (`v`: the last CP 16-byte pieces of each array's run) and stores it right before the next tile's
-// flat stores deliver the rest of the block.  Tails are multiples of 16 bytes (the vector path needs 16-byte aligned runs);
-// with an even n and a row pitch that is a multiple of 32 bytes they are 0 or 32 bytes (CP = 2), otherwise up to 48 (CP = 3).
-template <int N>
-struct MpFdCarry {
-  static constexpr int CP = (N % 2 == 0) ? 2 : 3;
-  static constexpr int C = MP_FD_KS * N / 4;  // 16-byte pieces per run
-  static constexpr bool ENABLED = C > CP;     // not for 1 - 3 joints: their runs are no longer than a tail
-  mp_io_u4 v[3][CP];
-  int bytes;  // of this lane's trajectory: how much of the previous tile's run is still to be written
-};
 // the tile still holds the run: keep its last CP pieces (own column, no bank conflicts)
 template <int N, int STEP, int RS>
 __device__ __forceinline__ void mp_fd_carry_keep(MpFdCarry<N>& K, const unsigned* __restrict__ col) {
@@ -703,6 +708,62 @@ __device__ __forceinline__ void mp_fd_carry_store(const MpFdCarry<N>& K, float* 
 #pragma unroll
     for (int q = 0; q < CP; ++q)
       if ((CP - q) * 16 <= K.bytes) *reinterpret_cast<mp_io_u4*>(arr[slot] + run - 4 * (CP - q)) = K.v[slot][q];
+}
+
+// The flush of the pipelined path: the same flat chunk order, stored with raw BUFFER stores through one descriptor per
+// array that covers exactly the wave's runs of this tile (base 64 bytes before trajectory b0's run, so that the tails held
+// back by the previous tile are inside it).  A lane that must not store (trajectory past the batch, piece held back, no
+// tail pending) gets an offset outside the descriptor and the hardware drops its write: no EXEC masks, no branches, and
+// the number of stores in flight is the same on every path - which is what lets the compiler wait for the prefetched
+// input rows with vmcnt(stores issued since) instead of draining every store (see the pipelined path in mp_body_fd_traj).
+__device__ __forceinline__ float* mp_uniform_ptr(float* p) {
+  const unsigned long long u = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+  return (float*)(((unsigned long long)hi << 32) | lo);
+}
+template <int N, int STEP, int RS>
+__device__ __forceinline__ void mp_fd_tile_out_buf(float* __restrict__ pos, float* __restrict__ vel, float* __restrict__ acc,
+                                                   long run0, int pitch, int nvalid, int lane, bool in_batch,
+                                                   const unsigned* __restrict__ lds, bool hold, int pm, int e_end,
+                                                   const MpFdCarry<N>& K) {
+  constexpr int NK = MpFdFlat<N>::NK, C = MpFdFlat<N>::C, CP = MpFdCarry<N>::CP;
+  constexpr int RUN_BYTES = MP_FD_KS * N * 4;
+  constexpr int kNowhere = 0x7ffffff0;  // past any descriptor: the write is dropped
+  float* const arr[3] = {pos, vel, acc};
+  const int bytes = 64 + ((nvalid - 1) * pitch + MP_FD_KS * N) * 4;
+  MpFdFlat<N> F;
+  F.lane = lane;
+#pragma unroll
+  for (int slot = 0; slot < 3; ++slot) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(mp_uniform_ptr(arr[slot] + run0 - 16), 0, bytes, 0x00020000);
+    if constexpr (MpFdCarry<N>::ENABLED) {
+      // what the previous tile held back of this lane's own trajectory (ends right before its run of this tile)
+#pragma unroll
+      for (int q = 0; q < CP; ++q) {
+        const bool go = in_batch && (CP - q) * 16 <= K.bytes;
+        __builtin_amdgcn_raw_buffer_store_b128(K.v[slot][q], rs, go ? 64 + lane * pitch * 4 - (CP - q) * 16 : kNowhere, 0, 0);
+      }
+    }
+    mp_io_u4 v[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      const int t = F.t(k), c = F.c(k);
+      unsigned e[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = 4 * c + i, s = r / N, j = r - s * N;  // run index -> (step, joint)
+        e[i] = lds[s * STEP + (slot * N + j) * RS + t];
+      }
+      v[k].x = e[0]; v[k].y = e[1]; v[k].z = e[2]; v[k].w = e[3];
+    }
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      const int t = F.t(k), c = F.c(k);
+      const int tail = hold ? ((t * pm + e_end) & MpFdCarry<N>::MASK) : 0;  // bytes of trajectory t's run past its last whole block
+      const bool go = 16 * c < RUN_BYTES - tail;             // (trajectories past the batch are outside the descriptor)
+      __builtin_amdgcn_raw_buffer_store_b128(v[k], rs, go ? 64 + (t * pitch + 4 * c) * 4 : kNowhere, 0, 0);
+    }
+  }
 }
 
 template <typename T, int TW, int W>
@@ -777,11 +838,11 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
   const bool block64 = false;
 #else
   const bool block64 = vec_out && MpFdCarry<N>::ENABLED &&
-                       (((unsigned long long)pos | (unsigned long long)vel | (unsigned long long)acc) & 63ull) == 0 &&
+                       (((unsigned long long)pos | (unsigned long long)vel | (unsigned long long)acc) & (unsigned long long)MpFdCarry<N>::MASK) == 0 &&
                        (N % 2 != 0 || ((Nt * N * 4) & 31) == 0) &&
-                       !((MP_FD_KS * N * 4) % 64 == 0 && ((Nt * N * 4) & 63) == 0);  // runs that are whole blocks anyway (n = 4, 8)
+                       !((MP_FD_KS * N * 4) % MpFdCarry<N>::BLOCK == 0 && ((Nt * N * 4) & MpFdCarry<N>::MASK) == 0);  // runs that are whole blocks anyway (n = 4, 8)
 #endif
-  const int pitch_mod = (int)((Nt * N * 4) & 63);
+  const int pitch_mod = (int)((Nt * N * 4) & MpFdCarry<N>::MASK);
   MpFdCarry<N> carry;
   carry.bytes = 0;
   // software pipeline of the vector path: `pre_*` hold the inputs of the tile about to start (loaded one tile ahead)
@@ -836,8 +897,112 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
   const unsigned wave_slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1u;
   unsigned tile_no = 0;
 #endif
+  long i0_start = 0;
+#if defined(MP_FD_PIPE)
+  // ---- The pipelined path (opt-in: measured 0.560 against 0.520 ms, see below): every whole tile when all rows are
+  // 16-byte aligned.  A tile boundary is "flush this
+  // tile's rows, fetch the next tile's torques / wrenches, wait for them": vmcnt counts loads and stores in issue order, so
+  // that wait drained the 18 stores first - the waves sat through the memory system's slowest moment at every boundary
+  // (tools/c5_phase_times.py: 4.4 - 6 k of the ~36 k cycles of a tile).  Here the next tile's rows are REQUESTED BEFORE the
+  // flush (into registers: 12 x 16 bytes per lane at n = 6) and parked in the tile after it; the stores are younger than
+  // the loads, so the wait before parking is vmcnt(number of stores) and the stores are never waited for.  For the compiler
+  // to know that number the boundary must not branch around memory instructions: the flush stores through buffer
+  // descriptors (mp_fd_tile_out_buf), the first tile is peeled (no "first time round" merge at the loop head).  The ISA
+  // does what was intended (s_waitcnt vmcnt(29) .. vmcnt(21) before the parks, 242 VGPRs, no scratch) and the kernel is 8 %
+  // SLOWER: the boundary is not waiting on a latency that could be hidden, the memory system is busy for that long with
+  // this access pattern whatever the order (tools/ubench_c5io.hip: the tile I/O alone, no arithmetic, takes 0.47 ms).
+  {
+    constexpr bool PIPE_OK = (MP_FD_KS * N * TW) % 4 == 0 && (MP_FD_KS * 6 * TW) % 4 == 0;
+    const bool piped = PIPE_OK && vec_tau && vec_out && (!HAS_FTIP || vec_f) && first_rows == MP_FD_KS && Nt >= MP_FD_KS &&
+                       Nt * N * 4 * 64 < (1l << 30);
+    if (piped) {
+      constexpr int TAU_DW = MP_FD_KS * N * TW, F_DW = MP_FD_KS * 6 * TW;
+      const unsigned* gt = reinterpret_cast<const unsigned*>(taumat + b * Nt * N);
+      const unsigned* gf = HAS_FTIP ? reinterpret_cast<const unsigned*>(Ftipmat + b * Nt * 6) : nullptr;
+      const int pitch = (int)(Nt * N);
+      mp_fd_tile_load<N, TW>(gt, pre_tau);
+      if (HAS_FTIP) mp_fd_tile_load<6, TW>(gf, pre_f);
+      auto tile = [&](const long i0) __attribute__((always_inline)) {
+        const bool more = i0 + 2 * MP_FD_KS <= Nt;  // another whole tile follows
+        mp_fd_tile_park<N, TW, TL::TAU0, STEP, RS>(pre_tau, col);
+        if (HAS_FTIP) mp_fd_tile_park<6, TW, TL::F0, STEP, RS>(pre_f, col);
+        MP_FD_TICK(tm_in);
+#if MP_FD_PRIO
+        if ((MP_FD_PRIO & 1) && ((tile_no ^ wave_slot) & 1u)) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+        ++tile_no;
+#endif
+#pragma unroll 1
+        for (int s = 0; s < MP_FD_KS; ++s) {
+          unsigned* cs = col + s * STEP;
+          T last[N];
+#pragma unroll
+          for (int j = 0; j < N; ++j) last[j] = T(0);
+          if (i0 + s > 0) {
+            T tau[N], tn[3] = {T(0), T(0), T(0)}, tf[3] = {T(0), T(0), T(0)};
+#pragma unroll
+            for (int j = 0; j < N; ++j) tau[j] = mp_fd_tile_get<T, TW, RS>(cs, TL::TAU0 + j, N);
+            bad.add(tau);
+            if (HAS_FTIP) {
+              T F[6];
+#pragma unroll
+              for (int k = 0; k < 6; ++k) F[k] = mp_fd_tile_get<T, TW, RS>(cs, TL::F0 + k, 6);
+              bad.add(F);
+              mp_wrench_to_frame1(M, F, tn, tf);
+            }
+            for (int k = 0; k < intRes; ++k) {
+              mp_forward_dynamics_auto<T, N, HAS_FTIP>(M, C.a0, tn, tf, q, qd, tau, last);
+#pragma unroll
+              for (int j = 0; j < N; ++j) {
+                qd[j] = qd[j] + last[j] * h;
+                q[j] = mp_clip(q[j] + qd[j] * h, M.qmin[j], M.qmax[j]);
+              }
+            }
+            bad.add(qd);
+          }
+          const bool poison = (i0 + s > 0) && bad.any();
+#pragma unroll
+          for (int j = 0; j < N; ++j) {
+            cs[j * RS] = poison ? 0x7fc00000u : __builtin_bit_cast(unsigned, (float)q[j]);
+            cs[(N + j) * RS] = poison ? 0x7fc00000u : __builtin_bit_cast(unsigned, (float)qd[j]);
+            cs[(2 * N + j) * RS] = poison ? 0x7fc00000u : __builtin_bit_cast(unsigned, (float)last[j]);
+          }
+        }
+        MP_FD_TICK(tm_cmp);
+#if MP_FD_PRIO
+        if (MP_FD_PRIO & 2) __builtin_amdgcn_s_setprio(3);
+#endif
+        if (more) {  // the next tile's rows: requested before this tile's rows leave
+          mp_fd_tile_load<N, TW>(gt + (i0 / MP_FD_KS + 1) * TAU_DW, pre_tau);
+          if (HAS_FTIP) mp_fd_tile_load<6, TW>(gf + (i0 / MP_FD_KS + 1) * F_DW, pre_f);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the tile was written column by column; the flush reads across
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        int fl_lane = lane;
+        asm volatile("" : "+v"(fl_lane));  // (keeps the per-lane chunk offsets from being hoisted out of the time loop and spilled)
+        const bool hold = block64 && more;  // the next tile completes the 64-byte blocks this one leaves open
+        const int e_end = (int)(((i0 + MP_FD_KS) * N * 4) & MpFdCarry<N>::MASK);
+        mp_fd_tile_out_buf<N, STEP, RS>(pos, vel, acc, (b0 * Nt + i0) * N, pitch, nvalid, fl_lane, in_batch, lds, hold, pitch_mod,
+                                        e_end, carry);
+        if constexpr (MpFdCarry<N>::ENABLED) {
+          carry.bytes = hold ? ((fl_lane * pitch_mod + e_end) & MpFdCarry<N>::MASK) : 0;
+          if (hold) mp_fd_carry_keep<N, STEP, RS>(carry, col);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the next tile's inputs overwrite these columns
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        MP_FD_TICK(tm_out);
+      };
+      tile(0);
+      long i0 = MP_FD_KS;
+      for (; i0 + MP_FD_KS <= Nt; i0 += MP_FD_KS) tile(i0);
+      i0_start = i0;
+    }
+  }
+#endif
   int tile_rows = first_rows;  // the first tile may be short (staggered phases); the others hold MP_FD_KS rows
-  for (long i0 = 0; i0 < Nt; i0 += tile_rows, tile_rows = MP_FD_KS) {
+  for (long i0 = i0_start; i0 < Nt; i0 += tile_rows, tile_rows = MP_FD_KS) {
     const long left = Nt - i0;
     const int rows = left < tile_rows ? (int)left : tile_rows;
     const bool full = rows == MP_FD_KS;
@@ -871,6 +1036,18 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
         mp_fd_tile_park<N, TW, TL::TAU0, STEP, RS>(now_tau, col);
         if (HAS_FTIP) mp_fd_tile_park<6, TW, TL::F0, STEP, RS>(now_f, col);
       }
+    } else
+#endif
+#if !defined(MP_FD_PREFETCH) && !defined(MP_FD_IN_SEPARATE)
+    // both input arrays in ONE round trip: all their loads are issued before the first row is parked (two separate
+    // load-wait-park sequences sit in different branches, and the compiler does not hoist loads across them)
+    if (full && vec_tau && (!HAS_FTIP || vec_f) && (MP_FD_KS * N * TW) % 4 == 0) {
+      MpFdPrefetch<N, TW> now_tau;
+      MpFdPrefetch<6, TW> now_f;
+      mp_fd_tile_load<N, TW>(reinterpret_cast<const unsigned*>(taumat + row0 * N), now_tau);
+      if (HAS_FTIP) mp_fd_tile_load<6, TW>(reinterpret_cast<const unsigned*>(Ftipmat + row0 * 6), now_f);
+      mp_fd_tile_park<N, TW, TL::TAU0, STEP, RS>(now_tau, col);
+      if (HAS_FTIP) mp_fd_tile_park<6, TW, TL::F0, STEP, RS>(now_f, col);
     } else
 #endif
     {
@@ -958,17 +1135,19 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
 #if MP_FD_PRIO
     if (MP_FD_PRIO & 2) __builtin_amdgcn_s_setprio(3);
 #endif
-    // Optional order of the tile boundary (MP_FD_PREFETCH).  Loads and stores share one counter (vmcnt) on gfx950 and
-    // complete out of order with respect to each other, so a wave that waits for a load while stores are in flight is
-    // made to wait for EVERY store too (the compiler emits vmcnt(0)): "flush this tile's rows, then fetch the next tile's
-    // torques / wrenches" drains 18 stores at every boundary.  With this switch the next tile's rows are requested FIRST
+    // Optional order of the tile boundary (MP_FD_PREFETCH).  Loads and stores share one counter (vmcnt, in issue order):
+    // a wave that waits for loads issued AFTER the flush waits for every store of the flush too, and where paths with
+    // different store counts meet the compiler falls back to vmcnt(0): "flush this tile's rows, then fetch the next
+    // tile's torques / wrenches" drains 18 stores at every boundary.  With this switch the next tile's rows are requested FIRST
     // and waited for before the first store is issued; the stores that follow are never waited for.  The rows wait in
     // registers across the flush only.
     if (PIPE && next_full) {
       if (vec_tau) { mp_fd_tile_load<N, TW>(reinterpret_cast<const unsigned*>(taumat + (row0 + rows) * N), pre_tau); have_tau = true; }
       if (HAS_FTIP && vec_f) { mp_fd_tile_load<6, TW>(reinterpret_cast<const unsigned*>(Ftipmat + (row0 + rows) * 6), pre_f); have_f = true; }
+#if MP_FD_PREFETCH + 0 < 2  // MP_FD_PREFETCH=2: no wait here - the rows are waited for after the flush (vmcnt counts in order)
       if (have_tau) mp_fd_tile_arrive<N, TW>(pre_tau);
       if (have_f) mp_fd_tile_arrive<6, TW>(pre_f);
+#endif
     }
 #if !defined(MP_FD_LANE_STORES)  // (A/B switch: MP_FD_LANE_STORES keeps the lane-by-lane stores)
     if (full && vec_out) {
@@ -982,13 +1161,13 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
       MpFdFlat<N> fl = flat;
       asm volatile("" : "+v"(fl.lane));
       const bool hold = block64 && next_full;  // the next tile is a whole tile: it completes the blocks this one leaves open
-      const int e_end = (int)(((i0 + MP_FD_KS) * N * 4) & 63);
+      const int e_end = (int)(((i0 + MP_FD_KS) * N * 4) & MpFdCarry<N>::MASK);
       if constexpr (MpFdCarry<N>::ENABLED) {
         if (block64 && in_batch && carry.bytes > 0) mp_fd_carry_store<N>(carry, pos, vel, acc, row0 * N);
       }
       mp_fd_tile_out_flat<N, STEP, RS>(pos, vel, acc, run0, Nt * N, nvalid, fl, lds, hold, pitch_mod, e_end);
       if constexpr (MpFdCarry<N>::ENABLED) {
-        carry.bytes = hold ? ((fl.lane * pitch_mod + e_end) & 63) : 0;
+        carry.bytes = hold ? ((fl.lane * pitch_mod + e_end) & MpFdCarry<N>::MASK) : 0;
         if (hold) mp_fd_carry_keep<N, STEP, RS>(carry, col);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the next tile's inputs overwrite these columns

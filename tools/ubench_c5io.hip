@@ -33,7 +33,29 @@ __global__ __launch_bounds__(64) void k_io(const float* __restrict__ tau, const 
   float x = (float)lane;
   for (long i0 = 0; i0 + KS <= Nt; i0 += KS) {
     u4 v[12];
-    if ((WHAT & 1) && (WHAT & 16)) {
+    if ((WHAT & 1) && (WHAT & 64)) {
+      // line-exact reads: a lane fetches a whole 128-byte line of each input stream only when its run of this tile reaches
+      // past what it has already fetched (the rest of a line waits in registers in the real thing); lanes that need nothing
+      // this tile get an offset outside the descriptor (no traffic, no branch)
+      const int tile = (int)(i0 / KS);
+      const long s0 = b * Nt * N * 4;
+      const long need = s0 + 96l * (tile + 1);
+      long have = tile == 0 ? (s0 & ~127l) : ((s0 + 96l * tile + 127) & ~127l);   // fetched so far (line boundary)
+      const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(tau), 0, (int)(B * Nt * N * 4), 0x00020000);
+      const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(F), 0, (int)(B * Nt * 6 * 4), 0x00020000);
+#pragma unroll
+      for (int rep = 0; rep < 2; ++rep) {  // (the first tile of a misaligned stream needs two lines)
+        const bool go = have < need && (rep == 0 || tile == 0);
+        const int off = go ? (int)have : 0x7ffffff0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          keep ^= __builtin_amdgcn_raw_buffer_load_b128(rt, off + 16 * k, 0, 0);
+          keep ^= __builtin_amdgcn_raw_buffer_load_b128(rf, off + 16 * k, 0, 0);
+        }
+        if (go) have += 128;
+        if (tile != 0) break;
+      }
+    } else if ((WHAT & 1) && (WHAT & 16)) {
       // whole 64-byte blocks: a run that starts on a block boundary ((b + tile) even) takes two blocks, the second one's
       // last 32 bytes are the head of the next tile's run and stay in registers; the next tile then needs one block only
       const int tile = (int)(i0 / KS);
@@ -75,7 +97,25 @@ __global__ __launch_bounds__(64) void k_io(const float* __restrict__ tau, const 
 #pragma unroll
       for (int k = 0; k < 12; ++k) keep ^= v[k];
     }
-    if ((WHAT & 2) && (WHAT & 8)) {
+    if ((WHAT & 2) && (WHAT & 32)) {
+      // whole 128-byte LINES only, each lane its own trajectory (an upper bound on what a line-exact flush costs: a
+      // cooperative version would coalesce better): this tile the lane writes the lines its stream has completed
+      const int tile = (int)(i0 / KS);
+      const bool last = i0 + 2 * KS > Nt;
+      float* const arr[3] = {pos, vel, acc};
+      const long s0 = b * Nt * N * 4;                          // byte offset of the trajectory's stream
+      const long done = tile == 0 ? s0 : ((s0 + 96l * tile) & ~127l);         // written so far (line boundary, or the start)
+      const long upto = last ? s0 + 96l * (tile + 1) : ((s0 + 96l * (tile + 1)) & ~127l);
+#pragma unroll
+      for (int slot = 0; slot < 3; ++slot) {
+        char* base = reinterpret_cast<char*>(arr[slot]);
+#pragma unroll
+        for (int k = 0; k < 14; ++k) {
+          const long at = done + 16l * k;
+          if (at < upto) *reinterpret_cast<u4*>(base + at) = keep;
+        }
+      }
+    } else if ((WHAT & 2) && (WHAT & 8)) {
       // 64-byte-aligned variant: a trajectory's run of this tile starts on a 64-byte boundary when (b + tile) is even -
       // then its last 32 bytes (pieces 4, 5) are an incomplete block and are held back; when (b + tile) is odd the run starts
       // 32 bytes into a block: the owning lane first writes the 32 bytes held back by the previous tile, then the whole run leaves
@@ -169,6 +209,14 @@ int main(int argc, char** argv) {
   RUN(3, 2, fma_iters, sleep_units / 2, f0, "loads + stores, FMA, odd CUs half a tile late");
   RUN(10, 2, fma_iters, 0, f0, "stores in whole 64-byte blocks, FMA between tiles");
   RUN(11, 2, fma_iters, 0, f0, "loads + stores in whole 64-byte blocks, FMA between tiles");
+  RUN(34, 0, 0, 0, 0.f, "stores in whole 128-byte lines (lane = trajectory), back to back");
+  RUN(35, 0, 0, 0, 0.f, "loads + stores in whole 128-byte lines, back to back");
+  RUN(34, 2, fma_iters, 0, f0, "stores in whole 128-byte lines, FMA between tiles");
+  RUN(35, 2, fma_iters, 0, f0, "loads + stores in whole 128-byte lines, FMA between tiles");
+  RUN(65, 0, 0, 0, 0.f, "loads line-exact (whole 128-byte lines, no re-reads), back to back");
+  RUN(65, 2, fma_iters, 0, f0, "loads line-exact, FMA between tiles");
+  RUN(75, 0, 0, 0, 0.f, "loads line-exact + stores in 64-byte blocks, back to back");
+  RUN(75, 2, fma_iters, 0, f0, "loads line-exact + stores in 64-byte blocks, FMA between tiles");
   RUN(17, 0, 0, 0, 0.f, "loads in whole 64-byte blocks only, back to back");
   RUN(17, 2, fma_iters, 0, f0, "loads in whole 64-byte blocks, FMA between tiles");
   RUN(27, 0, 0, 0, 0.f, "loads AND stores in whole 64-byte blocks, back to back");
