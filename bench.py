@@ -195,6 +195,19 @@ def bench_fd(args, cfg, info, hg, ctx, model, t, props):
     def step():
         ctx.fd_trajectory(model, d_th0, d_dth0, d_tau, d_F, B, N, g, 0.01, 1, d_pos, d_vel, d_acc, dtype=np.float32)
 
+    # cold figure (reported beside the sustained one, never as `value`): the first launches after half a second of idle, before
+    # the power controller has settled - this kernel runs at the 1400 W package limit, sustained launches take ~1.2x the cold ones
+    step(); ctx.synchronize()
+    time.sleep(0.5)
+    ca, cb = ctx.event(), ctx.event()
+    ncold = max(1, min(8, args.steps))
+    ca.record()
+    for _ in range(ncold):
+        step()
+    cb.record()
+    ctx.synchronize()
+    kern_ms_cold = cb.elapsed_ms_since(ca) / ncold
+    ca.destroy(); cb.destroy()
     ramp(ctx, step, args.ramp_ms)
     for _ in range(args.warmup):
         step()
@@ -224,9 +237,11 @@ def bench_fd(args, cfg, info, hg, ctx, model, t, props):
                    "inputs": "gravity-holding torques + 1e-3 disturbance, per-step wrench 0.02 x reference wrench (finite for all N steps)",
                    "sharding": f"batch axis over {world} rank(s), no collective in the timed step"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                     "traffic": None, "kernel": kernel_name(cfg), "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                     "traffic": None, "kernel": kernel_name(cfg), "kernel_ms": kern_ms, "kernel_ms_cold": kern_ms_cold,
+                     "frac_cold": alg_bytes / (kern_ms_cold * 1e-3) / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": alg_bytes,
                      "kernel_ms_method": "HIP events on the launch stream around the K launches of the timed region, / K",
-                     "note": "sequential in time: VALU-bound (mass matrix + solve per step), HBM line shown for reference"},
+                     "note": "sequential in time; bounded by what the memory system moves for this access pattern (96-byte runs 2400 bytes apart, every 4 steps: "
+                             "tools/ubench_c5io moves the tile I/O alone in 0.47-0.55 ms) at the package power limit; arithmetic alone 0.29 ms (DESIGN.md section 4)"},
         "setup": {"ramp_ms": args.ramp_ms, "what": "untimed launches before the W warm-up steps (clock ramp)"},
         "device": props["name"],
     }

@@ -1429,6 +1429,44 @@ def test_c5_rollout_full_horizon_against_reference_dump_and_oracle(tables):
         ctx.destroy()
 
 
+@pytest.mark.parametrize("robot", ["ur5", "iiwa14", "panda", "xarm6"])
+def test_rollout_every_lane_every_tile_against_the_oracle(robot, tables):
+    """The output rows of a tile leave wave-cooperatively and in whole 64-byte blocks: which lane stores which 16 bytes, and
+    in which tile, depends on the trajectory index, the tile index, the row size (n = 6: 96-byte runs, tails of 0 / 32
+    bytes; n = 7: 112-byte runs, tails of 0 / 16 / 32 / 48; n = 8: whole lines) and the horizon (last tile, partial tile,
+    unaligned rows fall back to lane-by-lane stores).  Every element of every trajectory is compared with the C oracle,
+    for horizons that end on a whole tile, on a partial tile and on unaligned rows, full and ragged waves, with and
+    without wrenches, generic and robot-specialised kernels."""
+    from manipulapy_amd import _hip
+    from oracle import c_oracle
+
+    tab = tables[robot]
+    n = tab.n
+    ctx = _hip.HipContext(0)
+    try:
+        gen = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee, tab.joint_limits)
+        spec = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee, tab.joint_limits)
+        ctx.specialize(spec)
+        for B, Nt in ((130, 8), (65, 12), (64, 16), (130, 20), (63, 36), (1, 24), (67, 10), (66, 11), (129, 40)):
+            th0, dth0, tm, Fm = _c5_workload(tab, B, Nt, 4000 + 10 * B + Nt)
+            x = [a.astype(np.float32) for a in (th0, dth0, tm, Fm)]
+            x64 = [a.astype(np.float64) for a in x]
+            for wrench in (True, False):
+                want = c_oracle.fd_trajectory(tab, *x64[:3], G0_, x64[3] if wrench else np.zeros_like(x64[3]), 0.01, 1,
+                                              joint_limits=tab.joint_limits)[:3]
+                assert all(np.isfinite(w).all() for w in want)
+                for model in (spec, gen):
+                    got = ctx.fd_trajectory_host(model, x[0], x[1], x[2], G0_, x[3] if wrench else None, 0.01, 1, dtype=np.float32)
+                    for k in range(3):
+                        assert got[k].shape == (B, Nt, n)
+                        scale = float(np.abs(want[k]).max())
+                        err = np.abs(got[k].astype(np.float64) - want[k])
+                        bad = np.argwhere(err > 1e-4 * scale)
+                        assert bad.size == 0, (robot, B, Nt, wrench, k, bad[:5].tolist(), float(err.max() / scale))
+    finally:
+        ctx.destroy()
+
+
 def test_nonfinite_rows_contract(tables):
     """The reference returns a non-finite row wherever an input of that row is NaN / inf and leaves the other rows alone
     (tests/golden/nonfinite.npz, generated by the reference; its try / except only covers exceptions).  The kernels —
