@@ -614,7 +614,7 @@ __device__ __forceinline__ void mp_fd_flat_init(MpFdFlat<N>& F, int lane) { F.la
 // flat stores deliver the rest of the block.  Tails are multiples of 16 bytes (the vector path needs 16-byte aligned runs);
 // with an even n and a row pitch that is a multiple of 32 bytes they are 0 or 32 bytes (CP = 2), otherwise up to 48 (CP = 3).
 #if !defined(MP_FD_BLOCK)
-#define MP_FD_BLOCK 64  // (128: whole lines - tails up to 96 bytes per array, 72 registers at n = 6; measured)
+#define MP_FD_BLOCK 128  // whole lines: tails up to 96 bytes per array (72 registers at n = 6); 64: whole half lines, 24 registers
 #endif
 template <int N>
 struct MpFdCarry {
@@ -623,6 +623,14 @@ struct MpFdCarry {
   static constexpr int CP_WANT = (N % 2 == 0) ? (BLOCK - 32) / 16 : (BLOCK - 16) / 16;  // largest tail, in pieces
   static constexpr int CP = CP_WANT < C ? CP_WANT : C;                                   // (a tail is never longer than a run)
   static constexpr bool ENABLED = BLOCK == 64 ? (C > CP) : (C >= 4 && MP_FD_KS * N * 4 <= BLOCK);  // 64: not for 1 - 3 joints
+  // which flush a kernel is COMPILED with (one of them: with both in one kernel the register allocator spills): the
+  // owner-lane flush where runs are not whole blocks by themselves, the wave-cooperative flat stores where they are (n = 8:
+  // flat 0.684 ms against 0.752 - 0.779 ms owner-lane on the Panda) and for the short rows of 1 - 3 joints
+#if defined(MP_FD_NO_OWNER)
+  static constexpr bool OWNER = false;
+#else
+  static constexpr bool OWNER = ENABLED && (MP_FD_KS * N * 4) % BLOCK != 0;
+#endif
   mp_io_u4 v[3][CP];
   int bytes;  // of this lane's trajectory: how much of the previous tile's run is still to be written
 };
@@ -708,6 +716,46 @@ __device__ __forceinline__ void mp_fd_carry_store(const MpFdCarry<N>& K, float* 
 #pragma unroll
     for (int q = 0; q < CP; ++q)
       if ((CP - q) * 16 <= K.bytes) *reinterpret_cast<mp_io_u4*>(arr[slot] + run - 4 * (CP - q)) = K.v[slot][q];
+}
+
+// Owner-lane flush (the default wherever runs are not whole blocks by themselves): every lane stores the rows of its OWN trajectory straight from its own tile
+// column - no cross-lane reads (no wave barrier, no chunk -> (trajectory, piece) arithmetic, no bank conflicts) - and only
+// what completes whole blocks: the pieces the previous tile held back, then this run's pieces up to its last whole block;
+// the rest stays in `K` for the next tile.  A store instruction then touches 64 different lines, but each lane's pieces of
+// one line leave within the same flush (tools/ubench_c5io.hip "whole 128-byte lines (lane = trajectory)").
+template <int N, int STEP, int RS>
+__device__ __forceinline__ void mp_fd_tile_out_owner(float* __restrict__ pos, float* __restrict__ vel, float* __restrict__ acc,
+                                                     long run, bool in_batch, const unsigned* __restrict__ col, int tail,
+                                                     MpFdCarry<N>& K) {
+  constexpr int C = MpFdCarry<N>::C, CP = MpFdCarry<N>::CP, RUN_BYTES = MP_FD_KS * N * 4;
+  float* const arr[3] = {pos, vel, acc};
+#pragma unroll
+  for (int slot = 0; slot < 3; ++slot) {
+    if (in_batch) {
+#pragma unroll
+      for (int q = 0; q < CP; ++q)
+        if ((CP - q) * 16 <= K.bytes) *reinterpret_cast<mp_io_u4*>(arr[slot] + run - 4 * (CP - q)) = K.v[slot][q];
+    }
+    mp_io_u4 v[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      unsigned e[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = 4 * c + i, s = r / N, j = r - s * N;
+        e[i] = col[s * STEP + (slot * N + j) * RS];
+      }
+      v[c].x = e[0]; v[c].y = e[1]; v[c].z = e[2]; v[c].w = e[3];
+    }
+    if (in_batch) {
+#pragma unroll
+      for (int c = 0; c < C; ++c)
+        if (16 * c < RUN_BYTES - tail) *reinterpret_cast<mp_io_u4*>(arr[slot] + run + 4 * c) = v[c];
+    }
+#pragma unroll
+    for (int q = 0; q < CP; ++q) K.v[slot][q] = v[C - CP + q];
+  }
+  K.bytes = tail;
 }
 
 // The flush of the pipelined path: the same flat chunk order, stored with raw BUFFER stores through one descriptor per
@@ -1149,8 +1197,22 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
       if (have_f) mp_fd_tile_arrive<6, TW>(pre_f);
 #endif
     }
+    bool flushed = false;
+    if constexpr (MpFdCarry<N>::OWNER) {  // (A/B switch: MP_FD_NO_OWNER sends these tiles through the wave-cooperative flat stores)
+     if (full && vec_out) {
+      const bool hold = block64 && next_full;
+      const int e_end = (int)(((i0 + MP_FD_KS) * N * 4) & MpFdCarry<N>::MASK);
+      int my = lane;
+      asm volatile("" : "+v"(my));
+      mp_fd_tile_out_owner<N, STEP, RS>(pos, vel, acc, row0 * N, in_batch, col, hold ? ((my * pitch_mod + e_end) & MpFdCarry<N>::MASK) : 0,
+                                        carry);
+      flushed = true;
+     }
+    }
+    if (flushed) {
+    } else
 #if !defined(MP_FD_LANE_STORES)  // (A/B switch: MP_FD_LANE_STORES keeps the lane-by-lane stores)
-    if (full && vec_out) {
+    if (!MpFdCarry<N>::OWNER && full && vec_out) {
       // the tile was written column by column (each lane its own); the flat stores read across columns
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
