@@ -893,6 +893,47 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
   const int pitch_mod = (int)((Nt * N * 4) & MpFdCarry<N>::MASK);
   MpFdCarry<N> carry;
   carry.bytes = 0;
+#if defined(MP_FD_IN_EXACT)
+  // Line-exact input reads (n = 6, float32; experiment).  A lane's 96-byte run of a tile starts where the previous one
+  // ended, so three of four runs straddle a 128-byte line and every line is fetched by two tiles ~20 us apart (FETCH_SIZE
+  // = 2.0 x the input bytes; the second fetch is an Infinity-Cache hit, not an L2 hit).  Here a lane fetches a whole line
+  // - the one that holds the LAST float of its run - only in the three of four tiles whose run reaches past what it already
+  // holds, keeps the line's last 96 bytes in registers (`held_*`, 48 registers for both arrays) and assembles the run from
+  // them and the new line.  With Nt % 4 == 0 the stream starts on a 32-byte boundary and everything moves in 32-byte groups:
+  // phase = (tile - u0) & 3 says how the three groups of the run map onto (held, new) groups; torques and wrenches have
+  // the same row size at n = 6, so one phase serves both.  Loads go through buffer descriptors over the whole arrays: a
+  // lane that needs nothing this tile, or whose line would start past the array, reads nothing (offset out of range).
+  constexpr bool EXACT_OK = N == 6 && TW == 1;
+  const unsigned long long in_bytes = (unsigned long long)B * (unsigned long long)Nt * 24ull;
+  const bool exact_in = EXACT_OK && first_rows == MP_FD_KS && (Nt & 3) == 0 && in_bytes < (1ull << 31) &&
+                        (((unsigned long long)taumat | (HAS_FTIP ? (unsigned long long)Ftipmat : 0ull)) & 127ull) == 0;
+  // (named members, literal indices: with arrays the compiler turns "select between two array elements" into a load from a
+  //  selected ADDRESS and the arrays end up in scratch memory)
+  struct Held { mp_io_u4 a, b, c, d, e, f; } held_tau, held_f;
+  int ex_s0 = 0, ex_u0 = 0;
+  __amdgpu_buffer_rsrc_t ex_rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(taumat), 0, exact_in ? (int)in_bytes : 0, 0x00020000);
+  __amdgpu_buffer_rsrc_t ex_rf = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(HAS_FTIP ? Ftipmat : taumat), 0,
+                                                                   exact_in && HAS_FTIP ? (int)in_bytes : 0, 0x00020000);
+  if (exact_in) {
+    ex_s0 = (int)(b * Nt * 24);          // byte offset of this lane's streams (both arrays)
+    ex_u0 = (ex_s0 >> 5) & 3;
+    const int line0 = ex_s0 & ~127;      // the line the stream starts in: its tail is what the first tile may need
+    held_tau.a = __builtin_amdgcn_raw_buffer_load_b128(ex_rt, line0 + 32, 0, 0);
+    held_tau.b = __builtin_amdgcn_raw_buffer_load_b128(ex_rt, line0 + 48, 0, 0);
+    held_tau.c = __builtin_amdgcn_raw_buffer_load_b128(ex_rt, line0 + 64, 0, 0);
+    held_tau.d = __builtin_amdgcn_raw_buffer_load_b128(ex_rt, line0 + 80, 0, 0);
+    held_tau.e = __builtin_amdgcn_raw_buffer_load_b128(ex_rt, line0 + 96, 0, 0);
+    held_tau.f = __builtin_amdgcn_raw_buffer_load_b128(ex_rt, line0 + 112, 0, 0);
+    if (HAS_FTIP) {
+      held_f.a = __builtin_amdgcn_raw_buffer_load_b128(ex_rf, line0 + 32, 0, 0);
+      held_f.b = __builtin_amdgcn_raw_buffer_load_b128(ex_rf, line0 + 48, 0, 0);
+      held_f.c = __builtin_amdgcn_raw_buffer_load_b128(ex_rf, line0 + 64, 0, 0);
+      held_f.d = __builtin_amdgcn_raw_buffer_load_b128(ex_rf, line0 + 80, 0, 0);
+      held_f.e = __builtin_amdgcn_raw_buffer_load_b128(ex_rf, line0 + 96, 0, 0);
+      held_f.f = __builtin_amdgcn_raw_buffer_load_b128(ex_rf, line0 + 112, 0, 0);
+    }
+  }
+#endif
   // software pipeline of the vector path: `pre_*` hold the inputs of the tile about to start (loaded one tile ahead)
 #if defined(MP_FD_PREFETCH)  // opt-in: measured neutral (tools/ab_c5.sh, tools/ab_c5_cycles.sh: the waves' s_waitcnt share drops
   // from 26 % to 18 % of their cycles and their issue stalls rise from 21 % to 31 %; kernel cycles 1.43 M vs 1.40 M)
@@ -1086,6 +1127,45 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
       }
     } else
 #endif
+#if defined(MP_FD_IN_EXACT)
+    bool parked = false;
+    if constexpr (N == 6 && TW == 1) {
+      if (exact_in && full) {
+        const int tile = (int)(i0 / MP_FD_KS);
+        const int phi = (tile - ex_u0) & 3;
+        const int off = phi != 3 ? ((ex_s0 + 96 * tile + 92) & ~127) : 0x7ffffff0;
+        const bool p0 = phi == 0, p1 = phi == 1, p2 = phi == 2;
+        // the run's six 16-byte pieces: group G (pieces 2G, 2G+1) is new group G in phase 0, G-1 in phase 1, G-2 in phase 2,
+        // and otherwise one of the held groups (held pieces a..f = pieces 2..7 of the previous line)
+        auto sel = [&](const mp_io_u4 x0, const mp_io_u4 x1, const mp_io_u4 x2, const mp_io_u4 x3) __attribute__((always_inline)) {
+          return p0 ? x0 : p1 ? x1 : p2 ? x2 : x3;
+        };
+        auto one = [&](const __amdgpu_buffer_rsrc_t rs, Held& h, MpFdPrefetch<6, 1>& r) __attribute__((always_inline)) {
+          const mp_io_u4 n0 = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+          const mp_io_u4 n1 = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 16, 0, 0);
+          const mp_io_u4 n2 = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 32, 0, 0);
+          const mp_io_u4 n3 = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 48, 0, 0);
+          const mp_io_u4 n4 = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 64, 0, 0);
+          const mp_io_u4 n5 = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 80, 0, 0);
+          const mp_io_u4 n6 = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 96, 0, 0);
+          const mp_io_u4 n7 = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 112, 0, 0);
+          r.v[0] = sel(n0, h.e, h.c, h.a); r.v[1] = sel(n1, h.f, h.d, h.b);
+          r.v[2] = sel(n2, n0, h.e, h.c);  r.v[3] = sel(n3, n1, h.f, h.d);
+          r.v[4] = sel(n4, n2, n0, h.e);   r.v[5] = sel(n5, n3, n1, h.f);
+          // (a lane that fetched nothing has no use for what it holds: its next run starts a new line)
+          h.a = n2; h.b = n3; h.c = n4; h.d = n5; h.e = n6; h.f = n7;
+        };
+        MpFdPrefetch<6, 1> run_tau, run_f;
+        one(ex_rt, held_tau, run_tau);
+        if (HAS_FTIP) one(ex_rf, held_f, run_f);
+        mp_fd_tile_park<6, 1, TL::TAU0, STEP, RS>(run_tau, col);
+        if (HAS_FTIP) mp_fd_tile_park<6, 1, TL::F0, STEP, RS>(run_f, col);
+        parked = true;
+      }
+    }
+    if (parked) {
+    } else
+#endif
 #if !defined(MP_FD_PREFETCH) && !defined(MP_FD_IN_SEPARATE)
     // both input arrays in ONE round trip: all their loads are issued before the first row is parked (two separate
     // load-wait-park sequences sit in different branches, and the compiler does not hoist loads across them)
@@ -1129,6 +1209,14 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
     ++tile_no;
 #endif
     for (int s = 0; s < rows; ++s) {
+#if MP_FD_PREFETCH + 0 == 3
+      // the next tile's rows are requested before the LAST integration step of this tile: by the time the flush starts they have
+      // arrived, the wait in front of the first store costs nothing and the stores are never waited for
+      if (PIPE && next_full && s == rows - 1) {
+        if (vec_tau) { mp_fd_tile_load<N, TW>(reinterpret_cast<const unsigned*>(taumat + (row0 + rows) * N), pre_tau); have_tau = true; }
+        if (HAS_FTIP && vec_f) { mp_fd_tile_load<6, TW>(reinterpret_cast<const unsigned*>(Ftipmat + (row0 + rows) * 6), pre_f); have_f = true; }
+      }
+#endif
       unsigned* cs = col + s * STEP;
       T last[N];
 #pragma unroll
@@ -1190,9 +1278,11 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
     // and waited for before the first store is issued; the stores that follow are never waited for.  The rows wait in
     // registers across the flush only.
     if (PIPE && next_full) {
+#if MP_FD_PREFETCH + 0 != 3  // (3: the loads were issued before the last integration step, see the step loop)
       if (vec_tau) { mp_fd_tile_load<N, TW>(reinterpret_cast<const unsigned*>(taumat + (row0 + rows) * N), pre_tau); have_tau = true; }
       if (HAS_FTIP && vec_f) { mp_fd_tile_load<6, TW>(reinterpret_cast<const unsigned*>(Ftipmat + (row0 + rows) * 6), pre_f); have_f = true; }
-#if MP_FD_PREFETCH + 0 < 2  // MP_FD_PREFETCH=2: no wait here - the rows are waited for after the flush (vmcnt counts in order)
+#endif
+#if MP_FD_PREFETCH + 0 != 2  // MP_FD_PREFETCH=2: no wait here - the rows are waited for after the flush (vmcnt counts in order)
       if (have_tau) mp_fd_tile_arrive<N, TW>(pre_tau);
       if (have_f) mp_fd_tile_arrive<6, TW>(pre_f);
 #endif
