@@ -1467,6 +1467,43 @@ def test_rollout_every_lane_every_tile_against_the_oracle(robot, tables):
         ctx.destroy()
 
 
+def test_rollout_output_pointers_off_the_line_boundary(tables):
+    """The whole-line output mode needs the three output arrays to start on a 128-byte boundary; device pointers that do not
+    (a caller's sub-buffer) must take the plain path and produce the same bits."""
+    from manipulapy_amd import _hip
+
+    tab = tables["xarm6"]
+    ctx = _hip.HipContext(0)
+    try:
+        model = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee, tab.joint_limits)
+        ctx.specialize(model)
+        B, Nt, n = 130, 24, 6
+        th0, dth0, tm, Fm = (a.astype(np.float32) for a in _c5_workload(tab, B, Nt, 99))
+        d_in = [ctx.to_device(a) for a in (th0, dth0, tm, Fm)]
+        nb = B * Nt * n * 4
+        outs = {}
+        for shift in (0, 16, 64, 32):
+            bufs = [ctx.alloc(nb + 256) for _ in range(3)]
+            for bf in bufs:
+                ctx.memset(bf, 0, nb + 256)
+            ctx.fd_trajectory(model, d_in[0], d_in[1], d_in[2], d_in[3], B, Nt, G0_, 0.01, 1,
+                              bufs[0].offset(shift), bufs[1].offset(shift), bufs[2].offset(shift), dtype=np.float32)
+            ctx.synchronize()
+            got = []
+            for bf in bufs:
+                raw = bf.download((nb + 256,), np.uint8)
+                got.append(raw[shift:shift + nb].view(np.float32).reshape(B, Nt, n).copy())
+                assert not raw[shift + nb:].any() and not raw[:shift].any()   # nothing written outside the arrays
+                bf.free()
+            outs[shift] = got
+        for shift in (16, 64, 32):
+            for a, b in zip(outs[0], outs[shift]):
+                np.testing.assert_array_equal(a, b)
+        assert np.isfinite(outs[0][0]).all() and np.abs(outs[0][2]).max() > 0
+    finally:
+        ctx.destroy()
+
+
 def test_nonfinite_rows_contract(tables):
     """The reference returns a non-finite row wherever an input of that row is NaN / inf and leaves the other rows alone
     (tests/golden/nonfinite.npz, generated by the reference; its try / except only covers exceptions).  The kernels —
