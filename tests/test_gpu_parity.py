@@ -1076,6 +1076,20 @@ def test_random_robots_on_gpu(seed, ctx):
                 sc = max(1.0, float(np.abs(o[name]).max()))
                 np.testing.assert_allclose(a[k][B - 1], o[name], rtol=tol, atol=tol * sc)
                 assert np.abs(a[k] - b[k]).max() <= (1e-6 if dt_ == np.float64 else 1e-3) * max(1.0, float(np.abs(a[k]).max()))
+    # every lane of every tile (four whole tiles): the flush mode depends on the row size - whole-line owner-lane stores for
+    # 4 - 7 joints (tails of up to a whole run), flat stores for 8, lane-by-lane rows for 1 - 3
+    from oracle import c_oracle
+    Nt = 16
+    tm, Fm = rng.uniform(-1, 1, (B, Nt, n)) * 0.3, rng.uniform(-1, 1, (B, Nt, 6)) * 0.3
+    x = [a.astype(np.float32) for a in (th0, dth0, tm, Fm)]
+    want = c_oracle.fd_trajectory(tab, *[a.astype(np.float64) for a in x[:3]], g, x[3].astype(np.float64), 0.002, 1,
+                                  joint_limits=tab.joint_limits)[:3]
+    if all(np.isfinite(w).all() for w in want):
+        for model in (gen, m):
+            got = ctx.fd_trajectory_host(model, x[0], x[1], x[2], g, x[3], 0.002, 1, dtype=np.float32)
+            for k in range(3):
+                sc = max(1.0, float(np.abs(want[k]).max()))
+                assert np.abs(got[k] - want[k]).max() <= 2e-3 * sc, (n, k, float(np.abs(got[k] - want[k]).max()), sc)
     prismatic = np.abs(tab.S[:3]).sum(axis=0) == 0
     lim = np.tile([-2.5, 2.5], (n, 1)).astype(float)
     lim[prismatic] = [-0.4, 0.4]
