@@ -560,6 +560,23 @@ __device__ __forceinline__ void mp_fd_tile_park(const MpFdPrefetch<E, TW>& r, un
   }
 }
 
+// pieces [K0, K1) only (MP_FD_SPLIT_PARK: the first step's rows are parked as soon as they arrive, the rest after it)
+template <int E, int TW, int BASE, int STEP, int W, int K0, int K1>
+__device__ __forceinline__ void mp_fd_tile_park_range(const MpFdPrefetch<E, TW>& r, unsigned* __restrict__ col) {
+#pragma unroll
+  for (int k = K0; k < K1; ++k) {
+    col[mp_fd_in_slot<E, TW, BASE, STEP, W>(4 * k)] = r.v[k].x;
+    col[mp_fd_in_slot<E, TW, BASE, STEP, W>(4 * k + 1)] = r.v[k].y;
+    col[mp_fd_in_slot<E, TW, BASE, STEP, W>(4 * k + 2)] = r.v[k].z;
+    col[mp_fd_in_slot<E, TW, BASE, STEP, W>(4 * k + 3)] = r.v[k].w;
+  }
+}
+template <int E, int TW, int K0, int K1>
+__device__ __forceinline__ void mp_fd_tile_load_range(const unsigned* __restrict__ g, MpFdPrefetch<E, TW>& r) {
+#pragma unroll
+  for (int k = K0; k < K1; ++k) r.v[k] = *reinterpret_cast<const mp_io_u4*>(g + 4 * k);
+}
+
 // tile -> global: output slot `slot` (0 pos, 1 vel, 2 acc) of MP_FD_KS rows (or `limit` dwords when VW == 1)
 template <int N, int STEP, int W, int VW>
 __device__ __forceinline__ void mp_fd_tile_out(float* __restrict__ gdst, int slot, int limit, const unsigned* __restrict__ col) {
@@ -1090,6 +1107,11 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
     }
   }
 #endif
+#if defined(MP_FD_SPLIT_PARK)
+  MpFdPrefetch<N, TW> late_tau;
+  MpFdPrefetch<6, TW> late_f;
+  bool late = false;
+#endif
   int tile_rows = first_rows;  // the first tile may be short (staggered phases); the others hold MP_FD_KS rows
   for (long i0 = i0_start; i0 < Nt; i0 += tile_rows, tile_rows = MP_FD_KS) {
     const long left = Nt - i0;
@@ -1170,12 +1192,27 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
     // both input arrays in ONE round trip: all their loads are issued before the first row is parked (two separate
     // load-wait-park sequences sit in different branches, and the compiler does not hoist loads across them)
     if (full && vec_tau && (!HAS_FTIP || vec_f) && (MP_FD_KS * N * TW) % 4 == 0) {
+#if defined(MP_FD_SPLIT_PARK)
+      // experiment: the pieces that hold the first step's rows are requested first and parked as soon as they are there; the
+      // others are parked after the first integration step, which runs while they arrive
+      constexpr int KT = (N * TW + 3) / 4, KF = (6 * TW + 3) / 4;
+      const unsigned* gt_ = reinterpret_cast<const unsigned*>(taumat + row0 * N);
+      const unsigned* gf_ = HAS_FTIP ? reinterpret_cast<const unsigned*>(Ftipmat + row0 * 6) : nullptr;
+      mp_fd_tile_load_range<N, TW, 0, KT>(gt_, late_tau);
+      if (HAS_FTIP) mp_fd_tile_load_range<6, TW, 0, KF>(gf_, late_f);
+      mp_fd_tile_load_range<N, TW, KT, MpFdPrefetch<N, TW>::NV>(gt_, late_tau);
+      if (HAS_FTIP) mp_fd_tile_load_range<6, TW, KF, MpFdPrefetch<6, TW>::NV>(gf_, late_f);
+      mp_fd_tile_park_range<N, TW, TL::TAU0, STEP, RS, 0, KT>(late_tau, col);
+      if (HAS_FTIP) mp_fd_tile_park_range<6, TW, TL::F0, STEP, RS, 0, KF>(late_f, col);
+      late = true;
+#else
       MpFdPrefetch<N, TW> now_tau;
       MpFdPrefetch<6, TW> now_f;
       mp_fd_tile_load<N, TW>(reinterpret_cast<const unsigned*>(taumat + row0 * N), now_tau);
       if (HAS_FTIP) mp_fd_tile_load<6, TW>(reinterpret_cast<const unsigned*>(Ftipmat + row0 * 6), now_f);
       mp_fd_tile_park<N, TW, TL::TAU0, STEP, RS>(now_tau, col);
       if (HAS_FTIP) mp_fd_tile_park<6, TW, TL::F0, STEP, RS>(now_f, col);
+#endif
     } else
 #endif
     {
@@ -1263,6 +1300,14 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
         cs[(N + j) * RS] = poison ? 0x7fc00000u : __builtin_bit_cast(unsigned, (float)qd[j]);
         cs[(2 * N + j) * RS] = poison ? 0x7fc00000u : __builtin_bit_cast(unsigned, (float)last[j]);
       }
+#if defined(MP_FD_SPLIT_PARK)
+      if (late) {  // (s == 0 of a tile whose later rows are still in registers)
+        constexpr int KT = (N * TW + 3) / 4, KF = (6 * TW + 3) / 4;
+        mp_fd_tile_park_range<N, TW, TL::TAU0, STEP, RS, KT, MpFdPrefetch<N, TW>::NV>(late_tau, col);
+        if (HAS_FTIP) mp_fd_tile_park_range<6, TW, TL::F0, STEP, RS, KF, MpFdPrefetch<6, TW>::NV>(late_f, col);
+        late = false;
+      }
+#endif
     }
 #if defined(MP_FD_EXP_NOOUT)
     if (i0 + rows < Nt) continue;
