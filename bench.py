@@ -149,6 +149,21 @@ def emit(result):
     print(json.dumps(result), flush=True)
 
 
+def device_copy_probe(ctx):
+    """the streaming rate this very GPU sustains in this very run, next to the 8 TB/s vendor peak the roofline
+    fraction is quoted against: a 16-byte-per-lane device copy and the 3-reads-1-write mix of the inverse-dynamics kernels,
+    arrays of 512 MB (nothing survives in the 256 MB Infinity Cache between launches)."""
+    try:
+        nb = 512 * 1024 * 1024
+        for _ in range(2):   # the first pass also ramps the clocks
+            copy = ctx.stream_bandwidth(nb, reads=1, reps=10)
+            mix = ctx.stream_bandwidth(nb, reads=3, reps=10)
+        return {"copy_GBps": copy, "mix_3_reads_1_write_GBps": mix, "bytes_per_array": nb,
+                "how": "mp_stream_bandwidth: float4 per lane, HIP events around 10 launches, (reads + 1) x bytes / time"}
+    except Exception as exc:   # a diagnostic: never costs the line
+        return {"error": str(exc)[:200]}
+
+
 def ramp(ctx, step, ms):
     """Setup, untimed: keep the GPU busy with the step for `ms` milliseconds (clock / power ramp after the idle setup phase;
     measured on c2: 0.080 ms per step right after start-up, 0.0747 ms once warm)."""
@@ -246,6 +261,8 @@ def bench_fd(args, cfg, info, hg, ctx, model, t, props):
         "device": props["name"],
     }
     attach_counters(result, args.config)
+    if info.rank == 0:
+        result["roofline"]["device_copy"] = device_copy_probe(ctx)
     if info.rank == 0 and world == 1 and not args.no_cpu_baseline:
         tab = oracle_tables(ref, cfg["robot"])
         pos = d_pos.download((B, N, n), np.float32)
@@ -680,6 +697,8 @@ def main():
         "device": props["name"],
     }
     attach_counters(result, args.config)
+    if info.rank == 0:
+        result["roofline"]["device_copy"] = device_copy_probe(ctx)
 
     if info.rank == 0 and world == 1 and not args.no_cpu_baseline and not hung:
         ns = rows  # the C oracle sizes its own sample from a time budget

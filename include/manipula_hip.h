@@ -60,6 +60,11 @@ int mp_ctx_properties(mp_ctx* ctx, char* name, size_t name_len, int* compute_uni
 /* Launch a 1-block probe kernel that writes its lane ids and check the result on the host.
  * Replaces the reference's device self-test kernel, cuda_kernels/_runtime.py:127-138. */
 int mp_selftest(mp_ctx* ctx);
+/* Device-copy microbenchmark for the roofline ("confirm the peak with a device-copy microbenchmark in the same
+ * run"): `reps` launches of dst = a (reads = 1) or dst = a + b + c (reads = 3, the 3 : 1 byte mix of the inverse-dynamics
+ * kernels) over arrays of bytes_per_array bytes, 16 bytes per lane; *gb_per_s = (reads + 1) * bytes * reps / elapsed.
+ * Nothing in the reference corresponds to it. */
+int mp_stream_bandwidth(mp_ctx* ctx, size_t bytes_per_array, int reads, int reps, double* gb_per_s);
 
 /* Profiling (replaces the reference's profile_start / profile_stop hooks, planning/trajectory_planning.py:295-296, and
  * the timing part of its performance_stats): while on, every device-pointer entry point (and so every *_host one)

@@ -49,6 +49,7 @@ SIGNATURES = {
     "mp_ctx_synchronize": (ctypes.c_int, [_vp]),
     "mp_ctx_properties": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint64)]),
     "mp_selftest": (ctypes.c_int, [_vp]),
+    "mp_stream_bandwidth": (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
     "mp_ctx_set_profiling": (ctypes.c_int, [_vp, ctypes.c_int]),
     "mp_ctx_profile": (ctypes.c_int, [_vp, _c_dp, ctypes.POINTER(ctypes.c_int64), _c_dp, ctypes.c_int]),
     "mp_malloc": (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.POINTER(_vp)]),
@@ -417,6 +418,12 @@ class HipContext:
 
     def selftest(self) -> None:
         _check(self.lib.mp_selftest(self.handle))
+
+    def stream_bandwidth(self, bytes_per_array: int, reads: int = 1, reps: int = 20) -> float:
+        """GB/s of a device copy (reads = 1) or of the 3-reads-1-write mix of the inverse-dynamics kernels (reads = 3)."""
+        out = ctypes.c_double(0.0)
+        _check(self.lib.mp_stream_bandwidth(self.handle, ctypes.c_size_t(int(bytes_per_array)), int(reads), int(reps), ctypes.byref(out)))
+        return float(out.value)
 
     def properties(self) -> dict:
         name = ctypes.create_string_buffer(256)

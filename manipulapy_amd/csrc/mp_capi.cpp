@@ -700,6 +700,36 @@ int mp_selftest(mp_ctx* ctx) {
   return MP_OK;
 }
 
+int mp_stream_bandwidth(mp_ctx* ctx, size_t bytes_per_array, int reads, int reps, double* gb_per_s) {
+  REQUIRE(ctx && gb_per_s, "mp_stream_bandwidth: null argument");
+  REQUIRE(reads == 1 || reads == 3, "mp_stream_bandwidth: reads must be 1 or 3");
+  REQUIRE(bytes_per_array >= 16 && reps >= 1, "mp_stream_bandwidth: nothing to move");
+  CTX_ENTER(ctx);
+  const size_t nb = bytes_per_array & ~(size_t)15;
+  Scratch sc(ctx);
+  void* buf[4] = {nullptr, nullptr, nullptr, nullptr};
+  for (int k = 0; k < (reads == 3 ? 4 : 2); ++k) {
+    if (int rc = sc.get(nb, &buf[k])) return rc;
+    HIP_TRY(hipMemsetAsync(buf[k], 0, nb, ctx->compute));
+  }
+  void *a = buf[0], *d = buf[reads == 3 ? 3 : 1];
+  const long n4 = (long)(nb / 16);
+  for (int w = 0; w < 3; ++w) HIP_TRY(mpk_stream(ctx->compute, reads, a, buf[1], buf[2], d, n4));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  HIP_TRY(hipEventCreate(&e0));
+  if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return set_err(MP_ERR_HIP, "mp_stream_bandwidth: hipEventCreate failed"); }
+  hipError_t e = hipEventRecord(e0, ctx->compute);
+  for (int r = 0; r < reps && e == hipSuccess; ++r) e = mpk_stream(ctx->compute, reads, a, buf[1], buf[2], d, n4);
+  if (e == hipSuccess) e = hipEventRecord(e1, ctx->compute);
+  if (e == hipSuccess) e = hipEventSynchronize(e1);
+  float ms = 0.f;
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (e != hipSuccess) return set_err(MP_ERR_HIP, "mp_stream_bandwidth: %s", hipGetErrorString(e));
+  *gb_per_s = (double)(reads + 1) * (double)nb * (double)reps / ((double)ms * 1e-3) / 1e9;
+  return MP_OK;
+}
+
 // ---------------------------------------------------------------------------------- device memory
 int mp_malloc(mp_ctx* ctx, size_t bytes, void** d_ptr) {
   REQUIRE(ctx && d_ptr, "mp_malloc: null argument");

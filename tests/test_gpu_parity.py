@@ -1518,6 +1518,20 @@ def test_rollout_output_pointers_off_the_line_boundary(tables):
         ctx.destroy()
 
 
+def test_stream_bandwidth_probe(ctx):
+    """The device-copy microbenchmark behind `roofline.device_copy`: both byte mixes stream at HBM-class rates,
+    bad arguments are refused."""
+    from manipulapy_amd import _hip
+
+    copy = ctx.stream_bandwidth(256 << 20, reads=1, reps=5)
+    mix = ctx.stream_bandwidth(256 << 20, reads=3, reps=5)
+    assert 1.5e3 < copy < 8.0e3 and 1.5e3 < mix < 8.0e3, (copy, mix)   # GB/s: above any PCIe / single-stack figure, below the peak
+    with pytest.raises(_hip.HipError):
+        ctx.stream_bandwidth(256 << 20, reads=2)
+    with pytest.raises(_hip.HipError):
+        ctx.stream_bandwidth(0, reads=1)
+
+
 def test_nonfinite_rows_contract(tables):
     """The reference returns a non-finite row wherever an input of that row is NaN / inf and leaves the other rows alone
     (tests/golden/nonfinite.npz, generated by the reference; its try / except only covers exceptions).  The kernels —
