@@ -791,7 +791,7 @@ __device__ __forceinline__ void mp_fd_tile_out_buf(float* __restrict__ pos, floa
                                                    long run0, int pitch, int nvalid, int lane, bool in_batch,
                                                    const unsigned* __restrict__ lds, bool hold, int pm, int e_end,
                                                    const MpFdCarry<N>& K) {
-  constexpr int NK = MpFdFlat<N>::NK, C = MpFdFlat<N>::C, CP = MpFdCarry<N>::CP;
+  constexpr int NK = MpFdFlat<N>::NK, CP = MpFdCarry<N>::CP;
   constexpr int RUN_BYTES = MP_FD_KS * N * 4;
   constexpr int kNowhere = 0x7ffffff0;  // past any descriptor: the write is dropped
   float* const arr[3] = {pos, vel, acc};
