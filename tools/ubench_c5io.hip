@@ -33,7 +33,17 @@ __global__ __launch_bounds__(64) void k_io(const float* __restrict__ tau, const 
   float x = (float)lane;
   for (long i0 = 0; i0 + KS <= Nt; i0 += KS) {
     u4 v[12];
-    if ((WHAT & 1) && (WHAT & 64)) {
+    if ((WHAT & 1) && (WHAT & 128)) {
+      // wave-cooperative flat loads: chunk f = k * 64 + lane of the wave's 64 runs is trajectory f / 6, piece f % 6 (a load
+      // instruction covers ~11 whole runs instead of 64 fragments; the real thing would transpose through LDS)
+      const long run0 = (b0 * Nt + i0) * N, pitch = Nt * N;
+#pragma unroll
+      for (int k = 0; k < C; ++k) {
+        const int f = k * 64 + lane, t = f / C, c = f - t * C;
+        keep ^= *reinterpret_cast<const u4*>(tau + run0 + (long)t * pitch + 4 * c);
+        keep ^= *reinterpret_cast<const u4*>(F + run0 + (long)t * pitch + 4 * c);
+      }
+    } else if ((WHAT & 1) && (WHAT & 64)) {
       // line-exact reads: a lane fetches a whole 128-byte line of each input stream only when its run of this tile reaches
       // past what it has already fetched (the rest of a line waits in registers in the real thing); lanes that need nothing
       // this tile get an offset outside the descriptor (no traffic, no branch)
@@ -217,6 +227,10 @@ int main(int argc, char** argv) {
   RUN(65, 2, fma_iters, 0, f0, "loads line-exact, FMA between tiles");
   RUN(75, 0, 0, 0, 0.f, "loads line-exact + stores in 64-byte blocks, back to back");
   RUN(75, 2, fma_iters, 0, f0, "loads line-exact + stores in 64-byte blocks, FMA between tiles");
+  RUN(129, 0, 0, 0, 0.f, "loads wave-cooperative (flat chunk order), back to back");
+  RUN(129, 2, fma_iters, 0, f0, "loads wave-cooperative, FMA between tiles");
+  RUN(163, 2, fma_iters, 0, f0, "loads wave-cooperative + stores in whole 128-byte lines, FMA between tiles");
+  RUN(35, 2, fma_iters, 0, f0, "loads lane-strided + stores in whole 128-byte lines, FMA between tiles (again)");
   RUN(17, 0, 0, 0, 0.f, "loads in whole 64-byte blocks only, back to back");
   RUN(17, 2, fma_iters, 0, f0, "loads in whole 64-byte blocks, FMA between tiles");
   RUN(27, 0, 0, 0, 0.f, "loads AND stores in whole 64-byte blocks, back to back");
