@@ -910,9 +910,10 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
   const int pitch_mod = (int)((Nt * N * 4) & MpFdCarry<N>::MASK);
   MpFdCarry<N> carry;
   carry.bytes = 0;
-#if defined(MP_FD_IN_EXACT)
-  // Line-exact input reads (n = 6, float32; experiment).  A lane's 96-byte run of a tile starts where the previous one
-  // ended, so three of four runs straddle a 128-byte line and every line is fetched by two tiles ~20 us apart (FETCH_SIZE
+#if !defined(MP_FD_NO_IN_EXACT)
+  // Line-exact input reads (n = 6, float32 inputs; A/B switch MP_FD_NO_IN_EXACT).  Time-neutral (0.499 against 0.503 ms) and
+  // kept for what it does to the traffic: HBM-side bytes per launch 2.21 GB -> 1.61 GB = 1.02 x the algorithmic bytes.
+  // A lane's 96-byte run of a tile starts where the previous one ended, so three of four runs straddle a 128-byte line and every line is fetched by two tiles ~20 us apart (FETCH_SIZE
   // = 2.0 x the input bytes; the second fetch is an Infinity-Cache hit, not an L2 hit).  Here a lane fetches a whole line
   // - the one that holds the LAST float of its run - only in the three of four tiles whose run reaches past what it already
   // holds, keeps the line's last 96 bytes in registers (`held_*`, 48 registers for both arrays) and assembles the run from
@@ -920,7 +921,11 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
   // phase = (tile - u0) & 3 says how the three groups of the run map onto (held, new) groups; torques and wrenches have
   // the same row size at n = 6, so one phase serves both.  Loads go through buffer descriptors over the whole arrays: a
   // lane that needs nothing this tile, or whose line would start past the array, reads nothing (offset out of range).
+#if defined(MP_SPECIALISED)
   constexpr bool EXACT_OK = N == 6 && TW == 1;
+#else  // the generic kernels carry the robot model in registers: 48 more for the held lines and they spill (0.80 -> 1.03 ms)
+  constexpr bool EXACT_OK = false;
+#endif
   const unsigned long long in_bytes = (unsigned long long)B * (unsigned long long)Nt * 24ull;
   const bool exact_in = EXACT_OK && first_rows == MP_FD_KS && (Nt & 3) == 0 && in_bytes < (1ull << 31) &&
                         (((unsigned long long)taumat | (HAS_FTIP ? (unsigned long long)Ftipmat : 0ull)) & 127ull) == 0;
@@ -1149,7 +1154,7 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
       }
     } else
 #endif
-#if defined(MP_FD_IN_EXACT)
+#if !defined(MP_FD_NO_IN_EXACT)
     bool parked = false;
     if constexpr (N == 6 && TW == 1) {
       if (exact_in && full) {
