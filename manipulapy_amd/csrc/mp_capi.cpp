@@ -27,6 +27,7 @@
 // ------------------------------------------------------------------------------------- objects
 struct MpSpec {  // run-time specialised kernels of one model on one device
   hipModule_t mod = nullptr;
+  hipModule_t mod_ilp = nullptr;  // second program (mp_jit part 1): id_s compiled with the max-ILP strategy; optional
   hipFunction_t id_pk[2] = {nullptr, nullptr}, traj_id_pk[2] = {nullptr, nullptr}, fd_traj[2] = {nullptr, nullptr};
   hipFunction_t id_d[2] = {nullptr, nullptr}, fk_jac_id_d[2] = {nullptr, nullptr}, fd_traj_pk[2] = {nullptr, nullptr};
   hipFunction_t ik = nullptr;
@@ -625,7 +626,10 @@ int mp_ctx_destroy(mp_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
   for (auto& pe : ctx->prof_pending) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
-  for (auto& kv : ctx->specs) if (kv.second.mod) (void)hipModuleUnload(kv.second.mod);
+  for (auto& kv : ctx->specs) {
+    if (kv.second.mod_ilp) (void)hipModuleUnload(kv.second.mod_ilp);
+    if (kv.second.mod) (void)hipModuleUnload(kv.second.mod);
+  }
   for (auto& kv : ctx->live) (void)hipFree(kv.first);
   if (ctx->queue_counter) (void)hipFree(ctx->queue_counter);
   if (ctx->time_tab) (void)hipFree(ctx->time_tab);
@@ -949,6 +953,7 @@ int mp_model_destroy(mp_model* model) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->compute);  // a launch of this model's kernels may still be in flight
     if (sp != ctx->specs.end()) {
+      if (sp->second.mod_ilp) (void)hipModuleUnload(sp->second.mod_ilp);
       if (sp->second.mod) (void)hipModuleUnload(sp->second.mod);
       ctx->specs.erase(sp);
     }
@@ -987,6 +992,12 @@ int mp_model_specialize_compile(const mp_model* model, size_t* code_bytes, int* 
   std::string err;
   bool cached = false;
   if (mp_jit_compile(model->f, model->d, &code, &cached, &err)) return set_err(MP_ERR_UNSUPPORTED, "mp_model_specialize_compile: %s", err.c_str());
+  {  // warm the cache of the second program too (best effort, like its use in mp_model_specialize)
+    const char* e = getenv("MANIPULAPY_HIP_ILP_PART");
+    std::vector<char> code2;
+    std::string err2;
+    if (!(e && e[0] == '0')) (void)mp_jit_compile(model->f, model->d, &code2, nullptr, &err2, 1);
+  }
   if (code_bytes) *code_bytes = code.size();
   if (from_cache) *from_cache = cached ? 1 : 0;
   return MP_OK;
@@ -1021,6 +1032,24 @@ int mp_model_specialize(mp_ctx* ctx, const mp_model* model) {
   {
     hipError_t e = hipModuleGetFunction(&sp.ik, sp.mod, "mp_spec_ik");
     if (e != hipSuccess) { (void)hipModuleUnload(sp.mod); return hip_err(e, "mp_spec_ik"); }
+  }
+  // the second program: same kernels, other scheduling strategy; anything that goes wrong here leaves the first program's
+  // versions in place (MANIPULAPY_HIP_ILP_PART=0 skips it)
+  {
+    const char* e = getenv("MANIPULAPY_HIP_ILP_PART");
+    if (!(e && e[0] == '0')) {
+      std::vector<char> code2;
+      std::string err2;
+      hipModule_t m2 = nullptr;
+      if (mp_jit_compile(model->f, model->d, &code2, nullptr, &err2, 1) == 0 && hipModuleLoadData(&m2, code2.data()) == hipSuccess) {
+        hipFunction_t f0 = nullptr, f1 = nullptr;
+        if (hipModuleGetFunction(&f0, m2, "mp_spec_id_s_f0") == hipSuccess && hipModuleGetFunction(&f1, m2, "mp_spec_id_s_f1") == hipSuccess) {
+          sp.mod_ilp = m2; sp.id_s[0] = f0; sp.id_s[1] = f1;
+        } else {
+          (void)hipModuleUnload(m2);
+        }
+      }
+    }
   }
   ctx->specs[model->uid] = sp;
   return MP_OK;

@@ -6,7 +6,8 @@
 #include "mp_model.h"
 
 // The translation unit that gets compiled for `M` (model literal + kernel wrappers).
-std::string mp_jit_source(const MpModel<float>& Mf, const MpModel<double>& Md);
+// part 0: every specialised kernel; part 1: the one-row-per-lane float32 inverse dynamics alone (built with another scheduling strategy)
+std::string mp_jit_source(const MpModel<float>& Mf, const MpModel<double>& Md, int part = 0);
 // Code object for gfx950, from the disk cache when present.  0 = ok, otherwise `err` holds the hiprtc log.
 int mp_jit_compile(const MpModel<float>& Mf, const MpModel<double>& Md, std::vector<char>* code, bool* from_cache,
-                   std::string* err);
+                   std::string* err, int part = 0);
