@@ -212,7 +212,15 @@ def test_kernel_specialiser_generates_and_compiles_without_a_gpu(tables, tmp_pat
     nb, cached = m.specialize_compile()
     assert nb > 10000 and not cached
     nb2, cached2 = m.specialize_compile()
-    assert nb2 == nb and cached2 and len(list(tmp_path.glob("*.hsaco"))) == 1
+    # two code objects: every kernel, and the one-row-per-lane float32 inverse dynamics built again with the max-ILP
+    # scheduling strategy (mp_jit part 1); MANIPULAPY_HIP_ILP_PART=0 leaves the second one out
+    assert nb2 == nb and cached2 and len(list(tmp_path.glob("*.hsaco"))) == 2
+    only = tmp_path / "first_program_only"
+    only.mkdir()
+    monkeypatch.setenv("MANIPULAPY_HIP_CACHE", str(only))
+    monkeypatch.setenv("MANIPULAPY_HIP_ILP_PART", "0")
+    nb3, cached3 = m.specialize_compile()
+    assert nb3 == nb and not cached3 and len(list(only.glob("*.hsaco"))) == 1
 
 
 # ----------------------------------------------------------------------------- device math on the host
