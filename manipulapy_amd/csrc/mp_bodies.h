@@ -621,15 +621,16 @@ __device__ __forceinline__ void mp_fd_flat_init(MpFdFlat<N>& F, int lane) { F.la
 // `pitch` = floats between the runs of neighbouring trajectories (Nt * N), `nvalid` = trajectories of this wave inside the
 // batch.  An array's LDS reads are issued before its first store (every chunk's column exists: f < 64 C gives t < 64), so the
 // wave waits for the LDS once per array and tile, and a whole wave stores without per-chunk branches.
-// Whole 64-byte blocks.  A trajectory's rows of one tile are a run of MP_FD_KS * N * 4 bytes (96 at n = 6) that starts where
-// the previous tile's run ended, so at n = 6 every second run ends 32 bytes into a 64-byte block: written as it comes, the
-// block reaches the L2 in two parts four steps (~20 us) apart, is evicted in between (one open block per trajectory and
-// array is far more than the L2s hold) and goes to memory as two partial writes.  tools/ubench_c5io.hip, the kernel's
-// tile I/O around a stand-in for the arithmetic: 0.589 ms written as it comes, 0.472 ms when only whole 64-byte blocks
-// are written.  So the tail of a run that ends inside a block is held back: the owner lane reads it out of its own tile
-// column into registers (`v`: the last CP 16-byte pieces of each array's run) and stores it right before the next tile's
-// flat stores deliver the rest of the block.  Tails are multiples of 16 bytes (the vector path needs 16-byte aligned runs);
-// with an even n and a row pitch that is a multiple of 32 bytes they are 0 or 32 bytes (CP = 2), otherwise up to 48 (CP = 3).
+// Whole blocks (MP_FD_BLOCK bytes: 128 = whole lines, the default; 64 = half lines).  A trajectory's rows of one tile are a run
+// of MP_FD_KS * N * 4 bytes (96 at n = 6) that starts where the previous tile's run ended, so most runs end inside a block:
+// written as it comes, the block reaches the L2 in two parts four steps (~20 us) apart, is evicted in between (one open
+// block per trajectory and array is far more than the L2s hold) and goes to memory as two partial writes.
+// tools/ubench_c5io.hip, the kernel's tile I/O around a stand-in for the arithmetic: 0.589 ms written as it comes, 0.472 ms
+// in whole 64-byte blocks, 0.468 ms in whole lines.  So the tail of a run that ends inside a block is held back: the owner
+// lane keeps it in registers (`v`: the last CP 16-byte pieces of each array's run, read out of its own tile column) and
+// stores it right before the rest of the block leaves with the next tile.  Tails are multiples of 16 bytes (the vector
+// path needs 16-byte aligned runs); with an even n and a row pitch that is a multiple of 32 bytes they are multiples of 32:
+// up to 96 bytes at BLOCK = 128 (CP = 6 pieces = the whole run at n = 6), 0 or 32 at BLOCK = 64 (CP = 2).
 #if !defined(MP_FD_BLOCK)
 #define MP_FD_BLOCK 128  // whole lines: tails up to 96 bytes per array (72 registers at n = 6); 64: whole half lines, 24 registers
 #endif
@@ -651,9 +652,9 @@ struct MpFdCarry {
   mp_io_u4 v[3][CP];
   int bytes;  // of this lane's trajectory: how much of the previous tile's run is still to be written
 };
-// `hold`: whole-64-byte-block mode (see MpFdCarry): the tail of a run that ends inside a 64-byte block is NOT stored (its
+// `hold`: whole-block mode (see MpFdCarry): the tail of a run that ends inside a block is NOT stored (its
 // owner lane keeps it and stores it right before the next tile's run, which completes the block); `pm` = bytes between
-// the runs of neighbouring trajectories mod 64, `e_end` = byte offset of the END of trajectory b0's run mod 64.
+// the runs of neighbouring trajectories mod BLOCK, `e_end` = byte offset of the END of trajectory b0's run mod BLOCK.
 template <int N, int STEP, int RS>
 __device__ __forceinline__ void mp_fd_tile_out_flat(float* __restrict__ pos, float* __restrict__ vel, float* __restrict__ acc,
                                                     long run0, long pitch, int nvalid, const MpFdFlat<N>& F,
@@ -898,11 +899,11 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
   // 16-byte vector accesses need every lane's run to start on a 16-byte boundary (wave-uniform tests)
   const bool vec_tau = ((Nt * N * (long)sizeof(T)) & 15) == 0, vec_out = ((Nt * N * 4) & 15) == 0;
   const bool vec_f = ((Nt * 6 * (long)sizeof(T)) & 15) == 0;
-  // whole-64-byte-block output (MpFdCarry): the arrays start on a block boundary, tails come in the sizes the carry holds
+  // whole-block output (MpFdCarry): the arrays start on a block boundary, tails come in the sizes the carry holds
 #if defined(MP_FD_NO_BLOCK64)  // A/B switch
-  const bool block64 = false;
+  const bool whole_blocks = false;
 #else
-  const bool block64 = vec_out && MpFdCarry<N>::ENABLED &&
+  const bool whole_blocks = vec_out && MpFdCarry<N>::ENABLED &&
                        (((unsigned long long)pos | (unsigned long long)vel | (unsigned long long)acc) & (unsigned long long)MpFdCarry<N>::MASK) == 0 &&
                        (N % 2 != 0 || ((Nt * N * 4) & 31) == 0) &&
                        !((MP_FD_KS * N * 4) % MpFdCarry<N>::BLOCK == 0 && ((Nt * N * 4) & MpFdCarry<N>::MASK) == 0);  // runs that are whole blocks anyway (n = 4, 8)
@@ -1092,7 +1093,7 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         int fl_lane = lane;
         asm volatile("" : "+v"(fl_lane));  // (keeps the per-lane chunk offsets from being hoisted out of the time loop and spilled)
-        const bool hold = block64 && more;  // the next tile completes the 64-byte blocks this one leaves open
+        const bool hold = whole_blocks && more;  // the next tile completes the blocks this one leaves open
         const int e_end = (int)(((i0 + MP_FD_KS) * N * 4) & MpFdCarry<N>::MASK);
         mp_fd_tile_out_buf<N, STEP, RS>(pos, vel, acc, (b0 * Nt + i0) * N, pitch, nvalid, fl_lane, in_batch, lds, hold, pitch_mod,
                                         e_end, carry);
@@ -1340,7 +1341,7 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
     bool flushed = false;
     if constexpr (MpFdCarry<N>::OWNER) {  // (A/B switch: MP_FD_NO_OWNER sends these tiles through the wave-cooperative flat stores)
      if (full && vec_out) {
-      const bool hold = block64 && next_full;
+      const bool hold = whole_blocks && next_full;
       const int e_end = (int)(((i0 + MP_FD_KS) * N * 4) & MpFdCarry<N>::MASK);
       int my = lane;
       asm volatile("" : "+v"(my));
@@ -1362,10 +1363,10 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
       // index keeps the compiler from hoisting a dozen per-lane 64-bit offsets out of the time loop (they were spilled)
       MpFdFlat<N> fl = flat;
       asm volatile("" : "+v"(fl.lane));
-      const bool hold = block64 && next_full;  // the next tile is a whole tile: it completes the blocks this one leaves open
+      const bool hold = whole_blocks && next_full;  // the next tile is a whole tile: it completes the blocks this one leaves open
       const int e_end = (int)(((i0 + MP_FD_KS) * N * 4) & MpFdCarry<N>::MASK);
       if constexpr (MpFdCarry<N>::ENABLED) {
-        if (block64 && in_batch && carry.bytes > 0) mp_fd_carry_store<N>(carry, pos, vel, acc, row0 * N);
+        if (whole_blocks && in_batch && carry.bytes > 0) mp_fd_carry_store<N>(carry, pos, vel, acc, row0 * N);
       }
       mp_fd_tile_out_flat<N, STEP, RS>(pos, vel, acc, run0, Nt * N, nvalid, fl, lds, hold, pitch_mod, e_end);
       if constexpr (MpFdCarry<N>::ENABLED) {
