@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: joint-timesteps/s of inverse_dynamics_trajectory over B x N rows.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c4] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config all|c2|c2f|c3|c4|c4s|c5|c5b] [--no-cpu-baseline]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W          (one rank per GPU)
 
@@ -12,6 +12,12 @@ one rank every GPU gets its own B trajectories (weak scaling) and evaluates its 
 the path has no exchange step, so the timed step has no collective.  The RCCL all-gather that
 reassembles the full torque history on every GPU is then measured in a second loop (step + all-gather)
 and reported in the "allgather" object next to `value`.
+
+The default run (`--config all`, one GPU) times c2 as the line's `value` / `roofline` / `cpu_baseline` and then every other
+BASELINE configuration (c2f, c3, c4, c4s, c5 on the time-major device layout, c5b on the batch-major one) into the line's
+`"configs"` object: ms_per_step, kernel, kernel_ms (+ cold), roofline {frac, traffic, algorithmic bytes}, roofline_valu and a
+`parity_sample` against the pinned C oracle.  Every parity sample is an ASSERTION: the line is still printed, and the
+process then exits with code 4 if any sample exceeds the suite's tolerances.
 
 torch is used ONLY for the multi-process rendezvous (gloo barrier / max / 128-byte id broadcast); the
 compute path is ctypes -> libmanipula_hip.so.  Prints ONE JSON line on rank 0.
@@ -43,10 +49,16 @@ CONFIGS = {
     "c4s": dict(robot="panda7", B=32768, N=200, dtype="f32", op="id",
                 desc="Franka Panda, the 7 arm joints only (first-seven-joint truncation of the reference's 8-joint tables), "
                      "B=32768/GPU x N=200, ID fp32 - the 7-DOF reading of BASELINE configs[3]"),
-    "c5": dict(robot="xarm6", B=131072, N=100, dtype="f32", op="fd_traj",
+    "c5": dict(robot="xarm6", B=131072, N=100, dtype="f32", op="fd_traj", layout="time_major",
                desc="xArm6 (6 DOF; the reference ships no xArm7), gravity + per-step Ftip, B=131072/GPU x N=100, mass matrix + "
-                    "forward-dynamics roll-out fp32, dt=0.01 intRes=1 (BASELINE configs[4] per-GPU shard)"),
+                    "forward-dynamics roll-out fp32, dt=0.01 intRes=1 (BASELINE configs[4] per-GPU shard); device arrays TIME-MAJOR "
+                    "(N,B,n): mp_fd_trajectory_tm_f32 - the reference has no batched roll-out, the batch axis' place in device memory "
+                    "is the library's choice"),
+    "c5b": dict(robot="xarm6", B=131072, N=100, dtype="f32", op="fd_traj", layout="batch_major",
+                desc="the same roll-out as c5 on BATCH-MAJOR device arrays (B,N,n): mp_fd_trajectory_f32, 4-step LDS tiles"),
 }
+SECONDARY = ("c2f", "c3", "c4", "c4s", "c5", "c5b")   # what `--config all` adds to the c2 line's "configs" object
+F32_ROW = 5e-6   # the suite's float32 floor: 1e-4 |ref| + 5e-6 max|row| (tests/test_gpu_parity.py)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 SEED = 20260705
 
@@ -71,7 +83,8 @@ def kernel_name(cfg):
                   ("k_id_pk" if cfg["dtype"] == "f32" else "k_id"),
             "fused": ("mp_spec_traj_id_s_f0" if forced == "s" else "mp_spec_traj_id_pk_f0") if spec else "k_traj_id_pk_tab",
             "fk_jac_id": "mp_spec_fk_jac_id_d_f0" if spec else "k_fk_jac_id",
-            "fd_traj": "mp_spec_fd_traj_f1" if spec else "k_fd_traj"}[cfg["op"]]
+            "fd_traj": (("mp_spec_fd_traj_tm_f1" if spec else "k_fd_traj_tm") if cfg.get("layout") == "time_major" else
+                        ("mp_spec_fd_traj_f1" if spec else "k_fd_traj"))}[cfg["op"]]
 
 
 def oracle_tables(ref, robot):
@@ -177,10 +190,42 @@ def ramp(ctx, step, ms):
     return n
 
 
+def parity_rows(got, want, dtype):
+    """The suite's element-wise bound (tests/test_gpu_parity.py assert_f32 / assert_f64): float32 1e-4 |ref| + 5e-6 max|row|,
+    float64 1e-6 |ref| + 1e-7.  `worst_over_tol` > 1 fails the run."""
+    want = np.asarray(want, np.float64).reshape(len(want), -1)
+    err = np.abs(np.asarray(got, np.float64).reshape(want.shape) - want)
+    if dtype == "f32":
+        tol = 1e-4 * np.abs(want) + F32_ROW * np.abs(want).max(axis=1, keepdims=True)
+        rule = "1e-4 |ref| + 5e-6 max|row|"
+    else:
+        tol = 1e-6 * np.abs(want) + 1e-7
+        rule = "1e-6 |ref| + 1e-7"
+    finite = bool(np.isfinite(np.asarray(got)).all())
+    worst = float((err / np.maximum(tol, 1e-300)).max()) if finite else float("inf")
+    return {"rows": int(want.shape[0]), "max_abs_err": float(err.max()) if finite else None, "max_abs_ref": float(np.abs(want).max()),
+            "tolerance": rule, "worst_over_tol": worst, "ok": bool(finite and worst <= 1.0)}
+
+
+def oracle_id_rows(robot, q, qd, qdd, budget_s):
+    """tau of the first rows of (q, qd, qdd) from the pinned C oracle, as many as `budget_s` seconds of host time cover."""
+    from oracle import c_oracle
+    from oracle import ref_numpy as ref
+
+    tab = oracle_tables(ref, robot)
+    q, qd, qdd = (np.ascontiguousarray(x, dtype=np.float64) for x in (q, qd, qdd))
+    probe = min(2048, q.shape[0])
+    t0 = time.perf_counter()
+    c_oracle.inverse_dynamics_rows(tab, q[:probe], qd[:probe], qdd[:probe])
+    rate = probe / max(time.perf_counter() - t0, 1e-6)
+    rows = int(min(q.shape[0], max(probe, rate * budget_s)))
+    return c_oracle.inverse_dynamics_rows(tab, q[:rows], qd[:rows], qdd[:rows])[0], tab
+
+
 FTIP_REF = np.array([1.0, -2.0, 0.5, 3.0, -1.5, 0.75])  # the reference's own non-zero wrench (tests/test_dynamics_golden.py:145)
 
 
-def bench_fd(args, cfg, info, hg, ctx, model, t, props):
+def bench_fd(args, cfg, info, hg, ctx, model, t, props, headline=True):
     """Config c5: B independent forward-dynamics roll-outs (mass matrix + bias + solve + integrate per step).
     Sequential in time, so the path is VALU-bound by construction; the HBM roofline line is reported as asked.
 
@@ -203,12 +248,16 @@ def bench_fd(args, cfg, info, hg, ctx, model, t, props):
     hold = ctx.id_trajectory_host(model, th0, zero, zero, g, None, dtype=np.float32)        # setup: gravity torques at the start pose
     taumat = (hold[:, None, :] + rng.uniform(-1, 1, (B, N, n)).astype(np.float32) * np.float32(1e-3)).astype(np.float32)
     Fm = (FTIP_REF.astype(np.float32) * np.float32(0.02) * rng.uniform(0.5, 1.0, (B, N, 1)).astype(np.float32)).astype(np.float32)
-    d_th0, d_dth0, d_tau, d_F = ctx.to_device(th0), ctx.to_device(dth0), ctx.to_device(taumat), ctx.to_device(Fm)
+    tmaj = cfg.get("layout") == "time_major"
+    # the device arrays in the layout under test (host copies stay (B,N,*) for the oracle)
+    dev = (lambda a: np.ascontiguousarray(np.swapaxes(a, 0, 1))) if tmaj else (lambda a: a)
+    d_th0, d_dth0, d_tau, d_F = ctx.to_device(th0), ctx.to_device(dth0), ctx.to_device(dev(taumat)), ctx.to_device(dev(Fm))
     ob = B * N * n * 4
     d_pos, d_vel, d_acc = ctx.alloc(ob), ctx.alloc(ob), ctx.alloc(ob)
+    bufs = [d_th0, d_dth0, d_tau, d_F, d_pos, d_vel, d_acc]
 
     def step():
-        ctx.fd_trajectory(model, d_th0, d_dth0, d_tau, d_F, B, N, g, 0.01, 1, d_pos, d_vel, d_acc, dtype=np.float32)
+        ctx.fd_trajectory(model, d_th0, d_dth0, d_tau, d_F, B, N, g, 0.01, 1, d_pos, d_vel, d_acc, dtype=np.float32, time_major=tmaj)
 
     # cold figure (reported beside the sustained one, never as `value`): the first launches after half a second of idle, before
     # the power controller has settled - this kernel runs at the 1400 W package limit, sustained launches take ~1.2x the cold ones
@@ -249,26 +298,29 @@ def bench_fd(args, cfg, info, hg, ctx, model, t, props):
         "dtype": cfg["dtype"], "data": "synthetic",
         "config": {"workload": cfg["desc"], "robot": cfg["robot"], "dof": n, "B_per_gpu": B, "N": N, "op": cfg["op"],
                    "kernel_variant": "robot-specialised (hiprtc)" if cfg["specialized"] else "generic",
+                   "device_layout": "time-major (N,B,n): whole lines per step, no LDS tile" if tmaj else "batch-major (B,N,n): 4-step LDS tiles",
                    "inputs": "gravity-holding torques + 1e-3 disturbance, per-step wrench 0.02 x reference wrench (finite for all N steps)",
                    "sharding": f"batch axis over {world} rank(s), no collective in the timed step"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                      "traffic": None, "kernel": kernel_name(cfg), "kernel_ms": kern_ms, "kernel_ms_cold": kern_ms_cold,
                      "frac_cold": alg_bytes / (kern_ms_cold * 1e-3) / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": alg_bytes,
                      "kernel_ms_method": "HIP events on the launch stream around the K launches of the timed region, / K",
-                     "note": "sequential in time; bounded by what the memory system moves for this access pattern (96-byte runs 2400 bytes apart, every 4 steps: "
-                             "tools/ubench_c5io moves the tile I/O alone in 0.47-0.55 ms) at the package power limit; arithmetic alone 0.29 ms (DESIGN.md section 4)"},
+                     "note": ("sequential in time, one lane per trajectory; every step streams whole lines (64 x 24-byte rows per array), the next step's rows "
+                              "are prefetched in registers; arithmetic alone 0.29 ms (DESIGN.md section 4)") if tmaj else
+                             ("sequential in time; bounded by what the memory system moves for this access pattern (96-byte runs 2400 bytes apart, every 4 steps: "
+                              "tools/ubench_c5io moves the tile I/O alone in 0.47-0.55 ms) at the package power limit; arithmetic alone 0.29 ms (DESIGN.md section 4)")},
         "setup": {"ramp_ms": args.ramp_ms, "what": "untimed launches before the W warm-up steps (clock ramp)"},
         "device": props["name"],
     }
-    attach_counters(result, args.config)
-    if info.rank == 0:
+    attach_counters(result, cfg["name"])
+    if info.rank == 0 and headline:
         result["roofline"]["device_copy"] = device_copy_probe(ctx)
     if info.rank == 0 and world == 1 and not args.no_cpu_baseline:
         tab = oracle_tables(ref, cfg["robot"])
-        pos = d_pos.download((B, N, n), np.float32)
-        vel = d_vel.download((B, N, n), np.float32)
-        acc = d_acc.download((B, N, n), np.float32)
+        host = (lambda d: np.ascontiguousarray(np.swapaxes(d.download((N, B, n), np.float32), 0, 1))) if tmaj else (lambda d: d.download((B, N, n), np.float32))
+        pos, vel, acc = host(d_pos), host(d_vel), host(d_acc)
         finite = bool(np.isfinite(pos).all() and np.isfinite(vel).all() and np.isfinite(acc).all())
+        budget = 8.0 if headline else 3.0
         # CPU baseline: the reference algorithm's roll-out restated in C (pinned to the reference's N = 100 dump), all N
         # steps of the first `nbt` trajectories of the same input on all host cores; sized from a probe to ~10 s
         x64 = [v.astype(np.float64) for v in (th0, dth0, taumat, Fm)]
@@ -276,7 +328,7 @@ def bench_fd(args, cfg, info, hg, ctx, model, t, props):
         tc = time.perf_counter()
         c_oracle.fd_trajectory(tab, x64[0][:probe], x64[1][:probe], x64[2][:probe], g, x64[3][:probe], 0.01, 1)
         rate = probe / max(time.perf_counter() - tc, 1e-6)
-        nbt = int(min(B, max(probe, rate * 8.0)))
+        nbt = int(min(B, max(probe, rate * budget)))
         tc = time.perf_counter()
         wp, wv, wa, threads = c_oracle.fd_trajectory(tab, x64[0][:nbt], x64[1][:nbt], x64[2][:nbt], g, x64[3][:nbt], 0.01, 1)
         dtc = time.perf_counter() - tc
@@ -300,15 +352,22 @@ def bench_fd(args, cfg, info, hg, ctx, model, t, props):
         t2 = np.stack([np.zeros_like(x64[2][:nd, 1:]), x64[2][:nd, 1:]], axis=2).reshape(-1, 2, n)
         f2 = np.stack([np.zeros_like(x64[3][:nd, 1:]), x64[3][:nd, 1:]], axis=2).reshape(-1, 2, 6)
         op, ov, oa, _ = c_oracle.fd_trajectory(tab, p0, v0, t2, g, f2, 0.01, 1)
-        defect = 0.0
-        for got, want in ((pos[:nd, 1:], op[:, 1]), (vel[:nd, 1:], ov[:, 1]), (acc[:nd, 1:], oa[:, 1])):
+        defect = {}
+        for name, got, want in (("positions", pos[:nd, 1:], op[:, 1]), ("velocities", vel[:nd, 1:], ov[:, 1]), ("accelerations", acc[:nd, 1:], oa[:, 1])):
             e = np.abs(got.reshape(-1, n).astype(np.float64) - want)
-            defect = max(defect, float((e.max(axis=1) / np.maximum(np.abs(want).max(axis=1), 1e-3)).max()))
-        par["one_step_defect"] = {"trajectories": nd, "steps_each": N - 1, "max_rel_to_row_max": defect}
+            defect[name] = float((e.max(axis=1) / np.maximum(np.abs(want).max(axis=1), 1e-3)).max())
+        # the suite's bounds (tests/test_gpu_parity.py::test_c5_rollout_full_horizon...): one float32 step lands within a few ulps
+        # for q / qd and within eps * cond(M) for qdd
+        bounds = {"positions": 2e-6, "velocities": 2e-5, "accelerations": 1e-4}
+        par["one_step_defect"] = {"trajectories": nd, "steps_each": N - 1, "max_rel_to_row_max": defect, "bounds": bounds}
+        par["ok"] = bool(finite and all(defect[k] <= bounds[k] for k in bounds) and par["drift_over_scale"]["p99"] <= 1e-4)
+        par["rule"] = "all outputs finite, one-step defect within bounds, 99 % of the trajectories within 1e-4 of each array's scale over all N steps"
         result["parity_sample"] = par
-    if info.rank == 0:
-        emit(result)
-    ctx.destroy()
+        if not headline:
+            result.pop("cpu_baseline", None)
+    for b in bufs:
+        b.free()
+    return result
 
 
 def attach_counters(result, config):
@@ -381,7 +440,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--config", default="all", choices=["all"] + sorted(CONFIGS),
+                    help="all (default): c2 as the line's value plus every other configuration in its \"configs\" object")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--launch", default="stream", choices=("stream", "graph"),
                     help="stream: one host call per step; graph: the K timed steps captured into one hipGraph launch")
@@ -416,19 +476,8 @@ def main():
         ids = hg.broadcast_bytes(bytes(range(128)) if info.rank == 0 else None, 128)
         if info.rank == 0:
             emit({"dryrun": True, "n_gpus": world, "max_rank_seen": top, "broadcast_ok": ids == bytes(range(128)),
-                  "config": {"workload": CONFIGS[args.config]["desc"]}})
+                  "config": {"workload": CONFIGS["c2" if args.config == "all" else args.config]["desc"]}})
         return
-
-    cfg = dict(CONFIGS[args.config])
-    if args.B or args.N or args.robot:
-        cfg["B"], cfg["N"], cfg["robot"] = args.B or cfg["B"], args.N or cfg["N"], args.robot or cfg["robot"]
-        cfg["desc"] += f" [OVERRIDDEN: B={cfg['B']} N={cfg['N']} robot={cfg['robot']}]"
-    t = robots.robot_tables(cfg["robot"])
-    n = t["S_list"].shape[1]
-    B, N = cfg["B"], cfg["N"]
-    rows = B * N
-    dt_np = np.float32 if cfg["dtype"] == "f32" else np.float64
-    wbytes = np.dtype(dt_np).itemsize
 
     dev = info.local_rank
     if os.environ.get("MANIPULAPY_BENCH_SHARE_DEVICE") == "1":  # development only: several ranks on one GPU
@@ -436,21 +485,105 @@ def main():
     ctx = _hip.HipContext(dev)
     ctx.selftest()
     props = ctx.properties()
+    names = [args.config] if args.config != "all" else ["c2"] + (list(SECONDARY) if world == 1 else [])
+    result, hung = run_config(names[0], args, info, hg, ctx, props, headline=True)
+    failed = []
+    if not (result.get("parity_sample") or {"ok": True}).get("ok", True):
+        failed.append(names[0])
+    if len(names) > 1 and not hung:
+        result["configs"] = {}
+        for name in names[1:]:
+            t0 = time.perf_counter()
+            try:
+                entry, _ = run_config(name, args, info, hg, ctx, props, headline=False)
+                entry = compact(entry)
+            except Exception as exc:   # one configuration failing to run is reported in its entry and fails the process
+                entry = {"error": f"{type(exc).__name__}: {str(exc)[:300]}"}
+            entry["wall_s"] = round(time.perf_counter() - t0, 2)
+            result["configs"][name] = entry
+            if "error" in entry or not (entry.get("parity_sample") or {"ok": True}).get("ok", True):
+                failed.append(name)
+    if failed:
+        result["parity_failed"] = failed
+    if info.rank == 0:
+        emit(result)
+    if hung:
+        os._exit(3)  # a stuck collective cannot be cancelled from Python: leave, non-zero, without another context call
+    ctx.destroy()
+    if world > 1 and result.get("allgather") is not None and result.get("verified") is False and info.rank == 0:
+        raise SystemExit(5)   # the reassembled torque history did not match the recomputation: not a result
+    if failed:
+        raise SystemExit(4)
+
+
+def compact(r):
+    """The entry a configuration gets in the default line's "configs" object."""
+    keep = ("metric", "value", "unit", "ms_per_step", "steps", "dtype")
+    out = {k: r[k] for k in keep if k in r}
+    out["workload"] = r["config"]["workload"]
+    out["kernel_variant"] = r["config"].get("kernel_variant")
+    rl = r["roofline"]
+    out["kernel"], out["kernel_ms"], out["kernel_ms_cold"] = rl["kernel"], rl["kernel_ms"], rl["kernel_ms_cold"]
+    out["roofline"] = {k: rl[k] for k in ("bound", "achieved", "peak", "unit", "frac", "frac_cold", "traffic", "algorithmic_bytes_per_launch") if k in rl}
+    if "roofline_valu" in r:
+        out["roofline_valu"] = {k: r["roofline_valu"][k] for k in ("frac", "valu_insts_per_launch", "issue_cycles_per_inst", "clock_hz", "source")}
+    if "parity_sample" in r:
+        out["parity_sample"] = r["parity_sample"]
+    return out
+
+
+def run_config(name, args, info, hg, ctx, props, headline):
+    """One configuration on this rank's GPU: (result dict in the line's format, collective hung?)."""
+    from manipulapy_amd import _hip, robots
+
+    world = info.world
+    cfg = dict(CONFIGS[name])
+    cfg["name"] = name
+    if args.B or args.N or args.robot:
+        cfg["B"], cfg["N"], cfg["robot"] = args.B or cfg["B"], args.N or cfg["N"], args.robot or cfg["robot"]
+        cfg["desc"] += f" [OVERRIDDEN: B={cfg['B']} N={cfg['N']} robot={cfg['robot']}]"
+    t = robots.robot_tables(cfg["robot"])
+    n = t["S_list"].shape[1]
     model = _hip.HipModel(t["S_list"], t["Mlist_per_link"], t["Glist"], t["M_ee"], t["joint_limits"])
     if not args.no_specialize:
         ctx.specialize(model)  # setup, untimed: hiprtc build of this robot's kernels (cached on disk)
     cfg["specialized"] = ctx.is_specialized(model)
     cfg["dof"] = n
+    try:
+        if cfg["op"] == "fd_traj":
+            return bench_fd(args, cfg, info, hg, ctx, model, t, props, headline), False
+        return bench_id(args, cfg, info, hg, ctx, model, t, props, headline)
+    finally:
+        ctx.synchronize()
+        ctx.trim_pool()   # the next configuration starts from an empty pool (c3 alone holds 22.5 GB)
 
-    if cfg["op"] == "fd_traj":
-        return bench_fd(args, cfg, info, hg, ctx, model, t, props)
+
+def bench_id(args, cfg, info, hg, ctx, model, t, props, headline):
+    """Configs c2 / c2f / c3 / c4 / c4s: rows = B x N independent (trajectory, timestep) rows per launch."""
+    from manipulapy_amd import _hip
+
+    world = info.world
+    n = cfg["dof"]
+    B, N = cfg["B"], cfg["N"]
+    rows = B * N
+    dt_np = np.float32 if cfg["dtype"] == "f32" else np.float64
+    wbytes = np.dtype(dt_np).itemsize
+    bufs = []
+
+    def alloc(nbytes):
+        bufs.append(ctx.alloc(nbytes))
+        return bufs[-1]
+
+    def to_device(a):
+        bufs.append(ctx.to_device(a))
+        return bufs[-1]
 
     # ---- synthetic input, generated ON the device (SURVEY §8d): start / end ~ U(joint limits), quintic, Tf = 2.
     #      The steps ROTATE over `nsets` distinct input / output sets (set k: its own seeded start / end pairs, its own
     #      q / qd / qdd / tau buffers) so that more than 1.1 GB is touched between two uses of the same bytes - nothing a
     #      step reads or writes can still sit in the 256 MB Infinity Cache from its previous use.  Set 0 is the one the
     #      parity sample, the CPU baseline and the all-gather phase use.
-    cid = {"c2": 2, "c2f": 2, "c3": 3, "c4": 4, "c4s": 4}[args.config]
+    cid = {"c2": 2, "c2f": 2, "c3": 3, "c4": 4, "c4s": 4}[cfg["name"]]
     lo, hi = t["joint_limits"][:, 0], t["joint_limits"][:, 1]
     alg_bytes_set = algorithmic_bytes_per_row(cfg, n) * rows
     nsets = args.input_sets if args.input_sets > 0 else int(min(4, max(1, -(-1_100_000_000 // alg_bytes_set))))
@@ -460,26 +593,27 @@ def main():
         rng = np.random.default_rng(SEED + cid + 1000 * info.rank + 100_000 * k)
         start = rng.uniform(lo, hi, (B, n)).astype(np.float32)
         end = rng.uniform(lo, hi, (B, n)).astype(np.float32)
-        d_start, d_end = ctx.to_device(start), ctx.to_device(end)
-        st = {"d_start": d_start, "d_end": d_end, "d_tau": ctx.alloc(nb)}
+        d_start, d_end = to_device(start), to_device(end)
+        st = {"d_start": d_start, "d_end": d_end, "d_tau": alloc(nb)}
         if cfg["op"] != "fused":
             nb32 = rows * n * 4
-            d_q32, d_qd32, d_qdd32 = ctx.alloc(nb32), ctx.alloc(nb32), ctx.alloc(nb32)
+            d_q32, d_qd32, d_qdd32 = alloc(nb32), alloc(nb32), alloc(nb32)
             ctx.batch_trajectory(model, d_start, d_end, B, N, 2.0, 5, d_q32, d_qd32, d_qdd32)
             ctx.synchronize()
             if cfg["dtype"] == "f32":
                 st["d_q"], st["d_qd"], st["d_qdd"] = d_q32, d_qd32, d_qdd32
             else:  # float64 configs: widen the same histories on the host once (setup, untimed)
-                st["d_q"], st["d_qd"], st["d_qdd"] = (ctx.alloc(rows * n * 8) for _ in range(3))
+                st["d_q"], st["d_qd"], st["d_qdd"] = (alloc(rows * n * 8) for _ in range(3))
                 for src, dst in ((d_q32, st["d_q"]), (d_qd32, st["d_qd"]), (d_qdd32, st["d_qdd"])):
                     h = src.download((rows * n,), np.float32).astype(np.float64)
                     dst.upload(h)
                     del h
                 for b in (d_q32, d_qd32, d_qdd32):
                     b.free()
+                    bufs.remove(b)
         if cfg["op"] == "fk_jac_id":
-            st["d_T"] = ctx.alloc(rows * 16 * wbytes)
-            st["d_J"] = ctx.alloc(rows * 6 * n * wbytes)
+            st["d_T"] = alloc(rows * 16 * wbytes)
+            st["d_J"] = alloc(rows * 6 * n * wbytes)
         sets.append(st)
     d_start, d_end, d_tau = sets[0]["d_start"], sets[0]["d_end"], sets[0]["d_tau"]
     d_q, d_qd, d_qdd = sets[0].get("d_q"), sets[0].get("d_qd"), sets[0].get("d_qdd")
@@ -580,7 +714,7 @@ def main():
     #      measured as a second timed loop (step + all-gather) and reported next to `value`
     allgather = None
     # MANIPULAPY_BENCH_FORCE_GATHER=1 runs the phase on a single GPU too (a one-rank communicator): exercises this code path
-    if (world > 1 or os.environ.get("MANIPULAPY_BENCH_FORCE_GATHER") == "1") and not args.no_gather:
+    if headline and (world > 1 or os.environ.get("MANIPULAPY_BENCH_FORCE_GATHER") == "1") and not args.no_gather:
         allgather = {"bytes_per_rank": nb, "collective": "ncclAllGather (RCCL), one call per step after the kernel"}
 
         def verify_gather(d_all):
@@ -607,7 +741,7 @@ def main():
                 uid = _hip.HipContext.comm_unique_id() if info.rank == 0 else None
                 uid = hg.broadcast_bytes(uid, _hip.UNIQUE_ID_BYTES)
                 comm = ctx.comm_create(uid, world, info.rank)
-                d_tau_all = ctx.alloc(nb * world)
+                d_tau_all = alloc(nb * world)
                 # the step just run wrote the tau of set (turn - 1) % nsets: that is the shard this rank contributes
                 wall_g, _ = timed(lambda: comm.allgather(sets[(turn[0] - 1) % nsets]["d_tau"], d_tau_all, nb))
                 ms_g = wall_g / args.steps * 1e3
@@ -696,37 +830,71 @@ def main():
         "setup": {"ramp_ms": args.ramp_ms, "what": "untimed launches before the W warm-up steps (clock ramp)"},
         "device": props["name"],
     }
-    attach_counters(result, args.config)
-    if info.rank == 0:
+    attach_counters(result, cfg["name"])
+    if info.rank == 0 and headline:
         result["roofline"]["device_copy"] = device_copy_probe(ctx)
 
     if info.rank == 0 and world == 1 and not args.no_cpu_baseline and not hung:
-        ns = rows  # the C oracle sizes its own sample from a time budget
-        q = d_q.download((rows, n), dt_np)[:ns]
-        qd = d_qd.download((rows, n), dt_np)[:ns]
-        qdd = d_qdd.download((rows, n), dt_np)[:ns]
         try:
-            base, tau_cpu = cpu_baseline(cfg["robot"], q, qd, qdd)
-            result["cpu_baseline"] = base
-            tau_gpu = d_tau.download((rows, n), dt_np)[: len(tau_cpu)]
-            err = np.abs(tau_gpu.astype(np.float64) - tau_cpu)
-            result["parity_sample"] = {"rows": int(len(tau_cpu)), "max_abs_err": float(err.max()),
-                                       "max_abs_tau": float(np.abs(tau_cpu).max())}
-            result["cpu_twin"] = cpu_twin_rate(model, q, qd, qdd, dt_np)
+            result.update(parity_and_baseline(cfg, ctx, model, t, sets[0], rows, n, dt_np, headline))
         except Exception as exc:  # the GPU line must not be lost to a host-side problem (no compiler, no OpenMP ...)
             result["cpu_baseline"] = {"value": None, "unit": "joint-timesteps/s", "cores": 0, "kind": "port",
-                                      "sample": f"not measured: {str(exc)[:200]}"}
+                                      "sample": f"not measured: {type(exc).__name__}: {str(exc)[:200]}"}
+            result["parity_sample"] = {"ok": False, "error": f"{type(exc).__name__}: {str(exc)[:200]}"}
     if allgather is not None:
         result["allgather"] = allgather
         # the three figures of an N > 1 line side by side: `value` is compute only (the timed step has no collective)
         result["value_with_allgather"] = allgather.get("value_with_allgather")
         result["value_overlapped"] = (allgather.get("overlapped") or {}).get("value")
         result["verified"] = bool(allgather.get("verified") is True and (allgather.get("overlapped") or {}).get("verified", True) is True)
-    if info.rank == 0:
-        emit(result)
-    if hung:
-        os._exit(3)  # a stuck collective cannot be cancelled from Python: leave, non-zero, without another context call
-    ctx.destroy()
+    if not hung:
+        for b in bufs:
+            b.free()
+    return result, hung
+
+
+def parity_and_baseline(cfg, ctx, model, t, st, rows, n, dt_np, headline):
+    """Set 0 of the benchmark input against the pinned C oracle (and, for FK / Jacobian, the NumPy oracle): the line's
+    `parity_sample` - an assertion, see main - and, for the headline configuration, `cpu_baseline` and `cpu_twin`."""
+    from oracle import ref_numpy as ref
+
+    out = {}
+    B, N = cfg["B"], cfg["N"]
+    if cfg["op"] == "fused":
+        # the oracle regenerates the trajectories itself (time scaling + clip, planning/trajectory.py:15-99, :311-313)
+        nb = min(B, 512 if headline else 128)
+        start = st["d_start"].download((B, n), np.float32)[:nb]
+        end = st["d_end"].download((B, n), np.float32)[:nb]
+        o = ref.batch_joint_trajectory(t["joint_limits"], start, end, 2.0, N, 5)
+        q, qd, qdd = (o[k].reshape(-1, n).astype(np.float64) for k in ("positions", "velocities", "accelerations"))
+    else:
+        ns = rows if headline else min(rows, 1 << 21)   # the C oracle sizes its own sample from a time budget
+        q = st["d_q"].download((ns, n), dt_np)
+        qd = st["d_qd"].download((ns, n), dt_np)
+        qdd = st["d_qdd"].download((ns, n), dt_np)
+    if headline:
+        base, tau_cpu = cpu_baseline(cfg["robot"], q, qd, qdd)
+        out["cpu_baseline"] = base
+    else:
+        tau_cpu, _ = oracle_id_rows(cfg["robot"], q, qd, qdd, 2.5)
+    tau_gpu = st["d_tau"].download((len(tau_cpu), n), dt_np)
+    par = parity_rows(tau_gpu, tau_cpu, cfg["dtype"])
+    par["what"] = "tau of the first rows of input set 0 against the pinned C oracle (oracle/oracle.c)"
+    if cfg["op"] == "fk_jac_id":
+        tab = oracle_tables(ref, cfg["robot"])
+        idx = np.linspace(0, len(q) - 1, 384).astype(np.int64)    # FK / Jacobian: NumPy oracle, rows spread over the sample
+        Tg = st["d_T"].download((len(q), 16), dt_np)[idx]
+        Jg = st["d_J"].download((len(q), 6 * n), dt_np)[idx]
+        Tw = np.stack([ref.fk_space(tab, q[i]) for i in idx]).reshape(len(idx), 16)
+        Jw = np.stack([ref.jacobian_space(tab, q[i]) for i in idx]).reshape(len(idx), 6 * n)
+        pt, pj = parity_rows(Tg, Tw, cfg["dtype"]), parity_rows(Jg, Jw, cfg["dtype"])
+        par["fk"] = {k: pt[k] for k in ("rows", "max_abs_err", "worst_over_tol", "ok")}
+        par["jacobian"] = {k: pj[k] for k in ("rows", "max_abs_err", "worst_over_tol", "ok")}
+        par["ok"] = bool(par["ok"] and pt["ok"] and pj["ok"])
+    out["parity_sample"] = par
+    if headline and cfg["op"] != "fused":
+        out["cpu_twin"] = cpu_twin_rate(model, q, qd, qdd, dt_np)
+    return out
 
 
 if __name__ == "__main__":

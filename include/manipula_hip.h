@@ -202,6 +202,21 @@ int mp_fd_trajectory_f64(mp_ctx* ctx, const mp_model* model, const double* d_the
                          const double* d_taumat, const double* d_Ftipmat, int64_t B, int64_t N, const double* g,
                          double dt, int intRes, float* d_pos, float* d_vel, float* d_acc);
 
+/* The same roll-out on the TIME-MAJOR device layout: d_taumat (N,B,n), d_Ftipmat (N,B,6) or NULL, d_pos / d_vel / d_acc
+ * (N,B,n); d_theta0 / d_dtheta0 stay (B,n).  The reference integrates ONE trajectory (planning/trajectory_dynamics.py:
+ * 382-423, :580-708); the batch axis is this library's extension, and with time outermost the trajectories of a wavefront
+ * are neighbours in memory at every step (whole cache lines per step instead of 4-step LDS tiles): the faster form for
+ * callers that keep their histories on the device.  Results are element for element those of mp_fd_trajectory_*. */
+int mp_fd_trajectory_tm_f32(mp_ctx* ctx, const mp_model* model, const float* d_theta0, const float* d_dtheta0,
+                            const float* d_taumat, const float* d_Ftipmat, int64_t B, int64_t N, const double* g,
+                            double dt, int intRes, float* d_pos, float* d_vel, float* d_acc);
+int mp_fd_trajectory_tm_f64(mp_ctx* ctx, const mp_model* model, const double* d_theta0, const double* d_dtheta0,
+                            const double* d_taumat, const double* d_Ftipmat, int64_t B, int64_t N, const double* g,
+                            double dt, int intRes, float* d_pos, float* d_vel, float* d_acc);
+/* d_dst (inner, outer, row_bytes) <- d_src (outer, inner, row_bytes): converts between the batch-major API arrays
+ * (B,N,n) and the time-major layout (N,B,n), either way.  row_bytes: a multiple of 4, at most 64. */
+int mp_transpose_rows(mp_ctx* ctx, const void* d_src, int64_t outer, int64_t inner, int64_t row_bytes, void* d_dst);
+
 /* cartesian_trajectory for B pose pairs (planning/trajectory.py:504-594, :676-737; replaces
  * cartesian_trajectory_kernel, cuda_kernels/trajectory_kernels.py:707-759, and the host-side orientation loop):
  * Xstart / Xend (B,4,4) float64; pos / vel / acc (B,N,3) and orientations (B,N,3,3) float32.  N >= 2. */

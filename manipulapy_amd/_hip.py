@@ -92,6 +92,9 @@ SIGNATURES = {
     "mp_forward_dynamics_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _c_dp, _c_dp, _vp]),
     "mp_fd_trajectory_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _c_dp, ctypes.c_double, ctypes.c_int, _vp, _vp, _vp]),
     "mp_fd_trajectory_f64": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _c_dp, ctypes.c_double, ctypes.c_int, _vp, _vp, _vp]),
+    "mp_fd_trajectory_tm_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _c_dp, ctypes.c_double, ctypes.c_int, _vp, _vp, _vp]),
+    "mp_fd_trajectory_tm_f64": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _c_dp, ctypes.c_double, ctypes.c_int, _vp, _vp, _vp]),
+    "mp_transpose_rows": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _vp]),
     "mp_mass_matrix_host_f64": (ctypes.c_int, [_vp, _vp, _c_dp, _i64, _c_dp]),
     "mp_forward_dynamics_host_f64": (ctypes.c_int, [_vp, _vp, _c_dp, _c_dp, _c_dp, _i64, _c_dp, _c_dp, _c_dp]),
     "mp_fd_trajectory_host_f32": (ctypes.c_int, [_vp, _vp, _c_fp, _c_fp, _c_fp, _c_fp, _i64, _i64, _c_dp, ctypes.c_double, ctypes.c_int, _c_fp, _c_fp, _c_fp]),
@@ -675,35 +678,84 @@ class HipContext:
                                                      _dptr(g), _dptr(F), _dptr(out)))
         return out
 
-    def fd_trajectory_host(self, model: HipModel, theta0, dtheta0, taumat, g, Ftipmat, dt, intRes, dtype=np.float64):
-        """B trajectories: theta0/dtheta0 (B,n), taumat (B,N,n), Ftipmat (B,N,6) or None -> 3 x (B,N,n) float32."""
+    def fd_trajectory_host(self, model: HipModel, theta0, dtheta0, taumat, g, Ftipmat, dt, intRes, dtype=np.float64,
+                           layout: str = "batch_major", device_layout: str | None = None):
+        """B trajectories: theta0/dtheta0 (B,n), taumat (B,N,n), Ftipmat (B,N,6) or None -> 3 x (B,N,n) float32.
+
+        layout="time_major": the HOST arrays are (N,B,n) / (N,B,6) and so are the results.  device_layout selects the kernel
+        ("batch_major": 4-step LDS tiles on (B,N,n); "time_major": whole lines per step on (N,B,n)); when it differs from the
+        host layout the arrays are converted on the device (mp_transpose_rows).  Default: the host layout's own kernel."""
+        if layout not in ("batch_major", "time_major") or device_layout not in (None, "batch_major", "time_major"):
+            raise ValueError("layout / device_layout must be 'batch_major' or 'time_major'")
         dtype = np.dtype(dtype)
         th = _as_c(theta0, dtype, name="thetalist")
         if th.ndim != 2 or th.shape[1] != model.n:
             raise ValueError(f"thetalist must be (B, {model.n}), got {th.shape}")
-        B = th.shape[0]
+        B, n = th.shape
         dth = _as_c(dtheta0, dtype, th.shape, "dthetalist")
         tm = _as_c(taumat, dtype, name="taumat")
-        if tm.ndim != 3 or tm.shape[0] != B or tm.shape[2] != model.n:
-            raise ValueError(f"taumat must be (B, N, {model.n}), got {tm.shape}")
-        N = tm.shape[1]
-        Fm = None if Ftipmat is None else _as_c(Ftipmat, dtype, (B, N, 6), "Ftipmat")
+        bax = 0 if layout == "batch_major" else 1
+        if tm.ndim != 3 or tm.shape[bax] != B or tm.shape[2] != n:
+            raise ValueError(f"taumat must be {'(B, N, %d)' % n if bax == 0 else '(N, B, %d)' % n}, got {tm.shape}")
+        N = tm.shape[1 - bax]
+        Fm = None if Ftipmat is None else _as_c(Ftipmat, dtype, tm.shape[:2] + (6,), "Ftipmat")
         g = _vec_or_none(g, 3, "g")
-        out = [np.zeros((B, N, model.n), dtype=np.float32) for _ in range(3)]
-        if dtype == np.float32:
-            fn, ptr = self.lib.mp_fd_trajectory_host_f32, _fptr
-        else:
-            fn, ptr = self.lib.mp_fd_trajectory_host_f64, _dptr
-        _check(fn(self.handle, model.handle, ptr(th), ptr(dth), ptr(tm), ptr(Fm), B, N, _dptr(g), float(dt), int(intRes),
-                  _fptr(out[0]), _fptr(out[1]), _fptr(out[2])))
+        out = [np.zeros(tm.shape[:2] + (n,), dtype=np.float32) for _ in range(3)]
+        if layout == "batch_major" and device_layout in (None, "batch_major"):
+            if dtype == np.float32:
+                fn, ptr = self.lib.mp_fd_trajectory_host_f32, _fptr
+            else:
+                fn, ptr = self.lib.mp_fd_trajectory_host_f64, _dptr
+            _check(fn(self.handle, model.handle, ptr(th), ptr(dth), ptr(tm), ptr(Fm), B, N, _dptr(g), float(dt), int(intRes),
+                      _fptr(out[0]), _fptr(out[1]), _fptr(out[2])))
+            return tuple(out)
+        if B == 0 or N == 0:
+            return tuple(out)
+        dev_tm = (device_layout or layout) == "time_major"
+        convert = dev_tm != (layout == "time_major")
+        outer, inner = tm.shape[0], tm.shape[1]      # of the host arrays
+        bufs = []
+        try:
+            def up(a):
+                bufs.append(self.to_device(a))
+                return bufs[-1]
+
+            def flip(d, row_bytes, o, i):
+                bufs.append(self.alloc(o * i * row_bytes))
+                self.transpose_rows(d, o, i, row_bytes, bufs[-1])
+                return bufs[-1]
+
+            d_th, d_dth, d_tau = up(th), up(dth), up(tm)
+            d_F = up(Fm) if Fm is not None else None
+            if convert:
+                d_tau = flip(d_tau, n * dtype.itemsize, outer, inner)
+                d_F = flip(d_F, 6 * dtype.itemsize, outer, inner) if d_F is not None else None
+            d_out = [self.alloc(B * N * n * 4) for _ in range(3)]
+            bufs.extend(d_out)
+            self.fd_trajectory(model, d_th, d_dth, d_tau, d_F, B, N, g, dt, intRes, *d_out, dtype=dtype, time_major=dev_tm)
+            for k in range(3):
+                src = flip(d_out[k], n * 4, inner, outer) if convert else d_out[k]
+                _check(self.lib.mp_memcpy_d2h(self.handle, out[k].ctypes.data, _p(src), out[k].nbytes))
+        finally:
+            for b in bufs:
+                b.free()
         return tuple(out)
 
     def fd_trajectory(self, model, d_theta0, d_dtheta0, d_taumat, d_Ftipmat, B, N, g, dt, intRes, d_pos, d_vel, d_acc,
-                      dtype=np.float32):
-        fn = self.lib.mp_fd_trajectory_f32 if np.dtype(dtype) == np.float32 else self.lib.mp_fd_trajectory_f64
+                      dtype=np.float32, time_major: bool = False):
+        """Device pointers.  time_major=False: taumat (B,N,n), Ftipmat (B,N,6), outputs (B,N,n); True: (N,B,*) throughout."""
+        f32 = np.dtype(dtype) == np.float32
+        if time_major:
+            fn = self.lib.mp_fd_trajectory_tm_f32 if f32 else self.lib.mp_fd_trajectory_tm_f64
+        else:
+            fn = self.lib.mp_fd_trajectory_f32 if f32 else self.lib.mp_fd_trajectory_f64
         g = _vec_or_none(g, 3, "g")
         _check(fn(self.handle, model.handle, _p(d_theta0), _p(d_dtheta0), _p(d_taumat), _p(d_Ftipmat), int(B), int(N), _dptr(g),
                   float(dt), int(intRes), _p(d_pos), _p(d_vel), _p(d_acc)))
+
+    def transpose_rows(self, d_src, outer, inner, row_bytes, d_dst):
+        """d_dst (inner, outer, row_bytes) <- d_src (outer, inner, row_bytes), on the device."""
+        _check(self.lib.mp_transpose_rows(self.handle, _p(d_src), int(outer), int(inner), int(row_bytes), _p(d_dst)))
 
     # ---- RCCL
     @staticmethod

@@ -1534,3 +1534,113 @@ __device__ __forceinline__ void mp_body_fd_traj_pk(const MT& M, const MpCall<flo
     }
   }
 }
+
+// ------------------------------------------------------------------ the roll-out, TIME-MAJOR device layout
+// forward_dynamics_trajectory for B trajectories whose device arrays are laid out (Nt, B, *): taumat (Nt, B, N),
+// Ftipmat (Nt, B, 6), pos / vel / acc (Nt, B, N).  The reference integrates ONE (N, n) trajectory
+// (planning/trajectory_dynamics.py:382-423, :580-708); the batch axis is this library's extension, so where it sits in
+// device memory is the library's choice, and with time outermost the 64 trajectories of a wave are neighbours in memory
+// at EVERY step: a step reads 64 x N x sizeof(T) contiguous bytes per input array and writes 64 x N x 4 contiguous bytes
+// per output array (1536 B = twelve whole lines at n = 6) - the access pattern of the inverse-dynamics kernels, which
+// streams at the chip's limit.  No LDS tile, no held-back tails, no tile boundary: the rows of step i + 1 are requested
+// before step i is integrated (N + 6 registers) and the output rows are stored as they are produced, never waited for
+// (vmcnt counts in issue order, and the only waits in the loop are for loads issued a whole step earlier).
+// Same arithmetic, same clip, same sticky non-finite verdict as mp_body_fd_traj; one lane = one trajectory.
+// The wave waits for the prefetched rows HERE (an empty asm that consumes every register): at the end of a step, behind the
+// step's stores, where the wait is vmcnt(number of stores) - the loads are a whole step old - and the stores stay in
+// flight.  Left to itself the compiler waits at the TOP of the next step, after the new loads were issued, with a count
+// that also drains the previous step's stores (the loop head merges the entry path, on which the rows are still pending).
+template <typename T, int N, bool HAS_FTIP>
+__device__ __forceinline__ void mp_fd_rows_arrived(T (&tau)[N], T (&F)[6]) {
+#pragma unroll
+  for (int j = 0; j < N; ++j) asm volatile("" : "+v"(tau[j]));
+  if (HAS_FTIP) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) asm volatile("" : "+v"(F[k]));
+  }
+}
+
+template <typename T, int N, bool HAS_FTIP, typename MT>
+__device__ __forceinline__ void mp_body_fd_traj_tm(const MT& M, const MpCall<T>& C, const T* __restrict__ theta0,
+                                                   const T* __restrict__ dtheta0, const T* __restrict__ taumat,
+                                                   const T* __restrict__ Ftipmat, long b, long B, long Nt, T h, int intRes,
+                                                   float* __restrict__ pos, float* __restrict__ vel, float* __restrict__ acc) {
+  T q[N], qd[N];
+  RunIO<T, N>::load(theta0, b, q);
+  RunIO<T, N>::load(dtheta0, b, qd);
+  MpBad<T> bad;
+  bad.add(q); bad.add(qd);
+  T tau_next[N], F_next[6];
+  {  // the rows of step 1 (a one-row history clamps to row 0, which is never consumed)
+    const long r1 = (Nt > 1 ? B : 0) + b;
+    RunIO<T, N>::load(taumat, r1, tau_next);
+    if (HAS_FTIP) RunIO<T, 6>::load(Ftipmat, r1, F_next);
+    mp_fd_rows_arrived<T, N, HAS_FTIP>(tau_next, F_next);
+  }
+  {  // row 0 = the initial state as given, zero acceleration
+    float p[N], v[N], a[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) { p[j] = (float)q[j]; v[j] = (float)qd[j]; a[j] = 0.0f; }
+    RunIO<float, N>::store(pos, b, p);
+    RunIO<float, N>::store(vel, b, v);
+    RunIO<float, N>::store(acc, b, a);
+  }
+  for (long i = 1; i < Nt; ++i) {
+    T tau[N], tn[3] = {T(0), T(0), T(0)}, tf[3] = {T(0), T(0), T(0)}, last[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) { tau[j] = tau_next[j]; last[j] = T(0); }
+    bad.add(tau);
+    if (HAS_FTIP) {
+      T F[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) F[k] = F_next[k];
+      bad.add(F);
+      mp_wrench_to_frame1(M, F, tn, tf);
+    }
+    {  // request the next step's rows now; the last step re-reads its own (no branch around memory instructions)
+      const long rn = (i + 1 < Nt ? i + 1 : i) * B + b;
+      RunIO<T, N>::load(taumat, rn, tau_next);
+      if (HAS_FTIP) RunIO<T, 6>::load(Ftipmat, rn, F_next);
+    }
+    for (int k = 0; k < intRes; ++k) {
+      mp_forward_dynamics_auto<T, N, HAS_FTIP>(M, C.a0, tn, tf, q, qd, tau, last);
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        qd[j] = qd[j] + last[j] * h;
+        q[j] = mp_clip(q[j] + qd[j] * h, M.qmin[j], M.qmax[j]);
+      }
+    }
+    bad.add(qd);
+    const bool poison = bad.any();
+    float p[N], v[N], a[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) { p[j] = (float)q[j]; v[j] = (float)qd[j]; a[j] = (float)last[j]; }
+    mp_poison_if(poison, p); mp_poison_if(poison, v); mp_poison_if(poison, a);
+    const long r = i * B + b;
+    RunIO<float, N>::store(pos, r, p);
+    RunIO<float, N>::store(vel, r, v);
+    RunIO<float, N>::store(acc, r, a);
+    mp_fd_rows_arrived<T, N, HAS_FTIP>(tau_next, F_next);
+  }
+}
+
+// (outer, inner, W dwords) -> (inner, outer, W dwords): the conversion between the batch-major API arrays (B, N, n) and
+// the time-major device layout (N, B, n), either way.  A block moves a TO x TI tile of rows through LDS: it reads TI * W
+// contiguous dwords per outer index and writes TO * W contiguous dwords per inner index (768 bytes each at n = 6).
+constexpr int MP_TR_TO = 32;
+__device__ __host__ constexpr int mp_tr_ti(int W) { return W <= 8 ? 32 : 16; }  // tile extent along `inner`: <= 33 KB of LDS up to 64-byte rows
+__device__ __forceinline__ void mp_body_transpose_rows(const unsigned* __restrict__ src, unsigned* __restrict__ dst, long outer,
+                                                       long inner, int W, long o0, long i0, unsigned* __restrict__ lds, int tid,
+                                                       int nthreads) {
+  const int RUN = mp_tr_ti(W) * W, PITCH = RUN + 1, TOTAL = MP_TR_TO * RUN;
+  for (int k = tid; k < TOTAL; k += nthreads) {
+    const int o = k / RUN, r = k - o * RUN;
+    if (o0 + o < outer && i0 + r / W < inner) lds[o * PITCH + r] = src[((o0 + o) * inner + i0) * W + r];
+  }
+  __syncthreads();
+  const int ORUN = MP_TR_TO * W;
+  for (int k = tid; k < TOTAL; k += nthreads) {
+    const int i = k / ORUN, rr = k - i * ORUN, o = rr / W, w = rr - o * W;
+    if (i0 + i < inner && o0 + o < outer) dst[((i0 + i) * outer + o0) * W + rr] = lds[o * PITCH + i * W + w];
+  }
+}

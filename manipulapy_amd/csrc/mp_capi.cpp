@@ -34,6 +34,7 @@ struct MpSpec {  // run-time specialised kernels of one model on one device
   hipFunction_t fd_s[2] = {nullptr, nullptr}, fd_d[2] = {nullptr, nullptr};  // forward dynamics per row, float32 / float64
   hipFunction_t id_s[2] = {nullptr, nullptr};                                  // inverse dynamics, float32, one row per lane
   hipFunction_t traj_id_s[2] = {nullptr, nullptr};                             // generation fused into it, one timestep per lane
+  hipFunction_t fd_traj_tm[2] = {nullptr, nullptr};                            // the roll-out on the time-major device layout
 };
 struct mp_ctx {
   int device = -1;
@@ -506,23 +507,25 @@ static int fdyn_impl(const char* fn, mp_ctx* ctx, const mp_model* model, const T
 
 // specialised forward-dynamics roll-out (float32 only): -1 = none available, otherwise the launch's return code
 int launch_fd_spec(mp_ctx* ctx, const mp_model* model, const MpCall<float>& c, const float* th0, const float* dth0,
-                    const float* taumat, const float* Fm, long B, long Nt, float h, int intRes, float* pos, float* vel, float* acc) {
+                    const float* taumat, const float* Fm, long B, long Nt, float h, int intRes, float* pos, float* vel, float* acc,
+                    bool time_major) {
   const MpSpec* sp = find_spec(ctx, model);
   if (!sp) return -1;
   MpCall<float> cc = c;
   void* args[] = {&cc, &th0, &dth0, &taumat, &Fm, &B, &Nt, &h, &intRes, &pos, &vel, &acc};
+  if (time_major) return launch_spec(ctx, sp->fd_traj_tm[Fm ? 1 : 0], B, args, 64);
   if (mpk_fd_packed()) return launch_spec(ctx, sp->fd_traj_pk[Fm ? 1 : 0], (B + 1) / 2, args, 64);  // two trajectories per lane
   return launch_spec(ctx, sp->fd_traj[Fm ? 1 : 0], B, args, 64);  // one wave per block (per-wave LDS tile)
 }
 int launch_fd_spec(mp_ctx*, const mp_model*, const MpCall<double>&, const double*, const double*, const double*, const double*,
-                   long, long, double, int, float*, float*, float*) {
+                   long, long, double, int, float*, float*, float*, bool) {
   return -1;
 }
 
 template <typename T>
 static int fdtraj_impl(const char* fn, mp_ctx* ctx, const mp_model* model, const T* d_theta0, const T* d_dtheta0,
                        const T* d_taumat, const T* d_Ftipmat, int64_t B, int64_t N, const double* g, double dt, int intRes,
-                       float* d_pos, float* d_vel, float* d_acc) {
+                       float* d_pos, float* d_vel, float* d_acc, bool time_major = false) {
   REQUIRE(ctx && model, "%s: null context or model", fn);
   CTX_ENTER(ctx);
   REQUIRE(B >= 0 && N >= 0, "%s: negative B or N", fn);
@@ -535,8 +538,14 @@ static int fdtraj_impl(const char* fn, mp_ctx* ctx, const mp_model* model, const
   make_call<T>(model, g, nullptr, &c);
   const T h = intRes > 0 ? (T)(dt / intRes) : (T)0;
   PROFILE_SCOPE(ctx, fn);
-  const int src = launch_fd_spec(ctx, model, c, d_theta0, d_dtheta0, d_taumat, d_Ftipmat, (long)B, (long)N, h, intRes, d_pos, d_vel, d_acc);
+  const int src = launch_fd_spec(ctx, model, c, d_theta0, d_dtheta0, d_taumat, d_Ftipmat, (long)B, (long)N, h, intRes, d_pos, d_vel, d_acc,
+                                 time_major);
   if (src >= 0) return src;  // a specialised kernel exists for this model: launched (0) or failed (error code)
+  if (time_major) {
+    HIP_TRY(mpk_fd_traj_tm<T>(ctx->compute, pick<T>(model), c, d_theta0, d_dtheta0, d_taumat, d_Ftipmat, (long)B, (long)N, h, intRes,
+                              d_pos, d_vel, d_acc));
+    return MP_OK;
+  }
   HIP_TRY(mpk_fd_traj<T>(ctx->compute, pick<T>(model), c, d_theta0, d_dtheta0, d_taumat, d_Ftipmat, (long)B, (long)N, h, intRes,
                          d_pos, d_vel, d_acc));
   return MP_OK;
@@ -1017,14 +1026,15 @@ int mp_model_specialize(mp_ctx* ctx, const mp_model* model) {
   if (mp_jit_compile(model->f, model->d, &code, nullptr, &err)) return set_err(MP_ERR_UNSUPPORTED, "mp_model_specialize: %s", err.c_str());
   MpSpec sp;
   HIP_TRY(hipModuleLoadData(&sp.mod, code.data()));
-  const char* names[10][2] = {{"mp_spec_id_pk_f0", "mp_spec_id_pk_f1"}, {"mp_spec_traj_id_pk_f0", "mp_spec_traj_id_pk_f1"},
+  const char* names[11][2] = {{"mp_spec_id_pk_f0", "mp_spec_id_pk_f1"}, {"mp_spec_traj_id_pk_f0", "mp_spec_traj_id_pk_f1"},
                              {"mp_spec_fd_traj_f0", "mp_spec_fd_traj_f1"}, {"mp_spec_id_d_f0", "mp_spec_id_d_f1"},
                              {"mp_spec_fk_jac_id_d_f0", "mp_spec_fk_jac_id_d_f1"}, {"mp_spec_fd_traj_pk_f0", "mp_spec_fd_traj_pk_f1"},
                              {"mp_spec_fd_s_f0", "mp_spec_fd_s_f1"}, {"mp_spec_fd_d_f0", "mp_spec_fd_d_f1"},
-                             {"mp_spec_id_s_f0", "mp_spec_id_s_f1"}, {"mp_spec_traj_id_s_f0", "mp_spec_traj_id_s_f1"}};
-  hipFunction_t* slots[10] = {sp.id_pk, sp.traj_id_pk, sp.fd_traj, sp.id_d, sp.fk_jac_id_d, sp.fd_traj_pk, sp.fd_s, sp.fd_d, sp.id_s,
-                              sp.traj_id_s};
-  for (int k = 0; k < 10; ++k)
+                             {"mp_spec_id_s_f0", "mp_spec_id_s_f1"}, {"mp_spec_traj_id_s_f0", "mp_spec_traj_id_s_f1"},
+                             {"mp_spec_fd_traj_tm_f0", "mp_spec_fd_traj_tm_f1"}};
+  hipFunction_t* slots[11] = {sp.id_pk, sp.traj_id_pk, sp.fd_traj, sp.id_d, sp.fk_jac_id_d, sp.fd_traj_pk, sp.fd_s, sp.fd_d, sp.id_s,
+                              sp.traj_id_s, sp.fd_traj_tm};
+  for (int k = 0; k < 11; ++k)
     for (int f = 0; f < 2; ++f) {
       hipError_t e = hipModuleGetFunction(&slots[k][f], sp.mod, names[k][f]);
       if (e != hipSuccess) { (void)hipModuleUnload(sp.mod); return hip_err(e, names[k][f]); }
@@ -1299,6 +1309,31 @@ int mp_fd_trajectory_f64(mp_ctx* ctx, const mp_model* model, const double* d_the
                          int intRes, float* d_pos, float* d_vel, float* d_acc) {
   return fdtraj_impl<double>("mp_fd_trajectory_f64", ctx, model, d_theta0, d_dtheta0, d_taumat, d_Ftipmat, B, N, g, dt, intRes,
                              d_pos, d_vel, d_acc);
+}
+int mp_fd_trajectory_tm_f32(mp_ctx* ctx, const mp_model* model, const float* d_theta0, const float* d_dtheta0,
+                            const float* d_taumat, const float* d_Ftipmat, int64_t B, int64_t N, const double* g, double dt,
+                            int intRes, float* d_pos, float* d_vel, float* d_acc) {
+  return fdtraj_impl<float>("mp_fd_trajectory_tm_f32", ctx, model, d_theta0, d_dtheta0, d_taumat, d_Ftipmat, B, N, g, dt, intRes,
+                            d_pos, d_vel, d_acc, true);
+}
+int mp_fd_trajectory_tm_f64(mp_ctx* ctx, const mp_model* model, const double* d_theta0, const double* d_dtheta0,
+                            const double* d_taumat, const double* d_Ftipmat, int64_t B, int64_t N, const double* g, double dt,
+                            int intRes, float* d_pos, float* d_vel, float* d_acc) {
+  return fdtraj_impl<double>("mp_fd_trajectory_tm_f64", ctx, model, d_theta0, d_dtheta0, d_taumat, d_Ftipmat, B, N, g, dt, intRes,
+                             d_pos, d_vel, d_acc, true);
+}
+int mp_transpose_rows(mp_ctx* ctx, const void* d_src, int64_t outer, int64_t inner, int64_t row_bytes, void* d_dst) {
+  REQUIRE(ctx, "mp_transpose_rows: null context");
+  CTX_ENTER(ctx);
+  REQUIRE(outer >= 0 && inner >= 0, "mp_transpose_rows: negative extent");
+  REQUIRE(row_bytes > 0 && row_bytes % 4 == 0 && row_bytes <= 64, "mp_transpose_rows: row_bytes %lld must be a multiple of 4 in 4..64",
+          (long long)row_bytes);
+  if (outer == 0 || inner == 0) return MP_OK;
+  REQUIRE(d_src && d_dst && d_src != d_dst, "mp_transpose_rows: null or aliased device pointer");
+  PROFILE_SCOPE(ctx, "mp_transpose_rows");
+  const int W = (int)(row_bytes / 4);
+  HIP_TRY(mpk_transpose_rows(ctx->compute, d_src, d_dst, (long)outer, (long)inner, W));
+  return MP_OK;
 }
 int mp_fd_trajectory_host_f32(mp_ctx* ctx, const mp_model* model, const float* theta0, const float* dtheta0,
                               const float* taumat, const float* Ftipmat, int64_t B, int64_t N, const double* g, double dt,

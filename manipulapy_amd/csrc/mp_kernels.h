@@ -37,6 +37,13 @@ template <typename T>
 hipError_t mpk_fd_traj(hipStream_t s, const MpModel<T>& M, const MpCall<T>& C, const T* theta0, const T* dtheta0,
                        const T* taumat, const T* Ftipmat, long B, long Nt, T h, int intRes, float* pos, float* vel, float* acc);
 
+// the same roll-out on the TIME-MAJOR device layout: taumat (Nt, B, n), Ftipmat (Nt, B, 6), pos / vel / acc (Nt, B, n)
+template <typename T>
+hipError_t mpk_fd_traj_tm(hipStream_t s, const MpModel<T>& M, const MpCall<T>& C, const T* theta0, const T* dtheta0,
+                          const T* taumat, const T* Ftipmat, long B, long Nt, T h, int intRes, float* pos, float* vel, float* acc);
+// (outer, inner, row_dwords x 4 bytes) -> (inner, outer, row_dwords x 4 bytes)
+hipError_t mpk_transpose_rows(hipStream_t s, const void* src, void* dst, long outer, long inner, int row_dwords);
+
 // Cartesian straight-line trajectories between B pose pairs (4x4 row-major float64): float32 (B,Nt,3) x3, (B,Nt,3,3)
 hipError_t mpk_cartesian_traj(hipStream_t s, const double* Xstart, const double* Xend, long B, long Nt, double Tf, int method,
                               float* pos, float* vel, float* acc, float* ori);

@@ -231,6 +231,28 @@ __global__ __launch_bounds__(kFdBlock, (sizeof(T) == 4 ? 2 : 1)) void k_fd_traj(
                                   mp_fd_first_rows<N>(blockIdx.x));
 }
 
+// the roll-out on the time-major device layout (mp_body_fd_traj_tm): no LDS, 64-thread blocks so that the 2048 waves of a
+// 131072-trajectory shard spread evenly over the 1024 SIMDs
+template <typename T, int N, bool HAS_FTIP>
+__global__ __launch_bounds__(kFdBlock, 2) void k_fd_traj_tm(const MpModel<T> M, const MpCall<T> C, const T* __restrict__ theta0,
+                                                            const T* __restrict__ dtheta0, const T* __restrict__ taumat,
+                                                            const T* __restrict__ Ftipmat, long B, long Nt, T h, int intRes,
+                                                            float* __restrict__ pos, float* __restrict__ vel, float* __restrict__ acc) {
+  const long b = (long)blockIdx.x * kFdBlock + threadIdx.x;
+  if (b >= B) return;
+  mp_body_fd_traj_tm<T, N, HAS_FTIP>(M, C, theta0, dtheta0, taumat, Ftipmat, b, B, Nt, h, intRes, pos, vel, acc);
+}
+
+// (outer, inner, W dwords) -> (inner, outer, W dwords), see mp_body_transpose_rows
+__global__ __launch_bounds__(kBlock) void k_transpose_rows(const unsigned* __restrict__ src, unsigned* __restrict__ dst, long outer,
+                                                           long inner, int W) {
+  extern __shared__ unsigned tr_lds[];
+  const int TI = mp_tr_ti(W);
+  const unsigned gx = (unsigned)((inner + TI - 1) / TI);  // tiles along `inner`; the grid is one-dimensional
+  const unsigned ty = blockIdx.x / gx, tx = blockIdx.x - ty * gx;
+  mp_body_transpose_rows(src, dst, outer, inner, W, (long)ty * MP_TR_TO, (long)tx * TI, tr_lds, (int)threadIdx.x, kBlock);
+}
+
 // float32, two trajectories per lane (packed math); the tile is twice as wide, so DOF 8 with wrenches is 60 KB
 template <int N, bool HAS_FTIP>
 __global__ __launch_bounds__(kFdBlock) void k_fd_traj_pk(const MpModel<float> M, const MpCall<float> C,
@@ -584,6 +606,34 @@ template hipError_t mpk_fd_traj<float>(hipStream_t, const MpModel<float>&, const
 template hipError_t mpk_fd_traj<double>(hipStream_t, const MpModel<double>&, const MpCall<double>&, const double*,
                                         const double*, const double*, const double*, long, long, double, int, float*, float*,
                                         float*);
+
+template <typename T>
+hipError_t mpk_fd_traj_tm(hipStream_t s, const MpModel<T>& M, const MpCall<T>& C, const T* theta0, const T* dtheta0,
+                          const T* taumat, const T* Ftipmat, long B, long Nt, T h, int intRes, float* pos, float* vel, float* acc) {
+  if (B <= 0 || Nt <= 0) return hipSuccess;
+  const dim3 grid((unsigned)((B + kFdBlock - 1) / kFdBlock));
+  MP_DISPATCH_N(M.n, {
+    if (Ftipmat) hipLaunchKernelGGL((k_fd_traj_tm<T, N, true>), grid, dim3(kFdBlock), 0, s, M, C, theta0, dtheta0, taumat, Ftipmat, B, Nt, h, intRes, pos, vel, acc);
+    else hipLaunchKernelGGL((k_fd_traj_tm<T, N, false>), grid, dim3(kFdBlock), 0, s, M, C, theta0, dtheta0, taumat, Ftipmat, B, Nt, h, intRes, pos, vel, acc);
+  })
+  return hipGetLastError();
+}
+template hipError_t mpk_fd_traj_tm<float>(hipStream_t, const MpModel<float>&, const MpCall<float>&, const float*, const float*,
+                                          const float*, const float*, long, long, float, int, float*, float*, float*);
+template hipError_t mpk_fd_traj_tm<double>(hipStream_t, const MpModel<double>&, const MpCall<double>&, const double*,
+                                           const double*, const double*, const double*, long, long, double, int, float*, float*,
+                                           float*);
+
+hipError_t mpk_transpose_rows(hipStream_t s, const void* src, void* dst, long outer, long inner, int row_dwords) {
+  if (outer <= 0 || inner <= 0 || row_dwords <= 0) return hipSuccess;
+  const int TI = mp_tr_ti(row_dwords);
+  const long gx = (inner + TI - 1) / TI, gy = (outer + MP_TR_TO - 1) / MP_TR_TO;
+  if (gx * gy > 0x7fffffffL) return hipErrorInvalidValue;
+  const size_t lds = (size_t)MP_TR_TO * (TI * row_dwords + 1) * sizeof(unsigned);
+  hipLaunchKernelGGL(k_transpose_rows, dim3((unsigned)(gx * gy)), dim3(kBlock), lds, s, (const unsigned*)src, (unsigned*)dst, outer,
+                     inner, row_dwords);
+  return hipGetLastError();
+}
 
 hipError_t mpk_cartesian_traj(hipStream_t s, const double* Xstart, const double* Xend, long B, long Nt, double Tf, int method,
                               float* pos, float* vel, float* acc, float* ori) {

@@ -1364,6 +1364,20 @@ def _c5_workload(tab, B, Nt, seed, dt_scale=1.0):
 
 G0_ = np.array([0.0, 0.0, -9.81])
 
+ROLLOUT_LAYOUTS = (("batch_major", None), ("time_major", None), ("batch_major", "time_major"))
+
+
+def _rollout(ctx, model, th0, dth0, tm, Fm, dt, intRes, dtype, layout="batch_major", device_layout=None):
+    """fd_trajectory_host on (B,N,*) arrays whatever the layout under test: layout="time_major" hands the library (N,B,*)
+    host arrays (the time-major kernel, no conversion) and turns the (N,B,n) results back; device_layout="time_major" keeps
+    the (B,N,*) host arrays and lets the library convert on the device (mp_transpose_rows) around the time-major kernel."""
+    if layout == "batch_major":
+        return ctx.fd_trajectory_host(model, th0, dth0, tm, G0_, Fm, dt, intRes, dtype=dtype, device_layout=device_layout)
+    t = lambda a: None if a is None else np.ascontiguousarray(np.swapaxes(a, 0, 1))
+    got = ctx.fd_trajectory_host(model, th0, dth0, t(tm), G0_, t(Fm), dt, intRes, dtype=dtype, layout="time_major",
+                                 device_layout=device_layout)
+    return tuple(np.ascontiguousarray(np.swapaxes(g, 0, 1)) for g in got)
+
 
 def _one_step_defect(tab, P, V, A, tm, Fm, dt, lim):
     """Teacher-forced check of every step of every trajectory: the oracle advances ONE step from the kernel's own
@@ -1410,8 +1424,9 @@ def test_c5_rollout_full_horizon_against_reference_dump_and_oracle(tables):
             x64 = [a.astype(np.float64) for a in x]
             want = c_oracle.fd_trajectory(tab, *x64[:3], G0_, x64[3], 0.01, 1, joint_limits=lim)[:3]
             assert all(np.isfinite(w).all() for w in want)
-            for model, tag in ((gen, "generic"), (spec, "specialised")):
-                got = ctx.fd_trajectory_host(model, x[0], x[1], x[2], G0_, x[3], 0.01, 1, dtype=dtype)
+            for model, tag, (layout, dev_layout) in ((m_, t_, l_) for (m_, t_) in ((gen, "generic"), (spec, "specialised")) for l_ in ROLLOUT_LAYOUTS):
+                tag = tag + "/" + layout + ("" if dev_layout is None else ">" + dev_layout)
+                got = _rollout(ctx, model, x[0], x[1], x[2], x[3], 0.01, 1, dtype, layout, dev_layout)
                 for k, name in enumerate(("positions", "velocities", "accelerations")):
                     assert got[k].dtype == np.float32 and got[k].shape == (B, Nt, 6) and np.isfinite(got[k]).all()
                     scale = float(np.abs(want[k]).max())
@@ -1436,9 +1451,10 @@ def test_c5_rollout_full_horizon_against_reference_dump_and_oracle(tables):
         x = [a.astype(np.float32) for a in (th0, dth0, tm, Fm)]
         x64 = [a.astype(np.float64) for a in x]
         want = c_oracle.fd_trajectory(tab, *x64[:3], G0_, x64[3], 0.001, 2, joint_limits=lim)[:3]
-        got = ctx.fd_trajectory_host(spec, *x[:3], G0_, x[3], 0.001, 2, dtype=np.float32)
-        for k in range(3):
-            assert np.abs(got[k] - want[k]).max() <= 1e-5 * np.abs(want[k]).max()
+        for layout, dev_layout in ROLLOUT_LAYOUTS:
+            got = _rollout(ctx, spec, *x[:3], x[3], 0.001, 2, np.float32, layout, dev_layout)
+            for k in range(3):
+                assert np.abs(got[k] - want[k]).max() <= 1e-5 * np.abs(want[k]).max()
     finally:
         ctx.destroy()
 
@@ -1470,13 +1486,14 @@ def test_rollout_every_lane_every_tile_against_the_oracle(robot, tables):
                                               joint_limits=tab.joint_limits)[:3]
                 assert all(np.isfinite(w).all() for w in want)
                 for model in (spec, gen):
-                    got = ctx.fd_trajectory_host(model, x[0], x[1], x[2], G0_, x[3] if wrench else None, 0.01, 1, dtype=np.float32)
-                    for k in range(3):
-                        assert got[k].shape == (B, Nt, n)
-                        scale = float(np.abs(want[k]).max())
-                        err = np.abs(got[k].astype(np.float64) - want[k])
-                        bad = np.argwhere(err > 1e-4 * scale)
-                        assert bad.size == 0, (robot, B, Nt, wrench, k, bad[:5].tolist(), float(err.max() / scale))
+                    for layout, dev_layout in ROLLOUT_LAYOUTS:
+                        got = _rollout(ctx, model, x[0], x[1], x[2], x[3] if wrench else None, 0.01, 1, np.float32, layout, dev_layout)
+                        for k in range(3):
+                            assert got[k].shape == (B, Nt, n)
+                            scale = float(np.abs(want[k]).max())
+                            err = np.abs(got[k].astype(np.float64) - want[k])
+                            bad = np.argwhere(err > 1e-4 * scale)
+                            assert bad.size == 0, (robot, B, Nt, wrench, layout, dev_layout, k, bad[:5].tolist(), float(err.max() / scale))
     finally:
         ctx.destroy()
 
@@ -1581,15 +1598,16 @@ def test_nonfinite_rows_contract(tables):
                 tm[1:] = np.nan_to_num(tm[1:], nan=0.01)      # only trajectory 0 keeps the NaN of the fixture (torque row 5)
                 Fm[65, 7, 4] = np.inf                          # wrench row 7 of trajectory 65
                 dth0[69, 0] = np.nan                           # initial state of trajectory 69
-                got = ctx.fd_trajectory_host(m, th0, dth0, tm, G0_, Fm, 0.01, 1, dtype=dtype)
-                for k, name in enumerate(("positions", "velocities", "accelerations")):
-                    np.testing.assert_array_equal(np.isfinite(got[k][0]), np.isfinite(z["fd_" + name]))
-                    np.testing.assert_allclose(got[k][0, :5], z["fd_" + name][:5], rtol=1e-4, atol=1e-4 * np.abs(z["fd_" + name][:5]).max())
-                    assert np.isfinite(got[k][65, :7]).all() and np.isnan(got[k][65, 7:]).all()
-                    assert np.isfinite(got[k][1:65]).all() and np.isfinite(got[k][66:69]).all()
-                    assert np.isnan(got[k][69, 1:]).all()   # row 0 is the initial state as given (acceleration 0), as in the reference
-                np.testing.assert_array_equal(got[0][69, 0], th0[69].astype(dtype).astype(np.float32))
-                assert np.isnan(got[1][69, 0, 0]) and np.isfinite(got[1][69, 0, 1:]).all() and (got[2][69, 0] == 0).all()
+                for layout in ("batch_major", "time_major"):
+                    got = _rollout(ctx, m, th0.astype(dtype), dth0.astype(dtype), tm.astype(dtype), Fm.astype(dtype), 0.01, 1, dtype, layout)
+                    for k, name in enumerate(("positions", "velocities", "accelerations")):
+                        np.testing.assert_array_equal(np.isfinite(got[k][0]), np.isfinite(z["fd_" + name]))
+                        np.testing.assert_allclose(got[k][0, :5], z["fd_" + name][:5], rtol=1e-4, atol=1e-4 * np.abs(z["fd_" + name][:5]).max())
+                        assert np.isfinite(got[k][65, :7]).all() and np.isnan(got[k][65, 7:]).all()
+                        assert np.isfinite(got[k][1:65]).all() and np.isfinite(got[k][66:69]).all()
+                        assert np.isnan(got[k][69, 1:]).all()   # row 0 is the initial state as given (acceleration 0), as in the reference
+                    np.testing.assert_array_equal(got[0][69, 0], th0[69].astype(dtype).astype(np.float32))
+                    assert np.isnan(got[1][69, 0, 0]) and np.isfinite(got[1][69, 0, 1:]).all() and (got[2][69, 0] == 0).all()
     finally:
         ctx.destroy()
 
@@ -1672,3 +1690,45 @@ def test_urdf_to_kernel_for_the_reference_robot_database(monkeypatch):
             np.testing.assert_allclose(proc.dynamics.inverse_dynamics(th, dth, ddth, g, F), want, rtol=1e-6, atol=1e-7, err_msg=name)
             done += 1
     assert done >= 30
+
+
+def test_transpose_rows_and_time_major_edge_cases(tables):
+    """mp_transpose_rows: (outer, inner, row) -> (inner, outer, row) for every row size the roll-out uses (n = 1..8 float32 /
+    float64, the 6-value wrench rows), ragged tiles and single rows / columns, bit for bit against NumPy.  And the
+    time-major roll-out on its edge shapes: one trajectory, one step (row 0 only), two steps, B not a multiple of 64,
+    float64 - against the batch-major kernel's rows, which the oracle tests pin."""
+    from manipulapy_amd import _hip
+
+    ctx = _hip.HipContext(0)
+    try:
+        rng = np.random.default_rng(11)
+        for outer, inner, row_bytes in ((1, 1, 4), (33, 65, 24), (64, 100, 24), (130, 7, 28), (5, 257, 32), (100, 64, 48), (31, 33, 56), (40, 50, 64), (1, 300, 24), (300, 1, 24)):
+            a = rng.integers(0, 2**32, (outer, inner, row_bytes // 4), dtype=np.uint32)
+            d_a = ctx.to_device(a)
+            d_b = ctx.alloc(a.nbytes)
+            ctx.transpose_rows(d_a, outer, inner, row_bytes, d_b)
+            got = d_b.download((inner, outer, row_bytes // 4), np.uint32)
+            np.testing.assert_array_equal(got, np.swapaxes(a, 0, 1))
+            d_a.free(); d_b.free()
+        with pytest.raises(_hip.HipError):
+            ctx.transpose_rows(ctx.alloc(64), 2, 2, 6, ctx.alloc(64))
+        tab = tables["xarm6"]
+        spec = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee, tab.joint_limits)
+        gen = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee, tab.joint_limits)
+        ctx.specialize(spec)
+        for B, Nt in ((1, 1), (1, 2), (3, 1), (65, 2), (64, 3), (200, 5), (1, 30)):
+            th0, dth0, tm, Fm = _c5_workload(tab, B, Nt, 31 * B + Nt)
+            for dtype in (np.float32, np.float64):
+                for model in (spec, gen):
+                    for wrench in (True, False):
+                        F = Fm if wrench else None
+                        a = _rollout(ctx, model, th0, dth0, tm, F, 0.01, 1, dtype)
+                        b = _rollout(ctx, model, th0, dth0, tm, F, 0.01, 1, dtype, "time_major")
+                        for k in range(3):
+                            assert b[k].shape == (B, Nt, 6)
+                            np.testing.assert_allclose(b[k], a[k], rtol=0, atol=2e-6 * max(1.0, float(np.abs(a[k]).max())))
+        # empty batch / empty horizon
+        z = ctx.fd_trajectory_host(spec, np.zeros((0, 6)), np.zeros((0, 6)), np.zeros((4, 0, 6)), G0_, None, 0.01, 1, layout="time_major")
+        assert z[0].shape == (4, 0, 6)
+    finally:
+        ctx.destroy()
