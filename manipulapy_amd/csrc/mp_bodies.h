@@ -1560,47 +1560,94 @@ __device__ __forceinline__ void mp_fd_rows_arrived(T (&tau)[N], T (&F)[6]) {
   }
 }
 
+// MP_TM_PRIO (default 1; A/B switch through MANIPULAPY_HIP_JIT_DEFINES): the favoured wave of a SIMD alternates step by step
+// (s_setprio from step index ^ wave slot) - the arbiter serves the older wave first, which then runs ahead and leaves its
+// partner alone at the end (c5: 0.391 against 0.398 ms).  Measured and not kept (profiles/r03_c5_tm_experiments.txt):
+// requesting the rows two steps ahead (three register sets, time loop unrolled by three): 0.391 against 0.389 ms;
+// non-temporal output stores: 0.396 against 0.398 ms.
+#if !defined(MP_TM_PRIO)
+#define MP_TM_PRIO 1
+#endif
+
+// One row of a time-major array for this lane: `ubase` = the array, `urow` = wave-uniform element index of the wave's first
+// row, `off` = this lane's element offset inside the wave's span (lane * COUNT: constant over the steps).  Written as
+// (uniform 64-bit base) + (32-bit per-lane offset) so that the access takes the scalar-base form (global_load ... v_off,
+// s[base:base+1]) and a step costs two scalar instructions per array instead of a per-lane 64-bit multiply-add.
+template <typename T, int COUNT>
+struct RowIO {
+  using IO = RunIO<T, COUNT>;
+  using V = typename IO::V;
+  static constexpr int K = IO::K;
+  static __device__ __forceinline__ void load(const T* __restrict__ ubase, long urow, unsigned off, T (&v)[COUNT]) {
+    const char* p = reinterpret_cast<const char*>(ubase + urow);
+#pragma unroll
+    for (int k = 0; k < COUNT / K; ++k) {
+      union { V vec; T e[K]; } u;
+      u.vec = *reinterpret_cast<const V*>(p + (size_t)(off * (unsigned)sizeof(T) + (unsigned)(k * sizeof(V))));
+#pragma unroll
+      for (int j = 0; j < K; ++j) v[k * K + j] = u.e[j];
+    }
+  }
+  static __device__ __forceinline__ void store(T* __restrict__ ubase, long urow, unsigned off, const T (&v)[COUNT]) {
+    char* p = reinterpret_cast<char*>(ubase + urow);
+#pragma unroll
+    for (int k = 0; k < COUNT / K; ++k) {
+      union { V vec; T e[K]; } u;
+#pragma unroll
+      for (int j = 0; j < K; ++j) u.e[j] = v[k * K + j];
+      *reinterpret_cast<V*>(p + (size_t)(off * (unsigned)sizeof(T) + (unsigned)(k * sizeof(V)))) = u.vec;
+    }
+  }
+};
+
+template <typename T, int N>
+struct MpTmRows {  // the input rows of one step
+  T tau[N], F[6];
+};
+
+// `b0` = the wave's first trajectory (wave-uniform), `lane` = this lane's index in the wave; the caller has already sent
+// lanes with b0 + lane >= B home.
 template <typename T, int N, bool HAS_FTIP, typename MT>
 __device__ __forceinline__ void mp_body_fd_traj_tm(const MT& M, const MpCall<T>& C, const T* __restrict__ theta0,
                                                    const T* __restrict__ dtheta0, const T* __restrict__ taumat,
-                                                   const T* __restrict__ Ftipmat, long b, long B, long Nt, T h, int intRes,
-                                                   float* __restrict__ pos, float* __restrict__ vel, float* __restrict__ acc) {
+                                                   const T* __restrict__ Ftipmat, long b0, int lane, long B, long Nt, T h,
+                                                   int intRes, float* __restrict__ pos, float* __restrict__ vel,
+                                                   float* __restrict__ acc) {
+  using Rows = MpTmRows<T, N>;
+  const unsigned offN = (unsigned)lane * N, off6 = (unsigned)lane * 6;
   T q[N], qd[N];
-  RunIO<T, N>::load(theta0, b, q);
-  RunIO<T, N>::load(dtheta0, b, qd);
+  RowIO<T, N>::load(theta0, b0 * N, offN, q);
+  RowIO<T, N>::load(dtheta0, b0 * N, offN, qd);
   MpBad<T> bad;
   bad.add(q); bad.add(qd);
-  T tau_next[N], F_next[6];
-  {  // the rows of step 1 (a one-row history clamps to row 0, which is never consumed)
-    const long r1 = (Nt > 1 ? B : 0) + b;
-    RunIO<T, N>::load(taumat, r1, tau_next);
-    if (HAS_FTIP) RunIO<T, 6>::load(Ftipmat, r1, F_next);
-    mp_fd_rows_arrived<T, N, HAS_FTIP>(tau_next, F_next);
-  }
-  {  // row 0 = the initial state as given, zero acceleration
-    float p[N], v[N], a[N];
-#pragma unroll
-    for (int j = 0; j < N; ++j) { p[j] = (float)q[j]; v[j] = (float)qd[j]; a[j] = 0.0f; }
-    RunIO<float, N>::store(pos, b, p);
-    RunIO<float, N>::store(vel, b, v);
-    RunIO<float, N>::store(acc, b, a);
-  }
-  for (long i = 1; i < Nt; ++i) {
+  auto request = [&](Rows& R, long step) __attribute__((always_inline)) {  // rows of `step` (clamped: the tail re-reads the last row)
+    const long r = (step < Nt ? step : Nt - 1) * B + b0;
+    RowIO<T, N>::load(taumat, r * N, offN, R.tau);
+    if (HAS_FTIP) RowIO<T, 6>::load(Ftipmat, r * 6, off6, R.F);
+  };
+  auto arrived = [&](Rows& R) __attribute__((always_inline)) { mp_fd_rows_arrived<T, N, HAS_FTIP>(R.tau, R.F); };
+#if MP_TM_PRIO
+  const unsigned wave_slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1u;  // HW_ID.WAVE_ID bit 0
+#endif
+  // one integration step from the rows in R; its output rows are stored and never waited for
+  auto step = [&](long i, const Rows& R) __attribute__((always_inline)) {
+#if MP_TM_PRIO
+    if (((unsigned)i ^ wave_slot) & 1u) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+#endif
     T tau[N], tn[3] = {T(0), T(0), T(0)}, tf[3] = {T(0), T(0), T(0)}, last[N];
 #pragma unroll
-    for (int j = 0; j < N; ++j) { tau[j] = tau_next[j]; last[j] = T(0); }
+    for (int j = 0; j < N; ++j) {
+      tau[j] = R.tau[j];
+      last[j] = T(0);
+    }
     bad.add(tau);
     if (HAS_FTIP) {
       T F[6];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) F[k] = F_next[k];
+      for (int k = 0; k < 6; ++k) F[k] = R.F[k];
       bad.add(F);
       mp_wrench_to_frame1(M, F, tn, tf);
-    }
-    {  // request the next step's rows now; the last step re-reads its own (no branch around memory instructions)
-      const long rn = (i + 1 < Nt ? i + 1 : i) * B + b;
-      RunIO<T, N>::load(taumat, rn, tau_next);
-      if (HAS_FTIP) RunIO<T, 6>::load(Ftipmat, rn, F_next);
     }
     for (int k = 0; k < intRes; ++k) {
       mp_forward_dynamics_auto<T, N, HAS_FTIP>(M, C.a0, tn, tf, q, qd, tau, last);
@@ -1611,16 +1658,37 @@ __device__ __forceinline__ void mp_body_fd_traj_tm(const MT& M, const MpCall<T>&
       }
     }
     bad.add(qd);
-    const bool poison = bad.any();
     float p[N], v[N], a[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) { p[j] = (float)q[j]; v[j] = (float)qd[j]; a[j] = (float)last[j]; }
-    mp_poison_if(poison, p); mp_poison_if(poison, v); mp_poison_if(poison, a);
-    const long r = i * B + b;
-    RunIO<float, N>::store(pos, r, p);
-    RunIO<float, N>::store(vel, r, v);
-    RunIO<float, N>::store(acc, r, a);
-    mp_fd_rows_arrived<T, N, HAS_FTIP>(tau_next, F_next);
+    // non-finite trajectories are rare: one wave-uniform branch instead of 3 N selects per step
+    if (__builtin_amdgcn_ballot_w64(bad.any()) != 0) {
+      const bool poison = bad.any();
+      mp_poison_if(poison, p); mp_poison_if(poison, v); mp_poison_if(poison, a);
+    }
+    {
+      const long r = (i * B + b0) * N;
+      RowIO<float, N>::store(pos, r, offN, p);
+      RowIO<float, N>::store(vel, r, offN, v);
+      RowIO<float, N>::store(acc, r, offN, a);
+    }
+  };
+  Rows R0;
+  request(R0, 1);
+  {  // row 0 = the initial state as given, zero acceleration
+    float p[N], v[N], a[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) { p[j] = (float)q[j]; v[j] = (float)qd[j]; a[j] = 0.0f; }
+    RowIO<float, N>::store(pos, b0 * N, offN, p);
+    RowIO<float, N>::store(vel, b0 * N, offN, v);
+    RowIO<float, N>::store(acc, b0 * N, offN, a);
+  }
+  arrived(R0);
+  for (long i = 1; i < Nt; ++i) {  // at the loop head R0 holds the rows of step i (arrived)
+    const Rows cur = R0;
+    request(R0, i + 1);
+    step(i, cur);
+    arrived(R0);
   }
 }
 

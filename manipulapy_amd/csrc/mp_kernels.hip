@@ -238,9 +238,9 @@ __global__ __launch_bounds__(kFdBlock, 2) void k_fd_traj_tm(const MpModel<T> M, 
                                                             const T* __restrict__ dtheta0, const T* __restrict__ taumat,
                                                             const T* __restrict__ Ftipmat, long B, long Nt, T h, int intRes,
                                                             float* __restrict__ pos, float* __restrict__ vel, float* __restrict__ acc) {
-  const long b = (long)blockIdx.x * kFdBlock + threadIdx.x;
-  if (b >= B) return;
-  mp_body_fd_traj_tm<T, N, HAS_FTIP>(M, C, theta0, dtheta0, taumat, Ftipmat, b, B, Nt, h, intRes, pos, vel, acc);
+  const long b0 = (long)blockIdx.x * kFdBlock;  // one wave per block: its first trajectory is wave-uniform
+  if (b0 + threadIdx.x >= B) return;
+  mp_body_fd_traj_tm<T, N, HAS_FTIP>(M, C, theta0, dtheta0, taumat, Ftipmat, b0, (int)threadIdx.x, B, Nt, h, intRes, pos, vel, acc);
 }
 
 // (outer, inner, W dwords) -> (inner, outer, W dwords), see mp_body_transpose_rows
