@@ -4,28 +4,6 @@
 #pragma once
 
 #include "mp_core.h"
-#include "mp_pair.h"
-
-// float32 forward dynamics: the scalar recursion of mp_core.h; MP_FD_PAIR=1 selects the pair-native one of mp_pair.h (one
-// trajectory fills both halves of the packed float32 instructions).  Measured on MI355X (tools/ab_c5.sh, config c5): the
-// pair form executes 18 % fewer VALU instructions per step (1153 vs 1412) and is 1-3 % SLOWER - tools/ubench_issue2.hip
-// shows why: on gfx950 a v_pk_fma_f32 occupies the SIMD for ~4 cycles, a scalar v_fma_f32 / v_fmac / v_mul for ~2, so a
-// packed instruction buys no arithmetic throughput, and its constant pairs cost two s_mov_b32 each on top.  Kept as a
-// measured negative result (and as the host-tested second implementation of the same recursion).
-#ifndef MP_FD_PAIR
-#define MP_FD_PAIR 0
-#endif
-template <typename T, int N, bool HAS_FTIP, typename MT>
-MP_HD void mp_forward_dynamics_auto(const MT& M, const typename MpTraits<T>::S (&a0)[3], const T (&tipn)[3], const T (&tipf)[3],
-                                    const T (&q)[N], const T (&qd)[N], const T (&tau)[N], T (&qdd)[N]) {
-#if MP_HAS_PACKED && MP_FD_PAIR
-  if constexpr (sizeof(T) == 4 && sizeof(typename MpTraits<T>::S) == 4 && N >= 2) {
-    mp_p_forward_dynamics<N, HAS_FTIP>(M, a0, tipn, tipf, q, qd, tau, qdd);
-    return;
-  }
-#endif
-  mp_forward_dynamics<T, N, HAS_FTIP>(M, a0, tipn, tipf, q, qd, tau, qdd);
-}
 
 // ---- widest legal vector type for a run of COUNT elements of T whose start is COUNT*sizeof(T)-strided
 template <typename T, int BYTES> struct VecOf;
@@ -52,11 +30,7 @@ struct RunIO {
 #pragma unroll
     for (int k = 0; k < COUNT / K; ++k) {
       union { V vec; T e[K]; } u;
-#if defined(MP_NT_LOAD)
-      u.vec = __builtin_nontemporal_load(&src[k]);
-#else
       u.vec = src[k];
-#endif
 #pragma unroll
       for (int j = 0; j < K; ++j) v[k * K + j] = u.e[j];
     }
@@ -68,11 +42,7 @@ struct RunIO {
       union { V vec; T e[K]; } u;
 #pragma unroll
       for (int j = 0; j < K; ++j) u.e[j] = v[k * K + j];
-#if defined(MP_NT_STORE)
-      __builtin_nontemporal_store(u.vec, &dst[k]);
-#else
       dst[k] = u.vec;
-#endif
     }
   }
 };
@@ -131,7 +101,7 @@ __device__ __forceinline__ void mp_body_fd(const MT& M, const MpCall<T>& C, cons
   RunIO<T, N>::load(qd, r, b);
   RunIO<T, N>::load(tau, r, t);
   const T tn[3] = {C.F1n[0], C.F1n[1], C.F1n[2]}, tf[3] = {C.F1f[0], C.F1f[1], C.F1f[2]};
-  mp_forward_dynamics_auto<T, N, HAS_FTIP>(M, C.a0, tn, tf, a, b, t, out);
+  mp_forward_dynamics<T, N, HAS_FTIP>(M, C.a0, tn, tf, a, b, t, out);
   MpBad<T> bad;
   bad.add(a); bad.add(b); bad.add(t);
   mp_poison_if(bad.any(), out);
@@ -486,8 +456,9 @@ constexpr int MP_FD_KS = 4;
 // position once the step has consumed it; [N,2N) velocity; [2N,3N) acceleration; the step's wrench (6 values, if
 // any) sits in [N,N+6) and is likewise consumed before the step's velocity / acceleration are written.
 // float64 inputs take two dwords per value and get their own columns after the three output slots.
-template <typename T, int N, bool HAS_FTIP, int W = 64>
+template <typename T, int N, bool HAS_FTIP>
 struct MpFdTile {
+  static constexpr int W = 64;                     // trajectories per wave
   static constexpr int TW = (int)sizeof(T) / 4;  // dwords per input value
   static constexpr int TAU0 = (TW == 1) ? 0 : 3 * N;
   static constexpr int F0 = (TW == 1) ? N : 5 * N;
@@ -496,11 +467,8 @@ struct MpFdTile {
   // Row stride in dwords.  A row holds one value of the W trajectories of the wave; the 64-wide tile pads it by one
   // dword: the flat stores read ACROSS rows (six lanes share a trajectory column and take different rows), which at a
   // stride of 64 dwords puts all six on one LDS bank (PMC: 60 % of the LDS cycles of config c5 were bank conflicts).
-#if !defined(MP_FD_ROW_PAD)
-#define MP_FD_ROW_PAD 1
-#endif
-  static constexpr int RS = W + (W == 64 ? MP_FD_ROW_PAD : 0);
-  static constexpr int STEP = COLS * RS;           // dwords per step (W = trajectories per wave: 64, or 128 packed)
+  static constexpr int RS = W + 1;                 // (conflict cycles 36.9 M -> 14.7 M per c5 launch; with the owner-lane flush: none)
+  static constexpr int STEP = COLS * RS;           // dwords per step
   static constexpr int DWORDS = MP_FD_KS * STEP;   // per wave
 };
 typedef unsigned mp_io_u4 __attribute__((ext_vector_type(4)));
@@ -530,9 +498,8 @@ __device__ __forceinline__ void mp_fd_tile_in(const unsigned* __restrict__ g, in
   }
 }
 
-// The same in two halves, for the optional pipelined vector path (MP_FD_PREFETCH): the global loads of the NEXT tile are
-// issued into registers and waited for right before the current tile's rows are flushed, and parked in the tile once
-// those rows have left it (see "Optional order of the tile boundary" in mp_body_fd_traj).
+// The same in two halves: all the loads of a tile (both input arrays) are issued into registers before the first row is
+// parked, so a tile's inputs cost ONE memory round trip.
 template <int E, int TW>
 struct MpFdPrefetch {
   static constexpr int NV = MP_FD_KS * E * TW / 4;  // 16-byte vectors per tile and lane
@@ -543,12 +510,6 @@ __device__ __forceinline__ void mp_fd_tile_load(const unsigned* __restrict__ g, 
 #pragma unroll
   for (int k = 0; k < MpFdPrefetch<E, TW>::NV; ++k) r.v[k] = *reinterpret_cast<const mp_io_u4*>(g + 4 * k);
 }
-// make the wave wait for the loads of `r` HERE (an empty asm that consumes every register)
-template <int E, int TW>
-__device__ __forceinline__ void mp_fd_tile_arrive(MpFdPrefetch<E, TW>& r) {
-#pragma unroll
-  for (int k = 0; k < MpFdPrefetch<E, TW>::NV; ++k) asm volatile("" : "+v"(r.v[k]));
-}
 template <int E, int TW, int BASE, int STEP, int W>
 __device__ __forceinline__ void mp_fd_tile_park(const MpFdPrefetch<E, TW>& r, unsigned* __restrict__ col) {
 #pragma unroll
@@ -558,23 +519,6 @@ __device__ __forceinline__ void mp_fd_tile_park(const MpFdPrefetch<E, TW>& r, un
     col[mp_fd_in_slot<E, TW, BASE, STEP, W>(4 * k + 2)] = r.v[k].z;
     col[mp_fd_in_slot<E, TW, BASE, STEP, W>(4 * k + 3)] = r.v[k].w;
   }
-}
-
-// pieces [K0, K1) only (MP_FD_SPLIT_PARK: the first step's rows are parked as soon as they arrive, the rest after it)
-template <int E, int TW, int BASE, int STEP, int W, int K0, int K1>
-__device__ __forceinline__ void mp_fd_tile_park_range(const MpFdPrefetch<E, TW>& r, unsigned* __restrict__ col) {
-#pragma unroll
-  for (int k = K0; k < K1; ++k) {
-    col[mp_fd_in_slot<E, TW, BASE, STEP, W>(4 * k)] = r.v[k].x;
-    col[mp_fd_in_slot<E, TW, BASE, STEP, W>(4 * k + 1)] = r.v[k].y;
-    col[mp_fd_in_slot<E, TW, BASE, STEP, W>(4 * k + 2)] = r.v[k].z;
-    col[mp_fd_in_slot<E, TW, BASE, STEP, W>(4 * k + 3)] = r.v[k].w;
-  }
-}
-template <int E, int TW, int K0, int K1>
-__device__ __forceinline__ void mp_fd_tile_load_range(const unsigned* __restrict__ g, MpFdPrefetch<E, TW>& r) {
-#pragma unroll
-  for (int k = K0; k < K1; ++k) r.v[k] = *reinterpret_cast<const mp_io_u4*>(g + 4 * k);
 }
 
 // tile -> global: output slot `slot` (0 pos, 1 vel, 2 acc) of MP_FD_KS rows (or `limit` dwords when VW == 1)
@@ -615,8 +559,6 @@ struct MpFdFlat {
   __device__ __forceinline__ int t(int k) const { return (int)((unsigned)(k * 64 + lane) / (unsigned)C); }
   __device__ __forceinline__ int c(int k) const { return (k * 64 + lane) - t(k) * C; }
 };
-template <int N>
-__device__ __forceinline__ void mp_fd_flat_init(MpFdFlat<N>& F, int lane) { F.lane = lane; }
 // `lds` = the wave's tile base (lane offset NOT applied), `run0` = float index of (trajectory b0, step i0, joint 0),
 // `pitch` = floats between the runs of neighbouring trajectories (Nt * N), `nvalid` = trajectories of this wave inside the
 // batch.  An array's LDS reads are issued before its first store (every chunk's column exists: f < 64 C gives t < 64), so the
@@ -631,9 +573,7 @@ __device__ __forceinline__ void mp_fd_flat_init(MpFdFlat<N>& F, int lane) { F.la
 // stores it right before the rest of the block leaves with the next tile.  Tails are multiples of 16 bytes (the vector
 // path needs 16-byte aligned runs); with an even n and a row pitch that is a multiple of 32 bytes they are multiples of 32:
 // up to 96 bytes at BLOCK = 128 (CP = 6 pieces = the whole run at n = 6), 0 or 32 at BLOCK = 64 (CP = 2).
-#if !defined(MP_FD_BLOCK)
-#define MP_FD_BLOCK 128  // whole lines: tails up to 96 bytes per array (72 registers at n = 6); 64: whole half lines, 24 registers
-#endif
+constexpr int MP_FD_BLOCK = 128;  // whole lines: tails up to 96 bytes per array (72 registers at n = 6); whole 64-byte half lines measured 0.520 against 0.497 ms
 template <int N>
 struct MpFdCarry {
   static constexpr int BLOCK = MP_FD_BLOCK, MASK = BLOCK - 1;
@@ -644,11 +584,7 @@ struct MpFdCarry {
   // which flush a kernel is COMPILED with (one of them: with both in one kernel the register allocator spills): the
   // owner-lane flush where runs are not whole blocks by themselves, the wave-cooperative flat stores where they are (n = 8:
   // flat 0.684 ms against 0.752 - 0.779 ms owner-lane on the Panda) and for the short rows of 1 - 3 joints
-#if defined(MP_FD_NO_OWNER)
-  static constexpr bool OWNER = false;
-#else
   static constexpr bool OWNER = ENABLED && (MP_FD_KS * N * 4) % BLOCK != 0;
-#endif
   mp_io_u4 v[3][CP];
   int bytes;  // of this lane's trajectory: how much of the previous tile's run is still to be written
 };
@@ -689,14 +625,7 @@ __device__ __forceinline__ void mp_fd_tile_out_flat(float* __restrict__ pos, flo
     } else if (nvalid == 64) {
 #pragma unroll
       for (int k = 0; k < NK; ++k) {
-#if defined(MP_FD_EXP_NOSTORE)  // experiment: everything of the flush except the global stores themselves
-        asm volatile("" :: "v"(v[k]));
-        if (F.lane == 999) *reinterpret_cast<mp_io_u4*>(base + (long)F.t(k) * pitch + 4 * F.c(k)) = v[k];
-#elif defined(MP_FD_NT_STORES)  // experiment: streaming (non-temporal) stores for the output rows
-        __builtin_nontemporal_store(v[k], reinterpret_cast<mp_io_u4*>(base + (long)F.t(k) * pitch + 4 * F.c(k)));
-#else
         *reinterpret_cast<mp_io_u4*>(base + (long)F.t(k) * pitch + 4 * F.c(k)) = v[k];
-#endif
       }
     } else {
 #pragma unroll
@@ -776,62 +705,6 @@ __device__ __forceinline__ void mp_fd_tile_out_owner(float* __restrict__ pos, fl
   K.bytes = tail;
 }
 
-// The flush of the pipelined path: the same flat chunk order, stored with raw BUFFER stores through one descriptor per
-// array that covers exactly the wave's runs of this tile (base 64 bytes before trajectory b0's run, so that the tails held
-// back by the previous tile are inside it).  A lane that must not store (trajectory past the batch, piece held back, no
-// tail pending) gets an offset outside the descriptor and the hardware drops its write: no EXEC masks, no branches, and
-// the number of stores in flight is the same on every path - which is what lets the compiler wait for the prefetched
-// input rows with vmcnt(stores issued since) instead of draining every store (see the pipelined path in mp_body_fd_traj).
-__device__ __forceinline__ float* mp_uniform_ptr(float* p) {
-  const unsigned long long u = (unsigned long long)p;
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
-  return (float*)(((unsigned long long)hi << 32) | lo);
-}
-template <int N, int STEP, int RS>
-__device__ __forceinline__ void mp_fd_tile_out_buf(float* __restrict__ pos, float* __restrict__ vel, float* __restrict__ acc,
-                                                   long run0, int pitch, int nvalid, int lane, bool in_batch,
-                                                   const unsigned* __restrict__ lds, bool hold, int pm, int e_end,
-                                                   const MpFdCarry<N>& K) {
-  constexpr int NK = MpFdFlat<N>::NK, CP = MpFdCarry<N>::CP;
-  constexpr int RUN_BYTES = MP_FD_KS * N * 4;
-  constexpr int kNowhere = 0x7ffffff0;  // past any descriptor: the write is dropped
-  float* const arr[3] = {pos, vel, acc};
-  const int bytes = 64 + ((nvalid - 1) * pitch + MP_FD_KS * N) * 4;
-  MpFdFlat<N> F;
-  F.lane = lane;
-#pragma unroll
-  for (int slot = 0; slot < 3; ++slot) {
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(mp_uniform_ptr(arr[slot] + run0 - 16), 0, bytes, 0x00020000);
-    if constexpr (MpFdCarry<N>::ENABLED) {
-      // what the previous tile held back of this lane's own trajectory (ends right before its run of this tile)
-#pragma unroll
-      for (int q = 0; q < CP; ++q) {
-        const bool go = in_batch && (CP - q) * 16 <= K.bytes;
-        __builtin_amdgcn_raw_buffer_store_b128(K.v[slot][q], rs, go ? 64 + lane * pitch * 4 - (CP - q) * 16 : kNowhere, 0, 0);
-      }
-    }
-    mp_io_u4 v[NK];
-#pragma unroll
-    for (int k = 0; k < NK; ++k) {
-      const int t = F.t(k), c = F.c(k);
-      unsigned e[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int r = 4 * c + i, s = r / N, j = r - s * N;  // run index -> (step, joint)
-        e[i] = lds[s * STEP + (slot * N + j) * RS + t];
-      }
-      v[k].x = e[0]; v[k].y = e[1]; v[k].z = e[2]; v[k].w = e[3];
-    }
-#pragma unroll
-    for (int k = 0; k < NK; ++k) {
-      const int t = F.t(k), c = F.c(k);
-      const int tail = hold ? ((t * pm + e_end) & MpFdCarry<N>::MASK) : 0;  // bytes of trajectory t's run past its last whole block
-      const bool go = 16 * c < RUN_BYTES - tail;             // (trajectories past the batch are outside the descriptor)
-      __builtin_amdgcn_raw_buffer_store_b128(v[k], rs, go ? 64 + (t * pitch + 4 * c) * 4 : kNowhere, 0, 0);
-    }
-  }
-}
-
 template <typename T, int TW, int W>
 __device__ __forceinline__ T mp_fd_tile_get(const unsigned* __restrict__ cs, int c, int E) {
   if constexpr (TW == 1) {
@@ -842,40 +715,13 @@ __device__ __forceinline__ T mp_fd_tile_get(const unsigned* __restrict__ cs, int
   }
 }
 
-// Staggered tile phases (MP_FD_STAGGER, off: measured 10 % SLOWER).  Every wave executes the same instructions, so all
-// 2048 waves of a launch reach their tile boundary together: the memory system idles through four integration steps and
-// then takes 64 KB from every wave at once while the vector units wait (config c5: 0.305 ms of arithmetic + 0.065 ms for
-// the inputs + 0.24 ms for the outputs add up to the 0.61 ms of the whole kernel; during the boundaries the memory system
-// moves ~7 TB/s).  Letting a wave start with a SHORT first tile of MP_FD_KS - stagger rows (stagger from the bits of the
-// block index that differ between the waves sharing a CU; later tiles must still start on a 16-byte boundary of every
-// lane's run, so the stagger is a multiple of 1 step for N % 4 == 0, 2 for other even N, none for odd N) spreads the
-// boundaries over the steps - and costs 0.683 against 0.621 ms: a wave computing beside a partner that sits in its
-// boundary issues at the single-wave rate, and the bursts of pure stores followed by pure loads that the lock step
-// produces are what the HBM likes.  Kept as a measured negative result.
-template <int N>
-__device__ __forceinline__ int mp_fd_first_rows(unsigned block) {
-#if !defined(MP_FD_STAGGER)
-  (void)block;
-  return MP_FD_KS;
-#else
-  constexpr int ALIGN = (N % 4 == 0) ? 1 : (N % 2 == 0) ? 2 : MP_FD_KS;
-  // which bit of the block index separates the two waves that share a SIMD depends on the dispatcher's placement
-  // (blocks go to the 8 XCDs round-robin; inside an XCD either CU by CU or round-robin over its 32 CUs): experiment knob
-#if !defined(MP_FD_STAGGER_SHIFT)
-#define MP_FD_STAGGER_SHIFT 5
-#endif
-  const int want = (int)((block >> MP_FD_STAGGER_SHIFT) & 1u) * (MP_FD_KS / 2);
-  return MP_FD_KS - (want / ALIGN) * ALIGN;
-#endif
-}
-
 // `lds` is this wave's tile (MpFdTile<T, N, HAS_FTIP>::DWORDS dwords), `lane` the lane index inside the wave
 template <typename T, int N, bool HAS_FTIP, typename MT>
 __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C, const T* __restrict__ theta0,
                                                 const T* __restrict__ dtheta0, const T* __restrict__ taumat,
                                                 const T* __restrict__ Ftipmat, long bl, long B, long Nt, T h, int intRes,
                                                 float* __restrict__ pos, float* __restrict__ vel, float* __restrict__ acc,
-                                                unsigned* __restrict__ lds, int lane, int first_rows = MP_FD_KS) {
+                                                unsigned* __restrict__ lds, int lane) {
   using TL = MpFdTile<T, N, HAS_FTIP>;
   constexpr int TW = TL::TW, STEP = TL::STEP, RS = TL::RS;
   // EVERY lane of the wave runs this body (the flat stores are wave-cooperative): lanes past the batch integrate the
@@ -889,8 +735,6 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
   T q[N], qd[N];
   RunIO<T, N>::load(theta0, b, q);
   RunIO<T, N>::load(dtheta0, b, qd);
-  MpFdFlat<N> flat;
-  mp_fd_flat_init<N>(flat, lane);
   // Sticky non-finite verdict (running maxima of the bit patterns, mp_core.h): the initial state, every torque / wrench
   // row consumed and the integrated velocity feed it; from the first step at which it trips, the trajectory's rows are
   // NaN, as in the reference, whose state stays non-finite once it is (row 0 is the initial state as given).
@@ -900,19 +744,14 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
   const bool vec_tau = ((Nt * N * (long)sizeof(T)) & 15) == 0, vec_out = ((Nt * N * 4) & 15) == 0;
   const bool vec_f = ((Nt * 6 * (long)sizeof(T)) & 15) == 0;
   // whole-block output (MpFdCarry): the arrays start on a block boundary, tails come in the sizes the carry holds
-#if defined(MP_FD_NO_BLOCK64)  // A/B switch
-  const bool whole_blocks = false;
-#else
   const bool whole_blocks = vec_out && MpFdCarry<N>::ENABLED &&
                        (((unsigned long long)pos | (unsigned long long)vel | (unsigned long long)acc) & (unsigned long long)MpFdCarry<N>::MASK) == 0 &&
                        (N % 2 != 0 || ((Nt * N * 4) & 31) == 0) &&
                        !((MP_FD_KS * N * 4) % MpFdCarry<N>::BLOCK == 0 && ((Nt * N * 4) & MpFdCarry<N>::MASK) == 0);  // runs that are whole blocks anyway (n = 4, 8)
-#endif
   const int pitch_mod = (int)((Nt * N * 4) & MpFdCarry<N>::MASK);
   MpFdCarry<N> carry;
   carry.bytes = 0;
-#if !defined(MP_FD_NO_IN_EXACT)
-  // Line-exact input reads (n = 6, float32 inputs; A/B switch MP_FD_NO_IN_EXACT).  Time-neutral (0.499 against 0.503 ms) and
+  // Line-exact input reads (n = 6, float32 inputs).  Time-neutral (0.499 against 0.503 ms) and
   // kept for what it does to the traffic: HBM-side bytes per launch 2.21 GB -> 1.61 GB = 1.02 x the algorithmic bytes.
   // A lane's 96-byte run of a tile starts where the previous one ended, so three of four runs straddle a 128-byte line and every line is fetched by two tiles ~20 us apart (FETCH_SIZE
   // = 2.0 x the input bytes; the second fetch is an Infinity-Cache hit, not an L2 hit).  Here a lane fetches a whole line
@@ -928,7 +767,7 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
   constexpr bool EXACT_OK = false;
 #endif
   const unsigned long long in_bytes = (unsigned long long)B * (unsigned long long)Nt * 24ull;
-  const bool exact_in = EXACT_OK && first_rows == MP_FD_KS && (Nt & 3) == 0 && in_bytes < (1ull << 31) &&
+  const bool exact_in = EXACT_OK && (Nt & 3) == 0 && in_bytes < (1ull << 31) &&
                         (((unsigned long long)taumat | (HAS_FTIP ? (unsigned long long)Ftipmat : 0ull)) & 127ull) == 0;
   // (named members, literal indices: with arrays the compiler turns "select between two array elements" into a load from a
   //  selected ADDRESS and the arrays end up in scratch memory)
@@ -956,206 +795,18 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
       held_f.f = __builtin_amdgcn_raw_buffer_load_b128(ex_rf, line0 + 112, 0, 0);
     }
   }
-#endif
-  // software pipeline of the vector path: `pre_*` hold the inputs of the tile about to start (loaded one tile ahead)
-#if defined(MP_FD_PREFETCH)  // opt-in: measured neutral (tools/ab_c5.sh, tools/ab_c5_cycles.sh: the waves' s_waitcnt share drops
-  // from 26 % to 18 % of their cycles and their issue stalls rise from 21 % to 31 %; kernel cycles 1.43 M vs 1.40 M)
-  constexpr bool PIPE = (MP_FD_KS * N * TW) % 4 == 0 && (MP_FD_KS * 6 * TW) % 4 == 0;
-#else
-  constexpr bool PIPE = false;
-#endif
-  MpFdPrefetch<N, TW> pre_tau;
-  MpFdPrefetch<6, TW> pre_f;
-  bool have_tau = false, have_f = false;
-#if defined(MP_FD_STAGGER_HW)
-  // Experiment: phases by HARDWARE placement.  The two waves that share a SIMD stay in phase (a lone wave issues at half
-  // rate), the phase comes from where the wave landed: MP_FD_STAGGER_HW phases, field MP_FD_STAGGER_HW_FIELD of HW_ID
-  // (0: CU_ID bits [11:8], 1: SIMD_ID [5:4], 2: SE_ID [15:13]), MP_FD_STAGGER_HW_SLEEP x 64 x 16 cycles per phase step.
-  {
-#if !defined(MP_FD_STAGGER_HW_FIELD)
-#define MP_FD_STAGGER_HW_FIELD 0
-#endif
-#if !defined(MP_FD_STAGGER_HW_SLEEP)
-#define MP_FD_STAGGER_HW_SLEEP 4
-#endif
-    constexpr int kReg = MP_FD_STAGGER_HW_FIELD == 0 ? ((3 << 11) | (8 << 6) | 4)
-                         : MP_FD_STAGGER_HW_FIELD == 1 ? ((1 << 11) | (4 << 6) | 4) : ((2 << 11) | (13 << 6) | 4);
-    const unsigned where = __builtin_amdgcn_s_getreg(kReg);
-    const int ph = (int)(where % (unsigned)(MP_FD_STAGGER_HW));
-    for (int k = 0; k < ph * MP_FD_STAGGER_HW_SLEEP; ++k) __builtin_amdgcn_s_sleep(16);
-  }
-#endif
-#if defined(MP_FD_STAGGER_SLEEP)  // experiment: the phase shift as an initial delay instead of a short first tile
-  if (first_rows != MP_FD_KS) {
-    for (int k = 0; k < MP_FD_STAGGER_SLEEP; ++k) __builtin_amdgcn_s_sleep(127);  // 127 x 64 cycles each
-    first_rows = MP_FD_KS;
-  }
-#endif
-#if defined(MP_FD_EXP_TIMING)  // experiment: per-wave cycle totals of the tile phases, left in acc row 1 of the wave's first trajectory
-  unsigned long long tm_in = 0, tm_cmp = 0, tm_out = 0, tm_mark = __builtin_readcyclecounter();
-  const unsigned long long tm_start = tm_mark;
-#define MP_FD_TICK(acc_) do { const unsigned long long now_ = __builtin_readcyclecounter(); acc_ += now_ - tm_mark; tm_mark = now_; } while (0)
-#else
-#define MP_FD_TICK(acc_) do { } while (0)
-#endif
-#if !defined(MP_FD_PRIO)
-#define MP_FD_PRIO 3
-#endif
-#if MP_FD_PRIO
   // Issue priority.  The two waves of a SIMD are not served alike: the arbiter takes the older one (wave slot 0) first, which
-  // then runs at the speed of a lone wave and finishes 25 % early, leaving its partner to integrate the rest alone
-  // (tools/c5_phase_times.py).  MP_FD_PRIO & 1: the favoured wave alternates tile by tile (s_setprio from tile index ^ wave
-  // slot); & 2: tile boundaries (loads, flat stores) run at the highest priority, so their memory requests leave early.
+  // then runs at the speed of a lone wave and finishes 25 % early, leaving its partner to integrate the rest alone.  The
+  // favoured wave alternates tile by tile (s_setprio from tile index ^ wave slot) and the tile boundaries (loads, stores)
+  // run at the highest priority, so their memory requests leave early: c5 0.554 -> 0.518 ms.
   const unsigned wave_slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1u;
   unsigned tile_no = 0;
-#endif
-  long i0_start = 0;
-#if defined(MP_FD_PIPE)
-  // ---- The pipelined path (opt-in: measured 0.560 against 0.520 ms, see below): every whole tile when all rows are
-  // 16-byte aligned.  A tile boundary is "flush this
-  // tile's rows, fetch the next tile's torques / wrenches, wait for them": vmcnt counts loads and stores in issue order, so
-  // that wait drained the 18 stores first - the waves sat through the memory system's slowest moment at every boundary
-  // (tools/c5_phase_times.py: 4.4 - 6 k of the ~36 k cycles of a tile).  Here the next tile's rows are REQUESTED BEFORE the
-  // flush (into registers: 12 x 16 bytes per lane at n = 6) and parked in the tile after it; the stores are younger than
-  // the loads, so the wait before parking is vmcnt(number of stores) and the stores are never waited for.  For the compiler
-  // to know that number the boundary must not branch around memory instructions: the flush stores through buffer
-  // descriptors (mp_fd_tile_out_buf), the first tile is peeled (no "first time round" merge at the loop head).  The ISA
-  // does what was intended (s_waitcnt vmcnt(29) .. vmcnt(21) before the parks, 242 VGPRs, no scratch) and the kernel is 8 %
-  // SLOWER: the boundary is not waiting on a latency that could be hidden, the memory system is busy for that long with
-  // this access pattern whatever the order (tools/ubench_c5io.hip: the tile I/O alone, no arithmetic, takes 0.47 ms).
-  {
-    constexpr bool PIPE_OK = (MP_FD_KS * N * TW) % 4 == 0 && (MP_FD_KS * 6 * TW) % 4 == 0;
-    const bool piped = PIPE_OK && vec_tau && vec_out && (!HAS_FTIP || vec_f) && first_rows == MP_FD_KS && Nt >= MP_FD_KS &&
-                       Nt * N * 4 * 64 < (1l << 30);
-    if (piped) {
-      constexpr int TAU_DW = MP_FD_KS * N * TW, F_DW = MP_FD_KS * 6 * TW;
-      const unsigned* gt = reinterpret_cast<const unsigned*>(taumat + b * Nt * N);
-      const unsigned* gf = HAS_FTIP ? reinterpret_cast<const unsigned*>(Ftipmat + b * Nt * 6) : nullptr;
-      const int pitch = (int)(Nt * N);
-      mp_fd_tile_load<N, TW>(gt, pre_tau);
-      if (HAS_FTIP) mp_fd_tile_load<6, TW>(gf, pre_f);
-      auto tile = [&](const long i0) __attribute__((always_inline)) {
-        const bool more = i0 + 2 * MP_FD_KS <= Nt;  // another whole tile follows
-        mp_fd_tile_park<N, TW, TL::TAU0, STEP, RS>(pre_tau, col);
-        if (HAS_FTIP) mp_fd_tile_park<6, TW, TL::F0, STEP, RS>(pre_f, col);
-        MP_FD_TICK(tm_in);
-#if MP_FD_PRIO
-        if ((MP_FD_PRIO & 1) && ((tile_no ^ wave_slot) & 1u)) __builtin_amdgcn_s_setprio(1);
-        else __builtin_amdgcn_s_setprio(0);
-        ++tile_no;
-#endif
-#pragma unroll 1
-        for (int s = 0; s < MP_FD_KS; ++s) {
-          unsigned* cs = col + s * STEP;
-          T last[N];
-#pragma unroll
-          for (int j = 0; j < N; ++j) last[j] = T(0);
-          if (i0 + s > 0) {
-            T tau[N], tn[3] = {T(0), T(0), T(0)}, tf[3] = {T(0), T(0), T(0)};
-#pragma unroll
-            for (int j = 0; j < N; ++j) tau[j] = mp_fd_tile_get<T, TW, RS>(cs, TL::TAU0 + j, N);
-            bad.add(tau);
-            if (HAS_FTIP) {
-              T F[6];
-#pragma unroll
-              for (int k = 0; k < 6; ++k) F[k] = mp_fd_tile_get<T, TW, RS>(cs, TL::F0 + k, 6);
-              bad.add(F);
-              mp_wrench_to_frame1(M, F, tn, tf);
-            }
-            for (int k = 0; k < intRes; ++k) {
-              mp_forward_dynamics_auto<T, N, HAS_FTIP>(M, C.a0, tn, tf, q, qd, tau, last);
-#pragma unroll
-              for (int j = 0; j < N; ++j) {
-                qd[j] = qd[j] + last[j] * h;
-                q[j] = mp_clip(q[j] + qd[j] * h, M.qmin[j], M.qmax[j]);
-              }
-            }
-            bad.add(qd);
-          }
-          const bool poison = (i0 + s > 0) && bad.any();
-#pragma unroll
-          for (int j = 0; j < N; ++j) {
-            cs[j * RS] = poison ? 0x7fc00000u : __builtin_bit_cast(unsigned, (float)q[j]);
-            cs[(N + j) * RS] = poison ? 0x7fc00000u : __builtin_bit_cast(unsigned, (float)qd[j]);
-            cs[(2 * N + j) * RS] = poison ? 0x7fc00000u : __builtin_bit_cast(unsigned, (float)last[j]);
-          }
-        }
-        MP_FD_TICK(tm_cmp);
-#if MP_FD_PRIO
-        if (MP_FD_PRIO & 2) __builtin_amdgcn_s_setprio(3);
-#endif
-        if (more) {  // the next tile's rows: requested before this tile's rows leave
-          mp_fd_tile_load<N, TW>(gt + (i0 / MP_FD_KS + 1) * TAU_DW, pre_tau);
-          if (HAS_FTIP) mp_fd_tile_load<6, TW>(gf + (i0 / MP_FD_KS + 1) * F_DW, pre_f);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the tile was written column by column; the flush reads across
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        int fl_lane = lane;
-        asm volatile("" : "+v"(fl_lane));  // (keeps the per-lane chunk offsets from being hoisted out of the time loop and spilled)
-        const bool hold = whole_blocks && more;  // the next tile completes the blocks this one leaves open
-        const int e_end = (int)(((i0 + MP_FD_KS) * N * 4) & MpFdCarry<N>::MASK);
-        mp_fd_tile_out_buf<N, STEP, RS>(pos, vel, acc, (b0 * Nt + i0) * N, pitch, nvalid, fl_lane, in_batch, lds, hold, pitch_mod,
-                                        e_end, carry);
-        if constexpr (MpFdCarry<N>::ENABLED) {
-          carry.bytes = hold ? ((fl_lane * pitch_mod + e_end) & MpFdCarry<N>::MASK) : 0;
-          if (hold) mp_fd_carry_keep<N, STEP, RS>(carry, col);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the next tile's inputs overwrite these columns
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        MP_FD_TICK(tm_out);
-      };
-      tile(0);
-      long i0 = MP_FD_KS;
-      for (; i0 + MP_FD_KS <= Nt; i0 += MP_FD_KS) tile(i0);
-      i0_start = i0;
-    }
-  }
-#endif
-#if defined(MP_FD_SPLIT_PARK)
-  MpFdPrefetch<N, TW> late_tau;
-  MpFdPrefetch<6, TW> late_f;
-  bool late = false;
-#endif
-  int tile_rows = first_rows;  // the first tile may be short (staggered phases); the others hold MP_FD_KS rows
-  for (long i0 = i0_start; i0 < Nt; i0 += tile_rows, tile_rows = MP_FD_KS) {
+  for (long i0 = 0; i0 < Nt; i0 += MP_FD_KS) {
     const long left = Nt - i0;
-    const int rows = left < tile_rows ? (int)left : tile_rows;
+    const int rows = left < MP_FD_KS ? (int)left : MP_FD_KS;
     const bool full = rows == MP_FD_KS;
     const long row0 = b * Nt + i0;
     const bool next_full = left - rows >= MP_FD_KS;  // the tile after this one is a whole tile
-#if !defined(MP_FD_EXP_NOIN)  // (experiments: MP_FD_EXP_NOIN / MP_FD_EXP_NOOUT build kernels without the input / output half of the tile I/O)
-#if defined(MP_FD_IN2)
-    // Experiment (off: 0.648 against 0.613 ms): inputs fetched for TWO tiles at a time (192-byte runs at n = 6 instead of
-    // 96-byte ones).  A lane's run starts wherever the previous one ended, so every 128-byte line that straddles two
-    // fetches is read twice (the lines of one fetch do not survive in L2 until the next: one open line per trajectory and
-    // array is 33 MB); halving the number of fetches halves the straddles.  The second tile's rows wait in registers (48
-    // of them, 227 VGPRs in all) across the four steps of the first.  The re-reads it saves are Infinity-Cache hits; the
-    // 24 loads per lane issued at once and the registers cost more than they return.
-    if (!PIPE && full && vec_tau && (!HAS_FTIP || vec_f)) {
-      if (have_tau) {  // second tile of a pair: its rows are in the registers
-        mp_fd_tile_park<N, TW, TL::TAU0, STEP, RS>(pre_tau, col);
-        if (HAS_FTIP) mp_fd_tile_park<6, TW, TL::F0, STEP, RS>(pre_f, col);
-        have_tau = false;
-      } else {
-        MpFdPrefetch<N, TW> now_tau;
-        MpFdPrefetch<6, TW> now_f;
-        const unsigned* gt = reinterpret_cast<const unsigned*>(taumat + row0 * N);
-        const unsigned* gf = HAS_FTIP ? reinterpret_cast<const unsigned*>(Ftipmat + row0 * 6) : nullptr;
-        mp_fd_tile_load<N, TW>(gt, now_tau);
-        if (HAS_FTIP) mp_fd_tile_load<6, TW>(gf, now_f);
-        if (next_full) {
-          mp_fd_tile_load<N, TW>(gt + MP_FD_KS * N * TW, pre_tau);
-          if (HAS_FTIP) mp_fd_tile_load<6, TW>(gf + MP_FD_KS * 6 * TW, pre_f);
-          have_tau = true;
-        }
-        mp_fd_tile_park<N, TW, TL::TAU0, STEP, RS>(now_tau, col);
-        if (HAS_FTIP) mp_fd_tile_park<6, TW, TL::F0, STEP, RS>(now_f, col);
-      }
-    } else
-#endif
-#if !defined(MP_FD_NO_IN_EXACT)
     bool parked = false;
     if constexpr (N == 6 && TW == 1) {
       if (exact_in && full) {
@@ -1193,73 +844,29 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
     }
     if (parked) {
     } else
-#endif
-#if !defined(MP_FD_PREFETCH) && !defined(MP_FD_IN_SEPARATE)
     // both input arrays in ONE round trip: all their loads are issued before the first row is parked (two separate
     // load-wait-park sequences sit in different branches, and the compiler does not hoist loads across them)
     if (full && vec_tau && (!HAS_FTIP || vec_f) && (MP_FD_KS * N * TW) % 4 == 0) {
-#if defined(MP_FD_SPLIT_PARK)
-      // experiment: the pieces that hold the first step's rows are requested first and parked as soon as they are there; the
-      // others are parked after the first integration step, which runs while they arrive
-      constexpr int KT = (N * TW + 3) / 4, KF = (6 * TW + 3) / 4;
-      const unsigned* gt_ = reinterpret_cast<const unsigned*>(taumat + row0 * N);
-      const unsigned* gf_ = HAS_FTIP ? reinterpret_cast<const unsigned*>(Ftipmat + row0 * 6) : nullptr;
-      mp_fd_tile_load_range<N, TW, 0, KT>(gt_, late_tau);
-      if (HAS_FTIP) mp_fd_tile_load_range<6, TW, 0, KF>(gf_, late_f);
-      mp_fd_tile_load_range<N, TW, KT, MpFdPrefetch<N, TW>::NV>(gt_, late_tau);
-      if (HAS_FTIP) mp_fd_tile_load_range<6, TW, KF, MpFdPrefetch<6, TW>::NV>(gf_, late_f);
-      mp_fd_tile_park_range<N, TW, TL::TAU0, STEP, RS, 0, KT>(late_tau, col);
-      if (HAS_FTIP) mp_fd_tile_park_range<6, TW, TL::F0, STEP, RS, 0, KF>(late_f, col);
-      late = true;
-#else
       MpFdPrefetch<N, TW> now_tau;
       MpFdPrefetch<6, TW> now_f;
       mp_fd_tile_load<N, TW>(reinterpret_cast<const unsigned*>(taumat + row0 * N), now_tau);
       if (HAS_FTIP) mp_fd_tile_load<6, TW>(reinterpret_cast<const unsigned*>(Ftipmat + row0 * 6), now_f);
       mp_fd_tile_park<N, TW, TL::TAU0, STEP, RS>(now_tau, col);
       if (HAS_FTIP) mp_fd_tile_park<6, TW, TL::F0, STEP, RS>(now_f, col);
-#endif
-    } else
-#endif
-    {
-      {
-      const unsigned* g = reinterpret_cast<const unsigned*>(taumat + row0 * N);
-      if (PIPE && full && vec_tau) {
-        if (!have_tau) mp_fd_tile_load<N, TW>(g, pre_tau);
-        mp_fd_tile_park<N, TW, TL::TAU0, STEP, RS>(pre_tau, col);
-        have_tau = false;
-      } else if (full && vec_tau) mp_fd_tile_in<N, TW, TL::TAU0, STEP, RS, 4>(g, 0, col);
-      else mp_fd_tile_in<N, TW, TL::TAU0, STEP, RS, 1>(g, rows * N * TW, col);
+    } else {  // partial tiles and rows that are not 16-byte aligned: array by array, vector or dword accesses
+      const unsigned* gt = reinterpret_cast<const unsigned*>(taumat + row0 * N);
+      if (full && vec_tau) mp_fd_tile_in<N, TW, TL::TAU0, STEP, RS, 4>(gt, 0, col);
+      else mp_fd_tile_in<N, TW, TL::TAU0, STEP, RS, 1>(gt, rows * N * TW, col);
+      if (HAS_FTIP) {
+        const unsigned* gf = reinterpret_cast<const unsigned*>(Ftipmat + row0 * 6);
+        if (full && vec_f) mp_fd_tile_in<6, TW, TL::F0, STEP, RS, 4>(gf, 0, col);
+        else mp_fd_tile_in<6, TW, TL::F0, STEP, RS, 1>(gf, rows * 6 * TW, col);
+      }
     }
-    if (HAS_FTIP) {
-      const unsigned* g = reinterpret_cast<const unsigned*>(Ftipmat + row0 * 6);
-      if (PIPE && full && vec_f) {
-        if (!have_f) mp_fd_tile_load<6, TW>(g, pre_f);
-        mp_fd_tile_park<6, TW, TL::F0, STEP, RS>(pre_f, col);
-        have_f = false;
-      } else if (full && vec_f) mp_fd_tile_in<6, TW, TL::F0, STEP, RS, 4>(g, 0, col);
-      else mp_fd_tile_in<6, TW, TL::F0, STEP, RS, 1>(g, rows * 6 * TW, col);
-    }
-    }
-#endif
-#if defined(MP_FD_EXP_TIMING)
-    __builtin_amdgcn_s_waitcnt(0);  // everything the input half issued has landed
-#endif
-    MP_FD_TICK(tm_in);
-#if MP_FD_PRIO
-    if ((MP_FD_PRIO & 1) && ((tile_no ^ wave_slot) & 1u)) __builtin_amdgcn_s_setprio(1);
+    if ((tile_no ^ wave_slot) & 1u) __builtin_amdgcn_s_setprio(1);
     else __builtin_amdgcn_s_setprio(0);
     ++tile_no;
-#endif
     for (int s = 0; s < rows; ++s) {
-#if MP_FD_PREFETCH + 0 == 3
-      // the next tile's rows are requested before the LAST integration step of this tile: by the time the flush starts they have
-      // arrived, the wait in front of the first store costs nothing and the stores are never waited for
-      if (PIPE && next_full && s == rows - 1) {
-        if (vec_tau) { mp_fd_tile_load<N, TW>(reinterpret_cast<const unsigned*>(taumat + (row0 + rows) * N), pre_tau); have_tau = true; }
-        if (HAS_FTIP && vec_f) { mp_fd_tile_load<6, TW>(reinterpret_cast<const unsigned*>(Ftipmat + (row0 + rows) * 6), pre_f); have_f = true; }
-      }
-#endif
       unsigned* cs = col + s * STEP;
       T last[N];
 #pragma unroll
@@ -1268,26 +875,18 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
         T tau[N], tn[3] = {T(0), T(0), T(0)}, tf[3] = {T(0), T(0), T(0)};
 #pragma unroll
         for (int j = 0; j < N; ++j)
-#if defined(MP_FD_EXP_NOIN)
-          tau[j] = q[j] * T(1e-3);
-#else
           tau[j] = mp_fd_tile_get<T, TW, RS>(cs, TL::TAU0 + j, N);
-#endif
         bad.add(tau);
         if (HAS_FTIP) {
           T F[6];
 #pragma unroll
           for (int k = 0; k < 6; ++k)
-#if defined(MP_FD_EXP_NOIN)
-            F[k] = qd[k % N] * T(1e-3);
-#else
             F[k] = mp_fd_tile_get<T, TW, RS>(cs, TL::F0 + k, 6);
-#endif
           bad.add(F);
           mp_wrench_to_frame1(M, F, tn, tf);
         }
         for (int k = 0; k < intRes; ++k) {
-          mp_forward_dynamics_auto<T, N, HAS_FTIP>(M, C.a0, tn, tf, q, qd, tau, last);
+          mp_forward_dynamics<T, N, HAS_FTIP>(M, C.a0, tn, tf, q, qd, tau, last);
 #pragma unroll
           for (int j = 0; j < N; ++j) {
             qd[j] = qd[j] + last[j] * h;
@@ -1297,49 +896,16 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
         bad.add(qd);
       }
       const bool poison = (i0 + s > 0) && bad.any();
-#if defined(MP_FD_EXP_NOOUT)
-      if (i0 + s + 1 == Nt)
-#endif
 #pragma unroll
       for (int j = 0; j < N; ++j) {
         cs[j * RS] = poison ? 0x7fc00000u : __builtin_bit_cast(unsigned, (float)q[j]);
         cs[(N + j) * RS] = poison ? 0x7fc00000u : __builtin_bit_cast(unsigned, (float)qd[j]);
         cs[(2 * N + j) * RS] = poison ? 0x7fc00000u : __builtin_bit_cast(unsigned, (float)last[j]);
       }
-#if defined(MP_FD_SPLIT_PARK)
-      if (late) {  // (s == 0 of a tile whose later rows are still in registers)
-        constexpr int KT = (N * TW + 3) / 4, KF = (6 * TW + 3) / 4;
-        mp_fd_tile_park_range<N, TW, TL::TAU0, STEP, RS, KT, MpFdPrefetch<N, TW>::NV>(late_tau, col);
-        if (HAS_FTIP) mp_fd_tile_park_range<6, TW, TL::F0, STEP, RS, KF, MpFdPrefetch<6, TW>::NV>(late_f, col);
-        late = false;
-      }
-#endif
     }
-#if defined(MP_FD_EXP_NOOUT)
-    if (i0 + rows < Nt) continue;
-#endif
-    MP_FD_TICK(tm_cmp);
-#if MP_FD_PRIO
-    if (MP_FD_PRIO & 2) __builtin_amdgcn_s_setprio(3);
-#endif
-    // Optional order of the tile boundary (MP_FD_PREFETCH).  Loads and stores share one counter (vmcnt, in issue order):
-    // a wave that waits for loads issued AFTER the flush waits for every store of the flush too, and where paths with
-    // different store counts meet the compiler falls back to vmcnt(0): "flush this tile's rows, then fetch the next
-    // tile's torques / wrenches" drains 18 stores at every boundary.  With this switch the next tile's rows are requested FIRST
-    // and waited for before the first store is issued; the stores that follow are never waited for.  The rows wait in
-    // registers across the flush only.
-    if (PIPE && next_full) {
-#if MP_FD_PREFETCH + 0 != 3  // (3: the loads were issued before the last integration step, see the step loop)
-      if (vec_tau) { mp_fd_tile_load<N, TW>(reinterpret_cast<const unsigned*>(taumat + (row0 + rows) * N), pre_tau); have_tau = true; }
-      if (HAS_FTIP && vec_f) { mp_fd_tile_load<6, TW>(reinterpret_cast<const unsigned*>(Ftipmat + (row0 + rows) * 6), pre_f); have_f = true; }
-#endif
-#if MP_FD_PREFETCH + 0 != 2  // MP_FD_PREFETCH=2: no wait here - the rows are waited for after the flush (vmcnt counts in order)
-      if (have_tau) mp_fd_tile_arrive<N, TW>(pre_tau);
-      if (have_f) mp_fd_tile_arrive<6, TW>(pre_f);
-#endif
-    }
+    __builtin_amdgcn_s_setprio(3);
     bool flushed = false;
-    if constexpr (MpFdCarry<N>::OWNER) {  // (A/B switch: MP_FD_NO_OWNER sends these tiles through the wave-cooperative flat stores)
+    if constexpr (MpFdCarry<N>::OWNER) {
      if (full && vec_out) {
       const bool hold = whole_blocks && next_full;
       const int e_end = (int)(((i0 + MP_FD_KS) * N * 4) & MpFdCarry<N>::MASK);
@@ -1352,7 +918,6 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
     }
     if (flushed) {
     } else
-#if !defined(MP_FD_LANE_STORES)  // (A/B switch: MP_FD_LANE_STORES keeps the lane-by-lane stores)
     if (!MpFdCarry<N>::OWNER && full && vec_out) {
       // the tile was written column by column (each lane its own); the flat stores read across columns
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1361,7 +926,8 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
       const long run0 = (b0 * Nt + i0) * N;
       // the chunk -> (trajectory, piece) split is the same for every tile; recomputing it from an opaque copy of the lane
       // index keeps the compiler from hoisting a dozen per-lane 64-bit offsets out of the time loop (they were spilled)
-      MpFdFlat<N> fl = flat;
+      MpFdFlat<N> fl;
+      fl.lane = lane;
       asm volatile("" : "+v"(fl.lane));
       const bool hold = whole_blocks && next_full;  // the next tile is a whole tile: it completes the blocks this one leaves open
       const int e_end = (int)(((i0 + MP_FD_KS) * N * 4) & MpFdCarry<N>::MASK);
@@ -1377,7 +943,6 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     } else
-#endif
     if (!in_batch) {
       // partial / unaligned tiles leave lane by lane: lanes past the batch have nothing to store
     } else if (full && vec_out) {
@@ -1388,149 +953,6 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
       mp_fd_tile_out<N, STEP, RS, 1>(pos + row0 * N, 0, rows * N, col);
       mp_fd_tile_out<N, STEP, RS, 1>(vel + row0 * N, 1, rows * N, col);
       mp_fd_tile_out<N, STEP, RS, 1>(acc + row0 * N, 2, rows * N, col);
-    }
-#if defined(MP_FD_EXP_TIMING)
-#if MP_FD_EXP_TIMING > 1
-    __builtin_amdgcn_s_waitcnt(0);  // > 1: the stores are waited for here, so their completion is booked to the flush
-#endif
-#endif
-    MP_FD_TICK(tm_out);
-  }
-#if defined(MP_FD_EXP_TIMING)
-  __builtin_amdgcn_s_waitcnt(0);
-  if (lane == 0 && Nt > 2) {
-    float* dbg = acc + (b0 * Nt + 1) * N;
-    dbg[0] = (float)tm_in; dbg[1] = (float)tm_cmp; dbg[2] = (float)tm_out;
-    dbg[3] = (float)(__builtin_readcyclecounter() - tm_start);
-    dbg[4] = (float)(tm_start & 0xffffff);
-    // where the wave ran: HW_ID bits [15:0] (wave, SIMD, pipe, CU, SH, SE) + XCC_ID bits [3:0] << 16
-    dbg[5] = (float)((__builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4) & 0xffffu) | ((__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 0xfu) << 16));
-  }
-#endif
-}
-
-// float32, TWO trajectories per lane (packed v_pk_* math): lane `p` integrates trajectories 2p and 2p+1.  Same tile
-// as above with 128 columns per wave (column = lane + 64 * half); B odd: the last lane's second half recomputes its
-// first trajectory and stores nothing.
-template <int N, bool HAS_FTIP, typename MT>
-__device__ __forceinline__ void mp_body_fd_traj_pk(const MT& M, const MpCall<float>& C, const float* __restrict__ theta0,
-                                                   const float* __restrict__ dtheta0, const float* __restrict__ taumat,
-                                                   const float* __restrict__ Ftipmat, long p, long B, long Nt, float h,
-                                                   int intRes, float* __restrict__ pos, float* __restrict__ vel,
-                                                   float* __restrict__ acc, unsigned* __restrict__ lds, int lane) {
-  using TL = MpFdTile<float, N, HAS_FTIP, 128>;
-  constexpr int STEP = TL::STEP, W = 128;
-  const long b0 = 2 * p, b1v = 2 * p + 1;
-  const bool two = b1v < B;
-  const long b1 = two ? b1v : b0;
-  unsigned* col0 = lds + lane;
-  unsigned* col1 = col0 + 64;
-  mp_f2 q[N], qd[N];
-  {
-    float a[N], b[N];
-    RunIO<float, N>::load(theta0, b0, a);
-    RunIO<float, N>::load(theta0, b1, b);
-#pragma unroll
-    for (int j = 0; j < N; ++j) q[j] = (mp_f2){a[j], b[j]};
-    RunIO<float, N>::load(dtheta0, b0, a);
-    RunIO<float, N>::load(dtheta0, b1, b);
-#pragma unroll
-    for (int j = 0; j < N; ++j) qd[j] = (mp_f2){a[j], b[j]};
-  }
-  MpBad<mp_f2> bad;  // sticky non-finite verdict per trajectory, see mp_body_fd_traj
-  bad.add(q); bad.add(qd);
-  const bool vec_tau = ((Nt * N * 4) & 15) == 0, vec_f = ((Nt * 6 * 4) & 15) == 0;
-  const mp_f2 hh = (mp_f2){h, h};
-  for (long i0 = 0; i0 < Nt; i0 += MP_FD_KS) {
-    const long left = Nt - i0;
-    const int rows = left < MP_FD_KS ? (int)left : MP_FD_KS;
-    const bool full = rows == MP_FD_KS;
-    const long r0 = b0 * Nt + i0, r1 = b1 * Nt + i0;
-    {
-      const unsigned* g0 = reinterpret_cast<const unsigned*>(taumat + r0 * N);
-      const unsigned* g1 = reinterpret_cast<const unsigned*>(taumat + r1 * N);
-      if (full && vec_tau) {
-        mp_fd_tile_in<N, 1, TL::TAU0, STEP, W, 4>(g0, 0, col0);
-        mp_fd_tile_in<N, 1, TL::TAU0, STEP, W, 4>(g1, 0, col1);
-      } else {
-        mp_fd_tile_in<N, 1, TL::TAU0, STEP, W, 1>(g0, rows * N, col0);
-        mp_fd_tile_in<N, 1, TL::TAU0, STEP, W, 1>(g1, rows * N, col1);
-      }
-    }
-    if (HAS_FTIP) {
-      const unsigned* g0 = reinterpret_cast<const unsigned*>(Ftipmat + r0 * 6);
-      const unsigned* g1 = reinterpret_cast<const unsigned*>(Ftipmat + r1 * 6);
-      if (full && vec_f) {
-        mp_fd_tile_in<6, 1, TL::F0, STEP, W, 4>(g0, 0, col0);
-        mp_fd_tile_in<6, 1, TL::F0, STEP, W, 4>(g1, 0, col1);
-      } else {
-        mp_fd_tile_in<6, 1, TL::F0, STEP, W, 1>(g0, rows * 6, col0);
-        mp_fd_tile_in<6, 1, TL::F0, STEP, W, 1>(g1, rows * 6, col1);
-      }
-    }
-    for (int s = 0; s < rows; ++s) {
-      unsigned* c0 = col0 + s * STEP;
-      unsigned* c1 = col1 + s * STEP;
-      mp_f2 last[N];
-#pragma unroll
-      for (int j = 0; j < N; ++j) last[j] = (mp_f2){0.f, 0.f};
-      if (i0 + s > 0) {
-        mp_f2 tau[N], tn[3], tf[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { tn[k] = (mp_f2){0.f, 0.f}; tf[k] = (mp_f2){0.f, 0.f}; }
-#pragma unroll
-        for (int j = 0; j < N; ++j)
-          tau[j] = (mp_f2){__builtin_bit_cast(float, c0[(TL::TAU0 + j) * W]), __builtin_bit_cast(float, c1[(TL::TAU0 + j) * W])};
-        bad.add(tau);
-        if (HAS_FTIP) {
-          mp_f2 F[6];
-#pragma unroll
-          for (int k = 0; k < 6; ++k)
-            F[k] = (mp_f2){__builtin_bit_cast(float, c0[(TL::F0 + k) * W]), __builtin_bit_cast(float, c1[(TL::F0 + k) * W])};
-          bad.add(F);
-          mp_wrench_to_frame1(M, F, tn, tf);
-        }
-        for (int k = 0; k < intRes; ++k) {
-          mp_forward_dynamics<mp_f2, N, HAS_FTIP>(M, C.a0, tn, tf, q, qd, tau, last);
-#pragma unroll
-          for (int j = 0; j < N; ++j) {
-            qd[j] = qd[j] + last[j] * hh;
-            q[j] = mp_clip(q[j] + qd[j] * hh, M.qmin[j], M.qmax[j]);
-          }
-        }
-        bad.add(qd);
-      }
-      const bool px = (i0 + s > 0) && bad.x.any(), py = (i0 + s > 0) && bad.y.any();
-#pragma unroll
-      for (int j = 0; j < N; ++j) {
-        // element copies first: __builtin_bit_cast applied directly to a vector-element lvalue (v.y) reads element 0
-        const float qx = q[j].x, qy = q[j].y, vx = qd[j].x, vy = qd[j].y, ax = last[j].x, ay = last[j].y;
-        c0[j * W] = px ? 0x7fc00000u : __builtin_bit_cast(unsigned, qx);
-        c1[j * W] = py ? 0x7fc00000u : __builtin_bit_cast(unsigned, qy);
-        c0[(N + j) * W] = px ? 0x7fc00000u : __builtin_bit_cast(unsigned, vx);
-        c1[(N + j) * W] = py ? 0x7fc00000u : __builtin_bit_cast(unsigned, vy);
-        c0[(2 * N + j) * W] = px ? 0x7fc00000u : __builtin_bit_cast(unsigned, ax);
-        c1[(2 * N + j) * W] = py ? 0x7fc00000u : __builtin_bit_cast(unsigned, ay);
-      }
-    }
-    if (full && vec_tau) {
-      mp_fd_tile_out<N, STEP, W, 4>(pos + r0 * N, 0, 0, col0);
-      mp_fd_tile_out<N, STEP, W, 4>(vel + r0 * N, 1, 0, col0);
-      mp_fd_tile_out<N, STEP, W, 4>(acc + r0 * N, 2, 0, col0);
-      if (two) {
-        mp_fd_tile_out<N, STEP, W, 4>(pos + r1 * N, 0, 0, col1);
-        mp_fd_tile_out<N, STEP, W, 4>(vel + r1 * N, 1, 0, col1);
-        mp_fd_tile_out<N, STEP, W, 4>(acc + r1 * N, 2, 0, col1);
-      }
-    } else {
-      mp_fd_tile_out<N, STEP, W, 1>(pos + r0 * N, 0, rows * N, col0);
-      mp_fd_tile_out<N, STEP, W, 1>(vel + r0 * N, 1, rows * N, col0);
-      mp_fd_tile_out<N, STEP, W, 1>(acc + r0 * N, 2, rows * N, col0);
-      if (two) {
-        mp_fd_tile_out<N, STEP, W, 1>(pos + r1 * N, 0, rows * N, col1);
-        mp_fd_tile_out<N, STEP, W, 1>(vel + r1 * N, 1, rows * N, col1);
-        mp_fd_tile_out<N, STEP, W, 1>(acc + r1 * N, 2, rows * N, col1);
-      }
     }
   }
 }
@@ -1650,7 +1072,7 @@ __device__ __forceinline__ void mp_body_fd_traj_tm(const MT& M, const MpCall<T>&
       mp_wrench_to_frame1(M, F, tn, tf);
     }
     for (int k = 0; k < intRes; ++k) {
-      mp_forward_dynamics_auto<T, N, HAS_FTIP>(M, C.a0, tn, tf, q, qd, tau, last);
+      mp_forward_dynamics<T, N, HAS_FTIP>(M, C.a0, tn, tf, q, qd, tau, last);
 #pragma unroll
       for (int j = 0; j < N; ++j) {
         qd[j] = qd[j] + last[j] * h;

@@ -29,7 +29,7 @@ struct MpSpec {  // run-time specialised kernels of one model on one device
   hipModule_t mod = nullptr;
   hipModule_t mod_ilp = nullptr;  // second program (mp_jit part 1): id_s compiled with the max-ILP strategy; optional
   hipFunction_t id_pk[2] = {nullptr, nullptr}, traj_id_pk[2] = {nullptr, nullptr}, fd_traj[2] = {nullptr, nullptr};
-  hipFunction_t id_d[2] = {nullptr, nullptr}, fk_jac_id_d[2] = {nullptr, nullptr}, fd_traj_pk[2] = {nullptr, nullptr};
+  hipFunction_t id_d[2] = {nullptr, nullptr}, fk_jac_id_d[2] = {nullptr, nullptr};
   hipFunction_t ik = nullptr;
   hipFunction_t fd_s[2] = {nullptr, nullptr}, fd_d[2] = {nullptr, nullptr};  // forward dynamics per row, float32 / float64
   hipFunction_t id_s[2] = {nullptr, nullptr};                                  // inverse dynamics, float32, one row per lane
@@ -254,7 +254,7 @@ int launch_spec(mp_ctx* ctx, hipFunction_t fn, long threads, void** args, unsign
   return MP_OK;
 }
 
-// float32 model resident in device memory (read by the persistent kernels with scalar loads)
+// float32 model resident in device memory (read by the *_dm kernels with scalar loads)
 int device_model(mp_ctx* ctx, const mp_model* model, const MpModel<float>** out) {
   auto it = ctx->dev_models.find(model->uid);
   if (it == ctx->dev_models.end()) {
@@ -267,10 +267,10 @@ int device_model(mp_ctx* ctx, const mp_model* model, const MpModel<float>** out)
   return MP_OK;
 }
 
-// MANIPULAPY_HIP_PERSIST = blocks per CU of the persistent float32 kernel (0 = plain one-shot kernel)
-int persist_blocks_per_cu() {
-  static const int v = [] { const char* e = getenv("MANIPULAPY_HIP_PERSIST"); return e ? atoi(e) : 0; }();
-  return v;
+// MANIPULAPY_HIP_GENERIC = "dm": the generic float32 inverse dynamics reads the model from device memory, one row per lane
+int generic_f32_mode() {
+  static const int mode = [] { const char* e = getenv("MANIPULAPY_HIP_GENERIC"); return (e && e[0] == 'd') ? 2 : 0; }();
+  return mode;
 }
 
 int launch_id(mp_ctx* ctx, const mp_model* model, const MpCall<double>& c, bool ftip, const double* q, const double* qd,
@@ -304,16 +304,10 @@ int launch_id(mp_ctx* ctx, const mp_model* model, const MpCall<float>& c, bool f
     HIP_TRY(mpk_id<float>(ctx->compute, model->f, c, ftip, q + off, qd + off, qdd + off, tau + off, rows - done));
     return MP_OK;
   }
-  const int per_cu = persist_blocks_per_cu();
-  const long blocks = (long)per_cu * ctx->compute_units;
-  if (per_cu > 0 && pairs > blocks * 256) {  // enough work for every resident lane to loop
+  if (generic_f32_mode() == 2 && !ctx->capturing) {  // one row per lane, device-resident model (not while capturing: first use uploads it)
     const MpModel<float>* dm = nullptr;
     if (int rc = device_model(ctx, model, &dm)) return rc;
-    HIP_TRY(mpk_id_f32_persist(ctx->compute, dm, model->d.n, c, ftip, q, qd, qdd, tau, pairs, (int)blocks));
-    const long done = 2 * pairs;
-    if (done == rows) return MP_OK;
-    const long off = done * model->d.n;
-    HIP_TRY(mpk_id<float>(ctx->compute, model->f, c, ftip, q + off, qd + off, qdd + off, tau + off, rows - done));
+    HIP_TRY(mpk_id_dm(ctx->compute, dm, model->d.n, c, ftip, q, qd, qdd, tau, rows));
     return MP_OK;
   }
   HIP_TRY(mpk_id<float>(ctx->compute, model->f, c, ftip, q, qd, qdd, tau, rows));
@@ -514,7 +508,6 @@ int launch_fd_spec(mp_ctx* ctx, const mp_model* model, const MpCall<float>& c, c
   MpCall<float> cc = c;
   void* args[] = {&cc, &th0, &dth0, &taumat, &Fm, &B, &Nt, &h, &intRes, &pos, &vel, &acc};
   if (time_major) return launch_spec(ctx, sp->fd_traj_tm[Fm ? 1 : 0], B, args, 64);
-  if (mpk_fd_packed()) return launch_spec(ctx, sp->fd_traj_pk[Fm ? 1 : 0], (B + 1) / 2, args, 64);  // two trajectories per lane
   return launch_spec(ctx, sp->fd_traj[Fm ? 1 : 0], B, args, 64);  // one wave per block (per-wave LDS tile)
 }
 int launch_fd_spec(mp_ctx*, const mp_model*, const MpCall<double>&, const double*, const double*, const double*, const double*,
@@ -1026,15 +1019,15 @@ int mp_model_specialize(mp_ctx* ctx, const mp_model* model) {
   if (mp_jit_compile(model->f, model->d, &code, nullptr, &err)) return set_err(MP_ERR_UNSUPPORTED, "mp_model_specialize: %s", err.c_str());
   MpSpec sp;
   HIP_TRY(hipModuleLoadData(&sp.mod, code.data()));
-  const char* names[11][2] = {{"mp_spec_id_pk_f0", "mp_spec_id_pk_f1"}, {"mp_spec_traj_id_pk_f0", "mp_spec_traj_id_pk_f1"},
+  const char* names[10][2] = {{"mp_spec_id_pk_f0", "mp_spec_id_pk_f1"}, {"mp_spec_traj_id_pk_f0", "mp_spec_traj_id_pk_f1"},
                              {"mp_spec_fd_traj_f0", "mp_spec_fd_traj_f1"}, {"mp_spec_id_d_f0", "mp_spec_id_d_f1"},
-                             {"mp_spec_fk_jac_id_d_f0", "mp_spec_fk_jac_id_d_f1"}, {"mp_spec_fd_traj_pk_f0", "mp_spec_fd_traj_pk_f1"},
+                             {"mp_spec_fk_jac_id_d_f0", "mp_spec_fk_jac_id_d_f1"},
                              {"mp_spec_fd_s_f0", "mp_spec_fd_s_f1"}, {"mp_spec_fd_d_f0", "mp_spec_fd_d_f1"},
                              {"mp_spec_id_s_f0", "mp_spec_id_s_f1"}, {"mp_spec_traj_id_s_f0", "mp_spec_traj_id_s_f1"},
                              {"mp_spec_fd_traj_tm_f0", "mp_spec_fd_traj_tm_f1"}};
-  hipFunction_t* slots[11] = {sp.id_pk, sp.traj_id_pk, sp.fd_traj, sp.id_d, sp.fk_jac_id_d, sp.fd_traj_pk, sp.fd_s, sp.fd_d, sp.id_s,
-                              sp.traj_id_s, sp.fd_traj_tm};
-  for (int k = 0; k < 11; ++k)
+  hipFunction_t* slots[10] = {sp.id_pk, sp.traj_id_pk, sp.fd_traj, sp.id_d, sp.fk_jac_id_d, sp.fd_s, sp.fd_d, sp.id_s, sp.traj_id_s,
+                              sp.fd_traj_tm};
+  for (int k = 0; k < 10; ++k)
     for (int f = 0; f < 2; ++f) {
       hipError_t e = hipModuleGetFunction(&slots[k][f], sp.mod, names[k][f]);
       if (e != hipSuccess) { (void)hipModuleUnload(sp.mod); return hip_err(e, names[k][f]); }

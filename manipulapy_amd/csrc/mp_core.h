@@ -32,10 +32,11 @@
 // The per-row math is written once for an arithmetic type T and a scalar type S = MpTraits<T>::S that
 // the wave-uniform model constants use:
 //   T = float / double : one row per lane;
-//   T = mp_f2 (2 x float): TWO rows per lane, so that every operation becomes a packed
-//       v_pk_{fma,mul,add}_f32 — on gfx950 a scalar v_fma_f32 and a v_pk_fma_f32 occupy the SIMD for
-//       the same ~4.5 cycles per wave-instruction (profiles/r01_ubench_valu.txt), so packing doubles
-//       the float32 rate (70 -> 130 TFLOP/s measured).
+//   T = mp_f2 (2 x float): TWO rows per lane, every operation a packed v_pk_{fma,mul,add}_f32.  On gfx950 a packed
+//       float32 instruction occupies the SIMD-32 for 4 cycles, a scalar v_fma_f32 / v_mul_f32 for 2
+//       (tools/ubench_issue2.hip, profiles/r02_ubench_issue.txt; r01's "packing doubles the rate" was read off a loop whose
+//       scalar form was not issue-limited), so packing buys no arithmetic throughput, only fewer instructions to issue:
+//       it is used where that pays (odd DOF, whose 4 n-byte rows only allow dword accesses) and nowhere else.
 #if defined(__clang__)
 #define MP_HAS_PACKED 1
 typedef float mp_f2 __attribute__((ext_vector_type(2)));
@@ -220,6 +221,29 @@ MP_HD void mp_poison_if(bool bad, T (&v)[N]) {
   for (int i = 0; i < N; ++i) mp_poison_if(bad, v[i]);
 }
 
+// ------------------------------------------------------------------------------ model access
+// Joint i of a model view.  By-value models (kernel arguments, constexpr literals, host structs): the member itself.  A
+// model read through a constant-address-space POINTER (the generic one-row-per-lane kernels, MpModelConstF below) launders the pointer
+// first: the 16 constants of a joint are then scalar-loaded where the joint's code uses them instead of all at once at the
+// top of the kernel - 185 dwords of model do not fit the ~100 SGPRs a wave has, and what does not fit is parked in VGPR
+// lanes (v_writelane / v_readlane: 60 of the 1203 instructions of the generic one-row kernel).
+template <typename MT>
+MP_HD const auto& mp_joint_of(const MT& M, int i) { return M.j[i]; }
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const __attribute__((address_space(4))) MpModel<float> MpModelConstF;
+typedef const __attribute__((address_space(4))) MpModel<double> MpModelConstD;
+__device__ __forceinline__ const __attribute__((address_space(4))) MpJoint<float>& mp_joint_of(MpModelConstF& M, int i) {
+  MpModelConstF* p = &M;
+  asm volatile("" : "+s"(p));  // opaque to CSE / hoisting: joint i's constants are loaded here
+  return p->j[i];
+}
+__device__ __forceinline__ const __attribute__((address_space(4))) MpJoint<double>& mp_joint_of(MpModelConstD& M, int i) {
+  MpModelConstD* p = &M;
+  asm volatile("" : "+s"(p));
+  return p->j[i];
+}
+#endif
+
 // ------------------------------------------------------------------------------ axis-aligned steps
 // Motion vector (w, v), parent -> child coordinates, child pose in parent = (E, r):
 //     w' = E^T w,  v' = E^T (v + w x r).
@@ -298,7 +322,7 @@ template <typename T, int N, typename MT>
 MP_HD void mp_joint_state(const MT& M, const T (&q)[N], MpJointState<T, N>& js) {
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    const auto& J = M.j[i];
+    const auto& J = mp_joint_of(M, i);
     const T qr = J.rev * q[i];
     mp_sincos(J.off + qr, js.s[i], js.c[i]);
     js.d[i] = J.d + (q[i] - qr);
@@ -323,7 +347,7 @@ MP_HD void mp_rnea(const MT& M, const typename MpTraits<T>::S (&a0)[3], const T 
   // forward pass: twists, accelerations, body wrenches
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    const auto& J = M.j[i];
+    const auto& J = mp_joint_of(M, i);
     if (i > 0) {
       mp_motion_A(J.ca, J.sa, J.a, wx, wy, wz, vx, vy, vz);
       mp_motion_A(J.ca, J.sa, J.a, dwx, dwy, dwz, dvx, dvy, dvz);
@@ -369,7 +393,7 @@ MP_HD void mp_rnea(const MT& M, const typename MpTraits<T>::S (&a0)[3], const T 
   // backward pass
 #pragma unroll
   for (int i = N - 1; i >= 0; --i) {
-    const auto& J = M.j[i];
+    const auto& J = mp_joint_of(M, i);
     tau[i] = J.rev * fnz[i] + (S(1) - J.rev) * ffz[i];
     if (i > 0) {
       T nx = fnx[i], ny = fny[i], nz = fnz[i], fx = ffx[i], fy = ffy[i], fz = ffz[i];
@@ -481,7 +505,7 @@ MP_HD void mp_mass_matrix_crba(const MT& M, const MpJointState<T, N>& js, T (&Mq
   Ic.xx = zero; Ic.xy = zero; Ic.xz = zero; Ic.yy = zero; Ic.yz = zero; Ic.zz = zero;
 #pragma unroll
   for (int i = N - 1; i >= 0; --i) {
-    const auto& J = M.j[i];
+    const auto& J = mp_joint_of(M, i);
     Ic.m = Ic.m + J.m; Ic.hx = Ic.hx + J.hx; Ic.hy = Ic.hy + J.hy; Ic.hz = Ic.hz + J.hz;
     Ic.xx = Ic.xx + J.Ixx; Ic.xy = Ic.xy + J.Ixy; Ic.xz = Ic.xz + J.Ixz; Ic.yy = Ic.yy + J.Iyy; Ic.yz = Ic.yz + J.Iyz;
     Ic.zz = Ic.zz + J.Izz;
@@ -492,10 +516,10 @@ MP_HD void mp_mass_matrix_crba(const MT& M, const MpJointState<T, N>& js, T (&Mq
     Mq[i][i] = r * nz + p * fz;
 #pragma unroll
     for (int k = i; k > 0; --k) {  // carry F from frame k to frame k-1, read the component along joint k-1
-      const auto& Jk = M.j[k];
+      const auto& Jk = mp_joint_of(M, k);
       mp_force_up_B(js.c[k], js.s[k], js.d[k], nx, ny, nz, fx, fy, fz);
       mp_force_up_A(Jk.ca, Jk.sa, Jk.a, nx, ny, nz, fx, fy, fz);
-      const auto& Jp = M.j[k - 1];
+      const auto& Jp = mp_joint_of(M, k - 1);
       const T v = Jp.rev * nz + (S(1) - Jp.rev) * fz;
       Mq[k - 1][i] = v;
       Mq[i][k - 1] = v;
@@ -576,7 +600,7 @@ MP_HD void mp_fk_jac(const MT& M, const MpJointState<T, N>& js, T* Tout, T* Jout
   T p0 = TR::splat(M.base_p[0]), p1 = TR::splat(M.base_p[1]), p2 = TR::splat(M.base_p[2]);
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    const auto& J = M.j[i];
+    const auto& J = mp_joint_of(M, i);
     if (i > 0) {  // . Rx(alpha) Tx(a)
       p0 += J.a * x0; p1 += J.a * x1; p2 += J.a * x2;
       const T a0 = y0, a1 = y1, a2 = y2;

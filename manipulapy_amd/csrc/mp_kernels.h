@@ -11,6 +11,10 @@ template <typename T>
 hipError_t mpk_id(hipStream_t s, const MpModel<T>& M, const MpCall<T>& C, bool ftip, const T* q, const T* qd,
                   const T* qdd, T* tau, long rows);
 
+// float32, one row per lane, the model read through a pointer to a device-resident copy (scalar loads joint by joint)
+hipError_t mpk_id_dm(hipStream_t s, const MpModel<float>* d_model, int n, const MpCall<float>& C, bool ftip, const float* q,
+                     const float* qd, const float* qdd, float* tau, long rows);
+
 hipError_t mpk_batch_traj(hipStream_t s, const MpModel<float>& M, const float* start, const float* end, long B,
                           long Nt, double Tf, int method, float* pos, float* vel, float* acc);
 
@@ -21,18 +25,12 @@ template <typename T>
 hipError_t mpk_fk_jac_id(hipStream_t s, const MpModel<T>& M, const MpCall<T>& C, bool ftip, const T* q, const T* qd,
                          const T* qdd, T* Tout, T* Jout, T* tau, long rows);
 
-// float32 persistent / prefetching form of the inverse-dynamics kernel: `pairs` row pairs (2 rows per
-// lane), model resident in device memory, fixed grid of `blocks` x 256 threads.
-hipError_t mpk_id_f32_persist(hipStream_t s, const MpModel<float>* d_model, int n, const MpCall<float>& C, bool ftip,
-                              const float* q, const float* qd, const float* qdd, float* tau, long pairs, int blocks);
-
 template <typename T>
 hipError_t mpk_mass_matrix(hipStream_t s, const MpModel<T>& M, const T* q, T* Mout, long rows);
 template <typename T>
 hipError_t mpk_forward_dynamics(hipStream_t s, const MpModel<T>& M, const MpCall<T>& C, bool ftip, const T* q, const T* qd,
                                 const T* tau, T* qdd, long rows);
 // Ftipmat == nullptr: no tip wrench.  h = dt / intRes.  Outputs are float32 (B, Nt, n).
-bool mpk_fd_packed();  // MANIPULAPY_HIP_FD=packed: float32 roll-outs with two trajectories per lane (measured slower; off by default)
 template <typename T>
 hipError_t mpk_fd_traj(hipStream_t s, const MpModel<T>& M, const MpCall<T>& C, const T* theta0, const T* dtheta0,
                        const T* taumat, const T* Ftipmat, long B, long Nt, T h, int intRes, float* pos, float* vel, float* acc);

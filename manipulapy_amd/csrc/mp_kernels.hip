@@ -37,6 +37,19 @@ __global__ __launch_bounds__(kBlock) void k_id(const MpModel<T> M, const MpCall<
   mp_body_id<T, N, HAS_FTIP>(M, C, q, qd, qdd, tau, r);
 }
 
+// The same with the model read through a pointer to device memory (scalar loads, K$-resident) instead of the kernel-argument
+// struct: the joints' constants are then loaded joint by joint where the recursion uses them (mp_joint_of, mp_core.h), not all
+// 185 dwords at the top of the kernel - which overflows the SGPR file into VGPR lanes (60 v_writelane / v_readlane of 1203
+// instructions at n = 6) and keeps the wave count down.
+template <typename T, int N, bool HAS_FTIP>
+__global__ __launch_bounds__(kBlock) void k_id_dm(const MpModel<T>* __restrict__ Mdev, const MpCall<T> C, const T* __restrict__ q,
+                                                  const T* __restrict__ qd, const T* __restrict__ qdd, T* __restrict__ tau, long rows) {
+  const long r = (long)blockIdx.x * kBlock + threadIdx.x;
+  if (r >= rows) return;
+  typedef const __attribute__((address_space(4))) MpModel<T> MC;
+  mp_body_id<T, N, HAS_FTIP>(*(MC*)Mdev, C, q, qd, qdd, tau, r);
+}
+
 // -------------------------------------------------------------- trajectory generation pieces
 template <int N>
 __global__ __launch_bounds__(kBlock) void k_batch_traj(const MpModel<float> M, const float* __restrict__ start,
@@ -85,52 +98,6 @@ __global__ __launch_bounds__(MP_PK_BLOCK, MP_PK_MINW) void k_id_pk(const MpModel
   const long p = (long)blockIdx.x * MP_PK_BLOCK + threadIdx.x;
   if (p >= pairs) return;
   mp_body_id_pk_split<N, HAS_FTIP>(M, C, q, qd, qdd, tau, p, pairs);  // rows p and p + pairs
-}
-
-// Persistent form of k_id_pk: a fixed grid walks the pairs with a grid stride and keeps the NEXT
-// pair's 3 x 2N inputs in flight (registers) while the current pair is being computed, so the HBM
-// latency that the plain kernel exposes at the head of every wave is hidden behind ~1250 VALU
-// instructions.  The model is read through a constant-address-space pointer that is laundered every
-// iteration: without that the compiler hoists all ~100 scalar loads out of the loop and spills the
-// SGPRs through v_writelane / v_readlane (measured: +50 % VALU instructions).
-typedef const __attribute__((address_space(4))) MpModel<float> MpModelConstF;
-
-template <int N, bool HAS_FTIP>
-__global__ __launch_bounds__(kBlock, MP_PK_MINW) void k_id_pk_persist(const MpModel<float>* __restrict__ Mdev,
-                                                             const MpCall<float> C, const float* __restrict__ q,
-                                                             const float* __restrict__ qd, const float* __restrict__ qdd,
-                                                             float* __restrict__ tau, long pairs) {
-  const long stride = (long)gridDim.x * kBlock;
-  long p = (long)blockIdx.x * kBlock + threadIdx.x;
-  if (p >= pairs) return;
-  float fa[2 * N], fb[2 * N], fc[2 * N];
-  RunIO<float, 2 * N>::load(q, p, fa);
-  RunIO<float, 2 * N>::load(qd, p, fb);
-  RunIO<float, 2 * N>::load(qdd, p, fc);
-  while (true) {
-    mp_f2 a[N], b[N], c[N], t[N];
-#pragma unroll
-    for (int j = 0; j < N; ++j) { a[j] = (mp_f2){fa[j], fa[N + j]}; b[j] = (mp_f2){fb[j], fb[N + j]}; c[j] = (mp_f2){fc[j], fc[N + j]}; }
-    const long pn = p + stride;
-    const bool more = pn < pairs;
-    if (more) {  // prefetch: these loads are only waited for at the top of the next iteration
-      RunIO<float, 2 * N>::load(q, pn, fa);
-      RunIO<float, 2 * N>::load(qd, pn, fb);
-      RunIO<float, 2 * N>::load(qdd, pn, fc);
-    }
-    MpModelConstF* Mc = (MpModelConstF*)Mdev;
-    asm volatile("" : "+s"(Mc));  // opaque to LICM / CSE: constants are (re)loaded where they are used
-    MpJointState<mp_f2, N> js;
-    mp_joint_state<mp_f2, N>(*Mc, a, js);
-    mp_rnea<mp_f2, N, HAS_FTIP>(*Mc, C, js, b, c, t);
-    MpBad<mp_f2> bad;
-    bad.add(a); bad.add(b); bad.add(c);
-#pragma unroll
-    for (int j = 0; j < N; ++j) t[j] = mp_clip(t[j], Mc->taumin[j], Mc->taumax[j]);
-    store_pair<N>(tau, p, t, bad);
-    if (!more) break;
-    p = pn;
-  }
 }
 
 template <int N, bool HAS_FTIP>
@@ -227,8 +194,7 @@ __global__ __launch_bounds__(kFdBlock, (sizeof(T) == 4 ? 2 : 1)) void k_fd_traj(
                                                       float* __restrict__ pos, float* __restrict__ vel, float* __restrict__ acc) {
   __shared__ unsigned lds[MpFdTile<T, N, HAS_FTIP>::DWORDS];
   const long b = (long)blockIdx.x * kFdBlock + threadIdx.x;  // lanes past the batch stay (wave-cooperative stores)
-  mp_body_fd_traj<T, N, HAS_FTIP>(M, C, theta0, dtheta0, taumat, Ftipmat, b, B, Nt, h, intRes, pos, vel, acc, lds, (int)threadIdx.x,
-                                  mp_fd_first_rows<N>(blockIdx.x));
+  mp_body_fd_traj<T, N, HAS_FTIP>(M, C, theta0, dtheta0, taumat, Ftipmat, b, B, Nt, h, intRes, pos, vel, acc, lds, (int)threadIdx.x);
 }
 
 // the roll-out on the time-major device layout (mp_body_fd_traj_tm): no LDS, 64-thread blocks so that the 2048 waves of a
@@ -251,20 +217,6 @@ __global__ __launch_bounds__(kBlock) void k_transpose_rows(const unsigned* __res
   const unsigned gx = (unsigned)((inner + TI - 1) / TI);  // tiles along `inner`; the grid is one-dimensional
   const unsigned ty = blockIdx.x / gx, tx = blockIdx.x - ty * gx;
   mp_body_transpose_rows(src, dst, outer, inner, W, (long)ty * MP_TR_TO, (long)tx * TI, tr_lds, (int)threadIdx.x, kBlock);
-}
-
-// float32, two trajectories per lane (packed math); the tile is twice as wide, so DOF 8 with wrenches is 60 KB
-template <int N, bool HAS_FTIP>
-__global__ __launch_bounds__(kFdBlock) void k_fd_traj_pk(const MpModel<float> M, const MpCall<float> C,
-                                                         const float* __restrict__ theta0, const float* __restrict__ dtheta0,
-                                                         const float* __restrict__ taumat, const float* __restrict__ Ftipmat,
-                                                         long B, long Nt, float h, int intRes, float* __restrict__ pos,
-                                                         float* __restrict__ vel, float* __restrict__ acc) {
-  __shared__ unsigned lds[MpFdTile<float, N, HAS_FTIP, 128>::DWORDS];
-  const long p = (long)blockIdx.x * kFdBlock + threadIdx.x;
-  if (2 * p >= B) return;
-  mp_body_fd_traj_pk<N, HAS_FTIP>(M, C, theta0, dtheta0, taumat, Ftipmat, p, B, Nt, h, intRes, pos, vel, acc, lds,
-                                  (int)threadIdx.x);
 }
 
 // ------------------------------------------------------------------- Cartesian straight-line path
@@ -396,16 +348,6 @@ inline bool use_packed_f32() {
 
 }  // namespace
 
-hipError_t mpk_id_f32_persist(hipStream_t s, const MpModel<float>* d_model, int n, const MpCall<float>& C, bool ftip,
-                              const float* q, const float* qd, const float* qdd, float* tau, long pairs, int blocks) {
-  if (pairs <= 0) return hipSuccess;
-  MP_DISPATCH_N(n, {
-    if (ftip) hipLaunchKernelGGL((k_id_pk_persist<N, true>), dim3(blocks), dim3(kBlock), 0, s, d_model, C, q, qd, qdd, tau, pairs);
-    else hipLaunchKernelGGL((k_id_pk_persist<N, false>), dim3(blocks), dim3(kBlock), 0, s, d_model, C, q, qd, qdd, tau, pairs);
-  })
-  return hipGetLastError();
-}
-
 // streaming probes for the roofline: dst = a (one read per write) or dst = a + b + c (the 3 : 1 byte mix of the ID kernels)
 typedef float mp_f4v __attribute__((ext_vector_type(4)));
 template <int READS>
@@ -451,6 +393,18 @@ hipError_t mpk_id<float>(hipStream_t s, const MpModel<float>& M, const MpCall<fl
   MP_DISPATCH_N(M.n, {
     if (ftip) hipLaunchKernelGGL((k_id<T, N, true>), dim3(grid_for(rest)), dim3(kBlock), 0, s, M, C, q + off, qd + off, qdd + off, tau + off, rest);
     else hipLaunchKernelGGL((k_id<T, N, false>), dim3(grid_for(rest)), dim3(kBlock), 0, s, M, C, q + off, qd + off, qdd + off, tau + off, rest);
+  })
+  return hipGetLastError();
+}
+
+// one row per lane, model through a device pointer (k_id_dm)
+hipError_t mpk_id_dm(hipStream_t s, const MpModel<float>* d_model, int n, const MpCall<float>& C, bool ftip, const float* q,
+                     const float* qd, const float* qdd, float* tau, long rows) {
+  if (rows <= 0) return hipSuccess;
+  using T = float;
+  MP_DISPATCH_N(n, {
+    if (ftip) hipLaunchKernelGGL((k_id_dm<T, N, true>), dim3(grid_for(rows)), dim3(kBlock), 0, s, d_model, C, q, qd, qdd, tau, rows);
+    else hipLaunchKernelGGL((k_id_dm<T, N, false>), dim3(grid_for(rows)), dim3(kBlock), 0, s, d_model, C, q, qd, qdd, tau, rows);
   })
   return hipGetLastError();
 }
@@ -562,39 +516,10 @@ template hipError_t mpk_forward_dynamics<float>(hipStream_t, const MpModel<float
 template hipError_t mpk_forward_dynamics<double>(hipStream_t, const MpModel<double>&, const MpCall<double>&, bool,
                                                  const double*, const double*, const double*, double*, long);
 
-// roll-out variant for float32 (A/B switch): MANIPULAPY_HIP_FD = "scalar" (default: one trajectory per lane) | "packed"
-// (two per lane, v_pk_* math).  Measured on c5 and at B = 1 M: packed is 8-10 % SLOWER - it needs > 128 VGPRs, so one
-// wave per SIMD is resident and nothing hides the dependent-issue stalls of the packed pipeline (57 % VALU utilisation
-// against 90 % for the scalar kernel at two waves per SIMD), and the specialised scalar code folds constants into
-// v_fmamk / v_fmaak literals that packed instructions cannot take (1379 VALU per step vs 1870 per pair).
-bool mpk_fd_packed() {
-  static const bool packed = [] {
-    const char* e = getenv("MANIPULAPY_HIP_FD");
-    return e && e[0] == 'p';
-  }();
-  return packed;
-}
-
-static hipError_t fd_traj_pk(hipStream_t s, const MpModel<float>& M, const MpCall<float>& C, const float* theta0,
-                             const float* dtheta0, const float* taumat, const float* Ftipmat, long B, long Nt, float h,
-                             int intRes, float* pos, float* vel, float* acc) {
-  const unsigned grid = (unsigned)(((B + 1) / 2 + kFdBlock - 1) / kFdBlock);
-  MP_DISPATCH_N(M.n, {
-    if (Ftipmat) hipLaunchKernelGGL((k_fd_traj_pk<N, true>), dim3(grid), dim3(kFdBlock), 0, s, M, C, theta0, dtheta0, taumat, Ftipmat, B, Nt, h, intRes, pos, vel, acc);
-    else hipLaunchKernelGGL((k_fd_traj_pk<N, false>), dim3(grid), dim3(kFdBlock), 0, s, M, C, theta0, dtheta0, taumat, Ftipmat, B, Nt, h, intRes, pos, vel, acc);
-  })
-  return hipGetLastError();
-}
-static hipError_t fd_traj_pk(hipStream_t, const MpModel<double>&, const MpCall<double>&, const double*, const double*,
-                             const double*, const double*, long, long, double, int, float*, float*, float*) {
-  return hipErrorInvalidValue;  // never selected for float64
-}
-
 template <typename T>
 hipError_t mpk_fd_traj(hipStream_t s, const MpModel<T>& M, const MpCall<T>& C, const T* theta0, const T* dtheta0,
                        const T* taumat, const T* Ftipmat, long B, long Nt, T h, int intRes, float* pos, float* vel, float* acc) {
   if (B <= 0 || Nt <= 0) return hipSuccess;
-  if (sizeof(T) == 4 && mpk_fd_packed()) return fd_traj_pk(s, M, C, theta0, dtheta0, taumat, Ftipmat, B, Nt, h, intRes, pos, vel, acc);
   MP_DISPATCH_N(M.n, {
     if (Ftipmat) hipLaunchKernelGGL((k_fd_traj<T, N, true>), dim3((unsigned)((B + kFdBlock - 1) / kFdBlock)), dim3(kFdBlock), 0, s, M, C, theta0, dtheta0, taumat, Ftipmat, B, Nt, h, intRes, pos, vel, acc);
     else hipLaunchKernelGGL((k_fd_traj<T, N, false>), dim3((unsigned)((B + kFdBlock - 1) / kFdBlock)), dim3(kFdBlock), 0, s, M, C, theta0, dtheta0, taumat, Ftipmat, B, Nt, h, intRes, pos, vel, acc);

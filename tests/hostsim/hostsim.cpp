@@ -4,7 +4,6 @@
 #include <cstring>
 
 #include "../../manipulapy_amd/csrc/mp_core.h"
-#include "../../manipulapy_amd/csrc/mp_pair.h"
 #include "../../manipulapy_amd/csrc/mp_ik.h"
 #include "../../manipulapy_amd/csrc/mp_model_compile.h"
 
@@ -86,7 +85,7 @@ int run(const MpModel<double>& Md, const MpCall<double>& Cd, bool ftip, long row
 namespace {
 // forward-dynamics pieces on the host: mode 0 = mass matrix (out: rows x n x n), 1 = forward dynamics
 // (out: rows x n), 2 = one trajectory roll-out like k_fd_traj (out: 3 x N x n, float32 rounded rows)
-template <typename T, int N, bool PAIR = false>
+template <typename T, int N>
 void run_fd(const MpModel<T>& M, const MpCall<T>& C, int mode, long rows, const double* q, const double* qd,
             const double* tau, const double* Ftipmat, double dt, int intRes, double* out) {
   if (mode == 0 || mode == 3) {  // 0: n unit-acceleration recursions, 3: composite-rigid-body algorithm
@@ -106,8 +105,7 @@ void run_fd(const MpModel<T>& M, const MpCall<T>& C, int mode, long rows, const 
     for (long r = 0; r < rows; ++r) {
       T a[N], b[N], t[N], o[N];
       for (int j = 0; j < N; ++j) { a[j] = (T)q[r * N + j]; b[j] = (T)qd[r * N + j]; t[j] = (T)tau[r * N + j]; }
-      if constexpr (PAIR && sizeof(T) == 4 && N >= 2) mp_p_forward_dynamics<N, true>(M, C.a0, tn, tf, a, b, t, o);
-      else mp_forward_dynamics<T, N, true>(M, C.a0, tn, tf, a, b, t, o);
+      mp_forward_dynamics<T, N, true>(M, C.a0, tn, tf, a, b, t, o);
       for (int j = 0; j < N; ++j) out[r * N + j] = (double)o[j];
     }
   } else {
@@ -126,8 +124,7 @@ void run_fd(const MpModel<T>& M, const MpCall<T>& C, int mode, long rows, const 
         mp_wrench_to_frame1(M, F, tn, tf);
       }
       for (int s = 0; s < intRes; ++s) {
-        if constexpr (PAIR && sizeof(T) == 4 && N >= 2) mp_p_forward_dynamics<N, true>(M, C.a0, tn, tf, a, b, t, last);
-        else mp_forward_dynamics<T, N, true>(M, C.a0, tn, tf, a, b, t, last);
+        mp_forward_dynamics<T, N, true>(M, C.a0, tn, tf, a, b, t, last);
         for (int j = 0; j < N; ++j) {
           b[j] = b[j] + last[j] * h;
           a[j] = mp_clip(a[j] + b[j] * h, M.qmin[j], M.qmax[j]);
@@ -137,7 +134,7 @@ void run_fd(const MpModel<T>& M, const MpCall<T>& C, int mode, long rows, const 
     }
   }
 }
-template <typename T, bool PAIR = false>
+template <typename T>
 int run_fd_t(const MpModel<double>& Md, const MpCall<double>& Cd, int mode, long rows, const double* q, const double* qd,
              const double* tau, const double* Ftipmat, double dt, int intRes, double* out) {
   MpModel<T> M;
@@ -145,7 +142,7 @@ int run_fd_t(const MpModel<double>& Md, const MpCall<double>& Cd, int mode, long
   mp_model_cast(Md, &M);
   mp_call_cast(Cd, &C);
   switch (Md.n) {
-#define CASE(N) case N: run_fd<T, N, PAIR>(M, C, mode, rows, q, qd, tau, Ftipmat, dt, intRes, out); return 0;
+#define CASE(N) case N: run_fd<T, N>(M, C, mode, rows, q, qd, tau, Ftipmat, dt, intRes, out); return 0;
     CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
 #undef CASE
   }
@@ -162,7 +159,6 @@ extern "C" int hostsim_fd(int n, const double* S, const double* Mcom, const doub
   if (rc) return rc;
   MpCall<double> Cd;
   mp_make_call(Md, g, Ftip, &Cd);
-  if (use_f32 == 2) return run_fd_t<float, true>(Md, Cd, mode, rows, q, qd, tau, Ftipmat, dt, intRes, out);  // pair-native (mp_pair.h)
   return use_f32 ? run_fd_t<float>(Md, Cd, mode, rows, q, qd, tau, Ftipmat, dt, intRes, out)
                  : run_fd_t<double>(Md, Cd, mode, rows, q, qd, tau, Ftipmat, dt, intRes, out);
 }

@@ -1732,3 +1732,39 @@ def test_transpose_rows_and_time_major_edge_cases(tables):
         assert z[0].shape == (4, 0, 6)
     finally:
         ctx.destroy()
+
+
+def test_id_f32_large_random_sample_two_level_bound(tables):
+    """300 000 rows of config c2's own input distribution (start / end uniform over UR5's +-2 pi limits, quintic, Tf = 2:
+    velocities up to 12 rad/s) through the generic and the robot-specialised float32 kernels against the pinned C oracle,
+    with the bound bench.py asserts on every run: 1e-4 |ref| + 5e-6 max|row| element-wise, and for the few rows per
+    hundred thousand whose torque is a small difference of large gravity / velocity-product terms (the only ones that miss
+    it) 1e-4 |ref| + 2e-5 x the row's largest term.  Fourteen rows per robot cannot meet such rows; this sample does."""
+    import bench
+    from manipulapy_amd import _hip
+    from oracle import c_oracle
+
+    tab = tables["ur5"]
+    lim = tab.joint_limits
+    rng = np.random.default_rng(20260705 + 2)
+    s_ = rng.uniform(lim[:, 0], lim[:, 1], (300, 6)).astype(np.float32)
+    e_ = rng.uniform(lim[:, 0], lim[:, 1], (300, 6)).astype(np.float32)
+    o = ref.batch_joint_trajectory(lim, s_, e_, 2.0, 1000, 5)
+    q, qd, qdd = (o[k].reshape(-1, 6) for k in ("positions", "velocities", "accelerations"))
+    want = c_oracle.inverse_dynamics_rows(tab, q.astype(np.float64), qd.astype(np.float64), qdd.astype(np.float64))[0]
+    terms = bench.id_terms(tab, q, qd, qdd)
+    ctx = _hip.HipContext(0)
+    try:
+        for specialise in (False, True):
+            m = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee, lim)
+            if specialise:
+                ctx.specialize(m)
+            tau = ctx.id_trajectory_host(m, q, qd, qdd, dtype=np.float32)
+            par = bench.parity_rows(tau, want, "f32", terms)
+            assert par["ok"], (specialise, par)
+            assert par["rows_over_first_bound"] <= 30, par   # a handful in 300 000; a broken recursion fails by the thousand
+            fused = ctx.traj_id_fused_host(m, s_, e_, 2.0, 1000, 5).reshape(-1, 6)
+            par = bench.parity_rows(fused, want, "f32", terms)
+            assert par["ok"] and par["rows_over_first_bound"] <= 30, (specialise, par)
+    finally:
+        ctx.destroy()

@@ -229,7 +229,7 @@ def hostsim():
     """g++ build of the SAME templates the kernels instantiate (tests/hostsim/hostsim.cpp)."""
     src = os.path.join(ROOT, "tests", "hostsim", "hostsim.cpp")
     out = os.path.join(ROOT, "tests", "hostsim", "libmp_hostsim.so")
-    deps = [src] + [os.path.join(ROOT, "manipulapy_amd", "csrc", f) for f in ("mp_core.h", "mp_pair.h", "mp_ik.h", "mp_model.h", "mp_model_compile.cpp", "mp_model_compile.h")]
+    deps = [src] + [os.path.join(ROOT, "manipulapy_amd", "csrc", f) for f in ("mp_core.h", "mp_ik.h", "mp_model.h", "mp_model_compile.cpp", "mp_model_compile.h")]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
         subprocess.run([HOST_CXX, "-O2", "-std=c++17", "-ffp-contract=fast", "-shared", "-fPIC", "-o", out, src,
                         os.path.join(ROOT, "manipulapy_amd", "csrc", "mp_model_compile.cpp")], check=True)
@@ -328,34 +328,6 @@ def test_device_fd_trajectory_on_host(hostsim):
                          int(z["intRes"]), f32, outshape=(3, N, 6))
         for k, key in enumerate(("positions", "velocities", "accelerations")):
             assert np.abs(out[k] - z[key]).max() <= tol * max(1.0, float(np.abs(z[key]).max()))
-
-
-@pytest.mark.parametrize("robot", ROBOTS)
-def test_pair_native_forward_dynamics_on_host(robot, hostsim, tables, dyn_golden):
-    """mp_pair.h (float32 forward dynamics with one trajectory in both halves of the packed instructions: what the
-    float32 roll-out and per-row forward-dynamics kernels run) against the scalar float32 recursion and the float64 one,
-    per row, and over the reference's N = 100 roll-out dump (xarm6)."""
-    tab, z = tables[robot], dyn_golden[robot]
-    K, n = len(z["thetas"]), tab.n
-    e32, ep = [], []
-    for i in range(K):
-        a = (tab, 1, 1, z["thetas"][i:i + 1], z["dthetas"][i:i + 1], z["inverse_dynamics"][i:i + 1], z["g"], z["ftips"][i])
-        q64 = hostsim.fd(*a, f32=0, outshape=(1, n))[0]
-        q32 = hostsim.fd(*a, f32=1, outshape=(1, n))[0]
-        qp = hostsim.fd(*a, f32=2, outshape=(1, n))[0]
-        scale = max(1.0, float(np.abs(q64).max()))
-        e32.append(np.abs(q32 - q64).max() / scale); ep.append(np.abs(qp - q64).max() / scale)
-    # as accurate as the scalar float32 recursion: a single row's error is rounding noise times cond(M) (up to 1e4 for
-    # the 8e-5 kg.m^2 wrists), so the two are compared over the 25 configurations, not row by row
-    assert np.median(ep) <= 3.0 * np.median(e32) + 1e-6 and max(ep) <= 4.0 * max(e32) + 2e-5, (np.median(e32), np.median(ep), max(e32), max(ep))
-    if robot == "xarm6":
-        f = np.load(golden_path("fd_rollout100_xarm6.npz"))
-        t2 = ref.load_tables(golden_path("model_xarm6.npz")); t2.joint_limits = f["joint_limits"]
-        for b in range(3):
-            x = [v.astype(np.float32).astype(np.float64) for v in (f["theta0"][b], f["dtheta0"][b], f["taumat"][b], f["Ftipmat"][b])]
-            out = hostsim.fd(t2, 2, 100, x[0], x[1], x[2], f["g"], np.zeros(6), x[3], 0.01, 1, 2, outshape=(3, 100, 6))
-            for k, key in enumerate(("positions", "velocities", "accelerations")):
-                assert np.abs(out[k] - f[key][b]).max() <= 1e-4 * np.abs(f[key][b]).max(), (b, key)
 
 
 def test_device_cartesian_trajectory_on_host(hostsim):
