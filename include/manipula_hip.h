@@ -301,6 +301,13 @@ int mp_fd_trajectory_cpu_f32(const mp_model* model, const float* theta0, const f
 int mp_fd_trajectory_cpu_f64(const mp_model* model, const double* theta0, const double* dtheta0, const double* taumat,
                              const double* Ftipmat, int64_t B, int64_t N, const double* g, double dt, int intRes, float* pos,
                              float* vel, float* acc, int nthreads);
+/* Batched inverse kinematics on the host: the iteration of mp_inverse_kinematics_f64 (reference kinematics/ik.py:39-311), one
+ * problem after the other per thread; same arguments and results as mp_inverse_kinematics_host_f64. */
+int mp_inverse_kinematics_cpu_f64(const mp_model* model, const double* T_desired, const double* theta0, int64_t B,
+                                  const double* joint_limits, double eomg, double ev, int max_iterations, double damping,
+                                  double step_cap, double weight_orientation, double weight_position, int adaptive_tuning,
+                                  int backtracking, uint32_t seed, double* theta, int32_t* success, int32_t* iterations,
+                                  int32_t* restarts, int nthreads);
 int mp_cartesian_trajectory_cpu_f32(const double* Xstart, const double* Xend, int64_t B, int64_t N, double Tf, int method,
                                     float* pos, float* vel, float* acc, float* orient, int nthreads);
 

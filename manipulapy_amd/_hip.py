@@ -116,6 +116,7 @@ SIGNATURES = {
     "mp_forward_dynamics_cpu_f64": (ctypes.c_int, [_vp, _c_dp, _c_dp, _c_dp, _i64, _c_dp, _c_dp, _c_dp, ctypes.c_int]),
     "mp_fd_trajectory_cpu_f32": (ctypes.c_int, [_vp, _c_fp, _c_fp, _c_fp, _c_fp, _i64, _i64, _c_dp, ctypes.c_double, ctypes.c_int, _c_fp, _c_fp, _c_fp, ctypes.c_int]),
     "mp_fd_trajectory_cpu_f64": (ctypes.c_int, [_vp, _c_dp, _c_dp, _c_dp, _c_dp, _i64, _i64, _c_dp, ctypes.c_double, ctypes.c_int, _c_fp, _c_fp, _c_fp, ctypes.c_int]),
+    "mp_inverse_kinematics_cpu_f64": (ctypes.c_int, [_vp, _c_dp, _c_dp, ctypes.c_int64, _c_dp, ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, _c_dp, _vp, _vp, _vp, ctypes.c_int]),
     "mp_cartesian_trajectory_cpu_f32": (ctypes.c_int, [_c_dp, _c_dp, _i64, _i64, ctypes.c_double, ctypes.c_int, _c_fp, _c_fp, _c_fp, _c_fp, ctypes.c_int]),
     "mp_comm_unique_id": (ctypes.c_int, [ctypes.POINTER(ctypes.c_uint8)]),
     "mp_comm_create": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint8), ctypes.c_int, ctypes.c_int, ctypes.POINTER(_vp)]),
@@ -827,6 +828,29 @@ def cpu_forward_dynamics(model: "HipModel", q, qd, tau, g=None, Ftip=None, nthre
                                                       _dptr(_vec_or_none(g, 3, "g")), _dptr(_vec_or_none(Ftip, 6, "Ftip")), _dptr(out),
                                                       int(nthreads)))
     return out
+
+
+def cpu_inverse_kinematics(model: "HipModel", T_desired, theta0, joint_limits=None, eomg=1e-6, ev=1e-6, max_iterations=10000,
+                           damping=2e-2, step_cap=0.3, weight_orientation=1.0, weight_position=1.0, adaptive_tuning=False,
+                           backtracking=False, seed=1234, nthreads: int = 0):
+    """HipContext.inverse_kinematics_host on the host cores (mp_inverse_kinematics_cpu_f64): same arguments, same results."""
+    T = _as_c(T_desired, np.float64, name="T_desired")
+    if T.ndim != 3 or T.shape[1:] != (4, 4):
+        raise ValueError(f"T_desired must be (B, 4, 4), got {T.shape}")
+    B = T.shape[0]
+    th0 = _as_c(theta0, np.float64, (B, model.n), "thetalist0")
+    lim = None
+    if joint_limits is not None:
+        lim = np.array([[-np.inf if lo is None else lo, np.inf if hi is None else hi] for lo, hi in joint_limits], dtype=np.float64)
+        if lim.shape != (model.n, 2):
+            raise ValueError(f"joint_limits must be ({model.n}, 2), got {lim.shape}")
+    th = np.zeros((B, model.n))
+    ok, it, rs = (np.zeros(B, dtype=np.int32) for _ in range(3))
+    _check(load_library().mp_inverse_kinematics_cpu_f64(
+        model.handle, _dptr(T), _dptr(th0), B, _dptr(lim), float(eomg), float(ev), int(max_iterations), float(damping), float(step_cap),
+        float(weight_orientation), float(weight_position), int(bool(adaptive_tuning)), int(bool(backtracking)), int(seed) & 0xFFFFFFFF,
+        _dptr(th), ok.ctypes.data_as(_vp), it.ctypes.data_as(_vp), rs.ctypes.data_as(_vp), int(nthreads)))
+    return th, ok.astype(bool), it, rs
 
 
 def cpu_fd_trajectory(model: "HipModel", theta0, dtheta0, taumat, g, Ftipmat, dt, intRes, dtype=np.float64, nthreads: int = 0):

@@ -267,9 +267,12 @@ int device_model(mp_ctx* ctx, const mp_model* model, const MpModel<float>** out)
   return MP_OK;
 }
 
-// MANIPULAPY_HIP_GENERIC = "dm": the generic float32 inverse dynamics reads the model from device memory, one row per lane
+// Which generic (no run-time specialisation) float32 inverse-dynamics kernel runs.  Default: one row per lane with the model read
+// from device memory joint by joint (k_id_dm: c2 0.100 ms against 0.119 packed / 0.127 scalar with the model in the kernel
+// arguments, c4 0.213 / 0.221 / 0.281; tools/ab_generic.sh).  MANIPULAPY_HIP_F32 = "packed" | "scalar" selects the two
+// kernel-argument forms (A/B measurements).
 int generic_f32_mode() {
-  static const int mode = [] { const char* e = getenv("MANIPULAPY_HIP_GENERIC"); return (e && e[0] == 'd') ? 2 : 0; }();
+  static const int mode = [] { const char* e = getenv("MANIPULAPY_HIP_F32"); return (e && (e[0] == 'p' || e[0] == 's')) ? 0 : 2; }();
   return mode;
 }
 

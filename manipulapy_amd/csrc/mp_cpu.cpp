@@ -14,6 +14,7 @@
 
 #include "../../include/manipula_hip.h"
 #include "mp_core.h"
+#include "mp_ik.h"
 #include "mp_handles.h"
 #include "mp_model_compile.h"
 
@@ -288,6 +289,47 @@ int mp_fd_trajectory_cpu_f64(const mp_model* model, const double* theta0, const 
                              const double* Ftipmat, int64_t B, int64_t N, const double* g, double dt, int intRes, float* pos,
                              float* vel, float* acc, int nthreads) {
   return fd_trajectory_cpu<double>(model, theta0, dtheta0, taumat, Ftipmat, B, N, g, dt, intRes, pos, vel, acc, nthreads);
+}
+
+int mp_inverse_kinematics_cpu_f64(const mp_model* model, const double* T_desired, const double* theta0, int64_t B,
+                                  const double* joint_limits, double eomg, double ev, int max_iterations, double damping,
+                                  double step_cap, double weight_orientation, double weight_position, int adaptive_tuning,
+                                  int backtracking, uint32_t seed, double* theta, int32_t* success, int32_t* iterations,
+                                  int32_t* restarts, int nthreads) {
+  if (!model) return fail("mp_inverse_kinematics_cpu_f64: null model");
+  if (B < 0) return fail("mp_inverse_kinematics_cpu_f64: negative problem count");
+  if (B == 0) return MP_OK;
+  if (!T_desired || !theta0 || !theta || !success || !iterations || !restarts) return fail("mp_inverse_kinematics_cpu_f64: null pointer");
+  if (max_iterations < 1) return fail("mp_inverse_kinematics_cpu_f64: max_iterations must be at least 1");
+  if (!(eomg > 0 && ev > 0 && damping >= 0 && step_cap > 0))
+    return fail("mp_inverse_kinematics_cpu_f64: eomg, ev, step_cap must be positive and damping non-negative");
+  MpIkParams P;
+  P.eomg = eomg; P.ev = ev; P.damping = damping; P.step_cap = step_cap; P.w_o = weight_orientation; P.w_p = weight_position;
+  P.max_iterations = max_iterations; P.seed = seed;
+  P.adaptive_tuning = adaptive_tuning ? 1 : 0; P.backtracking = backtracking ? 1 : 0;
+  const MpModel<double>& M = model->d;
+  for (int j = 0; j < MP_MAX_DOF; ++j) {
+    P.lo[j] = (j < M.n && joint_limits) ? joint_limits[2 * j] : -HUGE_VAL;
+    P.hi[j] = (j < M.n && joint_limits) ? joint_limits[2 * j + 1] : HUGE_VAL;
+    if (P.lo[j] > P.hi[j]) return fail("mp_inverse_kinematics_cpu_f64: a joint has its lower limit above its upper limit");
+  }
+  // the body of k_ik (csrc/mp_kernels.hip) per problem: begin, iterate until the iteration reports done
+  MP_CPU_DISPATCH(M.n, {
+    parallel_for(B, 1, nthreads, [&](int64_t lo, int64_t hi) {
+      for (int64_t row = lo; row < hi; ++row) {
+        MpIkState<N> S;
+        for (int j = 0; j < N; ++j) S.theta[j] = theta0[row * N + j];
+        mp_ik_begin(S, P);
+        int done = 0;
+        while (!(done = mp_ik_iterate<N>(M, P, S, T_desired + row * 16, theta0 + row * N))) {}
+        for (int j = 0; j < N; ++j) theta[row * N + j] = S.theta[j];
+        success[row] = done == 2 ? 1 : 0;
+        iterations[row] = S.k + 1;
+        restarts[row] = S.restarts;
+      }
+    });
+  })
+  return MP_OK;
 }
 
 int mp_cartesian_trajectory_cpu_f32(const double* Xstart, const double* Xend, int64_t B, int64_t N, double Tf, int method,

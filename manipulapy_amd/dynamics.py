@@ -15,12 +15,19 @@ active, its CPU launcher (the C ABI's *_cpu twin, same per-row code) with the Nu
 which are exact identities of tau = M qdd + c + g + Js^T F.  2-D inputs (rows, n) evaluate all rows
 in one launch.  There is no value-keyed cache (the
 reference's caches exist to amortise its 1 + 2n mass-matrix evaluations per point, which the
-analytic recursion does not need) and no legacy (Mlist_per_link=None) approximation.
+analytic recursion does not need).
+
+The legacy object (Mlist_per_link=None: what URDF.to_manipulator_dynamics() and hand-built models give,
+reference urdf/core.py:795-817) is reproduced, not rejected: the reference evaluates it with an approximation it documents
+as incorrect and warns about (dynamics/mass_matrix.py:45-57, :101-132, forces.py:81-95, :136-154).  That
+approximation is not rigid-body dynamics, so it cannot be a compiled link-frame model; it runs on the host in NumPy under
+every backend (same formulas, same warnings, pinned by tests/golden/legacy_dynamics.npz).
 """
 from __future__ import annotations
 
 import logging
 import os
+import warnings
 from typing import Optional
 
 import numpy as np
@@ -50,9 +57,9 @@ class ManipulatorDynamics(SerialManipulator):
         (the planner passes its own float32 limits)."""
         if self.Mlist_per_link is None:
             raise NotImplementedError(
-                "ManipulatorDynamics without Mlist_per_link: the reference's legacy approximation "
-                "(dynamics/mass_matrix.py:101-132) is documented as incorrect and is not reproduced; construct "
-                "the dynamics with per-link CoM transforms (URDFToSerialManipulator does).")
+                "ManipulatorDynamics without Mlist_per_link has no compiled model: its legacy approximation "
+                "(dynamics/mass_matrix.py:101-132) is evaluated on the host (mass_matrix / gravity_forces / inverse_dynamics / "
+                "forward_dynamics and the planner's trajectory methods do that by themselves)")
         if joint_limits is None and torque_limits is None:
             if self._dyn_model is None:
                 self._dyn_model = _hip.HipModel(self.S_list, np.asarray(self.Mlist_per_link), np.asarray(self.Glist), self._M_ee)
@@ -79,25 +86,93 @@ class ManipulatorDynamics(SerialManipulator):
         return execute_registered_kernel("dynamics.inverse_trajectory", self._model_for(np.shape(q)[0]), q, qd, qdd, g, Ftip,
                                          dtype=np.float64)
 
+    # ---- the legacy (Mlist_per_link=None) approximation, on the host
+    @property
+    def _legacy(self) -> bool:
+        return self.Mlist_per_link is None
+
+    def _mass_matrix_legacy(self, q: np.ndarray) -> np.ndarray:
+        """Row i = J_i^T (Ad_i^T G_i Ad_i) J_s with Ad_i = Ad(FK(q[:i + 1])), symmetrised
+        (reference dynamics/mass_matrix.py:101-132; documented there as incorrect, kept for hand-built models)."""
+        from .utils import adjoint_transform
+
+        n = len(q)
+        J = self.jacobian(q, frame="space")
+        M = np.zeros((n, n))
+        for i in range(n):
+            Ad = adjoint_transform(self.forward_kinematics(q[: i + 1], frame="space"))
+            M[i] = J[:, i] @ (Ad.T @ np.asarray(self.Glist[i], dtype=np.float64) @ Ad) @ J
+        return 0.5 * (M + M.T)
+
+    def _gravity_forces_legacy(self, q: np.ndarray, g: np.ndarray) -> np.ndarray:
+        """(R_i^T g) . (column sums of G_i's inertia block), R_i from FK(q[:i + 1]) (reference dynamics/forces.py:136-154)."""
+        out = np.zeros(len(q))
+        for i in range(len(q)):
+            R = self.forward_kinematics(q[: i + 1], "space")[:3, :3]
+            out[i] = (R.T @ g[:3]) @ np.asarray(self.Glist[i], dtype=np.float64)[:3, :3].sum(axis=0)
+        return out
+
+    def _warn_legacy(self, what: str, fix: str) -> None:
+        warnings.warn(f"{what} called without Mlist_per_link \u2014 using legacy approximation (incorrect for non-trivial "
+                      f"robots). Construct ManipulatorDynamics via URDFToSerialManipulator to get accurate {fix}.", stacklevel=3)
+
+    def _velocity_quadratic_legacy(self, q: np.ndarray, qd: np.ndarray, epsilon: float = 1e-6) -> np.ndarray:
+        """Christoffel form on the central difference of the (legacy) mass matrix (reference dynamics/cache.py:23-56,
+        forces.py:45-59)."""
+        n = len(q)
+        dM = np.zeros((n, n, n))
+        for k in range(n):
+            e = np.zeros(n)
+            e[k] = epsilon
+            dM[:, :, k] = (self.mass_matrix(q + e) - self.mass_matrix(q - e)) / (2.0 * epsilon)
+        c = np.zeros(n)
+        for i in range(n):
+            gamma = 0.5 * (dM[i] + dM[i].T - dM[:, :, i])
+            c[i] = qd @ gamma @ qd
+        return c
+
     # ---- public API
     def mass_matrix(self, thetalist) -> np.ndarray:
         """(n, n) mass matrix, or (rows, n, n) for a 2-D `thetalist`."""
+        if self._legacy:
+            self._warn_legacy("mass_matrix", "mass matrix")
+            q = np.asarray(thetalist, dtype=np.float64)
+            return self._mass_matrix_legacy(q) if q.ndim == 1 else np.stack([self._mass_matrix_legacy(r) for r in q])
         q = np.atleast_2d(np.asarray(thetalist, dtype=np.float64))
         M = execute_registered_kernel("dynamics.mass_matrix", self._model_for(q.shape[0]), q)
         return M if np.ndim(thetalist) == 2 else M[0]
 
     def velocity_quadratic_forces(self, thetalist, dthetalist) -> np.ndarray:
+        if self._legacy:
+            self._warn_legacy("mass_matrix", "mass matrix")   # (the reference warns once per uncached evaluation: 2n times here)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                return self._velocity_quadratic_legacy(np.asarray(thetalist, dtype=np.float64), np.asarray(dthetalist, dtype=np.float64))
         q = np.asarray(thetalist, dtype=np.float64)[None, :]
         qd = np.asarray(dthetalist, dtype=np.float64)[None, :]
         return self._id(q, qd, np.zeros_like(q), _ZERO3, None)[0]
 
     def gravity_forces(self, thetalist, g=None) -> np.ndarray:
-        q = np.asarray(thetalist, dtype=np.float64)[None, :]
         g = [0.0, 0.0, -9.81] if g is None else g
+        if self._legacy:
+            self._warn_legacy("gravity_forces", "gravity compensation")
+            return self._gravity_forces_legacy(np.asarray(thetalist, dtype=np.float64), np.asarray(g, dtype=np.float64))
+        q = np.asarray(thetalist, dtype=np.float64)[None, :]
         z = np.zeros_like(q)
         return self._id(q, z, z, g, None)[0]
 
+    def _legacy_terms(self, q, qd, g):
+        """M, c, g-forces and Js^T of the legacy model (each warns as the reference's does)."""
+        M = self.mass_matrix(q)
+        c = self.velocity_quadratic_forces(q, qd)
+        gf = self.gravity_forces(q, g)
+        return M, c, gf, self.jacobian(q).T
+
     def inverse_dynamics(self, thetalist, dthetalist, ddthetalist, g, Ftip) -> np.ndarray:
+        if self._legacy:   # M qdd + c + g + Js^T Ftip on the legacy terms (reference dynamics/id_fd.py:36-48)
+            q, qd = np.asarray(thetalist, dtype=np.float64), np.asarray(dthetalist, dtype=np.float64)
+            M, c, gf, Jt = self._legacy_terms(q, qd, g)
+            return M @ np.asarray(ddthetalist, dtype=np.float64) + c + gf + Jt @ np.asarray(Ftip, dtype=np.float64)
         q = np.asarray(thetalist, dtype=np.float64)[None, :]
         qd = np.asarray(dthetalist, dtype=np.float64)[None, :]
         qdd = np.asarray(ddthetalist, dtype=np.float64)[None, :]
@@ -105,6 +180,10 @@ class ManipulatorDynamics(SerialManipulator):
 
     def forward_dynamics(self, thetalist, dthetalist, taulist, g, Ftip) -> np.ndarray:
         """qdd (n,), or (rows, n) for 2-D inputs (one g / Ftip for all rows)."""
+        if self._legacy:   # solve(M, tau - c - g - Js^T Ftip) (reference dynamics/id_fd.py:71-83)
+            q, qd = np.asarray(thetalist, dtype=np.float64), np.asarray(dthetalist, dtype=np.float64)
+            M, c, gf, Jt = self._legacy_terms(q, qd, g)
+            return np.linalg.solve(M, np.asarray(taulist, dtype=np.float64) - c - gf - Jt @ np.asarray(Ftip, dtype=np.float64))
         q = np.atleast_2d(np.asarray(thetalist, dtype=np.float64))
         qd = np.atleast_2d(np.asarray(dthetalist, dtype=np.float64))
         tau = np.atleast_2d(np.asarray(taulist, dtype=np.float64))

@@ -81,31 +81,69 @@ class SerialManipulator:
 
     def _space_fk_jac(self, thetalist, want_T=True, want_J=True):
         q = np.atleast_2d(np.asarray(thetalist, dtype=np.float64))
-        n = self.S_list.shape[1]
-        if q.shape[1] != n:
-            raise ValueError(f"expected {n} joint values, got {q.shape[1]} (truncated chains are internal to the "
-                             "reference's mass matrix and not part of this API)")
         T, J, _ = execute_registered_kernel("kinematics.fk_jacobian", self._kin_model(), q, want_T=want_T, want_J=want_J)
         return T, J
 
-    def _require_consistent_B(self, frame: str) -> None:
-        if frame == "body" and not self._B_consistent:
-            raise NotImplementedError("body-frame kinematics needs B_list == Ad(M^-1) S_list in this build")
+    # ---- product of exponentials on the host, for what the compiled chain does not cover: a TRUNCATED joint vector
+    #      (reference kinematics/fk.py:59-70 / jacobian.py:62-73 loop over `thetalist`, so theta[:k] gives
+    #      prod_{j<k} exp([S_j] theta_j) . M - the reference's own mass matrix calls it that way, mass_matrix.py:71-75) and
+    #      body-frame results of a model whose B_list is not Ad(M^-1) S_list (fk.py:72-80, jacobian.py:74-91)
+    def _fk_poe(self, theta: np.ndarray, frame: str) -> np.ndarray:
+        from .utils import transform_from_twist
+
+        screws = self.S_list if frame == "space" else self.B_list
+        if len(theta) > screws.shape[1]:
+            raise IndexError(f"index {screws.shape[1]} is out of bounds for axis 1 with size {screws.shape[1]}")
+        T = np.eye(4)
+        for i, th in enumerate(theta):
+            T = T @ transform_from_twist(screws[:, i], th)
+        return T @ self._M_ee if frame == "space" else self._M_ee @ T
+
+    def _jacobian_poe(self, theta: np.ndarray, frame: str) -> np.ndarray:
+        from .utils import adjoint_transform, transform_from_twist
+
+        k = len(theta)
+        if k > self.S_list.shape[1]:
+            raise IndexError(f"index {self.S_list.shape[1]} is out of bounds for axis 1 with size {self.S_list.shape[1]}")
+        if k == 0:
+            if frame == "space":
+                return np.zeros((6, 0))
+            raise IndexError("list assignment index out of range")  # the reference seeds columns[n - 1] (jacobian.py:79)
+        T = np.eye(4)
+        cols = [None] * k
+        if frame == "space":
+            for i in range(k):
+                cols[i] = adjoint_transform(T) @ self.S_list[:, i]
+                T = T @ transform_from_twist(self.S_list[:, i], theta[i])
+        else:
+            cols[k - 1] = self.B_list[:, k - 1]
+            for i in range(k - 2, -1, -1):
+                T = T @ transform_from_twist(self.B_list[:, i + 1], -theta[i + 1])
+                cols[i] = adjoint_transform(T) @ self.B_list[:, i]
+        return np.stack(cols, axis=1)
+
+    def _needs_poe(self, thetalist, frame: str) -> bool:
+        return np.shape(thetalist)[-1] != self.S_list.shape[1] or (frame == "body" and not self._B_consistent)
 
     def forward_kinematics(self, thetalist, frame: str = "space") -> np.ndarray:
-        """End-effector pose (4, 4).  A 2-D `thetalist` (rows, n) returns (rows, 4, 4)."""
+        """End-effector pose (4, 4).  A 2-D `thetalist` (rows, n) returns (rows, 4, 4).  Fewer than n joint values give the
+        pose of the chain truncated after them, as in the reference (kinematics/fk.py:59-70)."""
         if frame not in ("space", "body"):
             raise ValueError("Invalid frame specified. Choose 'space' or 'body'.")
+        if self._needs_poe(thetalist, frame):
+            q = np.asarray(thetalist, dtype=np.float64)
+            return self._fk_poe(q, frame) if q.ndim == 1 else np.stack([self._fk_poe(r, frame) for r in q])
         # M . prod exp([B_i] q_i) == prod exp([S_i] q_i) . M whenever B = Ad(M^-1) S
-        self._require_consistent_B(frame)
         T, _ = self._space_fk_jac(thetalist, want_T=True, want_J=False)
         return T if np.ndim(thetalist) == 2 else T[0]
 
     def jacobian(self, thetalist, frame: str = "space") -> np.ndarray:
-        """(6, n) Jacobian, or (rows, 6, n) for a 2-D `thetalist`."""
+        """(6, n) Jacobian, or (rows, 6, n) for a 2-D `thetalist`; (6, k) for k < n joint values (jacobian.py:62-73)."""
         if frame not in ("space", "body"):
             raise ValueError("Invalid frame specified. Choose 'space' or 'body'.")
-        self._require_consistent_B(frame)
+        if self._needs_poe(thetalist, frame):
+            q = np.asarray(thetalist, dtype=np.float64)
+            return self._jacobian_poe(q, frame) if q.ndim == 1 else np.stack([self._jacobian_poe(r, frame) for r in q])
         T, J = self._space_fk_jac(thetalist, want_T=(frame == "body"), want_J=True)
         if frame == "body":  # J_b = Ad(T_sb^-1) J_s = [[R^T, 0], [-R^T [p], R^T]] J_s, all rows at once
             Rt = np.swapaxes(T[:, :3, :3], 1, 2)

@@ -29,6 +29,7 @@ from __future__ import annotations
 import logging
 import os
 import time
+import warnings
 from typing import Dict, Optional, Tuple
 
 import numpy as np
@@ -229,6 +230,9 @@ class OptimizedTrajectoryPlanning:
             raise ValueError(f"trajectories must be (N, n); got {q.shape}")
         if q.shape[0] == 0:
             return np.zeros(q.shape, dtype=np.float32)
+        if getattr(self.dynamics, "_legacy", False):
+            return get_backend().asarray(self._legacy_inverse_dynamics(q, np.asarray(dthetalist_trajectory),
+                                                                       np.asarray(ddthetalist_trajectory), gravity_vector, Ftip))
         dtype = np.float64 if q.dtype == np.float64 else np.float32
         tau = self._dispatch("dynamics.inverse_trajectory", self._hip_model(), q, dthetalist_trajectory,
                              ddthetalist_trajectory, gravity_vector, Ftip, dtype=dtype)
@@ -258,6 +262,9 @@ class OptimizedTrajectoryPlanning:
             raise ValueError(f"taumat must be (N, n); got {tm.shape}")
         if tm.shape[0] == 0:  # the reference seeds row 0 unconditionally (:614-617)
             raise IndexError("index 0 is out of bounds for axis 0 with size 0")
+        if getattr(self.dynamics, "_legacy", False):
+            b = get_backend()
+            return {k: b.asarray(v) for k, v in self._legacy_forward_dynamics(th, np.asarray(dthetalist), tm, g, Ftipmat, dt, intRes).items()}
         Fm = None if Ftipmat is None else np.asarray(Ftipmat)[None]
         r = self.batch_forward_dynamics_trajectory(th[None], np.asarray(dthetalist)[None], tm[None], g, Fm, dt, intRes)
         return {k: v[0] for k, v in r.items()}
@@ -280,6 +287,57 @@ class OptimizedTrajectoryPlanning:
                                        Ftipmat_batch, dt, int(intRes), dtype=dtype)
         b = get_backend()
         return {"positions": b.asarray(pos), "velocities": b.asarray(vel), "accelerations": b.asarray(acc)}
+
+    # ------------------------------------------------------------------ legacy dynamics objects (Mlist_per_link=None)
+    # The reference's approximation for such objects is not rigid-body dynamics (dynamics/mass_matrix.py:101-132), so there
+    # is no compiled model and no kernel for it: the planner walks the rows on the host exactly as the reference's CPU
+    # paths do (planning/trajectory_dynamics.py:308-380, :580-708), under every backend.
+    def _legacy_inverse_dynamics(self, q, qd, qdd, g, Ftip) -> np.ndarray:
+        t0 = time.time()
+        rows = []
+        with warnings.catch_warnings():   # one warning for the call instead of one per row and term
+            warnings.simplefilter("ignore")
+            for i in range(q.shape[0]):
+                try:
+                    rows.append(np.asarray(self.dynamics.inverse_dynamics(q[i], qd[i], qdd[i], g, Ftip), dtype=np.float32))
+                except Exception as exc:  # the reference's per-row semantics: a row that raises becomes zeros (:345-358)
+                    logger.warning("Error in inverse dynamics at point %d: %s", i, exc)
+                    rows.append(np.zeros(q.shape[1], dtype=np.float32))
+        warnings.warn("inverse_dynamics_trajectory on a ManipulatorDynamics without Mlist_per_link \u2014 using the reference's "
+                      "legacy approximation on the host (incorrect for non-trivial robots).", stacklevel=3)
+        tau = np.clip(np.stack(rows), self.torque_limits[:, 0], self.torque_limits[:, 1])
+        self._count("cpu", t0)
+        return tau
+
+    def _legacy_forward_dynamics(self, theta0, dtheta0, taumat, g, Ftipmat, dt, intRes) -> Dict[str, np.ndarray]:
+        t0 = time.time()
+        N, n = taumat.shape[0], theta0.shape[0]
+        th, dth = np.array(theta0), np.array(dtheta0)       # the state keeps the caller's dtype (:619-624)
+        lo, hi = self.joint_limits[:, 0], self.joint_limits[:, 1]
+        P, V, A = [th.astype(np.float32)], [dth.astype(np.float32)], [np.zeros(n, np.float32)]
+        if int(intRes) == 0:
+            raise ZeroDivisionError("float division by zero")
+        h = dt / intRes
+        Fm = np.zeros((N, 6)) if Ftipmat is None else np.asarray(Ftipmat)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for i in range(1, N):
+                acc = np.zeros(n, np.float32)
+                for _ in range(int(intRes)):
+                    try:
+                        dd = self.dynamics.forward_dynamics(th, dth, taumat[i], g, Fm[i])
+                    except Exception as exc:  # only the dynamics call is tolerated (:640-650)
+                        logger.warning("Error in forward dynamics at step %d: %s", i, exc)
+                        acc = np.zeros(n)
+                        continue
+                    dth = (dth + dd * h).astype(dth.dtype)
+                    th = np.clip((th + dth * h).astype(th.dtype), lo, hi)
+                    acc = dd
+                P.append(th.astype(np.float32)); V.append(dth.astype(np.float32)); A.append(np.asarray(acc, dtype=np.float32))
+        warnings.warn("forward_dynamics_trajectory on a ManipulatorDynamics without Mlist_per_link \u2014 using the reference's "
+                      "legacy approximation on the host (incorrect for non-trivial robots).", stacklevel=3)
+        self._count("cpu", t0)
+        return {"positions": np.stack(P), "velocities": np.stack(V), "accelerations": np.stack(A)}
 
     # ------------------------------------------------------------------ helpers kept from the reference
     def calculate_derivatives(self, positions, dt) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:

@@ -310,6 +310,10 @@ def _launch_ik_gpu(model, T_desired, theta0, **kw):
     return get_context().inverse_kinematics_host(model, T_desired, theta0, **kw)
 
 
+def _launch_ik_cpu(model, T_desired, theta0, **kw):
+    return _hip.cpu_inverse_kinematics(model, T_desired, theta0, **kw)
+
+
 def _launch_mass_matrix_gpu(model, q):
     return get_context().mass_matrix_host(model, q)
 
@@ -377,7 +381,7 @@ def _build_kernel_registry() -> KernelRegistry:
         ("dynamics.inverse_trajectory", "mp_id_trajectory_host_f32 / _f64", _launch_id_gpu, _launch_id_cpu),
         ("dynamics.fused_trajectory_inverse", "mp_traj_id_fused_host_f32", _launch_fused_gpu, _launch_fused_cpu),
         ("kinematics.fk_jacobian", "mp_fk_jac_id_host_f64", _launch_fk_jac_gpu, _launch_fk_jac_cpu),
-        ("kinematics.inverse", "mp_inverse_kinematics_host_f64", _launch_ik_gpu, None),
+        ("kinematics.inverse", "mp_inverse_kinematics_host_f64", _launch_ik_gpu, _launch_ik_cpu),
         ("dynamics.mass_matrix", "mp_mass_matrix_host_f64", _launch_mass_matrix_gpu, _launch_mass_matrix_cpu),
         ("dynamics.forward", "mp_forward_dynamics_host_f64", _launch_forward_dynamics_gpu, _launch_forward_dynamics_cpu),
         ("dynamics.forward_trajectory", "mp_fd_trajectory_host_f32 / _f64", _launch_fd_trajectory_gpu, _launch_fd_trajectory_cpu),

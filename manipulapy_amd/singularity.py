@@ -44,7 +44,7 @@ class Singularity:
     def near_singularity_detection(self, thetalist, threshold: float = 1e-2):
         c = self.condition_number(thetalist)
         flag = np.asarray(c) > threshold
-        return bool(flag) if flag.ndim == 0 else flag
+        return flag[()] if flag.ndim == 0 else flag   # numpy.bool_ for one configuration, as the reference returns (singularity_analysis.py:304)
 
     def manipulability(self, thetalist):
         """Yoshikawa measure sqrt(det(J J^T)) = product of the singular values (batched helper, not in the reference)."""

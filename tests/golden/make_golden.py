@@ -24,6 +24,7 @@ What it does:
       control_ur5.npz      : ManipulatorController laws on UR5 (`make_golden.py control`)
       utils.npz            : every public ManipulaPy.utils function on generic and branch-switching inputs (`make_golden.py utils`)
       (manipulapy_amd/data/) model_<robot>.npz, urdf/<robot>.urdf : the four benchmark robots' tables and URDF skeletons
+      legacy_dynamics.npz  : ManipulatorDynamics without Mlist_per_link + truncated / body-frame kinematics (`make_golden.py legacy`)
       urdf_suite.npz + urdf_suite/*.urdf : reference tables for all 28 database robots + the reference's URDF test fixtures
       reference_cpu_timings.json : cold-cache per-point timings of the reference
 
@@ -754,6 +755,62 @@ def dump_field():
     np.savez(os.path.join(HERE, "potential_field.npz"), **d)
 
 
+def dump_legacy():
+    """legacy_dynamics.npz: ManipulatorDynamics WITHOUT Mlist_per_link (the reference's legacy approximation,
+    dynamics/mass_matrix.py:101-132, forces.py:136-154) and truncated / body-frame kinematics (fk.py:59-80, jacobian.py:62-91)
+    on (A) the hand-built 6-DOF model of the reference's tests/test_public_api_freeze.py:104-158 - whose B_list is NOT
+    Ad(M^-1) S_list - and (B) URDF(ur5).to_manipulator_dynamics() (urdf/core.py:795-817)."""
+    from math import pi
+
+    from ManipulaPy.dynamics import ManipulatorDynamics
+    from ManipulaPy.path_planning import OptimizedTrajectoryPlanning
+
+    out = {}
+    S = np.array([[0, 0, 1, 0, 0, 0], [0, -1, 0, -0.089, 0, 0], [0, -1, 0, -0.089, 0, 0.425], [0, -1, 0, -0.089, 0, 0.817],
+                  [1, 0, 0, 0, 0.109, 0], [0, -1, 0, -0.089, 0, 0.817]], dtype=float).T
+    M = np.array([[1, 0, 0, 0.817], [0, 1, 0, 0], [0, 0, 1, 0.191], [0, 0, 0, 1]], dtype=float)
+    G = np.stack([np.eye(6) * (1.0 + 0.1 * i) for i in range(6)])
+    dynA = ManipulatorDynamics(M_list=M, omega_list=None, r_list=None, b_list=None, S_list=S, B_list=S.copy(), Glist=G)
+    proc, sm, _ = build("ur5")
+    dynB = proc.robot.to_manipulator_dynamics()
+    rng = np.random.default_rng(SEED + 77)
+    for tag, dyn in (("A", dynA), ("B", dynB)):
+        n = dyn.S_list.shape[1]
+        K = 5
+        th = rng.uniform(-1.5, 1.5, (K, n)); dth = rng.uniform(-1, 1, (K, n)); ddth = rng.uniform(-2, 2, (K, n))
+        F = rng.uniform(-2, 2, (K, 6))
+        out[f"{tag}_S"], out[f"{tag}_B"], out[f"{tag}_M"], out[f"{tag}_G"] = (np.asarray(dyn.S_list), np.asarray(dyn.B_list),
+                                                                               np.asarray(dyn.M_list), np.asarray(dyn.Glist))
+        out[f"{tag}_theta"], out[f"{tag}_dtheta"], out[f"{tag}_ddtheta"], out[f"{tag}_ftip"] = th, dth, ddth, F
+        mm, cc, gg, idd, fdd = [], [], [], [], []
+        for k in range(K):
+            clear_caches(dyn)
+            mm.append(dyn.mass_matrix(th[k])); cc.append(dyn.velocity_quadratic_forces(th[k], dth[k]))
+            gg.append(dyn.gravity_forces(th[k], G_VEC)); idd.append(dyn.inverse_dynamics(th[k], dth[k], ddth[k], G_VEC, F[k]))
+            fdd.append(dyn.forward_dynamics(th[k], dth[k], idd[-1], G_VEC, F[k]))
+        out[f"{tag}_mass"], out[f"{tag}_c"], out[f"{tag}_g"], out[f"{tag}_id"], out[f"{tag}_fd"] = map(np.array, (mm, cc, gg, idd, fdd))
+        # truncated chains and both frames
+        for k in range(0, n + 1):
+            out[f"{tag}_fk_space_{k}"] = dyn.forward_kinematics(th[0][:k], "space")
+            out[f"{tag}_fk_body_{k}"] = dyn.forward_kinematics(th[0][:k], "body")
+            out[f"{tag}_jac_space_{k}"] = dyn.jacobian(th[0][:k], "space")
+            if k >= 1:
+                out[f"{tag}_jac_body_{k}"] = dyn.jacobian(th[0][:k], "body")
+        # planner level: the reference's CPU loops over the legacy object
+        lim = [(-pi, pi)] * n
+        pl = OptimizedTrajectoryPlanning(dyn, "nonexistent.urdf", dyn, lim, use_cuda=False)
+        traj = pl.joint_trajectory(th[0], th[1], 1.0, 8, 5)
+        out[f"{tag}_traj_pos"], out[f"{tag}_traj_vel"], out[f"{tag}_traj_acc"] = traj["positions"], traj["velocities"], traj["accelerations"]
+        clear_caches(dyn)
+        out[f"{tag}_traj_tau"] = pl.inverse_dynamics_trajectory(traj["positions"], traj["velocities"], traj["accelerations"])
+        taum = np.array(idd)[:, :] * 0.5
+        clear_caches(dyn)
+        r = pl.forward_dynamics_trajectory(th[2], dth[2] * 0.1, np.tile(taum[2], (6, 1)), G_VEC, np.tile(F[2] * 0.1, (6, 1)), 0.01, 2)
+        out[f"{tag}_roll_tau"], out[f"{tag}_roll_F"] = np.tile(taum[2], (6, 1)), np.tile(F[2] * 0.1, (6, 1))
+        out[f"{tag}_roll_pos"], out[f"{tag}_roll_vel"], out[f"{tag}_roll_acc"] = r["positions"], r["velocities"], r["accelerations"]
+    np.savez(os.path.join(HERE, "legacy_dynamics.npz"), **out)
+
+
 def main():
     assert os.environ.get("PYTHONHASHSEED") == "0"
     if "urdf" in sys.argv[1:]:  # only (re)generate the URDF skeletons
@@ -772,7 +829,8 @@ def main():
         dump_ik()
         print("ik dumped")
         return
-    for name, fn in (("rollout100", dump_rollout100), ("nonfinite", dump_nonfinite), ("field", dump_field), ("urdf_suite", dump_urdf_suite)):
+    for name, fn in (("rollout100", dump_rollout100), ("nonfinite", dump_nonfinite), ("field", dump_field), ("urdf_suite", dump_urdf_suite),
+                     ("legacy", dump_legacy)):
         if name in sys.argv[1:]:
             fn()
             print(name, "dumped")
@@ -796,6 +854,7 @@ def main():
     dump_nonfinite()
     dump_field()
     dump_urdf_suite()
+    dump_legacy()
     print("trajectories dumped", flush=True)
     time_reference()
     print("timings dumped")

@@ -57,8 +57,8 @@ def test_no_gpu_means_loud_failure_not_fallback():
             pl.forward_dynamics_trajectory(np.zeros(6), np.zeros(6), np.zeros((3, 6)), None, None, 0.01, 1)
         with pytest.raises(RuntimeError):
             mp.OptimizedTrajectoryPlanning(sm, None, dyn, lim, use_cuda=True)
-        with pytest.raises(mp.BackendNotSupportedError):  # batched IK has no CPU launcher at all
-            mp.get_registered_kernel("kinematics.inverse").cpu_launcher()
+        with pytest.raises(_hip.HipUnavailableError):  # batched IK too: its CPU launcher serves the NumPy backend only
+            sm.iterative_inverse_kinematics(np.eye(4), np.zeros(6), max_iterations=5)
 
 
 # ----------------------------------------------------------------------------- CPU twins behind the same ABI

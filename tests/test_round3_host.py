@@ -1,0 +1,156 @@
+"""CPU-only tests of what round 3 added to the mirrored classes: the legacy (Mlist_per_link=None) dynamics object,
+truncated-theta and body-frame kinematics of models whose B_list is not Ad(M^-1) S_list, and the inverse-kinematics CPU
+launcher - each against outputs of the reference itself (tests/golden/make_golden.py legacy / ik)."""
+import warnings
+from math import pi
+
+import numpy as np
+import pytest
+
+from conftest import ROBOTS, golden_path
+from oracle import ref_numpy as ref
+
+import manipulapy_amd as mp
+
+
+def _legacy_objects():
+    z = np.load(golden_path("legacy_dynamics.npz"))
+    out = {}
+    for tag in ("A", "B"):
+        dyn = mp.ManipulatorDynamics(M_list=z[f"{tag}_M"], omega_list=None, r_list=None, b_list=None, S_list=z[f"{tag}_S"],
+                                     B_list=z[f"{tag}_B"], Glist=z[f"{tag}_G"])
+        out[tag] = dyn
+    return z, out
+
+
+def test_truncated_theta_and_body_frame_kinematics_match_the_reference():
+    """forward_kinematics(theta[:k]) = prod_{j<k} exp([S_j] theta_j) . M and jacobian(theta[:k]) (6, k), space and body frame
+    (reference kinematics/fk.py:59-80, jacobian.py:62-91) on a hand-built model whose B_list is NOT Ad(M^-1) S_list (A) and on
+    the UR5 tables (B)."""
+    z, objs = _legacy_objects()
+    for tag, dyn in objs.items():
+        n = dyn.S_list.shape[1]
+        th = z[f"{tag}_theta"][0]
+        for k in range(0, n + 1):
+            for frame in ("space", "body"):
+                np.testing.assert_allclose(dyn.forward_kinematics(th[:k], frame), z[f"{tag}_fk_{frame}_{k}"], rtol=1e-12, atol=1e-13)
+                if frame == "space" or k >= 1:
+                    J = dyn.jacobian(th[:k], frame)
+                    assert J.shape == (6, k)
+                    np.testing.assert_allclose(J, z[f"{tag}_jac_{frame}_{k}"], rtol=1e-12, atol=1e-13)
+        with pytest.raises(IndexError):
+            dyn.jacobian(th[:0], "body")
+        with pytest.raises(IndexError):
+            dyn.forward_kinematics(np.zeros(n + 1))
+        # a (rows, k) batch of truncated vectors
+        T = dyn.forward_kinematics(z[f"{tag}_theta"][:, :3])
+        assert T.shape == (5, 4, 4)
+        np.testing.assert_allclose(T[0], z[f"{tag}_fk_space_3"], rtol=1e-12, atol=1e-13)
+    # the full-length space-frame call still goes through the registered operation and agrees with the product of exponentials
+    sm, _, _ = mp.load_robot("ur5")
+    q = np.linspace(-1, 1, 6)
+    np.testing.assert_allclose(sm.forward_kinematics(q), sm._fk_poe(q, "space"), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(sm.jacobian(q, "body"), sm._jacobian_poe(q, "body"), rtol=1e-9, atol=1e-11)
+
+
+def test_legacy_dynamics_object_reproduces_the_reference_with_its_warning():
+    """ManipulatorDynamics(..., Mlist_per_link=None) - what URDF.to_manipulator_dynamics() returns (reference
+    urdf/core.py:795-817) - evaluates the reference's legacy approximation (dynamics/mass_matrix.py:101-132,
+    forces.py:136-154) and warns as the reference does; M, c, g, inverse and forward dynamics at 5 configurations."""
+    z, objs = _legacy_objects()
+    for tag, dyn in objs.items():
+        th, dth, ddth, F = (z[f"{tag}_{k}"] for k in ("theta", "dtheta", "ddtheta", "ftip"))
+        g = np.array([0.0, 0.0, -9.81])
+        with pytest.warns(UserWarning, match="without Mlist_per_link"):
+            dyn.mass_matrix(th[0])
+        with pytest.warns(UserWarning, match="legacy approximation"):
+            dyn.gravity_forces(th[0], g)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for k in range(len(th)):
+                M = dyn.mass_matrix(th[k])
+                np.testing.assert_allclose(M, z[f"{tag}_mass"][k], rtol=1e-10, atol=1e-12)
+                assert np.array_equal(M, M.T)
+                scale = np.abs(z[f"{tag}_c"][k]).max() + 1e-6
+                np.testing.assert_allclose(dyn.velocity_quadratic_forces(th[k], dth[k]), z[f"{tag}_c"][k], rtol=0, atol=1e-6 * scale + 1e-8)
+                np.testing.assert_allclose(dyn.gravity_forces(th[k], g), z[f"{tag}_g"][k], rtol=1e-10, atol=1e-12)
+                tau = dyn.inverse_dynamics(th[k], dth[k], ddth[k], g, F[k])
+                np.testing.assert_allclose(tau, z[f"{tag}_id"][k], rtol=1e-7, atol=1e-7)
+                assert tau.dtype == np.float64 and tau.shape == (len(th[k]),)
+                qdd = dyn.forward_dynamics(th[k], dth[k], z[f"{tag}_id"][k], g, F[k])
+                np.testing.assert_allclose(qdd, z[f"{tag}_fd"][k], rtol=1e-5, atol=1e-6)
+        with pytest.raises(NotImplementedError):
+            dyn.hip_model()
+
+
+def test_planner_on_a_legacy_dynamics_object_matches_the_reference_cpu_loops():
+    """inverse_dynamics_trajectory / forward_dynamics_trajectory of a planner whose dynamics object is the legacy one: the
+    reference's per-row host loops (planning/trajectory_dynamics.py:308-380, :580-708), float32 rows, under the NumPy
+    backend."""
+    z, objs = _legacy_objects()
+    for tag, dyn in objs.items():
+        n = dyn.S_list.shape[1]
+        pl = mp.OptimizedTrajectoryPlanning(dyn, "nonexistent.urdf", dyn, [(-pi, pi)] * n, use_cuda=False)
+        th = z[f"{tag}_theta"]
+        traj = pl.joint_trajectory(th[0], th[1], 1.0, 8, 5)
+        np.testing.assert_allclose(traj["positions"], z[f"{tag}_traj_pos"], rtol=3e-7, atol=1e-6)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            tau = pl.inverse_dynamics_trajectory(z[f"{tag}_traj_pos"], z[f"{tag}_traj_vel"], z[f"{tag}_traj_acc"])
+            assert tau.dtype == np.float32 and tau.shape == (8, n)
+            np.testing.assert_allclose(tau, z[f"{tag}_traj_tau"], rtol=1e-5, atol=1e-5 * np.abs(z[f"{tag}_traj_tau"]).max())
+            r = pl.forward_dynamics_trajectory(th[2], z[f"{tag}_dtheta"][2] * 0.1, z[f"{tag}_roll_tau"], np.array([0, 0, -9.81]),
+                                               z[f"{tag}_roll_F"], 0.01, 2)
+        for key, want in (("positions", "roll_pos"), ("velocities", "roll_vel"), ("accelerations", "roll_acc")):
+            assert r[key].dtype == np.float32 and r[key].shape == (6, n)
+            np.testing.assert_allclose(r[key], z[f"{tag}_{want}"], rtol=2e-4, atol=2e-5 * max(1.0, float(np.abs(z[f"{tag}_{want}"]).max())))
+        with pytest.warns(UserWarning, match="legacy approximation"):
+            pl.inverse_dynamics_trajectory(z[f"{tag}_traj_pos"][:2], z[f"{tag}_traj_vel"][:2], z[f"{tag}_traj_acc"][:2])
+
+
+def _restarted(tab, z, robot, i):
+    p = z[f"{robot}_params"][i]
+    return ref.iterative_inverse_kinematics(tab, z[f"{robot}_T_desired"][i], z[f"{robot}_theta0"][i], p[0], p[1], int(p[2]), p[3], p[4],
+                                            p[5], p[6], joint_limits=z[f"{robot}_joint_limits"], rng=np.random.RandomState(1234),
+                                            adaptive_tuning=bool(p[7]), backtracking=bool(p[8]))[3] > 0
+
+
+@pytest.mark.parametrize("robot", ROBOTS)
+def test_inverse_kinematics_cpu_launcher_against_reference_runs(robot, tables):
+    """The NumPy backend's launcher of "kinematics.inverse" (mp_inverse_kinematics_cpu_f64: the kernel's iteration on host
+    threads) against the reference's own iterative_inverse_kinematics runs (tests/golden/ik.npz) - the test the HIP kernel
+    passes, on the CPU - and batch == single."""
+    z = np.load(golden_path("ik.npz"))
+    tab = tables[robot]
+    lim = z[f"{robot}_joint_limits"]
+    sm, _, _ = mp.load_robot(robot)
+    sm.joint_limits = [(None if not np.isfinite(lo) else float(lo), None if not np.isfinite(hi) else float(hi)) for lo, hi in lim]
+    with mp.use_backend("numpy"):
+        checked = 0
+        for i in range(10):
+            p = z[f"{robot}_params"][i]
+            th, ok, it = sm.iterative_inverse_kinematics(z[f"{robot}_T_desired"][i], z[f"{robot}_theta0"][i], eomg=p[0], ev=p[1],
+                                                         max_iterations=int(p[2]), damping=p[3], step_cap=p[4],
+                                                         weight_orientation=p[5], weight_position=p[6],
+                                                         adaptive_tuning=bool(p[7]), backtracking=bool(p[8]))
+            want_ok, want_it = bool(z[f"{robot}_success"][i]), int(z[f"{robot}_iterations"][i])
+            if _restarted(tab, z, robot, i):
+                continue
+            checked += 1
+            assert ok == want_ok and abs(it - want_it) <= (1 if want_ok else 0), (robot, i, ok, it, want_it)
+            np.testing.assert_allclose(th, z[f"{robot}_theta"][i], rtol=0, atol=1e-6 if want_ok else 1e-5)
+        assert checked >= 5
+        rng = np.random.default_rng(31)
+        B = 64
+        fin = np.where(np.isfinite(lim), lim, np.array([-np.pi, np.pi]))
+        q_true = rng.uniform(0.6 * fin[:, 0], 0.6 * fin[:, 1], (B, tab.n))
+        T = np.stack([ref.fk_space(tab, q) for q in q_true])
+        q0 = np.clip(q_true + rng.uniform(-0.3, 0.3, (B, tab.n)), fin[:, 0], fin[:, 1])
+        th, ok, it = sm.batch_inverse_kinematics(T, q0, max_iterations=300)
+        assert ok.mean() > 0.5
+        for b in np.flatnonzero(ok)[:10]:
+            _, rot, tr = ref.ik_geometric_error(ref.fk_space(tab, th[b]), T[b])
+            assert rot < 1e-6 and tr < 1e-6
+        one = sm.iterative_inverse_kinematics(T[3], q0[3], max_iterations=300)
+        np.testing.assert_array_equal(one[0], th[3])
+        assert one[1] == ok[3] and one[2] == it[3]
