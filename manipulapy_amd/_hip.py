@@ -18,7 +18,8 @@ LIB_ENV = "MANIPULAPY_HIP_LIB"  # override the library path
 DEFAULT_LIB = os.path.join(_PKG, "libmanipula_hip.so")
 
 MP_OK = 0
-MP_MAX_DOF = 8
+MP_MAX_DOF = 8    # fully unrolled / specialisable kernels
+MP_BIG_DOF = 16   # run-time-n kernels (csrc/mp_dyn.h)
 UNIQUE_ID_BYTES = 128
 
 
@@ -372,9 +373,10 @@ class HipModel:
             v = vals[o:o + k].copy(); o += k
             return v
         d = {"n": int(raw[:4].view(np.int32)[0]), "base_R": take(9), "base_p": take(3), "tool_R": take(9), "tool_p": take(3)}
-        d["joints"] = take(16 * MP_MAX_DOF).reshape(MP_MAX_DOF, 16)
+        cap = (nb.value - head - 24 * w) // (20 * w)   # MP_MAX_DOF, or MP_BIG_DOF for the looped kernels' model (csrc/mp_model.h)
+        d["joints"] = take(16 * cap).reshape(cap, 16)
         for k in ("qmin", "qmax", "taumin", "taumax"):
-            d[k] = take(MP_MAX_DOF)
+            d[k] = take(cap)
         assert o * w + head == nb.value, (o * w + head, nb.value)
         return d
 

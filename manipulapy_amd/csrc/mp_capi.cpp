@@ -44,6 +44,7 @@ struct mp_ctx {
   std::map<size_t, std::vector<void*>> free_by_size;  // pool: exact-size free lists
   std::map<void*, size_t> live;                        // every buffer handed out -> its size
   std::map<uint64_t, void*> dev_models;                // model uid -> float32 model resident on this device
+  std::map<uint64_t, void*> dev_big[2];                // model uid -> MpBigModel<float> [0] / <double> [1] resident on this device
   std::map<uint64_t, MpSpec> specs;                    // model uid -> specialised kernels (mp_model_specialize)
   int compute_units = 0;
   bool capturing = false;                              // between mp_graph_begin and mp_graph_end
@@ -173,7 +174,8 @@ template <> const MpModel<double>& pick<double>(const mp_model* m) { return m->d
 template <typename T>
 void make_call(const mp_model* m, const double* g, const double* Ftip, MpCall<T>* c) {
   MpCall<double> cd;
-  mp_make_call(m->d, g ? g : kG, Ftip, &cd);
+  if (m->big) mp_make_call(m->bd, g ? g : kG, Ftip, &cd);
+  else mp_make_call(m->d, g ? g : kG, Ftip, &cd);
   mp_call_cast(cd, c);
 }
 
@@ -267,6 +269,31 @@ int device_model(mp_ctx* ctx, const mp_model* model, const MpModel<float>** out)
   return MP_OK;
 }
 
+// MpBigModel<T> of a 9..16-joint model resident in device memory (read by the looped k_dyn_* kernels through scalar loads)
+template <typename T> const MpBigModel<T>& pick_big(const mp_model* m);
+template <> const MpBigModel<float>& pick_big<float>(const mp_model* m) { return m->bf; }
+template <> const MpBigModel<double>& pick_big<double>(const mp_model* m) { return m->bd; }
+template <typename T>
+int device_big_model(mp_ctx* ctx, const mp_model* model, const MpBigModel<T>** out) {
+  auto& table = ctx->dev_big[sizeof(T) == 8 ? 1 : 0];
+  auto it = table.find(model->uid);
+  if (it == table.end()) {
+    REQUIRE(!ctx->capturing, "a model with more than %d joints is uploaded on first use: call once before capturing a launch graph", MP_MAX_DOF);
+    void* d = nullptr;
+    if (int rc = mp_malloc(ctx, sizeof(MpBigModel<T>), &d)) return rc;
+    HIP_TRY(hipMemcpy(d, &pick_big<T>(model), sizeof(MpBigModel<T>), hipMemcpyHostToDevice));
+    it = table.emplace(model->uid, d).first;
+  }
+  *out = static_cast<const MpBigModel<T>*>(it->second);
+  return MP_OK;
+}
+#define REQUIRE_SMALL(fn)                                                                                              \
+  do {                                                                                                                 \
+    if (model->big)                                                                                                    \
+      return set_err(MP_ERR_UNSUPPORTED, "%s: not available for models with more than %d joints (this one has %d)", fn, \
+                     MP_MAX_DOF, model->d.n);                                                                          \
+  } while (0)
+
 // Which generic (no run-time specialisation) float32 inverse-dynamics kernel runs.  Default: one row per lane with the model read
 // from device memory joint by joint (k_id_dm: c2 0.100 ms against 0.119 packed / 0.127 scalar with the model in the kernel
 // arguments, c4 0.213 / 0.221 / 0.281; tools/ab_generic.sh).  MANIPULAPY_HIP_F32 = "packed" | "scalar" selects the two
@@ -276,8 +303,18 @@ int generic_f32_mode() {
   return mode;
 }
 
+template <typename T>
+int launch_big_fk_jac_id(mp_ctx* ctx, const mp_model* model, const MpCall<T>& c, bool ftip, const T* q, const T* qd, const T* qdd, T* Tout,
+                         T* Jout, T* tau, long rows) {
+  const MpBigModel<T>* dm = nullptr;
+  if (int rc = device_big_model<T>(ctx, model, &dm)) return rc;
+  HIP_TRY(mpk_dyn_fk_jac_id<T>(ctx->compute, dm, c, ftip, q, qd, qdd, Tout, Jout, tau, rows));
+  return MP_OK;
+}
+
 int launch_id(mp_ctx* ctx, const mp_model* model, const MpCall<double>& c, bool ftip, const double* q, const double* qd,
               const double* qdd, double* tau, long rows) {
+  if (model->big) return launch_big_fk_jac_id<double>(ctx, model, c, ftip, q, qd, qdd, nullptr, nullptr, tau, rows);
   if (const MpSpec* sp = find_spec(ctx, model)) {
     MpCall<double> cc = c;
     void* args[] = {&cc, &q, &qd, &qdd, &tau, &rows};
@@ -288,6 +325,7 @@ int launch_id(mp_ctx* ctx, const mp_model* model, const MpCall<double>& c, bool 
 }
 int launch_id(mp_ctx* ctx, const mp_model* model, const MpCall<float>& c, bool ftip, const float* q, const float* qd,
               const float* qdd, float* tau, long rows) {
+  if (model->big) return launch_big_fk_jac_id<float>(ctx, model, c, ftip, q, qd, qdd, nullptr, nullptr, tau, rows);
   const long pairs = rows / 2;
   if (const MpSpec* sp = find_spec(ctx, model)) {
     if (spec_scalar_f32(model->d.n)) {  // one row per lane
@@ -363,6 +401,7 @@ static int fkjid_impl(const char* fn, mp_ctx* ctx, const mp_model* model, const 
   MpCall<T> c;
   make_call<T>(model, g, Ftip, &c);
   PROFILE_SCOPE(ctx, fn);
+  if (model->big) return launch_big_fk_jac_id<T>(ctx, model, c, any_nonzero(Ftip), d_q, d_qd, d_qdd, d_T, d_J, d_tau, (long)rows);
   const int src = launch_fkjid_spec(ctx, model, c, any_nonzero(Ftip), d_q, d_qd, d_qdd, d_T, d_J, d_tau, (long)rows);
   if (src >= 0) return src;
   HIP_TRY(mpk_fk_jac_id<T>(ctx->compute, pick<T>(model), c, any_nonzero(Ftip), d_q, d_qd, d_qdd, d_T, d_J, d_tau, (long)rows));
@@ -476,6 +515,12 @@ static int mm_impl(const char* fn, mp_ctx* ctx, const mp_model* model, const T* 
   REQUIRE(d_q && d_M, "%s: null device pointer", fn);
   REQUIRE(aligned16(d_q) && aligned16(d_M), "%s: device pointers must be 16-byte aligned", fn);
   PROFILE_SCOPE(ctx, fn);
+  if (model->big) {
+    const MpBigModel<T>* dm = nullptr;
+    if (int rc = device_big_model<T>(ctx, model, &dm)) return rc;
+    HIP_TRY(mpk_dyn_mass_matrix<T>(ctx->compute, dm, d_q, d_M, (long)rows));
+    return MP_OK;
+  }
   HIP_TRY(mpk_mass_matrix<T>(ctx->compute, pick<T>(model), d_q, d_M, (long)rows));
   return MP_OK;
 }
@@ -493,6 +538,12 @@ static int fdyn_impl(const char* fn, mp_ctx* ctx, const mp_model* model, const T
   make_call<T>(model, g, Ftip, &c);
   const bool ftip = any_nonzero(Ftip);
   PROFILE_SCOPE(ctx, fn);
+  if (model->big) {
+    const MpBigModel<T>* dm = nullptr;
+    if (int rc = device_big_model<T>(ctx, model, &dm)) return rc;
+    HIP_TRY(mpk_dyn_forward_dynamics<T>(ctx->compute, dm, c, ftip, d_q, d_qd, d_tau, d_qdd, (long)rows));
+    return MP_OK;
+  }
   if (const MpSpec* sp = find_spec(ctx, model)) {
     long nr = (long)rows;
     void* args[] = {&c, &d_q, &d_qd, &d_tau, &d_qdd, &nr};
@@ -534,6 +585,13 @@ static int fdtraj_impl(const char* fn, mp_ctx* ctx, const mp_model* model, const
   make_call<T>(model, g, nullptr, &c);
   const T h = intRes > 0 ? (T)(dt / intRes) : (T)0;
   PROFILE_SCOPE(ctx, fn);
+  if (model->big) {
+    const MpBigModel<T>* dm = nullptr;
+    if (int rc = device_big_model<T>(ctx, model, &dm)) return rc;
+    HIP_TRY(mpk_dyn_fd_traj<T>(ctx->compute, dm, c, d_theta0, d_dtheta0, d_taumat, d_Ftipmat, (long)B, (long)N, h, intRes, d_pos, d_vel,
+                               d_acc, time_major));
+    return MP_OK;
+  }
   const int src = launch_fd_spec(ctx, model, c, d_theta0, d_dtheta0, d_taumat, d_Ftipmat, (long)B, (long)N, h, intRes, d_pos, d_vel, d_acc,
                                  time_major);
   if (src >= 0) return src;  // a specialised kernel exists for this model: launched (0) or failed (error code)
@@ -931,16 +989,32 @@ int mp_model_create(int n, const double* S, const double* Mcom, const double* G,
   REQUIRE(out, "mp_model_create: null output");
   *out = nullptr;
   REQUIRE(S && Mcom && G && M_ee, "mp_model_create: S, Mcom, G and M_ee are required");
-  REQUIRE(n >= 1 && n <= MP_MAX_DOF, "mp_model_create: dof %d outside 1..%d", n, MP_MAX_DOF);
+  REQUIRE(n >= 1 && n <= MP_BIG_DOF, "mp_model_create: dof %d outside 1..%d", n, MP_BIG_DOF);
   mp_model* m = new (std::nothrow) mp_model;
   REQUIRE(m, "mp_model_create: out of host memory");
   char msg[400] = "";
-  int rc = mp_compile_model(n, S, Mcom, G, M_ee, joint_limits, torque_limits, &m->d, msg, sizeof msg);
+  int rc;
+  // MANIPULAPY_HIP_LOOPED=1 (tests): build every model for the run-time-n kernels, so that the looped recursions can be
+  // checked against the unrolled ones and the goldens on the 6..8-joint robots too
+  const char* looped = getenv("MANIPULAPY_HIP_LOOPED");
+  if (n <= MP_MAX_DOF && !(looped && looped[0] == '1')) {
+    rc = mp_compile_model(n, S, Mcom, G, M_ee, joint_limits, torque_limits, &m->d, msg, sizeof msg);
+    if (!rc) mp_model_cast(m->d, &m->f);
+  } else {  // 9..16 joints: the looped kernels' model; d / f only carry the joint count
+    m->big = true;
+    rc = mp_compile_model_big(n, S, Mcom, G, M_ee, joint_limits, torque_limits, &m->bd, msg, sizeof msg);
+    if (!rc) {
+      mp_model_cast(m->bd, &m->bf);
+      std::memset(&m->d, 0, sizeof m->d);
+      std::memset(&m->f, 0, sizeof m->f);
+      m->d.n = n;
+      m->f.n = n;
+    }
+  }
   if (rc) {
     delete m;
     return set_err(MP_ERR_MODEL, "mp_model_create: %s", msg);
   }
-  mp_model_cast(m->d, &m->f);
   static std::atomic<uint64_t> next_uid{1};
   m->uid = next_uid.fetch_add(1);
   *out = m;
@@ -954,7 +1028,8 @@ int mp_model_destroy(mp_model* model) {
     std::lock_guard<std::recursive_mutex> cl(ctx->mu);
     auto sp = ctx->specs.find(model->uid);
     auto dm = ctx->dev_models.find(model->uid);
-    if (sp == ctx->specs.end() && dm == ctx->dev_models.end()) continue;
+    const bool has_big = ctx->dev_big[0].count(model->uid) || ctx->dev_big[1].count(model->uid);
+    if (sp == ctx->specs.end() && dm == ctx->dev_models.end() && !has_big) continue;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->compute);  // a launch of this model's kernels may still be in flight
     if (sp != ctx->specs.end()) {
@@ -965,6 +1040,10 @@ int mp_model_destroy(mp_model* model) {
     if (dm != ctx->dev_models.end()) {
       (void)mp_free(ctx, dm->second);
       ctx->dev_models.erase(dm);
+    }
+    for (auto& table : ctx->dev_big) {
+      auto it = table.find(model->uid);
+      if (it != table.end()) { (void)mp_free(ctx, it->second); table.erase(it); }
     }
   }
   delete model;
@@ -978,11 +1057,12 @@ int mp_model_dof(const mp_model* model, int* n) {
 int mp_model_params(const mp_model* model, double* out) {
   REQUIRE(model && out, "mp_model_params: null argument");
   static_assert(sizeof(MpJoint<double>) == 16 * sizeof(double), "MpJoint layout");
-  for (int i = 0; i < model->d.n; ++i) std::memcpy(out + 16 * i, &model->d.j[i], 16 * sizeof(double));
+  for (int i = 0; i < model->d.n; ++i) std::memcpy(out + 16 * i, model->big ? &model->bd.j[i] : &model->d.j[i], 16 * sizeof(double));
   return MP_OK;
 }
 int mp_model_specialize_source(const mp_model* model, char* buf, size_t* len) {
   REQUIRE(model && len, "mp_model_specialize_source: null argument");
+  REQUIRE_SMALL("mp_model_specialize_source");
   const std::string src = mp_jit_source(model->f, model->d);
   if (buf) {
     REQUIRE(*len >= src.size() + 1, "mp_model_specialize_source: buffer too small");
@@ -993,6 +1073,7 @@ int mp_model_specialize_source(const mp_model* model, char* buf, size_t* len) {
 }
 int mp_model_specialize_compile(const mp_model* model, size_t* code_bytes, int* from_cache) {
   REQUIRE(model, "mp_model_specialize_compile: null model");
+  REQUIRE_SMALL("mp_model_specialize_compile");
   std::vector<char> code;
   std::string err;
   bool cached = false;
@@ -1015,6 +1096,7 @@ int mp_model_is_specialized(mp_ctx* ctx, const mp_model* model, int* yes) {
 }
 int mp_model_specialize(mp_ctx* ctx, const mp_model* model) {
   REQUIRE(ctx && model, "mp_model_specialize: null argument");
+  REQUIRE_SMALL("mp_model_specialize");
   CTX_ENTER(ctx);
   if (ctx->specs.count(model->uid)) return MP_OK;
   std::vector<char> code;
@@ -1062,17 +1144,21 @@ int mp_model_specialize(mp_ctx* ctx, const mp_model* model) {
 }
 int mp_model_blob(const mp_model* model, int use_f64, void* out, size_t* bytes) {
   REQUIRE(model && bytes, "mp_model_blob: null argument");
-  const size_t need = use_f64 ? sizeof(MpModel<double>) : sizeof(MpModel<float>);
+  const size_t need = model->big ? (use_f64 ? sizeof(MpBigModel<double>) : sizeof(MpBigModel<float>))
+                                 : (use_f64 ? sizeof(MpModel<double>) : sizeof(MpModel<float>));
   if (out) {
     REQUIRE(*bytes >= need, "mp_model_blob: buffer of %zu bytes, need %zu", *bytes, need);
-    std::memcpy(out, use_f64 ? (const void*)&model->d : (const void*)&model->f, need);
+    const void* src = model->big ? (use_f64 ? (const void*)&model->bd : (const void*)&model->bf)
+                                 : (use_f64 ? (const void*)&model->d : (const void*)&model->f);
+    std::memcpy(out, src, need);
   }
   *bytes = need;
   return MP_OK;
 }
 int mp_model_fk_host(const mp_model* model, const double* q, double* T) {
   REQUIRE(model && q && T, "mp_model_fk_host: null argument");
-  mp_compiled_fk(model->d, q, T);
+  if (model->big) mp_compiled_fk(model->bd, q, T);
+  else mp_compiled_fk(model->d, q, T);
   return MP_OK;
 }
 
@@ -1090,6 +1176,13 @@ int mp_batch_trajectory_f32(mp_ctx* ctx, const mp_model* model, const float* d_s
   REQUIRE(aligned16(d_start) && aligned16(d_end) && aligned16(d_pos) && aligned16(d_vel) && aligned16(d_acc),
           "mp_batch_trajectory_f32: device pointers must be 16-byte aligned");
   PROFILE_SCOPE(ctx, "mp_batch_trajectory_f32");
+  if (model->big) {
+    const MpBigModel<float>* dm = nullptr;
+    if (int rc = device_big_model<float>(ctx, model, &dm)) return rc;
+    MpCall<float> c0 = {};
+    HIP_TRY(mpk_dyn_traj(ctx->compute, dm, c0, false, d_start, d_end, (long)B, (long)N, Tf, method, d_pos, d_vel, d_acc, nullptr));
+    return MP_OK;
+  }
   HIP_TRY(mpk_batch_traj(ctx->compute, model->f, d_start, d_end, (long)B, (long)N, Tf, method, d_pos, d_vel, d_acc));
   return MP_OK;
 }
@@ -1115,6 +1208,12 @@ int mp_traj_id_fused_f32(mp_ctx* ctx, const mp_model* model, const float* d_star
   make_call<float>(model, g, Ftip, &c);
   const bool ftip = any_nonzero(Ftip);
   PROFILE_SCOPE(ctx, "mp_traj_id_fused_f32");
+  if (model->big) {
+    const MpBigModel<float>* dm = nullptr;
+    if (int rc = device_big_model<float>(ctx, model, &dm)) return rc;
+    HIP_TRY(mpk_dyn_traj(ctx->compute, dm, c, ftip, d_start, d_end, (long)B, (long)N, Tf, method, nullptr, nullptr, nullptr, d_tau));
+    return MP_OK;
+  }
   if (!mpk_packed_f32() && !find_spec(ctx, model)) {  // MANIPULAPY_HIP_F32=scalar, generic: one row per lane, time scaling per row
     HIP_TRY(mpk_traj_id(ctx->compute, model->f, c, ftip, d_start, d_end, (long)B, (long)N, Tf, method, d_tau));
     return MP_OK;
@@ -1476,6 +1575,7 @@ int mp_inverse_kinematics_f64(mp_ctx* ctx, const mp_model* model, const double* 
                               uint32_t seed,
                               double* d_theta, int32_t* d_success, int32_t* d_iterations, int32_t* d_restarts) {
   CHECK_COMMON("mp_inverse_kinematics_f64");
+  REQUIRE_SMALL("mp_inverse_kinematics_f64");
   REQUIRE(B >= 0, "mp_inverse_kinematics_f64: negative problem count");
   if (B == 0) return MP_OK;
   REQUIRE(d_T_desired && d_theta0 && d_theta && d_success && d_iterations && d_restarts, "mp_inverse_kinematics_f64: null device pointer");

@@ -14,6 +14,7 @@
 
 #include "../../include/manipula_hip.h"
 #include "mp_core.h"
+#include "mp_dyn.h"
 #include "mp_ik.h"
 #include "mp_handles.h"
 #include "mp_model_compile.h"
@@ -62,10 +63,15 @@ template <typename T> const MpModel<T>& pick(const mp_model* m);
 template <> const MpModel<float>& pick<float>(const mp_model* m) { return m->f; }
 template <> const MpModel<double>& pick<double>(const mp_model* m) { return m->d; }
 
+template <typename T> const MpBigModel<T>& pick_big(const mp_model* m);
+template <> const MpBigModel<float>& pick_big<float>(const mp_model* m) { return m->bf; }
+template <> const MpBigModel<double>& pick_big<double>(const mp_model* m) { return m->bd; }
+
 template <typename T>
 MpCall<T> make_call(const mp_model* m, const double* g, const double* Ftip) {
   MpCall<double> cd;
-  mp_make_call(m->d, g ? g : kG, Ftip, &cd);
+  if (m->big) mp_make_call(m->bd, g ? g : kG, Ftip, &cd);
+  else mp_make_call(m->d, g ? g : kG, Ftip, &cd);
   MpCall<T> c;
   mp_call_cast(cd, &c);
   return c;
@@ -81,7 +87,7 @@ MpCall<T> make_call(const mp_model* m, const double* g, const double* Ftip) {
     case 6: { constexpr int N = 6; __VA_ARGS__; } break;         \
     case 7: { constexpr int N = 7; __VA_ARGS__; } break;         \
     case 8: { constexpr int N = 8; __VA_ARGS__; } break;         \
-    default: return fail("dof outside 1..8");                    \
+    default: return fail("dof outside 1..8 (larger models take the looped path before this dispatch)");                    \
   }
 
 // ---- one row of FK / Jacobian / inverse dynamics: the body of k_fk_jac_id / k_id on the host
@@ -125,6 +131,16 @@ int fk_jac_id_cpu(const char* fn, const mp_model* model, const T* q, const T* qd
   const MpModel<T>& M = pick<T>(model);
   const MpCall<T> C = make_call<T>(model, g, Ftip);
   const bool ftip = any_nonzero(Ftip);
+  if (model->big) {  // 9..16 joints: the looped rows of csrc/mp_dyn.h
+    const MpBigModel<T>& MB = pick_big<T>(model);
+    parallel_for(rows, 128, nthreads, [&](int64_t lo, int64_t hi) {
+      for (int64_t r = lo; r < hi; ++r) {
+        if (ftip) mp_dyn_row_fk_jac_id<T, true>(MB, C, q, qd, qdd, Tout, Jout, tau, (long)r);
+        else mp_dyn_row_fk_jac_id<T, false>(MB, C, q, qd, qdd, Tout, Jout, tau, (long)r);
+      }
+    });
+    return MP_OK;
+  }
   MP_CPU_DISPATCH(M.n, {
     parallel_for(rows, 256, nthreads, [&](int64_t lo, int64_t hi) {
       if (ftip) rows_fk_jac_id<T, N, true>(M, C, q, qd, qdd, Tout, Jout, tau, lo, hi);
@@ -222,6 +238,16 @@ int fd_trajectory_cpu(const mp_model* model, const T* theta0, const T* dtheta0, 
   const MpModel<T>& M = pick<T>(model);
   const MpCall<T> C = make_call<T>(model, g, nullptr);
   const T h = (T)(dt / intRes);
+  if (model->big) {
+    const MpBigModel<T>& MB = pick_big<T>(model);
+    parallel_for(B, 1, nthreads, [&](int64_t lo, int64_t hi) {
+      for (int64_t b = lo; b < hi; ++b) {
+        if (Ftipmat) mp_dyn_rollout<T, true>(MB, C, theta0, dtheta0, taumat, Ftipmat, (long)b, (long)B, (long)Nt, h, intRes, pos, vel, acc, false);
+        else mp_dyn_rollout<T, false>(MB, C, theta0, dtheta0, taumat, Ftipmat, (long)b, (long)B, (long)Nt, h, intRes, pos, vel, acc, false);
+      }
+    });
+    return MP_OK;
+  }
   MP_CPU_DISPATCH(M.n, {
     parallel_for(B, 1, nthreads, [&](int64_t lo, int64_t hi) {
       if (Ftipmat) rollouts<T, N, true>(M, C, theta0, dtheta0, taumat, Ftipmat, Nt, h, intRes, pos, vel, acc, lo, hi);
@@ -258,6 +284,12 @@ int mp_mass_matrix_cpu_f64(const mp_model* model, const double* q, int64_t rows,
   if (rows == 0) return MP_OK;
   if (!q || !Mout) return fail("mp_mass_matrix_cpu_f64: null pointer");
   const MpModel<double>& M = model->d;
+  if (model->big) {
+    parallel_for(rows, 128, nthreads, [&](int64_t lo, int64_t hi) {
+      for (int64_t r = lo; r < hi; ++r) mp_dyn_row_mass_matrix<double>(model->bd, q, Mout, (long)r);
+    });
+    return MP_OK;
+  }
   MP_CPU_DISPATCH(M.n, { parallel_for(rows, 256, nthreads, [&](int64_t lo, int64_t hi) { rows_mass_matrix<double, N>(M, q, Mout, lo, hi); }); })
   return MP_OK;
 }
@@ -271,6 +303,15 @@ int mp_forward_dynamics_cpu_f64(const mp_model* model, const double* q, const do
   const MpModel<double>& M = model->d;
   const MpCall<double> C = make_call<double>(model, g, Ftip);
   const bool ftip = any_nonzero(Ftip);
+  if (model->big) {
+    parallel_for(rows, 64, nthreads, [&](int64_t lo, int64_t hi) {
+      for (int64_t r = lo; r < hi; ++r) {
+        if (ftip) mp_dyn_row_forward_dynamics<double, true>(model->bd, C, q, qd, tau, qdd, (long)r);
+        else mp_dyn_row_forward_dynamics<double, false>(model->bd, C, q, qd, tau, qdd, (long)r);
+      }
+    });
+    return MP_OK;
+  }
   MP_CPU_DISPATCH(M.n, {
     parallel_for(rows, 128, nthreads, [&](int64_t lo, int64_t hi) {
       if (ftip) rows_forward_dynamics<double, N, true>(M, C, q, qd, tau, qdd, lo, hi);
@@ -297,6 +338,7 @@ int mp_inverse_kinematics_cpu_f64(const mp_model* model, const double* T_desired
                                   int backtracking, uint32_t seed, double* theta, int32_t* success, int32_t* iterations,
                                   int32_t* restarts, int nthreads) {
   if (!model) return fail("mp_inverse_kinematics_cpu_f64: null model");
+  if (model->big) return mp_set_error(MP_ERR_UNSUPPORTED, "mp_inverse_kinematics_cpu_f64: not available for models with more than 8 joints");
   if (B < 0) return fail("mp_inverse_kinematics_cpu_f64: negative problem count");
   if (B == 0) return MP_OK;
   if (!T_desired || !theta0 || !theta || !success || !iterations || !restarts) return fail("mp_inverse_kinematics_cpu_f64: null pointer");

@@ -1,0 +1,355 @@
+// Run-time-n ("looped") forms of the per-row recursions of mp_core.h, for robots with more joints than the fully
+// unrolled kernels are instantiated for (MP_MAX_DOF = 8 < n <= MP_BIG_DOF = 16: the reference's Jaco arms with their
+// three-finger hands have 9 and 10 actuated joints, ManipulaPy_data/__init__.py:174-189, and its algorithms loop over any n,
+// dynamics/mass_matrix.py:62-96, kinematics/jacobian.py:62-73).  Same compiled link frames, same axis-aligned steps
+// (mp_motion_* / mp_force_* / mp_rbi_up_* of mp_core.h), same arithmetic order per joint; the joint index is a run-time loop
+// variable, so per-joint state lives in indexed arrays (scratch memory on the device) and the model is read joint by joint
+// through a pointer.  Speed is not the point here - any supported robot must compute, on the GPU and on the CPU launchers.
+// Header-only; compiles for gfx950 and, unchanged, for the host (csrc/mp_cpu.cpp, tests/hostsim).
+#pragma once
+
+#include "mp_core.h"
+
+#if defined(__clang__)
+#define MP_NOUNROLL _Pragma("nounroll")
+#else
+#define MP_NOUNROLL
+#endif
+
+template <typename T>
+struct MpDynState {  // sin / cos of the joint angles and the z shifts of one row
+  T s[MP_BIG_DOF], c[MP_BIG_DOF], d[MP_BIG_DOF];
+};
+
+template <typename T, typename MT>
+MP_HD void mp_dyn_joint_state(const MT& M, int n, const T* q, MpDynState<T>& js) {
+  MP_NOUNROLL
+  for (int i = 0; i < n; ++i) {
+    const auto& J = M.j[i];
+    const T qr = J.rev * q[i];
+    mp_sincos(J.off + qr, js.s[i], js.c[i]);
+    js.d[i] = J.d + (q[i] - qr);
+  }
+}
+
+// mp_rnea of mp_core.h with a run-time joint count.  tau is NOT clipped here.
+template <typename T, bool HAS_FTIP, typename MT>
+MP_HD void mp_dyn_rnea(const MT& M, int n, const T (&a0)[3], const T (&tipn)[3], const T (&tipf)[3], const MpDynState<T>& js,
+                       const T* qd, const T* qdd, T* tau) {
+  T fnx[MP_BIG_DOF], fny[MP_BIG_DOF], fnz[MP_BIG_DOF], ffx[MP_BIG_DOF], ffy[MP_BIG_DOF], ffz[MP_BIG_DOF];
+  T wx = 0, wy = 0, wz = 0, vx = 0, vy = 0, vz = 0;
+  T dwx = 0, dwy = 0, dwz = 0, dvx = a0[0], dvy = a0[1], dvz = a0[2];
+  T tnx = 0, tny = 0, tnz = 0, tfx = 0, tfy = 0, tfz = 0;
+  if (HAS_FTIP) { tnx = tipn[0]; tny = tipn[1]; tnz = tipn[2]; tfx = tipf[0]; tfy = tipf[1]; tfz = tipf[2]; }
+  MP_NOUNROLL
+  for (int i = 0; i < n; ++i) {  // forward pass: twists, accelerations, body wrenches
+    const auto& J = M.j[i];
+    if (i > 0) {
+      mp_motion_A(J.ca, J.sa, J.a, wx, wy, wz, vx, vy, vz);
+      mp_motion_A(J.ca, J.sa, J.a, dwx, dwy, dwz, dvx, dvy, dvz);
+      if (HAS_FTIP) mp_force_down_A(J.ca, J.sa, J.a, tnx, tny, tnz, tfx, tfy, tfz);
+    }
+    const T c = js.c[i], s = js.s[i], d = js.d[i];
+    mp_motion_B(c, s, d, wx, wy, wz, vx, vy, vz);
+    mp_motion_B(c, s, d, dwx, dwy, dwz, dvx, dvy, dvz);
+    if (HAS_FTIP) mp_force_down_B(c, s, d, tnx, tny, tnz, tfx, tfy, tfz);
+    const T qdr = J.rev * qd[i], qdp = qd[i] - qdr;
+    const T ar = J.rev * qdd[i], ap = qdd[i] - ar;
+    wz += qdr;
+    vz += qdp;
+    dwx += qdr * wy;
+    dwy -= qdr * wx;
+    dwz += ar;
+    dvx += qdr * vy + qdp * wy;
+    dvy -= qdr * vx + qdp * wx;
+    dvz += ap;
+    const T pnx = J.Ixx * wx + J.Ixy * wy + J.Ixz * wz + (J.hy * vz - J.hz * vy);
+    const T pny = J.Ixy * wx + J.Iyy * wy + J.Iyz * wz + (J.hz * vx - J.hx * vz);
+    const T pnz = J.Ixz * wx + J.Iyz * wy + J.Izz * wz + (J.hx * vy - J.hy * vx);
+    const T pfx = J.m * vx - (J.hy * wz - J.hz * wy);
+    const T pfy = J.m * vy - (J.hz * wx - J.hx * wz);
+    const T pfz = J.m * vz - (J.hx * wy - J.hy * wx);
+    fnx[i] = J.Ixx * dwx + J.Ixy * dwy + J.Ixz * dwz + (J.hy * dvz - J.hz * dvy) + (wy * pnz - wz * pny) + (vy * pfz - vz * pfy);
+    fny[i] = J.Ixy * dwx + J.Iyy * dwy + J.Iyz * dwz + (J.hz * dvx - J.hx * dvz) + (wz * pnx - wx * pnz) + (vz * pfx - vx * pfz);
+    fnz[i] = J.Ixz * dwx + J.Iyz * dwy + J.Izz * dwz + (J.hx * dvy - J.hy * dvx) + (wx * pny - wy * pnx) + (vx * pfy - vy * pfx);
+    ffx[i] = J.m * dvx - (J.hy * dwz - J.hz * dwy) + (wy * pfz - wz * pfy);
+    ffy[i] = J.m * dvy - (J.hz * dwx - J.hx * dwz) + (wz * pfx - wx * pfz);
+    ffz[i] = J.m * dvz - (J.hx * dwy - J.hy * dwx) + (wx * pfy - wy * pfx);
+  }
+  if (HAS_FTIP) {
+    fnx[n - 1] += tnx; fny[n - 1] += tny; fnz[n - 1] += tnz;
+    ffx[n - 1] += tfx; ffy[n - 1] += tfy; ffz[n - 1] += tfz;
+  }
+  MP_NOUNROLL
+  for (int i = n - 1; i >= 0; --i) {  // backward pass
+    const auto& J = M.j[i];
+    tau[i] = J.rev * fnz[i] + (T(1) - J.rev) * ffz[i];
+    if (i > 0) {
+      T nx = fnx[i], ny = fny[i], nz = fnz[i], fx = ffx[i], fy = ffy[i], fz = ffz[i];
+      mp_force_up_B(js.c[i], js.s[i], js.d[i], nx, ny, nz, fx, fy, fz);
+      mp_force_up_A(J.ca, J.sa, J.a, nx, ny, nz, fx, fy, fz);
+      fnx[i - 1] += nx; fny[i - 1] += ny; fnz[i - 1] += nz;
+      ffx[i - 1] += fx; ffy[i - 1] += fy; ffz[i - 1] += fz;
+    }
+  }
+}
+
+// mp_mass_matrix_crba of mp_core.h with a run-time joint count; Mq is n x n row-major with row pitch `ld`.
+template <typename T, typename MT>
+MP_HD void mp_dyn_mass_matrix(const MT& M, int n, const MpDynState<T>& js, T* Mq, int ld) {
+  MpRbi<T> Ic;
+  Ic.m = 0; Ic.hx = 0; Ic.hy = 0; Ic.hz = 0; Ic.xx = 0; Ic.xy = 0; Ic.xz = 0; Ic.yy = 0; Ic.yz = 0; Ic.zz = 0;
+  MP_NOUNROLL
+  for (int i = n - 1; i >= 0; --i) {
+    const auto& J = M.j[i];
+    Ic.m = Ic.m + J.m; Ic.hx = Ic.hx + J.hx; Ic.hy = Ic.hy + J.hy; Ic.hz = Ic.hz + J.hz;
+    Ic.xx = Ic.xx + J.Ixx; Ic.xy = Ic.xy + J.Ixy; Ic.xz = Ic.xz + J.Ixz; Ic.yy = Ic.yy + J.Iyy; Ic.yz = Ic.yz + J.Iyz;
+    Ic.zz = Ic.zz + J.Izz;
+    const T r = J.rev, p = T(1) - J.rev;
+    T nx = r * Ic.xz + p * Ic.hy, ny = r * Ic.yz - p * Ic.hx, nz = r * Ic.zz;
+    T fx = -(r * Ic.hy), fy = r * Ic.hx, fz = p * Ic.m;
+    Mq[i * ld + i] = r * nz + p * fz;
+    MP_NOUNROLL
+    for (int k = i; k > 0; --k) {
+      const auto& Jk = M.j[k];
+      mp_force_up_B(js.c[k], js.s[k], js.d[k], nx, ny, nz, fx, fy, fz);
+      mp_force_up_A(Jk.ca, Jk.sa, Jk.a, nx, ny, nz, fx, fy, fz);
+      const T rp = M.j[k - 1].rev;
+      const T v = rp * nz + (T(1) - rp) * fz;
+      Mq[(k - 1) * ld + i] = v;
+      Mq[i * ld + (k - 1)] = v;
+    }
+    if (i > 0) {
+      mp_rbi_up_B(js.c[i], js.s[i], js.d[i], Ic);
+      mp_rbi_up_A(J.ca, J.sa, J.a, Ic);
+    }
+  }
+}
+
+// mp_spd_solve of mp_core.h with a run-time size: Cholesky in place (row pitch `ld`), b overwritten by the solution
+template <typename T>
+MP_HD void mp_dyn_spd_solve(int n, T* A, int ld, T* b) {
+  MP_NOUNROLL
+  for (int j = 0; j < n; ++j) {
+    T d = A[j * ld + j];
+    for (int k = 0; k < j; ++k) d -= A[j * ld + k] * A[j * ld + k];
+    const T inv = mp_rsqrt(d);
+    A[j * ld + j] = inv;
+    for (int i = j + 1; i < n; ++i) {
+      T v = A[i * ld + j];
+      for (int k = 0; k < j; ++k) v -= A[i * ld + k] * A[j * ld + k];
+      A[i * ld + j] = v * inv;
+    }
+  }
+  MP_NOUNROLL
+  for (int i = 0; i < n; ++i) {
+    T v = b[i];
+    for (int k = 0; k < i; ++k) v -= A[i * ld + k] * b[k];
+    b[i] = v * A[i * ld + i];
+  }
+  MP_NOUNROLL
+  for (int i = n - 1; i >= 0; --i) {
+    T v = b[i];
+    for (int k = i + 1; k < n; ++k) v -= A[k * ld + i] * b[k];
+    b[i] = v * A[i * ld + i];
+  }
+}
+
+// qdd = M(q)^-1 (tau - bias), bias = ID(q, qd, 0, g, F)   (reference dynamics/id_fd.py:71-83)
+template <typename T, bool HAS_FTIP, typename MT>
+MP_HD void mp_dyn_forward_dynamics(const MT& M, int n, const T (&a0)[3], const T (&tipn)[3], const T (&tipf)[3], const T* q,
+                                   const T* qd, const T* tau, T* qdd) {
+  MpDynState<T> js;
+  mp_dyn_joint_state<T>(M, n, q, js);
+  T zero[MP_BIG_DOF], bias[MP_BIG_DOF], Mq[MP_BIG_DOF * MP_BIG_DOF];
+  for (int k = 0; k < n; ++k) zero[k] = T(0);
+  mp_dyn_rnea<T, HAS_FTIP>(M, n, a0, tipn, tipf, js, qd, zero, bias);
+  mp_dyn_mass_matrix<T>(M, n, js, Mq, MP_BIG_DOF);
+  for (int k = 0; k < n; ++k) qdd[k] = tau[k] - bias[k];
+  mp_dyn_spd_solve<T>(n, Mq, MP_BIG_DOF, qdd);
+}
+
+// mp_fk_jac of mp_core.h with a run-time joint count: Tout 4x4 row-major, Jout 6 x n row-major (either may be null)
+template <typename T, typename MT>
+MP_HD void mp_dyn_fk_jac(const MT& M, int n, const MpDynState<T>& js, T* Tout, T* Jout) {
+  T x0 = M.base_R[0], x1 = M.base_R[3], x2 = M.base_R[6];
+  T y0 = M.base_R[1], y1 = M.base_R[4], y2 = M.base_R[7];
+  T z0 = M.base_R[2], z1 = M.base_R[5], z2 = M.base_R[8];
+  T p0 = M.base_p[0], p1 = M.base_p[1], p2 = M.base_p[2];
+  MP_NOUNROLL
+  for (int i = 0; i < n; ++i) {
+    const auto& J = M.j[i];
+    if (i > 0) {
+      p0 += J.a * x0; p1 += J.a * x1; p2 += J.a * x2;
+      const T a0 = y0, a1 = y1, a2 = y2;
+      y0 = J.ca * a0 + J.sa * z0; y1 = J.ca * a1 + J.sa * z1; y2 = J.ca * a2 + J.sa * z2;
+      z0 = J.ca * z0 - J.sa * a0; z1 = J.ca * z1 - J.sa * a1; z2 = J.ca * z2 - J.sa * a2;
+    }
+    if (Jout) {
+      const T cx = p1 * z2 - p2 * z1, cy = p2 * z0 - p0 * z2, cz = p0 * z1 - p1 * z0;
+      const T r = J.rev, pr = T(1) - J.rev;
+      Jout[0 * n + i] = r * z0; Jout[1 * n + i] = r * z1; Jout[2 * n + i] = r * z2;
+      Jout[3 * n + i] = r * cx + pr * z0; Jout[4 * n + i] = r * cy + pr * z1; Jout[5 * n + i] = r * cz + pr * z2;
+    }
+    const T c = js.c[i], s = js.s[i], d = js.d[i];
+    const T b0 = x0, b1 = x1, b2 = x2;
+    x0 = c * b0 + s * y0; x1 = c * b1 + s * y1; x2 = c * b2 + s * y2;
+    y0 = c * y0 - s * b0; y1 = c * y1 - s * b1; y2 = c * y2 - s * b2;
+    p0 += d * z0; p1 += d * z1; p2 += d * z2;
+  }
+  if (Tout) {
+    const auto& R = M.tool_R;
+    const auto& t = M.tool_p;
+    Tout[0] = x0 * R[0] + y0 * R[3] + z0 * R[6]; Tout[1] = x0 * R[1] + y0 * R[4] + z0 * R[7]; Tout[2] = x0 * R[2] + y0 * R[5] + z0 * R[8];
+    Tout[4] = x1 * R[0] + y1 * R[3] + z1 * R[6]; Tout[5] = x1 * R[1] + y1 * R[4] + z1 * R[7]; Tout[6] = x1 * R[2] + y1 * R[5] + z1 * R[8];
+    Tout[8] = x2 * R[0] + y2 * R[3] + z2 * R[6]; Tout[9] = x2 * R[1] + y2 * R[4] + z2 * R[7]; Tout[10] = x2 * R[2] + y2 * R[5] + z2 * R[8];
+    Tout[3] = p0 + x0 * t[0] + y0 * t[1] + z0 * t[2];
+    Tout[7] = p1 + x1 * t[0] + y1 * t[1] + z1 * t[2];
+    Tout[11] = p2 + x2 * t[0] + y2 * t[1] + z2 * t[2];
+    Tout[12] = T(0); Tout[13] = T(0); Tout[14] = T(0); Tout[15] = T(1);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ whole rows
+// One row `r` of each operation on plain row-major arrays: what a lane of the k_dyn_* kernels and one iteration of the
+// CPU launchers' loops execute.  Non-finite inputs poison the row (mp_core.h, MpBad).
+template <typename T>
+MP_HD bool mp_dyn_bad(const T* v, int n, MpBad<T>& bad) {
+  for (int j = 0; j < n; ++j) bad.add(v[j]);
+  return bad.any();
+}
+
+template <typename T, bool HAS_FTIP, typename MT>
+MP_HD void mp_dyn_row_fk_jac_id(const MT& M, const MpCall<T>& C, const T* q, const T* qd, const T* qdd, T* Tout, T* Jout, T* tau,
+                                long r) {
+  const int n = M.n;
+  T a[MP_BIG_DOF];
+  for (int j = 0; j < n; ++j) a[j] = q[r * n + j];
+  MpDynState<T> js;
+  mp_dyn_joint_state<T>(M, n, a, js);
+  MpBad<T> bad;
+  mp_dyn_bad(a, n, bad);
+  if (Tout || Jout) {
+    T TT[16], JJ[6 * MP_BIG_DOF];
+    mp_dyn_fk_jac<T>(M, n, js, Tout ? TT : nullptr, Jout ? JJ : nullptr);
+    const bool p = bad.any();
+    if (Tout) for (int k = 0; k < 16; ++k) { T v = TT[k]; mp_poison_if(p, v); Tout[r * 16 + k] = v; }
+    if (Jout) for (int k = 0; k < 6 * n; ++k) { T v = JJ[k]; mp_poison_if(p, v); Jout[r * 6 * n + k] = v; }
+  }
+  if (tau) {
+    T b[MP_BIG_DOF], c[MP_BIG_DOF], t[MP_BIG_DOF];
+    for (int j = 0; j < n; ++j) { b[j] = qd[r * n + j]; c[j] = qdd[r * n + j]; }
+    mp_dyn_rnea<T, HAS_FTIP>(M, n, C.a0, C.F1n, C.F1f, js, b, c, t);
+    mp_dyn_bad(b, n, bad);
+    const bool p = mp_dyn_bad(c, n, bad);
+    for (int j = 0; j < n; ++j) {
+      T v = mp_clip(t[j], M.taumin[j], M.taumax[j]);
+      mp_poison_if(p, v);
+      tau[r * n + j] = v;
+    }
+  }
+}
+
+template <typename T, typename MT>
+MP_HD void mp_dyn_row_mass_matrix(const MT& M, const T* q, T* Mout, long r) {
+  const int n = M.n;
+  T a[MP_BIG_DOF], Mq[MP_BIG_DOF * MP_BIG_DOF];
+  for (int j = 0; j < n; ++j) a[j] = q[r * n + j];
+  MpDynState<T> js;
+  mp_dyn_joint_state<T>(M, n, a, js);
+  mp_dyn_mass_matrix<T>(M, n, js, Mq, MP_BIG_DOF);
+  MpBad<T> bad;
+  const bool p = mp_dyn_bad(a, n, bad);
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) { T v = Mq[i * MP_BIG_DOF + j]; mp_poison_if(p, v); Mout[(r * n + i) * n + j] = v; }
+}
+
+template <typename T, bool HAS_FTIP, typename MT>
+MP_HD void mp_dyn_row_forward_dynamics(const MT& M, const MpCall<T>& C, const T* q, const T* qd, const T* tau, T* qdd, long r) {
+  const int n = M.n;
+  T a[MP_BIG_DOF], b[MP_BIG_DOF], t[MP_BIG_DOF], o[MP_BIG_DOF];
+  for (int j = 0; j < n; ++j) { a[j] = q[r * n + j]; b[j] = qd[r * n + j]; t[j] = tau[r * n + j]; }
+  mp_dyn_forward_dynamics<T, HAS_FTIP>(M, n, C.a0, C.F1n, C.F1f, a, b, t, o);
+  MpBad<T> bad;
+  mp_dyn_bad(a, n, bad); mp_dyn_bad(b, n, bad);
+  const bool p = mp_dyn_bad(t, n, bad);
+  for (int j = 0; j < n; ++j) { T v = o[j]; mp_poison_if(p, v); qdd[r * n + j] = v; }
+}
+
+// forward_dynamics_trajectory for trajectory `b` of B (reference planning/trajectory_dynamics.py:580-708): the loop of
+// mp_body_fd_traj / mp_body_fd_traj_tm with a run-time joint count.  Row (b, i) sits at b * Nt + i (batch-major arrays) or
+// i * B + b (time-major arrays).
+template <typename T, bool HAS_FTIP, typename MT>
+MP_HD void mp_dyn_rollout(const MT& M, const MpCall<T>& C, const T* theta0, const T* dtheta0, const T* taumat, const T* Ftipmat,
+                          long b, long B, long Nt, T h, int intRes, float* pos, float* vel, float* acc, bool time_major) {
+  const int n = M.n;
+  T q[MP_BIG_DOF], qd[MP_BIG_DOF], tau[MP_BIG_DOF], last[MP_BIG_DOF];
+  for (int j = 0; j < n; ++j) { q[j] = theta0[b * n + j]; qd[j] = dtheta0[b * n + j]; }
+  MpBad<T> bad;
+  mp_dyn_bad(q, n, bad); mp_dyn_bad(qd, n, bad);
+  const unsigned nanbits = 0x7fc00000u;
+  for (long i = 0; i < Nt; ++i) {
+    const long row = time_major ? i * B + b : b * Nt + i;
+    for (int j = 0; j < n; ++j) last[j] = T(0);
+    if (i > 0) {
+      T tn[3] = {T(0), T(0), T(0)}, tf[3] = {T(0), T(0), T(0)};
+      for (int j = 0; j < n; ++j) tau[j] = taumat[row * n + j];
+      mp_dyn_bad(tau, n, bad);
+      if (HAS_FTIP) {
+        T F[6];
+        for (int k = 0; k < 6; ++k) F[k] = Ftipmat[row * 6 + k];
+        mp_dyn_bad(F, 6, bad);
+        mp_wrench_to_frame1(M, F, tn, tf);
+      }
+      for (int k = 0; k < intRes; ++k) {
+        mp_dyn_forward_dynamics<T, HAS_FTIP>(M, n, C.a0, tn, tf, q, qd, tau, last);
+        for (int j = 0; j < n; ++j) {
+          qd[j] = qd[j] + last[j] * h;
+          q[j] = mp_clip(q[j] + qd[j] * h, M.qmin[j], M.qmax[j]);
+        }
+      }
+      mp_dyn_bad(qd, n, bad);
+    }
+    const bool poison = i > 0 && bad.any();
+    for (int j = 0; j < n; ++j) {
+      const float nanf_ = __builtin_bit_cast(float, nanbits);
+      pos[row * n + j] = poison ? nanf_ : (float)q[j];
+      vel[row * n + j] = poison ? nanf_ : (float)qd[j];
+      acc[row * n + j] = poison ? nanf_ : (float)last[j];
+    }
+  }
+}
+
+// row (b, t) of the time-scaled trajectory (the arithmetic of traj_row, mp_bodies.h) and, optionally, its torques
+template <bool HAS_FTIP, typename MT>
+MP_HD void mp_dyn_row_traj(const MT& M, const MpCall<float>& C, const float* start, const float* end, long b, long t, long Nt,
+                           double Tf, int method, float* pos, float* vel, float* acc, float* tau) {
+  const int n = M.n;
+  const double tt = (double)t * (Tf / (double)(Nt - 1));
+  double s, sd, sdd;
+  mp_time_scaling(method, tt / Tf, Tf, s, sd, sdd);
+  float p[MP_BIG_DOF], v[MP_BIG_DOF], a[MP_BIG_DOF];
+  for (int j = 0; j < n; ++j) {
+    const float a0 = start[b * n + j];
+    const double d = (double)(end[b * n + j] - a0);  // float32 difference first, as the reference types it
+    p[j] = mp_clip((float)(s * d + (double)a0), M.qmin[j], M.qmax[j]);
+    v[j] = (float)(sd * d);
+    a[j] = (float)(sdd * d);
+  }
+  const long r = b * Nt + t;
+  if (pos) for (int j = 0; j < n; ++j) { pos[r * n + j] = p[j]; vel[r * n + j] = v[j]; acc[r * n + j] = a[j]; }
+  if (tau) {
+    MpDynState<float> js;
+    mp_dyn_joint_state<float>(M, n, p, js);
+    float tq[MP_BIG_DOF];
+    mp_dyn_rnea<float, HAS_FTIP>(M, n, C.a0, C.F1n, C.F1f, js, v, a, tq);
+    MpBad<float> bad;
+    mp_dyn_bad(p, n, bad); mp_dyn_bad(v, n, bad);
+    const bool poison = mp_dyn_bad(a, n, bad);
+    for (int j = 0; j < n; ++j) {
+      float x = mp_clip(tq[j], M.taumin[j], M.taumax[j]);
+      mp_poison_if(poison, x);
+      tau[r * n + j] = x;
+    }
+  }
+}

@@ -5,8 +5,11 @@
 #include "mp_model.h"
 
 struct mp_model {
-  MpModel<double> d;
+  MpModel<double> d;   // n <= MP_MAX_DOF: the unrolled kernels take these by value.  d.n is ALWAYS the joint count.
   MpModel<float> f;
+  bool big = false;    // MP_MAX_DOF < n <= MP_BIG_DOF: only bd / bf hold the joints; the looped kernels (csrc/mp_dyn.h) read them
+  MpBigModel<double> bd;
+  MpBigModel<float> bf;
   uint64_t uid;  // never reused, so a context's device copies cannot alias a destroyed model
 };
 

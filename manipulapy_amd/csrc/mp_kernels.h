@@ -42,6 +42,23 @@ hipError_t mpk_fd_traj_tm(hipStream_t s, const MpModel<T>& M, const MpCall<T>& C
 // (outer, inner, row_dwords x 4 bytes) -> (inner, outer, row_dwords x 4 bytes)
 hipError_t mpk_transpose_rows(hipStream_t s, const void* src, void* dst, long outer, long inner, int row_dwords);
 
+// ---- 9..16 joints (csrc/mp_dyn.h): run-time-n kernels, the model (MpBigModel<T>) resident in device memory
+template <typename T>
+hipError_t mpk_dyn_fk_jac_id(hipStream_t s, const MpBigModel<T>* d_model, const MpCall<T>& C, bool ftip, const T* q, const T* qd,
+                             const T* qdd, T* Tout, T* Jout, T* tau, long rows);
+template <typename T>
+hipError_t mpk_dyn_mass_matrix(hipStream_t s, const MpBigModel<T>* d_model, const T* q, T* Mout, long rows);
+template <typename T>
+hipError_t mpk_dyn_forward_dynamics(hipStream_t s, const MpBigModel<T>* d_model, const MpCall<T>& C, bool ftip, const T* q, const T* qd,
+                                    const T* tau, T* qdd, long rows);
+template <typename T>
+hipError_t mpk_dyn_fd_traj(hipStream_t s, const MpBigModel<T>* d_model, const MpCall<T>& C, const T* theta0, const T* dtheta0,
+                           const T* taumat, const T* Ftipmat, long B, long Nt, T h, int intRes, float* pos, float* vel, float* acc,
+                           bool time_major);
+// pos / vel / acc (all three or none) and / or tau of the time-scaled trajectories
+hipError_t mpk_dyn_traj(hipStream_t s, const MpBigModel<float>* d_model, const MpCall<float>& C, bool ftip, const float* start,
+                        const float* end, long B, long Nt, double Tf, int method, float* pos, float* vel, float* acc, float* tau);
+
 // Cartesian straight-line trajectories between B pose pairs (4x4 row-major float64): float32 (B,Nt,3) x3, (B,Nt,3,3)
 hipError_t mpk_cartesian_traj(hipStream_t s, const double* Xstart, const double* Xend, long B, long Nt, double Tf, int method,
                               float* pos, float* vel, float* acc, float* ori);

@@ -11,6 +11,7 @@
 #include <cstdlib>
 
 #include "mp_bodies.h"
+#include "mp_dyn.h"
 #include "mp_ik.h"
 #include "mp_kernels.h"
 
@@ -322,6 +323,56 @@ __global__ __launch_bounds__(kBlock) void k_ik(const MpModel<double> M, const Mp
   }
 }
 
+// ------------------------------------------------------------------- 9..16 joints: run-time-n kernels (csrc/mp_dyn.h)
+// One lane per row (or per trajectory), the model read through a pointer to device memory, per-joint state in indexed
+// arrays.  Plain per-lane accesses: these kernels exist so that every robot the reference can evaluate computes here too.
+template <typename T> using MpBigConst = const __attribute__((address_space(4))) MpBigModel<T>;
+
+template <typename T, bool HAS_FTIP>
+__global__ __launch_bounds__(kBlock) void k_dyn_fk_jac_id(const MpBigModel<T>* __restrict__ Mdev, const MpCall<T> C,
+                                                          const T* __restrict__ q, const T* __restrict__ qd, const T* __restrict__ qdd,
+                                                          T* __restrict__ Tout, T* __restrict__ Jout, T* __restrict__ tau, long rows) {
+  const long r = (long)blockIdx.x * kBlock + threadIdx.x;
+  if (r >= rows) return;
+  mp_dyn_row_fk_jac_id<T, HAS_FTIP>(*(MpBigConst<T>*)Mdev, C, q, qd, qdd, Tout, Jout, tau, r);
+}
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_dyn_mass_matrix(const MpBigModel<T>* __restrict__ Mdev, const T* __restrict__ q,
+                                                            T* __restrict__ Mout, long rows) {
+  const long r = (long)blockIdx.x * kBlock + threadIdx.x;
+  if (r >= rows) return;
+  mp_dyn_row_mass_matrix<T>(*(MpBigConst<T>*)Mdev, q, Mout, r);
+}
+template <typename T, bool HAS_FTIP>
+__global__ __launch_bounds__(kBlock) void k_dyn_forward_dynamics(const MpBigModel<T>* __restrict__ Mdev, const MpCall<T> C,
+                                                                 const T* __restrict__ q, const T* __restrict__ qd,
+                                                                 const T* __restrict__ tau, T* __restrict__ qdd, long rows) {
+  const long r = (long)blockIdx.x * kBlock + threadIdx.x;
+  if (r >= rows) return;
+  mp_dyn_row_forward_dynamics<T, HAS_FTIP>(*(MpBigConst<T>*)Mdev, C, q, qd, tau, qdd, r);
+}
+template <typename T, bool HAS_FTIP>
+__global__ __launch_bounds__(64) void k_dyn_fd_traj(const MpBigModel<T>* __restrict__ Mdev, const MpCall<T> C,
+                                                    const T* __restrict__ theta0, const T* __restrict__ dtheta0,
+                                                    const T* __restrict__ taumat, const T* __restrict__ Ftipmat, long B, long Nt, T h,
+                                                    int intRes, float* __restrict__ pos, float* __restrict__ vel,
+                                                    float* __restrict__ acc, int time_major) {
+  const long b = (long)blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  mp_dyn_rollout<T, HAS_FTIP>(*(MpBigConst<T>*)Mdev, C, theta0, dtheta0, taumat, Ftipmat, b, B, Nt, h, intRes, pos, vel, acc,
+                              time_major != 0);
+}
+template <bool HAS_FTIP>
+__global__ __launch_bounds__(kBlock) void k_dyn_traj(const MpBigModel<float>* __restrict__ Mdev, const MpCall<float> C,
+                                                     const float* __restrict__ start, const float* __restrict__ end, long B, long Nt,
+                                                     double Tf, int method, float* __restrict__ pos, float* __restrict__ vel,
+                                                     float* __restrict__ acc, float* __restrict__ tau) {
+  const long r = (long)blockIdx.x * kBlock + threadIdx.x;
+  if (r >= B * Nt) return;
+  const long b = r / Nt;
+  mp_dyn_row_traj<HAS_FTIP>(*(MpBigConst<float>*)Mdev, C, start, end, b, r - b * Nt, Nt, Tf, method, pos, vel, acc, tau);
+}
+
 inline unsigned grid_for(long rows) { return (unsigned)((rows + kBlock - 1) / kBlock); }
 
 // float32 variant selection (A/B switch for profiling): MANIPULAPY_HIP_F32 = "packed" (default) | "scalar"
@@ -548,6 +599,62 @@ template hipError_t mpk_fd_traj_tm<float>(hipStream_t, const MpModel<float>&, co
 template hipError_t mpk_fd_traj_tm<double>(hipStream_t, const MpModel<double>&, const MpCall<double>&, const double*,
                                            const double*, const double*, const double*, long, long, double, int, float*, float*,
                                            float*);
+
+// ---- launchers of the run-time-n kernels (d_model: MpBigModel<T> resident in device memory)
+template <typename T>
+hipError_t mpk_dyn_fk_jac_id(hipStream_t s, const MpBigModel<T>* d_model, const MpCall<T>& C, bool ftip, const T* q, const T* qd,
+                             const T* qdd, T* Tout, T* Jout, T* tau, long rows) {
+  if (rows <= 0) return hipSuccess;
+  if (ftip) hipLaunchKernelGGL((k_dyn_fk_jac_id<T, true>), dim3(grid_for(rows)), dim3(kBlock), 0, s, d_model, C, q, qd, qdd, Tout, Jout, tau, rows);
+  else hipLaunchKernelGGL((k_dyn_fk_jac_id<T, false>), dim3(grid_for(rows)), dim3(kBlock), 0, s, d_model, C, q, qd, qdd, Tout, Jout, tau, rows);
+  return hipGetLastError();
+}
+template hipError_t mpk_dyn_fk_jac_id<float>(hipStream_t, const MpBigModel<float>*, const MpCall<float>&, bool, const float*, const float*,
+                                             const float*, float*, float*, float*, long);
+template hipError_t mpk_dyn_fk_jac_id<double>(hipStream_t, const MpBigModel<double>*, const MpCall<double>&, bool, const double*,
+                                              const double*, const double*, double*, double*, double*, long);
+template <typename T>
+hipError_t mpk_dyn_mass_matrix(hipStream_t s, const MpBigModel<T>* d_model, const T* q, T* Mout, long rows) {
+  if (rows <= 0) return hipSuccess;
+  hipLaunchKernelGGL((k_dyn_mass_matrix<T>), dim3(grid_for(rows)), dim3(kBlock), 0, s, d_model, q, Mout, rows);
+  return hipGetLastError();
+}
+template hipError_t mpk_dyn_mass_matrix<float>(hipStream_t, const MpBigModel<float>*, const float*, float*, long);
+template hipError_t mpk_dyn_mass_matrix<double>(hipStream_t, const MpBigModel<double>*, const double*, double*, long);
+template <typename T>
+hipError_t mpk_dyn_forward_dynamics(hipStream_t s, const MpBigModel<T>* d_model, const MpCall<T>& C, bool ftip, const T* q, const T* qd,
+                                    const T* tau, T* qdd, long rows) {
+  if (rows <= 0) return hipSuccess;
+  if (ftip) hipLaunchKernelGGL((k_dyn_forward_dynamics<T, true>), dim3(grid_for(rows)), dim3(kBlock), 0, s, d_model, C, q, qd, tau, qdd, rows);
+  else hipLaunchKernelGGL((k_dyn_forward_dynamics<T, false>), dim3(grid_for(rows)), dim3(kBlock), 0, s, d_model, C, q, qd, tau, qdd, rows);
+  return hipGetLastError();
+}
+template hipError_t mpk_dyn_forward_dynamics<float>(hipStream_t, const MpBigModel<float>*, const MpCall<float>&, bool, const float*,
+                                                    const float*, const float*, float*, long);
+template hipError_t mpk_dyn_forward_dynamics<double>(hipStream_t, const MpBigModel<double>*, const MpCall<double>&, bool, const double*,
+                                                     const double*, const double*, double*, long);
+template <typename T>
+hipError_t mpk_dyn_fd_traj(hipStream_t s, const MpBigModel<T>* d_model, const MpCall<T>& C, const T* theta0, const T* dtheta0,
+                           const T* taumat, const T* Ftipmat, long B, long Nt, T h, int intRes, float* pos, float* vel, float* acc,
+                           bool time_major) {
+  if (B <= 0 || Nt <= 0) return hipSuccess;
+  const dim3 grid((unsigned)((B + 63) / 64));
+  const int tm = time_major ? 1 : 0;
+  if (Ftipmat) hipLaunchKernelGGL((k_dyn_fd_traj<T, true>), grid, dim3(64), 0, s, d_model, C, theta0, dtheta0, taumat, Ftipmat, B, Nt, h, intRes, pos, vel, acc, tm);
+  else hipLaunchKernelGGL((k_dyn_fd_traj<T, false>), grid, dim3(64), 0, s, d_model, C, theta0, dtheta0, taumat, Ftipmat, B, Nt, h, intRes, pos, vel, acc, tm);
+  return hipGetLastError();
+}
+template hipError_t mpk_dyn_fd_traj<float>(hipStream_t, const MpBigModel<float>*, const MpCall<float>&, const float*, const float*,
+                                           const float*, const float*, long, long, float, int, float*, float*, float*, bool);
+template hipError_t mpk_dyn_fd_traj<double>(hipStream_t, const MpBigModel<double>*, const MpCall<double>&, const double*, const double*,
+                                            const double*, const double*, long, long, double, int, float*, float*, float*, bool);
+hipError_t mpk_dyn_traj(hipStream_t s, const MpBigModel<float>* d_model, const MpCall<float>& C, bool ftip, const float* start,
+                        const float* end, long B, long Nt, double Tf, int method, float* pos, float* vel, float* acc, float* tau) {
+  if (B <= 0 || Nt <= 0) return hipSuccess;
+  if (ftip) hipLaunchKernelGGL((k_dyn_traj<true>), dim3(grid_for(B * Nt)), dim3(kBlock), 0, s, d_model, C, start, end, B, Nt, Tf, method, pos, vel, acc, tau);
+  else hipLaunchKernelGGL((k_dyn_traj<false>), dim3(grid_for(B * Nt)), dim3(kBlock), 0, s, d_model, C, start, end, B, Nt, Tf, method, pos, vel, acc, tau);
+  return hipGetLastError();
+}
 
 hipError_t mpk_transpose_rows(hipStream_t s, const void* src, void* dst, long outer, long inner, int row_dwords) {
   if (outer <= 0 || inner <= 0 || row_dwords <= 0) return hipSuccess;

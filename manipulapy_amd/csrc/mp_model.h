@@ -14,7 +14,10 @@
 #pragma once
 
 #ifndef MP_MAX_DOF
-#define MP_MAX_DOF 8
+#define MP_MAX_DOF 8    // fully unrolled kernels (model in kernel arguments / constexpr literal): 1..8 joints
+#endif
+#ifndef MP_BIG_DOF
+#define MP_BIG_DOF 16   // looped run-time-n kernels (csrc/mp_dyn.h, model in device memory): 9..16 joints
 #endif
 
 template <typename T>
@@ -29,18 +32,20 @@ struct MpJoint {
   T Ixx, Ixy, Ixz, Iyy, Iyz, Izz;     // rotational inertia about the link-frame ORIGIN
 };
 
-template <typename T>
-struct MpModel {
+template <typename T, int CAP>
+struct MpModelT {
   int n;
   int pad_[3];
   T base_R[9];   // pose of link frame 1 (at q1 = 0, before its own Rz/Tz) in the space frame
   T base_p[3];
   T tool_R[9];   // end-effector home pose M_ee in link frame n
   T tool_p[3];
-  MpJoint<T> j[MP_MAX_DOF];
-  T qmin[MP_MAX_DOF], qmax[MP_MAX_DOF];       // joint limits (float32-rounded, as the planner holds them)
-  T taumin[MP_MAX_DOF], taumax[MP_MAX_DOF];   // torque limits (+-inf by default)
+  MpJoint<T> j[CAP];
+  T qmin[CAP], qmax[CAP];       // joint limits (float32-rounded, as the planner holds them)
+  T taumin[CAP], taumax[CAP];   // torque limits (+-inf by default)
 };
+template <typename T> using MpModel = MpModelT<T, MP_MAX_DOF>;     // what the unrolled kernels take by value
+template <typename T> using MpBigModel = MpModelT<T, MP_BIG_DOF>;  // what the looped kernels read through a pointer
 
 // Per-call constants derived on the host in fp64 (gravity / tip wrench seen from link frame 1's parent).
 template <typename T>

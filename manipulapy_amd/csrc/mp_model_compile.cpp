@@ -84,8 +84,10 @@ void fail(char* err, size_t errlen, const char* fmt, int i, double v) {
 
 }  // namespace
 
+namespace {
 // FK through the compiled chain (fp64), for the self-check and for host-side consumers.
-void mp_compiled_fk(const MpModel<double>& m, const double* q, double* T /*16*/) {
+template <int CAP>
+void compiled_fk(const MpModelT<double, CAP>& m, const double* q, double* T /*16*/) {
   double A[16] = {m.base_R[0], m.base_R[1], m.base_R[2], m.base_p[0], m.base_R[3], m.base_R[4], m.base_R[5], m.base_p[1],
                   m.base_R[6], m.base_R[7], m.base_R[8], m.base_p[2], 0, 0, 0, 1};
   for (int i = 0; i < m.n; ++i) {
@@ -103,18 +105,24 @@ void mp_compiled_fk(const MpModel<double>& m, const double* q, double* T /*16*/)
                          m.tool_R[6], m.tool_R[7], m.tool_R[8], m.tool_p[2], 0, 0, 0, 1};
   mat4_mul(A, Tl, T);
 }
+}  // namespace
 
-int mp_compile_model(int n, const double* S, const double* Mcom, const double* G, const double* M_ee,
-                     const double* joint_limits, const double* torque_limits, MpModel<double>* out, char* err,
-                     size_t errlen) {
-  if (n < 1 || n > MP_MAX_DOF) { fail(err, errlen, "dof %d outside 1..8 (%g)", n, 0.0); return 1; }
+void mp_compiled_fk(const MpModel<double>& m, const double* q, double* T) { compiled_fk<MP_MAX_DOF>(m, q, T); }
+void mp_compiled_fk(const MpBigModel<double>& m, const double* q, double* T) { compiled_fk<MP_BIG_DOF>(m, q, T); }
+
+namespace {
+template <int CAP>
+int compile_model(int n, const double* S, const double* Mcom, const double* G, const double* M_ee,
+                  const double* joint_limits, const double* torque_limits, MpModelT<double, CAP>* out, char* err,
+                  size_t errlen) {
+  if (n < 1 || n > CAP) { fail(err, errlen, "dof %d outside 1..%g", n, (double)CAP); return 1; }
   std::memset(out, 0, sizeof(*out));
   out->n = n;
   const double EPS = 1e-9;
 
   // ---- 1. joint lines at the home pose
-  V3 z[MP_MAX_DOF], c[MP_MAX_DOF];
-  bool rev[MP_MAX_DOF];
+  V3 z[CAP], c[CAP];
+  bool rev[CAP];
   for (int i = 0; i < n; ++i) {
     V3 w{S[0 * n + i], S[1 * n + i], S[2 * n + i]}, v{S[3 * n + i], S[4 * n + i], S[5 * n + i]};
     const double nw = norm(w), nv = norm(v);
@@ -133,7 +141,7 @@ int mp_compile_model(int n, const double* S, const double* Mcom, const double* G
   }
 
   // ---- 2. modified-DH frame assignment: x_i = common normal from axis i to axis i+1
-  Frame H[MP_MAX_DOF];
+  Frame H[CAP];
   for (int i = 0; i < n; ++i) {
     Frame& F = H[i];
     F.z = z[i];
@@ -259,7 +267,7 @@ int mp_compile_model(int n, const double* S, const double* Mcom, const double* G
     rel(H[n - 1], E, out->tool_R, out->tool_p);
   }
   const double INF = HUGE_VAL;
-  for (int i = 0; i < MP_MAX_DOF; ++i) {
+  for (int i = 0; i < CAP; ++i) {
     const bool in = i < n;
     // the planner holds limits as float32 (reference planning/trajectory_planning.py:218-223)
     out->qmin[i] = (in && joint_limits) ? (double)(float)joint_limits[2 * i] : -INF;
@@ -270,7 +278,7 @@ int mp_compile_model(int n, const double* S, const double* Mcom, const double* G
 
   // ---- 6. self-check: compiled chain == product of exponentials (reference kinematics/fk.py:59-70)
   for (int trial = 0; trial < 4; ++trial) {
-    double q[MP_MAX_DOF], T[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}, E[16], Tc[16];
+    double q[CAP], T[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}, E[16], Tc[16];
     for (int i = 0; i < n; ++i) {
       q[i] = (trial == 0) ? 0.0 : std::sin(12.9898 * (i + 1) + 78.233 * trial) * (rev[i] ? 2.5 : 0.05);
       double Si[6];
@@ -279,18 +287,28 @@ int mp_compile_model(int n, const double* S, const double* Mcom, const double* G
       mat4_mul(T, E, T);
     }
     mat4_mul(T, M_ee, T);
-    mp_compiled_fk(*out, q, Tc);
+    compiled_fk<CAP>(*out, q, Tc);
     double e = 0;
     for (int k = 0; k < 16; ++k) e = std::fmax(e, std::fabs(T[k] - Tc[k]));
     if (e > 1e-9) { fail(err, errlen, "self-check %d: compiled FK differs from PoE FK by %g", trial, e); return 5; }
   }
   return 0;
 }
+}  // namespace
+
+int mp_compile_model(int n, const double* S, const double* Mcom, const double* G, const double* M_ee,
+                     const double* joint_limits, const double* torque_limits, MpModel<double>* out, char* err,
+                     size_t errlen) {
+  return compile_model<MP_MAX_DOF>(n, S, Mcom, G, M_ee, joint_limits, torque_limits, out, err, errlen);
+}
+int mp_compile_model_big(int n, const double* S, const double* Mcom, const double* G, const double* M_ee,
+                         const double* joint_limits, const double* torque_limits, MpBigModel<double>* out, char* err,
+                         size_t errlen) {
+  return compile_model<MP_BIG_DOF>(n, S, Mcom, G, M_ee, joint_limits, torque_limits, out, err, errlen);
+}
 
 // per-call constants (gravity, tip wrench) seen from the frame link 1 is attached to
-void mp_make_call(const MpModel<double>& m, const double g[3], const double Ftip[6], MpCall<double>* c) {
-  const double* R = m.base_R;
-  const double* p = m.base_p;
+void mp_make_call(const double R[9], const double p[3], const double g[3], const double Ftip[6], MpCall<double>* c) {
   for (int k = 0; k < 3; ++k) c->a0[k] = -(R[0 + k] * g[0] + R[3 + k] * g[1] + R[6 + k] * g[2]);
   double n[3] = {0, 0, 0}, f[3] = {0, 0, 0};
   if (Ftip) { n[0] = Ftip[0]; n[1] = Ftip[1]; n[2] = Ftip[2]; f[0] = Ftip[3]; f[1] = Ftip[4]; f[2] = Ftip[5]; }

@@ -34,6 +34,7 @@ from typing import Dict, Optional, Tuple
 
 import numpy as np
 
+from . import _hip
 from . import registry as _reg
 from .backend import get_backend
 
@@ -94,7 +95,7 @@ class OptimizedTrajectoryPlanning:
         """Dynamics tables + THIS planner's float32 joint / torque limits, compiled once."""
         if self._model is None:
             self._model = self.dynamics.hip_model(self.joint_limits.astype(np.float64), self.torque_limits.astype(np.float64))
-            if self._gpu_routed() and os.environ.get("MANIPULAPY_HIP_SPECIALIZE", "1") != "0":
+            if self._gpu_routed() and os.environ.get("MANIPULAPY_HIP_SPECIALIZE", "1") != "0" and self._model.n <= _hip.MP_MAX_DOF:
                 # float32 kernels with this robot's constants baked in (hiprtc, ~1.5 s once, cached on disk);
                 # purely an optimisation: the generic kernels compute the same values
                 try:

@@ -610,10 +610,15 @@ def dump_urdf_suite():
         lim = finite_limits(sm, n)
         th = rng.uniform(lim[:, 0], lim[:, 1]); dth = rng.uniform(-1, 1, n); ddth = rng.uniform(-1, 1, n)
         d[f"{name}__theta"], d[f"{name}__dtheta"], d[f"{name}__ddtheta"] = th, dth, ddth
-        if n <= 8:
-            clear_caches(dyn)
-            d[f"{name}__tau"] = np.asarray(dyn.inverse_dynamics(th, dth, ddth, G_VEC, FTIP_REF))
-            d[f"{name}__T"] = np.asarray(sm.forward_kinematics(th))
+        clear_caches(dyn)
+        d[f"{name}__tau"] = np.asarray(dyn.inverse_dynamics(th, dth, ddth, G_VEC, FTIP_REF))
+        d[f"{name}__T"] = np.asarray(sm.forward_kinematics(th))
+        if n > 8:  # the robots only the run-time-n kernels serve: pin every operation of the path, not only tau and T
+            d[f"{name}__mass"] = np.asarray(dyn.mass_matrix(th))
+            d[f"{name}__J"] = np.asarray(sm.jacobian(th))
+            d[f"{name}__qdd"] = np.asarray(dyn.forward_dynamics(th, dth, d[f"{name}__tau"], G_VEC, FTIP_REF))
+            d[f"{name}__c"] = np.asarray(dyn.velocity_quadratic_forces(th, dth))
+            d[f"{name}__g"] = np.asarray(dyn.gravity_forces(th, G_VEC))
         write_skeleton(path, os.path.join(out_dir, f"{name}.urdf"), name)
         names.append(name)
         print(f"urdf suite: {name}: n={n} ee={ee} leaves={len(leaves) + 1}", flush=True)

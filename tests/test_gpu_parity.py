@@ -1661,19 +1661,18 @@ def test_planner_profiling_specialised_dispatch_and_model_release(tables):
 def test_urdf_to_kernel_for_the_reference_robot_database(monkeypatch):
     """URDF file -> manipulapy_amd.URDFToSerialManipulator -> OptimizedTrajectoryPlanning.inverse_dynamics_trajectory /
     SerialManipulator.forward_kinematics on the GPU, against the REFERENCE's torques and poses for the same URDF
-    (tests/golden/urdf_suite.npz: all robots of the reference's database with <= 8 joints - UR, Panda, iiwa, Gen3,
-    Fanuc, CRX, IRB2400, xArm6 + gripper, Robotiq - and its URDF test fixtures incl. the branched tree, the prismatic
-    chain, mimic and continuous joints); float64 and float32 kernels."""
+    (tests/golden/urdf_suite.npz: all robots of the reference's database - UR, Panda, iiwa, Gen3, Fanuc, CRX, IRB2400,
+    xArm6 + gripper, Robotiq, and the Jaco arms whose hands bring them to 9 / 10 actuated joints (run-time-n kernels,
+    csrc/mp_dyn.h) - and its URDF test fixtures incl. the branched tree, the prismatic chain, mimic and continuous joints);
+    float64 and float32 kernels."""
     import manipulapy_amd as mp
 
     monkeypatch.setenv("MANIPULAPY_HIP_SPECIALIZE", "0")   # 34 robots x ~2 s of hiprtc each buys nothing here: generic kernels
     z = np.load(golden_path("urdf_suite.npz"))
     g, F = np.array([0.0, 0.0, -9.81]), np.array([1.0, -2.0, 0.5, 3.0, -1.5, 0.75])
-    done = 0
+    done, big = 0, []
     with mp.use_backend("hip"):
         for name in [str(n) for n in z["names"]]:
-            if f"{name}__tau" not in z.files:
-                continue   # the Jaco arms with their three-finger hands have 9 / 10 actuated joints (MP_MAX_DOF = 8)
             proc = mp.URDFToSerialManipulator(golden_path(os.path.join("urdf_suite", f"{name}.urdf")), tip_link=str(z[f"{name}__ee"]))
             n = proc.robot_data["actuated_joints_num"]
             th, dth, ddth, want = z[f"{name}__theta"], z[f"{name}__dtheta"], z[f"{name}__ddtheta"], z[f"{name}__tau"]
@@ -1688,8 +1687,23 @@ def test_urdf_to_kernel_for_the_reference_robot_database(monkeypatch):
             assert_f32(t32, np.tile(want, (rows, 1)))
             np.testing.assert_allclose(proc.serial_manipulator.forward_kinematics(th), z[f"{name}__T"], atol=1e-10, err_msg=name)
             np.testing.assert_allclose(proc.dynamics.inverse_dynamics(th, dth, ddth, g, F), want, rtol=1e-6, atol=1e-7, err_msg=name)
+            if n > 8:   # every operation of the path on the robots only the looped kernels serve
+                big.append(name)
+                sm, dyn = proc.serial_manipulator, proc.dynamics
+                np.testing.assert_allclose(sm.jacobian(th), z[f"{name}__J"], atol=1e-10)
+                np.testing.assert_allclose(dyn.mass_matrix(th), z[f"{name}__mass"], rtol=1e-9, atol=1e-11)
+                np.testing.assert_allclose(dyn.gravity_forces(th, g), z[f"{name}__g"], rtol=1e-9, atol=1e-10)
+                qdd = dyn.forward_dynamics(th, dth, want, g, F)
+                np.testing.assert_allclose(qdd, z[f"{name}__qdd"], rtol=1e-5, atol=1e-5 * max(1.0, float(np.abs(z[f"{name}__qdd"]).max())))
+                r = pl.batch_forward_dynamics_trajectory(np.tile(th, (70, 1)), np.tile(dth, (70, 1)), np.tile(want, (70, 4, 1)), g,
+                                                         np.tile(F, (70, 4, 1)), 1e-4, 1)
+                np.testing.assert_allclose(r["accelerations"][69, 1], z[f"{name}__qdd"], rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(z[f"{name}__qdd"]).max())))
+                traj = pl.batch_joint_trajectory(np.tile(th, (3, 1)).astype(np.float32), np.tile(th + 0.1, (3, 1)).astype(np.float32), 1.0, 700, 5)
+                tau_f = pl.batch_inverse_dynamics_trajectory(np.tile(th, (3, 1)).astype(np.float32), np.tile(th + 0.1, (3, 1)).astype(np.float32), 1.0, 700, 5)
+                two = pl.inverse_dynamics_trajectory(traj["positions"].reshape(-1, n), traj["velocities"].reshape(-1, n), traj["accelerations"].reshape(-1, n))
+                np.testing.assert_allclose(tau_f.reshape(-1, n), two, rtol=1e-5, atol=1e-5 * float(np.abs(two).max()))
             done += 1
-    assert done >= 30
+    assert done >= 32 and sorted(big) == ["jaco_6dof", "jaco_7dof"], (done, big)
 
 
 def test_transpose_rows_and_time_major_edge_cases(tables):
@@ -1767,5 +1781,62 @@ def test_id_f32_large_random_sample_two_level_bound(tables):
             fused = ctx.traj_id_fused_host(m, s_, e_, 2.0, 1000, 5).reshape(-1, 6)
             par = bench.parity_rows(fused, want, "f32", terms)
             assert par["ok"] and par["rows_over_first_bound"] <= 30, (specialise, par)
+    finally:
+        ctx.destroy()
+
+
+@pytest.mark.parametrize("robot", ROBOTS)
+def test_looped_kernels_equal_the_unrolled_kernels(robot, tables, dyn_golden, monkeypatch):
+    """MANIPULAPY_HIP_LOOPED=1 builds a 6..8-joint model for the run-time-n kernels (k_dyn_*, csrc/mp_dyn.h): inverse dynamics,
+    FK + Jacobian, mass matrix, forward dynamics, the roll-out on both device layouts, trajectory generation and the fused
+    kernel must reproduce the unrolled kernels (which the goldens pin) - float32 and float64, ragged row counts."""
+    from manipulapy_amd import _hip
+
+    tab, z = tables[robot], dyn_golden[robot]
+    n = tab.n
+    ctx = _hip.HipContext(0)
+    try:
+        unrolled = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee, tab.joint_limits)
+        monkeypatch.setenv("MANIPULAPY_HIP_LOOPED", "1")
+        looped = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee, tab.joint_limits)
+        monkeypatch.delenv("MANIPULAPY_HIP_LOOPED")
+        rng = np.random.default_rng(17)
+        rows = 333
+        q, qd, qdd = (rng.uniform(-1.5, 1.5, (rows, n)) for _ in range(3))
+        g, F = z["g"], z["ftips"][0]
+        for dtype, tol in ((np.float64, 1e-11), (np.float32, 3e-5)):
+            for wrench in (None, F):
+                a = ctx.id_trajectory_host(unrolled, q, qd, qdd, g, wrench, dtype=dtype)
+                b = ctx.id_trajectory_host(looped, q, qd, qdd, g, wrench, dtype=dtype)
+                np.testing.assert_allclose(b, a, rtol=tol, atol=tol * np.abs(a).max())
+        Ta, Ja, ta = ctx.fk_jac_id_host(unrolled, q, qd, qdd, g, F)
+        Tb, Jb, tb = ctx.fk_jac_id_host(looped, q, qd, qdd, g, F)
+        np.testing.assert_allclose(Tb, Ta, rtol=0, atol=1e-12); np.testing.assert_allclose(Jb, Ja, rtol=0, atol=1e-12)
+        np.testing.assert_allclose(tb, ta, rtol=1e-11, atol=1e-11 * np.abs(ta).max())
+        np.testing.assert_allclose(ctx.mass_matrix_host(looped, q), ctx.mass_matrix_host(unrolled, q), rtol=1e-11, atol=1e-12)
+        fa = ctx.forward_dynamics_host(unrolled, q, qd, ta, g, F)
+        fb = ctx.forward_dynamics_host(looped, q, qd, ta, g, F)
+        np.testing.assert_allclose(fb, fa, rtol=1e-7, atol=1e-8 * max(1.0, float(np.abs(fa).max())))
+        B, Nt = 70, 10
+        th0, dth0, tm, Fm = _c5_workload(tab, B, Nt, 5 + n)
+        for dtype, tol in ((np.float64, 1e-6), (np.float32, 2e-4)):
+            ra = _rollout(ctx, unrolled, th0, dth0, tm, Fm, 0.01, 2, dtype)
+            for layout in ("batch_major", "time_major"):
+                rb = _rollout(ctx, looped, th0, dth0, tm, Fm, 0.01, 2, dtype, layout)
+                for k in range(3):
+                    np.testing.assert_allclose(rb[k], ra[k], rtol=0, atol=tol * max(1.0, float(np.abs(ra[k]).max())))
+        lim = tab.joint_limits
+        s_ = rng.uniform(lim[:, 0], lim[:, 1], (5, n)).astype(np.float32); e_ = rng.uniform(lim[:, 0], lim[:, 1], (5, n)).astype(np.float32)
+        pa = ctx.batch_trajectory_host(unrolled, s_, e_, 2.0, 77, 5)
+        pb = ctx.batch_trajectory_host(looped, s_, e_, 2.0, 77, 5)
+        for k in range(3):
+            np.testing.assert_array_equal(pb[k], pa[k])
+        ua = ctx.traj_id_fused_host(unrolled, s_, e_, 2.0, 77, 5)
+        ub = ctx.traj_id_fused_host(looped, s_, e_, 2.0, 77, 5)
+        np.testing.assert_allclose(ub, ua, rtol=3e-5, atol=3e-5 * np.abs(ua).max())
+        with pytest.raises(_hip.HipError):
+            ctx.specialize(looped)
+        with pytest.raises(_hip.HipError):
+            ctx.inverse_kinematics_host(looped, Ta[:2], q[:2])
     finally:
         ctx.destroy()

@@ -154,3 +154,96 @@ def test_inverse_kinematics_cpu_launcher_against_reference_runs(robot, tables):
         one = sm.iterative_inverse_kinematics(T[3], q0[3], max_iterations=300)
         np.testing.assert_array_equal(one[0], th[3])
         assert one[1] == ok[3] and one[2] == it[3]
+
+
+# ----------------------------------------------------------------------------- more than 8 joints (csrc/mp_dyn.h)
+def _jaco(name):
+    import os
+
+    z = np.load(golden_path("urdf_suite.npz"))
+    proc = mp.URDFToSerialManipulator(golden_path(os.path.join("urdf_suite", f"{name}.urdf")), tip_link=str(z[f"{name}__ee"]))
+    return z, proc
+
+
+@pytest.mark.parametrize("name", ["jaco_6dof", "jaco_7dof"])
+def test_robots_with_more_than_eight_joints_compute_on_the_cpu_launchers(name):
+    """The reference's Jaco arms with their three-finger hands (9 / 10 actuated joints, ManipulaPy_data/__init__.py:174-189):
+    forward kinematics, Jacobian, mass matrix, velocity / gravity forces, inverse and forward dynamics, and the planner's
+    inverse-dynamics trajectory and roll-out through the run-time-n rows of csrc/mp_dyn.h (NumPy backend: *_cpu launchers),
+    against the reference's own values for the same URDF (tests/golden/urdf_suite.npz)."""
+    z, proc = _jaco(name)
+    sm, dyn = proc.serial_manipulator, proc.dynamics
+    n = proc.robot_data["actuated_joints_num"]
+    assert n in (9, 10)
+    th, dth, ddth = z[f"{name}__theta"], z[f"{name}__dtheta"], z[f"{name}__ddtheta"]
+    g, F = np.array([0.0, 0.0, -9.81]), np.array([1.0, -2.0, 0.5, 3.0, -1.5, 0.75])
+    np.testing.assert_allclose(sm.forward_kinematics(th), z[f"{name}__T"], atol=1e-10)
+    np.testing.assert_allclose(sm.jacobian(th), z[f"{name}__J"], atol=1e-10)
+    M = dyn.mass_matrix(th)
+    np.testing.assert_allclose(M, z[f"{name}__mass"], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(dyn.gravity_forces(th, g), z[f"{name}__g"], rtol=1e-9, atol=1e-10)
+    c = dyn.velocity_quadratic_forces(th, dth)
+    np.testing.assert_allclose(c, z[f"{name}__c"], rtol=0, atol=1e-7 * max(1.0, np.abs(z[f"{name}__c"]).max()))  # the reference's is a finite difference
+    tau = dyn.inverse_dynamics(th, dth, ddth, g, F)
+    np.testing.assert_allclose(tau, z[f"{name}__tau"], rtol=1e-6, atol=1e-6)
+    qdd = dyn.forward_dynamics(th, dth, z[f"{name}__tau"], g, F)
+    np.testing.assert_allclose(qdd, z[f"{name}__qdd"], rtol=1e-5, atol=1e-5 * max(1.0, np.abs(z[f"{name}__qdd"]).max()))
+    np.testing.assert_allclose(qdd, ddth, rtol=1e-5, atol=1e-5)   # FD(ID(qdd)) == qdd
+    lim = np.array([[-10.0, 10.0]] * n)
+    pl = mp.OptimizedTrajectoryPlanning(sm, None, dyn, lim, use_cuda=False)
+    rows = 70
+    q = np.tile(th, (rows, 1)); qd = np.tile(dth, (rows, 1)); q2 = np.tile(ddth, (rows, 1))
+    t64 = pl.inverse_dynamics_trajectory(q, qd, q2, g, F)
+    assert t64.dtype == np.float32 and t64.shape == (rows, n)
+    np.testing.assert_allclose(t64, np.tile(z[f"{name}__tau"], (rows, 1)), rtol=2e-6, atol=2e-6 * np.abs(z[f"{name}__tau"]).max())
+    t32 = pl.inverse_dynamics_trajectory(q.astype(np.float32), qd.astype(np.float32), q2.astype(np.float32), g, F)
+    np.testing.assert_allclose(t32, t64, rtol=1e-4, atol=5e-5 * np.abs(t64).max())
+    # a short roll-out: row 1's acceleration is forward_dynamics of the initial state, as in the reference's loop
+    taum = np.tile(z[f"{name}__tau"], (4, 1))
+    r = pl.forward_dynamics_trajectory(th, dth, taum, g, np.tile(F, (4, 1)), 1e-4, 1)
+    assert r["positions"].shape == (4, n) and r["accelerations"].dtype == np.float32
+    np.testing.assert_allclose(r["accelerations"][1], z[f"{name}__qdd"], rtol=1e-4, atol=1e-4 * max(1.0, np.abs(z[f"{name}__qdd"]).max()))
+    traj = pl.joint_trajectory(th, th + 0.1, 1.0, 16, 5)
+    assert traj["positions"].shape == (16, n)
+    with pytest.raises(Exception):   # inverse kinematics is not offered beyond 8 joints
+        sm.iterative_inverse_kinematics(z[f"{name}__T"], th, max_iterations=5)
+
+
+@pytest.mark.parametrize("robot", ROBOTS)
+def test_looped_rows_equal_the_unrolled_rows_on_the_benchmark_robots(robot, tables, dyn_golden, monkeypatch):
+    """MANIPULAPY_HIP_LOOPED=1 builds a 6..8-joint model for the run-time-n path: its CPU launchers must reproduce the
+    unrolled ones (same frames, same per-joint arithmetic) and the reference's goldens."""
+    from manipulapy_amd import _hip
+
+    tab, z = tables[robot], dyn_golden[robot]
+    unrolled = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee, tab.joint_limits)
+    monkeypatch.setenv("MANIPULAPY_HIP_LOOPED", "1")
+    looped = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee, tab.joint_limits)
+    monkeypatch.delenv("MANIPULAPY_HIP_LOOPED")
+    assert looped.blob()["joints"].shape == (16, 16) and unrolled.blob()["joints"].shape == (8, 16)
+    q, qd, qdd = z["thetas"], z["dthetas"], z["ddthetas"]
+    g = z["g"]
+    for dtype, tol in ((np.float64, 1e-12), (np.float32, 2e-5)):
+        for F in (None, z["ftips"][0]):
+            a = _hip.cpu_id_trajectory(unrolled, q, qd, qdd, g, F, dtype=dtype)
+            b = _hip.cpu_id_trajectory(looped, q, qd, qdd, g, F, dtype=dtype)
+            np.testing.assert_allclose(b, a, rtol=tol, atol=tol * np.abs(a).max())
+    Ta, Ja, _ = _hip.cpu_fk_jac_id(unrolled, q)
+    Tb, Jb, _ = _hip.cpu_fk_jac_id(looped, q)
+    np.testing.assert_allclose(Tb, Ta, rtol=0, atol=1e-13); np.testing.assert_allclose(Jb, Ja, rtol=0, atol=1e-13)
+    np.testing.assert_allclose(_hip.cpu_mass_matrix(looped, q), _hip.cpu_mass_matrix(unrolled, q), rtol=1e-12, atol=1e-13)
+    tau = _hip.cpu_id_trajectory(unrolled, q, qd, qdd, g, z["ftips"][0], dtype=np.float64)
+    fa = _hip.cpu_forward_dynamics(unrolled, q, qd, tau, g, z["ftips"][0])
+    fb = _hip.cpu_forward_dynamics(looped, q, qd, tau, g, z["ftips"][0])
+    np.testing.assert_allclose(fb, fa, rtol=1e-8, atol=1e-9 * max(1.0, np.abs(fa).max()))
+    B, N = 5, 12
+    rng = np.random.default_rng(5)
+    tm = np.tile(tau[:B, None, :], (1, N, 1)) + rng.uniform(-1e-3, 1e-3, (B, N, tab.n))
+    Fm = rng.uniform(-0.02, 0.02, (B, N, 6))
+    for dtype in (np.float64, np.float32):
+        ra = _hip.cpu_fd_trajectory(unrolled, q[:B], qd[:B] * 0.1, tm, g, Fm, 0.01, 2, dtype=dtype)
+        rb = _hip.cpu_fd_trajectory(looped, q[:B], qd[:B] * 0.1, tm, g, Fm, 0.01, 2, dtype=dtype)
+        for k in range(3):
+            np.testing.assert_allclose(rb[k], ra[k], rtol=0, atol=(1e-6 if dtype == np.float64 else 2e-4) * max(1.0, float(np.abs(ra[k]).max())))
+    with pytest.raises(_hip.HipError):
+        looped.specialize_source()
