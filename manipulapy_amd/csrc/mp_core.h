@@ -232,21 +232,11 @@ MP_HD const auto& mp_joint_of(const MT& M, int i) { return M.j[i]; }
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef const __attribute__((address_space(4))) MpModel<float> MpModelConstF;
 typedef const __attribute__((address_space(4))) MpModel<double> MpModelConstD;
-#if defined(MP_DM_WHOLE_JOINT)  // A/B: the whole 64-byte joint in one scalar load per use site
-__device__ __forceinline__ MpJoint<float> mp_joint_of(MpModelConstF& M, int i) {
-  MpModelConstF* p = &M;
-  asm volatile("" : "+s"(p));
-  MpJoint<float> J;
-  __builtin_memcpy(&J, (const void __attribute__((address_space(4)))*)&p->j[i], sizeof J);
-  return J;
-}
-#else
 __device__ __forceinline__ const __attribute__((address_space(4))) MpJoint<float>& mp_joint_of(MpModelConstF& M, int i) {
   MpModelConstF* p = &M;
   asm volatile("" : "+s"(p));  // opaque to CSE / hoisting: joint i's constants are loaded here
   return p->j[i];
 }
-#endif
 __device__ __forceinline__ const __attribute__((address_space(4))) MpJoint<double>& mp_joint_of(MpModelConstD& M, int i) {
   MpModelConstD* p = &M;
   asm volatile("" : "+s"(p));
