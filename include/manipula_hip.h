@@ -321,6 +321,10 @@ int mp_comm_destroy(mp_comm* comm);
 /* d_recv (nranks * bytes_per_rank) <- every rank's d_send (bytes_per_rank); enqueued on the compute
  * stream after the kernels already queued there. */
 int mp_comm_allgather(mp_comm* comm, const void* d_send, void* d_recv, size_t bytes_per_rank);
+/* Uneven shards (B % nranks != 0; sharding.shard_range gives the first B % nranks ranks one trajectory more): rank r
+ * contributes bytes_of_rank[r] bytes and d_recv receives the shards back to back in rank order.  Grouped ncclSend / ncclRecv
+ * per peer on the compute stream (ncclAllGather needs equal counts).  Every rank passes the same nranks-entry array. */
+int mp_comm_allgatherv(mp_comm* comm, const void* d_send, void* d_recv, const size_t* bytes_of_rank);
 /* The same reassembly, overlapped with compute.  d_all holds nranks slots of bytes_per_rank; a rank writes ITS slot
  * chunk by chunk with ordinary launches on the compute stream (output pointer = slot + offset) and, after the launches
  * of a chunk, calls mp_comm_exchange_chunk: the bytes [offset, offset + nbytes) of its slot go to every peer, every
@@ -329,6 +333,10 @@ int mp_comm_allgather(mp_comm* comm, const void* d_send, void* d_recv, size_t by
  * beside the exchange.  Every rank must issue the same sequence of chunks.  mp_comm_join makes the compute stream
  * wait for all exchanges issued so far (call it before anything reads d_all). */
 int mp_comm_exchange_chunk(mp_comm* comm, void* d_all, size_t bytes_per_rank, size_t offset, size_t nbytes);
+/* mp_comm_exchange_chunk for uneven shards: rank r's slot starts slot_offset[r] bytes into d_all, and this chunk is
+ * [chunk_offset[r], chunk_offset[r] + chunk_bytes[r]) of it; nranks entries each, the same arrays on every rank. */
+int mp_comm_exchange_chunk_v(mp_comm* comm, void* d_all, const size_t* slot_offset, const size_t* chunk_offset,
+                             const size_t* chunk_bytes);
 /* Buffer lifetime: mp_free hands a buffer back to the pool immediately, and the pool orders reuse with respect to the
  * context's COMPUTE stream only.  A buffer a communicator is still reading or writing on its own stream (after
  * mp_comm_exchange_chunk) must therefore not be freed before mp_comm_join (mp_comm_allgather runs on the compute

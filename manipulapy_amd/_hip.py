@@ -125,6 +125,8 @@ SIGNATURES = {
     "mp_comm_allgather": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t]),
     "mp_comm_exchange_chunk": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t]),
     "mp_comm_join": (ctypes.c_int, [_vp]),
+    "mp_comm_allgatherv": (ctypes.c_int, [_vp, _vp, _vp, ctypes.POINTER(ctypes.c_size_t)]),
+    "mp_comm_exchange_chunk_v": (ctypes.c_int, [_vp, _vp, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),
 }
 
 _lib = None
@@ -922,6 +924,19 @@ class HipComm:
         peer, the peers' same range arrives in their slots, on the communicator's own stream (overlaps later kernels)."""
         _check(self.ctx.lib.mp_comm_exchange_chunk(self.handle, _p(d_all), ctypes.c_size_t(int(bytes_per_rank)),
                                                    ctypes.c_size_t(int(offset)), ctypes.c_size_t(int(nbytes))))
+
+    def _sizes(self, values):
+        if len(values) != self.nranks:
+            raise ValueError(f"expected {self.nranks} per-rank values, got {len(values)}")
+        return (ctypes.c_size_t * self.nranks)(*[int(v) for v in values])
+
+    def allgatherv(self, d_send, d_recv, bytes_of_rank) -> None:
+        """Uneven shards: rank r contributes bytes_of_rank[r] bytes; d_recv gets them back to back in rank order."""
+        _check(self.ctx.lib.mp_comm_allgatherv(self.handle, _p(d_send), _p(d_recv), self._sizes(bytes_of_rank)))
+
+    def exchange_chunk_v(self, d_all, slot_offset, chunk_offset, chunk_bytes) -> None:
+        _check(self.ctx.lib.mp_comm_exchange_chunk_v(self.handle, _p(d_all), self._sizes(slot_offset), self._sizes(chunk_offset),
+                                                     self._sizes(chunk_bytes)))
 
     def join(self) -> None:
         """The compute stream waits for every exchange issued so far."""

@@ -771,7 +771,9 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
                         (((unsigned long long)taumat | (HAS_FTIP ? (unsigned long long)Ftipmat : 0ull)) & 127ull) == 0;
   // (named members, literal indices: with arrays the compiler turns "select between two array elements" into a load from a
   //  selected ADDRESS and the arrays end up in scratch memory)
-  struct Held { mp_io_u4 a, b, c, d, e, f; } held_tau, held_f;
+  struct Held { mp_io_u4 a, b, c, d, e, f; };
+  const mp_io_u4 zero4 = {0u, 0u, 0u, 0u};
+  Held held_tau = {zero4, zero4, zero4, zero4, zero4, zero4}, held_f = held_tau;
   int ex_s0 = 0, ex_u0 = 0;
   __amdgpu_buffer_rsrc_t ex_rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(taumat), 0, exact_in ? (int)in_bytes : 0, 0x00020000);
   __amdgpu_buffer_rsrc_t ex_rf = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(HAS_FTIP ? Ftipmat : taumat), 0,
@@ -812,7 +814,8 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
       if (exact_in && full) {
         const int tile = (int)(i0 / MP_FD_KS);
         const int phi = (tile - ex_u0) & 3;
-        const int off = phi != 3 ? ((ex_s0 + 96 * tile + 92) & ~127) : 0x7ffffff0;
+        // (a lane that needs nothing reads past the descriptor and gets nothing; the sentinel leaves room for the + 112 below)
+        const int off = phi != 3 ? ((ex_s0 + 96 * tile + 92) & ~127) : 0x7fffff00;
         const bool p0 = phi == 0, p1 = phi == 1, p2 = phi == 2;
         // the run's six 16-byte pieces: group G (pieces 2G, 2G+1) is new group G in phase 0, G-1 in phase 1, G-2 in phase 2,
         // and otherwise one of the held groups (held pieces a..f = pieces 2..7 of the previous line)

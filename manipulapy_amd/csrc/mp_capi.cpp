@@ -55,6 +55,9 @@ struct mp_ctx {
   int tab_method = 0;
   bool tab_volatile = false;                           // a launch graph holds a table kernel: never trust the cache again
   std::vector<void*> retired_tabs;                     // outgrown tables that captured graphs may still reference
+  int live_graphs = 0;                                 // launch graphs captured on this context and not yet destroyed
+  std::vector<hipModule_t> retired_mods;               // code objects / device models of destroyed models that a live graph (or
+  std::vector<void*> retired_bufs;                     //   an open capture) may still reference: released with the last graph
   std::recursive_mutex mu;                             // serialises the entry points of this context (CTX_ENTER)
   // profiling (mp_ctx_set_profiling): every device-pointer entry point brackets its launches with a timed HIP event pair
   // on the compute stream and an roctx range; the pairs are resolved when the figures are read (mp_ctx_profile)
@@ -73,6 +76,7 @@ struct mp_graph {
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
   int device = -1;
+  mp_ctx* ctx = nullptr;  // the context it was captured on (only dereferenced while that context is still registered)
 };
 
 namespace {
@@ -161,6 +165,23 @@ struct KernelScope {
     if (a && b) {
       if (hipEventRecord(b, ctx->compute) == hipSuccess) ctx->prof_pending.push_back({a, b});
       else { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
+      // Nobody may ever read the figures (profiling is a flag of the shared context; other users of it never call
+      // mp_ctx_profile): pairs that have completed are folded into the totals here, oldest first, once a few are pending,
+      // so a long-lived process holds a bounded number of events.
+      if (ctx->prof_pending.size() > 32) {
+        size_t done = 0;
+        while (done < ctx->prof_pending.size() && hipEventQuery(ctx->prof_pending[done].b) == hipSuccess) {
+          float ms = 0.f;
+          if (hipEventElapsedTime(&ms, ctx->prof_pending[done].a, ctx->prof_pending[done].b) == hipSuccess) {
+            ctx->prof_total_ms += ms; ctx->prof_last_ms = ms; ctx->prof_launches += 1;
+          }
+          (void)hipEventDestroy(ctx->prof_pending[done].a);
+          (void)hipEventDestroy(ctx->prof_pending[done].b);
+          ++done;
+        }
+        (void)hipGetLastError();  // hipErrorNotReady of the first unfinished pair is not an error
+        ctx->prof_pending.erase(ctx->prof_pending.begin(), ctx->prof_pending.begin() + (long)done);
+      }
     }
     if (ranged) roctx().pop();
   }
@@ -693,6 +714,7 @@ int mp_ctx_destroy(mp_ctx* ctx) {
     if (kv.second.mod_ilp) (void)hipModuleUnload(kv.second.mod_ilp);
     if (kv.second.mod) (void)hipModuleUnload(kv.second.mod);
   }
+  for (hipModule_t m : ctx->retired_mods) (void)hipModuleUnload(m);
   for (auto& kv : ctx->live) (void)hipFree(kv.first);
   if (ctx->queue_counter) (void)hipFree(ctx->queue_counter);
   if (ctx->time_tab) (void)hipFree(ctx->time_tab);
@@ -963,7 +985,8 @@ int mp_graph_end(mp_ctx* ctx, mp_graph** out) {
   mp_graph* gr = new (std::nothrow) mp_graph;
   if (!gr) { (void)hipGraphExecDestroy(ex); (void)hipGraphDestroy(g); }
   REQUIRE(gr, "mp_graph_end: out of host memory");
-  gr->graph = g; gr->exec = ex; gr->device = ctx->device;
+  gr->graph = g; gr->exec = ex; gr->device = ctx->device; gr->ctx = ctx;
+  ++ctx->live_graphs;
   *out = gr;
   return MP_OK;
 }
@@ -974,12 +997,34 @@ int mp_graph_launch(mp_ctx* ctx, mp_graph* graph) {
   HIP_TRY(hipGraphLaunch(graph->exec, ctx->compute));
   return MP_OK;
 }
+// what destroyed models left behind for the sake of live graphs (ctx->mu held, device bound, no capture open)
+static void release_retired(mp_ctx* ctx) {
+  (void)hipStreamSynchronize(ctx->compute);
+  for (hipModule_t m : ctx->retired_mods) (void)hipModuleUnload(m);
+  ctx->retired_mods.clear();
+  for (void* p : ctx->retired_bufs) (void)mp_free(ctx, p);
+  ctx->retired_bufs.clear();
+}
+
 int mp_graph_destroy(mp_graph* graph) {
   if (!graph) return MP_OK;
+  int prev = -1;
+  (void)hipGetDevice(&prev);
   (void)hipSetDevice(graph->device);
   (void)hipGraphExecDestroy(graph->exec);
   (void)hipGraphDestroy(graph->graph);
+  {
+    std::lock_guard<std::mutex> lk(g_ctxs_mu);
+    if (graph->ctx && g_ctxs.count(graph->ctx)) {  // the context may have been destroyed first (it took the retired objects with it)
+      std::lock_guard<std::recursive_mutex> cl(graph->ctx->mu);
+      if (--graph->ctx->live_graphs <= 0 && !graph->ctx->capturing) {
+        graph->ctx->live_graphs = 0;
+        release_retired(graph->ctx);
+      }
+    }
+  }
   delete graph;
+  if (prev >= 0) (void)hipSetDevice(prev);
   return MP_OK;
 }
 
@@ -1022,31 +1067,48 @@ int mp_model_create(int n, const double* S, const double* Mcom, const double* G,
 }
 int mp_model_destroy(mp_model* model) {
   if (!model) return MP_OK;
-  // drop what the live contexts hold for this model: its specialised code object and its device-resident copy
-  std::lock_guard<std::mutex> lk(g_ctxs_mu);
-  for (mp_ctx* ctx : g_ctxs) {
-    std::lock_guard<std::recursive_mutex> cl(ctx->mu);
-    auto sp = ctx->specs.find(model->uid);
-    auto dm = ctx->dev_models.find(model->uid);
-    const bool has_big = ctx->dev_big[0].count(model->uid) || ctx->dev_big[1].count(model->uid);
-    if (sp == ctx->specs.end() && dm == ctx->dev_models.end() && !has_big) continue;
-    (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->compute);  // a launch of this model's kernels may still be in flight
-    if (sp != ctx->specs.end()) {
-      if (sp->second.mod_ilp) (void)hipModuleUnload(sp->second.mod_ilp);
-      if (sp->second.mod) (void)hipModuleUnload(sp->second.mod);
-      ctx->specs.erase(sp);
-    }
-    if (dm != ctx->dev_models.end()) {
-      (void)mp_free(ctx, dm->second);
-      ctx->dev_models.erase(dm);
-    }
-    for (auto& table : ctx->dev_big) {
-      auto it = table.find(model->uid);
-      if (it != table.end()) { (void)mp_free(ctx, it->second); table.erase(it); }
+  // Drop what the live contexts hold for this model: its specialised code objects and its device-resident copies.  A launch
+  // graph captured on a context keeps kernel nodes of those code objects and the addresses of those copies (the handles
+  // hold no reference to the models they captured), and during an open capture neither a stream synchronisation nor a
+  // buffer release is legal - so with a live graph or an open capture they are RETIRED (released with the last graph, or
+  // with the context) instead of released here.  Called from Python's garbage collector at arbitrary times: the calling
+  // thread's current device is restored.
+  int prev = -1;
+  {
+    std::lock_guard<std::mutex> lk(g_ctxs_mu);
+    if (!g_ctxs.empty()) (void)hipGetDevice(&prev);  // (no context, no HIP call: CPU-launcher processes never touch the runtime)
+    for (mp_ctx* ctx : g_ctxs) {
+      std::lock_guard<std::recursive_mutex> cl(ctx->mu);
+      auto sp = ctx->specs.find(model->uid);
+      auto dm = ctx->dev_models.find(model->uid);
+      const bool has_big = ctx->dev_big[0].count(model->uid) || ctx->dev_big[1].count(model->uid);
+      if (sp == ctx->specs.end() && dm == ctx->dev_models.end() && !has_big) continue;
+      const bool retire = ctx->capturing || ctx->live_graphs > 0;
+      if (!retire) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->compute);  // a launch of this model's kernels may still be in flight
+      }
+      if (sp != ctx->specs.end()) {
+        for (hipModule_t m : {sp->second.mod_ilp, sp->second.mod}) {
+          if (!m) continue;
+          if (retire) ctx->retired_mods.push_back(m);
+          else (void)hipModuleUnload(m);
+        }
+        ctx->specs.erase(sp);
+      }
+      auto drop = [&](void* p) {
+        if (retire) ctx->retired_bufs.push_back(p);
+        else (void)mp_free(ctx, p);
+      };
+      if (dm != ctx->dev_models.end()) { drop(dm->second); ctx->dev_models.erase(dm); }
+      for (auto& table : ctx->dev_big) {
+        auto it = table.find(model->uid);
+        if (it != table.end()) { drop(it->second); table.erase(it); }
+      }
     }
   }
   delete model;
+  if (prev >= 0) (void)hipSetDevice(prev);
   return MP_OK;
 }
 int mp_model_dof(const mp_model* model, int* n) {
@@ -1137,6 +1199,70 @@ int mp_model_specialize(mp_ctx* ctx, const mp_model* model) {
           (void)hipModuleUnload(m2);
         }
       }
+    }
+  }
+  // Self-check of THIS code object's non-finite guard.  The specialised kernels are built with -ffinite-math-only; their guard
+  // works on bit patterns (csrc/mp_core.h) and today's compiler leaves it alone, but that flag would let a future one fold it.
+  // A row with a NaN and a row with an infinity must come back NaN and their neighbours finite - from the one-row, the
+  // two-row and the float64 kernel - or the code object is refused and the generic kernels (built without the flag) serve.
+  {
+    const int n = model->d.n;
+    const long rows = 128, pairs = rows / 2;
+    std::vector<float> h((size_t)rows * n, 0.25f), out((size_t)rows * n * 2, 0.0f);
+    std::vector<double> hd((size_t)rows * n, 0.25), outd((size_t)rows * n, 0.0);
+    h[3 * n] = __builtin_nanf(""); h[(size_t)70 * n + (n > 1 ? 1 : 0)] = __builtin_inff();
+    hd[3 * n] = __builtin_nan(""); hd[(size_t)70 * n + (n > 1 ? 1 : 0)] = -__builtin_inf();
+    const size_t fb = h.size() * sizeof(float), db = hd.size() * sizeof(double);
+    Scratch sc(ctx);
+    void *dq, *dz, *d0, *d1, *dqd, *dzd, *d2;
+    if (int rc = sc.get(fb, &dq)) return rc;
+    if (int rc = sc.get(fb, &dz)) return rc;
+    if (int rc = sc.get(fb, &d0)) return rc;
+    if (int rc = sc.get(fb, &d1)) return rc;
+    if (int rc = sc.get(db, &dqd)) return rc;
+    if (int rc = sc.get(db, &dzd)) return rc;
+    if (int rc = sc.get(db, &d2)) return rc;
+    auto unload = [&] { if (sp.mod_ilp) (void)hipModuleUnload(sp.mod_ilp); (void)hipModuleUnload(sp.mod); };
+    hipError_t he = hipMemcpyAsync(dq, h.data(), fb, hipMemcpyHostToDevice, ctx->compute);
+    if (he == hipSuccess) he = hipMemsetAsync(dz, 0, fb, ctx->compute);
+    if (he == hipSuccess) he = hipMemcpyAsync(dqd, hd.data(), db, hipMemcpyHostToDevice, ctx->compute);
+    if (he == hipSuccess) he = hipMemsetAsync(dzd, 0, db, ctx->compute);
+    if (he != hipSuccess) { unload(); return hip_err(he, "mp_model_specialize: self-check upload"); }
+    MpCall<float> cf;
+    MpCall<double> cd;
+    make_call<float>(model, nullptr, nullptr, &cf);
+    make_call<double>(model, nullptr, nullptr, &cd);
+    long nr = rows, np_ = pairs;
+    const float *q = (const float*)dq, *z = (const float*)dz;
+    float *o0 = (float*)d0, *o1 = (float*)d1;
+    const double *qd_ = (const double*)dqd, *zd = (const double*)dzd;
+    double* o2 = (double*)d2;
+    void* a0[] = {&cf, &q, &z, &z, &o0, &nr};
+    void* a1[] = {&cf, &q, &z, &z, &o1, &np_};
+    void* a2[] = {&cd, &qd_, &zd, &zd, &o2, &nr};
+    int rc = launch_spec(ctx, sp.id_s[0], rows, a0);
+    if (!rc) rc = launch_spec(ctx, sp.id_pk[0], pairs, a1);
+    if (!rc) rc = launch_spec(ctx, sp.id_d[0], rows, a2);
+    if (rc) { unload(); return rc; }
+    he = hipMemcpyAsync(out.data(), d0, fb, hipMemcpyDeviceToHost, ctx->compute);
+    if (he == hipSuccess) he = hipMemcpyAsync(out.data() + h.size(), d1, fb, hipMemcpyDeviceToHost, ctx->compute);
+    if (he == hipSuccess) he = hipMemcpyAsync(outd.data(), d2, db, hipMemcpyDeviceToHost, ctx->compute);
+    if (he == hipSuccess) he = hipStreamSynchronize(ctx->compute);
+    if (he != hipSuccess) { unload(); return hip_err(he, "mp_model_specialize: self-check download"); }
+    bool ok = true;
+    for (int k = 0; k < 3 && ok; ++k) {
+      for (long r : {3L, 70L, 4L, 69L, 0L, 127L}) {
+        const bool want_nan = r == 3 || r == 70;
+        for (int j = 0; j < n; ++j) {
+          const double v = k < 2 ? (double)out[(size_t)k * h.size() + (size_t)r * n + j] : outd[(size_t)r * n + j];
+          if ((v != v) != want_nan) ok = false;
+        }
+      }
+    }
+    if (!ok) {
+      unload();
+      return set_err(MP_ERR_UNSUPPORTED, "mp_model_specialize: the specialised kernels of this toolchain do not keep the non-finite row "
+                                         "contract (self-check failed); the generic kernels are used instead");
     }
   }
   ctx->specs[model->uid] = sp;

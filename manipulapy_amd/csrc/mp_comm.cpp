@@ -123,6 +123,36 @@ int mp_comm_allgather(mp_comm* comm, const void* d_send, void* d_recv, size_t by
   return MP_OK;
 }
 
+// Uneven shards (B % world != 0): rank r contributes bytes_of_rank[r] bytes, d_recv holds the shards back to back in rank order.
+// ncclAllGather wants equal counts, so this is the grouped point-to-point form (one ncclSend + ncclRecv per peer in one group:
+// xGMI is point to point, all links carry a share at once) on the compute stream, plus a device copy of this rank's own shard.
+int mp_comm_allgatherv(mp_comm* comm, const void* d_send, void* d_recv, const size_t* bytes_of_rank) {
+  if (!comm || !d_recv || !bytes_of_rank) return mp_set_error(MP_ERR_INVALID, "mp_comm_allgatherv: null argument");
+  if (hipSetDevice(mp_ctx_device(comm->ctx)) != hipSuccess) return mp_set_error(MP_ERR_HIP, "mp_comm_allgatherv: hipSetDevice failed");
+  hipStream_t s = mp_ctx_compute_stream(comm->ctx);
+  char* base = static_cast<char*>(d_recv);
+  size_t mine_off = 0;
+  for (int p = 0; p < comm->rank; ++p) mine_off += bytes_of_rank[p];
+  const size_t mine = bytes_of_rank[comm->rank];
+  if (mine && !d_send) return mp_set_error(MP_ERR_INVALID, "mp_comm_allgatherv: null send buffer");
+  if (mine && d_send != base + mine_off &&
+      hipMemcpyAsync(base + mine_off, d_send, mine, hipMemcpyDeviceToDevice, s) != hipSuccess)
+    return mp_set_error(MP_ERR_HIP, "mp_comm_allgatherv: device copy of the local shard failed");
+  if (comm->nranks == 1) return MP_OK;
+  if (int rc = g_api.GroupStart()) return nccl_fail("ncclGroupStart", rc);
+  int err = 0;
+  size_t off = 0;
+  for (int p = 0; p < comm->nranks && !err; off += bytes_of_rank[p], ++p) {
+    if (p == comm->rank) continue;
+    if (mine) err = g_api.Send(d_send, mine, 0, p, comm->comm, s);
+    if (!err && bytes_of_rank[p]) err = g_api.Recv(base + off, bytes_of_rank[p], 0, p, comm->comm, s);
+  }
+  const int end = g_api.GroupEnd();
+  if (err) return nccl_fail("ncclSend / ncclRecv", err);
+  if (end) return nccl_fail("ncclGroupEnd", end);
+  return MP_OK;
+}
+
 // order stream `after` behind everything queued so far on stream `before`
 static int chain(hipStream_t before, hipStream_t after, const char* fn) {
   hipEvent_t ev = nullptr;
@@ -150,6 +180,28 @@ int mp_comm_exchange_chunk(mp_comm* comm, void* d_all, size_t bytes_per_rank, si
     // xGMI is point to point: one send and one receive per peer, all seven links busy at once (no ring)
     err = g_api.Send(base + (size_t)comm->rank * bytes_per_rank + offset, nbytes, 0, p, comm->comm, comm->stream);
     if (!err) err = g_api.Recv(base + (size_t)p * bytes_per_rank + offset, nbytes, 0, p, comm->comm, comm->stream);
+  }
+  const int end = g_api.GroupEnd();
+  if (err) return nccl_fail("ncclSend / ncclRecv", err);
+  if (end) return nccl_fail("ncclGroupEnd", end);
+  return MP_OK;
+}
+
+// The overlapped exchange for uneven shards: rank r's slot starts slot_offset[r] bytes into d_all and this chunk covers
+// [chunk_offset[r], chunk_offset[r] + chunk_bytes[r]) of it (every rank passes the same three arrays, nranks entries each).
+int mp_comm_exchange_chunk_v(mp_comm* comm, void* d_all, const size_t* slot_offset, const size_t* chunk_offset, const size_t* chunk_bytes) {
+  if (!comm || !d_all || !slot_offset || !chunk_offset || !chunk_bytes) return mp_set_error(MP_ERR_INVALID, "mp_comm_exchange_chunk_v: null argument");
+  if (hipSetDevice(mp_ctx_device(comm->ctx)) != hipSuccess) return mp_set_error(MP_ERR_HIP, "mp_comm_exchange_chunk_v: hipSetDevice failed");
+  if (int rc = chain(mp_ctx_compute_stream(comm->ctx), comm->stream, "mp_comm_exchange_chunk_v: event chain failed")) return rc;
+  if (comm->nranks == 1) return MP_OK;
+  char* base = static_cast<char*>(d_all);
+  const int me = comm->rank;
+  if (int rc = g_api.GroupStart()) return nccl_fail("ncclGroupStart", rc);
+  int err = 0;
+  for (int p = 0; p < comm->nranks && !err; ++p) {
+    if (p == me) continue;
+    if (chunk_bytes[me]) err = g_api.Send(base + slot_offset[me] + chunk_offset[me], chunk_bytes[me], 0, p, comm->comm, comm->stream);
+    if (!err && chunk_bytes[p]) err = g_api.Recv(base + slot_offset[p] + chunk_offset[p], chunk_bytes[p], 0, p, comm->comm, comm->stream);
   }
   const int end = g_api.GroupEnd();
   if (err) return nccl_fail("ncclSend / ncclRecv", err);

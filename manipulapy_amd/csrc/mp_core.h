@@ -175,6 +175,10 @@ MP_HD T mp_clip(T v, typename MpTraits<T>::S lo, typename MpTraits<T>::S hi) {
 // A value is non-finite iff its exponent field is all ones: for the raw (high) word b that is  b >= POS as a signed
 // integer (positive values) or b >= NEG as an unsigned one (negative values) - two running maxima, which the compiler
 // folds into v_max3_i32 / v_max3_u32: one instruction per value checked.
+// (Under -ffinite-math-only a float value carries "never NaN / inf" facts that a future optimiser might follow through the
+// bit cast; routing the word through an empty asm would stop that and costs a register copy per value - +30 instructions per
+// roll-out step.  Instead mp_model_specialize CHECKS every code object it loads: a NaN row must come back NaN, or the
+// specialised kernels are refused and the generic ones, built without that flag, serve - csrc/mp_capi.cpp.)
 MP_HD int mp_hi_word(float x) { return __builtin_bit_cast(int, x); }
 MP_HD int mp_hi_word(double x) { return (int)(__builtin_bit_cast(long long, x) >> 32); }
 template <typename T> struct MpBadBits;

@@ -35,7 +35,9 @@ int thread_count(int64_t items, int64_t grain, int nthreads) {
   return (int)std::max<int64_t>(1, std::min<int64_t>(want, by_work));
 }
 
-// fn(lo, hi) over [0, items) in contiguous slices, one per thread; small inputs stay on the calling thread
+// fn(lo, hi) over [0, items) in contiguous slices, one per thread; small inputs stay on the calling thread.  A thread that
+// cannot be started (std::system_error under a pid / thread limit) must not cross the C ABI as an exception: its slice, and
+// every later one, runs on the calling thread instead, and the threads already started are joined either way.
 template <class F>
 int parallel_for(int64_t items, int64_t grain, int nthreads, F fn) {
   const int T = thread_count(items, grain, nthreads);
@@ -43,13 +45,22 @@ int parallel_for(int64_t items, int64_t grain, int nthreads, F fn) {
   std::vector<std::thread> pool;
   pool.reserve(T - 1);
   const int64_t per = (items + T - 1) / T;
+  int started = 1;
   for (int t = 1; t < T; ++t) {
     const int64_t lo = std::min(items, t * per), hi = std::min(items, lo + per);
-    if (lo < hi) pool.emplace_back([=] { fn(lo, hi); });
+    if (lo >= hi) continue;
+    bool spawned = false;
+    try {
+      pool.emplace_back([=] { fn(lo, hi); });
+      spawned = true;
+      ++started;
+    } catch (...) {
+    }
+    if (!spawned) fn(lo, hi);
   }
   fn((int64_t)0, std::min(items, per));
   for (auto& th : pool) th.join();
-  return T;
+  return started;
 }
 
 bool any_nonzero(const double* F) {

@@ -87,8 +87,12 @@ class OptimizedTrajectoryPlanning:
         self._model = None
         # reference planning/trajectory_planning.py:295-296 (profile_start): here a timed HIP event pair and an roctx
         # range around every launch of the context, read back into performance_stats after each GPU call
+        self._profiling_held = False
+        self._prof_base = {"kernel_ms_total": 0.0, "timed_calls": 0}
         if self.enable_profiling and self.cuda_available and self._gpu_routed():
-            _reg.get_context().set_profiling(True)
+            _reg.acquire_profiling()          # released by close() / __del__: the flag belongs to the shared context
+            self._profiling_held = True
+            self._prof_base = _reg.get_context().profile()   # this planner reports what was timed SINCE, not the context's totals
 
     # ------------------------------------------------------------------ plumbing
     def _hip_model(self):
@@ -126,10 +130,11 @@ class OptimizedTrajectoryPlanning:
         if kind == "gpu":
             self.performance_stats["kernel_launches"] += 1
             self.performance_stats["best_kernel_used"] = "hip"
-            if self.enable_profiling:
+            if self.enable_profiling and self._profiling_held:
                 p = _reg.get_context().profile()
-                self.performance_stats.update({"gpu_kernel_ms_total": p["kernel_ms_total"], "gpu_kernel_ms_last": p["kernel_ms_last"],
-                                               "gpu_timed_calls": p["timed_calls"]})
+                self.performance_stats.update({"gpu_kernel_ms_total": p["kernel_ms_total"] - self._prof_base["kernel_ms_total"],
+                                               "gpu_kernel_ms_last": p["kernel_ms_last"],
+                                               "gpu_timed_calls": p["timed_calls"] - self._prof_base["timed_calls"]})
         else:
             self._last_cpu_time = dt
 
@@ -354,8 +359,20 @@ class OptimizedTrajectoryPlanning:
         self.performance_stats = {"gpu_calls": 0, "cpu_calls": 0, "total_gpu_time": 0.0, "total_cpu_time": 0.0,
                                   "memory_transfers": 0, "kernel_launches": 0, "speedup_achieved": 0.0, "best_kernel_used": "none",
                                   "gpu_kernel_ms_total": 0.0, "gpu_kernel_ms_last": 0.0, "gpu_timed_calls": 0}
-        if self.enable_profiling and self._gpu_routed():
-            _reg.get_context().profile(reset=True)
+        if self.enable_profiling and getattr(self, "_profiling_held", False):
+            self._prof_base = _reg.get_context().profile()   # re-base this planner; other users of the context keep their totals
+
+    def close(self) -> None:
+        """Give back what this planner holds on the shared context (its profiling reference)."""
+        if getattr(self, "_profiling_held", False):
+            self._profiling_held = False
+            _reg.release_profiling()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def cleanup_gpu_memory(self) -> None:
         """Return the context's pooled device buffers to the driver (reference planning/trajectory_planning.py:502-524)."""

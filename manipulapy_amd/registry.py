@@ -306,6 +306,32 @@ def _launch_fk_jac_gpu(model, q, qd=None, qdd=None, g=None, Ftip=None, want_T=Tr
     return get_context().fk_jac_id_host(model, q, qd, qdd, g, Ftip, want_T, want_J)
 
 
+# ---- profiling is a flag of the shared context: planners that asked for it hold a reference, the last one out switches it off
+_profiling_users = 0
+_profiling_lock = threading.Lock()
+
+
+def acquire_profiling() -> None:
+    global _profiling_users
+    with _profiling_lock:
+        _profiling_users += 1
+        if _profiling_users == 1:
+            get_context().set_profiling(True)
+
+
+def release_profiling() -> None:
+    global _profiling_users
+    with _profiling_lock:
+        if _profiling_users == 0:
+            return
+        _profiling_users -= 1
+        if _profiling_users == 0 and _ctx is not None and getattr(_ctx, "handle", None) is not None:
+            try:
+                _ctx.set_profiling(False)
+            except Exception:  # interpreter shutdown: the context may already be gone
+                pass
+
+
 def _launch_ik_gpu(model, T_desired, theta0, **kw):
     return get_context().inverse_kinematics_host(model, T_desired, theta0, **kw)
 

@@ -13,7 +13,7 @@ from typing import Optional, Tuple
 
 import numpy as np
 
-__all__ = ["ShardInfo", "shard_range", "shard_batch", "dist_env", "HostGather"]
+__all__ = ["ShardInfo", "shard_range", "shard_batch", "shard_layout", "dist_env", "HostGather"]
 
 
 @dataclass(frozen=True)
@@ -40,6 +40,14 @@ def shard_range(total: int, world: int, rank: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def shard_layout(total: int, world: int, bytes_per_item: int):
+    """(byte counts, byte offsets) of every rank's shard of `total` items in the gathered buffer, rank order - what
+    HipComm.allgatherv / exchange_chunk_v take when total % world != 0."""
+    counts = [(hi - lo) * bytes_per_item for lo, hi in (shard_range(total, world, r) for r in range(world))]
+    offsets = [sum(counts[:r]) for r in range(world)]
+    return counts, offsets
+
+
 def shard_batch(start_batch: np.ndarray, end_batch: np.ndarray, world: int, rank: int):
     """This rank's rows of the (B, n) start / end arrays."""
     lo, hi = shard_range(start_batch.shape[0], world, rank)
@@ -59,15 +67,26 @@ class HostGather:
             dist.init_process_group("gloo", rank=self.info.rank, world_size=self.info.world)
 
     def allgather(self, local: np.ndarray) -> np.ndarray:
-        """(world * rows_local, ...) in rank order; all shards must have the same shape."""
+        """(sum of the ranks' rows, ...) in rank order.  The shards may differ in their FIRST dimension (shard_range hands the
+        first B % world ranks one trajectory more): the row counts are exchanged first, every shard travels padded to the
+        largest and is trimmed on arrival."""
         if self.info.world == 1:
             return local.copy()
         import torch
 
-        t = torch.from_numpy(np.ascontiguousarray(local))
+        local = np.ascontiguousarray(local)
+        counts = torch.zeros(self.info.world, dtype=torch.int64)
+        mine = torch.tensor([local.shape[0]], dtype=torch.int64)
+        parts = [torch.zeros(1, dtype=torch.int64) for _ in range(self.info.world)]
+        self.dist.all_gather(parts, mine)
+        counts = [int(p.item()) for p in parts]
+        top = max(counts)
+        padded = np.zeros((top,) + local.shape[1:], dtype=local.dtype)
+        padded[: local.shape[0]] = local
+        t = torch.from_numpy(padded)
         outs = [torch.empty_like(t) for _ in range(self.info.world)]
         self.dist.all_gather(outs, t)
-        return np.concatenate([o.numpy() for o in outs], axis=0)
+        return np.concatenate([o.numpy()[:c] for o, c in zip(outs, counts)], axis=0)
 
     def barrier(self) -> None:
         if self.info.world > 1:

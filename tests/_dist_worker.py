@@ -1,5 +1,7 @@
-"""Worker for tests/test_host_logic.py::test_two_process_gloo_shard_and_gather (launched by
-torch.distributed.run, world_size 2, gloo, CPU only)."""
+"""Worker for tests/test_host_logic.py::test_multi_process_gloo_shard_and_gather (launched by torch.distributed.run,
+world_size 2 or 3, gloo, CPU only).  Every rank evaluates ITS shard of the torque history - what north_star all-gathers -
+through the CPU launchers, the shards (uneven when B % world != 0) are gathered in rank order, and rank 0 compares the
+result with the single-process evaluation of the whole batch."""
 import sys
 
 import numpy as np
@@ -21,13 +23,20 @@ def main(out_path):
     local = pl.batch_joint_trajectory(ls, le, 2.0, N, 5)["positions"]
     assert local.shape == (hi - lo, N, 6)
     gathered = hg.allgather(local)
+    # the torque history: inverse_dynamics_trajectory of the shard (generation fused into it), gathered
+    tau_local = pl.batch_inverse_dynamics_trajectory(ls, le, 2.0, N, 5)
+    assert tau_local.shape == (hi - lo, N, 6) and tau_local.dtype == np.float32
+    tau = hg.allgather(tau_local)
+    counts, offsets = sharding.shard_layout(B, info.world, N * 6 * 4)
+    assert counts[info.rank] == tau_local.nbytes and sum(counts) == tau.nbytes and offsets[info.rank] == lo * N * 6 * 4
     payload = hg.broadcast_bytes(bytes(range(128)) if info.rank == 0 else None, 128)
     assert payload == bytes(range(128))
     mx = hg.max(float(info.rank))
     hg.barrier()
     if info.rank == 0:
         single = pl.batch_joint_trajectory(s, e, 2.0, N, 5)["positions"]
-        np.savez(out_path, gathered=gathered, single=single, world=info.world, max_val=mx)
+        tau_single = pl.batch_inverse_dynamics_trajectory(s, e, 2.0, N, 5)
+        np.savez(out_path, gathered=gathered, single=single, tau=tau, tau_single=tau_single, world=info.world, max_val=mx)
 
 
 if __name__ == "__main__":

@@ -1640,7 +1640,7 @@ def test_planner_profiling_specialised_dispatch_and_model_release(tables):
         assert st2["gpu_kernel_ms_total"] <= st2["total_gpu_time"] * 1e3  # kernel time is inside the wall time of the calls
         pl.reset_performance_stats()
         assert pl.get_performance_stats()["gpu_timed_calls"] == 0
-        ctx.set_profiling(False)
+        pl.close()   # gives the context's profiling flag back (reference-counted: registry.acquire_profiling)
         # generic vs specialised: MANIPULAPY_HIP_SPECIALIZE is honoured per process, so check the flag on a fresh model instead
         tab = tables["ur5"]
         m = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee, tab.joint_limits)
@@ -1838,5 +1838,113 @@ def test_looped_kernels_equal_the_unrolled_kernels(robot, tables, dyn_golden, mo
             ctx.specialize(looped)
         with pytest.raises(_hip.HipError):
             ctx.inverse_kinematics_host(looped, Ta[:2], q[:2])
+    finally:
+        ctx.destroy()
+
+
+def test_launch_graph_survives_the_models_it_captured(tables):
+    """A captured launch graph holds kernel nodes of a model's specialised code object and the address of its device-resident
+    copy, and no reference to the model: dropping the model (Python's garbage collector does that at arbitrary times) must
+    not unload / free them while the graph is alive - replaying it afterwards has to give the same bits - and they are
+    released with the last graph.  Also: destroying a model during an open capture must not invalidate the capture."""
+    from manipulapy_amd import _hip
+
+    tab = tables["ur5"]
+    ctx = _hip.HipContext(0)
+    try:
+        rng = np.random.default_rng(3)
+        rows = 4096
+        q, qd, qdd = (rng.uniform(-1, 1, (rows, 6)).astype(np.float32) for _ in range(3))
+        d = [ctx.to_device(a) for a in (q, qd, qdd)]
+        out_spec, out_gen = ctx.alloc(q.nbytes), ctx.alloc(q.nbytes)
+        spec = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee, tab.joint_limits)
+        gen = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee, tab.joint_limits)   # generic path: device-resident model copy
+        ctx.specialize(spec)
+        ctx.id_trajectory(spec, *d, rows, out_spec); ctx.id_trajectory(gen, *d, rows, out_gen); ctx.synchronize()
+        want_spec, want_gen = out_spec.download((rows, 6), np.float32), out_gen.download((rows, 6), np.float32)
+        victim = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee, tab.joint_limits)
+        ctx.specialize(victim)
+        with ctx.capture() as cap:
+            ctx.id_trajectory(spec, *d, rows, out_spec)
+            victim.destroy()                  # inside an open capture: retired, not synchronised / freed
+            ctx.id_trajectory(gen, *d, rows, out_gen)
+        graph = cap.graph
+        spec.destroy(); gen.destroy()         # the graph still references their code object / device copy
+        for _ in range(3):
+            ctx.memset(out_spec, 0, q.nbytes); ctx.memset(out_gen, 0, q.nbytes)
+            # allocations in between would recycle a freed device model's buffer
+            junk = [ctx.to_device(np.full(256, 7.0, np.float32)) for _ in range(8)]
+            graph.launch(); ctx.synchronize()
+            np.testing.assert_array_equal(out_spec.download((rows, 6), np.float32), want_spec)
+            np.testing.assert_array_equal(out_gen.download((rows, 6), np.float32), want_gen)
+            for j in junk:
+                j.free()
+        graph.destroy()                        # last graph: the retired objects go now
+        m2 = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee, tab.joint_limits)
+        ctx.specialize(m2)
+        ctx.id_trajectory(m2, *d, rows, out_spec); ctx.synchronize()
+        np.testing.assert_array_equal(out_spec.download((rows, 6), np.float32), want_spec)
+    finally:
+        ctx.destroy()
+
+
+def test_profiling_is_reference_counted_and_bounded():
+    """enable_profiling planners share the context's flag: the last one to close() switches it off, each reports what was timed
+    since ITS start, and a caller that never reads the figures does not accumulate events without bound."""
+    import manipulapy_amd as mp
+    from manipulapy_amd import registry
+
+    sm, dyn, lim = mp.load_robot("ur5")
+    rng = np.random.default_rng(2)
+    s_ = rng.uniform(lim[:, 0], lim[:, 1], (16, 6)).astype(np.float32); e_ = rng.uniform(lim[:, 0], lim[:, 1], (16, 6)).astype(np.float32)
+    with mp.use_backend("hip"):
+        ctx = registry.get_context()
+        p1 = mp.OptimizedTrajectoryPlanning(sm, None, dyn, lim, enable_profiling=True)
+        p1.batch_inverse_dynamics_trajectory(s_, e_, 2.0, 400, 5)
+        p2 = mp.OptimizedTrajectoryPlanning(sm, None, dyn, lim, enable_profiling=True)
+        assert p2.get_performance_stats()["gpu_timed_calls"] == 0          # p1's calls are not p2's
+        p2.batch_inverse_dynamics_trajectory(s_, e_, 2.0, 400, 5)
+        assert p2.get_performance_stats()["gpu_timed_calls"] >= 1
+        a = p1.get_performance_stats()["gpu_timed_calls"]
+        p1.reset_performance_stats()
+        assert p1.get_performance_stats()["gpu_timed_calls"] == 0 and p2.get_performance_stats()["gpu_timed_calls"] >= 1 and a >= 1
+        p1.close()
+        plain = mp.OptimizedTrajectoryPlanning(sm, None, dyn, lim)
+        before = ctx.profile()["timed_calls"]
+        plain.batch_inverse_dynamics_trajectory(s_, e_, 2.0, 400, 5)       # p2 still holds the flag: timed
+        assert ctx.profile()["timed_calls"] > before
+        for _ in range(200):                                                # nobody reads: pending pairs are folded in on the way
+            plain.batch_inverse_dynamics_trajectory(s_[:2], e_[:2], 2.0, 64, 5)
+        p2.close()
+        before = ctx.profile()["timed_calls"]
+        plain.batch_inverse_dynamics_trajectory(s_, e_, 2.0, 400, 5)       # last reference gone: not timed any more
+        assert ctx.profile()["timed_calls"] == before
+        p2.close()                                                          # idempotent
+
+
+def test_uneven_allgather_on_a_one_rank_communicator():
+    """mp_comm_allgatherv / mp_comm_exchange_chunk_v with nranks = 1 (all a one-GPU box can run): the local shard lands at
+    its offset of the gathered buffer, in place or from a separate send buffer; argument checks.  The peer traffic itself
+    is exercised by the driver's multi-GPU run (bench.py)."""
+    from manipulapy_amd import _hip, sharding
+
+    ctx = _hip.HipContext(0)
+    try:
+        comm = ctx.comm_create(_hip.HipContext.comm_unique_id(), 1, 0)
+        counts, offsets = sharding.shard_layout(10, 1, 792)
+        a = np.arange(counts[0] // 4, dtype=np.float32)
+        d_a, d_all = ctx.to_device(a), ctx.alloc(counts[0])
+        ctx.memset(d_all, 0, counts[0])
+        comm.allgatherv(d_a, d_all, counts)
+        ctx.synchronize()
+        np.testing.assert_array_equal(d_all.download(a.shape, np.float32), a)
+        comm.allgatherv(d_all, d_all, counts)          # in place: nothing to copy
+        comm.exchange_chunk_v(d_all, offsets, [0], [counts[0] // 2])
+        comm.join()
+        ctx.synchronize()
+        np.testing.assert_array_equal(d_all.download(a.shape, np.float32), a)
+        with pytest.raises(ValueError):
+            comm.allgatherv(d_a, d_all, [1, 2])
+        comm.destroy()
     finally:
         ctx.destroy()

@@ -657,20 +657,33 @@ def test_shard_ranges_cover_exactly():
         sharding.shard_range(4, 2, 2)
 
 
-def test_two_process_gloo_shard_and_gather(tmp_path):
-    """world_size = 2 over gloo on the CPU: each rank generates its shard of a batch trajectory on the
-    NumPy path, the all-gather reassembles the full (B, N, n) history in rank order."""
+@pytest.mark.parametrize("world", [2, 3])
+def test_multi_process_gloo_shard_and_gather(world, tmp_path):
+    """world_size = 2 and 3 over gloo on the CPU: each rank generates its shard of a batch trajectory AND evaluates its shard of
+    the torque history (the array north_star all-gathers) through the CPU launchers; the all-gather reassembles both in rank
+    order - with B = 10 the shards are uneven at world 3 (4 / 3 / 3 trajectories) - and equals the single-process result."""
     worker = os.path.join(ROOT, "tests", "_dist_worker.py")
     out = tmp_path / "result.npz"
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", PYTHONPATH=ROOT, MANIPULAPY_FORCE_CPU="1")
-    port = 29500 + (os.getpid() % 400)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", PYTHONPATH=ROOT, MANIPULAPY_FORCE_CPU="1", MANIPULAPY_CPU_THREADS="2")
+    port = 29500 + (os.getpid() % 400) + world
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), worker, str(out)]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stderr[-2000:]
     z = np.load(out)
     np.testing.assert_array_equal(z["gathered"], z["single"])
-    assert z["world"] == 2 and abs(float(z["max_val"]) - 1.0) < 1e-12
+    np.testing.assert_array_equal(z["tau"], z["tau_single"])
+    assert z["tau"].shape == (10, 33, 6) and np.abs(z["tau"]).max() > 1.0
+    assert z["world"] == world and abs(float(z["max_val"]) - (world - 1)) < 1e-12
+
+
+def test_shard_layout_matches_shard_range():
+    for total, world in ((10, 3), (7, 8), (262144, 8), (5, 1)):
+        counts, offsets = sharding.shard_layout(total, world, 24)
+        assert sum(counts) == total * 24 and offsets[0] == 0
+        for r in range(world):
+            lo, hi = sharding.shard_range(total, world, r)
+            assert counts[r] == (hi - lo) * 24 and offsets[r] == lo * 24
 
 
 def test_potential_field_cpu_launcher_against_reference_dump():
