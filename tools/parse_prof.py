@@ -33,9 +33,16 @@ except Exception as exc:  # older runs without a JSON line: the whole-run stats 
     summary["kernel_stats_timed_region"] = {"error": str(exc)[:200]}
 for f in glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
     acc = defaultdict(list)
-    for r in csv.DictReader(open(f)):
-        name = r.get("Kernel_Name", "")
-        if any(t in name for t in ("k_id", "k_fk", "k_traj", "k_fd", "mp_spec_")):
+    rows = [r for r in csv.DictReader(open(f)) if any(t in r.get("Kernel_Name", "") for t in ("k_id", "k_fk", "k_traj", "k_fd", "mp_spec_"))]
+    # per kernel name only the launches of its most frequent grid: the benchmark's own (mp_model_specialize's self-check
+    # launches the same kernels on 128 rows once per model)
+    grids = defaultdict(lambda: defaultdict(int))
+    for r in rows:
+        grids[r["Kernel_Name"]][r.get("Grid_Size", "")] += 1
+    main_grid = {k: max(v, key=v.get) for k, v in grids.items()}
+    for r in rows:
+        name = r["Kernel_Name"]
+        if r.get("Grid_Size", "") == main_grid[name]:
             acc[(name.split("(")[0][-40:], r["Counter_Name"])].append(float(r["Counter_Value"]))
     for (k, c), v in acc.items():
         summary.setdefault("counters", {}).setdefault(k, {})[c] = {"mean": sum(v) / len(v), "n": len(v)}
