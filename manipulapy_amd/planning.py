@@ -275,10 +275,18 @@ class OptimizedTrajectoryPlanning:
         r = self.batch_forward_dynamics_trajectory(th[None], np.asarray(dthetalist)[None], tm[None], g, Fm, dt, intRes)
         return {k: v[0] for k, v in r.items()}
 
-    def batch_forward_dynamics_trajectory(self, theta0_batch, dtheta0_batch, taumat_batch, g, Ftipmat_batch, dt, intRes
-                                          ) -> Dict[str, np.ndarray]:
+    def batch_forward_dynamics_trajectory(self, theta0_batch, dtheta0_batch, taumat_batch, g, Ftipmat_batch, dt, intRes,
+                                          layout: str = "batch_major", device_layout: Optional[str] = None) -> Dict[str, np.ndarray]:
         """B independent roll-outs in one launch: theta0 / dtheta0 (B, n), taumat (B, N, n), Ftipmat (B, N, 6) or
-        None -> (B, N, n) float32 arrays.  New (the reference integrates one trajectory per call)."""
+        None -> (B, N, n) float32 arrays.  New (the reference integrates one trajectory per call).
+
+        layout="time_major": taumat / Ftipmat and the three results are (N, B, *) - the layout of the faster device kernel
+        (mp_fd_trajectory_tm_*: every step touches whole cache lines), for callers that build their histories step by step.
+        device_layout ("batch_major" / "time_major") picks the kernel independently of the host layout (converted on the
+        device); from host arrays the call is PCIe-bound either way (profiles/r03_time_ops.jsonl), so the default is the
+        host layout's own kernel."""
+        if layout not in ("batch_major", "time_major"):
+            raise ValueError("layout must be 'batch_major' or 'time_major'")
         th = np.asarray(theta0_batch)
         if th.ndim != 2:
             raise ValueError(f"initial states must be (B, n); got {th.shape}")
@@ -290,7 +298,7 @@ class OptimizedTrajectoryPlanning:
         if g is None:
             g = np.array([0.0, 0.0, -9.81])
         pos, vel, acc = self._dispatch("dynamics.forward_trajectory", self._hip_model(), th, dtheta0_batch, taumat_batch, g,
-                                       Ftipmat_batch, dt, int(intRes), dtype=dtype)
+                                       Ftipmat_batch, dt, int(intRes), dtype=dtype, layout=layout, device_layout=device_layout)
         b = get_backend()
         return {"positions": b.asarray(pos), "velocities": b.asarray(vel), "accelerations": b.asarray(acc)}
 

@@ -260,7 +260,13 @@ def _launch_forward_dynamics_cpu(model, q, qd, tau, g=None, Ftip=None):
     return _hip.cpu_forward_dynamics(model, q, qd, tau, g, Ftip)
 
 
-def _launch_fd_trajectory_cpu(model, theta0, dtheta0, taumat, g, Ftipmat, dt, intRes, dtype=np.float64):
+def _launch_fd_trajectory_cpu(model, theta0, dtheta0, taumat, g, Ftipmat, dt, intRes, dtype=np.float64, layout="batch_major",
+                              device_layout=None):
+    del device_layout   # (a device-side choice; the host rows are walked in whatever order they come)
+    if layout == "time_major":   # host arrays (N, B, *): the CPU rows are batch-major
+        sw = lambda a: None if a is None else np.ascontiguousarray(np.swapaxes(np.asarray(a), 0, 1))
+        out = _hip.cpu_fd_trajectory(model, theta0, dtheta0, sw(taumat), g, sw(Ftipmat), dt, intRes, dtype=dtype)
+        return tuple(sw(o) for o in out)
     return _hip.cpu_fd_trajectory(model, theta0, dtheta0, taumat, g, Ftipmat, dt, intRes, dtype=dtype)
 
 
@@ -348,8 +354,10 @@ def _launch_forward_dynamics_gpu(model, q, qd, tau, g=None, Ftip=None):
     return get_context().forward_dynamics_host(model, q, qd, tau, g, Ftip)
 
 
-def _launch_fd_trajectory_gpu(model, theta0, dtheta0, taumat, g, Ftipmat, dt, intRes, dtype=np.float64):
-    return get_context().fd_trajectory_host(model, theta0, dtheta0, taumat, g, Ftipmat, dt, intRes, dtype=dtype)
+def _launch_fd_trajectory_gpu(model, theta0, dtheta0, taumat, g, Ftipmat, dt, intRes, dtype=np.float64, layout="batch_major",
+                              device_layout=None):
+    return get_context().fd_trajectory_host(model, theta0, dtheta0, taumat, g, Ftipmat, dt, intRes, dtype=dtype, layout=layout,
+                                            device_layout=device_layout)
 
 
 def _launch_cartesian_gpu(Xstart, Xend, Tf, N, method):

@@ -1948,3 +1948,28 @@ def test_uneven_allgather_on_a_one_rank_communicator():
         comm.destroy()
     finally:
         ctx.destroy()
+
+
+def test_planner_rollout_layouts_on_the_gpu():
+    """batch_forward_dynamics_trajectory under the "hip" backend: (B, N, *) arrays through the batch-major kernel, the same
+    arrays through device transposes + the time-major kernel (device_layout), and (N, B, *) arrays through the time-major
+    kernel directly - the same roll-outs to float32 rounding, against the CPU launcher's."""
+    import manipulapy_amd as mp
+
+    sm, dyn, lim = mp.load_robot("xarm6")
+    rng = np.random.default_rng(8)
+    B, N, n = 200, 24, 6
+    th0, dth0 = rng.uniform(-0.5, 0.5, (B, n)), rng.uniform(-0.2, 0.2, (B, n))
+    tm, Fm = rng.uniform(-0.5, 0.5, (B, N, n)), rng.uniform(-0.02, 0.02, (B, N, 6))
+    sw = lambda x: np.ascontiguousarray(np.swapaxes(x, 0, 1))
+    cpu = mp.OptimizedTrajectoryPlanning(sm, None, dyn, lim, use_cuda=False).batch_forward_dynamics_trajectory(th0, dth0, tm, None, Fm, 0.005, 1)
+    with mp.use_backend("hip"):
+        pl = mp.OptimizedTrajectoryPlanning(sm, None, dyn, lim)
+        a = pl.batch_forward_dynamics_trajectory(th0, dth0, tm, None, Fm, 0.005, 1)
+        b = pl.batch_forward_dynamics_trajectory(th0, dth0, tm, None, Fm, 0.005, 1, device_layout="time_major")
+        c = pl.batch_forward_dynamics_trajectory(th0, dth0, sw(tm), None, sw(Fm), 0.005, 1, layout="time_major")
+    for k in ("positions", "velocities", "accelerations"):
+        scale = max(1.0, float(np.abs(cpu[k]).max()))
+        assert c[k].shape == (N, B, n) and a[k].shape == b[k].shape == (B, N, n)
+        for got in (a[k], b[k], sw(c[k])):
+            np.testing.assert_allclose(got, cpu[k], rtol=0, atol=1e-6 * scale)

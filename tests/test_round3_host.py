@@ -247,3 +247,22 @@ def test_looped_rows_equal_the_unrolled_rows_on_the_benchmark_robots(robot, tabl
             np.testing.assert_allclose(rb[k], ra[k], rtol=0, atol=(1e-6 if dtype == np.float64 else 2e-4) * max(1.0, float(np.abs(ra[k]).max())))
     with pytest.raises(_hip.HipError):
         looped.specialize_source()
+
+
+def test_planner_rollout_layout_option_on_the_cpu_launcher(tables):
+    """batch_forward_dynamics_trajectory(layout="time_major"): (N, B, *) host arrays in and out, the same numbers as the
+    (B, N, *) call (NumPy backend: CPU launcher); a bad layout name raises."""
+    sm, dyn, lim = mp.load_robot("xarm6")
+    pl = mp.OptimizedTrajectoryPlanning(sm, None, dyn, lim, use_cuda=False)
+    rng = np.random.default_rng(8)
+    B, N, n = 5, 9, 6
+    th0, dth0 = rng.uniform(-0.5, 0.5, (B, n)), rng.uniform(-0.2, 0.2, (B, n))
+    tm, Fm = rng.uniform(-0.5, 0.5, (B, N, n)), rng.uniform(-0.02, 0.02, (B, N, 6))
+    a = pl.batch_forward_dynamics_trajectory(th0, dth0, tm, None, Fm, 0.01, 2)
+    sw = lambda x: np.ascontiguousarray(np.swapaxes(x, 0, 1))
+    b = pl.batch_forward_dynamics_trajectory(th0, dth0, sw(tm), None, sw(Fm), 0.01, 2, layout="time_major")
+    for k in ("positions", "velocities", "accelerations"):
+        assert b[k].shape == (N, B, n)
+        np.testing.assert_array_equal(sw(b[k]), a[k])
+    with pytest.raises(ValueError):
+        pl.batch_forward_dynamics_trajectory(th0, dth0, tm, None, Fm, 0.01, 2, layout="columns")

@@ -157,6 +157,34 @@ def main():
         ms = (time.perf_counter() - t0) / 3 * 1e3
         out.append(dict(op=name, robot="ur5", dtype="float64", rows=R, ms=ms, rows_per_s=R / ms * 1e3,
                         pcie_GBps=R * (n * 8 + 128 + 48 * n) / ms / 1e6))
+    # the roll-out from host arrays (PCIe inclusive), (B, N, n) in and out: the batch-major kernel directly, against device
+    # transposes around the time-major kernel; and the device transpose alone
+    sm, dyn, lim = mp.load_robot("xarm6")
+    xm = _hip.HipModel(dyn.S_list, dyn.Mlist_per_link, dyn.Glist, sm.M_list, lim)
+    ctx.specialize(xm)
+    B, N, n = 32768, 100, 6
+    th0 = rng.uniform(-0.5, 0.5, (B, n)).astype(np.float32); dth0 = rng.uniform(-0.2, 0.2, (B, n)).astype(np.float32)
+    hold = ctx.id_trajectory_host(xm, th0, np.zeros_like(th0), np.zeros_like(th0), [0, 0, -9.81], None, dtype=np.float32)
+    tm = (hold[:, None, :] + rng.uniform(-1e-3, 1e-3, (B, N, n))).astype(np.float32)
+    Fm = rng.uniform(-0.02, 0.02, (B, N, 6)).astype(np.float32)
+    tmT, FmT = np.ascontiguousarray(np.swapaxes(tm, 0, 1)), np.ascontiguousarray(np.swapaxes(Fm, 0, 1))
+    for name, fn in (("fd_trajectory_host (B,N,n) arrays, batch-major kernel", lambda: ctx.fd_trajectory_host(xm, th0, dth0, tm, None, Fm, 0.01, 1, dtype=np.float32)),
+                     ("fd_trajectory_host (B,N,n) arrays, device transposes + time-major kernel",
+                      lambda: ctx.fd_trajectory_host(xm, th0, dth0, tm, None, Fm, 0.01, 1, dtype=np.float32, device_layout="time_major")),
+                     ("fd_trajectory_host (N,B,n) arrays, time-major kernel",
+                      lambda: ctx.fd_trajectory_host(xm, th0, dth0, tmT, None, FmT, 0.01, 1, dtype=np.float32, layout="time_major"))):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            fn()
+        ms = (time.perf_counter() - t0) / 3 * 1e3
+        out.append(dict(op=name, robot="xarm6", dtype="float32", trajectories=B, steps=N, ms=ms, jt_per_s=B * N * n / ms * 1e3,
+                        pcie_GBps=B * N * (4 * n + 6) * 4 / ms / 1e6))
+    Bt = 131072
+    src, dst = ctx.alloc(Bt * N * n * 4), ctx.alloc(Bt * N * n * 4)
+    for name, o_, i_ in (("transpose_rows (B,N,24 B) -> (N,B,24 B)", Bt, N), ("transpose_rows (N,B,24 B) -> (B,N,24 B)", N, Bt)):
+        ms = timed(ctx, lambda: ctx.transpose_rows(src, o_, i_, n * 4, dst))
+        out.append(dict(op=name, dtype="float32", rows=Bt * N, ms=ms, alg_GBps=2 * Bt * N * n * 4 / ms / 1e6))
     for r in out:
         print(json.dumps(r))
     ctx.destroy()
