@@ -37,11 +37,13 @@ extern "C" {
 #define MP_ERR_UNSUPPORTED 4  /* valid request this build does not implement */
 #define MP_ERR_COMM 5         /* RCCL failure */
 
-#define MP_MAX_DOF 8
+#define MP_MAX_DOF 8      /* joints of the fully unrolled / run-time-specialisable kernels */
+#define MP_BIG_DOF 16     /* joints mp_model_create accepts: 9..16 run looped run-time-n kernels (csrc/mp_dyn.h; no
+                             specialisation, no inverse kinematics - MP_ERR_UNSUPPORTED) */
 #define MP_UNIQUE_ID_BYTES 128
 
 typedef struct mp_ctx mp_ctx;     /* device context: device id, streams, device-buffer pool */
-typedef struct mp_model mp_model; /* compiled robot model (host object, passed to kernels by value) */
+typedef struct mp_model mp_model; /* compiled robot model (host object; reaches the kernels by value or as a device copy) */
 typedef struct mp_event mp_event; /* HIP event on the context's compute stream */
 typedef struct mp_graph mp_graph; /* instantiated HIP graph captured from the context's compute stream */
 typedef struct mp_comm mp_comm;   /* RCCL communicator (one rank per process) */
@@ -114,10 +116,13 @@ int mp_graph_destroy(mp_graph* graph);
  *   S (6,n) space screws [w;v]; Mcom n x (4,4) = Mlist_per_link; G n x (6,6) = Glist;
  *   M_ee (4,4) = M_list; joint_limits (n,2) or NULL (= unbounded); torque_limits (n,2) or NULL
  *   (= +-inf, planning/trajectory_planning.py:219-223).  Limits are rounded to float32 as the
- *   planner stores them (:218).  No device is needed: the model is host data. */
+ *   planner stores them (:218).  No device is needed: the model is host data.  1 <= n <= MP_BIG_DOF (the reference's
+ *   algorithms loop over any n, dynamics/mass_matrix.py:62-96; its database goes up to 10 actuated joints). */
 int mp_model_create(int n, const double* S, const double* Mcom, const double* G, const double* M_ee,
                     const double* joint_limits, const double* torque_limits, mp_model** out);
-/* Also releases what every live context holds for the model (specialised code object, device-resident copy). */
+/* Also releases what every live context holds for the model (specialised code object, device-resident copies); while a
+ * launch graph captured on a context is alive, or a capture is open, they are retired instead and released with the last
+ * graph / the context (a graph keeps kernel nodes and device addresses of the models it captured, no reference). */
 int mp_model_destroy(mp_model* model);
 int mp_model_dof(const mp_model* model, int* n);
 /* Compiled per-joint parameters, 16 doubles per joint (see csrc/mp_model.h): for inspection/tests. */

@@ -266,3 +266,48 @@ def test_planner_rollout_layout_option_on_the_cpu_launcher(tables):
         np.testing.assert_array_equal(sw(b[k]), a[k])
     with pytest.raises(ValueError):
         pl.batch_forward_dynamics_trajectory(th0, dth0, tm, None, Fm, 0.01, 2, layout="columns")
+
+
+def test_bench_parity_rules_and_line_shape():
+    """bench.py's asserted parity sample on synthetic data: inside the first bound -> ok; a row over the first bound but inside 4
+    float32 input ulps -> ok after re-examination; over both -> fails; a NaN in the GPU result -> fails.  And the entry a
+    configuration gets in the default line's "configs" object has the fields the driver-visible line promises."""
+    import bench
+
+    tab = ref.load_tables(golden_path("model_ur5.npz"))
+    rng = np.random.default_rng(4)
+    q, qd, qdd = (rng.uniform(-1, 1, (64, 6)).astype(np.float32) for _ in range(3))
+    from oracle import c_oracle
+
+    want = c_oracle.inverse_dynamics_rows(tab, q.astype(np.float64), qd.astype(np.float64), qdd.astype(np.float64))[0]
+    sens = bench.id_sensitivity(tab, q, qd, qdd)
+    S = sens(np.arange(64))
+    assert S.shape == (64, 6) and (S > 0).all() and S.max() < 1e-3          # one ulp of a |x| < 1 input moves tau by ~1e-6 N.m
+    ok = bench.parity_rows(want + 1e-7, want, "f32", sens)
+    assert ok["ok"] and ok["rows_over_first_bound"] == 0
+    tol1 = 1e-4 * np.abs(want) + bench.F32_ROW * np.abs(want).max(axis=1, keepdims=True)
+    bump = want.copy()
+    bump[5, 2] += tol1[5, 2] + 2.0 * S[5, 2]                                 # over the first bound by 2 input ulps
+    mid = bench.parity_rows(bump, want, "f32", sens)
+    assert mid["ok"] and mid["rows_over_first_bound"] == 1 and mid["worst_over_first_bound"] > 1.0
+    assert not bench.parity_rows(bump, want, "f32")["ok"]                    # without the sensitivity callback the first bound decides
+    bump[5, 2] += 50.0 * S[5, 2] + tol1[5, 2]
+    assert not bench.parity_rows(bump, want, "f32", sens)["ok"]
+    bad = want.copy(); bad[0, 0] = np.nan
+    assert not bench.parity_rows(bad, want, "f32", sens)["ok"]
+    assert bench.parity_rows(want * (1 + 5e-7), want, "f64")["ok"] and not bench.parity_rows(want * (1 + 5e-6) + 1e-6, want, "f64")["ok"]
+    # the "configs" entry
+    full = {"metric": "m", "value": 1.0, "unit": "u", "ms_per_step": 0.1, "steps": 5, "dtype": "f32",
+            "config": {"workload": "w", "kernel_variant": "generic"},
+            "roofline": {"bound": "hbm", "achieved": 1.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.1, "frac_cold": 0.1, "traffic": 3.0,
+                         "algorithmic_bytes_per_launch": 3, "kernel": "k", "kernel_ms": 0.1, "kernel_ms_cold": 0.2, "device_copy": {}},
+            "roofline_valu": {"frac": 0.5, "valu_insts_per_launch": 1, "issue_cycles_per_inst": 2.0, "clock_hz": 1.0, "source": "s", "peak": 1},
+            "parity_sample": {"ok": True}, "cpu_baseline": {"value": 1}}
+    entry = bench.compact(full)
+    for key in ("ms_per_step", "value", "kernel", "kernel_ms", "kernel_ms_cold", "roofline", "roofline_valu", "parity_sample", "workload"):
+        assert key in entry
+    assert entry["roofline"]["traffic"] == 3.0 and "device_copy" not in entry["roofline"] and "cpu_baseline" not in entry
+    assert set(bench.SECONDARY) == {"c2f", "c3", "c4", "c4s", "c5", "c5b"} and bench.CONFIGS["c5"]["layout"] == "time_major"
+    for name, cfg in bench.CONFIGS.items():   # kernel names the traffic files must carry to be attached
+        for spec in (True, False):
+            assert isinstance(bench.kernel_name(dict(cfg, specialized=spec, dof=6)), str)
