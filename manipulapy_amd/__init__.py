@@ -18,10 +18,12 @@ from . import ik_helpers, utils
 from .potential_field import PotentialField
 from .robots import load_robot, robot_tables, robot_urdf
 from .urdf import URDFToSerialManipulator
+from . import trac_ik
+from .trac_ik import TracIKSolver, trac_ik_solve
 
 __version__ = "0.1.0"
 __all__ = ["ArrayBackend", "HipBackend", "NumpyBackend", "get_backend", "get_registered", "register", "set_backend",
            "use_backend", "BackendNotSupportedError", "KernelRegistration", "KernelRegistry", "check_hip_availability",
            "execute_registered_kernel", "get_context", "get_gpu_properties", "get_registered_kernel",
            "SerialManipulator", "ManipulatorDynamics", "OptimizedTrajectoryPlanning", "TrajectoryPlanning", "ManipulatorController", "Singularity", "ik_helpers", "utils", "PotentialField",
-           "load_robot", "robot_tables", "robot_urdf", "URDFToSerialManipulator"]
+           "load_robot", "robot_tables", "robot_urdf", "URDFToSerialManipulator", "trac_ik", "TracIKSolver", "trac_ik_solve"]

@@ -1678,22 +1678,25 @@ int mp_potential_field_host_f32(mp_ctx* ctx, const float* positions, const float
   return MP_OK;
 }
 
+}  // extern "C"
+template <typename PT, int CAP>
 static int ik_params(const char* fn, const mp_model* model, const double* joint_limits, double eomg, double ev, int max_iterations,
                      double damping, double step_cap, double w_o, double w_p, int adaptive, int backtracking, uint32_t seed,
-                     MpIkParams* P) {
+                     PT* P) {
   REQUIRE(max_iterations >= 1, "%s: max_iterations must be at least 1 (got %d)", fn, max_iterations);
   REQUIRE(eomg > 0 && ev > 0 && damping >= 0 && step_cap > 0, "%s: eomg, ev, step_cap must be positive and damping non-negative", fn);
   P->eomg = eomg; P->ev = ev; P->damping = damping; P->step_cap = step_cap; P->w_o = w_o; P->w_p = w_p;
   P->max_iterations = max_iterations; P->seed = seed;
   P->adaptive_tuning = adaptive ? 1 : 0; P->backtracking = backtracking ? 1 : 0;
   const int n = model->d.n;
-  for (int j = 0; j < MP_MAX_DOF; ++j) {
+  for (int j = 0; j < CAP; ++j) {
     P->lo[j] = (j < n && joint_limits) ? joint_limits[2 * j] : -HUGE_VAL;
     P->hi[j] = (j < n && joint_limits) ? joint_limits[2 * j + 1] : HUGE_VAL;
     REQUIRE(!(P->lo[j] > P->hi[j]), "%s: joint %d has lower limit above upper limit", fn, j);
   }
   return MP_OK;
 }
+extern "C" {
 
 int mp_inverse_kinematics_f64(mp_ctx* ctx, const mp_model* model, const double* d_T_desired, const double* d_theta0, int64_t B,
                               const double* joint_limits, double eomg, double ev, int max_iterations, double damping,
@@ -1701,19 +1704,29 @@ int mp_inverse_kinematics_f64(mp_ctx* ctx, const mp_model* model, const double* 
                               uint32_t seed,
                               double* d_theta, int32_t* d_success, int32_t* d_iterations, int32_t* d_restarts) {
   CHECK_COMMON("mp_inverse_kinematics_f64");
-  REQUIRE_SMALL("mp_inverse_kinematics_f64");
   REQUIRE(B >= 0, "mp_inverse_kinematics_f64: negative problem count");
   if (B == 0) return MP_OK;
   REQUIRE(d_T_desired && d_theta0 && d_theta && d_success && d_iterations && d_restarts, "mp_inverse_kinematics_f64: null device pointer");
   REQUIRE(aligned16(d_T_desired) && aligned16(d_theta0) && aligned16(d_theta), "mp_inverse_kinematics_f64: device pointers must be 16-byte aligned");
-  MpIkParams P;
-  if (int rc = ik_params("mp_inverse_kinematics_f64", model, joint_limits, eomg, ev, max_iterations, damping, step_cap,
-                         weight_orientation, weight_position, adaptive_tuning, backtracking, seed, &P))
-    return rc;
   if (!ctx->queue_counter) {
     REQUIRE(!ctx->capturing, "mp_inverse_kinematics_f64: first use allocates; call it once before capturing a launch graph");
     HIP_TRY(hipMalloc(&ctx->queue_counter, 256));
   }
+  if (model->big) {  // 9..16 joints: the same iteration on the run-time-n kinematics (csrc/mp_dyn.h)
+    MpIkBigParams PB;
+    if (int rc = ik_params<MpIkBigParams, MP_BIG_DOF>("mp_inverse_kinematics_f64", model, joint_limits, eomg, ev, max_iterations, damping,
+                                                      step_cap, weight_orientation, weight_position, adaptive_tuning, backtracking, seed, &PB))
+      return rc;
+    const MpBigModel<double>* dm = nullptr;
+    if (int rc = device_big_model<double>(ctx, model, &dm)) return rc;
+    HIP_TRY(mpk_dyn_ik(ctx->compute, dm, PB, d_T_desired, d_theta0, (long)B, d_theta, d_success, d_iterations, d_restarts,
+                       (unsigned long long*)ctx->queue_counter, ctx->compute_units));
+    return MP_OK;
+  }
+  MpIkParams P;
+  if (int rc = ik_params<MpIkParams, MP_MAX_DOF>("mp_inverse_kinematics_f64", model, joint_limits, eomg, ev, max_iterations, damping, step_cap,
+                                                 weight_orientation, weight_position, adaptive_tuning, backtracking, seed, &P))
+    return rc;
   if (const MpSpec* sp = find_spec(ctx, model)) {  // this robot's constants baked in (mp_model_specialize)
     for (int j = 0; j < MP_MAX_DOF; ++j) {  // the specialised build assumes finite arithmetic: open limits become huge ones
       if (!(P.lo[j] > -1e300)) P.lo[j] = -1e300;

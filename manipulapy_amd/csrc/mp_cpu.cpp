@@ -349,23 +349,46 @@ int mp_inverse_kinematics_cpu_f64(const mp_model* model, const double* T_desired
                                   int backtracking, uint32_t seed, double* theta, int32_t* success, int32_t* iterations,
                                   int32_t* restarts, int nthreads) {
   if (!model) return fail("mp_inverse_kinematics_cpu_f64: null model");
-  if (model->big) return mp_set_error(MP_ERR_UNSUPPORTED, "mp_inverse_kinematics_cpu_f64: not available for models with more than 8 joints");
   if (B < 0) return fail("mp_inverse_kinematics_cpu_f64: negative problem count");
   if (B == 0) return MP_OK;
   if (!T_desired || !theta0 || !theta || !success || !iterations || !restarts) return fail("mp_inverse_kinematics_cpu_f64: null pointer");
   if (max_iterations < 1) return fail("mp_inverse_kinematics_cpu_f64: max_iterations must be at least 1");
   if (!(eomg > 0 && ev > 0 && damping >= 0 && step_cap > 0))
     return fail("mp_inverse_kinematics_cpu_f64: eomg, ev, step_cap must be positive and damping non-negative");
-  MpIkParams P;
-  P.eomg = eomg; P.ev = ev; P.damping = damping; P.step_cap = step_cap; P.w_o = weight_orientation; P.w_p = weight_position;
-  P.max_iterations = max_iterations; P.seed = seed;
-  P.adaptive_tuning = adaptive_tuning ? 1 : 0; P.backtracking = backtracking ? 1 : 0;
-  const MpModel<double>& M = model->d;
-  for (int j = 0; j < MP_MAX_DOF; ++j) {
-    P.lo[j] = (j < M.n && joint_limits) ? joint_limits[2 * j] : -HUGE_VAL;
-    P.hi[j] = (j < M.n && joint_limits) ? joint_limits[2 * j + 1] : HUGE_VAL;
-    if (P.lo[j] > P.hi[j]) return fail("mp_inverse_kinematics_cpu_f64: a joint has its lower limit above its upper limit");
+  auto fill = [&](auto& P, int cap) -> bool {
+    P.eomg = eomg; P.ev = ev; P.damping = damping; P.step_cap = step_cap; P.w_o = weight_orientation; P.w_p = weight_position;
+    P.max_iterations = max_iterations; P.seed = seed;
+    P.adaptive_tuning = adaptive_tuning ? 1 : 0; P.backtracking = backtracking ? 1 : 0;
+    for (int j = 0; j < cap; ++j) {
+      P.lo[j] = (j < model->d.n && joint_limits) ? joint_limits[2 * j] : -HUGE_VAL;
+      P.hi[j] = (j < model->d.n && joint_limits) ? joint_limits[2 * j + 1] : HUGE_VAL;
+      if (P.lo[j] > P.hi[j]) return false;
+    }
+    return true;
+  };
+  if (model->big) {  // 9..16 joints: the body of k_dyn_ik (run-time-n kinematics of csrc/mp_dyn.h under the same iteration)
+    MpIkBigParams PB;
+    if (!fill(PB, MP_BIG_DOF)) return fail("mp_inverse_kinematics_cpu_f64: a joint has its lower limit above its upper limit");
+    const MpBigModel<double>& MB = model->bd;
+    const int n = MB.n;
+    parallel_for(B, 1, nthreads, [&](int64_t lo, int64_t hi) {
+      for (int64_t row = lo; row < hi; ++row) {
+        MpIkState<MP_BIG_DOF> S;
+        for (int j = 0; j < MP_BIG_DOF; ++j) S.theta[j] = j < n ? theta0[row * n + j] : 0.0;
+        mp_ik_begin(S, PB);
+        int done = 0;
+        while (!(done = mp_ik_iterate<MP_BIG_DOF, MpIkLooped>(MB, PB, S, T_desired + row * 16, theta0 + row * n))) {}
+        for (int j = 0; j < n; ++j) theta[row * n + j] = S.theta[j];
+        success[row] = done == 2 ? 1 : 0;
+        iterations[row] = S.k + 1;
+        restarts[row] = S.restarts;
+      }
+    });
+    return MP_OK;
   }
+  MpIkParams P;
+  if (!fill(P, MP_MAX_DOF)) return fail("mp_inverse_kinematics_cpu_f64: a joint has its lower limit above its upper limit");
+  const MpModel<double>& M = model->d;
   // the body of k_ik (csrc/mp_kernels.hip) per problem: begin, iterate until the iteration reports done
   MP_CPU_DISPATCH(M.n, {
     parallel_for(B, 1, nthreads, [&](int64_t lo, int64_t hi) {

@@ -353,3 +353,18 @@ MP_HD void mp_dyn_row_traj(const MT& M, const MpCall<float>& C, const float* sta
     }
   }
 }
+
+// ------------------------------------------------------------------------------- inverse kinematics, 9..16 joints
+// The kinematics policy of mp_ik.h for a run-time joint count: the damped-least-squares iteration itself (error, step,
+// restart, adaptive damping, line search) is the one template of mp_ik.h; only the joint count and FK + Jacobian differ.
+#include "mp_ik.h"
+struct MpIkLooped {
+  template <typename MT>
+  MP_HD static int count(const MT& M) { return M.n; }
+  template <bool WANT_J, typename MT>
+  MP_HD static void fk(const MT& M, const double (&theta)[MP_BIG_DOF], double (&Tc)[16], double (&J)[6 * MP_BIG_DOF]) {
+    MpDynState<double> js;
+    mp_dyn_joint_state<double>(M, M.n, theta, js);
+    mp_dyn_fk_jac<double>(M, M.n, js, Tc, WANT_J ? J : nullptr);  // J: 6 x n row-major, as the iteration indexes it
+  }
+};

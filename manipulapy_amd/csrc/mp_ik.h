@@ -22,12 +22,30 @@
 // -ffinite-math-only, under which comparisons against an infinite constant are not dependable
 #define MP_IK_BIG 1e300
 
-struct MpIkParams {
+template <int CAP>
+struct MpIkParamsT {
   double eomg, ev, damping, step_cap, w_o, w_p;
   int max_iterations;
   unsigned seed;
   int adaptive_tuning, backtracking;
-  double lo[MP_MAX_DOF], hi[MP_MAX_DOF];
+  double lo[CAP], hi[CAP];
+};
+typedef MpIkParamsT<MP_MAX_DOF> MpIkParams;     // up to 8 joints: the unrolled kernels
+typedef MpIkParamsT<MP_BIG_DOF> MpIkBigParams;  // 9..16 joints: the run-time-n form (MpIkLooped, csrc/mp_dyn.h)
+
+// Where the iteration gets its joint count and its forward kinematics / Jacobian from.  MpIkUnrolled<N>: N is the joint
+// count, every loop below unrolls, mp_fk_jac of mp_core.h.  MpIkLooped (csrc/mp_dyn.h): N is the CAPACITY of the per-problem
+// arrays (MP_BIG_DOF), the count is the model's, the loops stay loops.
+template <int N>
+struct MpIkUnrolled {
+  template <typename MT>
+  MP_HD static constexpr int count(const MT&) { return N; }
+  template <bool WANT_J, typename MT>
+  MP_HD static void fk(const MT& M, const double (&theta)[N], double (&Tc)[16], double (&J)[6 * N]) {
+    MpJointState<double, N> js;
+    mp_joint_state<double, N>(M, theta, js);
+    mp_fk_jac<double, N, WANT_J>(M, js, Tc, J);
+  }
 };
 
 // 6-vector [angular, space frame; linear], rotation angle and translation norm between two poses (4x4 row-major)
@@ -92,19 +110,18 @@ struct MpIkState {
 // re-hashed from memory on the rare restart: the specialised 6-DOF kernel sits exactly at the 256-VGPR line.)
 
 // content hash of a problem (target position + initial guess): keys the restart noise
-template <int N>
-MP_HD unsigned long long mp_ik_key(const double* Td, const double* theta0) {
+MP_HD unsigned long long mp_ik_key(int n, const double* Td, const double* theta0) {
   unsigned long long h = 0xCBF29CE484222325ull;  // FNV-1a over the bit patterns
 #pragma unroll
   for (int k = 0; k < 3; ++k) h = (h ^ __builtin_bit_cast(unsigned long long, Td[4 * k + 3])) * 0x100000001B3ull;
 #pragma unroll
-  for (int j = 0; j < N; ++j) h = (h ^ __builtin_bit_cast(unsigned long long, theta0[j])) * 0x100000001B3ull;
+  for (int j = 0; j < n; ++j) h = (h ^ __builtin_bit_cast(unsigned long long, theta0[j])) * 0x100000001B3ull;
   return h;
 }
 
 // S.theta (initial guess) must be set
-template <int N>
-MP_HD void mp_ik_begin(MpIkState<N>& S, const MpIkParams& P) {
+template <int N, typename PT>
+MP_HD void mp_ik_begin(MpIkState<N>& S, const PT& P) {
   S.damping = P.damping; S.step_cap = P.step_cap; S.nu = 2.0; S.prev_err = MP_IK_BIG;
 #pragma unroll
   for (int j = 0; j < N; ++j) S.best[j] = S.theta[j];
@@ -116,9 +133,10 @@ MP_HD void mp_ik_begin(MpIkState<N>& S, const MpIkParams& P) {
 // One trip of the reference's loop (kinematics/ik.py:182-269).  Returns 0 while the problem is running, 1 when it finished
 // without meeting the tolerances, 2 when it finished successfully; S.theta is then the answer and S.k + 1 the reference's
 // iteration count.  Tdp = the target pose, theta0 = the problem's initial guess (both re-read from memory when needed).
-template <int N, typename MT>
-MP_HD int mp_ik_iterate(const MT& M, const MpIkParams& P, MpIkState<N>& S, const double* __restrict__ Tdp,
+template <int N, typename KIN = MpIkUnrolled<N>, typename MT, typename PT>
+MP_HD int mp_ik_iterate(const MT& M, const PT& P, MpIkState<N>& S, const double* __restrict__ Tdp,
                         const double* __restrict__ theta0) {
+  const int nj = KIN::count(M);  // = N (a constant: the loops unroll) for MpIkUnrolled
   double Td[16];
 #pragma unroll
   for (int k = 0; k < 12; ++k) Td[k] = Tdp[k];  // the last row of a pose is never read
@@ -126,20 +144,16 @@ MP_HD int mp_ik_iterate(const MT& M, const MpIkParams& P, MpIkState<N>& S, const
   if (S.k >= P.max_iterations) {  // exhausted (the for / else): fall back to the best configuration seen (:273-280)
     if (S.best_err < S.cur_err) {
 #pragma unroll
-      for (int j = 0; j < N; ++j) S.theta[j] = S.best[j];
-      MpJointState<double, N> js;
-      mp_joint_state<double, N>(M, S.theta, js);
+      for (int j = 0; j < nj; ++j) S.theta[j] = S.best[j];
       double Tc[16], J[6 * N], V[6], rot, tr;
-      mp_fk_jac<double, N, false>(M, js, Tc, J);
+      KIN::template fk<false>(M, S.theta, Tc, J);
       mp_ik_error(Tc, Td, V, rot, tr);
       return (rot < P.eomg && tr < P.ev) ? 2 : 1;
     }
     return 1;
   }
-  MpJointState<double, N> js;
-  mp_joint_state<double, N>(M, S.theta, js);
   double Tc[16], J[6 * N], V[6], rot, tr;
-  mp_fk_jac<double, N, true>(M, js, Tc, J);
+  KIN::template fk<true>(M, S.theta, Tc, J);
   mp_ik_error(Tc, Td, V, rot, tr);
   S.cur_err = rot + tr;
   if (rot < P.eomg && tr < P.ev) return 2;
@@ -147,14 +161,14 @@ MP_HD int mp_ik_iterate(const MT& M, const MpIkParams& P, MpIkState<N>& S, const
     S.best_err = S.cur_err;
     S.stall = 0;
 #pragma unroll
-    for (int j = 0; j < N; ++j) S.best[j] = S.theta[j];
+    for (int j = 0; j < nj; ++j) S.best[j] = S.theta[j];
   } else {
     ++S.stall;
   }
   if (S.stall > 20) {
-    const unsigned long long key = mp_ik_key<N>(Tdp, theta0);
+    const unsigned long long key = mp_ik_key(nj, Tdp, theta0);
 #pragma unroll
-    for (int j = 0; j < N; ++j) {
+    for (int j = 0; j < nj; ++j) {
       const double t = S.best[j] + 0.1 * mp_ik_normal(P.seed, key, S.restarts, j);
       S.theta[j] = t < P.lo[j] ? P.lo[j] : (t > P.hi[j] ? P.hi[j] : t);
     }
@@ -188,7 +202,7 @@ MP_HD int mp_ik_iterate(const MT& M, const MpIkParams& P, MpIkState<N>& S, const
     for (int c = 0; c <= r; ++c) {
       double s = (r == c) ? lam : 0.0;
 #pragma unroll
-      for (int j = 0; j < N; ++j) s += J[r * N + j] * J[c * N + j];
+      for (int j = 0; j < nj; ++j) s += J[r * nj + j] * J[c * nj + j];
       A[r][c] = s;
       A[c][r] = s;
     }
@@ -196,10 +210,10 @@ MP_HD int mp_ik_iterate(const MT& M, const MpIkParams& P, MpIkState<N>& S, const
   mp_spd_solve<double, 6>(A, y);
   double d[N], nd = 0.0;
 #pragma unroll
-  for (int j = 0; j < N; ++j) {
+  for (int j = 0; j < nj; ++j) {
     double s = 0.0;
 #pragma unroll
-    for (int r = 0; r < 6; ++r) s += J[r * N + j] * y[r];
+    for (int r = 0; r < 6; ++r) s += J[r * nj + j] * y[r];
     d[j] = s;
     nd += s * s;
   }
@@ -209,38 +223,36 @@ MP_HD int mp_ik_iterate(const MT& M, const MpIkParams& P, MpIkState<N>& S, const
     const double scales[5] = {1.0, 0.5, 0.25, 0.125, 0.75};
     double keep[N], keep_err = S.cur_err;
 #pragma unroll
-    for (int j = 0; j < N; ++j) keep[j] = S.theta[j];
+    for (int j = 0; j < nj; ++j) keep[j] = S.theta[j];
     for (int c = 0; c < 5; ++c) {
       double cand[N];
 #pragma unroll
-      for (int j = 0; j < N; ++j) {
+      for (int j = 0; j < nj; ++j) {
         const double t = S.theta[j] + scales[c] * (d[j] * scale);
         cand[j] = t < P.lo[j] ? P.lo[j] : (t > P.hi[j] ? P.hi[j] : t);
       }
-      MpJointState<double, N> jc;
-      mp_joint_state<double, N>(M, cand, jc);
       double Tt[16], Jt[6 * N], Vt[6], rt, tt;
-      mp_fk_jac<double, N, false>(M, jc, Tt, Jt);
+      KIN::template fk<false>(M, cand, Tt, Jt);
       mp_ik_error(Tt, Td, Vt, rt, tt);
       if (rt + tt < keep_err) {
         keep_err = rt + tt;
 #pragma unroll
-        for (int j = 0; j < N; ++j) keep[j] = cand[j];
+        for (int j = 0; j < nj; ++j) keep[j] = cand[j];
       }
     }
     if (keep_err < S.cur_err * 1.1) {
 #pragma unroll
-      for (int j = 0; j < N; ++j) S.theta[j] = keep[j];
+      for (int j = 0; j < nj; ++j) S.theta[j] = keep[j];
     } else {  // every scale failed by more than 10 %: a small step anyway
 #pragma unroll
-      for (int j = 0; j < N; ++j) {
+      for (int j = 0; j < nj; ++j) {
         const double t = S.theta[j] + 0.1 * (d[j] * scale);
         S.theta[j] = t < P.lo[j] ? P.lo[j] : (t > P.hi[j] ? P.hi[j] : t);
       }
     }
   } else {
 #pragma unroll
-    for (int j = 0; j < N; ++j) {
+    for (int j = 0; j < nj; ++j) {
       const double t = S.theta[j] + d[j] * scale;
       S.theta[j] = t < P.lo[j] ? P.lo[j] : (t > P.hi[j] ? P.hi[j] : t);
     }
@@ -250,15 +262,15 @@ MP_HD int mp_ik_iterate(const MT& M, const MpIkParams& P, MpIkState<N>& S, const
 }
 
 // theta: in = initial guess, out = solution.  Returns the reference's iteration count; sets success / restarts.
-template <int N, typename MT>
-MP_HD int mp_ik_solve(const MT& M, const MpIkParams& P, const double (&Td)[16], double (&theta)[N], int& success, int& restarts) {
+template <int N, typename KIN = MpIkUnrolled<N>, typename MT, typename PT>
+MP_HD int mp_ik_solve(const MT& M, const PT& P, const double (&Td)[16], double (&theta)[N], int& success, int& restarts) {
   MpIkState<N> S;
   double theta0[N];
 #pragma unroll
   for (int j = 0; j < N; ++j) { S.theta[j] = theta[j]; theta0[j] = theta[j]; }
   mp_ik_begin(S, P);
   int done;
-  while (!(done = mp_ik_iterate<N>(M, P, S, Td, theta0))) {}
+  while (!(done = mp_ik_iterate<N, KIN>(M, P, S, Td, theta0))) {}
 #pragma unroll
   for (int j = 0; j < N; ++j) theta[j] = S.theta[j];
   success = done == 2 ? 1 : 0;

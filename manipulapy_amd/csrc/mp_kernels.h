@@ -68,10 +68,16 @@ hipError_t mpk_potential_field(hipStream_t s, const float* pos, const float* goa
                                float influence, float* pot, float* grad);
 
 // B damped-least-squares inverse-kinematics problems (csrc/mp_ik.h): Tdes (B,4,4), theta0 / theta (B,n) float64
-struct MpIkParams;
+template <int CAP> struct MpIkParamsT;
+typedef MpIkParamsT<MP_MAX_DOF> MpIkParams;
+typedef MpIkParamsT<MP_BIG_DOF> MpIkBigParams;
 // queue_counter: 8 bytes of device memory owned by the caller (zeroed here on the stream before the launch)
 hipError_t mpk_ik(hipStream_t s, const MpModel<double>& M, const MpIkParams& P, const double* Tdes, const double* theta0, long B,
                   double* theta, int* success, int* iterations, int* restarts, unsigned long long* queue_counter, int compute_units);
+// the same for 9..16 joints (run-time joint count, the model resident in device memory)
+hipError_t mpk_dyn_ik(hipStream_t s, const MpBigModel<double>* d_model, const MpIkBigParams& P, const double* Tdes, const double* theta0,
+                      long B, double* theta, int* success, int* iterations, int* restarts, unsigned long long* queue_counter,
+                      int compute_units);
 
 // table-driven fused generation + ID (float32): `tab` = 3 doubles per timestep written by mpk_time_table for the same
 // (Nt, Tf, method); one lane takes timesteps t and t + ceil(Nt / 2) of one trajectory

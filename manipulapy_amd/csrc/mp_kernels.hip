@@ -667,6 +667,33 @@ hipError_t mpk_transpose_rows(hipStream_t s, const void* src, void* dst, long ou
   return hipGetLastError();
 }
 
+// inverse kinematics with a run-time joint count: the work queue of k_ik, the looped kinematics of mp_dyn.h
+__global__ __launch_bounds__(kBlock) void k_dyn_ik(const MpBigModel<double>* __restrict__ Mdev, const MpIkBigParams P,
+                                                   const double* __restrict__ Tdes, const double* __restrict__ theta0, long B,
+                                                   double* __restrict__ theta, int* __restrict__ success, int* __restrict__ iterations,
+                                                   int* __restrict__ restarts, unsigned long long* __restrict__ next) {
+  MpBigConst<double>& M = *(MpBigConst<double>*)Mdev;
+  const int n = M.n;
+  MpIkState<MP_BIG_DOF> S;
+  bool have = false;
+  long row = 0;
+  for (;;) {  // exit: the counter only grows, so every lane sees row >= B eventually
+    if (!have) {
+      row = (long)atomicAdd(next, 1ull);
+      if (row >= B) break;
+      for (int j = 0; j < MP_BIG_DOF; ++j) S.theta[j] = j < n ? theta0[row * n + j] : 0.0;
+      mp_ik_begin(S, P);
+      have = true;
+    }
+    if (const int done = mp_ik_iterate<MP_BIG_DOF, MpIkLooped>(M, P, S, Tdes + row * 16, theta0 + row * n)) {
+      for (int j = 0; j < n; ++j) theta[row * n + j] = S.theta[j];
+      success[row] = done == 2 ? 1 : 0;
+      iterations[row] = S.k + 1;
+      restarts[row] = S.restarts;
+      have = false;
+    }
+  }
+}
 hipError_t mpk_cartesian_traj(hipStream_t s, const double* Xstart, const double* Xend, long B, long Nt, double Tf, int method,
                               float* pos, float* vel, float* acc, float* ori) {
   if (B <= 0 || Nt <= 0) return hipSuccess;
@@ -684,6 +711,18 @@ hipError_t mpk_ik(hipStream_t s, const MpModel<double>& M, const MpIkParams& P, 
   const long want = (B + kBlock - 1) / kBlock, cap = 2L * (compute_units > 0 ? compute_units : 256);
   const unsigned grid = (unsigned)(want < cap ? want : cap);
   MP_DISPATCH_N(M.n, { hipLaunchKernelGGL((k_ik<N>), dim3(grid), dim3(kBlock), 0, s, M, P, Tdes, theta0, B, theta, success, iterations, restarts, queue_counter); })
+  return hipGetLastError();
+}
+
+hipError_t mpk_dyn_ik(hipStream_t s, const MpBigModel<double>* d_model, const MpIkBigParams& P, const double* Tdes, const double* theta0,
+                      long B, double* theta, int* success, int* iterations, int* restarts, unsigned long long* queue_counter,
+                      int compute_units) {
+  if (B <= 0) return hipSuccess;
+  hipError_t e = hipMemsetAsync(queue_counter, 0, sizeof(unsigned long long), s);
+  if (e != hipSuccess) return e;
+  const long want = (B + kBlock - 1) / kBlock, cap = 2L * (compute_units > 0 ? compute_units : 256);
+  hipLaunchKernelGGL(k_dyn_ik, dim3((unsigned)(want < cap ? want : cap)), dim3(kBlock), 0, s, d_model, P, Tdes, theta0, B, theta, success,
+                     iterations, restarts, queue_counter);
   return hipGetLastError();
 }
 

@@ -162,7 +162,8 @@ class SerialManipulator:
         iteration (optionally with its adaptive damping and its five-scale line search); `self.joint_limits` is the
         projection box (None = open end)."""
         model = self._kin_model()
-        if np.shape(T_desired_batch)[0] >= 16384 and os.environ.get("MANIPULAPY_HIP_SPECIALIZE", "1") != "0":
+        if (np.shape(T_desired_batch)[0] >= 16384 and os.environ.get("MANIPULAPY_HIP_SPECIALIZE", "1") != "0"
+                and model.n <= _hip.MP_MAX_DOF):
             from .registry import _hip_routing_enabled, get_context
 
             if _hip_routing_enabled():  # big batch: the ~2 s (first time; cached on disk) of baking this robot's constants in pays for itself
@@ -189,6 +190,16 @@ class SerialManipulator:
         th, ok, it = self.batch_inverse_kinematics(T[None], np.asarray(thetalist0, dtype=np.float64)[None], eomg, ev, max_iterations,
                                                    damping, step_cap, weight_orientation, weight_position, adaptive_tuning, backtracking)
         return th[0], bool(ok[0]), int(it[0])
+
+    def trac_ik(self, T_desired, theta0=None, timeout: float = 0.2, eomg: float = 1e-4, ev: float = 1e-4, num_restarts: int = 5,
+                use_parallel: bool = False):
+        """TRAC-IK style multi-start solve: (theta, success, solve_time) (reference kinematics/ik.py:600-651).  All initial
+        guesses are rows of one batched inverse-kinematics launch - see manipulapy_amd/trac_ik.py."""
+        from .trac_ik import trac_ik_solve
+
+        if theta0 is not None:
+            theta0 = np.array(theta0, dtype=float)
+        return trac_ik_solve(self, T_desired, theta0, timeout, eomg, ev, num_restarts, use_parallel)
 
     def smart_inverse_kinematics(self, T_desired, strategy: str = "workspace_heuristic", theta_current=None, T_current=None, cache=None,
                                  eomg: float = 1e-6, ev: float = 1e-6, max_iterations: int = 10000, plot_residuals: bool = False,

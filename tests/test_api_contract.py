@@ -10,7 +10,7 @@ and, for every symbol this package mirrors, the test asserts
 
 under the default NumPy backend (CPU suite) and under the "hip" backend (-m gpu).  The fixture robot is the hand-built
 6-DOF model of the reference's test - a ManipulatorDynamics WITHOUT Mlist_per_link, i.e. the legacy approximation.
-Symbols deliberately not mirrored are listed in NOT_MIRRORED and checked to be exactly the rest of the contract.
+All 22 frozen symbols are mirrored; NOT_MIRRORED (empty) is checked to be exactly the rest of the contract.
 """
 import inspect
 import json
@@ -26,9 +26,8 @@ import manipulapy_amd as mp
 HERE = os.path.dirname(os.path.abspath(__file__))
 GOLDEN = json.load(open(os.path.join(HERE, "golden", "api_contract_golden.json")))
 
-# TRAC-IK (dual-solver racing with a wall-clock timeout) is outside the hot path and its next-rows (SURVEY.md section 8,
-# DESIGN.md section 8): not built, so not frozen here.
-NOT_MIRRORED = {"SerialManipulator.trac_ik", "trac_ik.TracIKSolver.solve", "trac_ik.trac_ik_solve"}
+# every frozen symbol is mirrored (the TRAC-IK three since round 3: manipulapy_amd/trac_ik.py)
+NOT_MIRRORED = set()
 
 
 def split_top(text, sep=","):
@@ -113,7 +112,12 @@ def build_calls():
     traj = planner.joint_trajectory(theta, theta2, 1.0, 8, 5)
     pos, vel, acc = traj["positions"], traj["velocities"], traj["accelerations"]
     taumat, ftipmat = np.zeros((pos.shape[0], 6)), np.zeros((pos.shape[0], 6))
+    trac_solver = mp.TracIKSolver(fk_func=lambda th: robot.forward_kinematics(th, frame="space"),
+                                  jacobian_func=lambda th: robot.jacobian(th, frame="space"), joint_limits=robot.joint_limits, n_joints=6)
     return {
+        "SerialManipulator.trac_ik": (robot.trac_ik, lambda: robot.trac_ik(T_desired, theta0=theta.copy(), timeout=0.05)),
+        "trac_ik.TracIKSolver.solve": (trac_solver.solve, lambda: trac_solver.solve(T_desired, theta0=theta.copy(), timeout=0.05)),
+        "trac_ik.trac_ik_solve": (mp.trac_ik_solve, lambda: mp.trac_ik_solve(robot, T_desired, theta0=theta.copy(), timeout=0.05)),
         "SerialManipulator.forward_kinematics": (robot.forward_kinematics, lambda: robot.forward_kinematics(theta)),
         "SerialManipulator.jacobian": (robot.jacobian, lambda: robot.jacobian(theta)),
         "SerialManipulator.end_effector_velocity": (robot.end_effector_velocity, lambda: robot.end_effector_velocity(theta, dtheta)),

@@ -1702,6 +1702,16 @@ def test_urdf_to_kernel_for_the_reference_robot_database(monkeypatch):
                 tau_f = pl.batch_inverse_dynamics_trajectory(np.tile(th, (3, 1)).astype(np.float32), np.tile(th + 0.1, (3, 1)).astype(np.float32), 1.0, 700, 5)
                 two = pl.inverse_dynamics_trajectory(traj["positions"].reshape(-1, n), traj["velocities"].reshape(-1, n), traj["accelerations"].reshape(-1, n))
                 np.testing.assert_allclose(tau_f.reshape(-1, n), two, rtol=1e-5, atol=1e-5 * float(np.abs(two).max()))
+                # inverse kinematics (k_dyn_ik) and the multi-start solve built on it
+                rng = np.random.default_rng(4)
+                goal = mp.ik_helpers.clip_to_limits(th + rng.uniform(-0.2, 0.2, (40, n)), sm.joint_limits)
+                Tg = np.stack([sm.forward_kinematics(x) for x in goal])
+                sol, ok, it = sm.batch_inverse_kinematics(Tg, np.tile(th, (40, 1)), max_iterations=2000, adaptive_tuning=True, backtracking=True)
+                assert ok.all(), (name, ok, it)
+                for a_, T_ in zip(sol, Tg):
+                    assert np.abs(sm.forward_kinematics(a_)[:3, 3] - T_[:3, 3]).max() < 2e-6
+                t_sol, t_ok, t_s = sm.trac_ik(Tg[0], theta0=th)
+                assert t_ok and np.abs(sm.forward_kinematics(t_sol)[:3, 3] - Tg[0][:3, 3]).max() < 2e-4
             done += 1
     assert done >= 32 and sorted(big) == ["jaco_6dof", "jaco_7dof"], (done, big)
 
@@ -1836,8 +1846,22 @@ def test_looped_kernels_equal_the_unrolled_kernels(robot, tables, dyn_golden, mo
         np.testing.assert_allclose(ub, ua, rtol=3e-5, atol=3e-5 * np.abs(ua).max())
         with pytest.raises(_hip.HipError):
             ctx.specialize(looped)
-        with pytest.raises(_hip.HipError):
-            ctx.inverse_kinematics_host(looped, Ta[:2], q[:2])
+        # inverse kinematics: k_dyn_ik (run-time-n kinematics) against k_ik and against the CPU launcher - one iteration template
+        q0 = np.clip(q[:96] * 0.6, lim[:, 0], lim[:, 1])
+        goal = np.clip(q0 + rng.uniform(-0.15, 0.15, q0.shape), lim[:, 0], lim[:, 1])
+        Tg = ctx.fk_jac_id_host(unrolled, goal)[0]
+        for opts in (dict(), dict(adaptive_tuning=True, backtracking=True)):
+            ia = ctx.inverse_kinematics_host(unrolled, Tg, q0, lim, max_iterations=1500, **opts)
+            ib = ctx.inverse_kinematics_host(looped, Tg, q0, lim, max_iterations=1500, **opts)
+            ic = _hip.cpu_inverse_kinematics(looped, Tg, q0, lim, max_iterations=1500, **opts)
+            assert ib[1].mean() > 0.9
+            same = ia[2] == ib[2]
+            assert same.mean() > 0.95          # rounding may move an iteration count on a slow problem; never the answer's quality
+            np.testing.assert_allclose(ib[0][same & ia[1]], ia[0][same & ia[1]], rtol=0, atol=1e-6)
+            np.testing.assert_array_equal(ib[1], ic[1])
+            okb = ib[1]
+            Tb_ = ctx.fk_jac_id_host(looped, ib[0][okb])[0]
+            assert np.abs(Tb_[:, :3, 3] - Tg[okb][:, :3, 3]).max() < 2e-6
     finally:
         ctx.destroy()
 
