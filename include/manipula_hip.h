@@ -281,6 +281,14 @@ int mp_inverse_kinematics_host_f64(mp_ctx* ctx, const mp_model* model, const dou
                               uint32_t seed,
                                    double* theta, int32_t* success, int32_t* iterations, int32_t* restarts);
 
+/* K closed-loop regulation runs under joint-space PD torque, one lane each, float64 - the simulations the reference's
+ * Ziegler-Nichols gain sweep runs one gain after the other (control/metrics.py:315-355: tau = Kp (des - theta) - Kd omega,
+ * alpha = M^-1 (tau - c - g), omega += alpha dt, theta += omega dt, error = |theta - des|, stop after a step > 10 whose
+ * error exceeds 1e10).  Host arrays: theta0 / theta_des (K,n), Kp / Kd (K); errors (K,steps) - entries past a run's
+ * count are left untouched - and count (K) come back.  g: 3 doubles or NULL (0,0,-9.81). */
+int mp_pd_regulation_host_f64(mp_ctx* ctx, const mp_model* model, const double* theta0, const double* theta_des, const double* Kp,
+                              const double* Kd, int64_t K, const double* g, double dt, int steps, double* errors, int32_t* count);
+
 /* ---- CPU twins (csrc/mp_cpu.cpp): what the kernel registry's cpu_launcher of each operation calls ----------------
  * The reference routes every registered operation through `gpu_launcher if _cuda_routing_enabled() else cpu_launcher`
  * (cuda_kernels/registry.py:85-89) and its planner mixins pick _*_cpu when _should_use_gpu is false
@@ -315,6 +323,8 @@ int mp_inverse_kinematics_cpu_f64(const mp_model* model, const double* T_desired
                                   int32_t* restarts, int nthreads);
 int mp_cartesian_trajectory_cpu_f32(const double* Xstart, const double* Xend, int64_t B, int64_t N, double Tf, int method,
                                     float* pos, float* vel, float* acc, float* orient, int nthreads);
+int mp_pd_regulation_cpu_f64(const mp_model* model, const double* theta0, const double* theta_des, const double* Kp, const double* Kd,
+                             int64_t K, const double* g, double dt, int steps, double* errors, int32_t* count, int nthreads);
 
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI (new; the reference is single-device) ------
  * Trajectory batches are sharded over ranks with no exchange during compute; the only collective is

@@ -109,6 +109,8 @@ SIGNATURES = {
     "mp_id_trajectory_host_f64": (ctypes.c_int, [_vp, _vp, _c_dp, _c_dp, _c_dp, _i64, _c_dp, _c_dp, _c_dp]),
     "mp_traj_id_fused_host_f32": (ctypes.c_int, [_vp, _vp, _c_fp, _c_fp, _i64, _i64, ctypes.c_double, ctypes.c_int, _c_dp, _c_dp, _c_fp]),
     "mp_fk_jac_id_host_f64": (ctypes.c_int, [_vp, _vp, _c_dp, _c_dp, _c_dp, _i64, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp]),
+    "mp_pd_regulation_host_f64": (ctypes.c_int, [_vp, _vp, _c_dp, _c_dp, _c_dp, _c_dp, _i64, _c_dp, ctypes.c_double, ctypes.c_int, _c_dp, _vp]),
+    "mp_pd_regulation_cpu_f64": (ctypes.c_int, [_vp, _c_dp, _c_dp, _c_dp, _c_dp, _i64, _c_dp, ctypes.c_double, ctypes.c_int, _c_dp, _vp, ctypes.c_int]),
     "mp_cpu_threads": (ctypes.c_int, [_i64]),
     "mp_id_trajectory_cpu_f32": (ctypes.c_int, [_vp, _c_fp, _c_fp, _c_fp, _i64, _c_dp, _c_dp, _c_fp, ctypes.c_int]),
     "mp_id_trajectory_cpu_f64": (ctypes.c_int, [_vp, _c_dp, _c_dp, _c_dp, _i64, _c_dp, _c_dp, _c_dp, ctypes.c_int]),
@@ -652,6 +654,15 @@ class HipContext:
             ok.ctypes.data_as(_vp), it.ctypes.data_as(_vp), rs.ctypes.data_as(_vp)))
         return th, ok.astype(bool), it, rs
 
+    def pd_regulation_host(self, model: HipModel, theta0, theta_des, Kp, Kd, g, dt, steps):
+        """K closed-loop PD regulation runs in one launch (mp_pd_regulation_host_f64): theta0 / theta_des (K,n), Kp / Kd (K,) ->
+        (errors (K,steps) float64 with NaN past each run's end, count (K,) int32)."""
+        args = _pd_regulation_args(model, theta0, theta_des, Kp, Kd, g, steps)
+        th0, des, kp, kd, gv, err, cnt = args
+        _check(self.lib.mp_pd_regulation_host_f64(self.handle, model.handle, _dptr(th0), _dptr(des), _dptr(kp), _dptr(kd), th0.shape[0], _dptr(gv),
+                                                  float(dt), int(steps), _dptr(err), cnt.ctypes.data_as(_vp)))
+        return err, cnt
+
     def inverse_kinematics(self, model, d_T_desired, d_theta0, B, d_theta, d_success, d_iterations, d_restarts, joint_limits=None,
                            eomg=1e-6, ev=1e-6, max_iterations=10000, damping=2e-2, step_cap=0.3, weight_orientation=1.0,
                            weight_position=1.0, adaptive_tuning=False, backtracking=False, seed=1234):
@@ -832,6 +843,27 @@ def cpu_forward_dynamics(model: "HipModel", q, qd, tau, g=None, Ftip=None, nthre
                                                       _dptr(_vec_or_none(g, 3, "g")), _dptr(_vec_or_none(Ftip, 6, "Ftip")), _dptr(out),
                                                       int(nthreads)))
     return out
+
+
+def _pd_regulation_args(model, theta0, theta_des, Kp, Kd, g, steps):
+    th0 = _as_c(theta0, np.float64, name="theta0")
+    if th0.ndim != 2 or th0.shape[1] != model.n:
+        raise ValueError(f"theta0 must be (K, {model.n}), got {th0.shape}")
+    K = th0.shape[0]
+    des = _as_c(theta_des, np.float64, (K, model.n), "theta_des")
+    kp, kd = _as_c(Kp, np.float64, (K,), "Kp"), _as_c(Kd, np.float64, (K,), "Kd")
+    gv = None if g is None else _as_c(g, np.float64, (3,), "g")
+    if int(steps) < 0:
+        raise ValueError("steps must be non-negative")
+    return th0, des, kp, kd, gv, np.full((K, int(steps)), np.nan), np.zeros(K, dtype=np.int32)
+
+
+def cpu_pd_regulation(model: "HipModel", theta0, theta_des, Kp, Kd, g, dt, steps, nthreads: int = 0):
+    """HipContext.pd_regulation_host on the host cores (mp_pd_regulation_cpu_f64): same arguments, same results."""
+    th0, des, kp, kd, gv, err, cnt = _pd_regulation_args(model, theta0, theta_des, Kp, Kd, g, steps)
+    _check(load_library().mp_pd_regulation_cpu_f64(model.handle, _dptr(th0), _dptr(des), _dptr(kp), _dptr(kd), th0.shape[0], _dptr(gv), float(dt),
+                                                   int(steps), _dptr(err), cnt.ctypes.data_as(_vp), int(nthreads)))
+    return err, cnt
 
 
 def cpu_inverse_kinematics(model: "HipModel", T_desired, theta0, joint_limits=None, eomg=1e-6, ev=1e-6, max_iterations=10000,

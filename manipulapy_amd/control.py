@@ -11,8 +11,9 @@ mass matrix and an inverse-dynamics call per sample.  Inverse dynamics is affine
 which is what runs here — for a single sample or for a whole batch of (rows, n) samples in one launch.
 The reference's other model-based laws (PD / PID, PD + feed-forward, joint- and Cartesian-space PD, robust and adaptive
 control, the Kalman filter on [q; qd]) are the same inverse- / forward-dynamics / FK / Jacobian calls plus host arithmetic and
-are mirrored below, with the step-response metrics and the Ziegler-Nichols gain formulas; the closed-loop gain sweep
-(`find_ultimate_gain_and_period`) and the response plot stay out of scope.
+are mirrored below, with the step-response metrics, the Ziegler-Nichols gain formulas and the closed-loop gain sweep
+(`find_ultimate_gain_and_period`: every gain of the ladder is one lane of a single "control.pd_regulation" launch); the
+response plot stays out of scope.
 """
 from __future__ import annotations
 
@@ -232,6 +233,41 @@ class ManipulatorController:
 
     def tune_controller(self, Ku, Tu, kind: str = "PID"):
         return self.ziegler_nichols_tuning(Ku, Tu, kind)
+
+    def find_ultimate_gain_and_period(self, thetalist, desired_joint_angles, dt, max_steps: int = 1000):
+        """(ultimate_gain, ultimate_period, gain_history, error_history) by the reference's sweep (control/metrics.py:280-366): for
+        Kp = 0.01, 0.011, ... (x 1.1, below 1000) simulate `max_steps` steps of the arm under tau = Kp (desired - theta) from rest
+        (semi-implicit Euler on M^-1 (tau - c - g), g = [0, 0, -9.81]) and stop at the first gain whose error norm rose over the
+        last step by less than 20 %.  The reference runs the gains one after the other; the runs are independent, so here the
+        whole ladder (121 gains) is ONE registered "control.pd_regulation" launch, one lane per gain, and the sequential stopping
+        rule is applied to its output - the same answer.  The integral state is reset like the reference's."""
+        from .registry import execute_registered_kernel
+
+        theta = np.asarray(thetalist, dtype=np.float64).copy()
+        desired = np.asarray(desired_joint_angles, dtype=np.float64)
+        steps = int(max_steps)
+        gains, Kp = [], 0.01
+        while Kp < 1000:        # the ladder the reference's `while not oscillation and Kp < 1000` can visit
+            gains.append(Kp)
+            Kp *= 1.1
+        K = len(gains)
+        self.eint = np.zeros_like(theta)
+        if getattr(self.dynamics, "Mlist_per_link", None) is None:
+            raise NotImplementedError("find_ultimate_gain_and_period needs a compiled model (ManipulatorDynamics with Mlist_per_link)")
+        errors, count = execute_registered_kernel("control.pd_regulation", self.dynamics._model_for(K), np.tile(theta, (K, 1)),
+                                                  np.tile(desired, (K, 1)), np.asarray(gains), np.zeros(K), np.array([0.0, 0.0, -9.81]),
+                                                  float(dt), steps)
+        gain_history, error_history, ultimate = [], [], gains[-1] * 1.1   # (ladder exhausted: the reference leaves with the next Kp)
+        for k in range(K):
+            e = errors[k, : count[k]].copy()
+            gain_history.append(gains[k])
+            error_history.append(e)
+            if len(e) >= 2 and e[-2] < e[-1] < e[-2] * 1.2:
+                ultimate = gains[k]
+                break
+        last = error_history[-1] if error_history else np.zeros(0)
+        crossings = int(np.count_nonzero(np.diff(np.sign(last)))) // 2 if len(last) > 1 else 0
+        return float(ultimate), float((steps * dt) / max(1, crossings)), gain_history, error_history
 
     def _id(self, q, qd, qdd, g, Ftip):
         single = q.ndim == 1

@@ -1606,6 +1606,48 @@ int mp_forward_dynamics_host_f64(mp_ctx* ctx, const mp_model* model, const doubl
   return MP_OK;
 }
 
+int mp_pd_regulation_host_f64(mp_ctx* ctx, const mp_model* model, const double* theta0, const double* theta_des, const double* Kp,
+                              const double* Kd, int64_t K, const double* g, double dt, int steps, double* errors, int32_t* count) {
+  CHECK_COMMON("mp_pd_regulation_host_f64");
+  REQUIRE(K >= 0 && steps >= 0, "mp_pd_regulation_host_f64: negative run or step count");
+  if (K == 0) return MP_OK;
+  REQUIRE(theta0 && theta_des && Kp && Kd && count && (errors || steps == 0), "mp_pd_regulation_host_f64: null host pointer");
+  REQUIRE(std::isfinite(dt), "mp_pd_regulation_host_f64: dt must be finite");
+  const size_t qb = (size_t)K * (size_t)model->d.n * sizeof(double), kb = (size_t)K * sizeof(double),
+               eb = (size_t)K * (size_t)steps * sizeof(double), cb = (size_t)K * sizeof(int32_t);
+  Scratch sc(ctx);
+  void *d0, *dd, *dkp, *dkd, *de, *dc;
+  if (int rc = sc.get(qb, &d0)) return rc;
+  if (int rc = sc.get(qb, &dd)) return rc;
+  if (int rc = sc.get(kb, &dkp)) return rc;
+  if (int rc = sc.get(kb, &dkd)) return rc;
+  if (int rc = sc.get(eb, &de)) return rc;
+  if (int rc = sc.get(cb, &dc)) return rc;
+  H2D(d0, theta0, qb);
+  H2D(dd, theta_des, qb);
+  H2D(dkp, Kp, kb);
+  H2D(dkd, Kd, kb);
+  if (eb) H2D(de, errors, eb);  // entries past a run's count keep the caller's values
+  MpCall<double> c;
+  make_call<double>(model, g, nullptr, &c);
+  {
+    PROFILE_SCOPE(ctx, "mp_pd_regulation_host_f64");
+    if (model->big) {
+      const MpBigModel<double>* dm = nullptr;
+      if (int rc = device_big_model<double>(ctx, model, &dm)) return rc;
+      HIP_TRY(mpk_dyn_pd_regulation(ctx->compute, dm, c, (double*)d0, (double*)dd, (double*)dkp, (double*)dkd, (long)K, dt, steps,
+                                    (double*)de, (int*)dc));
+    } else {
+      HIP_TRY(mpk_pd_regulation(ctx->compute, model->d, c, (double*)d0, (double*)dd, (double*)dkp, (double*)dkd, (long)K, dt, steps,
+                                (double*)de, (int*)dc));
+    }
+  }
+  if (eb) D2H(errors, de, eb);
+  D2H(count, dc, cb);
+  HIP_TRY(hipStreamSynchronize(ctx->compute));
+  return MP_OK;
+}
+
 int mp_cartesian_trajectory_f32(mp_ctx* ctx, const double* d_Xstart, const double* d_Xend, int64_t B, int64_t N, double Tf,
                                 int method, float* d_pos, float* d_vel, float* d_acc, float* d_orient) {
   REQUIRE(ctx, "mp_cartesian_trajectory_f32: null context");
@@ -1736,7 +1778,7 @@ int mp_inverse_kinematics_f64(mp_ctx* ctx, const mp_model* model, const double* 
     long nb = (long)B;
     void* counter = ctx->queue_counter;
     void* args[] = {&P, &d_T_desired, &d_theta0, &nb, &d_theta, &d_success, &d_iterations, &d_restarts, &counter};
-    const long want = (nb + 255) / 256, cap = 2L * (ctx->compute_units > 0 ? ctx->compute_units : 256);
+    const long want = (nb + 255) / 256, cap = 1L * (ctx->compute_units > 0 ? ctx->compute_units : 256);  // one block per CU: see mp_spec_ik
     return launch_spec(ctx, sp->ik, (want < cap ? want : cap) * 256, args);
   }
   HIP_TRY(mpk_ik(ctx->compute, model->d, P, d_T_desired, d_theta0, (long)B, d_theta, d_success, d_iterations, d_restarts,

@@ -589,6 +589,37 @@ MP_HD void mp_forward_dynamics(const MT& M, const typename MpTraits<T>::S (&a0)[
   mp_spd_solve<T, N>(Mq, qdd);
 }
 
+// One closed-loop regulation run under joint-space PD torque (the inner loop of the reference's gain sweep,
+// control/metrics.py:316-346): tau = Kp (des - theta) - Kd omega, alpha = forward dynamics without a tip wrench,
+// omega += alpha dt, theta += omega dt, err[step] = |theta - des|_2; the run stops after a step > 10 whose error
+// exceeds 1e10.  Returns the number of errors recorded.
+template <typename T, int N, typename MT>
+MP_HD int mp_pd_regulation_run(const MT& M, const typename MpTraits<T>::S (&a0)[3], const T (&theta0)[N], const T (&des)[N], T Kp,
+                               T Kd, T dt, int steps, T* err) {
+  T th[N], om[N], tau[N], al[N];
+  const T z3[3] = {T(0), T(0), T(0)};
+#pragma unroll
+  for (int j = 0; j < N; ++j) { th[j] = theta0[j]; om[j] = T(0); }
+  int done = 0;
+  for (int step = 0; step < steps; ++step) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) tau[j] = Kp * (des[j] - th[j]) - Kd * om[j];
+    mp_forward_dynamics<T, N, false>(M, a0, z3, z3, th, om, tau, al);
+    T e2 = T(0);
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      om[j] += al[j] * dt;
+      th[j] += om[j] * dt;
+      e2 += (th[j] - des[j]) * (th[j] - des[j]);
+    }
+    const T e = sqrt(e2);
+    err[step] = e;
+    done = step + 1;
+    if (step > 10 && e > T(1e10)) break;
+  }
+  return done;
+}
+
 // ------------------------------------------------------------------------- FK + space Jacobian
 // T (4x4 row-major) = prod T_{i-1,i}(q_i) . tool ;  J (6 x N row-major), column i = [z_i ; o_i x z_i]
 // (revolute) or [0 ; z_i] (prismatic), z_i / o_i = axis / origin of link frame i in the space frame —

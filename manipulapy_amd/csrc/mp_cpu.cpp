@@ -408,6 +408,35 @@ int mp_inverse_kinematics_cpu_f64(const mp_model* model, const double* T_desired
   return MP_OK;
 }
 
+int mp_pd_regulation_cpu_f64(const mp_model* model, const double* theta0, const double* theta_des, const double* Kp, const double* Kd,
+                             int64_t K, const double* g, double dt, int steps, double* errors, int32_t* count, int nthreads) {
+  if (!model) return fail("mp_pd_regulation_cpu_f64: null model");
+  if (K < 0 || steps < 0) return fail("mp_pd_regulation_cpu_f64: negative run or step count");
+  if (K == 0) return MP_OK;
+  if (!theta0 || !theta_des || !Kp || !Kd || !count || (!errors && steps > 0)) return fail("mp_pd_regulation_cpu_f64: null pointer");
+  const MpCall<double> C = make_call<double>(model, g, nullptr);
+  const int n = model->d.n;
+  if (model->big) {  // the body of k_dyn_pd_regulation
+    parallel_for(K, 1, nthreads, [&](int64_t lo, int64_t hi) {
+      for (int64_t k = lo; k < hi; ++k)
+        count[k] = mp_dyn_pd_regulation_run<double>(model->bd, C.a0, theta0 + k * n, theta_des + k * n, Kp[k], Kd[k], dt, steps,
+                                                    errors + k * steps);
+    });
+    return MP_OK;
+  }
+  const MpModel<double>& M = model->d;
+  MP_CPU_DISPATCH(M.n, {  // the body of k_pd_regulation
+    parallel_for(K, 1, nthreads, [&](int64_t lo, int64_t hi) {
+      for (int64_t k = lo; k < hi; ++k) {
+        double a[N], d[N];
+        for (int j = 0; j < N; ++j) { a[j] = theta0[k * N + j]; d[j] = theta_des[k * N + j]; }
+        count[k] = mp_pd_regulation_run<double, N>(M, C.a0, a, d, Kp[k], Kd[k], dt, steps, errors + k * steps);
+      }
+    });
+  })
+  return MP_OK;
+}
+
 int mp_cartesian_trajectory_cpu_f32(const double* Xstart, const double* Xend, int64_t B, int64_t N, double Tf, int method,
                                     float* pos, float* vel, float* acc, float* orient, int nthreads) {
   if (B < 0 || N < 0) return fail("mp_cartesian_trajectory_cpu_f32: negative count");

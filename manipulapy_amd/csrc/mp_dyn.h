@@ -354,6 +354,31 @@ MP_HD void mp_dyn_row_traj(const MT& M, const MpCall<float>& C, const float* sta
   }
 }
 
+// mp_pd_regulation_run of mp_core.h with a run-time joint count
+template <typename T, typename MT>
+MP_HD int mp_dyn_pd_regulation_run(const MT& M, const T (&a0)[3], const T* theta0, const T* des, T Kp, T Kd, T dt, int steps, T* err) {
+  const int n = M.n;
+  T th[MP_BIG_DOF], om[MP_BIG_DOF], tau[MP_BIG_DOF], al[MP_BIG_DOF];
+  const T z3[3] = {T(0), T(0), T(0)};
+  for (int j = 0; j < n; ++j) { th[j] = theta0[j]; om[j] = T(0); }
+  int done = 0;
+  for (int step = 0; step < steps; ++step) {
+    for (int j = 0; j < n; ++j) tau[j] = Kp * (des[j] - th[j]) - Kd * om[j];
+    mp_dyn_forward_dynamics<T, false>(M, n, a0, z3, z3, th, om, tau, al);
+    T e2 = T(0);
+    for (int j = 0; j < n; ++j) {
+      om[j] += al[j] * dt;
+      th[j] += om[j] * dt;
+      e2 += (th[j] - des[j]) * (th[j] - des[j]);
+    }
+    const T e = sqrt(e2);
+    err[step] = e;
+    done = step + 1;
+    if (step > 10 && e > T(1e10)) break;
+  }
+  return done;
+}
+
 // ------------------------------------------------------------------------------- inverse kinematics, 9..16 joints
 // The kinematics policy of mp_ik.h for a run-time joint count: the damped-least-squares iteration itself (error, step,
 // restart, adaptive damping, line search) is the one template of mp_ik.h; only the joint count and FK + Jacobian differ.

@@ -74,6 +74,11 @@ typedef MpIkParamsT<MP_BIG_DOF> MpIkBigParams;
 // queue_counter: 8 bytes of device memory owned by the caller (zeroed here on the stream before the launch)
 hipError_t mpk_ik(hipStream_t s, const MpModel<double>& M, const MpIkParams& P, const double* Tdes, const double* theta0, long B,
                   double* theta, int* success, int* iterations, int* restarts, unsigned long long* queue_counter, int compute_units);
+// K closed-loop PD regulation runs (csrc/mp_core.h mp_pd_regulation_run): theta0 / des (K,n), Kp / Kd (K), err (K,steps), count (K)
+hipError_t mpk_pd_regulation(hipStream_t s, const MpModel<double>& M, const MpCall<double>& C, const double* theta0, const double* des,
+                             const double* Kp, const double* Kd, long K, double dt, int steps, double* err, int* count);
+hipError_t mpk_dyn_pd_regulation(hipStream_t s, const MpBigModel<double>* d_model, const MpCall<double>& C, const double* theta0,
+                                 const double* des, const double* Kp, const double* Kd, long K, double dt, int steps, double* err, int* count);
 // the same for 9..16 joints (run-time joint count, the model resident in device memory)
 hipError_t mpk_dyn_ik(hipStream_t s, const MpBigModel<double>* d_model, const MpIkBigParams& P, const double* Tdes, const double* theta0,
                       long B, double* theta, int* success, int* iterations, int* restarts, unsigned long long* queue_counter,

@@ -667,6 +667,29 @@ hipError_t mpk_transpose_rows(hipStream_t s, const void* src, void* dst, long ou
   return hipGetLastError();
 }
 
+// K closed-loop regulation runs (mp_pd_regulation_run), one lane each: rows of theta0 / des (K, n), gains per run, errors (K, steps)
+template <int N>
+__global__ __launch_bounds__(64) void k_pd_regulation(const MpModel<double> M, const MpCall<double> C, const double* __restrict__ theta0,
+                                                      const double* __restrict__ des, const double* __restrict__ Kp,
+                                                      const double* __restrict__ Kd, long K, double dt, int steps,
+                                                      double* __restrict__ err, int* __restrict__ count) {
+  const long k = (long)blockIdx.x * 64 + threadIdx.x;
+  if (k >= K) return;
+  double a[N], d[N];
+  RunIO<double, N>::load(theta0, k, a);
+  RunIO<double, N>::load(des, k, d);
+  count[k] = mp_pd_regulation_run<double, N>(M, C.a0, a, d, Kp[k], Kd[k], dt, steps, err + k * steps);
+}
+__global__ __launch_bounds__(64) void k_dyn_pd_regulation(const MpBigModel<double>* __restrict__ Mdev, const MpCall<double> C,
+                                                          const double* __restrict__ theta0, const double* __restrict__ des,
+                                                          const double* __restrict__ Kp, const double* __restrict__ Kd, long K, double dt,
+                                                          int steps, double* __restrict__ err, int* __restrict__ count) {
+  const long k = (long)blockIdx.x * 64 + threadIdx.x;
+  if (k >= K) return;
+  MpBigConst<double>& M = *(MpBigConst<double>*)Mdev;
+  count[k] = mp_dyn_pd_regulation_run<double>(M, C.a0, theta0 + k * M.n, des + k * M.n, Kp[k], Kd[k], dt, steps, err + k * steps);
+}
+
 // inverse kinematics with a run-time joint count: the work queue of k_ik, the looped kinematics of mp_dyn.h
 __global__ __launch_bounds__(kBlock) void k_dyn_ik(const MpBigModel<double>* __restrict__ Mdev, const MpIkBigParams P,
                                                    const double* __restrict__ Tdes, const double* __restrict__ theta0, long B,
@@ -711,6 +734,19 @@ hipError_t mpk_ik(hipStream_t s, const MpModel<double>& M, const MpIkParams& P, 
   const long want = (B + kBlock - 1) / kBlock, cap = 2L * (compute_units > 0 ? compute_units : 256);
   const unsigned grid = (unsigned)(want < cap ? want : cap);
   MP_DISPATCH_N(M.n, { hipLaunchKernelGGL((k_ik<N>), dim3(grid), dim3(kBlock), 0, s, M, P, Tdes, theta0, B, theta, success, iterations, restarts, queue_counter); })
+  return hipGetLastError();
+}
+
+hipError_t mpk_pd_regulation(hipStream_t s, const MpModel<double>& M, const MpCall<double>& C, const double* theta0, const double* des,
+                             const double* Kp, const double* Kd, long K, double dt, int steps, double* err, int* count) {
+  if (K <= 0 || steps <= 0) return hipSuccess;
+  MP_DISPATCH_N(M.n, { hipLaunchKernelGGL((k_pd_regulation<N>), dim3((unsigned)((K + 63) / 64)), dim3(64), 0, s, M, C, theta0, des, Kp, Kd, K, dt, steps, err, count); })
+  return hipGetLastError();
+}
+hipError_t mpk_dyn_pd_regulation(hipStream_t s, const MpBigModel<double>* d_model, const MpCall<double>& C, const double* theta0,
+                                 const double* des, const double* Kp, const double* Kd, long K, double dt, int steps, double* err, int* count) {
+  if (K <= 0 || steps <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_dyn_pd_regulation, dim3((unsigned)((K + 63) / 64)), dim3(64), 0, s, d_model, C, theta0, des, Kp, Kd, K, dt, steps, err, count);
   return hipGetLastError();
 }
 

@@ -346,6 +346,14 @@ def _launch_ik_cpu(model, T_desired, theta0, **kw):
     return _hip.cpu_inverse_kinematics(model, T_desired, theta0, **kw)
 
 
+def _launch_pd_regulation_gpu(model, theta0, theta_des, Kp, Kd, g, dt, steps):
+    return get_context().pd_regulation_host(model, theta0, theta_des, Kp, Kd, g, dt, steps)
+
+
+def _launch_pd_regulation_cpu(model, theta0, theta_des, Kp, Kd, g, dt, steps):
+    return _hip.cpu_pd_regulation(model, theta0, theta_des, Kp, Kd, g, dt, steps)
+
+
 def _launch_mass_matrix_gpu(model, q):
     return get_context().mass_matrix_host(model, q)
 
@@ -420,6 +428,7 @@ def _build_kernel_registry() -> KernelRegistry:
         ("dynamics.forward", "mp_forward_dynamics_host_f64", _launch_forward_dynamics_gpu, _launch_forward_dynamics_cpu),
         ("dynamics.forward_trajectory", "mp_fd_trajectory_host_f32 / _f64", _launch_fd_trajectory_gpu, _launch_fd_trajectory_cpu),
         ("trajectory.cartesian", "mp_cartesian_trajectory_host_f32", _launch_cartesian_gpu, _launch_cartesian_cpu),
+        ("control.pd_regulation", "mp_pd_regulation_host_f64", _launch_pd_regulation_gpu, _launch_pd_regulation_cpu),
     ):
         reg.register(KernelRegistration(
             name=name, implementation=impl, launch_config=_grid_1d, cpu_fallback=cpu, gpu_launcher=gpu,

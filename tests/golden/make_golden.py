@@ -22,6 +22,7 @@ What it does:
       cartesian_ur5.npz    : cartesian_trajectory dumps (`make_golden.py cartesian` regenerates only this)
       ik.npz               : iterative_inverse_kinematics dumps, 10 problems per robot (`make_golden.py ik`)
       control_ur5.npz      : ManipulatorController laws on UR5 (`make_golden.py control`)
+      gain_sweep_ur5.npz   : ManipulatorController.find_ultimate_gain_and_period on UR5 (`make_golden.py gain_sweep`)
       utils.npz            : every public ManipulaPy.utils function on generic and branch-switching inputs (`make_golden.py utils`)
       (manipulapy_amd/data/) model_<robot>.npz, urdf/<robot>.urdf : the four benchmark robots' tables and URDF skeletons
       legacy_dynamics.npz  : ManipulatorDynamics without Mlist_per_link + truncated / body-frame kinematics (`make_golden.py legacy`)
@@ -453,6 +454,27 @@ def dump_control():
     np.savez(os.path.join(HERE, "control_ur5.npz"), **d)
 
 
+def dump_gain_sweep():
+    """ManipulatorController.find_ultimate_gain_and_period (control/metrics.py:280-366) on UR5: the closed-loop P-control
+    simulations of the gain ladder 0.01 * 1.1^k - ultimate gain / period, the gains visited and every run's error history."""
+    from ManipulaPy.control import ManipulatorController
+
+    proc, sm, dyn = build("ur5")
+    d = {}
+    cases = {"a": (np.full(6, 0.1), np.full(6, 0.5), 0.01, 40),
+             "b": (np.array([0.3, -1.2, 1.0, -0.4, 0.2, 0.1]), np.array([0.35, -1.25, 1.05, -0.45, 0.25, 0.05]), 0.002, 25),
+             "c": (np.array([0.0, -1.5707963, 0.0, 0.0, 0.0, 0.0]), np.array([0.2, -1.4, 0.1, 0.1, -0.1, 0.05]), 0.005, 30)}
+    for tag, (th, des, dt, steps) in cases.items():
+        clear_caches(dyn)
+        t0 = time.time()
+        Ku, Tu, gains, errs = ManipulatorController(dyn).find_ultimate_gain_and_period(th.copy(), des.copy(), dt, steps)
+        d[f"{tag}_theta"], d[f"{tag}_des"], d[f"{tag}_dt"], d[f"{tag}_steps"] = th, des, dt, steps
+        d[f"{tag}_Ku"], d[f"{tag}_Tu"], d[f"{tag}_gains"] = Ku, Tu, np.asarray(gains)
+        d[f"{tag}_errors"] = np.stack([np.asarray(e) for e in errs])
+        print(tag, "gains visited", len(gains), "Ku", Ku, "Tu", Tu, f"{time.time() - t0:.1f}s", flush=True)
+    np.savez(os.path.join(HERE, "gain_sweep_ur5.npz"), **d)
+
+
 def dump_utils():
     """ManipulaPy.utils (so3 / se3 / screw / time_scaling): every public function on generic inputs and on the inputs where its
     branches switch (identity, tiny angles on both sides of each Taylor band, near-pi, exact half turns about several axes,
@@ -834,7 +856,7 @@ def main():
         dump_ik()
         print("ik dumped")
         return
-    for name, fn in (("rollout100", dump_rollout100), ("nonfinite", dump_nonfinite), ("field", dump_field), ("urdf_suite", dump_urdf_suite),
+    for name, fn in (("gain_sweep", dump_gain_sweep), ("rollout100", dump_rollout100), ("nonfinite", dump_nonfinite), ("field", dump_field), ("urdf_suite", dump_urdf_suite),
                      ("legacy", dump_legacy)):
         if name in sys.argv[1:]:
             fn()
@@ -860,6 +882,7 @@ def main():
     dump_field()
     dump_urdf_suite()
     dump_legacy()
+    dump_gain_sweep()
     print("trajectories dumped", flush=True)
     time_reference()
     print("timings dumped")

@@ -376,3 +376,61 @@ def test_trac_ik_multi_start():
     T = jaco.forward_kinematics(q)
     th, ok, t = jaco.trac_ik(T, theta0=q + 0.02, timeout=3.0)
     assert th.shape == (n,) and ok and np.abs(jaco.forward_kinematics(th) - T).max() < 2e-4
+
+
+def _gain_sweep_cases():
+    z = np.load(golden_path("gain_sweep_ur5.npz"))
+    return z, [(t, z[f"{t}_theta"], z[f"{t}_des"], float(z[f"{t}_dt"]), int(z[f"{t}_steps"])) for t in "abc"]
+
+
+def check_gain_sweep(controller):
+    """find_ultimate_gain_and_period against the reference's own runs (tests/golden/gain_sweep_ur5.npz: 6, 24 and 1 gains
+    visited): the same ultimate gain / period, the same gains, every run's error history (the reference's Coriolis term is a
+    finite difference of mass matrices: 1e-7 of the history's scale is its noise over <= 40 steps)."""
+    z, cases = _gain_sweep_cases()
+    for tag, th, des, dt, steps in cases:
+        th_in = th.copy()
+        Ku, Tu, gains, errs = controller.find_ultimate_gain_and_period(th_in, des, dt, steps)
+        assert isinstance(Ku, float) and isinstance(Tu, float) and isinstance(gains, list) and isinstance(errs, list)
+        np.testing.assert_array_equal(th_in, th)                                   # the caller's state is not advanced
+        assert Ku == pytest.approx(float(z[f"{tag}_Ku"]), rel=1e-12) and Tu == pytest.approx(float(z[f"{tag}_Tu"]), rel=1e-12)
+        np.testing.assert_allclose(gains, z[f"{tag}_gains"], rtol=1e-12)
+        want = z[f"{tag}_errors"]
+        assert len(errs) == len(want)
+        np.testing.assert_allclose(np.stack(errs), want, rtol=0, atol=1e-7 * np.abs(want).max())
+
+
+def test_gain_sweep_on_the_cpu_launcher():
+    sm, dyn, lim = mp.load_robot("ur5")
+    check_gain_sweep(mp.ManipulatorController(dyn))
+    from manipulapy_amd import _hip
+
+    # the launcher itself: per-run gains / targets, a damped run, the blow-up stop, zero steps, bad shapes
+    model = dyn.hip_model()
+    th0 = np.tile(np.full(6, 0.1), (4, 1)); des = np.tile(np.full(6, 0.5), (4, 1))
+    err, cnt = _hip.cpu_pd_regulation(model, th0, des, [5.0, 5.0, 7.0, 0.0], [0.0, 1e-3, 0.0, 0.0], None, 0.01, 60)
+    assert err.shape == (4, 60) and cnt.tolist()[:2] == [60, 60] and cnt[3] == 60
+    assert np.isfinite(err[:2, :10]).all() and not np.array_equal(err[0, :10], err[1, :10])   # the derivative gain acts
+    # a gain that diverges slowly enough to pass 1e10 after step 10: the run stops there, the rest keeps the NaN fill
+    assert 11 < cnt[2] < 60 and np.isnan(err[2, cnt[2]:]).all() and err[2, cnt[2] - 1] > 1e10 and np.isfinite(err[2, :cnt[2]]).all()
+    e0, c0 = _hip.cpu_pd_regulation(model, th0, des, np.ones(4), np.zeros(4), [0, 0, -9.81], 0.01, 0)
+    assert e0.shape == (4, 0) and (c0 == 0).all()
+    with pytest.raises(ValueError):
+        _hip.cpu_pd_regulation(model, th0[:, :5], des, np.ones(4), np.zeros(4), None, 0.01, 5)
+    # one thread == all threads, and a 9-joint arm runs (run-time-n body)
+    a = _hip.cpu_pd_regulation(model, th0, des, [1, 2, 3, 4], np.zeros(4), None, 0.01, 30, nthreads=1)
+    b = _hip.cpu_pd_regulation(model, th0, des, [1, 2, 3, 4], np.zeros(4), None, 0.01, 30, nthreads=4)
+    np.testing.assert_array_equal(a[0], b[0])
+    zj, proc = _jaco("jaco_6dof")
+    th = zj["jaco_6dof__theta"]
+    Ku, Tu, gains, errs = mp.ManipulatorController(proc.dynamics).find_ultimate_gain_and_period(th, th + 0.05, 0.002, 20)
+    assert Ku > 0 and Tu > 0 and len(gains) == len(errs) >= 1 and all(np.isfinite(e).all() for e in errs)
+    # its first run = stepping forward_dynamics by hand
+    q, w = th.copy(), np.zeros_like(th)
+    for step in range(3):
+        al = proc.dynamics.forward_dynamics(q, w, gains[0] * (th + 0.05 - q), [0, 0, -9.81], np.zeros(6))
+        w = w + al * 0.002; q = q + w * 0.002
+        assert errs[0][step] == pytest.approx(np.linalg.norm(q - th - 0.05), rel=1e-9)
+    legacy = _legacy_objects()[1]["A"]
+    with pytest.raises(NotImplementedError):
+        mp.ManipulatorController(legacy).find_ultimate_gain_and_period(np.zeros(6), np.ones(6) * 0.1, 0.01, 3)
