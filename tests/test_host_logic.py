@@ -525,9 +525,10 @@ def test_kernel_registry_semantics():
     for v in ("auto", "auto_tune", "standard", "vectorized", "memory_optimized", "warp_optimized", "cache_friendly"):
         assert f"trajectory.{v}" in names
     for n in ("trajectory.batch", "dynamics.inverse_trajectory", "dynamics.fused_trajectory_inverse", "kinematics.fk_jacobian",
-              "dynamics.mass_matrix", "dynamics.forward", "dynamics.forward_trajectory", "trajectory.cartesian", "kinematics.inverse"):
+              "dynamics.mass_matrix", "dynamics.forward", "dynamics.forward_trajectory", "trajectory.cartesian", "kinematics.inverse",
+              "control.pd_regulation"):
         assert n in names
-    with pytest.raises(KeyError, match="Available kernels: dynamics.forward, dynamics.forward_trajectory"):
+    with pytest.raises(KeyError, match="Available kernels: control.pd_regulation, dynamics.forward, dynamics.forward_trajectory"):
         mp.get_registered_kernel("trajectory.nope")
     entry = mp.get_registered_kernel("trajectory.standard")
     with pytest.raises(ValueError, match="already registered"):
