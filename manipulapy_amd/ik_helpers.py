@@ -14,7 +14,7 @@ import numpy as np
 Limits = Sequence[Tuple[Optional[float], Optional[float]]]
 
 __all__ = ["workspace_heuristic_guess", "random_in_limits", "midpoint_of_limits", "clip_to_limits", "extrapolate_from_current",
-           "IKInitialGuessCache", "se3_log_vector"]
+           "IKInitialGuessCache", "se3_log_vector", "adaptive_multi_start_ik"]
 
 
 def clip_to_limits(theta: np.ndarray, joint_limits: Limits) -> np.ndarray:
@@ -128,3 +128,35 @@ class IKInitialGuessCache:
     def _pose_distance(T1, T2) -> float:
         return float(np.linalg.norm(T1[:3, 3] - T2[:3, 3]) + 0.1 * np.linalg.norm(T1[:3, :3] - T2[:3, :3], "fro"))
 
+
+
+# (strategy, damping, step cap) ladder of the reference's adaptive multi-start (kinematics/ik_helpers.py:505-520)
+_ADAPTIVE_LADDER = (("workspace_heuristic", 0.02, 0.3), ("midpoint", 0.03, 0.3), ("random", 0.02, 0.3), ("random", 0.03, 0.25),
+                    ("random", 0.015, 0.35), ("random", 0.01, 0.4), ("random", 0.04, 0.2), ("workspace_heuristic", 0.01, 0.4),
+                    ("random", 0.05, 0.15), ("midpoint", 0.01, 0.5))
+
+
+def adaptive_multi_start_ik(ik_solver_func, T_desired, max_attempts: int = 10, eomg: float = 2e-3, ev: float = 2e-3,
+                            max_iterations: int = 1500, verbose: bool = False):
+    """Up to ten attempts of `ik_solver_func` (a robot's smart_inverse_kinematics) with the reference's ladder of initial-guess
+    strategies and damping / step-cap pairs, first success wins (reference kinematics/ik_helpers.py:449-577): returns
+    (theta, success, total iterations, winning strategy or "none (failed)"); on failure theta is the LAST attempt's, as in the
+    reference; an attempt that raises is skipped.  For many targets at once see SerialManipulator.batch_robust_inverse_kinematics."""
+    last, total = None, 0
+    for attempt, (strategy, damping, step_cap) in enumerate(_ADAPTIVE_LADDER[:max_attempts]):
+        if verbose:
+            print(f"Attempt {attempt + 1}/{max_attempts}: strategy={strategy}, damping={damping}, step_cap={step_cap}")
+        try:
+            theta, ok, iters = ik_solver_func(T_desired, strategy=strategy, eomg=eomg, ev=ev, max_iterations=max_iterations,
+                                              damping=damping, step_cap=step_cap)
+        except Exception as exc:   # the reference skips a failing attempt
+            if verbose:
+                print(f"  exception: {exc}")
+            continue
+        total += iters
+        if ok:
+            return theta, True, total, strategy
+        last = theta
+    if last is None:
+        last = midpoint_of_limits([])
+    return last, False, total, "none (failed)"

@@ -92,6 +92,18 @@ class _Joint:
             T[:3, 3] = self.axis * q
         return self.origin @ T
 
+    def child_poses(self, q: np.ndarray) -> np.ndarray:
+        """child_pose for a vector of joint values: (N,) -> (N,4,4)."""
+        q = np.asarray(q, dtype=np.float64)
+        T = np.tile(np.eye(4), (q.shape[0], 1, 1))
+        if self.kind in ("revolute", "continuous"):
+            x, y, z = self.axis
+            K = np.array([[0, -z, y], [z, 0, -x], [-y, x, 0]])
+            T[:, :3, :3] = np.eye(3) + np.sin(q)[:, None, None] * K + (1 - np.cos(q))[:, None, None] * (K @ K)
+        elif self.kind == "prismatic":
+            T[:, :3, 3] = np.outer(q, self.axis)
+        return self.origin @ T
+
 
 def _parse(path: str) -> Tuple[Dict[str, _Link], List[_Joint]]:
     try:
@@ -220,7 +232,8 @@ def extract_tables(path: str, tip_link: Optional[str] = None) -> Dict[str, objec
         limits[i] = j.limit if j.limit is not None else (-np.pi, np.pi)
     B = _adjoint(np.linalg.inv(M)) @ S
     return {"M": M, "S_list": S, "B_list": B, "G_list": G, "Mlist_per_link": Mcom, "joint_limits": limits, "omega_list": om,
-            "r_list": rl, "joint_names": [j.name for j in actuated], "ee_name": ee}
+            "r_list": rl, "joint_names": [j.name for j in actuated], "ee_name": ee,
+            "_tree": {"links": links, "joints": joints, "chain": chain, "roots": roots, "actuated": actuated}}
 
 
 class URDFToSerialManipulator:
@@ -248,3 +261,234 @@ class URDFToSerialManipulator:
                                             S_list=d["Slist"], B_list=d["Blist"], Glist=d["Glist"],
                                             Mlist_per_link=d["Mlist_per_link"])
         self.manipulator_dynamics = self.dynamics
+        self._tree = t["_tree"]
+        self._cfg: Dict[str, float] = {}   # the "current configuration" link_fk(None) / get_transform(cfg=None) use
+
+    # ---- convenience surface of the reference's processor (urdf_processor.py:140-168, :363-617); the tree walks are the
+    #      reference's urdf/core.py:498-667 (update_cfg / link_fk / link_fk_batch / get_transform) on this module's parse
+    @staticmethod
+    def transform_to_xyz(T) -> np.ndarray:
+        return np.array(np.asarray(T)[0:3, 3])
+
+    @staticmethod
+    def w_p_to_slist(w, p, robot_dof: int) -> np.ndarray:
+        """Rows w_i, p_i -> (6, robot_dof) screw axes [w; -w x p]."""
+        w, p = np.asarray(w, dtype=np.float64), np.asarray(p, dtype=np.float64)
+        return np.transpose([np.concatenate([w[i], np.cross(-w[i], p[i])]) for i in range(robot_dof)])
+
+    def get_link(self, robot=None, link_name: Optional[str] = None):
+        """The parsed link record by name, None if absent.  (The reference's is a static (robot, link_name) helper; both call
+        shapes are accepted: get_link(name) and get_link(processor, name).)"""
+        name = link_name if link_name is not None else robot
+        return self._tree["links"].get(name)
+
+    @property
+    def num_dofs(self) -> int:
+        return len(self._tree["actuated"])
+
+    @property
+    def joint_names(self) -> List[str]:
+        return [j.name for j in self._tree["actuated"]]
+
+    @property
+    def link_names(self) -> List[str]:
+        return list(self._tree["links"])
+
+    @property
+    def end_effector_name(self) -> str:
+        return self.tables["ee_name"]
+
+    @property
+    def joint_limits_array(self) -> np.ndarray:
+        return np.array(self.tables["joint_limits"], dtype=np.float64)
+
+    def print_joint_info(self) -> Dict[str, object]:
+        names = [j.name for j in self._tree["joints"]]
+        return {"num_joints": len(names), "joint_names": names}
+
+    def load_urdf(self, urdf_name: str) -> Dict[str, object]:
+        import warnings
+
+        warnings.warn("load_urdf() is deprecated. Use _extract_robot_data() instead.", DeprecationWarning, stacklevel=2)
+        return self.robot_data
+
+    def initialize_serial_manipulator(self):
+        return self.serial_manipulator
+
+    def initialize_manipulator_dynamics(self):
+        return self.dynamics
+
+    def get_serial_manipulator(self):
+        """A fresh SerialManipulator from the tables (reference urdf/core.py:771-795)."""
+        from .kinematics import SerialManipulator
+
+        d = self.robot_data
+        return SerialManipulator(M_list=d["M"], omega_list=d["omega_list"], S_list=d["Slist"], B_list=d["Blist"], G_list=d["Glist"],
+                                 joint_limits=d["joint_limits"])
+
+    def get_manipulator_dynamics(self):
+        """The reference's URDF.to_manipulator_dynamics() (urdf/core.py:797-817) passes no Mlist_per_link: the LEGACY object."""
+        from .dynamics import ManipulatorDynamics
+
+        d = self.robot_data
+        return ManipulatorDynamics(M_list=d["M"], omega_list=d["omega_list"], r_list=self.tables["r_list"], b_list=None,
+                                   S_list=d["Slist"], B_list=d["Blist"], Glist=d["Glist"])
+
+    def forward_kinematics(self, cfg, frame: str = "space") -> np.ndarray:
+        return self.serial_manipulator.forward_kinematics(cfg, frame=frame)
+
+    def jacobian(self, cfg, frame: str = "space") -> np.ndarray:
+        return self.serial_manipulator.jacobian(cfg, frame=frame)
+
+    def inverse_kinematics(self, T_desired, initial_guess=None, method: str = "robust", **kwargs):
+        """(theta, success, iterations) by "robust" (default), "smart" or "iterative" inverse kinematics."""
+        if initial_guess is None:
+            initial_guess = np.zeros(self.num_dofs)
+        if method == "robust":
+            theta, ok, iters, _ = self.serial_manipulator.robust_inverse_kinematics(T_desired, **kwargs)
+            return theta, ok, iters
+        if method == "smart":
+            return self.serial_manipulator.smart_inverse_kinematics(T_desired, **kwargs)
+        return self.serial_manipulator.iterative_inverse_kinematics(T_desired, initial_guess, **kwargs)
+
+    def _update_cfg(self, cfg) -> None:
+        if cfg is None:
+            return
+        if isinstance(cfg, dict):
+            self._cfg.update({k: float(v) for k, v in cfg.items()})
+            return
+        arr = np.asarray(cfg, dtype=np.float64).flatten()
+        if len(arr) != self.num_dofs:
+            raise ValueError(f"Configuration length {len(arr)} != num_actuated_joints {self.num_dofs}")
+        for j, v in zip(self._tree["actuated"], arr):
+            self._cfg[j.name] = float(v)
+
+    def _joint_value(self, j: _Joint) -> float:
+        if j.mimic is not None:
+            return self._cfg.get(j.mimic[0], 0.0) * j.mimic[1] + j.mimic[2]
+        return self._cfg.get(j.name, 0.0)
+
+    def link_fk(self, cfg=None, use_names: bool = True) -> Dict[str, np.ndarray]:
+        """Pose of EVERY link in the world frame at `cfg` (array in actuated-joint order, {joint name: value}, or None for the
+        configuration of the last call, which persists like the reference's).  Mimic joints follow their master."""
+        del use_names
+        self._update_cfg(cfg)
+        out = {r: np.eye(4) for r in self._tree["roots"]}
+        for j in self._tree["chain"]:
+            out[j.child] = out.get(j.parent, np.eye(4)) @ j.child_pose(self._joint_value(j))
+        return out
+
+    def batch_forward_kinematics(self, cfgs, link_name: Optional[str] = None):
+        """All-link forward kinematics for N configurations: {link: (N,4,4)}, or the (N,4,4) of `link_name`.  For the end
+        effector of a plain serial chain this is the batched kinematics launch (kinematics.fk_jacobian); other links - and
+        trees whose screw model differs from the tree walk: actuated joints off the tip's path (branches; the product of
+        exponentials moves the tip with them, the tree does not) or mimic joints (the screw model holds them still) - walk
+        the tree vectorised, like the reference's link_fk_batch."""
+        cfgs = np.asarray(cfgs, dtype=np.float64)
+        if cfgs.ndim == 1:
+            cfgs = cfgs.reshape(1, -1)
+        if cfgs.shape[1] != self.num_dofs:
+            raise ValueError(f"Configuration columns {cfgs.shape[1]} != num_actuated_joints {self.num_dofs}")
+        known = set(self._tree["roots"]) | {j.child for j in self._tree["chain"]}
+        if link_name is not None and link_name not in known:
+            raise ValueError(f"Unknown link: {link_name}. Available: {sorted(known)}")
+        if link_name is not None and link_name == self.end_effector_name and self._serial_to_tip():
+            return self.serial_manipulator.forward_kinematics(cfgs)
+        n = cfgs.shape[0]
+        col = {j.name: i for i, j in enumerate(self._tree["actuated"])}
+        out = {r: np.tile(np.eye(4), (n, 1, 1)) for r in self._tree["roots"]}
+        for j in self._tree["chain"]:
+            if j.mimic is not None:
+                q = cfgs[:, col.get(j.mimic[0], 0)] * j.mimic[1] + j.mimic[2]
+            elif j.name in col:
+                q = cfgs[:, col[j.name]]
+            else:
+                q = np.zeros(n)
+            parent = out.get(j.parent)
+            out[j.child] = np.matmul(parent if parent is not None else np.tile(np.eye(4), (n, 1, 1)), j.child_poses(q))
+        return out[link_name] if link_name is not None else out
+
+    def _serial_to_tip(self) -> bool:
+        """True when the screw model and the tree agree on the tip: every actuated joint lies on the root -> tip path and no
+        joint of the tree is a mimic joint."""
+        by_child = {j.child: j for j in self._tree["chain"]}
+        path, cur = set(), self.end_effector_name
+        while cur in by_child:
+            path.add(by_child[cur].name)
+            cur = by_child[cur].parent
+        return all(j.name in path for j in self._tree["actuated"]) and not any(j.mimic for j in self._tree["chain"])
+
+    def get_end_effector_transforms(self, cfgs) -> np.ndarray:
+        return self.batch_forward_kinematics(cfgs, link_name=self.end_effector_name)
+
+    def get_transform(self, frame_to: str, frame_from: str = "world", cfg=None) -> np.ndarray:
+        """Pose of link `frame_to` expressed in `frame_from` ("world" or a link name)."""
+        fk = self.link_fk(cfg)
+        if frame_to not in fk:
+            raise ValueError(f"Unknown frame: {frame_to}")
+        if frame_from == "world":
+            return fk[frame_to]
+        if frame_from not in fk:
+            raise ValueError(f"Unknown frame: {frame_from}")
+        return np.linalg.inv(fk[frame_from]) @ fk[frame_to]
+
+    def validate(self) -> Dict[str, object]:
+        """{"valid": bool, "issues": [{"severity", "message"}]}: the structural checks of the reference's validator
+        (urdf/validation.py:119-326: missing links, several parents, no / several roots, disconnected links, cycles, zero
+        axes, missing or empty limits, empty mimic references) on this module's parse; ERRORs make it invalid."""
+        links, joints = self._tree["links"], self._tree["joints"]
+        issues: List[Dict[str, str]] = []
+        add = lambda sev, msg: issues.append({"severity": sev, "message": msg})  # noqa: E731
+        if not links:
+            return {"valid": False, "issues": [{"severity": "ERROR", "message": "URDF has no links"}]}
+        parent_of: Dict[str, str] = {}
+        kids: Dict[str, List[str]] = {}
+        for j in joints:
+            if j.parent not in links:
+                add("ERROR", f"Parent link '{j.parent}' not found")
+            if j.child not in links:
+                add("ERROR", f"Child link '{j.child}' not found")
+            if j.child in parent_of:
+                add("ERROR", f"Link '{j.child}' has multiple parents: '{parent_of[j.child]}' and '{j.parent}'")
+            else:
+                parent_of[j.child] = j.parent
+            kids.setdefault(j.parent, []).append(j.child)
+        roots = [name for name in links if name not in parent_of]
+        if not roots:
+            add("ERROR", "No root link found - possible cycle in kinematic tree")
+        elif len(roots) > 1:
+            add("WARNING", f"Multiple root links found: {roots}. Only the first will be used for kinematics.")
+        if roots:
+            reach, stack = set(), [roots[0]]
+            while stack:
+                cur = stack.pop()
+                if cur not in reach:
+                    reach.add(cur)
+                    stack.extend(kids.get(cur, []))
+            lost = set(links) - reach
+            if lost:
+                add("WARNING", f"Disconnected links found: {sorted(lost)}")
+        for start in links:   # a link that reaches itself by walking up its parents
+            seen, cur = [start], parent_of.get(start)
+            while cur is not None and cur not in seen:
+                seen.append(cur)
+                cur = parent_of.get(cur)
+            if cur is not None:
+                cyc = seen[seen.index(cur):] + [cur]
+                add("ERROR", f"Cycle detected in kinematic tree: {' -> '.join(cyc)}")
+                break
+        for j in joints:
+            norm = float(np.linalg.norm(j.axis))
+            if abs(norm - 1.0) > 1e-6:
+                add("WARNING", f"Joint axis not normalized (norm={norm:.6f})")
+            if j.kind in ("revolute", "prismatic"):
+                if j.limit is None:
+                    add("WARNING", "Joint has no limits defined")
+                elif j.limit[0] >= j.limit[1]:
+                    add("WARNING", f"Joint limits invalid: lower ({j.limit[0]}) >= upper ({j.limit[1]})")
+            if j.mimic is not None and not j.mimic[0]:
+                add("ERROR", "Mimic joint reference is empty")
+        return {"valid": not any(i["severity"] == "ERROR" for i in issues), "issues": issues}
+
+    def __repr__(self) -> str:
+        return f"URDFToSerialManipulator(urdf='{self.urdf_name}', dofs={self.num_dofs}, backend='builtin')"

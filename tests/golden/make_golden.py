@@ -22,6 +22,7 @@ What it does:
       cartesian_ur5.npz    : cartesian_trajectory dumps (`make_golden.py cartesian` regenerates only this)
       ik.npz               : iterative_inverse_kinematics dumps, 10 problems per robot (`make_golden.py ik`)
       control_ur5.npz      : ManipulatorController laws on UR5 (`make_golden.py control`)
+      urdf_api.npz         : URDFToSerialManipulator's convenience surface on ten urdf_suite files (`make_golden.py urdf_api`)
       gain_sweep_ur5.npz   : ManipulatorController.find_ultimate_gain_and_period on UR5 (`make_golden.py gain_sweep`)
       utils.npz            : every public ManipulaPy.utils function on generic and branch-switching inputs (`make_golden.py utils`)
       (manipulapy_amd/data/) model_<robot>.npz, urdf/<robot>.urdf : the four benchmark robots' tables and URDF skeletons
@@ -454,6 +455,44 @@ def dump_control():
     np.savez(os.path.join(HERE, "control_ur5.npz"), **d)
 
 
+def dump_urdf_api():
+    """The convenience surface of URDFToSerialManipulator (urdf_processor.py:363-617) on a few of the urdf_suite skeletons
+    (the SAME files the build reads): link / joint names, all-link forward kinematics at one configuration and for a batch,
+    transforms between links, the validation report."""
+    d = {}
+    names = ["ur5", "panda", "xarm6_gripper", "robotiq_2f_85", "jaco_6dof", "fixture_branched", "fixture_mimic_joints", "fixture_multi_root",
+             "fixture_prismatic_joint", "fixture_continuous_joints"]
+    rng = np.random.default_rng(SEED + 900)
+    for name in names:
+        proc = URDFToSerialManipulator(os.path.join(HERE, "urdf_suite", f"{name}.urdf"), load_meshes=False)
+        n = proc.num_dofs
+        info = proc.print_joint_info()
+        d[f"{name}__num_dofs"] = np.array(n); d[f"{name}__joint_names"] = np.array(proc.joint_names)
+        d[f"{name}__link_names"] = np.array(proc.link_names); d[f"{name}__ee"] = np.array(proc.end_effector_name)
+        d[f"{name}__all_joint_names"] = np.array(info["joint_names"]); d[f"{name}__limits"] = np.asarray(proc.joint_limits_array, dtype=np.float64)
+        cfg = rng.uniform(-1.0, 1.0, n)
+        cfgs = rng.uniform(-1.0, 1.0, (4, n))
+        fk = proc.link_fk(cfg)
+        order = list(fk.keys())
+        d[f"{name}__cfg"], d[f"{name}__cfgs"] = cfg, cfgs
+        d[f"{name}__fk_links"] = np.array(order); d[f"{name}__fk"] = np.stack([np.asarray(fk[k]) for k in order])
+        fkb = proc.batch_forward_kinematics(cfgs)
+        d[f"{name}__fkb"] = np.stack([np.asarray(fkb[k]) for k in order])
+        d[f"{name}__ee_batch"] = np.asarray(proc.get_end_effector_transforms(cfgs))
+        a, b = order[-1], order[len(order) // 2]
+        d[f"{name}__tf_pair"] = np.array([a, b])
+        d[f"{name}__tf"] = np.asarray(proc.get_transform(a, b, cfg)); d[f"{name}__tf_world"] = np.asarray(proc.get_transform(a, "world", cfg))
+        d[f"{name}__fk_current"] = np.stack([np.asarray(v) for v in proc.link_fk(None).values()])   # the configuration persists
+        v = proc.validate()
+        d[f"{name}__valid"] = np.array(bool(v["valid"]))
+        d[f"{name}__issues"] = np.array([f"{i['severity']}|{i['message']}" for i in v["issues"]] or ["<none>"])
+        d[f"{name}__fk_ee"] = np.asarray(proc.forward_kinematics(cfg)); d[f"{name}__jac"] = np.asarray(proc.jacobian(cfg))
+        print(name, n, len(order), bool(v["valid"]), len(v["issues"]), flush=True)
+    d["w_p_in_w"], d["w_p_in_p"] = rng.uniform(-1, 1, (4, 3)), rng.uniform(-1, 1, (4, 3))
+    d["w_p_out"] = np.asarray(URDFToSerialManipulator.w_p_to_slist(d["w_p_in_w"], d["w_p_in_p"], 4))
+    np.savez(os.path.join(HERE, "urdf_api.npz"), **d)
+
+
 def dump_gain_sweep():
     """ManipulatorController.find_ultimate_gain_and_period (control/metrics.py:280-366) on UR5: the closed-loop P-control
     simulations of the gain ladder 0.01 * 1.1^k - ultimate gain / period, the gains visited and every run's error history."""
@@ -856,7 +895,7 @@ def main():
         dump_ik()
         print("ik dumped")
         return
-    for name, fn in (("gain_sweep", dump_gain_sweep), ("rollout100", dump_rollout100), ("nonfinite", dump_nonfinite), ("field", dump_field), ("urdf_suite", dump_urdf_suite),
+    for name, fn in (("urdf_api", dump_urdf_api), ("gain_sweep", dump_gain_sweep), ("rollout100", dump_rollout100), ("nonfinite", dump_nonfinite), ("field", dump_field), ("urdf_suite", dump_urdf_suite),
                      ("legacy", dump_legacy)):
         if name in sys.argv[1:]:
             fn()
@@ -883,6 +922,7 @@ def main():
     dump_urdf_suite()
     dump_legacy()
     dump_gain_sweep()
+    dump_urdf_api()
     print("trajectories dumped", flush=True)
     time_reference()
     print("timings dumped")

@@ -2043,3 +2043,13 @@ def test_gain_sweep_is_one_launch_and_matches_the_reference(tables, monkeypatch)
         assert e0.shape == (3, 0) and (c0 == 0).all()
     finally:
         ctx.destroy()
+
+
+def test_urdf_processor_surface_under_the_hip_backend():
+    """The processor's convenience surface (tests/golden/urdf_api.npz) with the tip batches of plain serial chains routed to the
+    kinematics kernel."""
+    import manipulapy_amd as mp
+    from test_round3_host import check_urdf_processor_surface
+
+    with mp.use_backend("hip"):
+        check_urdf_processor_surface()

@@ -434,3 +434,113 @@ def test_gain_sweep_on_the_cpu_launcher():
     legacy = _legacy_objects()[1]["A"]
     with pytest.raises(NotImplementedError):
         mp.ManipulatorController(legacy).find_ultimate_gain_and_period(np.zeros(6), np.ones(6) * 0.1, 0.01, 3)
+
+
+def check_urdf_processor_surface():
+    """URDFToSerialManipulator's convenience surface against the reference on ten of the urdf_suite files
+    (tests/golden/urdf_api.npz): names, all-link forward kinematics (one configuration, a batch, the persisting current
+    configuration), transforms between links, end-effector batches, the validation report."""
+    import os
+
+    z = np.load(golden_path("urdf_api.npz"))
+    names = sorted({k.split("__")[0] for k in z.files if "__" in k})
+    assert len(names) == 10
+    kernel_routed = 0
+    for name in names:
+        proc = mp.URDFToSerialManipulator(golden_path(os.path.join("urdf_suite", f"{name}.urdf")), tip_link=str(z[f"{name}__ee"]))
+        ref_joints = [str(x) for x in z[f"{name}__joint_names"]]
+        assert proc.num_dofs == int(z[f"{name}__num_dofs"]) and proc.end_effector_name == str(z[f"{name}__ee"])
+        # (several roots: the reference orders them by a hash-seeded set, this reader by the file - same joints, other order)
+        assert sorted(proc.joint_names) == sorted(ref_joints) and (proc.joint_names == ref_joints or name == "fixture_multi_root")
+        assert proc.link_names == [str(x) for x in z[f"{name}__link_names"]]
+        assert proc.print_joint_info() == {"num_joints": len(z[f"{name}__all_joint_names"]), "joint_names": [str(x) for x in z[f"{name}__all_joint_names"]]}
+        perm = [ref_joints.index(j) for j in proc.joint_names]          # reference column of each of this reader's joints
+        np.testing.assert_allclose(proc.joint_limits_array, z[f"{name}__limits"][perm], atol=0)
+        cfg, cfgs = z[f"{name}__cfg"][perm], z[f"{name}__cfgs"][:, perm]
+        links = [str(x) for x in z[f"{name}__fk_links"]]
+        fk = proc.link_fk(cfg)
+        assert sorted(fk) == sorted(links)
+        for k, T in zip(links, z[f"{name}__fk"]):
+            np.testing.assert_allclose(fk[k], T, atol=1e-12, err_msg=f"{name} {k}")
+        again = proc.link_fk(None)                                         # the configuration persists
+        for k, T in zip(links, z[f"{name}__fk_current"]):
+            np.testing.assert_allclose(again[k], T, atol=1e-12)
+        by_name = proc.link_fk({j: float(v) for j, v in zip(proc.joint_names, cfg)})
+        np.testing.assert_array_equal(by_name[links[-1]], fk[links[-1]])
+        fkb = proc.batch_forward_kinematics(cfgs)
+        for k, T in zip(links, z[f"{name}__fkb"]):
+            np.testing.assert_allclose(fkb[k], T, atol=1e-12)
+        np.testing.assert_allclose(proc.get_end_effector_transforms(cfgs), z[f"{name}__ee_batch"], atol=1e-12)
+        np.testing.assert_allclose(proc.batch_forward_kinematics(cfgs, links[2 % len(links)]), z[f"{name}__fkb"][2 % len(links)], atol=1e-12)
+        kernel_routed += proc._serial_to_tip()
+        a, b = (str(x) for x in z[f"{name}__tf_pair"])
+        np.testing.assert_allclose(proc.get_transform(a, b, cfg), z[f"{name}__tf"], atol=1e-12)
+        np.testing.assert_allclose(proc.get_transform(a, "world"), z[f"{name}__tf_world"], atol=1e-12)
+        if name != "fixture_multi_root":                                   # (the screw model's column order follows the joint order)
+            np.testing.assert_allclose(proc.forward_kinematics(cfg), z[f"{name}__fk_ee"], atol=1e-12)
+            np.testing.assert_allclose(proc.jacobian(cfg), z[f"{name}__jac"], atol=1e-12)
+        v = proc.validate()
+        assert v["valid"] == bool(z[f"{name}__valid"])
+        assert ([f"{i['severity']}|{i['message']}" for i in v["issues"]] or ["<none>"]) == [str(x) for x in z[f"{name}__issues"]]
+        with pytest.raises(ValueError):
+            proc.get_transform("no_such_link")
+        with pytest.raises(ValueError):
+            proc.batch_forward_kinematics(cfgs[:, :-1] if proc.num_dofs > 1 else np.zeros((2, 5)))
+        with pytest.raises(ValueError):
+            proc.batch_forward_kinematics(cfgs, "no_such_link")
+        assert repr(proc).startswith("URDFToSerialManipulator(urdf=") and proc.get_link("no_such_link") is None
+        assert proc.get_link(links[0]).name == links[0] and proc.get_link(proc, links[0]).name == links[0]
+        np.testing.assert_array_equal(proc.transform_to_xyz(fk[links[-1]]), fk[links[-1]][:3, 3])
+    assert kernel_routed >= 2          # ur5 and the prismatic chain are plain serial chains: their tip batches are kernel launches
+    np.testing.assert_allclose(mp.URDFToSerialManipulator.w_p_to_slist(z["w_p_in_w"], z["w_p_in_p"], 4), z["w_p_out"], atol=1e-15)
+
+
+def test_urdf_processor_surface_on_the_cpu_launchers():
+    check_urdf_processor_surface()
+    import os
+
+    proc = mp.URDFToSerialManipulator(golden_path(os.path.join("urdf_suite", "ur5.urdf")), tip_link="tool0")
+    with pytest.warns(DeprecationWarning):
+        assert proc.load_urdf("ignored") is proc.robot_data
+    assert proc.initialize_serial_manipulator() is proc.serial_manipulator and proc.initialize_manipulator_dynamics() is proc.dynamics
+    sm2, dyn2 = proc.get_serial_manipulator(), proc.get_manipulator_dynamics()
+    q = np.array([0.1, -0.7, 0.5, 0.2, -0.3, 0.4])
+    np.testing.assert_allclose(sm2.forward_kinematics(q), proc.forward_kinematics(q), atol=1e-14)
+    assert dyn2.Mlist_per_link is None                                      # the reference's to_manipulator_dynamics(): the legacy object
+    with pytest.warns(UserWarning):
+        dyn2.mass_matrix(q)
+    T = proc.forward_kinematics(q)
+    for method, kw in (("iterative", dict(max_iterations=300)), ("smart", dict(max_iterations=300)), ("robust", dict(max_iterations=300, max_attempts=3))):
+        th, ok, it = proc.inverse_kinematics(T, initial_guess=q + 0.05, method=method, eomg=1e-5, ev=1e-5, **kw)
+        assert th.shape == (6,) and isinstance(it, (int, np.integer))
+        if ok:
+            assert np.abs(proc.forward_kinematics(th)[:3, 3] - T[:3, 3]).max() < 1e-4
+    broken = mp.URDFToSerialManipulator(golden_path(os.path.join("urdf_suite", "fixture_multi_root.urdf")))
+    assert broken.validate()["valid"] and len(broken.validate()["issues"]) == 2
+
+
+def test_adaptive_multi_start_ik_ladder():
+    """ik_helpers.adaptive_multi_start_ik: the ladder is walked in order with the reference's parameters, stops at the first
+    success, sums the iterations, skips raising attempts, reports "none (failed)" with the last attempt's configuration."""
+    calls = []
+
+    def solver(T, strategy, eomg, ev, max_iterations, damping, step_cap):
+        calls.append((strategy, damping, step_cap, eomg, ev, max_iterations))
+        if len(calls) == 2:
+            raise RuntimeError("skipped")
+        return np.full(3, float(len(calls))), len(calls) == 4, 10 * len(calls)
+
+    th, ok, total, name = mp.ik_helpers.adaptive_multi_start_ik(solver, np.eye(4))
+    assert ok and name == "random" and total == 10 + 30 + 40 and th[0] == 4.0
+    assert [c[:3] for c in calls] == [("workspace_heuristic", 0.02, 0.3), ("midpoint", 0.03, 0.3), ("random", 0.02, 0.3), ("random", 0.03, 0.25)]
+    assert calls[0][3:] == (2e-3, 2e-3, 1500)
+    calls.clear()
+    th, ok, total, name = mp.ik_helpers.adaptive_multi_start_ik(lambda *a, **k: (np.zeros(2), False, 7), np.eye(4), max_attempts=3)
+    assert not ok and name == "none (failed)" and total == 21
+    # on a real robot
+    sm = mp.load_robot("ur5")[0]
+    q = np.array([0.3, -1.0, 0.8, -0.4, 0.5, 0.2])
+    T = sm.forward_kinematics(q)
+    np.random.seed(3)
+    th, ok, total, name = mp.ik_helpers.adaptive_multi_start_ik(sm.smart_inverse_kinematics, T, max_attempts=6)
+    assert ok and np.abs(sm.forward_kinematics(th)[:3, 3] - T[:3, 3]).max() < 5e-3 and total > 0
