@@ -118,6 +118,32 @@ def main():
         for b in (dq, dT, d0, dth, dok, dit, drs):
             b.free()
         model.destroy()
+    # 9 / 10-joint arms (run-time-n kernels): inverse kinematics, and the controller's gain sweep (121 closed-loop runs, one launch)
+    import time as _time
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+    zj = np.load(os.path.join(gold, "urdf_suite.npz"))
+    proc = mp.URDFToSerialManipulator(os.path.join(gold, "urdf_suite", "jaco_7dof.urdf"), tip_link=str(zj["jaco_7dof__ee"]))
+    smj = proc.serial_manipulator
+    nj, Bj = len(smj.joint_limits), 1 << 16
+    thj = zj["jaco_7dof__theta"]
+    goal = mp.ik_helpers.clip_to_limits(thj + rng.uniform(-0.2, 0.2, (Bj, nj)), smj.joint_limits)
+    with mp.use_backend("hip"):
+        Tg = smj.forward_kinematics(goal)
+        smj.batch_inverse_kinematics(Tg[:256], np.tile(thj, (256, 1)), max_iterations=200)
+        t0 = _time.perf_counter()
+        sol, okj, itj = smj.batch_inverse_kinematics(Tg, np.tile(thj, (Bj, 1)), max_iterations=200)
+        ms = (_time.perf_counter() - t0) * 1e3
+        out.append(dict(op="inverse_kinematics host call (10 joints, k_dyn_ik)", robot="jaco_7dof", dtype="float64", problems=Bj, ms=ms,
+                        problems_per_s=Bj / ms * 1e3, success_rate=float(okj.mean()), mean_iterations=float(itj.mean())))
+        smu, dynu, limu = mp.load_robot("ur5")
+        ctl = mp.ManipulatorController(dynu)
+        ctl.find_ultimate_gain_and_period(np.full(6, 0.1), np.full(6, 0.5), 0.01, 10)
+        for steps in (200, 1000):
+            t0 = _time.perf_counter()
+            Ku, Tu, gh, eh = ctl.find_ultimate_gain_and_period(np.full(6, 0.1), np.full(6, 0.5), 0.01, steps)
+            ms = (_time.perf_counter() - t0) * 1e3
+            out.append(dict(op="find_ultimate_gain_and_period (121 gains, one k_pd_regulation launch)", robot="ur5", dtype="float64", steps=steps,
+                            ms=ms, gains_visited=len(gh), Ku=Ku, closed_loop_steps_per_s=121 * steps / ms * 1e3))
     # host-buffer entry points (PCIe inclusive): what a drop-in caller holding NumPy arrays sees
     sm, dyn, lim = mp.load_robot("ur5")
     model = _hip.HipModel(dyn.S_list, dyn.Mlist_per_link, dyn.Glist, sm.M_list, lim)
