@@ -739,13 +739,13 @@ hipError_t mpk_ik(hipStream_t s, const MpModel<double>& M, const MpIkParams& P, 
 
 hipError_t mpk_pd_regulation(hipStream_t s, const MpModel<double>& M, const MpCall<double>& C, const double* theta0, const double* des,
                              const double* Kp, const double* Kd, long K, double dt, int steps, double* err, int* count) {
-  if (K <= 0 || steps <= 0) return hipSuccess;
+  if (K <= 0) return hipSuccess;  // (steps == 0 still launches: every run reports a count of 0)
   MP_DISPATCH_N(M.n, { hipLaunchKernelGGL((k_pd_regulation<N>), dim3((unsigned)((K + 63) / 64)), dim3(64), 0, s, M, C, theta0, des, Kp, Kd, K, dt, steps, err, count); })
   return hipGetLastError();
 }
 hipError_t mpk_dyn_pd_regulation(hipStream_t s, const MpBigModel<double>* d_model, const MpCall<double>& C, const double* theta0,
                                  const double* des, const double* Kp, const double* Kd, long K, double dt, int steps, double* err, int* count) {
-  if (K <= 0 || steps <= 0) return hipSuccess;
+  if (K <= 0) return hipSuccess;  // (steps == 0 still launches: every run reports a count of 0)
   hipLaunchKernelGGL(k_dyn_pd_regulation, dim3((unsigned)((K + 63) / 64)), dim3(64), 0, s, d_model, C, theta0, des, Kp, Kd, K, dt, steps, err, count);
   return hipGetLastError();
 }
