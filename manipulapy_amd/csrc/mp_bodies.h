@@ -204,12 +204,56 @@ __device__ __forceinline__ void mp_wave_store_flat(T* __restrict__ gbase, long r
   }
 }
 
-// rows that are whole lines go out per piece, everything else in flat order
+// Rows that are not even a whole number of 16-byte chunks (an odd element count: the 7 x 7 mass matrix is 49 values, 196 / 392
+// bytes): chunking per row would leave 4- / 8-byte stores (256 / 512 bytes per store instruction: 4.0 TB/s measured on the
+// iiwa14 mass matrix where the 6 x 6 one reaches 5.7).  16 rows always ARE a whole number of 16-byte chunks, so they are staged
+// back to back (unpadded: an odd dword pitch spreads the 16 staging lanes over distinct banks by itself) and streamed out as
+// 16-byte chunks that ignore the row boundaries; only the chunk that straddles the end of the valid rows is written by element.
+typedef unsigned mp_u4 __attribute__((ext_vector_type(4)));
+template <typename T, int COUNT>
+__device__ __forceinline__ void mp_wave_store_flat16(T* __restrict__ gbase, long row0, int lane, int nvalid, const T (&v)[COUNT],
+                                                     char* __restrict__ lds) {
+  constexpr int ROWS = 16, ROWB = COUNT * (int)sizeof(T), SPAN = ROWS * ROWB, NCH = SPAN / 16, NJ = (NCH + 63) / 64;
+  static_assert(SPAN % 16 == 0 && SPAN <= MP_WAVE_LDS_BYTES, "16 rows must be whole 16-byte chunks and fit the wave's staging slice");
+  char* gout = reinterpret_cast<char*>(gbase + row0 * COUNT);  // 64 rows per wave: a multiple of 16 bytes from a 16-byte-aligned base
+  const int valid_bytes = nvalid * ROWB;
+#pragma unroll
+  for (int pass = 0; pass < 64 / ROWS; ++pass) {
+    if ((lane >> 4) == pass) {
+      T* dst = reinterpret_cast<T*>(lds + (lane & (ROWS - 1)) * ROWB);
+#pragma unroll
+      for (int e = 0; e < COUNT; ++e) dst[e] = v[e];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int f = j * 64 + lane;  // flat 16-byte chunk inside this pass's 16 rows
+      if (f < NCH) {
+        const int gofs = pass * SPAN + f * 16;
+        if (gofs + 16 <= valid_bytes) {
+          *reinterpret_cast<mp_u4*>(gout + gofs) = *reinterpret_cast<const mp_u4*>(lds + f * 16);
+        } else if (gofs < valid_bytes) {  // the one chunk across the end of the valid rows (last wave only)
+#pragma unroll
+          for (int b = 0; b < 16; b += (int)sizeof(T))
+            if (gofs + b < valid_bytes) *reinterpret_cast<T*>(gout + gofs + b) = *reinterpret_cast<const T*>(lds + f * 16 + b);
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
+// rows that are whole lines go out per piece, rows of whole 16-byte chunks in flat chunk order, odd rows as flat 16-byte chunks
 template <typename T, int COUNT>
 __device__ __forceinline__ void mp_wave_store_auto(T* __restrict__ gbase, long row0, int lane, int nvalid, const T (&v)[COUNT],
                                                    char* __restrict__ lds) {
   if constexpr ((COUNT * (int)sizeof(T)) % 128 == 0) mp_wave_store<T, COUNT>(gbase, row0, lane, nvalid, v, lds);
-  else mp_wave_store_flat<T, COUNT>(gbase, row0, lane, nvalid, v, lds);
+  else if constexpr ((COUNT * (int)sizeof(T)) % 16 == 0) mp_wave_store_flat<T, COUNT>(gbase, row0, lane, nvalid, v, lds);
+  else mp_wave_store_flat16<T, COUNT>(gbase, row0, lane, nvalid, v, lds);
 }
 
 // T (4x4), space Jacobian (6xN) and tau for row `r`, any output optional: the body of k_fk_jac_id.
