@@ -2053,3 +2053,38 @@ def test_urdf_processor_surface_under_the_hip_backend():
 
     with mp.use_backend("hip"):
         check_urdf_processor_surface()
+
+
+def test_mass_matrix_store_paths_every_n_and_tail():
+    """The mass-matrix kernel's three row-store paths (whole 128-byte lines / whole 16-byte chunks / odd rows as 16-byte chunks across
+    the row boundaries, csrc/mp_bodies.h mp_wave_store_auto): every joint count 1..8, float32 and float64, row counts around the
+    16-row staging passes and the 64-row wave, against the CPU launcher; a guard band behind the output must stay untouched."""
+    from manipulapy_amd import _hip
+    from test_random_robots import FLAVOURS, random_robot
+
+    ctx = _hip.HipContext(0)
+    try:
+        rng = np.random.default_rng(77)
+        for n in range(1, 9):
+            tab = random_robot(rng, n, FLAVOURS[n % len(FLAVOURS)])
+            model = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee, tab.joint_limits)
+            for rows in (1, 15, 16, 17, 31, 33, 63, 64, 65, 130, 333):
+                q = rng.uniform(-2, 2, (rows, n))
+                want = _hip.cpu_mass_matrix(model, q)
+                for dtype, tol in ((np.float64, 1e-11), (np.float32, 3e-5)):
+                    item = np.dtype(dtype).itemsize
+                    nb = rows * n * n * item
+                    guard = 4096
+                    d_q = ctx.to_device(q.astype(dtype))
+                    d_M = ctx.alloc(nb + guard)
+                    ctx.memset(d_M, 0xA5, nb + guard)
+                    ctx.mass_matrix(model, d_q, rows, d_M, dtype=dtype)
+                    ctx.synchronize()
+                    raw = d_M.download((nb + guard,), np.uint8)
+                    assert (raw[nb:] == 0xA5).all(), (n, rows, dtype)              # nothing written past the last valid row
+                    got = raw[:nb].view(dtype).reshape(rows, n, n)
+                    np.testing.assert_allclose(got, want, rtol=tol, atol=tol * np.abs(want).max(), err_msg=f"n={n} rows={rows} {dtype}")
+                    d_q.free(); d_M.free()
+            model.destroy()
+    finally:
+        ctx.destroy()
