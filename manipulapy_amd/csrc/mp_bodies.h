@@ -16,6 +16,32 @@ template <> struct VecOf<float, 4> { using type = float; static constexpr int K 
 template <> struct VecOf<double, 16> { using type = mp_io_d2; static constexpr int K = 2; };
 template <> struct VecOf<double, 8> { using type = double; static constexpr int K = 1; };
 
+// Non-temporal global accesses for data a launch touches once.  They pay ONLY where one instruction covers whole lines (the
+// wave-cooperative movers below): on the c2 pattern - three 98 MB input streams, one output stream, rotating sets - plain
+// accesses reach 5.7 TB/s and non-temporal ones 6.4 (tools/ubench_nt.hip, 16 contiguous bytes per lane), but applied to the
+// per-lane 24-byte rows of RunIO, which touch every line with two or three instructions and rely on the caches to merge them,
+// they LOSE (c2 0.069 -> 0.085 ms, c3 3.8 -> 4.6 ms).  MP_STREAM_NT=0 (MANIPULAPY_HIP_JIT_DEFINES) gives the plain forms for an A/B.
+#if !defined(MP_STREAM_NT)
+#define MP_STREAM_NT 1
+#endif
+typedef unsigned mp_u4 __attribute__((ext_vector_type(4)));
+template <typename V>
+__device__ __forceinline__ V mp_stream_load(const V* p) {
+#if MP_STREAM_NT
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+template <typename V>
+__device__ __forceinline__ void mp_stream_store(V v, V* p) {
+#if MP_STREAM_NT
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+
 template <typename T, int COUNT>
 struct RunIO {
   static constexpr int BYTES = COUNT * (int)sizeof(T);
@@ -90,6 +116,83 @@ __device__ __forceinline__ void mp_body_id(const MT& M, const MpCall<T>& C, cons
   bad.add(a); bad.add(b); bad.add(c);
   mp_poison_if(bad.any(), t);
   RunIO<T, N>::store(tau, r, t);
+}
+
+// The same rows moved as WHOLE LINES with non-temporal accesses: a wave moves its 64 consecutive rows of every array as flat
+// 16-byte chunks (one contiguous 1.5 - 2 KB span per array), stages them in its LDS slice and each lane picks its row there;
+// tau leaves the same way.  c2 0.0688 -> 0.0662-0.0673 ms, c4 0.140 -> 0.131-0.137 (tools/ab_co.sh); with plain accesses the
+// same staging LOSES 3-4 % (0.071-0.072), as it did in round 1 - the gain is the non-temporal path, the staging is what
+// makes it applicable.  FULL waves only: `rows64` is a multiple of 64 (the host launches the per-lane kernel on the last
+// rows), `lds` is this wave's slice of MpRowStage<T, N>::BYTES bytes.
+template <typename T, int N>
+struct MpRowStage {
+  static constexpr int ROWB = N * (int)sizeof(T), SPAN = 64 * ROWB, NCH = SPAN / 16, NJ = (NCH + 63) / 64;
+  static constexpr int BYTES = 3 * SPAN;
+  static_assert(SPAN % 16 == 0, "64 rows are whole 16-byte chunks");
+  static __device__ __forceinline__ void fetch(const T* __restrict__ base, long row0, int lane, mp_u4 (&buf)[NJ]) {
+    const mp_u4* g = reinterpret_cast<const mp_u4*>(base + row0 * N);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+      if (j * 64 + lane < NCH) buf[j] = mp_stream_load(g + j * 64 + lane);
+  }
+  static __device__ __forceinline__ void stage(const mp_u4 (&buf)[NJ], int lane, char* __restrict__ region) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+      if (j * 64 + lane < NCH) *reinterpret_cast<mp_u4*>(region + (j * 64 + lane) * 16) = buf[j];
+  }
+  static __device__ __forceinline__ void row_in(const char* __restrict__ region, int lane, T (&v)[N]) {
+    const T* src = reinterpret_cast<const T*>(region + lane * ROWB);
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[j] = src[j];
+  }
+  static __device__ __forceinline__ void row_out(char* __restrict__ region, int lane, const T (&v)[N]) {
+    T* dst = reinterpret_cast<T*>(region + lane * ROWB);
+#pragma unroll
+    for (int j = 0; j < N; ++j) dst[j] = v[j];
+  }
+  static __device__ __forceinline__ void flush(T* __restrict__ base, long row0, int lane, const char* __restrict__ region) {
+    mp_u4* g = reinterpret_cast<mp_u4*>(base + row0 * N);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+      if (j * 64 + lane < NCH) mp_stream_store(*reinterpret_cast<const mp_u4*>(region + (j * 64 + lane) * 16), g + j * 64 + lane);
+  }
+  static __device__ __forceinline__ void sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+};
+
+template <typename T, int N, bool HAS_FTIP, typename MT>
+__device__ __forceinline__ void mp_body_id_co(const MT& M, const MpCall<T>& C, const T* __restrict__ q, const T* __restrict__ qd,
+                                              const T* __restrict__ qdd, T* __restrict__ tau, long row0, int lane, char* __restrict__ lds) {
+  using ST = MpRowStage<T, N>;
+  {
+    mp_u4 bq[ST::NJ], bd[ST::NJ], ba[ST::NJ];
+    ST::fetch(q, row0, lane, bq);
+    ST::fetch(qd, row0, lane, bd);
+    ST::fetch(qdd, row0, lane, ba);
+    ST::stage(bq, lane, lds);
+    ST::stage(bd, lane, lds + ST::SPAN);
+    ST::stage(ba, lane, lds + 2 * ST::SPAN);
+  }
+  ST::sync();
+  T a[N], b[N], c[N], t[N];
+  ST::row_in(lds, lane, a);
+  ST::row_in(lds + ST::SPAN, lane, b);
+  ST::row_in(lds + 2 * ST::SPAN, lane, c);
+  MpJointState<T, N> js;
+  mp_joint_state<T, N>(M, a, js);
+  mp_rnea<T, N, HAS_FTIP>(M, C, js, b, c, t);
+#pragma unroll
+  for (int j = 0; j < N; ++j) t[j] = mp_clip(t[j], M.taumin[j], M.taumax[j]);
+  MpBad<T> bad;  // the non-finite row contract of mp_body_id
+  bad.add(a); bad.add(b); bad.add(c);
+  mp_poison_if(bad.any(), t);
+  ST::sync();  // every lane has read its rows: the first region is free
+  ST::row_out(lds, lane, t);
+  ST::sync();
+  ST::flush(tau, row0, lane, lds);
 }
 
 // qdd for row `r` = forward_dynamics(q, qd, tau, g, F) with one wrench for every row: the body of k_forward_dynamics
@@ -209,7 +312,6 @@ __device__ __forceinline__ void mp_wave_store_flat(T* __restrict__ gbase, long r
 // iiwa14 mass matrix where the 6 x 6 one reaches 5.7).  16 rows always ARE a whole number of 16-byte chunks, so they are staged
 // back to back (unpadded: an odd dword pitch spreads the 16 staging lanes over distinct banks by itself) and streamed out as
 // 16-byte chunks that ignore the row boundaries; only the chunk that straddles the end of the valid rows is written by element.
-typedef unsigned mp_u4 __attribute__((ext_vector_type(4)));
 template <typename T, int COUNT>
 __device__ __forceinline__ void mp_wave_store_flat16(T* __restrict__ gbase, long row0, int lane, int nvalid, const T (&v)[COUNT],
                                                      char* __restrict__ lds) {

@@ -35,6 +35,7 @@ struct MpSpec {  // run-time specialised kernels of one model on one device
   hipFunction_t id_s[2] = {nullptr, nullptr};                                  // inverse dynamics, float32, one row per lane
   hipFunction_t traj_id_s[2] = {nullptr, nullptr};                             // generation fused into it, one timestep per lane
   hipFunction_t fd_traj_tm[2] = {nullptr, nullptr};                            // the roll-out on the time-major device layout
+  hipFunction_t id_co[2] = {nullptr, nullptr};   // id_s with whole-line non-temporal row movement through LDS (full waves only); optional
 };
 struct mp_ctx {
   int device = -1;
@@ -351,8 +352,20 @@ int launch_id(mp_ctx* ctx, const mp_model* model, const MpCall<float>& c, bool f
   if (const MpSpec* sp = find_spec(ctx, model)) {
     if (spec_scalar_f32(model->d.n)) {  // one row per lane
       MpCall<float> cc = c;
-      void* args[] = {&cc, &q, &qd, &qdd, &tau, &rows};
-      return launch_spec(ctx, sp->id_s[ftip ? 1 : 0], rows, args);
+      long done = 0;
+      if (sp->id_co[ftip ? 1 : 0] && rows >= 64 && !getenv("MANIPULAPY_X_NOCO")) {  // whole waves: rows moved as whole lines, non-temporal (mp_body_id_co)
+        long rows64 = rows & ~63L;
+        void* args[] = {&cc, &q, &qd, &qdd, &tau, &rows64};
+        if (int rc = launch_spec(ctx, sp->id_co[ftip ? 1 : 0], rows64, args)) return rc;
+        done = rows64;
+      }
+      if (done == rows) return MP_OK;
+      const long off = done * model->d.n;  // the last rows (< 64), or everything without the whole-line kernel: per-lane rows
+      const float *q2 = q + off, *qd2 = qd + off, *qdd2 = qdd + off;
+      float* tau2 = tau + off;
+      long left = rows - done;
+      void* args[] = {&cc, &q2, &qd2, &qdd2, &tau2, &left};
+      return launch_spec(ctx, sp->id_s[ftip ? 1 : 0], left, args);
     }
     if (pairs > 0) {
       MpCall<float> cc = c;
@@ -1183,6 +1196,9 @@ int mp_model_specialize(mp_ctx* ctx, const mp_model* model) {
     hipError_t e = hipModuleGetFunction(&sp.ik, sp.mod, "mp_spec_ik");
     if (e != hipSuccess) { (void)hipModuleUnload(sp.mod); return hip_err(e, "mp_spec_ik"); }
   }
+  if (hipModuleGetFunction(&sp.id_co[0], sp.mod, "mp_spec_id_co_f0") != hipSuccess ||
+      hipModuleGetFunction(&sp.id_co[1], sp.mod, "mp_spec_id_co_f1") != hipSuccess)
+    sp.id_co[0] = sp.id_co[1] = nullptr;
   // the second program: same kernels, other scheduling strategy; anything that goes wrong here leaves the first program's
   // versions in place (MANIPULAPY_HIP_ILP_PART=0 skips it)
   {
@@ -1195,6 +1211,10 @@ int mp_model_specialize(mp_ctx* ctx, const mp_model* model) {
         hipFunction_t f0 = nullptr, f1 = nullptr;
         if (hipModuleGetFunction(&f0, m2, "mp_spec_id_s_f0") == hipSuccess && hipModuleGetFunction(&f1, m2, "mp_spec_id_s_f1") == hipSuccess) {
           sp.mod_ilp = m2; sp.id_s[0] = f0; sp.id_s[1] = f1;
+          hipFunction_t c0 = nullptr, c1 = nullptr;
+          if (hipModuleGetFunction(&c0, m2, "mp_spec_id_co_f0") == hipSuccess && hipModuleGetFunction(&c1, m2, "mp_spec_id_co_f1") == hipSuccess) {
+            sp.id_co[0] = c0; sp.id_co[1] = c1;
+          }
         } else {
           (void)hipModuleUnload(m2);
         }
@@ -1208,13 +1228,14 @@ int mp_model_specialize(mp_ctx* ctx, const mp_model* model) {
   {
     const int n = model->d.n;
     const long rows = 128, pairs = rows / 2;
-    std::vector<float> h((size_t)rows * n, 0.25f), out((size_t)rows * n * 2, 0.0f);
+    std::vector<float> h((size_t)rows * n, 0.25f), out((size_t)rows * n * 3, 0.0f);
     std::vector<double> hd((size_t)rows * n, 0.25), outd((size_t)rows * n, 0.0);
     h[3 * n] = __builtin_nanf(""); h[(size_t)70 * n + (n > 1 ? 1 : 0)] = __builtin_inff();
     hd[3 * n] = __builtin_nan(""); hd[(size_t)70 * n + (n > 1 ? 1 : 0)] = -__builtin_inf();
     const size_t fb = h.size() * sizeof(float), db = hd.size() * sizeof(double);
     Scratch sc(ctx);
-    void *dq, *dz, *d0, *d1, *dqd, *dzd, *d2;
+    void *dq, *dz, *d0, *d1, *dqd, *dzd, *d2, *d3;
+    if (int rc = sc.get(fb, &d3)) return rc;
     if (int rc = sc.get(fb, &dq)) return rc;
     if (int rc = sc.get(fb, &dz)) return rc;
     if (int rc = sc.get(fb, &d0)) return rc;
@@ -1240,22 +1261,28 @@ int mp_model_specialize(mp_ctx* ctx, const mp_model* model) {
     void* a0[] = {&cf, &q, &z, &z, &o0, &nr};
     void* a1[] = {&cf, &q, &z, &z, &o1, &np_};
     void* a2[] = {&cd, &qd_, &zd, &zd, &o2, &nr};
+    float* o3 = (float*)d3;
+    void* a3[] = {&cf, &q, &z, &z, &o3, &nr};
     int rc = launch_spec(ctx, sp.id_s[0], rows, a0);
     if (!rc) rc = launch_spec(ctx, sp.id_pk[0], pairs, a1);
     if (!rc) rc = launch_spec(ctx, sp.id_d[0], rows, a2);
+    if (!rc && sp.id_co[0]) rc = launch_spec(ctx, sp.id_co[0], rows, a3);
     if (rc) { unload(); return rc; }
     he = hipMemcpyAsync(out.data(), d0, fb, hipMemcpyDeviceToHost, ctx->compute);
     if (he == hipSuccess) he = hipMemcpyAsync(out.data() + h.size(), d1, fb, hipMemcpyDeviceToHost, ctx->compute);
+    if (he == hipSuccess && sp.id_co[0]) he = hipMemcpyAsync(out.data() + 2 * h.size(), d3, fb, hipMemcpyDeviceToHost, ctx->compute);
     if (he == hipSuccess) he = hipMemcpyAsync(outd.data(), d2, db, hipMemcpyDeviceToHost, ctx->compute);
     if (he == hipSuccess) he = hipStreamSynchronize(ctx->compute);
     if (he != hipSuccess) { unload(); return hip_err(he, "mp_model_specialize: self-check download"); }
     bool ok = true;
-    for (int k = 0; k < 3 && ok; ++k) {
+    for (int k = 0; k < 4 && ok; ++k) {  // 0: one row per lane, 1: two rows per lane, 2: float64, 3: whole-line row movement
+      if (k == 3 && !sp.id_co[0]) break;
       for (long r : {3L, 70L, 4L, 69L, 0L, 127L}) {
         const bool want_nan = r == 3 || r == 70;
         for (int j = 0; j < n; ++j) {
-          const double v = k < 2 ? (double)out[(size_t)k * h.size() + (size_t)r * n + j] : outd[(size_t)r * n + j];
+          const double v = k == 2 ? outd[(size_t)r * n + j] : (double)out[(size_t)(k == 3 ? 2 : k) * h.size() + (size_t)r * n + j];
           if ((v != v) != want_nan) ok = false;
+          if (k == 3 && !want_nan && out[2 * h.size() + (size_t)r * n + j] != out[(size_t)r * n + j]) ok = false;  // = the per-lane kernel's bits
         }
       }
     }
