@@ -42,6 +42,26 @@ __device__ __forceinline__ void mp_stream_store(V v, V* p) {
 #endif
 }
 
+// MP_FK_CO / MP_COOP_NT (default 1; 0 through MANIPULAPY_HIP_JIT_DEFINES for an A/B): whole-line non-temporal movement of the input
+// rows / tau of the FK + Jacobian + ID kernel, non-temporal wave-cooperative output stores.  c3 on a box in its fast state:
+// 3.71 ms plain, 3.66 stores only, 3.52 inputs only, 3.45 both (frac 0.82); in its slow (power-capped) state 4.09 / 3.99 /
+// 4.21 / 4.12 - the staging instructions cost there what the memory path gains (profiles/r03_nontemporal_ab.txt)
+#if !defined(MP_FK_CO)
+#define MP_FK_CO 1
+#endif
+// the wave-cooperative row stores further down (whole 16-byte chunks in flat order): non-temporal under MP_COOP_NT
+#if !defined(MP_COOP_NT)
+#define MP_COOP_NT 1
+#endif
+template <typename V>
+__device__ __forceinline__ void mp_coop_store(V v, V* p) {
+#if MP_COOP_NT
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+
 template <typename T, int COUNT>
 struct RunIO {
   static constexpr int BYTES = COUNT * (int)sizeof(T);
@@ -254,7 +274,7 @@ __device__ __forceinline__ void mp_wave_store(T* __restrict__ gbase, long row0, 
       const int g = j * 64 + lane;  // flat chunk index inside this piece of the wave's 64 rows
       const int row = g / PC, col = g - row * PC;
       const V val = *reinterpret_cast<const V*>(lds + row * PITCH + col * W);
-      if (row < nvalid) gout[(long)row * CH + p * PC + col] = val;
+      if (row < nvalid) mp_coop_store(val, gout + ((long)row * CH + p * PC + col));
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -298,7 +318,7 @@ __device__ __forceinline__ void mp_wave_store_flat(T* __restrict__ gbase, long r
       if (f < TOTAL) {
         const int row = f / CH, col = f - row * CH;
         const V val = *reinterpret_cast<const V*>(lds + row * PITCH + col * W);
-        if (pass * ROWS + row < nvalid) gout[(long)pass * TOTAL + f] = val;
+        if (pass * ROWS + row < nvalid) mp_coop_store(val, gout + ((long)pass * TOTAL + f));
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -335,7 +355,7 @@ __device__ __forceinline__ void mp_wave_store_flat16(T* __restrict__ gbase, long
       if (f < NCH) {
         const int gofs = pass * SPAN + f * 16;
         if (gofs + 16 <= valid_bytes) {
-          *reinterpret_cast<mp_u4*>(gout + gofs) = *reinterpret_cast<const mp_u4*>(lds + f * 16);
+          mp_coop_store(*reinterpret_cast<const mp_u4*>(lds + f * 16), reinterpret_cast<mp_u4*>(gout + gofs));
         } else if (gofs < valid_bytes) {  // the one chunk across the end of the valid rows (last wave only)
 #pragma unroll
           for (int b = 0; b < 16; b += (int)sizeof(T))
@@ -366,6 +386,8 @@ __device__ __forceinline__ void mp_body_fk_jac_id(const MT& M, const MpCall<T>& 
                                                   const T* __restrict__ qd, const T* __restrict__ qdd, T* __restrict__ Tout,
                                                   T* __restrict__ Jout, T* __restrict__ tau, long r, long rows,
                                                   char* __restrict__ lds) {
+  using ST = MpRowStage<T, N>;
+  static_assert(ST::SPAN <= MP_WAVE_LDS_BYTES, "one array's 64 rows fit the wave's staging slice");
   const int lane = (int)(threadIdx.x & 63);
   const long row0 = r - lane;
   if (row0 >= rows) return;  // whole wave out of range (wave-uniform)
@@ -373,8 +395,30 @@ __device__ __forceinline__ void mp_body_fk_jac_id(const MT& M, const MpCall<T>& 
   const long rr = valid ? r : rows - 1;  // out-of-range lanes recompute the last row and store nothing
   const long left = rows - row0;
   const int nvalid = left < 64 ? (int)left : 64;
+#if MP_FK_CO
+  // A full wave moves its input rows and tau as whole lines, non-temporal (MpRowStage; see mp_body_id_co): all three arrays are
+  // requested up front, each is staged through the slice when its values are needed.  The last, partial wave: per-lane rows.
+  const bool full = nvalid == 64;
+#else
+  const bool full = false;
+#endif
+  mp_u4 bq[ST::NJ], bd[ST::NJ], ba[ST::NJ];
+  if (full) {
+    ST::fetch(q, row0, lane, bq);
+    if (tau != nullptr) {
+      ST::fetch(qd, row0, lane, bd);
+      ST::fetch(qdd, row0, lane, ba);
+    }
+  }
   T a[N];
-  RunIO<T, N>::load(q, rr, a);
+  if (full) {
+    ST::stage(bq, lane, lds);
+    ST::sync();
+    ST::row_in(lds, lane, a);
+    ST::sync();
+  } else {
+    RunIO<T, N>::load(q, rr, a);
+  }
   MpJointState<T, N> js;
   mp_joint_state<T, N>(M, a, js);
   MpBad<T> bad;
@@ -389,14 +433,31 @@ __device__ __forceinline__ void mp_body_fk_jac_id(const MT& M, const MpCall<T>& 
   }
   if (tau != nullptr) {
     T b[N], c[N], t[N];
-    RunIO<T, N>::load(qd, rr, b);
-    RunIO<T, N>::load(qdd, rr, c);
+    if (full) {
+      ST::stage(bd, lane, lds);
+      ST::sync();
+      ST::row_in(lds, lane, b);
+      ST::sync();
+      ST::stage(ba, lane, lds);
+      ST::sync();
+      ST::row_in(lds, lane, c);
+      ST::sync();
+    } else {
+      RunIO<T, N>::load(qd, rr, b);
+      RunIO<T, N>::load(qdd, rr, c);
+    }
     mp_rnea<T, N, HAS_FTIP>(M, C, js, b, c, t);
 #pragma unroll
     for (int j = 0; j < N; ++j) t[j] = mp_clip(t[j], M.taumin[j], M.taumax[j]);
     bad.add(b); bad.add(c);
     mp_poison_if(bad.any(), t);
-    if (valid) RunIO<T, N>::store(tau, r, t);
+    if (full) {
+      ST::row_out(lds, lane, t);
+      ST::sync();
+      ST::flush(tau, row0, lane, lds);
+    } else if (valid) {
+      RunIO<T, N>::store(tau, r, t);
+    }
   }
 }
 
