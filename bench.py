@@ -78,7 +78,7 @@ def kernel_name(cfg):
     """The dominant kernel of the step (must match what the launcher picks: csrc/mp_capi.cpp spec_scalar_f32)."""
     spec = cfg.get("specialized")
     forced = os.environ.get("MANIPULAPY_HIP_F32", "")[:1]
-    scalar = forced == "s" or (forced != "p" and cfg.get("dof", 0) % 2 == 0)   # specialised float32: one row per lane for even DOF
+    scalar = forced != "p"   # specialised float32: one row per lane unless the packed kernel is forced
     co = not os.environ.get("MANIPULAPY_X_NOCO")   # whole-line row movement (mp_spec_id_co) unless switched off for an A/B
     return {"id": ((("mp_spec_id_co_f0" if co else "mp_spec_id_s_f0") if scalar else "mp_spec_id_pk_f0") if cfg["dtype"] == "f32" else "mp_spec_id_d_f0") if spec else
                   (({"p": "k_id_pk", "s": "k_id"}.get(forced, "k_id_dm")) if cfg["dtype"] == "f32" else "k_id"),

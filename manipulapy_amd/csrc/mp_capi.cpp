@@ -257,15 +257,16 @@ bool specialize_enabled() {
 }
 // Which float32 form the robot-specialised inverse-dynamics kernels take.  MANIPULAPY_HIP_F32 = "scalar" | "packed" forces
 // one; by default the scalar one-row-per-lane form (v_fma_f32: ~2 cycles per wave instruction on gfx950, the packed forms ~4;
-// measured c2 +5 %, c4 +7.5 %) except for odd joint counts, whose 4 n-byte rows only allow dword accesses and measure
-// 4 % better two rows per lane (c4s, n = 7).
+// measured c2 +5 %, c4 +7.5 %).  Until the rows moved as whole lines (mp_spec_id_co) odd joint counts, whose 4 n-byte rows only
+// allow dword accesses per lane, measured 4 % better two rows per lane; now c4s (n = 7) takes 0.119-0.120 ms against 0.128-0.129.
 bool spec_scalar_f32(int n) {
   static const int forced = [] {
     const char* e = getenv("MANIPULAPY_HIP_F32");
     return !e ? 0 : (e[0] == 's' ? 1 : (e[0] == 'p' ? 2 : 0));
   }();
   if (forced) return forced == 1;
-  return (n & 1) == 0;
+  (void)n;   // every joint count since the rows move as whole lines (mp_spec_id_co): c4s, n = 7: 0.119-0.120 ms against 0.128-0.129 packed
+  return true;
 }
 const MpSpec* find_spec(mp_ctx* ctx, const mp_model* model) {
   if (!specialize_enabled()) return nullptr;

@@ -57,14 +57,35 @@ __global__ __launch_bounds__(kBlock) void k_batch_traj(const MpModel<float> M, c
                                                        const float* __restrict__ end, long B, long Nt, double Tf,
                                                        int method, float* __restrict__ pos, float* __restrict__ vel,
                                                        float* __restrict__ acc) {
+  // A pure write kernel: a full wave's 64 consecutive rows of each output leave as whole lines, non-temporal, through LDS
+  // (MpRowStage, csrc/mp_bodies.h); the last, partial wave stores per lane.  (Non-temporal PER-LANE stores of these 24-byte rows
+  // halve the rate: 0.053 -> 0.096 ms.)
+  using ST = MpRowStage<float, N>;
+  __shared__ __attribute__((aligned(16))) char lds[kBlock / 64][3 * ST::SPAN];
+  const long total = B * Nt;
   const long r = (long)blockIdx.x * kBlock + threadIdx.x;
-  if (r >= B * Nt) return;
+  const int lane = (int)(threadIdx.x & 63);
+  const long row0 = r - lane;
+  if (row0 >= total) return;
+  const bool full = row0 + 64 <= total;  // wave-uniform
+  if (r >= total) return;                // (only in the partial wave)
   const long b = r / Nt, t = r - b * Nt;
   float p[N], v[N], a[N];
   traj_row<N>(M, start, end, b, t, Nt, Tf, method, p, v, a);
-  RunIO<float, N>::store(pos, r, p);
-  RunIO<float, N>::store(vel, r, v);
-  RunIO<float, N>::store(acc, r, a);
+  if (full) {
+    char* w = lds[threadIdx.x >> 6];
+    ST::row_out(w, lane, p);
+    ST::row_out(w + ST::SPAN, lane, v);
+    ST::row_out(w + 2 * ST::SPAN, lane, a);
+    ST::sync();
+    ST::flush(pos, row0, lane, w);
+    ST::flush(vel, row0, lane, w + ST::SPAN);
+    ST::flush(acc, row0, lane, w + 2 * ST::SPAN);
+  } else {
+    RunIO<float, N>::store(pos, r, p);
+    RunIO<float, N>::store(vel, r, v);
+    RunIO<float, N>::store(acc, r, a);
+  }
 }
 
 template <int N, bool HAS_FTIP>
