@@ -172,8 +172,12 @@ def device_copy_probe(ctx):
         for _ in range(2):   # the first pass also ramps the clocks
             copy = ctx.stream_bandwidth(nb, reads=1, reps=10)
             mix = ctx.stream_bandwidth(nb, reads=3, reps=10)
-        return {"copy_GBps": copy, "mix_3_reads_1_write_GBps": mix, "bytes_per_array": nb,
-                "how": "mp_stream_bandwidth: float4 per lane, HIP events around 10 launches, (reads + 1) x bytes / time"}
+            copy_nt = ctx.stream_bandwidth(nb, reads=1, reps=10, nontemporal=True)
+            mix_nt = ctx.stream_bandwidth(nb, reads=3, reps=10, nontemporal=True)
+        return {"copy_GBps": copy, "mix_3_reads_1_write_GBps": mix, "copy_nontemporal_GBps": copy_nt,
+                "mix_3_reads_1_write_nontemporal_GBps": mix_nt, "bytes_per_array": nb,
+                "how": "mp_stream_bandwidth: float4 per lane, HIP events around 10 launches, (reads + 1) x bytes / time; the "
+                       "non-temporal pair is the access form of the whole-line row movers (mp_spec_id_co)"}
     except Exception as exc:   # a diagnostic: never costs the line
         return {"error": str(exc)[:200]}
 

@@ -65,6 +65,7 @@ int mp_selftest(mp_ctx* ctx);
 /* Device-copy microbenchmark for the roofline ("confirm the peak with a device-copy microbenchmark in the same
  * run"): `reps` launches of dst = a (reads = 1) or dst = a + b + c (reads = 3, the 3 : 1 byte mix of the inverse-dynamics
  * kernels) over arrays of bytes_per_array bytes, 16 bytes per lane; *gb_per_s = (reads + 1) * bytes * reps / elapsed.
+ * reads = 11 / 13: the same two kernels with non-temporal loads and stores (what the whole-line row movers use).
  * Nothing in the reference corresponds to it. */
 int mp_stream_bandwidth(mp_ctx* ctx, size_t bytes_per_array, int reads, int reps, double* gb_per_s);
 

@@ -429,10 +429,12 @@ class HipContext:
     def selftest(self) -> None:
         _check(self.lib.mp_selftest(self.handle))
 
-    def stream_bandwidth(self, bytes_per_array: int, reads: int = 1, reps: int = 20) -> float:
-        """GB/s of a device copy (reads = 1) or of the 3-reads-1-write mix of the inverse-dynamics kernels (reads = 3)."""
+    def stream_bandwidth(self, bytes_per_array: int, reads: int = 1, reps: int = 20, nontemporal: bool = False) -> float:
+        """GB/s of a device copy (reads = 1) or of the 3-reads-1-write mix of the inverse-dynamics kernels (reads = 3), with plain
+        or non-temporal accesses."""
         out = ctypes.c_double(0.0)
-        _check(self.lib.mp_stream_bandwidth(self.handle, ctypes.c_size_t(int(bytes_per_array)), int(reads), int(reps), ctypes.byref(out)))
+        _check(self.lib.mp_stream_bandwidth(self.handle, ctypes.c_size_t(int(bytes_per_array)), int(reads) + (10 if nontemporal else 0), int(reps),
+                                            ctypes.byref(out)))
         return float(out.value)
 
     def properties(self) -> dict:

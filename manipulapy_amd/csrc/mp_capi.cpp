@@ -805,7 +805,9 @@ int mp_selftest(mp_ctx* ctx) {
 
 int mp_stream_bandwidth(mp_ctx* ctx, size_t bytes_per_array, int reads, int reps, double* gb_per_s) {
   REQUIRE(ctx && gb_per_s, "mp_stream_bandwidth: null argument");
-  REQUIRE(reads == 1 || reads == 3, "mp_stream_bandwidth: reads must be 1 or 3");
+  const bool nt = reads > 10;  // 11 / 13: the same two kernels with non-temporal loads and stores
+  if (nt) reads -= 10;
+  REQUIRE(reads == 1 || reads == 3, "mp_stream_bandwidth: reads must be 1 or 3 (plain accesses), 11 or 13 (non-temporal)");
   REQUIRE(bytes_per_array >= 16 && reps >= 1, "mp_stream_bandwidth: nothing to move");
   CTX_ENTER(ctx);
   const size_t nb = bytes_per_array & ~(size_t)15;
@@ -817,12 +819,12 @@ int mp_stream_bandwidth(mp_ctx* ctx, size_t bytes_per_array, int reads, int reps
   }
   void *a = buf[0], *d = buf[reads == 3 ? 3 : 1];
   const long n4 = (long)(nb / 16);
-  for (int w = 0; w < 3; ++w) HIP_TRY(mpk_stream(ctx->compute, reads, a, buf[1], buf[2], d, n4));
+  for (int w = 0; w < 3; ++w) HIP_TRY(mpk_stream(ctx->compute, reads, nt, a, buf[1], buf[2], d, n4));
   hipEvent_t e0 = nullptr, e1 = nullptr;
   HIP_TRY(hipEventCreate(&e0));
   if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return set_err(MP_ERR_HIP, "mp_stream_bandwidth: hipEventCreate failed"); }
   hipError_t e = hipEventRecord(e0, ctx->compute);
-  for (int r = 0; r < reps && e == hipSuccess; ++r) e = mpk_stream(ctx->compute, reads, a, buf[1], buf[2], d, n4);
+  for (int r = 0; r < reps && e == hipSuccess; ++r) e = mpk_stream(ctx->compute, reads, nt, a, buf[1], buf[2], d, n4);
   if (e == hipSuccess) e = hipEventRecord(e1, ctx->compute);
   if (e == hipSuccess) e = hipEventSynchronize(e1);
   float ms = 0.f;

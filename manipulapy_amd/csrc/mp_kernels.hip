@@ -422,21 +422,22 @@ inline bool use_packed_f32() {
 
 // streaming probes for the roofline: dst = a (one read per write) or dst = a + b + c (the 3 : 1 byte mix of the ID kernels)
 typedef float mp_f4v __attribute__((ext_vector_type(4)));
-template <int READS>
+template <int READS, bool NT>
 __global__ __launch_bounds__(256) void k_stream(const mp_f4v* __restrict__ a, const mp_f4v* __restrict__ b, const mp_f4v* __restrict__ c,
                                                 mp_f4v* __restrict__ d, long n4) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n4) return;
-  mp_f4v v = a[i];
-  if (READS == 3) v = v + b[i] + c[i];
-  d[i] = v;
+  mp_f4v v = NT ? __builtin_nontemporal_load(a + i) : a[i];
+  if (READS == 3) v = v + (NT ? __builtin_nontemporal_load(b + i) : b[i]) + (NT ? __builtin_nontemporal_load(c + i) : c[i]);
+  if (NT) __builtin_nontemporal_store(v, d + i);
+  else d[i] = v;
 }
-hipError_t mpk_stream(hipStream_t s, int reads, const void* a, const void* b, const void* c, void* d, long n4) {
+hipError_t mpk_stream(hipStream_t s, int reads, bool nontemporal, const void* a, const void* b, const void* c, void* d, long n4) {
   const unsigned grid = (unsigned)((n4 + 255) / 256);
-  if (reads == 3)
-    hipLaunchKernelGGL((k_stream<3>), dim3(grid), dim3(256), 0, s, (const mp_f4v*)a, (const mp_f4v*)b, (const mp_f4v*)c, (mp_f4v*)d, n4);
-  else
-    hipLaunchKernelGGL((k_stream<1>), dim3(grid), dim3(256), 0, s, (const mp_f4v*)a, (const mp_f4v*)b, (const mp_f4v*)c, (mp_f4v*)d, n4);
+#define MP_STREAM_LAUNCH(R, NT) hipLaunchKernelGGL((k_stream<R, NT>), dim3(grid), dim3(256), 0, s, (const mp_f4v*)a, (const mp_f4v*)b, (const mp_f4v*)c, (mp_f4v*)d, n4)
+  if (reads == 3) { if (nontemporal) MP_STREAM_LAUNCH(3, true); else MP_STREAM_LAUNCH(3, false); }
+  else { if (nontemporal) MP_STREAM_LAUNCH(1, true); else MP_STREAM_LAUNCH(1, false); }
+#undef MP_STREAM_LAUNCH
   return hipGetLastError();
 }
 

@@ -1543,6 +1543,9 @@ def test_stream_bandwidth_probe(ctx):
     copy = ctx.stream_bandwidth(256 << 20, reads=1, reps=5)
     mix = ctx.stream_bandwidth(256 << 20, reads=3, reps=5)
     assert 1.5e3 < copy < 8.0e3 and 1.5e3 < mix < 8.0e3, (copy, mix)   # GB/s: above any PCIe / single-stack figure, below the peak
+    copy_nt = ctx.stream_bandwidth(256 << 20, reads=1, reps=5, nontemporal=True)
+    mix_nt = ctx.stream_bandwidth(256 << 20, reads=3, reps=5, nontemporal=True)
+    assert 1.5e3 < copy_nt < 8.0e3 and 1.5e3 < mix_nt < 8.0e3, (copy_nt, mix_nt)
     with pytest.raises(_hip.HipError):
         ctx.stream_bandwidth(256 << 20, reads=2)
     with pytest.raises(_hip.HipError):
