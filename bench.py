@@ -79,7 +79,7 @@ def kernel_name(cfg):
     spec = cfg.get("specialized")
     forced = os.environ.get("MANIPULAPY_HIP_F32", "")[:1]
     scalar = forced != "p"   # specialised float32: one row per lane unless the packed kernel is forced
-    co = not os.environ.get("MANIPULAPY_X_NOCO")   # whole-line row movement (mp_spec_id_co) unless switched off for an A/B
+    co = os.environ.get("MANIPULAPY_HIP_ID_CO", "1") != "0"   # whole-line row movement (mp_spec_id_co) unless switched off for an A/B
     return {"id": ((("mp_spec_id_co_f0" if co else "mp_spec_id_s_f0") if scalar else "mp_spec_id_pk_f0") if cfg["dtype"] == "f32" else "mp_spec_id_d_f0") if spec else
                   (({"p": "k_id_pk", "s": "k_id"}.get(forced, "k_id_dm")) if cfg["dtype"] == "f32" else "k_id"),
             "fused": ("mp_spec_traj_id_s_f0" if forced == "s" else "mp_spec_traj_id_pk_f0") if spec else ("k_traj_id" if forced == "s" else "k_traj_id_pk_tab"),

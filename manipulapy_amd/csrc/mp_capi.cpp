@@ -259,6 +259,11 @@ bool specialize_enabled() {
 // one; by default the scalar one-row-per-lane form (v_fma_f32: ~2 cycles per wave instruction on gfx950, the packed forms ~4;
 // measured c2 +5 %, c4 +7.5 %).  Until the rows moved as whole lines (mp_spec_id_co) odd joint counts, whose 4 n-byte rows only
 // allow dword accesses per lane, measured 4 % better two rows per lane; now c4s (n = 7) takes 0.119-0.120 ms against 0.128-0.129.
+// MANIPULAPY_HIP_ID_CO=0: the per-lane kernel for every row (A/B against the whole-line kernel, tools/ab_co.sh)
+static bool id_co_enabled() {
+  static const bool on = [] { const char* e = getenv("MANIPULAPY_HIP_ID_CO"); return !(e && e[0] == '0'); }();
+  return on;
+}
 bool spec_scalar_f32(int n) {
   static const int forced = [] {
     const char* e = getenv("MANIPULAPY_HIP_F32");
@@ -354,7 +359,7 @@ int launch_id(mp_ctx* ctx, const mp_model* model, const MpCall<float>& c, bool f
     if (spec_scalar_f32(model->d.n)) {  // one row per lane
       MpCall<float> cc = c;
       long done = 0;
-      if (sp->id_co[ftip ? 1 : 0] && rows >= 64 && !getenv("MANIPULAPY_X_NOCO")) {  // whole waves: rows moved as whole lines, non-temporal (mp_body_id_co)
+      if (sp->id_co[ftip ? 1 : 0] && rows >= 64 && id_co_enabled()) {  // whole waves: rows moved as whole lines, non-temporal (mp_body_id_co)
         long rows64 = rows & ~63L;
         void* args[] = {&cc, &q, &qd, &qdd, &tau, &rows64};
         if (int rc = launch_spec(ctx, sp->id_co[ftip ? 1 : 0], rows64, args)) return rc;
