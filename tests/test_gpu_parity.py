@@ -12,6 +12,8 @@ Tolerances (BASELINE.json north_star: 1e-6 rel fp64 / 1e-4 rel fp32 against the 
 """
 import os
 
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -2089,5 +2091,56 @@ def test_mass_matrix_store_paths_every_n_and_tail():
                     np.testing.assert_allclose(got, want, rtol=tol, atol=tol * np.abs(want).max(), err_msg=f"n={n} rows={rows} {dtype}")
                     d_q.free(); d_M.free()
             model.destroy()
+    finally:
+        ctx.destroy()
+
+
+@pytest.mark.parametrize("robot", ["ur5", "panda7", "panda"])
+def test_whole_line_inverse_dynamics_kernel_edges(robot):
+    """mp_spec_id_co (rows >= 64 of a specialised float32 model move as whole lines, non-temporal, through LDS; the last < 64 rows
+    take the per-lane kernel): n = 6 / 7 / 8, row counts around the 64-row wave and the 256-row block, against the CPU launcher;
+    rows on either side of the hand-over; a NaN / inf row inside a full wave poisons only itself; device pointers at odd multiples
+    of 16 bytes; nothing is written past the end."""
+    import manipulapy_amd as mp
+    from manipulapy_amd import _hip
+
+    t = mp.robot_tables(robot)
+    n = t["S_list"].shape[1]
+    ctx = _hip.HipContext(0)
+    try:
+        model = _hip.HipModel(t["S_list"], t["Mlist_per_link"], t["Glist"], t["M_ee"], t["joint_limits"])
+        ctx.specialize(model)
+        rng = np.random.default_rng(31)
+        F = np.array([1.0, -2.0, 0.5, 3.0, -1.5, 0.75])
+        for rows in (1, 63, 64, 65, 127, 128, 129, 255, 256, 257, 1000, 4096 + 77):
+            q, qd, qdd = (rng.uniform(-1.5, 1.5, (rows, n)).astype(np.float32) for _ in range(3))
+            for wrench in (None, F):
+                want = _hip.cpu_id_trajectory(model, q, qd, qdd, None, wrench, dtype=np.float32)
+                got = ctx.id_trajectory_host(model, q, qd, qdd, None, wrench, dtype=np.float32)
+                assert_f32(got, want.astype(np.float64))
+        # a non-finite row inside a full wave, and one in the per-lane tail
+        rows = 64 * 3 + 20
+        q, qd, qdd = (rng.uniform(-1, 1, (rows, n)).astype(np.float32) for _ in range(3))
+        q[70, 0] = np.nan; qd[130, n - 1] = np.inf; qdd[rows - 3, 1] = -np.inf
+        got = ctx.id_trajectory_host(model, q, qd, qdd, dtype=np.float32)
+        bad = np.zeros(rows, bool); bad[[70, 130, rows - 3]] = True
+        assert np.isnan(got[bad]).all() and np.isfinite(got[~bad]).all()
+        # device pointers 16 bytes into their buffers (the chunks are 16-byte aligned, not line aligned), guard band behind tau
+        rows = 64 * 5 + 9
+        q, qd, qdd = (rng.uniform(-1, 1, (rows, n)).astype(np.float32) for _ in range(3))
+        nb = rows * n * 4
+        bufs = []
+        for a in (q, qd, qdd):
+            d = ctx.alloc(nb + 64)
+            _hip._check(ctx.lib.mp_memcpy_h2d(ctx.handle, d.offset(16), a.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(nb)))
+            bufs.append(d)
+        d_tau = ctx.alloc(nb + 4096)
+        ctx.memset(d_tau, 0x5A, nb + 4096)
+        ctx.id_trajectory(model, bufs[0].offset(16), bufs[1].offset(16), bufs[2].offset(16), rows, d_tau.offset(16), dtype=np.float32)
+        ctx.synchronize()
+        raw = d_tau.download((nb + 4096,), np.uint8)
+        assert (raw[:16] == 0x5A).all() and (raw[16 + nb:] == 0x5A).all()
+        got = raw[16:16 + nb].view(np.float32).reshape(rows, n)
+        assert_f32(got, _hip.cpu_id_trajectory(model, q, qd, qdd, dtype=np.float32).astype(np.float64))
     finally:
         ctx.destroy()
