@@ -362,7 +362,7 @@ int launch_id(mp_ctx* ctx, const mp_model* model, const MpCall<float>& c, bool f
       if (sp->id_co[ftip ? 1 : 0] && rows >= 64 && id_co_enabled()) {  // whole waves: rows moved as whole lines, non-temporal (mp_body_id_co)
         long rows64 = rows & ~63L;
         void* args[] = {&cc, &q, &qd, &qdd, &tau, &rows64};
-        if (int rc = launch_spec(ctx, sp->id_co[ftip ? 1 : 0], rows64, args)) return rc;
+        if (int rc = launch_spec(ctx, sp->id_co[ftip ? 1 : 0], rows64, args, MP_JIT_ID_CO_BLOCK)) return rc;
         done = rows64;
       }
       if (done == rows) return MP_OK;
@@ -1274,7 +1274,7 @@ int mp_model_specialize(mp_ctx* ctx, const mp_model* model) {
     int rc = launch_spec(ctx, sp.id_s[0], rows, a0);
     if (!rc) rc = launch_spec(ctx, sp.id_pk[0], pairs, a1);
     if (!rc) rc = launch_spec(ctx, sp.id_d[0], rows, a2);
-    if (!rc && sp.id_co[0]) rc = launch_spec(ctx, sp.id_co[0], rows, a3);
+    if (!rc && sp.id_co[0]) rc = launch_spec(ctx, sp.id_co[0], rows, a3, MP_JIT_ID_CO_BLOCK);
     if (rc) { unload(); return rc; }
     he = hipMemcpyAsync(out.data(), d0, fb, hipMemcpyDeviceToHost, ctx->compute);
     if (he == hipSuccess) he = hipMemcpyAsync(out.data() + h.size(), d1, fb, hipMemcpyDeviceToHost, ctx->compute);

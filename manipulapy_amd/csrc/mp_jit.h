@@ -1,5 +1,8 @@
 // Run-time kernel specialisation (see mp_jit.cpp).
 #pragma once
+
+// threads per block of the whole-line inverse-dynamics kernel mp_spec_id_co (its source and its launcher must agree)
+#define MP_JIT_ID_CO_BLOCK 64
 #include <string>
 #include <vector>
 
