@@ -19,7 +19,8 @@ What is different, on purpose:
   * with the "hip" backend the dynamics always go to the device (the reference applies its work
     threshold to them too; a launch costs microseconds here, so the threshold only steers trajectory
     generation, whose NumPy path is BASELINE config 0);
-  * collision avoidance is absent (host-only, mesh-dependent, a no-op without meshes — SURVEY §8c);
+  * collision avoidance: the mesh-less checker (never a collision, like the reference's without mesh files) and `plan_trajectory`'s
+    potential-field waypoint push are in; mesh loading is not (SURVEY §8c);
   * `batch_inverse_dynamics_trajectory` is new: joint_trajectory -> inverse_dynamics_trajectory fused
     on the device for B start/end pairs; `batch_forward_dynamics_trajectory` is new: B roll-outs of
     forward_dynamics_trajectory (planning/trajectory_dynamics.py:580-708) in one launch.
@@ -57,8 +58,17 @@ class OptimizedTrajectoryPlanning:
         self.kernel_type = kernel_type if kernel_type is not None else "auto"
         self.target_speedup = target_speedup if target_speedup is not None else 40.0
         self.enable_profiling = bool(enable_profiling)
-        self.collision_checker = None  # out of scope
-        self.potential_field = None
+        # collision helpers as the reference sets them up (planning/trajectory_planning.py:229-238): both, or neither when the
+        # URDF cannot be read.  The checker is the mesh-less one (potential_field.py): it never reports a collision.
+        try:
+            from .potential_field import CollisionChecker, PotentialField
+
+            self.collision_checker = CollisionChecker(urdf_path)
+            self.potential_field = PotentialField()
+        except Exception as exc:
+            logger.warning("Could not initialise collision checker: %s", exc)
+            self.collision_checker = None
+            self.potential_field = None
         self._last_cpu_time = 0.0
         self.performance_stats = {"gpu_calls": 0, "cpu_calls": 0, "total_gpu_time": 0.0, "total_cpu_time": 0.0,
                                   "memory_transfers": 0, "kernel_launches": 0, "speedup_achieved": 0.0,
@@ -354,6 +364,29 @@ class OptimizedTrajectoryPlanning:
         return {"positions": np.stack(P), "velocities": np.stack(V), "accelerations": np.stack(A)}
 
     # ------------------------------------------------------------------ helpers kept from the reference
+    def plan_trajectory(self, start_position, target_position, obstacle_points):
+        """Six joint-space waypoints on the straight line start -> target; with obstacles (points in joint space) and a
+        potential field each waypoint is pushed down the field's gradient, 0.01 per step, until the collision checker reports it
+        free (at once, with the mesh-less checker) or ten steps have passed (reference planning/collision_host.py:90-152).
+        Host arithmetic throughout, like the reference's.  Returns a list of joint lists."""
+        start = np.asarray(start_position, dtype=np.float64)
+        target = np.asarray(target_position, dtype=np.float64)
+        logger.info("Planning trajectory from %d to %d DOF", len(start), len(target))
+        num_waypoints = 5
+        out = []
+        for i in range(num_waypoints + 1):
+            alpha = i / num_waypoints
+            waypoint = (1 - alpha) * start + alpha * target
+            if obstacle_points and self.potential_field:
+                obstacles = [np.asarray(o, dtype=np.float64) for o in obstacle_points]
+                for _ in range(10):
+                    waypoint = waypoint - 0.01 * self.potential_field.compute_gradient(waypoint, target, obstacles)
+                    if self.collision_checker and not self.collision_checker.check_collision(waypoint):
+                        break
+            out.append(waypoint.tolist())
+        logger.info("Planned trajectory with %d waypoints", len(out))
+        return out
+
     def calculate_derivatives(self, positions, dt) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
         """First differences (reference planning/trajectory_dynamics.py:710-735)."""
         p = np.asarray(positions)

@@ -4,13 +4,19 @@ Attraction 1/2 k_a |q - q_goal|^2; repulsion 10 * sum over obstacles within the 
 2 k_r (1/d - 1/d0)^2; gradient k_a (q - q_goal) + sum of -40 k_r (1/d - 1/d0) / d^3 (q - q_obs), with the reference's guards
 (distances and the influence distance floored at 1e-10; an obstacle exactly at q pushes along the first axis with
 magnitude k_r).  Host NumPy, vectorised over the obstacles; the Cartesian fused field on the GPU is a different function
-(registry name `potential_field.fused`).  The mesh-based collision checker of the reference is out of scope.
+(registry name `potential_field.fused`).
+
+`CollisionChecker` is the mesh-less form of the reference's (potential_field/collision.py:35-230): that one builds a convex hull
+per link from the URDF's collision / visual MESHES and tests the hulls pairwise; without mesh files (trimesh is absent here, and
+the robot descriptions this package ships are kinematic + inertial skeletons) it has no hulls and never reports a collision -
+which is exactly what this class reproduces: it parses the URDF (a missing or malformed file raises, as the reference's does),
+keeps `convex_hulls = {}` and answers False.  Mesh loading stays out of scope.
 """
 from __future__ import annotations
 
 import numpy as np
 
-__all__ = ["PotentialField"]
+__all__ = ["PotentialField", "CollisionChecker"]
 
 
 class PotentialField:
@@ -55,3 +61,27 @@ class PotentialField:
         escape[:, 0] = t(self.repulsive_gain)
         contrib = np.where(exact[:, None], escape, regular)
         return grad + np.sum(np.where((d <= t(self.influence_distance))[:, None], contrib, t(0.0)), axis=0)
+
+
+class CollisionChecker:
+    def __init__(self, urdf_path: str, backend: str = "builtin", load_meshes: bool = True) -> None:
+        import os
+
+        from .urdf import UrdfError, _parse
+
+        del load_meshes
+        if backend != "builtin":
+            raise NotImplementedError("only the built-in URDF reader exists in manipulapy_amd")
+        if not os.path.isfile(str(urdf_path)):
+            raise FileNotFoundError(f"URDF file not found: {os.path.abspath(str(urdf_path))}")
+        try:
+            self.links, self.joints = _parse(str(urdf_path))
+        except UrdfError:
+            raise
+        self.urdf_path = str(urdf_path)
+        self.convex_hulls: dict = {}   # no mesh geometry is ever loaded
+
+    def check_collision(self, thetalist) -> bool:
+        """True if two links' hulls intersect at `thetalist` - never, without hulls."""
+        del thetalist
+        return False

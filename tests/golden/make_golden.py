@@ -22,6 +22,7 @@ What it does:
       cartesian_ur5.npz    : cartesian_trajectory dumps (`make_golden.py cartesian` regenerates only this)
       ik.npz               : iterative_inverse_kinematics dumps, 10 problems per robot (`make_golden.py ik`)
       control_ur5.npz      : ManipulatorController laws on UR5 (`make_golden.py control`)
+      plan_ur5.npz         : OptimizedTrajectoryPlanning.plan_trajectory on the mesh-less UR5 (`make_golden.py plan`)
       urdf_api.npz         : URDFToSerialManipulator's convenience surface on ten urdf_suite files (`make_golden.py urdf_api`)
       gain_sweep_ur5.npz   : ManipulatorController.find_ultimate_gain_and_period on UR5 (`make_golden.py gain_sweep`)
       utils.npz            : every public ManipulaPy.utils function on generic and branch-switching inputs (`make_golden.py utils`)
@@ -453,6 +454,32 @@ def dump_control():
     d["kin_jvel_space"] = np.stack([np.asarray(sm.joint_velocity(q, V)) for q, V in zip(qs, Vs)])
     d["kin_jvel_body"] = np.stack([np.asarray(sm.joint_velocity(q, V, frame="body")) for q, V in zip(qs, Vs)])
     np.savez(os.path.join(HERE, "control_ur5.npz"), **d)
+
+
+def dump_plan():
+    """OptimizedTrajectoryPlanning.plan_trajectory (planning/collision_host.py:90-152) on the UR5 skeleton URDF (no meshes: the collision
+    checker never reports a collision, so every waypoint takes exactly one potential-field step when obstacles are given), and
+    PotentialField's own values at a few points."""
+    from ManipulaPy.path_planning import OptimizedTrajectoryPlanning
+    from ManipulaPy.potential_field import PotentialField
+
+    proc, sm, dyn = build("ur5")
+    urdf = os.path.join(PKG_DATA, "urdf", "ur5.urdf")
+    lim = finite_limits(sm, 6)
+    pl = OptimizedTrajectoryPlanning(sm, urdf, dyn, lim, use_cuda=False)
+    assert pl.collision_checker is not None and pl.potential_field is not None
+    rng = np.random.default_rng(SEED + 950)
+    d = {}
+    start, target = rng.uniform(-1, 1, 6), rng.uniform(-1, 1, 6)
+    obstacles = [rng.uniform(-1, 1, 6) for _ in range(4)] + [0.5 * (start + target) + 0.05]
+    d["start"], d["target"], d["obstacles"] = start, target, np.stack(obstacles)
+    d["with_obstacles"] = np.asarray(pl.plan_trajectory(start.tolist(), target.tolist(), obstacles))
+    d["without_obstacles"] = np.asarray(pl.plan_trajectory(start.tolist(), target.tolist(), []))
+    d["collision_free"] = np.array([bool(pl.collision_checker.check_collision(q)) for q in (start, target, np.zeros(6))])
+    pl2 = OptimizedTrajectoryPlanning(sm, "nonexistent.urdf", dyn, lim, use_cuda=False)
+    d["no_checker"] = np.array([pl2.collision_checker is None, pl2.potential_field is None])
+    d["no_checker_plan"] = np.asarray(pl2.plan_trajectory(start.tolist(), target.tolist(), obstacles))
+    np.savez(os.path.join(HERE, "plan_ur5.npz"), **d)
 
 
 def dump_urdf_api():
@@ -895,7 +922,7 @@ def main():
         dump_ik()
         print("ik dumped")
         return
-    for name, fn in (("urdf_api", dump_urdf_api), ("gain_sweep", dump_gain_sweep), ("rollout100", dump_rollout100), ("nonfinite", dump_nonfinite), ("field", dump_field), ("urdf_suite", dump_urdf_suite),
+    for name, fn in (("plan", dump_plan), ("urdf_api", dump_urdf_api), ("gain_sweep", dump_gain_sweep), ("rollout100", dump_rollout100), ("nonfinite", dump_nonfinite), ("field", dump_field), ("urdf_suite", dump_urdf_suite),
                      ("legacy", dump_legacy)):
         if name in sys.argv[1:]:
             fn()
@@ -923,6 +950,7 @@ def main():
     dump_legacy()
     dump_gain_sweep()
     dump_urdf_api()
+    dump_plan()
     print("trajectories dumped", flush=True)
     time_reference()
     print("timings dumped")
