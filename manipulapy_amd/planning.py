@@ -395,6 +395,73 @@ class OptimizedTrajectoryPlanning:
         j = (a[1:] - a[:-1]) / dt
         return v, a, j
 
+    # ---- the planner's own timing helpers (reference planning/trajectory_planning.py:526-658, :660-830), without the console tables
+    def benchmark_all_kernels(self, N: int = 5000, num_joints: int = 6, num_runs: int = 5) -> Dict[str, Dict[str, object]]:
+        """Times `joint_trajectory` under each of the reference's five trajectory-kernel names - on gfx950 they are one kernel, the
+        names stay valid registry entries - and returns {name: mean / std / min / max / all_times / success_rate / trajectory_shape};
+        {} when the GPU is not routed to (as the reference returns without CUDA)."""
+        if not self._gpu_routed():
+            logger.warning("GPU not available for benchmarking")
+            return {}
+        start = np.random.uniform(-1, 1, num_joints).astype(np.float32)
+        end = np.random.uniform(-1, 1, num_joints).astype(np.float32)
+        results: Dict[str, Dict[str, object]] = {}
+        for kernel_type in ("standard", "vectorized", "memory_optimized", "warp_optimized", "cache_friendly"):
+            self.reset_performance_stats()
+            times, shape = [], None
+            for _ in range(num_runs):
+                t0 = time.time()
+                try:
+                    shape = self.joint_trajectory(start, end, 2.0, N, 5, kernel_type=kernel_type, enable_monitoring=False)["positions"].shape
+                    times.append(time.time() - t0)
+                except Exception as exc:
+                    logger.warning("Kernel %s failed: %s", kernel_type, exc)
+                    times.append(float("inf"))
+            if times and min(times) < float("inf"):
+                good = [t for t in times if t < float("inf")]
+                results[kernel_type] = {"mean_time": float(np.mean(good)), "std_time": float(np.std(good)), "min_time": float(np.min(good)),
+                                        "max_time": float(np.max(good)), "all_times": times, "success_rate": len(good) / len(times),
+                                        "trajectory_shape": shape}
+        return results
+
+    def benchmark_performance(self, test_cases=None, include_cpu_comparison: bool = True) -> Dict[str, Dict[str, object]]:
+        """Times `joint_trajectory` on a list of {"N", "joints", "name"} cases (three runs each; default: four sizes at this
+        robot's joint count) and, when the GPU is routed to and asked for, the CPU launcher of the same call for a speed-up."""
+        n = len(self.joint_limits)
+        if test_cases is None:
+            test_cases = [{"N": 100, "joints": n, "name": "Small"}, {"N": 1000, "joints": n, "name": "Medium"},
+                          {"N": 5000, "joints": n, "name": "Large"}, {"N": 10000, "joints": n, "name": "Very Large"}]
+        results: Dict[str, Dict[str, object]] = {}
+        for case in test_cases:
+            N, joints, name = case["N"], case["joints"], case["name"]
+            start = np.random.uniform(-1, 1, joints).astype(np.float32)
+            end = np.random.uniform(-1, 1, joints).astype(np.float32)
+            self.reset_performance_stats()
+            times = []
+            for _ in range(3):
+                t0 = time.time()
+                traj = self.joint_trajectory(start, end, 2.0, N, 5)
+                times.append(time.time() - t0)
+            stats = self.get_performance_stats()
+            mean = float(np.mean(times))
+            results[name] = {"mean_time": mean, "std_time": float(np.std(times)), "min_time": min(times), "max_time": max(times), "N": N,
+                             "joints": joints, "stats": stats, "used_gpu": stats["gpu_calls"] > 0,
+                             "trajectory_shape": traj["positions"].shape, "speedup_achieved": stats.get("speedup_achieved", 0),
+                             "kernel_used": stats.get("best_kernel_used", "unknown"), "elements_per_second": (N * joints) / mean if mean > 0 else 0.0}
+            if include_cpu_comparison and results[name]["used_gpu"]:
+                old = self.cpu_threshold
+                self.cpu_threshold = float("inf")   # the routing rule then picks the CPU launcher
+                try:
+                    t0 = time.time()
+                    self.joint_trajectory(start, end, 2.0, N, 5)
+                    cpu_time = time.time() - t0
+                finally:
+                    self.cpu_threshold = old
+                results[name]["cpu_time"] = cpu_time
+                results[name]["actual_speedup"] = cpu_time / mean if mean > 0 else 0
+            logger.info("%s benchmark: %.4fs, GPU: %s", name, mean, results[name]["used_gpu"])
+        return results
+
     def reset_performance_stats(self) -> None:
         """reference planning/trajectory_planning.py:489-500."""
         self.performance_stats = {"gpu_calls": 0, "cpu_calls": 0, "total_gpu_time": 0.0, "total_cpu_time": 0.0,

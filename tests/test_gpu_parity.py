@@ -2144,3 +2144,19 @@ def test_whole_line_inverse_dynamics_kernel_edges(robot):
         assert_f32(got, _hip.cpu_id_trajectory(model, q, qd, qdd, dtype=np.float32).astype(np.float64))
     finally:
         ctx.destroy()
+
+
+def test_planner_benchmark_helpers_on_the_gpu():
+    """benchmark_all_kernels: the reference's five kernel names all run (one kernel here); benchmark_performance reports the GPU
+    route and a measured CPU-launcher comparison."""
+    import manipulapy_amd as mp
+
+    sm, dyn, lim = mp.load_robot("ur5")
+    with mp.use_backend("hip"):
+        pl = mp.OptimizedTrajectoryPlanning(sm, mp.robot_urdf("ur5"), dyn, lim, cuda_threshold=1)
+        r = pl.benchmark_all_kernels(N=10000, num_joints=6, num_runs=2)   # (N x n above the planner's GPU threshold of ~42 700 elements)
+        assert sorted(r) == ["cache_friendly", "memory_optimized", "standard", "vectorized", "warp_optimized"]
+        assert all(e["success_rate"] == 1.0 and e["trajectory_shape"] == (10000, 6) and len(e["all_times"]) == 2 for e in r.values())
+        b = pl.benchmark_performance([{"N": 10000, "joints": 6, "name": "case"}])
+        assert b["case"]["used_gpu"] and b["case"]["cpu_time"] > 0 and b["case"]["actual_speedup"] > 0 and b["case"]["stats"]["gpu_calls"] == 3
+        pl.close()

@@ -569,3 +569,18 @@ def test_plan_trajectory_and_the_mesh_less_collision_checker():
         CollisionChecker("nonexistent.urdf")
     with pytest.raises(NotImplementedError):
         CollisionChecker(mp.robot_urdf("ur5"), backend="pybullet")
+
+
+def test_planner_benchmark_helpers_without_a_gpu():
+    """benchmark_performance / benchmark_all_kernels (reference planning/trajectory_planning.py:526-830): result keys and shapes;
+    without GPU routing the kernel sweep returns {} like the reference without CUDA, and no CPU-vs-CPU speed-up is invented."""
+    sm, dyn, lim = mp.load_robot("ur5")
+    pl = mp.OptimizedTrajectoryPlanning(sm, mp.robot_urdf("ur5"), dyn, lim, use_cuda=False)
+    r = pl.benchmark_performance([{"N": 40, "joints": 6, "name": "tiny"}, {"N": 80, "joints": 6, "name": "small"}])
+    assert sorted(r) == ["small", "tiny"]
+    for name, N in (("tiny", 40), ("small", 80)):
+        e = r[name]
+        assert e["trajectory_shape"] == (N, 6) and e["used_gpu"] is False and "actual_speedup" not in e
+        assert e["min_time"] <= e["mean_time"] <= e["max_time"] and e["elements_per_second"] > 0 and e["stats"]["cpu_calls"] == 3
+    assert set(pl.benchmark_performance()) == {"Small", "Medium", "Large", "Very Large"}
+    assert pl.benchmark_all_kernels(N=20, num_runs=1) == {}
