@@ -2160,3 +2160,27 @@ def test_planner_benchmark_helpers_on_the_gpu():
         b = pl.benchmark_performance([{"N": 10000, "joints": 6, "name": "case"}])
         assert b["case"]["used_gpu"] and b["case"]["cpu_time"] > 0 and b["case"]["actual_speedup"] > 0 and b["case"]["stats"]["gpu_calls"] == 3
         pl.close()
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5])
+def test_whole_line_kernel_small_joint_counts(n):
+    """mp_spec_id_co for 1..5 joints (4..20-byte rows: 16..80 chunks per wave and array, partly filled chunk instructions) on random
+    chains: rows through the whole-line kernel and the per-lane tail against the CPU launcher, with and without a tip wrench."""
+    from manipulapy_amd import _hip
+    from test_random_robots import FLAVOURS, random_robot
+
+    rng = np.random.default_rng(500 + n)
+    tab = random_robot(rng, n, FLAVOURS[(n + 2) % len(FLAVOURS)])
+    ctx = _hip.HipContext(0)
+    try:
+        model = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee, tab.joint_limits)
+        ctx.specialize(model)
+        for rows in (64, 64 * 7 + 5, 2048 + 63):
+            q, qd, qdd = (rng.uniform(-1.5, 1.5, (rows, n)).astype(np.float32) for _ in range(3))
+            for wrench in (None, np.array([0.5, -1.0, 0.25, 2.0, -1.5, 0.75])):
+                want = _hip.cpu_id_trajectory(model, q, qd, qdd, None, wrench, dtype=np.float32)
+                got = ctx.id_trajectory_host(model, q, qd, qdd, None, wrench, dtype=np.float32)
+                # (a one- or two-value row has no "row scale" to hold its cancellations against: the batch's scale is the floor here)
+                np.testing.assert_allclose(got, want, rtol=1e-4, atol=5e-6 * float(np.abs(want).max()))
+    finally:
+        ctx.destroy()
