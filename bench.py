@@ -195,18 +195,21 @@ def ramp(ctx, step, ms):
     return n
 
 
-F32_INPUT_ULPS = 4.0   # second float32 bound, see parity_rows
+F64_FD_NOISE = 4e-9   # float64 floor per (rad/s)^2 of |qd|^2, see parity_rows
 
 
-def parity_rows(got, want, dtype, sensitivity=None):
-    """The suite's element-wise bound (tests/test_gpu_parity.py assert_f32 / assert_f64): float32 1e-4 |ref| + 5e-6 max|row|,
-    float64 1e-6 |ref| + 1e-7.  Over millions of random rows a float32 recursion meets rows whose torque is a small
-    difference of large terms (|tau| < 0.5 N.m out of gravity and velocity-product torques of tens of N.m at 12 rad/s): there
-    the float32 INPUTS themselves do not determine tau to 5e-6 of the row.  Rows that miss the first bound are therefore
-    re-examined: the excess must stay below 4 x the change of tau that ONE float32 ulp in each input causes (`sensitivity`: a
-    callable row indices -> sum over the 3n inputs of |tau(x +- ulp) - tau(x)| from the float64 oracle) - no float32 method
-    can be expected to beat a few ulps of its own inputs; a row that misses that too fails the run.
-    `worst_over_tol` > 1 fails."""
+def parity_rows(got, want, dtype, sensitivity=None, qd=None):
+    """The suite's element-wise bound (tests/test_gpu_parity.py assert_f32 / assert_f64), on EVERY row, nothing else decides `ok`:
+    float32  1e-4 |ref| + 5e-6 max|row|;
+    float64  1e-6 |ref| + 1e-7 + 4e-9 |qd|^2 when the rows' velocities `qd` are given - the oracle's velocity-product term is the
+             reference's central difference of the mass matrix with eps = 1e-6 (dynamics/cache.py:39-52), whose rounding noise
+             u |M| / eps ~ 1e-10 per Christoffel symbol enters tau multiplied by |qd|^2: measured 0.9 - 2.9e-9 |qd|^2 on 9 M rows of
+             four robots (profiles/r04_f32_precision_study.txt); the analytic recursion of the kernels does not have it.
+    Round 3 re-judged float32 rows that missed the bound against a fitted multiple of their input sensitivity.  That second level
+    is gone: since round 4 the float32 kernels take joint offsets exactly and evaluate ill-conditioned rows in float64
+    (csrc/mp_core.h, mp_rnea_row) and every row of the 12.3 M of c2 sits at <= 0.4 x the bound.  `sensitivity` (a callable row
+    indices -> sum over the 3n inputs of |tau(x +- 1 float32 ulp) - tau(x)|, float64 oracle) is kept as a printed DIAGNOSTIC for
+    rows that miss the bound: `worst_excess_over_input_ulps` says how many input ulps the miss is worth."""
     want = np.asarray(want, np.float64).reshape(len(want), -1)
     err = np.abs(np.asarray(got, np.float64).reshape(want.shape) - want)
     if dtype == "f32":
@@ -215,6 +218,10 @@ def parity_rows(got, want, dtype, sensitivity=None):
     else:
         tol = 1e-6 * np.abs(want) + 1e-7
         rule = "1e-6 |ref| + 1e-7"
+        if qd is not None:
+            v2 = (np.asarray(qd, np.float64).reshape(len(want), -1) ** 2).sum(axis=1, keepdims=True)
+            tol = tol + F64_FD_NOISE * v2
+            rule += " + 4e-9 |qd|^2 (the oracle's finite-difference noise)"
     finite = bool(np.isfinite(np.asarray(got)).all())
     out = {"rows": int(want.shape[0]), "max_abs_err": float(err.max()) if finite else None, "max_abs_ref": float(np.abs(want).max()),
            "tolerance": rule}
@@ -225,12 +232,11 @@ def parity_rows(got, want, dtype, sensitivity=None):
     over = np.nonzero((ratio > 1.0).any(axis=1))[0]
     out["rows_over_first_bound"] = int(len(over))
     out["worst_over_first_bound"] = float(ratio.max())
-    if len(over) and sensitivity is not None and dtype == "f32":
-        S = np.asarray(sensitivity(over), np.float64).reshape(len(over), -1)
-        ratio[over] = err[over] / (tol[over] + F32_INPUT_ULPS * S)
-        out["tolerance"] = rule + "; rows over it: + 4 x sum_k |tau(x_k +- 1 float32 ulp) - tau(x)| (float64 oracle)"
     out["worst_over_tol"] = float(ratio.max())
-    out["ok"] = bool(out["worst_over_tol"] <= 1.0)
+    out["ok"] = bool(len(over) == 0)
+    if len(over) and sensitivity is not None and dtype == "f32":   # diagnostic only
+        S = np.asarray(sensitivity(over[:256]), np.float64).reshape(len(over[:256]), -1)
+        out["worst_excess_over_input_ulps"] = float(((err[over[:256]] - tol[over[:256]]) / np.maximum(S, 1e-300)).max())
     return out
 
 
@@ -492,6 +498,8 @@ def main():
     ap.add_argument("--config", default="all", choices=["all"] + sorted(CONFIGS),
                     help="all (default): c2 as the line's value plus every other configuration in its \"configs\" object")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--parity-set0-only", dest="parity_all_sets", action="store_false",
+                    help="headline parity sample: only input set 0 (default: every input set the timed steps rotate over, ~10 s each)")
     ap.add_argument("--launch", default="stream", choices=("stream", "graph"),
                     help="stream: one host call per step; graph: the K timed steps captured into one hipGraph launch")
     ap.add_argument("--event-stride", type=int, default=0,
@@ -886,6 +894,20 @@ def bench_id(args, cfg, info, hg, ctx, model, t, props, headline):
     if info.rank == 0 and world == 1 and not args.no_cpu_baseline and not hung:
         try:
             result.update(parity_and_baseline(cfg, ctx, model, t, sets[0], rows, n, dt_np, headline))
+            if headline and cfg["op"] == "id" and args.parity_all_sets:
+                # the other input sets the timed steps rotated over: every row the headline figure was measured on is checked
+                others = []
+                for k in range(1, nsets):
+                    st = sets[k]
+                    q, qd, qdd = (st[key].download((rows, n), dt_np) for key in ("d_q", "d_qd", "d_qdd"))
+                    want, _ = oracle_id_rows(cfg["robot"], q, qd, qdd, 10.0)
+                    got = st["d_tau"].download((len(want), n), dt_np)
+                    pk = parity_rows(got, want, cfg["dtype"], qd=qd[:len(want)])
+                    others.append({"set": k, **{key: pk[key] for key in ("rows", "rows_over_first_bound", "worst_over_tol", "ok")}})
+                    del q, qd, qdd, want, got
+                result["parity_sample"]["other_input_sets"] = others
+                result["parity_sample"]["rows_all_sets"] = result["parity_sample"]["rows"] + sum(o["rows"] for o in others)
+                result["parity_sample"]["ok"] = bool(result["parity_sample"]["ok"] and all(o["ok"] for o in others))
         except Exception as exc:  # the GPU line must not be lost to a host-side problem (no compiler, no OpenMP ...)
             result["cpu_baseline"] = {"value": None, "unit": "joint-timesteps/s", "cores": 0, "kind": "port",
                                       "sample": f"not measured: {type(exc).__name__}: {str(exc)[:200]}"}
@@ -927,7 +949,7 @@ def parity_and_baseline(cfg, ctx, model, t, st, rows, n, dt_np, headline):
     else:
         tau_cpu, _ = oracle_id_rows(cfg["robot"], q, qd, qdd, 2.5)
     tau_gpu = st["d_tau"].download((len(tau_cpu), n), dt_np)
-    par = parity_rows(tau_gpu, tau_cpu, cfg["dtype"], id_sensitivity(oracle_tables(ref, cfg["robot"]), q, qd, qdd))
+    par = parity_rows(tau_gpu, tau_cpu, cfg["dtype"], id_sensitivity(oracle_tables(ref, cfg["robot"]), q, qd, qdd), qd=qd[:len(tau_cpu)])
     par["what"] = "tau of the first rows of input set 0 against the pinned C oracle (oracle/oracle.c)"
     if cfg["op"] == "fk_jac_id":
         tab = oracle_tables(ref, cfg["robot"])

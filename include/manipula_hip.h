@@ -304,6 +304,12 @@ int mp_id_trajectory_cpu_f32(const mp_model* model, const float* q, const float*
                              const double* g, const double* Ftip, float* tau, int nthreads);
 int mp_id_trajectory_cpu_f64(const mp_model* model, const double* q, const double* qd, const double* qdd, int64_t rows,
                              const double* g, const double* Ftip, double* tau, int nthreads);
+/* Diagnostic: in_f64[r] = 1 where the float32 inverse-dynamics kernels (and mp_id_trajectory_cpu_f32) evaluate row r in float64 -
+ * the rows whose joint wrenches exceed 16 x their largest torque, where a float32 recursion cannot hold the parity bound
+ * 1e-4 |ref| + 5e-6 max|row| (csrc/mp_core.h, mp_rnea_row).  No counterpart in the reference, whose path is float64 throughout
+ * (planning/trajectory_dynamics.py:308-380). */
+int mp_id_row_precision_cpu_f32(const mp_model* model, const float* q, const float* qd, const float* qdd, int64_t rows,
+                                const double* g, const double* Ftip, uint8_t* in_f64, int nthreads);
 int mp_fk_jac_id_cpu_f64(const mp_model* model, const double* q, const double* qd, const double* qdd, int64_t rows,
                          const double* g, const double* Ftip, double* T, double* J, double* tau, int nthreads);
 int mp_mass_matrix_cpu_f64(const mp_model* model, const double* q, int64_t rows, double* M, int nthreads);

@@ -113,6 +113,7 @@ SIGNATURES = {
     "mp_pd_regulation_cpu_f64": (ctypes.c_int, [_vp, _c_dp, _c_dp, _c_dp, _c_dp, _i64, _c_dp, ctypes.c_double, ctypes.c_int, _c_dp, _vp, ctypes.c_int]),
     "mp_cpu_threads": (ctypes.c_int, [_i64]),
     "mp_id_trajectory_cpu_f32": (ctypes.c_int, [_vp, _c_fp, _c_fp, _c_fp, _i64, _c_dp, _c_dp, _c_fp, ctypes.c_int]),
+    "mp_id_row_precision_cpu_f32": (ctypes.c_int, [_vp, _c_fp, _c_fp, _c_fp, _i64, _c_dp, _c_dp, _vp, ctypes.c_int]),
     "mp_id_trajectory_cpu_f64": (ctypes.c_int, [_vp, _c_dp, _c_dp, _c_dp, _i64, _c_dp, _c_dp, _c_dp, ctypes.c_int]),
     "mp_fk_jac_id_cpu_f64": (ctypes.c_int, [_vp, _c_dp, _c_dp, _c_dp, _i64, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp, ctypes.c_int]),
     "mp_mass_matrix_cpu_f64": (ctypes.c_int, [_vp, _c_dp, _i64, _c_dp, ctypes.c_int]),
@@ -377,8 +378,9 @@ class HipModel:
             v = vals[o:o + k].copy(); o += k
             return v
         d = {"n": int(raw[:4].view(np.int32)[0]), "base_R": take(9), "base_p": take(3), "tool_R": take(9), "tool_p": take(3)}
-        cap = (nb.value - head - 24 * w) // (20 * w)   # MP_MAX_DOF, or MP_BIG_DOF for the looped kernels' model (csrc/mp_model.h)
-        d["joints"] = take(16 * cap).reshape(cap, 16)
+        F = 18                                           # MP_JOINT_FIELDS (csrc/mp_model.h): the 16 of params() + cos / sin of the offset
+        cap = (nb.value - head - 24 * w) // ((F + 4) * w)   # MP_MAX_DOF, or MP_BIG_DOF for the looped kernels' model
+        d["joints"] = take(F * cap).reshape(cap, F)
         for k in ("qmin", "qmax", "taumin", "taumax"):
             d[k] = take(cap)
         assert o * w + head == nb.value, (o * w + head, nb.value)
@@ -805,6 +807,21 @@ def cpu_id_trajectory(model: "HipModel", q, qd, qdd, g=None, Ftip=None, dtype=np
     _check(fn(model.handle, _ptr(q, dtype), _ptr(qd, dtype), _ptr(qdd, dtype), q.shape[0], _dptr(_vec_or_none(g, 3, "g")),
               _dptr(_vec_or_none(Ftip, 6, "Ftip")), _ptr(tau, dtype), int(nthreads)))
     return tau
+
+
+def cpu_id_row_precision(model: "HipModel", q, qd, qdd, g=None, Ftip=None, nthreads: int = 0) -> np.ndarray:
+    """(rows,) bool: the rows the float32 inverse-dynamics kernels evaluate in float64 (ill-conditioned rows, csrc/mp_core.h)."""
+    lib = load_library()
+    q = _as_c(q, np.float32, name="q")
+    if q.ndim != 2 or q.shape[1] != model.n:
+        raise ValueError(f"q must be (rows, {model.n}); got {q.shape}")
+    rows = q.shape[0]
+    qd, qdd = _as_c(qd, np.float32, q.shape, "qd"), _as_c(qdd, np.float32, q.shape, "qdd")
+    out = np.zeros(rows, dtype=np.uint8)
+    _check(lib.mp_id_row_precision_cpu_f32(model.handle, _ptr(q, np.float32), _ptr(qd, np.float32), _ptr(qdd, np.float32), rows,
+                                           _dptr(_vec_or_none(g, 3, "g")), _dptr(_vec_or_none(Ftip, 6, "Ftip")),
+                                           out.ctypes.data_as(_vp), nthreads))
+    return out.astype(bool)
 
 
 def cpu_fk_jac_id(model: "HipModel", q, qd=None, qdd=None, g=None, Ftip=None, want_T=True, want_J=True, nthreads: int = 0):

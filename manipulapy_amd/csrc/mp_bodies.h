@@ -149,7 +149,7 @@ __device__ __forceinline__ void mp_body_id(const MT& M, const MpCall<T>& C, cons
   RunIO<T, N>::load(qdd, r, c);
   MpJointState<T, N> js;
   mp_joint_state<T, N>(M, a, js);
-  mp_rnea<T, N, HAS_FTIP>(M, C, js, b, c, t);
+  mp_rnea_row<T, N, HAS_FTIP>(M, C, js, a, b, c, t);
 #pragma unroll
   for (int j = 0; j < N; ++j) t[j] = mp_clip(t[j], M.taumin[j], M.taumax[j]);
   MpBad<T> bad;  // a NaN / inf anywhere in the row's inputs -> a NaN row, as the reference returns (mp_core.h)
@@ -223,7 +223,7 @@ __device__ __forceinline__ void mp_body_id_co(const MT& M, const MpCall<T>& C, c
   ST::row_in(lds + 2 * ST::SPAN, lane, c);
   MpJointState<T, N> js;
   mp_joint_state<T, N>(M, a, js);
-  mp_rnea<T, N, HAS_FTIP>(M, C, js, b, c, t);
+  mp_rnea_row<T, N, HAS_FTIP>(M, C, js, a, b, c, t);
 #pragma unroll
   for (int j = 0; j < N; ++j) t[j] = mp_clip(t[j], M.taumin[j], M.taumax[j]);
   MpBad<T> bad;  // the non-finite row contract of mp_body_id
@@ -466,7 +466,7 @@ __device__ __forceinline__ void mp_body_fk_jac_id(const MT& M, const MpCall<T>& 
       RunIO<T, N>::load(qd, rr, b);
       RunIO<T, N>::load(qdd, rr, c);
     }
-    mp_rnea<T, N, HAS_FTIP>(M, C, js, b, c, t);
+    mp_rnea_row<T, N, HAS_FTIP>(M, C, js, a, b, c, t);
 #pragma unroll
     for (int j = 0; j < N; ++j) t[j] = mp_clip(t[j], M.taumin[j], M.taumax[j]);
     bad.add(b); bad.add(c);
@@ -514,7 +514,7 @@ __device__ __forceinline__ void mp_body_id_pk(const MT& M, const MpCall<float>& 
   load_pair<N>(qdd, p, c);
   MpJointState<mp_f2, N> js;
   mp_joint_state<mp_f2, N>(M, a, js);
-  mp_rnea<mp_f2, N, HAS_FTIP>(M, C, js, b, c, t);
+  mp_rnea_row<N, HAS_FTIP>(M, C, js, a, b, c, t);
   MpBad<mp_f2> bad;
   bad.add(a); bad.add(b); bad.add(c);
 #pragma unroll
@@ -541,7 +541,7 @@ __device__ __forceinline__ void mp_body_id_pk_split(const MT& M, const MpCall<fl
   }
   MpJointState<mp_f2, N> js;
   mp_joint_state<mp_f2, N>(M, v[0], js);
-  mp_rnea<mp_f2, N, HAS_FTIP>(M, C, js, v[1], v[2], t);
+  mp_rnea_row<N, HAS_FTIP>(M, C, js, v[0], v[1], v[2], t);
   MpBad<mp_f2> bad;
   bad.add(v[0]); bad.add(v[1]); bad.add(v[2]);
   float lo[N], hi[N];
@@ -573,7 +573,7 @@ __device__ __forceinline__ void mp_body_traj_id_pk(const MT& M, const MpCall<flo
   for (int j = 0; j < N; ++j) { qq[j] = (mp_f2){p0[j], p1[j]}; qd[j] = (mp_f2){v0[j], v1[j]}; qdd[j] = (mp_f2){a0[j], a1[j]}; }
   MpJointState<mp_f2, N> js;
   mp_joint_state<mp_f2, N>(M, qq, js);
-  mp_rnea<mp_f2, N, HAS_FTIP>(M, C, js, qd, qdd, tq);
+  mp_rnea_row<N, HAS_FTIP>(M, C, js, qq, qd, qdd, tq);
   MpBad<mp_f2> bad;  // a non-finite end point makes the generated row non-finite
   bad.add(qq); bad.add(qd); bad.add(qdd);
 #pragma unroll
@@ -606,7 +606,7 @@ __device__ __forceinline__ void mp_body_traj_id_pk_tab(const MT& M, const MpCall
   }
   MpJointState<mp_f2, N> js;
   mp_joint_state<mp_f2, N>(M, qq, js);
-  mp_rnea<mp_f2, N, HAS_FTIP>(M, C, js, qd, qdd, tq);
+  mp_rnea_row<N, HAS_FTIP>(M, C, js, qq, qd, qdd, tq);
   MpBad<mp_f2> bad;  // a non-finite end point makes the generated row non-finite
   bad.add(qq); bad.add(qd); bad.add(qdd);
   float lo[N], hi[N];
@@ -641,13 +641,61 @@ __device__ __forceinline__ void mp_body_traj_id_tab(const MT& M, const MpCall<fl
   }
   MpJointState<float, N> js;
   mp_joint_state<float, N>(M, qq, js);
-  mp_rnea<float, N, HAS_FTIP>(M, C, js, qd, qdd, tq);
+  mp_rnea_row<float, N, HAS_FTIP>(M, C, js, qq, qd, qdd, tq);
 #pragma unroll
   for (int j = 0; j < N; ++j) tq[j] = mp_clip(tq[j], M.taumin[j], M.taumax[j]);
   MpBad<float> bad;  // a non-finite end point makes the generated row non-finite
   bad.add(qq); bad.add(qd); bad.add(qdd);
   mp_poison_if(bad.any(), tq);
   RunIO<float, N>::store_wo(tau, b * Nt + t, tq);
+}
+
+// The same rows taken FLAT, one wave per 64 consecutive rows of the (B, Nt) torque history, tau leaving as whole lines (MpRowStage,
+// non-temporal) instead of per-lane 24-byte runs (PMC on the packed form: 1.036 x the algorithmic bytes written; this one 1.000).
+// row -> (trajectory, timestep) without a division per lane: the wave's first row is divided ON THE SCALAR UNIT by a host-supplied
+// reciprocal (`magic` = floor(2^32 / Nt): one s_mul_hi_u32 and one correction step; rows < 2^32), a lane past the end of that
+// trajectory belongs to the next one (Nt >= 64: at most one wrap per wave).  The last, partial wave stores per lane.
+template <int N, bool HAS_FTIP, typename MT>
+__device__ __forceinline__ void mp_body_traj_id_co(const MT& M, const MpCall<float>& C, const float* __restrict__ start,
+                                                   const float* __restrict__ end, unsigned row0, int lane, unsigned rows, unsigned Nt,
+                                                   unsigned magic, const double* __restrict__ tab, float* __restrict__ tau,
+                                                   char* __restrict__ lds) {
+  using ST = MpRowStage<float, N>;
+  const bool full = rows - row0 >= 64u;  // wave-uniform
+  const bool valid = row0 + (unsigned)lane < rows;
+  unsigned b0 = (unsigned)(((unsigned long long)row0 * magic) >> 32);
+  unsigned t0 = row0 - b0 * Nt;
+  if (t0 >= Nt) { t0 -= Nt; ++b0; }    // scalar compare / select
+  unsigned t = t0 + (valid ? (unsigned)lane : 0u);  // lanes past the end recompute the wave's first row and store nothing
+  unsigned b = b0;
+  if (t >= Nt) { t -= Nt; ++b; }
+  float a[N], e[N];
+  RunIO<float, N>::load(start, (long)b, a);
+  RunIO<float, N>::load(end, (long)b, e);
+  const double s0 = tab[3 * t], sd0 = tab[3 * t + 1], sdd0 = tab[3 * t + 2];
+  float qq[N], qd[N], qdd[N], tq[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const double d = (double)(e[j] - a[j]);  // float32 difference first, as the reference types it
+    qq[j] = mp_clip((float)(s0 * d + (double)a[j]), M.qmin[j], M.qmax[j]);
+    qd[j] = (float)(sd0 * d);
+    qdd[j] = (float)(sdd0 * d);
+  }
+  MpJointState<float, N> js;
+  mp_joint_state<float, N>(M, qq, js);
+  mp_rnea_row<float, N, HAS_FTIP>(M, C, js, qq, qd, qdd, tq);
+#pragma unroll
+  for (int j = 0; j < N; ++j) tq[j] = mp_clip(tq[j], M.taumin[j], M.taumax[j]);
+  MpBad<float> bad;  // a non-finite end point makes the generated row non-finite
+  bad.add(qq); bad.add(qd); bad.add(qdd);
+  mp_poison_if(bad.any(), tq);
+  if (full) {
+    ST::row_out(lds, lane, tq);
+    ST::sync();
+    ST::flush(tau, (long)row0, lane, lds);
+  } else if (valid) {
+    RunIO<float, N>::store_wo(tau, (long)row0 + lane, tq);
+  }
 }
 
 // lane -> (trajectory, timestep pair) for the kernel above: `bpt` blocks of `block` lanes per trajectory

@@ -36,6 +36,7 @@ struct MpSpec {  // run-time specialised kernels of one model on one device
   hipFunction_t traj_id_s[2] = {nullptr, nullptr};                             // generation fused into it, one timestep per lane
   hipFunction_t fd_traj_tm[2] = {nullptr, nullptr};                            // the roll-out on the time-major device layout
   hipFunction_t id_co[2] = {nullptr, nullptr};   // id_s with whole-line non-temporal row movement through LDS (full waves only); optional
+  hipFunction_t traj_id_co[2] = {nullptr, nullptr};  // generation fused into it on flat rows, tau as whole lines; optional
 };
 struct mp_ctx {
   int device = -1;
@@ -1139,7 +1140,7 @@ int mp_model_dof(const mp_model* model, int* n) {
 }
 int mp_model_params(const mp_model* model, double* out) {
   REQUIRE(model && out, "mp_model_params: null argument");
-  static_assert(sizeof(MpJoint<double>) == 16 * sizeof(double), "MpJoint layout");
+  static_assert(sizeof(MpJoint<double>) == MP_JOINT_FIELDS * sizeof(double), "MpJoint layout");  // the first 16 fields are the documented ones
   for (int i = 0; i < model->d.n; ++i) std::memcpy(out + 16 * i, model->big ? &model->bd.j[i] : &model->d.j[i], 16 * sizeof(double));
   return MP_OK;
 }
@@ -1207,6 +1208,9 @@ int mp_model_specialize(mp_ctx* ctx, const mp_model* model) {
   if (hipModuleGetFunction(&sp.id_co[0], sp.mod, "mp_spec_id_co_f0") != hipSuccess ||
       hipModuleGetFunction(&sp.id_co[1], sp.mod, "mp_spec_id_co_f1") != hipSuccess)
     sp.id_co[0] = sp.id_co[1] = nullptr;
+  if (hipModuleGetFunction(&sp.traj_id_co[0], sp.mod, "mp_spec_traj_id_co_f0") != hipSuccess ||
+      hipModuleGetFunction(&sp.traj_id_co[1], sp.mod, "mp_spec_traj_id_co_f1") != hipSuccess)
+    sp.traj_id_co[0] = sp.traj_id_co[1] = nullptr;
   // the second program: same kernels, other scheduling strategy; anything that goes wrong here leaves the first program's
   // versions in place (MANIPULAPY_HIP_ILP_PART=0 skips it)
   {
@@ -1243,15 +1247,12 @@ int mp_model_specialize(mp_ctx* ctx, const mp_model* model) {
     const size_t fb = h.size() * sizeof(float), db = hd.size() * sizeof(double);
     Scratch sc(ctx);
     void *dq, *dz, *d0, *d1, *dqd, *dzd, *d2, *d3;
-    if (int rc = sc.get(fb, &d3)) return rc;
-    if (int rc = sc.get(fb, &dq)) return rc;
-    if (int rc = sc.get(fb, &dz)) return rc;
-    if (int rc = sc.get(fb, &d0)) return rc;
-    if (int rc = sc.get(fb, &d1)) return rc;
-    if (int rc = sc.get(db, &dqd)) return rc;
-    if (int rc = sc.get(db, &dzd)) return rc;
-    if (int rc = sc.get(db, &d2)) return rc;
     auto unload = [&] { if (sp.mod_ilp) (void)hipModuleUnload(sp.mod_ilp); (void)hipModuleUnload(sp.mod); };
+    {  // an allocation that fails (out of memory, an open graph capture) must not leak the two code objects loaded above
+      void** slot[8] = {&d3, &dq, &dz, &d0, &d1, &dqd, &dzd, &d2};
+      for (int k = 0; k < 8; ++k)
+        if (int rc = sc.get(k < 5 ? fb : db, slot[k])) { unload(); return rc; }
+    }
     hipError_t he = hipMemcpyAsync(dq, h.data(), fb, hipMemcpyHostToDevice, ctx->compute);
     if (he == hipSuccess) he = hipMemsetAsync(dz, 0, fb, ctx->compute);
     if (he == hipSuccess) he = hipMemcpyAsync(dqd, hd.data(), db, hipMemcpyHostToDevice, ctx->compute);
@@ -1400,6 +1401,15 @@ int mp_traj_id_fused_f32(mp_ctx* ctx, const mp_model* model, const float* d_star
   if (const MpSpec* sp = find_spec(ctx, model)) {
     long nt = (long)N;
     const double* tab = ctx->time_tab;
+    // default: flat rows, one timestep per lane in scalar arithmetic, tau as whole lines (csrc/mp_bodies.h, mp_body_traj_id_co);
+    // MANIPULAPY_HIP_TRAJ_CO=0 (experiment switch) keeps the two-timesteps-per-lane packed form
+    static const bool traj_co = !(getenv("MANIPULAPY_HIP_TRAJ_CO") && getenv("MANIPULAPY_HIP_TRAJ_CO")[0] == '0');
+    if (traj_co && sp->traj_id_co[ftip ? 1 : 0] && N >= 64 && (unsigned long long)B * (unsigned long long)N < 0xffffffc0ull) {
+      unsigned rows = (unsigned)((unsigned long long)B * (unsigned long long)N), ntu = (unsigned)N;
+      unsigned magic = (unsigned)(0x100000000ull / (unsigned long long)N);
+      void* args[] = {&c, &d_start, &d_end, &ntu, &magic, &tab, &d_tau, &rows};
+      return launch_spec(ctx, sp->traj_id_co[ftip ? 1 : 0], (long)rows, args, 64);
+    }
     if (!mpk_packed_f32()) {  // MANIPULAPY_HIP_F32=scalar: one timestep per lane (measured slower: c2f 0.063 vs 0.054 ms)
       unsigned bpt = (unsigned)((nt + 255) / 256);
       void* args[] = {&c, &d_start, &d_end, &nt, &bpt, &tab, &d_tau};

@@ -139,6 +139,11 @@ MP_HD double mp_max(double a, double b) { return a > b ? a : b; }
 MP_HD mp_f2 mp_min(mp_f2 a, mp_f2 b) { return (a < b) ? a : b; }
 MP_HD mp_f2 mp_max(mp_f2 a, mp_f2 b) { return (a > b) ? a : b; }
 #endif
+MP_HD float mp_abs(float a) { return __builtin_fabsf(a); }
+MP_HD double mp_abs(double a) { return __builtin_fabs(a); }
+#if MP_HAS_PACKED
+MP_HD mp_f2 mp_abs(mp_f2 a) { return __builtin_elementwise_abs(a); }
+#endif
 MP_HD float mp_sqrt(float x) { return sqrtf(x); }
 MP_HD double mp_sqrt(double x) { return sqrt(x); }
 #if MP_HAS_PACKED
@@ -248,6 +253,15 @@ __device__ __forceinline__ const __attribute__((address_space(4))) MpJoint<doubl
 }
 #endif
 
+// The same model as an ordinary (generic address space) object: what a NON-inlined function can take - its arguments arrive in
+// vector registers, where the scalar-register laundering above is not legal; loads become vector loads (cold paths only).
+template <typename MT>
+MP_HD const MT& mp_plain_model(const MT& M) { return M; }
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ const MpModel<float>& mp_plain_model(MpModelConstF& M) { return *(const MpModel<float>*)(&M); }
+__device__ __forceinline__ const MpModel<double>& mp_plain_model(MpModelConstD& M) { return *(const MpModel<double>*)(&M); }
+#endif
+
 // ------------------------------------------------------------------------------ axis-aligned steps
 // Motion vector (w, v), parent -> child coordinates, child pose in parent = (E, r):
 //     w' = E^T w,  v' = E^T (v + w x r).
@@ -328,7 +342,12 @@ MP_HD void mp_joint_state(const MT& M, const T (&q)[N], MpJointState<T, N>& js) 
   for (int i = 0; i < N; ++i) {
     const auto& J = mp_joint_of(M, i);
     const T qr = J.rev * q[i];
-    mp_sincos(J.off + qr, js.s[i], js.c[i]);
+    // sin / cos of off + q through the constant rotation (co, so) - see MpJoint: exact for right-angle offsets (a swap / a sign,
+    // folded away in the robot-specialised kernels), one rounding per product otherwise; q is never added to anything first
+    T s0, c0;
+    mp_sincos(qr, s0, c0);
+    js.s[i] = s0 * J.co + c0 * J.so;
+    js.c[i] = c0 * J.co - s0 * J.so;
     js.d[i] = J.d + (q[i] - qr);
   }
 }
@@ -336,9 +355,11 @@ MP_HD void mp_joint_state(const MT& M, const T (&q)[N], MpJointState<T, N>& js) 
 // Recursive Newton-Euler in the compiled link frames.  tau is NOT clipped here.
 // a0: linear acceleration of the base in the pre-joint-1 frame (= base_R^T (-g)), wave-uniform.
 // tipn / tipf: the tip wrench [moment; force] expressed in the pre-joint-1 frame, per row (ignored unless HAS_FTIP).
-template <typename T, int N, bool HAS_FTIP, typename MT>
-MP_HD void mp_rnea(const MT& M, const typename MpTraits<T>::S (&a0)[3], const T (&tipn)[3], const T (&tipf)[3],
-                   const MpJointState<T, N>& js, const T (&qd)[N], const T (&qdd)[N], T (&tau)[N]) {
+// SCALE: also return the largest joint-wrench moment / force component met on the way back (sN, sF): what a float32 row's
+// rounding errors scale with - mp_id_row_is_hard below compares them with the row's own torques.
+template <typename T, int N, bool HAS_FTIP, bool SCALE, typename MT>
+MP_HD void mp_rnea_impl(const MT& M, const typename MpTraits<T>::S (&a0)[3], const T (&tipn)[3], const T (&tipf)[3],
+                        const MpJointState<T, N>& js, const T (&qd)[N], const T (&qdd)[N], T (&tau)[N], T& sN, T& sF) {
   using S = typename MpTraits<T>::S;
   using TR = MpTraits<T>;
   const T zero = TR::splat(S(0));
@@ -395,10 +416,17 @@ MP_HD void mp_rnea(const MT& M, const typename MpTraits<T>::S (&a0)[3], const T 
     ffx[N - 1] += tfx; ffy[N - 1] += tfy; ffz[N - 1] += tfz;
   }
   // backward pass
+  if (SCALE) { sN = zero; sF = zero; }
 #pragma unroll
   for (int i = N - 1; i >= 0; --i) {
     const auto& J = mp_joint_of(M, i);
     tau[i] = J.rev * fnz[i] + (S(1) - J.rev) * ffz[i];
+    // (joint 0's wrench is left out: only its z component is a torque, the other five - and the last force transform that makes
+    // them - are dead code without this test, ~35 instructions; joint 1's wrench is the same load seen one frame further out)
+    if (SCALE && (i > 0 || N == 1)) {  // |.| are source modifiers, the maxima v_max3_f32: four instructions per joint
+      sN = mp_max(mp_max(mp_max(sN, mp_abs(fnx[i])), mp_abs(fny[i])), mp_abs(fnz[i]));
+      sF = mp_max(mp_max(mp_max(sF, mp_abs(ffx[i])), mp_abs(ffy[i])), mp_abs(ffz[i]));
+    }
     if (i > 0) {
       T nx = fnx[i], ny = fny[i], nz = fnz[i], fx = ffx[i], fy = ffy[i], fz = ffz[i];
       mp_force_up_B(js.c[i], js.s[i], js.d[i], nx, ny, nz, fx, fy, fz);
@@ -407,6 +435,13 @@ MP_HD void mp_rnea(const MT& M, const typename MpTraits<T>::S (&a0)[3], const T 
       ffx[i - 1] += fx; ffy[i - 1] += fy; ffz[i - 1] += fz;
     }
   }
+}
+
+template <typename T, int N, bool HAS_FTIP, typename MT>
+MP_HD void mp_rnea(const MT& M, const typename MpTraits<T>::S (&a0)[3], const T (&tipn)[3], const T (&tipf)[3],
+                   const MpJointState<T, N>& js, const T (&qd)[N], const T (&qdd)[N], T (&tau)[N]) {
+  T sN, sF;
+  mp_rnea_impl<T, N, HAS_FTIP, false>(M, a0, tipn, tipf, js, qd, qdd, tau, sN, sF);
 }
 
 // Same with the wave-uniform per-call constants (gravity + one tip wrench for every row).
@@ -418,6 +453,115 @@ MP_HD void mp_rnea(const MT& M, const MpCall<typename MpTraits<T>::S>& C, const 
   const T tf[3] = {TR::splat(C.F1f[0]), TR::splat(C.F1f[1]), TR::splat(C.F1f[2])};
   mp_rnea<T, N, HAS_FTIP>(M, C.a0, tn, tf, js, qd, qdd, tau);
 }
+
+// ------------------------------------------------------------- float32 rows, adaptive precision
+// A float32 recursion carries ~1 ulp of its LARGEST intermediate terms into every torque.  Almost always that is far inside the
+// parity bound (1e-4 |ref| + 5e-6 max|row|); it is not on the few rows per thousand whose torques are a small difference of large
+// terms - an arm swinging at 10 rad/s whose joint wrenches reach hundreds of N.m while every torque of the row is a few N.m (over
+// c2's 12.3 M rows the plain float32 kernel missed the bound on 76, by up to 4.8 x; with the joint offsets taken exactly - MpJoint
+// co / so - on 1, by 1.3 x).  Such a row announces itself: the largest joint-wrench component the backward pass meets, moments
+// plus forces times the robot's length scale, is more than MP_HARD_ROW_K x the row's largest torque.  Those rows - 0.7 - 1.6 % of
+// c2-distributed rows, in runs of consecutive timesteps, 2 - 5 % of the waves - are evaluated again in float64 from the same
+// float32 inputs (model constants widened, sin / cos in float64).  What stays float32 then sits at <= 0.33 x the bound on 9 M rows
+// of four robots, the float64 rows at <= 0.1 x (profiles/r04_f32_precision_study.txt).  Deterministic: a row's precision depends
+// on that row's values only.
+#ifndef MP_HARD_ROW_K
+#define MP_HARD_ROW_K 16.0f
+#endif
+#ifndef MP_ADAPTIVE_F32   // 0 (experiment switch): plain float32 rows, for A/B measurements of what the test and the float64 rows cost
+#define MP_ADAPTIVE_F32 1
+#endif
+template <int N>
+MP_HD bool mp_id_row_is_hard(const float (&tau)[N], float sN, float sF, float lscale) {
+  float rowmax = 0.0f;
+#pragma unroll
+  for (int i = 0; i < N; ++i) rowmax = mp_max(rowmax, mp_abs(tau[i]));
+  return sN + lscale * sF > MP_HARD_ROW_K * rowmax;   // false for NaN rows: they are poisoned by the callers as before
+}
+
+template <int N> struct MpRowF { float v[N]; };   // a row by value: registers across the call below, never memory
+
+// The float64 evaluation of one float32 row.  INLINED on the device, behind an unlikely branch: the kernels that use it are held
+// to 75 - 110 VGPRs by their launch bounds and this body wants ~170 - inlined it is register-allocated under the kernel's own budget,
+// the block is laid out after s_endpgm and every spill (27 scratch stores / loads at n = 6) lands inside it; the float32 path keeps
+// its registers and its instruction stream (tools/spec_asm.py).  As a real function it would be allocated 180 VGPRs of its own and
+// the KERNEL's allocation is the maximum over its callees (six waves per SIMD -> two), and clang accepts no register cap on a
+// non-kernel function.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MP_COLD __device__ __forceinline__
+#else
+#define MP_COLD static __attribute__((noinline))
+#endif
+template <int N, bool HAS_FTIP, typename MT>
+MP_COLD MpRowF<N> mp_id_row_f64(const MT& M, const MpCall<float>& C, MpRowF<N> q, MpRowF<N> qd, MpRowF<N> qdd) {
+  double a[N], b[N], c[N], t[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) { a[i] = (double)q.v[i]; b[i] = (double)qd.v[i]; c[i] = (double)qdd.v[i]; }
+  MpCall<double> Cd;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { Cd.a0[k] = (double)C.a0[k]; Cd.F1n[k] = (double)C.F1n[k]; Cd.F1f[k] = (double)C.F1f[k]; }
+  MpJointState<double, N> js;
+  mp_joint_state<double, N>(M, a, js);
+  mp_rnea<double, N, HAS_FTIP>(M, Cd, js, b, c, t);
+  MpRowF<N> out;
+#pragma unroll
+  for (int i = 0; i < N; ++i) out.v[i] = (float)t[i];
+  return out;
+}
+
+// tau (unclipped) of one row given its joint state: float64 rows are the recursion itself; float32 rows the float32 recursion,
+// and the float64 one where the row is ill-conditioned
+template <typename T> struct MpIsF32 { static constexpr bool value = false; };
+template <> struct MpIsF32<float> { static constexpr bool value = true; };
+template <typename T, int N, bool HAS_FTIP, typename MT>
+MP_HD void mp_rnea_row(const MT& M, const MpCall<typename MpTraits<T>::S>& C, const MpJointState<T, N>& js, const T (&q)[N],
+                       const T (&qd)[N], const T (&qdd)[N], T (&tau)[N]) {
+  if constexpr (MpIsF32<T>::value && MP_ADAPTIVE_F32) {
+    const float tn[3] = {C.F1n[0], C.F1n[1], C.F1n[2]}, tf[3] = {C.F1f[0], C.F1f[1], C.F1f[2]};
+    float sN, sF;
+    mp_rnea_impl<float, N, HAS_FTIP, true>(M, C.a0, tn, tf, js, qd, qdd, tau, sN, sF);
+    if (__builtin_expect(mp_id_row_is_hard<N>(tau, sN, sF, M.lscale), 0)) {
+      MpRowF<N> a, b, c;
+#pragma unroll
+      for (int i = 0; i < N; ++i) { a.v[i] = q[i]; b.v[i] = qd[i]; c.v[i] = qdd[i]; }
+      const MpRowF<N> t = mp_id_row_f64<N, HAS_FTIP>(mp_plain_model(M), C, a, b, c);
+#pragma unroll
+      for (int i = 0; i < N; ++i) tau[i] = t.v[i];
+    }
+  } else {
+    mp_rnea<T, N, HAS_FTIP>(M, C, js, qd, qdd, tau);
+  }
+}
+#if MP_HAS_PACKED
+// two float32 rows per lane: the same test per row, the float64 evaluation for whichever of the two needs it
+template <int N, bool HAS_FTIP, typename MT>
+MP_HD void mp_rnea_row(const MT& M, const MpCall<float>& C, const MpJointState<mp_f2, N>& js, const mp_f2 (&q)[N],
+                       const mp_f2 (&qd)[N], const mp_f2 (&qdd)[N], mp_f2 (&tau)[N]) {
+  const mp_f2 tn[3] = {(mp_f2)(C.F1n[0]), (mp_f2)(C.F1n[1]), (mp_f2)(C.F1n[2])};
+  const mp_f2 tf[3] = {(mp_f2)(C.F1f[0]), (mp_f2)(C.F1f[1]), (mp_f2)(C.F1f[2])};
+  mp_f2 sN, sF;
+  mp_rnea_impl<mp_f2, N, HAS_FTIP, true>(M, C.a0, tn, tf, js, qd, qdd, tau, sN, sF);
+  float tx[N], ty[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) { tx[i] = tau[i].x; ty[i] = tau[i].y; }
+  if (mp_id_row_is_hard<N>(tx, sN.x, sF.x, M.lscale)) {
+    MpRowF<N> a, b, c;
+#pragma unroll
+    for (int i = 0; i < N; ++i) { a.v[i] = q[i].x; b.v[i] = qd[i].x; c.v[i] = qdd[i].x; }
+    const MpRowF<N> t = mp_id_row_f64<N, HAS_FTIP>(mp_plain_model(M), C, a, b, c);
+#pragma unroll
+    for (int i = 0; i < N; ++i) tau[i].x = t.v[i];
+  }
+  if (mp_id_row_is_hard<N>(ty, sN.y, sF.y, M.lscale)) {
+    MpRowF<N> a, b, c;
+#pragma unroll
+    for (int i = 0; i < N; ++i) { a.v[i] = q[i].y; b.v[i] = qd[i].y; c.v[i] = qdd[i].y; }
+    const MpRowF<N> t = mp_id_row_f64<N, HAS_FTIP>(mp_plain_model(M), C, a, b, c);
+#pragma unroll
+    for (int i = 0; i < N; ++i) tau[i].y = t.v[i];
+  }
+}
+#endif
 
 // A space-frame wrench [m; f] seen from the pre-joint-1 frame: f' = R^T f, n' = R^T (n - p x f)
 // (what mp_make_call does on the host for a per-call wrench; here per row).

@@ -123,7 +123,7 @@ void rows_fk_jac_id(const MpModel<T>& M, const MpCall<T>& C, const T* q, const T
     if (tau) {
       T b[N], c[N], t[N];
       for (int j = 0; j < N; ++j) { b[j] = qd[r * N + j]; c[j] = qdd[r * N + j]; }
-      mp_rnea<T, N, F>(M, C, js, b, c, t);
+      mp_rnea_row<T, N, F>(M, C, js, a, b, c, t);
       for (int j = 0; j < N; ++j) t[j] = mp_clip(t[j], M.taumin[j], M.taumax[j]);
       bad.add(b); bad.add(c);
       mp_poison_if(bad.any(), t);
@@ -282,6 +282,33 @@ int mp_id_trajectory_cpu_f64(const mp_model* model, const double* q, const doubl
                              const double* g, const double* Ftip, double* tau, int nthreads) {
   if (rows > 0 && !tau) return fail("mp_id_trajectory_cpu_f64: null tau");
   return fk_jac_id_cpu<double>("mp_id_trajectory_cpu_f64: null pointer", model, q, qd, qdd, rows, g, Ftip, nullptr, nullptr, tau, nthreads);
+}
+// which rows the float32 inverse-dynamics kernels evaluate in float64 (mp_core.h, mp_id_row_is_hard): 1 per such row
+int mp_id_row_precision_cpu_f32(const mp_model* model, const float* q, const float* qd, const float* qdd, int64_t rows,
+                                const double* g, const double* Ftip, uint8_t* in_f64, int nthreads) {
+  if (!model) return fail("mp_id_row_precision_cpu_f32: null model");
+  if (rows < 0) return fail("mp_id_row_precision_cpu_f32: negative row count");
+  if (rows == 0) return MP_OK;
+  if (!q || !qd || !qdd || !in_f64) return fail("mp_id_row_precision_cpu_f32: null pointer");
+  if (model->big) return fail("mp_id_row_precision_cpu_f32: models of more than 8 joints run the looped kernels, which stay float32");
+  const MpModel<float>& M = model->f;
+  const MpCall<float> C = make_call<float>(model, g, Ftip);
+  const bool ftip = any_nonzero(Ftip);
+  MP_CPU_DISPATCH(M.n, {
+    parallel_for(rows, 256, nthreads, [&](int64_t lo, int64_t hi) {
+      const float tn[3] = {C.F1n[0], C.F1n[1], C.F1n[2]}, tf[3] = {C.F1f[0], C.F1f[1], C.F1f[2]};
+      for (int64_t r = lo; r < hi; ++r) {
+        float a[N], b[N], c[N], t[N], sN, sF;
+        for (int j = 0; j < N; ++j) { a[j] = q[r * N + j]; b[j] = qd[r * N + j]; c[j] = qdd[r * N + j]; }
+        MpJointState<float, N> js;
+        mp_joint_state<float, N>(M, a, js);
+        if (ftip) mp_rnea_impl<float, N, true, true>(M, C.a0, tn, tf, js, b, c, t, sN, sF);
+        else mp_rnea_impl<float, N, false, true>(M, C.a0, tn, tf, js, b, c, t, sN, sF);
+        in_f64[r] = mp_id_row_is_hard<N>(t, sN, sF, M.lscale) ? 1 : 0;
+      }
+    });
+  })
+  return MP_OK;
 }
 int mp_fk_jac_id_cpu_f64(const mp_model* model, const double* q, const double* qd, const double* qdd, int64_t rows,
                          const double* g, const double* Ftip, double* T, double* J, double* tau, int nthreads) {

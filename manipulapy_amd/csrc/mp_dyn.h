@@ -27,7 +27,10 @@ MP_HD void mp_dyn_joint_state(const MT& M, int n, const T* q, MpDynState<T>& js)
   for (int i = 0; i < n; ++i) {
     const auto& J = M.j[i];
     const T qr = J.rev * q[i];
-    mp_sincos(J.off + qr, js.s[i], js.c[i]);
+    T s0, c0;  // the offset enters as a constant rotation of (sin q, cos q), never as a sum with q (MpJoint::co / so)
+    mp_sincos(qr, s0, c0);
+    js.s[i] = s0 * J.co + c0 * J.so;
+    js.c[i] = c0 * J.co - s0 * J.so;
     js.d[i] = J.d + (q[i] - qr);
   }
 }

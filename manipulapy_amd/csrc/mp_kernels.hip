@@ -100,7 +100,7 @@ __global__ __launch_bounds__(kBlock) void k_traj_id(const MpModel<float> M, cons
   traj_row<N>(M, start, end, b, t, Nt, Tf, method, p, v, a);
   MpJointState<float, N> js;
   mp_joint_state<float, N>(M, p, js);
-  mp_rnea<float, N, HAS_FTIP>(M, C, js, v, a, tq);
+  mp_rnea_row<float, N, HAS_FTIP>(M, C, js, p, v, a, tq);
 #pragma unroll
   for (int j = 0; j < N; ++j) tq[j] = mp_clip(tq[j], M.taumin[j], M.taumax[j]);
   MpBad<float> bad;

@@ -25,17 +25,26 @@ struct MpJoint {
   T ca, sa;    // cos / sin of alpha_i  (rotation about parent x)
   T a;         // shift along parent x
   T d;         // shift along own z at q = 0
-  T off;       // joint-angle offset (rotation about own z at q = 0)
+  T off;       // joint-angle offset (rotation about own z at q = 0): host-side only (self-check FK); the kernels use co / so
   T rev;       // 1 = revolute, 0 = prismatic
   T m;         // link mass
   T hx, hy, hz;                       // first moment m * c (c = CoM in link frame)
   T Ixx, Ixy, Ixz, Iyy, Iyz, Izz;     // rotational inertia about the link-frame ORIGIN
+  // cos / sin of `off`, exact 0 / +-1 at right angles.  The per-row code takes sin / cos of the joint variable ALONE and turns
+  // the result by this constant rotation instead of adding `off` to the angle first: a float32 sum off + q is rounded at the
+  // spacing of the SUM (up to 2.4e-7 rad for |off + q| in [4, 8)), an error the link lengths and gravity torques multiply by
+  // hundreds of N.m - it was the whole of the float32 kernels' distance from the 1e-4 |ref| + 5e-6 max|row| bound on rows whose
+  // torque is a small difference of large terms (profiles/r04_f32_precision_study.txt); q itself is exact.
+  T co, so;
 };
+constexpr int MP_JOINT_FIELDS = 18;
 
 template <typename T, int CAP>
 struct MpModelT {
   int n;
-  int pad_[3];
+  float lscale;  // the robot's length scale, max_i (|a_i| + |d_i|): weighs joint forces against moments in the float32 kernels'
+                 // conditioning test (mp_core.h, mp_id_row_is_hard); float whatever T is
+  int pad_[2];
   T base_R[9];   // pose of link frame 1 (at q1 = 0, before its own Rz/Tz) in the space frame
   T base_p[3];
   T tool_R[9];   // end-effector home pose M_ee in link frame n

@@ -194,6 +194,7 @@ int compile_model(int n, const double* S, const double* Mcom, const double* G, c
   for (int i = 0; i < n; ++i) {
     MpJoint<double>& j = out->j[i];
     j.rev = rev[i] ? 1.0 : 0.0;
+    j.co = 1; j.so = 0;
     if (i == 0) { j.ca = 1; j.sa = 0; j.a = 0; j.d = 0; j.off = 0; continue; }
     double R[9], p[3];
     rel(H[i - 1], H[i], R, p);
@@ -214,6 +215,8 @@ int compile_model(int n, const double* S, const double* Mcom, const double* G, c
     if (std::fabs(j.a) < 1e-14) j.a = 0;
     if (std::fabs(j.d) < 1e-14) j.d = 0;
     if (std::fabs(j.off) < 1e-14) j.off = 0;
+    j.co = std::cos(j.off); j.so = std::sin(j.off);
+    snap(j.co); snap(j.so);
   }
 
   // ---- 4. link inertias about the link-frame origin
@@ -257,6 +260,12 @@ int compile_model(int n, const double* S, const double* Mcom, const double* G, c
     j.m = m; j.hx = m * cp[0]; j.hy = m * cp[1]; j.hz = m * cp[2];
     j.Ixx = Io[0]; j.Ixy = 0.5 * (Io[1] + Io[3]); j.Ixz = 0.5 * (Io[2] + Io[6]);
     j.Iyy = Io[4]; j.Iyz = 0.5 * (Io[5] + Io[7]); j.Izz = Io[8];
+  }
+
+  {  // length scale for the float32 kernels' conditioning test: the longest joint-to-joint offset (never zero)
+    double L = 0;
+    for (int i = 0; i < n; ++i) L = std::fmax(L, std::fabs(out->j[i].a) + std::fabs(out->j[i].d));
+    out->lscale = (float)std::fmax(L, 1e-3);
   }
 
   // ---- 5. tool frame, limits

@@ -24,7 +24,8 @@ inline void mp_make_call(const MpModelT<double, CAP>& m, const double g[3], cons
 template <typename T, int SC, int DC>
 inline void mp_model_cast(const MpModelT<double, SC>& s, MpModelT<T, DC>* d) {
   d->n = s.n;
-  d->pad_[0] = d->pad_[1] = d->pad_[2] = 0;
+  d->lscale = s.lscale;
+  d->pad_[0] = d->pad_[1] = 0;
   for (int k = 0; k < 9; ++k) { d->base_R[k] = (T)s.base_R[k]; d->tool_R[k] = (T)s.tool_R[k]; }
   for (int k = 0; k < 3; ++k) { d->base_p[k] = (T)s.base_p[k]; d->tool_p[k] = (T)s.tool_p[k]; }
   for (int i = 0; i < DC; ++i) {
@@ -33,6 +34,7 @@ inline void mp_model_cast(const MpModelT<double, SC>& s, MpModelT<T, DC>* d) {
     const bool in = i < SC;
     b.ca = in ? (T)a.ca : T(0); b.sa = in ? (T)a.sa : T(0); b.a = in ? (T)a.a : T(0); b.d = in ? (T)a.d : T(0);
     b.off = in ? (T)a.off : T(0); b.rev = in ? (T)a.rev : T(0);
+    b.co = in ? (T)a.co : T(1); b.so = in ? (T)a.so : T(0);
     b.m = in ? (T)a.m : T(0); b.hx = in ? (T)a.hx : T(0); b.hy = in ? (T)a.hy : T(0); b.hz = in ? (T)a.hz : T(0);
     b.Ixx = in ? (T)a.Ixx : T(0); b.Ixy = in ? (T)a.Ixy : T(0); b.Ixz = in ? (T)a.Ixz : T(0);
     b.Iyy = in ? (T)a.Iyy : T(0); b.Iyz = in ? (T)a.Iyz : T(0); b.Izz = in ? (T)a.Izz : T(0);

@@ -1763,39 +1763,46 @@ def test_transpose_rows_and_time_major_edge_cases(tables):
         ctx.destroy()
 
 
-def test_id_f32_large_random_sample_two_level_bound(tables):
-    """300 000 rows of config c2's own input distribution (start / end uniform over UR5's +-2 pi limits, quintic, Tf = 2:
-    velocities up to 12 rad/s) through the generic and the robot-specialised float32 kernels against the pinned C oracle,
-    with the bound bench.py asserts on every run: 1e-4 |ref| + 5e-6 max|row| element-wise, and for the few rows per
-    hundred thousand whose torque is a small difference of large gravity / velocity-product terms (the only ones that miss
-    it) an excess below 4 x what one float32 ulp in each input changes.  Fourteen rows per robot cannot meet such rows;
-    this sample does."""
+@pytest.mark.parametrize("robot", ROBOTS)
+def test_id_large_random_sample_every_row_inside_the_bound(robot, tables):
+    """300 000 rows of config c2's own input distribution (start / end uniform over the joint limits, quintic, Tf = 2: velocities
+    up to 12 rad/s) through the generic and the robot-specialised kernels, the fused kernel included, against the pinned C oracle.
+    EVERY row inside the suite's element-wise bound - float32 1e-4 |ref| + 5e-6 max|row| with room to spare (<= 0.6 x), float64
+    1e-6 |ref| + 1e-7 + 4e-9 |qd|^2 (the oracle's finite-difference noise at these speeds, bench.parity_rows).  Round 3 needed a
+    second, fitted allowance here for the rows whose torque is a small difference of large terms; since round 4 the float32
+    kernels take joint offsets exactly and evaluate those rows in float64 (csrc/mp_core.h, mp_rnea_row): the rows the product
+    itself reports as float64 (mp_id_row_precision_cpu_f32) must land at <= 0.2 x the bound."""
     import bench
     from manipulapy_amd import _hip
     from oracle import c_oracle
 
-    tab = tables["ur5"]
+    tab = tables[robot]
+    n = tab.n
     lim = tab.joint_limits
     rng = np.random.default_rng(20260705 + 2)
-    s_ = rng.uniform(lim[:, 0], lim[:, 1], (300, 6)).astype(np.float32)
-    e_ = rng.uniform(lim[:, 0], lim[:, 1], (300, 6)).astype(np.float32)
+    s_ = rng.uniform(lim[:, 0], lim[:, 1], (300, n)).astype(np.float32)
+    e_ = rng.uniform(lim[:, 0], lim[:, 1], (300, n)).astype(np.float32)
     o = ref.batch_joint_trajectory(lim, s_, e_, 2.0, 1000, 5)
-    q, qd, qdd = (o[k].reshape(-1, 6) for k in ("positions", "velocities", "accelerations"))
+    q, qd, qdd = (np.ascontiguousarray(o[k].reshape(-1, n), dtype=np.float32) for k in ("positions", "velocities", "accelerations"))
     want = c_oracle.inverse_dynamics_rows(tab, q.astype(np.float64), qd.astype(np.float64), qdd.astype(np.float64))[0]
-    terms = bench.id_sensitivity(tab, q, qd, qdd)
+    tol = 1e-4 * np.abs(want) + 5e-6 * np.abs(want).max(axis=1, keepdims=True)
     ctx = _hip.HipContext(0)
     try:
         for specialise in (False, True):
             m = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee, lim)
             if specialise:
                 ctx.specialize(m)
-            tau = ctx.id_trajectory_host(m, q, qd, qdd, dtype=np.float32)
-            par = bench.parity_rows(tau, want, "f32", terms)
-            assert par["ok"], (specialise, par)
-            assert par["rows_over_first_bound"] <= 30, par   # a handful in 300 000; a broken recursion fails by the thousand
-            fused = ctx.traj_id_fused_host(m, s_, e_, 2.0, 1000, 5).reshape(-1, 6)
-            par = bench.parity_rows(fused, want, "f32", terms)
-            assert par["ok"] and par["rows_over_first_bound"] <= 30, (specialise, par)
+            in_f64 = _hip.cpu_id_row_precision(m, q, qd, qdd)
+            for name, tau in (("id", ctx.id_trajectory_host(m, q, qd, qdd, dtype=np.float32)),
+                              ("fused", ctx.traj_id_fused_host(m, s_, e_, 2.0, 1000, 5).reshape(-1, n))):
+                par = bench.parity_rows(tau, want, "f32")
+                assert par["ok"] and par["rows_over_first_bound"] == 0 and par["worst_over_tol"] <= 0.6, (robot, specialise, name, par)
+                if in_f64.any():
+                    r = (np.abs(tau[in_f64].astype(np.float64) - want[in_f64]) / tol[in_f64]).max()
+                    assert r <= 0.2, (robot, specialise, name, float(r), int(in_f64.sum()))
+            t64 = ctx.id_trajectory_host(m, q.astype(np.float64), qd.astype(np.float64), qdd.astype(np.float64), dtype=np.float64)
+            par = bench.parity_rows(t64, want, "f64", qd=qd)
+            assert par["ok"], (robot, specialise, "f64", par)
     finally:
         ctx.destroy()
 
@@ -2098,14 +2105,22 @@ def test_mass_matrix_store_paths_every_n_and_tail():
 @pytest.mark.parametrize("robot", ["ur5", "panda7", "panda"])
 def test_whole_line_inverse_dynamics_kernel_edges(robot):
     """mp_spec_id_co (rows >= 64 of a specialised float32 model move as whole lines, non-temporal, through LDS; the last < 64 rows
-    take the per-lane kernel): n = 6 / 7 / 8, row counts around the 64-row wave and the 256-row block, against the CPU launcher;
-    rows on either side of the hand-over; a NaN / inf row inside a full wave poisons only itself; device pointers at odd multiples
-    of 16 bytes; nothing is written past the end."""
+    take the per-lane kernel): n = 6 / 7 / 8, row counts around the 64-row wave and the 256-row block, against the PINNED C ORACLE
+    (oracle/oracle.c - not the product's own CPU launcher, which shares the kernels' templates); rows on either side of the
+    hand-over; a NaN / inf row inside a full wave poisons only itself; device pointers at odd multiples of 16 bytes; nothing is
+    written past the end."""
+    import bench
     import manipulapy_amd as mp
     from manipulapy_amd import _hip
+    from oracle import c_oracle
 
     t = mp.robot_tables(robot)
+    tab = bench.oracle_tables(ref, robot)
     n = t["S_list"].shape[1]
+
+    def oracle(q, qd, qdd, wrench=None):
+        return c_oracle.inverse_dynamics_rows(tab, q.astype(np.float64), qd.astype(np.float64), qdd.astype(np.float64), None, wrench)[0]
+
     ctx = _hip.HipContext(0)
     try:
         model = _hip.HipModel(t["S_list"], t["Mlist_per_link"], t["Glist"], t["M_ee"], t["joint_limits"])
@@ -2115,9 +2130,8 @@ def test_whole_line_inverse_dynamics_kernel_edges(robot):
         for rows in (1, 63, 64, 65, 127, 128, 129, 255, 256, 257, 1000, 4096 + 77):
             q, qd, qdd = (rng.uniform(-1.5, 1.5, (rows, n)).astype(np.float32) for _ in range(3))
             for wrench in (None, F):
-                want = _hip.cpu_id_trajectory(model, q, qd, qdd, None, wrench, dtype=np.float32)
                 got = ctx.id_trajectory_host(model, q, qd, qdd, None, wrench, dtype=np.float32)
-                assert_f32(got, want.astype(np.float64))
+                assert_f32(got, oracle(q, qd, qdd, wrench))
         # a non-finite row inside a full wave, and one in the per-lane tail
         rows = 64 * 3 + 20
         q, qd, qdd = (rng.uniform(-1, 1, (rows, n)).astype(np.float32) for _ in range(3))
@@ -2141,7 +2155,7 @@ def test_whole_line_inverse_dynamics_kernel_edges(robot):
         raw = d_tau.download((nb + 4096,), np.uint8)
         assert (raw[:16] == 0x5A).all() and (raw[16 + nb:] == 0x5A).all()
         got = raw[16:16 + nb].view(np.float32).reshape(rows, n)
-        assert_f32(got, _hip.cpu_id_trajectory(model, q, qd, qdd, dtype=np.float32).astype(np.float64))
+        assert_f32(got, oracle(q, qd, qdd))
     finally:
         ctx.destroy()
 
@@ -2165,8 +2179,9 @@ def test_planner_benchmark_helpers_on_the_gpu():
 @pytest.mark.parametrize("n", [1, 2, 3, 4, 5])
 def test_whole_line_kernel_small_joint_counts(n):
     """mp_spec_id_co for 1..5 joints (4..20-byte rows: 16..80 chunks per wave and array, partly filled chunk instructions) on random
-    chains: rows through the whole-line kernel and the per-lane tail against the CPU launcher, with and without a tip wrench."""
+    chains: rows through the whole-line kernel and the per-lane tail against the pinned C oracle, with and without a tip wrench."""
     from manipulapy_amd import _hip
+    from oracle import c_oracle
     from test_random_robots import FLAVOURS, random_robot
 
     rng = np.random.default_rng(500 + n)
@@ -2178,7 +2193,7 @@ def test_whole_line_kernel_small_joint_counts(n):
         for rows in (64, 64 * 7 + 5, 2048 + 63):
             q, qd, qdd = (rng.uniform(-1.5, 1.5, (rows, n)).astype(np.float32) for _ in range(3))
             for wrench in (None, np.array([0.5, -1.0, 0.25, 2.0, -1.5, 0.75])):
-                want = _hip.cpu_id_trajectory(model, q, qd, qdd, None, wrench, dtype=np.float32)
+                want = c_oracle.inverse_dynamics_rows(tab, q.astype(np.float64), qd.astype(np.float64), qdd.astype(np.float64), None, wrench)[0]
                 got = ctx.id_trajectory_host(model, q, qd, qdd, None, wrench, dtype=np.float32)
                 # (a one- or two-value row has no "row scale" to hold its cancellations against: the batch's scale is the floor here)
                 np.testing.assert_allclose(got, want, rtol=1e-4, atol=5e-6 * float(np.abs(want).max()))

@@ -2,6 +2,7 @@
 # A/B of c5 roll-out kernel variants on ONE box, interleaved over several rounds (the kernel is power-limited: the same
 # build measures 0.54 - 0.65 ms from run to run, so variants are alternated and min / median reported).
 # usage: tools/ab_c5.sh "name1|defines1|flags1" "name2|defines2|flags2" ...
+export MANIPULAPY_HIP_EXPERIMENT=1  # JIT_DEFINES / JIT_FLAGS are honoured only with this
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 ROUNDS=${ROUNDS:-5}
 OUT=$(mktemp)

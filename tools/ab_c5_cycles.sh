@@ -1,6 +1,7 @@
 #!/bin/bash
 # A/B of c5 roll-out kernel variants in CYCLES (GRBM_GUI_ACTIVE / 8 XCDs per launch, immune to the clock the box happens to
 # hold) plus the wave-cycle split.  usage: tools/ab_c5_cycles.sh "name|defines" ...
+export MANIPULAPY_HIP_EXPERIMENT=1  # JIT_DEFINES / JIT_FLAGS are honoured only with this
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 for spec in "$@"; do

@@ -1,5 +1,6 @@
 #!/bin/bash
 # roll-out kernel by robot (row size): default build vs switches given as JIT defines.  usage: tools/ab_c5_robots2.sh "name|defines" ...
+export MANIPULAPY_HIP_EXPERIMENT=1  # JIT_DEFINES / JIT_FLAGS are honoured only with this
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 for robot in ${ROBOTS:-xarm6 panda7 panda ur5 iiwa14}; do
   for round in 1 2 3; do

@@ -1,5 +1,6 @@
 #!/bin/bash
 # c3 (fp64 FK + Jacobian + ID): non-temporal cooperative stores, whole-line non-temporal inputs / tau, both
+export MANIPULAPY_HIP_EXPERIMENT=1  # JIT_DEFINES / JIT_FLAGS are honoured only with this
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 for round in 1 2 3 4 5 6; do for f in "plain|MANIPULAPY_HIP_JIT_DEFINES=MP_COOP_NT=0,MP_FK_CO=0" "coop_nt|MANIPULAPY_HIP_JIT_DEFINES=MP_FK_CO=0" "fk_co|MANIPULAPY_HIP_JIT_DEFINES=MP_COOP_NT=0" "both|MANIPULAPY_X=0"; do
 IFS='|' read -r name kv <<< "$f"

@@ -1,5 +1,6 @@
 #!/bin/bash
 # A/B of extra hiprtc flags on several configs, interleaved: tools/ab_flags.sh "<flags>" cfg1 cfg2 ...   (flags comma-separated)
+export MANIPULAPY_HIP_EXPERIMENT=1  # JIT_DEFINES / JIT_FLAGS are honoured only with this
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 FLAGS="$1"; shift
 for cfg in "$@"; do

@@ -1,5 +1,6 @@
 #!/bin/bash
 # sample the card's power / clocks while a config runs its sustained loop: tools/power_probe.sh <config> [steps] [JIT defines]
+export MANIPULAPY_HIP_EXPERIMENT=1  # JIT_DEFINES / JIT_FLAGS are honoured only with this
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 CFG=${1:-c5}; STEPS=${2:-4000}; export MANIPULAPY_HIP_JIT_DEFINES="${3:-}"
 python $R/bench.py --config $CFG --steps $STEPS --warmup 5 --no-cpu-baseline > /tmp/pp_bench.txt 2>/dev/null &

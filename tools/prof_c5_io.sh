@@ -1,5 +1,6 @@
 #!/bin/bash
 # PMC passes that split the roll-out kernel's memory-side stalls: tools/prof_c5_io.sh <outdir-name> [JIT defines]
+export MANIPULAPY_HIP_EXPERIMENT=1  # JIT_DEFINES / JIT_FLAGS are honoured only with this
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/${1:-prof_c5_io}; D=${2:-}
 mkdir -p $OUT

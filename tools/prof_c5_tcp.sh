@@ -1,5 +1,6 @@
 #!/bin/bash
 # PMC passes on the cache side of the roll-out kernel (L1 = TCP, L2 = TCC): tools/prof_c5_tcp.sh <outdir-name> [JIT defines]
+export MANIPULAPY_HIP_EXPERIMENT=1  # JIT_DEFINES / JIT_FLAGS are honoured only with this
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/${1:-prof_c5_tcp}; D=${2:-}
 mkdir -p $OUT

@@ -1,5 +1,6 @@
 #!/bin/bash
 # FETCH_SIZE / WRITE_SIZE of a config with given JIT defines: tools/prof_traffic.sh <config> <outdir-name> [defines]
+export MANIPULAPY_HIP_EXPERIMENT=1  # JIT_DEFINES / JIT_FLAGS are honoured only with this
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 CFG=${1:-c5}; OUT=$R/gpurun_out/${2:-traffic_$CFG}; export MANIPULAPY_HIP_JIT_DEFINES="${3:-}"
 mkdir -p $OUT; cd /tmp && export TMPDIR=/tmp
