@@ -138,22 +138,67 @@ __device__ __forceinline__ void traj_row(const MT& M, const float* __restrict__ 
 }
 
 
+// ------------------------------------------------------------ the float64 re-evaluation, wave by wave
+// Rows whose float32 result is ill-conditioned (`hard`, mp_rnea_f32) are evaluated again by mp_rnea_cold with the per-joint state
+// in LDS: `lds` is MpColdLds<N, G>::BYTES bytes that belong to this wave alone, G lanes work at a time (slot = the lane's rank among
+// the wave's flagged lanes), the others wait; a wave without a flagged row leaves at the first branch.  `load` hands a lane its
+// row's inputs again (from global memory, or regenerated) - the float32 pass does not keep them in registers for this.  tau is
+// replaced for the flagged lanes only (unclipped).
+template <int N, int G>
+struct MpColdLds { static constexpr int BYTES = G * MpColdSlot<N>::BYTES; };
+constexpr int MP_COLD_G = 8;  // slots of the kernels that carry a buffer of their own (256-thread blocks: one buffer per wave)
+// that buffer, declared in a kernel of BLOCK threads (float32 rows only: W = sizeof(T)), and this wave's part of it
+#define MP_COLD_BUFFER(N, BLOCK, W) \
+  __shared__ __attribute__((aligned(16))) char mp_cold_lds[(BLOCK) / 64][(W) == 4 ? MpColdLds<N, MP_COLD_G>::BYTES : 16]
+#define MP_COLD_PTR (mp_cold_lds[threadIdx.x >> 6])
+
+template <int N, bool HAS_FTIP, int G, typename MT, typename LoadFn>
+__device__ __forceinline__ void mp_cold_rows(const MT& M, const MpCall<float>& C, bool hard, char* __restrict__ lds, LoadFn load,
+                                             float (&tau)[N]) {
+#if MP_ADAPTIVE_F32
+  const unsigned long long mask = __builtin_amdgcn_ballot_w64(hard);
+  if (__builtin_expect(mask == 0ull, 1)) return;  // wave-uniform
+  const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+  const int total = __builtin_popcountll(mask);
+  for (int base = 0; base < total; base += G) {  // wave-uniform trip count
+    const int slot = rank - base;
+    if (hard && slot >= 0 && slot < G) {
+      float q[N], qd[N], qdd[N];
+      load(q, qd, qdd);
+      MpColdMem<N> st{lds + slot * MpColdSlot<N>::BYTES};
+#if defined(MP_COLD_MODEL)   // robot-specialised program: the float64 literal of the same robot
+      mp_rnea_cold<N, HAS_FTIP>(MP_COLD_MODEL, C, q, qd, qdd, st, tau);
+#else
+      mp_rnea_cold<N, HAS_FTIP>(M, C, q, qd, qdd, st, tau);
+#endif
+    }
+  }
+#endif
+}
+
 // ------------------------------------------------------------------ one row per lane (float / double)
-// tau for row `r`: the body of k_id
+// tau for row `r`: the body of k_id.  `cold`: this wave's MpColdLds<N, MP_COLD_G> buffer (float rows only; unused for double).
 template <typename T, int N, bool HAS_FTIP, typename MT>
 __device__ __forceinline__ void mp_body_id(const MT& M, const MpCall<T>& C, const T* __restrict__ q, const T* __restrict__ qd,
-                                           const T* __restrict__ qdd, T* __restrict__ tau, long r) {
+                                           const T* __restrict__ qdd, T* __restrict__ tau, long r, char* __restrict__ cold = nullptr) {
   T a[N], b[N], c[N], t[N];
   RunIO<T, N>::load(q, r, a);
   RunIO<T, N>::load(qd, r, b);
   RunIO<T, N>::load(qdd, r, c);
   MpJointState<T, N> js;
   mp_joint_state<T, N>(M, a, js);
-  mp_rnea_row<T, N, HAS_FTIP>(M, C, js, a, b, c, t);
-#pragma unroll
-  for (int j = 0; j < N; ++j) t[j] = mp_clip(t[j], M.taumin[j], M.taumax[j]);
   MpBad<T> bad;  // a NaN / inf anywhere in the row's inputs -> a NaN row, as the reference returns (mp_core.h)
   bad.add(a); bad.add(b); bad.add(c);
+  if constexpr (MpIsF32<T>::value) {
+    const bool hard = mp_rnea_f32<N, HAS_FTIP>(M, C, js, b, c, t) && !bad.any();
+    mp_cold_rows<N, HAS_FTIP, MP_COLD_G>(M, C, hard, cold, [&](float (&x)[N], float (&y)[N], float (&z)[N]) {
+      RunIO<float, N>::load(q, r, x); RunIO<float, N>::load(qd, r, y); RunIO<float, N>::load(qdd, r, z);
+    }, t);
+  } else {
+    mp_rnea<T, N, HAS_FTIP>(M, C, js, b, c, t);
+  }
+#pragma unroll
+  for (int j = 0; j < N; ++j) t[j] = mp_clip(t[j], M.taumin[j], M.taumax[j]);
   mp_poison_if(bad.any(), t);
   RunIO<T, N>::store(tau, r, t);
 }
@@ -223,16 +268,42 @@ __device__ __forceinline__ void mp_body_id_co(const MT& M, const MpCall<T>& C, c
   ST::row_in(lds + 2 * ST::SPAN, lane, c);
   MpJointState<T, N> js;
   mp_joint_state<T, N>(M, a, js);
-  mp_rnea_row<T, N, HAS_FTIP>(M, C, js, a, b, c, t);
-#pragma unroll
-  for (int j = 0; j < N; ++j) t[j] = mp_clip(t[j], M.taumin[j], M.taumax[j]);
   MpBad<T> bad;  // the non-finite row contract of mp_body_id
   bad.add(a); bad.add(b); bad.add(c);
-  mp_poison_if(bad.any(), t);
+  const bool poison = bad.any();
+  bool hard = false;
+  if constexpr (MpIsF32<T>::value) hard = mp_rnea_f32<N, HAS_FTIP>(M, C, js, b, c, t) && !poison;
+  else mp_rnea<T, N, HAS_FTIP>(M, C, js, b, c, t);
+#pragma unroll
+  for (int j = 0; j < N; ++j) t[j] = mp_clip(t[j], M.taumin[j], M.taumax[j]);
+  mp_poison_if(poison, t);
   ST::sync();  // every lane has read its rows: the first region is free
   ST::row_out(lds, lane, t);
   ST::sync();
   ST::flush(tau, row0, lane, lds);
+  if constexpr (MpIsF32<T>::value) {
+    // ill-conditioned rows again, in float64, AFTER the wave's float32 rows have left: the whole slice is free for their state
+    // (12 lanes at a time), the inputs come back from memory and the result overwrites the row's 4 N bytes.  Rare (a few per
+    // cent of the waves take the branch at all), so the order of the two stores to the same bytes is made explicit.
+    if (__builtin_amdgcn_ballot_w64(hard) != 0ull) {
+      ST::sync();
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      constexpr int G = ST::BYTES / MpColdSlot<N>::BYTES;
+      static_assert(G >= 8, "the wave's row slice holds at least eight re-evaluation slots");
+      // the row index is made opaque here: otherwise the per-lane addresses below are computed once at the top of the kernel,
+      // shared with the fetch, and kept alive (or spilled) across the whole float32 pass for the sake of this branch
+      long rr = row0 + lane;
+      asm volatile("" : "+v"(rr));
+      mp_cold_rows<N, HAS_FTIP, G>(M, C, hard, lds, [&](float (&x)[N], float (&y)[N], float (&z)[N]) {
+        RunIO<float, N>::load(q, rr, x); RunIO<float, N>::load(qd, rr, y); RunIO<float, N>::load(qdd, rr, z);
+      }, t);
+      if (hard) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) t[j] = mp_clip(t[j], M.taumin[j], M.taumax[j]);
+        RunIO<float, N>::store(tau, rr, t);
+      }
+    }
+  }
 }
 
 // qdd for row `r` = forward_dynamics(q, qd, tau, g, F) with one wrench for every row: the body of k_forward_dynamics
@@ -466,10 +537,12 @@ __device__ __forceinline__ void mp_body_fk_jac_id(const MT& M, const MpCall<T>& 
       RunIO<T, N>::load(qd, rr, b);
       RunIO<T, N>::load(qdd, rr, c);
     }
-    mp_rnea_row<T, N, HAS_FTIP>(M, C, js, a, b, c, t);
+    bad.add(b); bad.add(c);
+    bool hard = false;
+    if constexpr (MpIsF32<T>::value) hard = mp_rnea_f32<N, HAS_FTIP>(M, C, js, b, c, t) && !bad.any() && valid;
+    else mp_rnea<T, N, HAS_FTIP>(M, C, js, b, c, t);
 #pragma unroll
     for (int j = 0; j < N; ++j) t[j] = mp_clip(t[j], M.taumin[j], M.taumax[j]);
-    bad.add(b); bad.add(c);
     mp_poison_if(bad.any(), t);
     if (full) {
       ST::row_out(lds, lane, t);
@@ -477,6 +550,21 @@ __device__ __forceinline__ void mp_body_fk_jac_id(const MT& M, const MpCall<T>& 
       ST::flush(tau, row0, lane, lds);
     } else if (valid) {
       RunIO<T, N>::store(tau, r, t);
+    }
+    if constexpr (MpIsF32<T>::value) {  // ill-conditioned float32 rows again in float64, after the wave's rows have left (see mp_body_id_co)
+      if (__builtin_amdgcn_ballot_w64(hard) != 0ull) {
+        ST::sync();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        constexpr int G = MP_WAVE_LDS_BYTES / MpColdSlot<N>::BYTES;
+        mp_cold_rows<N, HAS_FTIP, G>(M, C, hard, lds, [&](float (&x)[N], float (&y)[N], float (&z)[N]) {
+          RunIO<float, N>::load(q, rr, x); RunIO<float, N>::load(qd, rr, y); RunIO<float, N>::load(qdd, rr, z);
+        }, t);
+        if (hard) {
+#pragma unroll
+          for (int j = 0; j < N; ++j) t[j] = mp_clip(t[j], M.taumin[j], M.taumax[j]);
+          RunIO<float, N>::store(tau, r, t);
+        }
+      }
     }
   }
 }
@@ -503,20 +591,51 @@ __device__ __forceinline__ void store_pair(float* __restrict__ base, long pair, 
 }
 
 
+// the packed recursion of a lane's two rows + the float64 re-evaluation of whichever of the two needs it (`cold`: this wave's
+// MpColdLds<N, MP_COLD_G> buffer; the inputs are still in the lane's registers here - these are the A/B forms, not register-tuned)
+template <int N, bool HAS_FTIP, typename MT>
+__device__ __forceinline__ void mp_rnea_pk(const MT& M, const MpCall<float>& C, const MpJointState<mp_f2, N>& js, const mp_f2 (&q)[N],
+                                           const mp_f2 (&qd)[N], const mp_f2 (&qdd)[N], mp_f2 (&tau)[N], const MpBad<mp_f2>& bad,
+                                           char* __restrict__ cold) {
+#if MP_ADAPTIVE_F32
+  const mp_f2 tn[3] = {(mp_f2)(C.F1n[0]), (mp_f2)(C.F1n[1]), (mp_f2)(C.F1n[2])};
+  const mp_f2 tf[3] = {(mp_f2)(C.F1f[0]), (mp_f2)(C.F1f[1]), (mp_f2)(C.F1f[2])};
+  mp_f2 sN, sF;
+  mp_rnea_impl<mp_f2, N, HAS_FTIP, true>(M, C.a0, tn, tf, js, qd, qdd, tau, sN, sF);
+  float tx[N], ty[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) { tx[i] = tau[i].x; ty[i] = tau[i].y; }
+  const bool hx = mp_id_row_is_hard<N>(tx, sN.x, sF.x, M.lscale) && !bad.x.any();
+  const bool hy = mp_id_row_is_hard<N>(ty, sN.y, sF.y, M.lscale) && !bad.y.any();
+  mp_cold_rows<N, HAS_FTIP, MP_COLD_G>(M, C, hx, cold, [&](float (&a)[N], float (&b)[N], float (&c)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) { a[i] = q[i].x; b[i] = qd[i].x; c[i] = qdd[i].x; }
+  }, tx);
+  mp_cold_rows<N, HAS_FTIP, MP_COLD_G>(M, C, hy, cold, [&](float (&a)[N], float (&b)[N], float (&c)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) { a[i] = q[i].y; b[i] = qd[i].y; c[i] = qdd[i].y; }
+  }, ty);
+#pragma unroll
+  for (int i = 0; i < N; ++i) tau[i] = (mp_f2){tx[i], ty[i]};
+#else
+  mp_rnea<mp_f2, N, HAS_FTIP>(M, C, js, qd, qdd, tau);
+#endif
+}
+
 // tau for the row pair `p` (rows 2p, 2p+1): the body of k_id_pk
 template <int N, bool HAS_FTIP, typename MT>
 __device__ __forceinline__ void mp_body_id_pk(const MT& M, const MpCall<float>& C, const float* __restrict__ q,
                                               const float* __restrict__ qd, const float* __restrict__ qdd,
-                                              float* __restrict__ tau, long p) {
+                                              float* __restrict__ tau, long p, char* __restrict__ cold) {
   mp_f2 a[N], b[N], c[N], t[N];
   load_pair<N>(q, p, a);
   load_pair<N>(qd, p, b);
   load_pair<N>(qdd, p, c);
   MpJointState<mp_f2, N> js;
   mp_joint_state<mp_f2, N>(M, a, js);
-  mp_rnea_row<N, HAS_FTIP>(M, C, js, a, b, c, t);
   MpBad<mp_f2> bad;
   bad.add(a); bad.add(b); bad.add(c);
+  mp_rnea_pk<N, HAS_FTIP>(M, C, js, a, b, c, t, bad, cold);
 #pragma unroll
   for (int j = 0; j < N; ++j) t[j] = mp_clip(t[j], M.taumin[j], M.taumax[j]);
   store_pair<N>(tau, p, t, bad);
@@ -528,7 +647,7 @@ __device__ __forceinline__ void mp_body_id_pk(const MT& M, const MpCall<float>& 
 template <int N, bool HAS_FTIP, typename MT>
 __device__ __forceinline__ void mp_body_id_pk_split(const MT& M, const MpCall<float>& C, const float* __restrict__ q,
                                                     const float* __restrict__ qd, const float* __restrict__ qdd,
-                                                    float* __restrict__ tau, long p, long stride) {
+                                                    float* __restrict__ tau, long p, long stride, char* __restrict__ cold) {
   mp_f2 v[3][N], t[N];
   const float* src[3] = {q, qd, qdd};
 #pragma unroll
@@ -541,9 +660,9 @@ __device__ __forceinline__ void mp_body_id_pk_split(const MT& M, const MpCall<fl
   }
   MpJointState<mp_f2, N> js;
   mp_joint_state<mp_f2, N>(M, v[0], js);
-  mp_rnea_row<N, HAS_FTIP>(M, C, js, v[0], v[1], v[2], t);
   MpBad<mp_f2> bad;
   bad.add(v[0]); bad.add(v[1]); bad.add(v[2]);
+  mp_rnea_pk<N, HAS_FTIP>(M, C, js, v[0], v[1], v[2], t, bad, cold);
   float lo[N], hi[N];
 #pragma unroll
   for (int j = 0; j < N; ++j) {
@@ -560,7 +679,7 @@ __device__ __forceinline__ void mp_body_id_pk_split(const MT& M, const MpCall<fl
 template <int N, bool HAS_FTIP, typename MT>
 __device__ __forceinline__ void mp_body_traj_id_pk(const MT& M, const MpCall<float>& C, const float* __restrict__ start,
                                                    const float* __restrict__ end, long p, long Nt, double Tf, int method,
-                                                   float* __restrict__ tau) {
+                                                   float* __restrict__ tau, char* __restrict__ cold) {
   const long r0 = 2 * p;
   const long b0 = r0 / Nt, t0 = r0 - b0 * Nt;
   const bool wrap = t0 + 1 >= Nt;  // the pair may straddle two trajectories
@@ -573,9 +692,9 @@ __device__ __forceinline__ void mp_body_traj_id_pk(const MT& M, const MpCall<flo
   for (int j = 0; j < N; ++j) { qq[j] = (mp_f2){p0[j], p1[j]}; qd[j] = (mp_f2){v0[j], v1[j]}; qdd[j] = (mp_f2){a0[j], a1[j]}; }
   MpJointState<mp_f2, N> js;
   mp_joint_state<mp_f2, N>(M, qq, js);
-  mp_rnea_row<N, HAS_FTIP>(M, C, js, qq, qd, qdd, tq);
   MpBad<mp_f2> bad;  // a non-finite end point makes the generated row non-finite
   bad.add(qq); bad.add(qd); bad.add(qdd);
+  mp_rnea_pk<N, HAS_FTIP>(M, C, js, qq, qd, qdd, tq, bad, cold);
 #pragma unroll
   for (int j = 0; j < N; ++j) tq[j] = mp_clip(tq[j], M.taumin[j], M.taumax[j]);
   store_pair<N>(tau, p, tq, bad);
@@ -589,7 +708,8 @@ __device__ __forceinline__ void mp_body_traj_id_pk(const MT& M, const MpCall<flo
 template <int N, bool HAS_FTIP, typename MT>
 __device__ __forceinline__ void mp_body_traj_id_pk_tab(const MT& M, const MpCall<float>& C, const float* __restrict__ start,
                                                        const float* __restrict__ end, long b, long t0, long t1, bool valid1,
-                                                       long Nt, const double* __restrict__ tab, float* __restrict__ tau) {
+                                                       long Nt, const double* __restrict__ tab, float* __restrict__ tau,
+                                                       char* __restrict__ cold) {
   float a[N], e[N];
   RunIO<float, N>::load(start, b, a);
   RunIO<float, N>::load(end, b, e);
@@ -606,9 +726,9 @@ __device__ __forceinline__ void mp_body_traj_id_pk_tab(const MT& M, const MpCall
   }
   MpJointState<mp_f2, N> js;
   mp_joint_state<mp_f2, N>(M, qq, js);
-  mp_rnea_row<N, HAS_FTIP>(M, C, js, qq, qd, qdd, tq);
   MpBad<mp_f2> bad;  // a non-finite end point makes the generated row non-finite
   bad.add(qq); bad.add(qd); bad.add(qdd);
+  mp_rnea_pk<N, HAS_FTIP>(M, C, js, qq, qd, qdd, tq, bad, cold);
   float lo[N], hi[N];
 #pragma unroll
   for (int j = 0; j < N; ++j) {
@@ -626,7 +746,7 @@ __device__ __forceinline__ void mp_body_traj_id_pk_tab(const MT& M, const MpCall
 template <int N, bool HAS_FTIP, typename MT>
 __device__ __forceinline__ void mp_body_traj_id_tab(const MT& M, const MpCall<float>& C, const float* __restrict__ start,
                                                     const float* __restrict__ end, long b, long t, long Nt,
-                                                    const double* __restrict__ tab, float* __restrict__ tau) {
+                                                    const double* __restrict__ tab, float* __restrict__ tau, char* __restrict__ cold) {
   float a[N], e[N];
   RunIO<float, N>::load(start, b, a);
   RunIO<float, N>::load(end, b, e);
@@ -641,11 +761,15 @@ __device__ __forceinline__ void mp_body_traj_id_tab(const MT& M, const MpCall<fl
   }
   MpJointState<float, N> js;
   mp_joint_state<float, N>(M, qq, js);
-  mp_rnea_row<float, N, HAS_FTIP>(M, C, js, qq, qd, qdd, tq);
-#pragma unroll
-  for (int j = 0; j < N; ++j) tq[j] = mp_clip(tq[j], M.taumin[j], M.taumax[j]);
   MpBad<float> bad;  // a non-finite end point makes the generated row non-finite
   bad.add(qq); bad.add(qd); bad.add(qdd);
+  const bool hard = mp_rnea_f32<N, HAS_FTIP>(M, C, js, qd, qdd, tq) && !bad.any();
+  mp_cold_rows<N, HAS_FTIP, MP_COLD_G>(M, C, hard, cold, [&](float (&x)[N], float (&y)[N], float (&z)[N]) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) { x[j] = qq[j]; y[j] = qd[j]; z[j] = qdd[j]; }
+  }, tq);
+#pragma unroll
+  for (int j = 0; j < N; ++j) tq[j] = mp_clip(tq[j], M.taumin[j], M.taumax[j]);
   mp_poison_if(bad.any(), tq);
   RunIO<float, N>::store_wo(tau, b * Nt + t, tq);
 }
@@ -655,6 +779,7 @@ __device__ __forceinline__ void mp_body_traj_id_tab(const MT& M, const MpCall<fl
 // row -> (trajectory, timestep) without a division per lane: the wave's first row is divided ON THE SCALAR UNIT by a host-supplied
 // reciprocal (`magic` = floor(2^32 / Nt): one s_mul_hi_u32 and one correction step; rows < 2^32), a lane past the end of that
 // trajectory belongs to the next one (Nt >= 64: at most one wrap per wave).  The last, partial wave stores per lane.
+constexpr int MP_TRAJ_CO_LDS = 4096;  // per wave (one wave per block): 64 tau rows (<= 2 KB) / eight or more re-evaluation slots
 template <int N, bool HAS_FTIP, typename MT>
 __device__ __forceinline__ void mp_body_traj_id_co(const MT& M, const MpCall<float>& C, const float* __restrict__ start,
                                                    const float* __restrict__ end, unsigned row0, int lane, unsigned rows, unsigned Nt,
@@ -683,18 +808,43 @@ __device__ __forceinline__ void mp_body_traj_id_co(const MT& M, const MpCall<flo
   }
   MpJointState<float, N> js;
   mp_joint_state<float, N>(M, qq, js);
-  mp_rnea_row<float, N, HAS_FTIP>(M, C, js, qq, qd, qdd, tq);
-#pragma unroll
-  for (int j = 0; j < N; ++j) tq[j] = mp_clip(tq[j], M.taumin[j], M.taumax[j]);
   MpBad<float> bad;  // a non-finite end point makes the generated row non-finite
   bad.add(qq); bad.add(qd); bad.add(qdd);
-  mp_poison_if(bad.any(), tq);
+  const bool poison = bad.any();
+  const bool hard = mp_rnea_f32<N, HAS_FTIP>(M, C, js, qd, qdd, tq) && !poison && valid;
+#pragma unroll
+  for (int j = 0; j < N; ++j) tq[j] = mp_clip(tq[j], M.taumin[j], M.taumax[j]);
+  mp_poison_if(poison, tq);
   if (full) {
     ST::row_out(lds, lane, tq);
     ST::sync();
     ST::flush(tau, (long)row0, lane, lds);
   } else if (valid) {
     RunIO<float, N>::store_wo(tau, (long)row0 + lane, tq);
+  }
+  // ill-conditioned rows again in float64 after the wave's rows have left (see mp_body_id_co); the inputs are generated again
+  if (__builtin_amdgcn_ballot_w64(hard) != 0ull) {
+    ST::sync();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    constexpr int G = MP_TRAJ_CO_LDS / MpColdSlot<N>::BYTES;
+    mp_cold_rows<N, HAS_FTIP, G>(M, C, hard, lds, [&](float (&x)[N], float (&y)[N], float (&z)[N]) {
+      float a2[N], e2[N];
+      RunIO<float, N>::load(start, (long)b, a2);
+      RunIO<float, N>::load(end, (long)b, e2);
+      const double u0 = tab[3 * t], u1 = tab[3 * t + 1], u2 = tab[3 * t + 2];
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        const double d = (double)(e2[j] - a2[j]);
+        x[j] = mp_clip((float)(u0 * d + (double)a2[j]), M.qmin[j], M.qmax[j]);
+        y[j] = (float)(u1 * d);
+        z[j] = (float)(u2 * d);
+      }
+    }, tq);
+    if (hard) {
+#pragma unroll
+      for (int j = 0; j < N; ++j) tq[j] = mp_clip(tq[j], M.taumin[j], M.taumax[j]);
+      RunIO<float, N>::store(tau, (long)row0 + lane, tq);
+    }
   }
 }
 

@@ -253,15 +253,6 @@ __device__ __forceinline__ const __attribute__((address_space(4))) MpJoint<doubl
 }
 #endif
 
-// The same model as an ordinary (generic address space) object: what a NON-inlined function can take - its arguments arrive in
-// vector registers, where the scalar-register laundering above is not legal; loads become vector loads (cold paths only).
-template <typename MT>
-MP_HD const MT& mp_plain_model(const MT& M) { return M; }
-#if defined(__HIP_DEVICE_COMPILE__)
-__device__ __forceinline__ const MpModel<float>& mp_plain_model(MpModelConstF& M) { return *(const MpModel<float>*)(&M); }
-__device__ __forceinline__ const MpModel<double>& mp_plain_model(MpModelConstD& M) { return *(const MpModel<double>*)(&M); }
-#endif
-
 // ------------------------------------------------------------------------------ axis-aligned steps
 // Motion vector (w, v), parent -> child coordinates, child pose in parent = (E, r):
 //     w' = E^T w,  v' = E^T (v + w x r).
@@ -460,11 +451,11 @@ MP_HD void mp_rnea(const MT& M, const MpCall<typename MpTraits<T>::S>& C, const 
 // terms - an arm swinging at 10 rad/s whose joint wrenches reach hundreds of N.m while every torque of the row is a few N.m (over
 // c2's 12.3 M rows the plain float32 kernel missed the bound on 76, by up to 4.8 x; with the joint offsets taken exactly - MpJoint
 // co / so - on 1, by 1.3 x).  Such a row announces itself: the largest joint-wrench component the backward pass meets, moments
-// plus forces times the robot's length scale, is more than MP_HARD_ROW_K x the row's largest torque.  Those rows - 0.7 - 1.6 % of
-// c2-distributed rows, in runs of consecutive timesteps, 2 - 5 % of the waves - are evaluated again in float64 from the same
-// float32 inputs (model constants widened, sin / cos in float64).  What stays float32 then sits at <= 0.33 x the bound on 9 M rows
-// of four robots, the float64 rows at <= 0.1 x (profiles/r04_f32_precision_study.txt).  Deterministic: a row's precision depends
-// on that row's values only.
+// plus forces times the robot's length scale, is more than MP_HARD_ROW_K x the row's largest torque.  Those rows - a fraction of a
+// per cent to 1.5 % of c2-distributed rows, in runs of consecutive timesteps - are evaluated again with the twist / acceleration /
+// wrench recursion in float64 from the same float32 inputs, model constants and sin / cos (mp_rnea_cold).  What stays float32 sits
+// at <= 0.4 x the bound on 12.3 M rows, the re-evaluated rows at <= 0.25 x (profiles/r04_f32_precision_study.txt).
+// Deterministic: a row's precision depends on that row's values only.
 #ifndef MP_HARD_ROW_K
 #define MP_HARD_ROW_K 16.0f
 #endif
@@ -479,89 +470,168 @@ MP_HD bool mp_id_row_is_hard(const float (&tau)[N], float sN, float sF, float ls
   return sN + lscale * sF > MP_HARD_ROW_K * rowmax;   // false for NaN rows: they are poisoned by the callers as before
 }
 
-template <int N> struct MpRowF { float v[N]; };   // a row by value: registers across the call below, never memory
-
-// The float64 evaluation of one float32 row.  INLINED on the device, behind an unlikely branch: the kernels that use it are held
-// to 75 - 110 VGPRs by their launch bounds and this body wants ~170 - inlined it is register-allocated under the kernel's own budget,
-// the block is laid out after s_endpgm and every spill (27 scratch stores / loads at n = 6) lands inside it; the float32 path keeps
-// its registers and its instruction stream (tools/spec_asm.py).  As a real function it would be allocated 180 VGPRs of its own and
-// the KERNEL's allocation is the maximum over its callees (six waves per SIMD -> two), and clang accepts no register cap on a
-// non-kernel function.
-#if defined(__HIP_DEVICE_COMPILE__)
-#define MP_COLD __device__ __forceinline__
-#else
-#define MP_COLD static __attribute__((noinline))
-#endif
+// The float32 recursion of one row + its verdict.  tau is NOT clipped.
 template <int N, bool HAS_FTIP, typename MT>
-MP_COLD MpRowF<N> mp_id_row_f64(const MT& M, const MpCall<float>& C, MpRowF<N> q, MpRowF<N> qd, MpRowF<N> qdd) {
-  double a[N], b[N], c[N], t[N];
-#pragma unroll
-  for (int i = 0; i < N; ++i) { a[i] = (double)q.v[i]; b[i] = (double)qd.v[i]; c[i] = (double)qdd.v[i]; }
-  MpCall<double> Cd;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) { Cd.a0[k] = (double)C.a0[k]; Cd.F1n[k] = (double)C.F1n[k]; Cd.F1f[k] = (double)C.F1f[k]; }
-  MpJointState<double, N> js;
-  mp_joint_state<double, N>(M, a, js);
-  mp_rnea<double, N, HAS_FTIP>(M, Cd, js, b, c, t);
-  MpRowF<N> out;
-#pragma unroll
-  for (int i = 0; i < N; ++i) out.v[i] = (float)t[i];
-  return out;
+MP_HD bool mp_rnea_f32(const MT& M, const MpCall<float>& C, const MpJointState<float, N>& js, const float (&qd)[N],
+                       const float (&qdd)[N], float (&tau)[N]) {
+#if MP_ADAPTIVE_F32
+  const float tn[3] = {C.F1n[0], C.F1n[1], C.F1n[2]}, tf[3] = {C.F1f[0], C.F1f[1], C.F1f[2]};
+  float sN, sF;
+  mp_rnea_impl<float, N, HAS_FTIP, true>(M, C.a0, tn, tf, js, qd, qdd, tau, sN, sF);
+  return mp_id_row_is_hard<N>(tau, sN, sF, M.lscale);
+#else
+  mp_rnea<float, N, HAS_FTIP>(M, C, js, qd, qdd, tau);
+  return false;
+#endif
 }
 
-// tau (unclipped) of one row given its joint state: float64 rows are the recursion itself; float32 rows the float32 recursion,
-// and the float64 one where the row is ill-conditioned
+// Where the re-evaluation keeps its per-joint state: 6 N float64 body / joint wrench components + 6 N float32 (sin / cos / shift,
+// the row's q / qd / qdd, tau on the way out).
+// On the device that is a slot of the wave's LDS - the re-evaluation wants ~170 VGPRs with these in registers, the kernels that
+// host it are held to 80 - 110 by their launch bounds, and spilling them to scratch memory made the waves that take this path
+// stragglers (54 scratch round trips each) and, past 140 MB of scratch per dispatch, every launch allocate its own: c2 +19 %, c4
+// +43 % (profiles/r04_adaptive_ab.txt).  On the host plain arrays.
+template <int N> struct MpColdSlot { static constexpr int BYTES = 6 * N * 8 + 6 * N * 4; };
+template <int N>
+struct MpColdLocal {
+  double f[6 * N];
+  float j[6 * N];
+  MP_HD double getf(int k) const { return f[k]; }
+  MP_HD void putf(int k, double v) { f[k] = v; }
+  MP_HD float getj(int k) const { return j[k]; }
+  MP_HD void putj(int k, float v) { j[k] = v; }
+};
+template <int N>
+struct MpColdMem {  // a slot in (LDS) memory: [6 N doubles][6 N floats].  Volatile: a lane reads back only what it wrote itself, so
+  char* p;          // the optimiser would otherwise forward every value in a register and delete the stores - the spill again
+  MP_HD double getf(int k) const { return reinterpret_cast<const volatile double*>(p)[k]; }
+  MP_HD void putf(int k, double v) { reinterpret_cast<volatile double*>(p)[k] = v; }
+  MP_HD float getj(int k) const { return reinterpret_cast<const volatile float*>(p + 6 * N * 8)[k]; }
+  MP_HD void putj(int k, float v) { reinterpret_cast<volatile float*>(p + 6 * N * 8)[k] = v; }
+};
+
+// mp_rnea_impl with the twist / acceleration / wrench chains in float64 (float32 inputs, float32 sin / cos with exact offsets;
+// `M` is the float32 model or, in the robot-specialised programs, its float64 original) and the per-joint state in `st`.  tau is NOT clipped.  The joint loops are ROLLED on purpose
+// (the model is indexed at run time: scalar loads with a register offset, from the kernel arguments, the device copy or the
+// specialised literal alike): unrolled, the scheduler interleaves the joints' float64 work into 150 - 200 live VGPRs, which under
+// the hosting kernels' 80 is ~80 scratch round trips; rolled it is one joint's worth of state at a time, and ~170 instructions
+// of code instead of ~1400.
+#if defined(__clang__)
+#define MP_ROLLED _Pragma("clang loop unroll(disable)")
+#else
+#define MP_ROLLED
+#endif
+// ... and inside a joint the scheduler is told not to move anything across the stage boundaries below: left alone it overlaps the
+// six wrench components with the chain update for latency's sake and needs ~96 - 116 VGPRs, in program order ~70
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MP_STAGE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define MP_STAGE() ((void)0)
+#endif
+template <int N, bool HAS_FTIP, typename MT, typename ST>
+MP_HD void mp_rnea_cold(const MT& M, const MpCall<float>& C, const float (&q)[N], const float (&qd)[N], const float (&qdd)[N], ST st,
+                        float (&tau)[N]) {
+  double wx = 0, wy = 0, wz = 0, vx = 0, vy = 0, vz = 0;
+  double dwx = 0, dwy = 0, dwz = 0, dvx = (double)C.a0[0], dvy = (double)C.a0[1], dvz = (double)C.a0[2];
+  double tnx = 0, tny = 0, tnz = 0, tfx = 0, tfy = 0, tfz = 0;
+  if (HAS_FTIP) { tnx = (double)C.F1n[0]; tny = (double)C.F1n[1]; tnz = (double)C.F1n[2]; tfx = (double)C.F1f[0]; tfy = (double)C.F1f[1]; tfz = (double)C.F1f[2]; }
+  // the row's inputs are read through `st` too (indexed by the loop variable): registers cannot be indexed at run time
+#pragma unroll
+  for (int i = 0; i < N; ++i) { st.putj(3 * N + i, q[i]); st.putj(4 * N + i, qd[i]); st.putj(5 * N + i, qdd[i]); }
+  MP_ROLLED
+  for (int i = 0; i < N; ++i) {
+    const auto& J = mp_joint_of(M, i);
+    const float qi = st.getj(3 * N + i);
+    float sf, cf;
+    {  // the float32 joint state of mp_joint_state (M may be the float64 model: its constants are narrowed here)
+      const float qr = (float)J.rev * qi;
+      float s0, c0;
+      mp_sincos(qr, s0, c0);
+      sf = s0 * (float)J.co + c0 * (float)J.so;
+      cf = c0 * (float)J.co - s0 * (float)J.so;
+      const float df = (float)J.d + (qi - qr);
+      st.putj(i, sf); st.putj(N + i, cf); st.putj(2 * N + i, df);
+    }
+    const double ca = (double)J.ca, sa = (double)J.sa, la = (double)J.a;
+    if (i > 0) {
+      mp_motion_A<double, double>(ca, sa, la, wx, wy, wz, vx, vy, vz);
+      mp_motion_A<double, double>(ca, sa, la, dwx, dwy, dwz, dvx, dvy, dvz);
+      if (HAS_FTIP) mp_force_down_A<double, double>(ca, sa, la, tnx, tny, tnz, tfx, tfy, tfz);
+    }
+    MP_STAGE();
+    const double s = (double)sf, c = (double)cf, d = (double)st.getj(2 * N + i);
+    mp_motion_B<double>(c, s, d, wx, wy, wz, vx, vy, vz);
+    mp_motion_B<double>(c, s, d, dwx, dwy, dwz, dvx, dvy, dvz);
+    if (HAS_FTIP) mp_force_down_B<double>(c, s, d, tnx, tny, tnz, tfx, tfy, tfz);
+    const double rev = (double)J.rev, qdi = (double)st.getj(4 * N + i), qddi = (double)st.getj(5 * N + i);
+    const double qdr = rev * qdi, qdp = qdi - qdr;
+    const double ar = rev * qddi, ap = qddi - ar;
+    wz += qdr;
+    vz += qdp;
+    dwx += qdr * wy;
+    dwy -= qdr * wx;
+    dwz += ar;
+    dvx += qdr * vy + qdp * wy;
+    dvy -= qdr * vx + qdp * wx;
+    dvz += ap;
+    MP_STAGE();
+    const double Ixx = (double)J.Ixx, Ixy = (double)J.Ixy, Ixz = (double)J.Ixz, Iyy = (double)J.Iyy, Iyz = (double)J.Iyz, Izz = (double)J.Izz;
+    const double hx = (double)J.hx, hy = (double)J.hy, hz = (double)J.hz, m = (double)J.m;
+    const double pnx = Ixx * wx + Ixy * wy + Ixz * wz + (hy * vz - hz * vy);
+    const double pny = Ixy * wx + Iyy * wy + Iyz * wz + (hz * vx - hx * vz);
+    const double pnz = Ixz * wx + Iyz * wy + Izz * wz + (hx * vy - hy * vx);
+    const double pfx = m * vx - (hy * wz - hz * wy);
+    const double pfy = m * vy - (hz * wx - hx * wz);
+    const double pfz = m * vz - (hx * wy - hy * wx);
+    MP_STAGE();
+    st.putf(6 * i + 0, Ixx * dwx + Ixy * dwy + Ixz * dwz + (hy * dvz - hz * dvy) + (wy * pnz - wz * pny) + (vy * pfz - vz * pfy));
+    MP_STAGE();
+    st.putf(6 * i + 1, Ixy * dwx + Iyy * dwy + Iyz * dwz + (hz * dvx - hx * dvz) + (wz * pnx - wx * pnz) + (vz * pfx - vx * pfz));
+    MP_STAGE();
+    st.putf(6 * i + 2, Ixz * dwx + Iyz * dwy + Izz * dwz + (hx * dvy - hy * dvx) + (wx * pny - wy * pnx) + (vx * pfy - vy * pfx));
+    MP_STAGE();
+    st.putf(6 * i + 3, m * dvx - (hy * dwz - hz * dwy) + (wy * pfz - wz * pfy));
+    st.putf(6 * i + 4, m * dvy - (hz * dwx - hx * dwz) + (wz * pfx - wx * pfz));
+    st.putf(6 * i + 5, m * dvz - (hx * dwy - hy * dwx) + (wx * pfy - wy * pfx));
+    MP_STAGE();
+  }
+  // the children's wrench, already in the current joint's frame (the tip wrench rides it from the start)
+  double ax = tnx, ay = tny, az = tnz, bx = tfx, by = tfy, bz = tfz;
+  MP_ROLLED
+  for (int i = N - 1; i >= 0; --i) {
+    const auto& J = mp_joint_of(M, i);
+    double nx = st.getf(6 * i + 0) + ax, ny = st.getf(6 * i + 1) + ay, nz = st.getf(6 * i + 2) + az;
+    double fx = st.getf(6 * i + 3) + bx, fy = st.getf(6 * i + 4) + by, fz = st.getf(6 * i + 5) + bz;
+    const double rev = (double)J.rev;
+    st.putj(3 * N + i, (float)(rev * nz + (1.0 - rev) * fz));   // tau_i, in the slot q_i occupied
+    if (i > 0) {
+      const double s = (double)st.getj(i), c = (double)st.getj(N + i), d = (double)st.getj(2 * N + i);
+      mp_force_up_B<double>(c, s, d, nx, ny, nz, fx, fy, fz);
+      mp_force_up_A<double, double>((double)J.ca, (double)J.sa, (double)J.a, nx, ny, nz, fx, fy, fz);
+      ax = nx; ay = ny; az = nz; bx = fx; by = fy; bz = fz;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) tau[i] = st.getj(3 * N + i);
+}
+
+// Host form (CPU launchers, tests/hostsim): tau (unclipped) of one row given its joint state - float64 rows are the recursion
+// itself; float32 rows the float32 recursion and, where the row is ill-conditioned, the re-evaluation above.  The kernels do the
+// same through mp_rnea_f32 + mp_cold_rows (csrc/mp_bodies.h), which runs the re-evaluation wave by wave out of LDS.
 template <typename T> struct MpIsF32 { static constexpr bool value = false; };
 template <> struct MpIsF32<float> { static constexpr bool value = true; };
 template <typename T, int N, bool HAS_FTIP, typename MT>
 MP_HD void mp_rnea_row(const MT& M, const MpCall<typename MpTraits<T>::S>& C, const MpJointState<T, N>& js, const T (&q)[N],
                        const T (&qd)[N], const T (&qdd)[N], T (&tau)[N]) {
-  if constexpr (MpIsF32<T>::value && MP_ADAPTIVE_F32) {
-    const float tn[3] = {C.F1n[0], C.F1n[1], C.F1n[2]}, tf[3] = {C.F1f[0], C.F1f[1], C.F1f[2]};
-    float sN, sF;
-    mp_rnea_impl<float, N, HAS_FTIP, true>(M, C.a0, tn, tf, js, qd, qdd, tau, sN, sF);
-    if (__builtin_expect(mp_id_row_is_hard<N>(tau, sN, sF, M.lscale), 0)) {
-      MpRowF<N> a, b, c;
-#pragma unroll
-      for (int i = 0; i < N; ++i) { a.v[i] = q[i]; b.v[i] = qd[i]; c.v[i] = qdd[i]; }
-      const MpRowF<N> t = mp_id_row_f64<N, HAS_FTIP>(mp_plain_model(M), C, a, b, c);
-#pragma unroll
-      for (int i = 0; i < N; ++i) tau[i] = t.v[i];
+  if constexpr (MpIsF32<T>::value) {
+    if (mp_rnea_f32<N, HAS_FTIP>(M, C, js, qd, qdd, tau)) {
+      MpColdLocal<N> st;
+      mp_rnea_cold<N, HAS_FTIP>(M, C, q, qd, qdd, st, tau);
     }
   } else {
     mp_rnea<T, N, HAS_FTIP>(M, C, js, qd, qdd, tau);
   }
 }
-#if MP_HAS_PACKED
-// two float32 rows per lane: the same test per row, the float64 evaluation for whichever of the two needs it
-template <int N, bool HAS_FTIP, typename MT>
-MP_HD void mp_rnea_row(const MT& M, const MpCall<float>& C, const MpJointState<mp_f2, N>& js, const mp_f2 (&q)[N],
-                       const mp_f2 (&qd)[N], const mp_f2 (&qdd)[N], mp_f2 (&tau)[N]) {
-  const mp_f2 tn[3] = {(mp_f2)(C.F1n[0]), (mp_f2)(C.F1n[1]), (mp_f2)(C.F1n[2])};
-  const mp_f2 tf[3] = {(mp_f2)(C.F1f[0]), (mp_f2)(C.F1f[1]), (mp_f2)(C.F1f[2])};
-  mp_f2 sN, sF;
-  mp_rnea_impl<mp_f2, N, HAS_FTIP, true>(M, C.a0, tn, tf, js, qd, qdd, tau, sN, sF);
-  float tx[N], ty[N];
-#pragma unroll
-  for (int i = 0; i < N; ++i) { tx[i] = tau[i].x; ty[i] = tau[i].y; }
-  if (mp_id_row_is_hard<N>(tx, sN.x, sF.x, M.lscale)) {
-    MpRowF<N> a, b, c;
-#pragma unroll
-    for (int i = 0; i < N; ++i) { a.v[i] = q[i].x; b.v[i] = qd[i].x; c.v[i] = qdd[i].x; }
-    const MpRowF<N> t = mp_id_row_f64<N, HAS_FTIP>(mp_plain_model(M), C, a, b, c);
-#pragma unroll
-    for (int i = 0; i < N; ++i) tau[i].x = t.v[i];
-  }
-  if (mp_id_row_is_hard<N>(ty, sN.y, sF.y, M.lscale)) {
-    MpRowF<N> a, b, c;
-#pragma unroll
-    for (int i = 0; i < N; ++i) { a.v[i] = q[i].y; b.v[i] = qd[i].y; c.v[i] = qdd[i].y; }
-    const MpRowF<N> t = mp_id_row_f64<N, HAS_FTIP>(mp_plain_model(M), C, a, b, c);
-#pragma unroll
-    for (int i = 0; i < N; ++i) tau[i].y = t.v[i];
-  }
-}
-#endif
 
 // A space-frame wrench [m; f] seen from the pre-joint-1 frame: f' = R^T f, n' = R^T (n - p x f)
 // (what mp_make_call does on the host for a per-call wrench; here per row).

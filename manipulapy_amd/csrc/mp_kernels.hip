@@ -33,9 +33,10 @@ template <typename T, int N, bool HAS_FTIP>
 __global__ __launch_bounds__(kBlock) void k_id(const MpModel<T> M, const MpCall<T> C, const T* __restrict__ q,
                                                const T* __restrict__ qd, const T* __restrict__ qdd,
                                                T* __restrict__ tau, long rows) {
+  MP_COLD_BUFFER(N, kBlock, sizeof(T));
   const long r = (long)blockIdx.x * kBlock + threadIdx.x;
   if (r >= rows) return;
-  mp_body_id<T, N, HAS_FTIP>(M, C, q, qd, qdd, tau, r);
+  mp_body_id<T, N, HAS_FTIP>(M, C, q, qd, qdd, tau, r, MP_COLD_PTR);
 }
 
 // The same with the model read through a pointer to device memory (scalar loads, K$-resident) instead of the kernel-argument
@@ -45,10 +46,11 @@ __global__ __launch_bounds__(kBlock) void k_id(const MpModel<T> M, const MpCall<
 template <typename T, int N, bool HAS_FTIP>
 __global__ __launch_bounds__(kBlock) void k_id_dm(const MpModel<T>* __restrict__ Mdev, const MpCall<T> C, const T* __restrict__ q,
                                                   const T* __restrict__ qd, const T* __restrict__ qdd, T* __restrict__ tau, long rows) {
+  MP_COLD_BUFFER(N, kBlock, sizeof(T));
   const long r = (long)blockIdx.x * kBlock + threadIdx.x;
   if (r >= rows) return;
   typedef const __attribute__((address_space(4))) MpModel<T> MC;
-  mp_body_id<T, N, HAS_FTIP>(*(MC*)Mdev, C, q, qd, qdd, tau, r);
+  mp_body_id<T, N, HAS_FTIP>(*(MC*)Mdev, C, q, qd, qdd, tau, r, MP_COLD_PTR);
 }
 
 // -------------------------------------------------------------- trajectory generation pieces
@@ -93,6 +95,7 @@ __global__ __launch_bounds__(kBlock) void k_traj_id(const MpModel<float> M, cons
                                                     const float* __restrict__ start, const float* __restrict__ end,
                                                     long row0, long rows, long Nt, double Tf, int method,
                                                     float* __restrict__ tau) {
+  MP_COLD_BUFFER(N, kBlock, 4);
   const long r = row0 + (long)blockIdx.x * kBlock + threadIdx.x;
   if (r >= rows) return;
   const long b = r / Nt, t = r - b * Nt;
@@ -100,11 +103,15 @@ __global__ __launch_bounds__(kBlock) void k_traj_id(const MpModel<float> M, cons
   traj_row<N>(M, start, end, b, t, Nt, Tf, method, p, v, a);
   MpJointState<float, N> js;
   mp_joint_state<float, N>(M, p, js);
-  mp_rnea_row<float, N, HAS_FTIP>(M, C, js, p, v, a, tq);
-#pragma unroll
-  for (int j = 0; j < N; ++j) tq[j] = mp_clip(tq[j], M.taumin[j], M.taumax[j]);
   MpBad<float> bad;
   bad.add(p); bad.add(v); bad.add(a);
+  const bool hard = mp_rnea_f32<N, HAS_FTIP>(M, C, js, v, a, tq) && !bad.any();
+  mp_cold_rows<N, HAS_FTIP, MP_COLD_G>(M, C, hard, MP_COLD_PTR, [&](float (&x)[N], float (&y)[N], float (&z)[N]) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) { x[j] = p[j]; y[j] = v[j]; z[j] = a[j]; }
+  }, tq);
+#pragma unroll
+  for (int j = 0; j < N; ++j) tq[j] = mp_clip(tq[j], M.taumin[j], M.taumax[j]);
   mp_poison_if(bad.any(), tq);
   RunIO<float, N>::store(tau, r, tq);
 }
@@ -117,18 +124,20 @@ template <int N, bool HAS_FTIP>
 __global__ __launch_bounds__(MP_PK_BLOCK, MP_PK_MINW) void k_id_pk(const MpModel<float> M, const MpCall<float> C,
                                                      const float* __restrict__ q, const float* __restrict__ qd,
                                                      const float* __restrict__ qdd, float* __restrict__ tau, long pairs) {
+  MP_COLD_BUFFER(N, MP_PK_BLOCK, 4);
   const long p = (long)blockIdx.x * MP_PK_BLOCK + threadIdx.x;
   if (p >= pairs) return;
-  mp_body_id_pk_split<N, HAS_FTIP>(M, C, q, qd, qdd, tau, p, pairs);  // rows p and p + pairs
+  mp_body_id_pk_split<N, HAS_FTIP>(M, C, q, qd, qdd, tau, p, pairs, MP_COLD_PTR);  // rows p and p + pairs
 }
 
 template <int N, bool HAS_FTIP>
 __global__ __launch_bounds__(kBlock, MP_PK_MINW) void k_traj_id_pk(const MpModel<float> M, const MpCall<float> C,
                                                           const float* __restrict__ start, const float* __restrict__ end,
                                                           long pairs, long Nt, double Tf, int method, float* __restrict__ tau) {
+  MP_COLD_BUFFER(N, kBlock, 4);
   const long p = (long)blockIdx.x * kBlock + threadIdx.x;
   if (p >= pairs) return;
-  mp_body_traj_id_pk<N, HAS_FTIP>(M, C, start, end, p, Nt, Tf, method, tau);
+  mp_body_traj_id_pk<N, HAS_FTIP>(M, C, start, end, p, Nt, Tf, method, tau, MP_COLD_PTR);
 }
 
 // per-call table of the time scaling, three doubles per timestep: exactly traj_row's arithmetic, once per timestep
@@ -147,10 +156,11 @@ __global__ __launch_bounds__(kBlock, MP_PK_MINW) void k_traj_id_pk_tab(const MpM
                                                               const float* __restrict__ start, const float* __restrict__ end,
                                                               long Nt, unsigned bpt, const double* __restrict__ tab,
                                                               float* __restrict__ tau) {
+  MP_COLD_BUFFER(N, kBlock, 4);
   long b, t0, t1;
   bool valid1;
   if (!mp_traj_pair(blockIdx.x, threadIdx.x, kBlock, bpt, Nt, b, t0, t1, valid1)) return;
-  mp_body_traj_id_pk_tab<N, HAS_FTIP>(M, C, start, end, b, t0, t1, valid1, Nt, tab, tau);
+  mp_body_traj_id_pk_tab<N, HAS_FTIP>(M, C, start, end, b, t0, t1, valid1, Nt, tab, tau, MP_COLD_PTR);
 }
 
 // ------------------------------------------------------------- FK + space Jacobian + ID fused
