@@ -155,7 +155,7 @@ constexpr int MP_COLD_G = 8;  // slots of the kernels that carry a buffer of the
 template <int N, bool HAS_FTIP, int G, typename MT, typename LoadFn>
 __device__ __forceinline__ void mp_cold_rows(const MT& M, const MpCall<float>& C, bool hard, char* __restrict__ lds, LoadFn load,
                                              float (&tau)[N]) {
-#if MP_ADAPTIVE_F32
+#if MP_ADAPTIVE_F32 && defined(__HIP_DEVICE_COMPILE__)
   const unsigned long long mask = __builtin_amdgcn_ballot_w64(hard);
   if (__builtin_expect(mask == 0ull, 1)) return;  // wave-uniform
   const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
@@ -165,11 +165,12 @@ __device__ __forceinline__ void mp_cold_rows(const MT& M, const MpCall<float>& C
     if (hard && slot >= 0 && slot < G) {
       float q[N], qd[N], qdd[N];
       load(q, qd, qdd);
-      MpColdMem<N> st{lds + slot * MpColdSlot<N>::BYTES};
+      MpColdMem<N> st{(MP_LDS_AS char*)(lds + slot * MpColdSlot<N>::BYTES)};
 #if defined(MP_COLD_MODEL)   // robot-specialised program: the float64 literal of the same robot
       mp_rnea_cold<N, HAS_FTIP>(MP_COLD_MODEL, C, q, qd, qdd, st, tau);
-#else
-      mp_rnea_cold<N, HAS_FTIP>(M, C, q, qd, qdd, st, tau);
+#else                        // generic kernels: the float64 model in device memory (scalar loads), or the float32 one widened
+      if (C.cold_model) mp_rnea_cold<N, HAS_FTIP>(*(MpModelConstD*)C.cold_model, C, q, qd, qdd, st, tau);
+      else mp_rnea_cold<N, HAS_FTIP>(M, C, q, qd, qdd, st, tau);
 #endif
     }
   }

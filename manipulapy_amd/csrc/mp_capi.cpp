@@ -285,17 +285,40 @@ int launch_spec(mp_ctx* ctx, hipFunction_t fn, long threads, void** args, unsign
   return MP_OK;
 }
 
-// float32 model resident in device memory (read by the *_dm kernels with scalar loads)
+// float32 model resident in device memory (read by the *_dm kernels with scalar loads), followed in the same buffer by the
+// float64 model (read by the float64 re-evaluation of ill-conditioned float32 rows in the generic kernels, MpCall::cold_model)
+constexpr size_t kDevModelD = (sizeof(MpModel<float>) + 255) & ~(size_t)255;  // offset of the float64 copy
 int device_model(mp_ctx* ctx, const mp_model* model, const MpModel<float>** out) {
   auto it = ctx->dev_models.find(model->uid);
   if (it == ctx->dev_models.end()) {
     void* d = nullptr;
-    if (int rc = mp_malloc(ctx, sizeof(MpModel<float>), &d)) return rc;
+    if (int rc = mp_malloc(ctx, kDevModelD + sizeof(MpModel<double>), &d)) return rc;
     HIP_TRY(hipMemcpy(d, &model->f, sizeof(MpModel<float>), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy((char*)d + kDevModelD, &model->d, sizeof(MpModel<double>), hipMemcpyHostToDevice));
     it = ctx->dev_models.emplace(model->uid, d).first;
   }
   *out = static_cast<const MpModel<float>*>(it->second);
   return MP_OK;
+}
+// a float32 call's constants + where its kernels find the float64 model.  Generic kernels only (the specialised programs carry
+// the literal); never uploads during a graph capture (the kernels then widen the float32 model: same rows, a little less exact).
+void make_call_f32(mp_ctx* ctx, const mp_model* model, const double* g, const double* Ftip, MpCall<float>* c) {
+  make_call<float>(model, g, Ftip, c);
+  if (model->big || find_spec(ctx, model)) return;
+  auto it = ctx->dev_models.find(model->uid);
+  if (it == ctx->dev_models.end() && !ctx->capturing) {
+    const MpModel<float>* dm = nullptr;
+    if (device_model(ctx, model, &dm) != MP_OK) return;
+    it = ctx->dev_models.find(model->uid);
+  }
+  if (it != ctx->dev_models.end()) c->cold_model = (const char*)it->second + kDevModelD;
+}
+template <typename T> void make_call_ctx(mp_ctx* ctx, const mp_model* model, const double* g, const double* Ftip, MpCall<T>* c);
+template <> void make_call_ctx<float>(mp_ctx* ctx, const mp_model* model, const double* g, const double* Ftip, MpCall<float>* c) {
+  make_call_f32(ctx, model, g, Ftip, c);
+}
+template <> void make_call_ctx<double>(mp_ctx*, const mp_model* model, const double* g, const double* Ftip, MpCall<double>* c) {
+  make_call<double>(model, g, Ftip, c);
 }
 
 // MpBigModel<T> of a 9..16-joint model resident in device memory (read by the looped k_dyn_* kernels through scalar loads)
@@ -408,7 +431,7 @@ static int id_impl(const char* fn, mp_ctx* ctx, const mp_model* model, const T* 
   REQUIRE(aligned16(d_q) && aligned16(d_qd) && aligned16(d_qdd) && aligned16(d_tau),
           "%s: device pointers must be 16-byte aligned", fn);
   MpCall<T> c;
-  make_call<T>(model, g, Ftip, &c);
+  make_call_ctx<T>(ctx, model, g, Ftip, &c);
   PROFILE_SCOPE(ctx, fn);
   return launch_id(ctx, model, c, any_nonzero(Ftip), d_q, d_qd, d_qdd, d_tau, (long)rows);
 }
@@ -440,7 +463,7 @@ static int fkjid_impl(const char* fn, mp_ctx* ctx, const mp_model* model, const 
   REQUIRE(aligned16(d_q) && aligned16(d_qd) && aligned16(d_qdd) && aligned16(d_T) && aligned16(d_J) && aligned16(d_tau),
           "%s: device pointers must be 16-byte aligned", fn);
   MpCall<T> c;
-  make_call<T>(model, g, Ftip, &c);
+  make_call_ctx<T>(ctx, model, g, Ftip, &c);
   PROFILE_SCOPE(ctx, fn);
   if (model->big) return launch_big_fk_jac_id<T>(ctx, model, c, any_nonzero(Ftip), d_q, d_qd, d_qdd, d_T, d_J, d_tau, (long)rows);
   const int src = launch_fkjid_spec(ctx, model, c, any_nonzero(Ftip), d_q, d_qd, d_qdd, d_T, d_J, d_tau, (long)rows);
@@ -1367,7 +1390,7 @@ int mp_traj_id_fused_f32(mp_ctx* ctx, const mp_model* model, const float* d_star
   REQUIRE(aligned16(d_start) && aligned16(d_end) && aligned16(d_tau),
           "mp_traj_id_fused_f32: device pointers must be 16-byte aligned");
   MpCall<float> c;
-  make_call<float>(model, g, Ftip, &c);
+  make_call_f32(ctx, model, g, Ftip, &c);
   const bool ftip = any_nonzero(Ftip);
   PROFILE_SCOPE(ctx, "mp_traj_id_fused_f32");
   if (model->big) {

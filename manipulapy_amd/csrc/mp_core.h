@@ -485,33 +485,38 @@ MP_HD bool mp_rnea_f32(const MT& M, const MpCall<float>& C, const MpJointState<f
 #endif
 }
 
-// Where the re-evaluation keeps its per-joint state: 6 N float64 body / joint wrench components + 6 N float32 (sin / cos / shift,
-// the row's q / qd / qdd, tau on the way out).
+// Where the re-evaluation keeps its per-joint state: 8 N float64 (six body / joint wrench components, sin, cos) + 4 N float32 (the
+// joint's shift, the row's q / qd / qdd, tau on the way out).
 // On the device that is a slot of the wave's LDS - the re-evaluation wants ~170 VGPRs with these in registers, the kernels that
 // host it are held to 80 - 110 by their launch bounds, and spilling them to scratch memory made the waves that take this path
 // stragglers (54 scratch round trips each) and, past 140 MB of scratch per dispatch, every launch allocate its own: c2 +19 %, c4
 // +43 % (profiles/r04_adaptive_ab.txt).  On the host plain arrays.
-template <int N> struct MpColdSlot { static constexpr int BYTES = 6 * N * 8 + 6 * N * 4; };
+template <int N> struct MpColdSlot { static constexpr int BYTES = 8 * N * 8 + 4 * N * 4; };
 template <int N>
 struct MpColdLocal {
-  double f[6 * N];
-  float j[6 * N];
+  double f[8 * N];
+  float j[4 * N];
   MP_HD double getf(int k) const { return f[k]; }
   MP_HD void putf(int k, double v) { f[k] = v; }
   MP_HD float getj(int k) const { return j[k]; }
   MP_HD void putj(int k, float v) { j[k] = v; }
 };
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MP_LDS_AS __attribute__((address_space(3)))   // the slot is LDS: said in the pointer's type, or the accesses become FLAT ones
+#else
+#define MP_LDS_AS
+#endif
 template <int N>
-struct MpColdMem {  // a slot in (LDS) memory: [6 N doubles][6 N floats].  Volatile: a lane reads back only what it wrote itself, so
-  char* p;          // the optimiser would otherwise forward every value in a register and delete the stores - the spill again
-  MP_HD double getf(int k) const { return reinterpret_cast<const volatile double*>(p)[k]; }
-  MP_HD void putf(int k, double v) { reinterpret_cast<volatile double*>(p)[k] = v; }
-  MP_HD float getj(int k) const { return reinterpret_cast<const volatile float*>(p + 6 * N * 8)[k]; }
-  MP_HD void putj(int k, float v) { reinterpret_cast<volatile float*>(p + 6 * N * 8)[k] = v; }
+struct MpColdMem {  // a slot in (LDS) memory: [8 N doubles][4 N floats].  Volatile: a lane reads back only what it wrote itself, so
+  MP_LDS_AS char* p;  // the optimiser would otherwise forward every value in a register and delete the stores - the spill again
+  MP_HD double getf(int k) const { return reinterpret_cast<const volatile MP_LDS_AS double*>(p)[k]; }
+  MP_HD void putf(int k, double v) { reinterpret_cast<volatile MP_LDS_AS double*>(p)[k] = v; }
+  MP_HD float getj(int k) const { return reinterpret_cast<const volatile MP_LDS_AS float*>(p + 8 * N * 8)[k]; }
+  MP_HD void putj(int k, float v) { reinterpret_cast<volatile MP_LDS_AS float*>(p + 8 * N * 8)[k] = v; }
 };
 
-// mp_rnea_impl with the twist / acceleration / wrench chains in float64 (float32 inputs, float32 sin / cos with exact offsets;
-// `M` is the float32 model or, in the robot-specialised programs, its float64 original) and the per-joint state in `st`.  tau is NOT clipped.  The joint loops are ROLLED on purpose
+// mp_rnea_impl in float64 throughout (sin / cos included) from the row's float32 inputs; `M` is the float32 model or, in the
+// robot-specialised programs and the CPU launchers, its float64 original; the per-joint state lives in `st`.  tau is NOT clipped.  The joint loops are ROLLED on purpose
 // (the model is indexed at run time: scalar loads with a register offset, from the kernel arguments, the device copy or the
 // specialised literal alike): unrolled, the scheduler interleaves the joints' float64 work into 150 - 200 live VGPRs, which under
 // the hosting kernels' 80 is ~80 scratch round trips; rolled it is one joint's worth of state at a time, and ~170 instructions
@@ -537,33 +542,32 @@ MP_HD void mp_rnea_cold(const MT& M, const MpCall<float>& C, const float (&q)[N]
   if (HAS_FTIP) { tnx = (double)C.F1n[0]; tny = (double)C.F1n[1]; tnz = (double)C.F1n[2]; tfx = (double)C.F1f[0]; tfy = (double)C.F1f[1]; tfz = (double)C.F1f[2]; }
   // the row's inputs are read through `st` too (indexed by the loop variable): registers cannot be indexed at run time
 #pragma unroll
-  for (int i = 0; i < N; ++i) { st.putj(3 * N + i, q[i]); st.putj(4 * N + i, qd[i]); st.putj(5 * N + i, qdd[i]); }
+  for (int i = 0; i < N; ++i) { st.putj(N + i, q[i]); st.putj(2 * N + i, qd[i]); st.putj(3 * N + i, qdd[i]); }
   MP_ROLLED
   for (int i = 0; i < N; ++i) {
     const auto& J = mp_joint_of(M, i);
-    const float qi = st.getj(3 * N + i);
-    float sf, cf;
-    {  // the float32 joint state of mp_joint_state (M may be the float64 model: its constants are narrowed here)
-      const float qr = (float)J.rev * qi;
-      float s0, c0;
+    const float qi = st.getj(N + i);
+    double s, c, d;
+    {  // sin / cos in float64: on these rows the float32 pair's last bit is the largest single error (0.35 x the bound against 0.09)
+      const double qr = (double)J.rev * (double)qi;
+      double s0, c0;
       mp_sincos(qr, s0, c0);
-      sf = s0 * (float)J.co + c0 * (float)J.so;
-      cf = c0 * (float)J.co - s0 * (float)J.so;
-      const float df = (float)J.d + (qi - qr);
-      st.putj(i, sf); st.putj(N + i, cf); st.putj(2 * N + i, df);
+      s = s0 * (double)J.co + c0 * (double)J.so;
+      c = c0 * (double)J.co - s0 * (double)J.so;
+      d = (double)J.d + ((double)qi - qr);
+      st.putf(6 * N + i, s); st.putf(7 * N + i, c); st.putj(i, (float)d);
     }
+    MP_STAGE();
     const double ca = (double)J.ca, sa = (double)J.sa, la = (double)J.a;
     if (i > 0) {
       mp_motion_A<double, double>(ca, sa, la, wx, wy, wz, vx, vy, vz);
       mp_motion_A<double, double>(ca, sa, la, dwx, dwy, dwz, dvx, dvy, dvz);
       if (HAS_FTIP) mp_force_down_A<double, double>(ca, sa, la, tnx, tny, tnz, tfx, tfy, tfz);
     }
-    MP_STAGE();
-    const double s = (double)sf, c = (double)cf, d = (double)st.getj(2 * N + i);
     mp_motion_B<double>(c, s, d, wx, wy, wz, vx, vy, vz);
     mp_motion_B<double>(c, s, d, dwx, dwy, dwz, dvx, dvy, dvz);
     if (HAS_FTIP) mp_force_down_B<double>(c, s, d, tnx, tny, tnz, tfx, tfy, tfz);
-    const double rev = (double)J.rev, qdi = (double)st.getj(4 * N + i), qddi = (double)st.getj(5 * N + i);
+    const double rev = (double)J.rev, qdi = (double)st.getj(2 * N + i), qddi = (double)st.getj(3 * N + i);
     const double qdr = rev * qdi, qdp = qdi - qdr;
     const double ar = rev * qddi, ap = qddi - ar;
     wz += qdr;
@@ -603,16 +607,16 @@ MP_HD void mp_rnea_cold(const MT& M, const MpCall<float>& C, const float (&q)[N]
     double nx = st.getf(6 * i + 0) + ax, ny = st.getf(6 * i + 1) + ay, nz = st.getf(6 * i + 2) + az;
     double fx = st.getf(6 * i + 3) + bx, fy = st.getf(6 * i + 4) + by, fz = st.getf(6 * i + 5) + bz;
     const double rev = (double)J.rev;
-    st.putj(3 * N + i, (float)(rev * nz + (1.0 - rev) * fz));   // tau_i, in the slot q_i occupied
+    st.putj(N + i, (float)(rev * nz + (1.0 - rev) * fz));   // tau_i, in the slot q_i occupied
     if (i > 0) {
-      const double s = (double)st.getj(i), c = (double)st.getj(N + i), d = (double)st.getj(2 * N + i);
+      const double s = st.getf(6 * N + i), c = st.getf(7 * N + i), d = (double)st.getj(i);
       mp_force_up_B<double>(c, s, d, nx, ny, nz, fx, fy, fz);
       mp_force_up_A<double, double>((double)J.ca, (double)J.sa, (double)J.a, nx, ny, nz, fx, fy, fz);
       ax = nx; ay = ny; az = nz; bx = fx; by = fy; bz = fz;
     }
   }
 #pragma unroll
-  for (int i = 0; i < N; ++i) tau[i] = st.getj(3 * N + i);
+  for (int i = 0; i < N; ++i) tau[i] = st.getj(N + i);
 }
 
 // Host form (CPU launchers, tests/hostsim): tau (unclipped) of one row given its joint state - float64 rows are the recursion
@@ -626,7 +630,8 @@ MP_HD void mp_rnea_row(const MT& M, const MpCall<typename MpTraits<T>::S>& C, co
   if constexpr (MpIsF32<T>::value) {
     if (mp_rnea_f32<N, HAS_FTIP>(M, C, js, qd, qdd, tau)) {
       MpColdLocal<N> st;
-      mp_rnea_cold<N, HAS_FTIP>(M, C, q, qd, qdd, st, tau);
+      if (C.cold_model) mp_rnea_cold<N, HAS_FTIP>(*static_cast<const MpModel<double>*>(C.cold_model), C, q, qd, qdd, st, tau);
+      else mp_rnea_cold<N, HAS_FTIP>(M, C, q, qd, qdd, st, tau);
     }
   } else {
     mp_rnea<T, N, HAS_FTIP>(M, C, js, qd, qdd, tau);

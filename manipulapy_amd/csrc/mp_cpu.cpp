@@ -85,6 +85,7 @@ MpCall<T> make_call(const mp_model* m, const double* g, const double* Ftip) {
   else mp_make_call(m->d, g ? g : kG, Ftip, &cd);
   MpCall<T> c;
   mp_call_cast(cd, &c);
+  if (!m->big) c.cold_model = &m->d;  // the float64 model for the re-evaluated float32 rows (mp_core.h, mp_rnea_row)
   return c;
 }
 

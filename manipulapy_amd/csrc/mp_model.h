@@ -62,4 +62,9 @@ struct MpCall {
   T a0[3];      // base_R^T * (-g): linear acceleration of the (fictitiously accelerated) base
   T F1n[3];     // Ftip moment, expressed in the pre-joint-1 frame
   T F1f[3];     // Ftip force,  expressed in the pre-joint-1 frame
+  // float32 calls: the float64 model (MpModel<double>) of the same robot, in memory the callee can read (device memory for the
+  // kernels, the handle's own copy for the CPU launchers), or null.  The float64 re-evaluation of ill-conditioned float32 rows
+  // (mp_core.h, mp_rnea_cold) reads its constants there; null makes it widen the float32 model instead.  The robot-specialised
+  // programs carry the float64 model as a literal and ignore this.
+  const void* cold_model;
 };
