@@ -146,6 +146,10 @@ __device__ __forceinline__ void traj_row(const MT& M, const float* __restrict__ 
 // replaced for the flagged lanes only (unclipped).
 template <int N, int G>
 struct MpColdLds { static constexpr int BYTES = G * MpColdSlot<N>::BYTES; };
+// the wave's earlier stores are acknowledged before a lane overwrites bytes another lane of the wave has just written (the
+// whole-line flush, then the re-evaluated row).  A release FENCE is the wrong tool: at agent scope it is `buffer_wbl2` - the
+// whole L2 written back, ~30 us per wave that takes the branch, c2 0.066 -> 0.275 ms - and at workgroup scope it is nothing at all.
+__device__ __forceinline__ void mp_wait_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 constexpr int MP_COLD_G = 8;  // slots of the kernels that carry a buffer of their own (256-thread blocks: one buffer per wave)
 // that buffer, declared in a kernel of BLOCK threads (float32 rows only: W = sizeof(T)), and this wave's part of it
 #define MP_COLD_BUFFER(N, BLOCK, W) \
@@ -288,7 +292,7 @@ __device__ __forceinline__ void mp_body_id_co(const MT& M, const MpCall<T>& C, c
     // cent of the waves take the branch at all), so the order of the two stores to the same bytes is made explicit.
     if (__builtin_amdgcn_ballot_w64(hard) != 0ull) {
       ST::sync();
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      mp_wait_stores();
       constexpr int G = ST::BYTES / MpColdSlot<N>::BYTES;
       static_assert(G >= 8, "the wave's row slice holds at least eight re-evaluation slots");
       // the row index is made opaque here: otherwise the per-lane addresses below are computed once at the top of the kernel,
@@ -555,7 +559,7 @@ __device__ __forceinline__ void mp_body_fk_jac_id(const MT& M, const MpCall<T>& 
     if constexpr (MpIsF32<T>::value) {  // ill-conditioned float32 rows again in float64, after the wave's rows have left (see mp_body_id_co)
       if (__builtin_amdgcn_ballot_w64(hard) != 0ull) {
         ST::sync();
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        mp_wait_stores();
         constexpr int G = MP_WAVE_LDS_BYTES / MpColdSlot<N>::BYTES;
         mp_cold_rows<N, HAS_FTIP, G>(M, C, hard, lds, [&](float (&x)[N], float (&y)[N], float (&z)[N]) {
           RunIO<float, N>::load(q, rr, x); RunIO<float, N>::load(qd, rr, y); RunIO<float, N>::load(qdd, rr, z);
@@ -826,7 +830,7 @@ __device__ __forceinline__ void mp_body_traj_id_co(const MT& M, const MpCall<flo
   // ill-conditioned rows again in float64 after the wave's rows have left (see mp_body_id_co); the inputs are generated again
   if (__builtin_amdgcn_ballot_w64(hard) != 0ull) {
     ST::sync();
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    mp_wait_stores();
     constexpr int G = MP_TRAJ_CO_LDS / MpColdSlot<N>::BYTES;
     mp_cold_rows<N, HAS_FTIP, G>(M, C, hard, lds, [&](float (&x)[N], float (&y)[N], float (&z)[N]) {
       float a2[N], e2[N];

@@ -37,7 +37,7 @@ def main():
     m = _hip.HipModel(t["S_list"], t["Mlist_per_link"], t["Glist"], t["M_ee"], t["joint_limits"])
     edges = [0.25, 0.5, 0.75, 1.0]
     counts = np.zeros(len(edges), dtype=np.int64)
-    worst, rows_total, max_abs_err = 0.0, 0, 0.0
+    worst, rows_total, max_abs_err, in_f64, waves, waves_f64 = 0.0, 0, 0.0, 0, 0, 0
     t0 = time.time()
     for k in range(nsets):
         rng = np.random.default_rng(bench.SEED + cid + 100_000 * k)
@@ -49,6 +49,10 @@ def main():
             q, qd, qdd = (np.ascontiguousarray(o[key].reshape(-1, n), dtype=np.float32) for key in ("positions", "velocities", "accelerations"))
             want = c_oracle.inverse_dynamics_rows(tab, q.astype(np.float64), qd.astype(np.float64), qdd.astype(np.float64))[0]
             got = _hip.cpu_id_trajectory(m, q, qd, qdd, dtype=np.float32)
+            hard = _hip.cpu_id_row_precision(m, q, qd, qdd)
+            in_f64 += int(hard.sum())
+            w = hard[:len(hard) // 64 * 64].reshape(-1, 64).any(axis=1)
+            waves += len(w); waves_f64 += int(w.sum())
             err = np.abs(got.astype(np.float64) - want)
             tol = 1e-4 * np.abs(want) + bench.F32_ROW * np.abs(want).max(axis=1, keepdims=True)
             ratio = (err / tol).max(axis=1)
@@ -61,6 +65,8 @@ def main():
     print(json.dumps({"config": name, "robot": cfg["robot"], "rows": rows_total, "input_sets": nsets,
                       "bound": "1e-4 |ref| + 5e-6 max|row|", "worst_over_bound": worst, "max_abs_err": max_abs_err,
                       "rows_over": {str(e): int(c) for e, c in zip(edges, counts)},
+                      "rows_evaluated_in_float64": in_f64, "share_of_rows": in_f64 / max(rows_total, 1),
+                      "share_of_64_row_waves_with_such_a_row": waves_f64 / max(waves, 1),
                       "evaluator": "mp_id_trajectory_cpu float32 (the kernels' mp_rnea template on the host) vs oracle/oracle.c"}))
 
 
