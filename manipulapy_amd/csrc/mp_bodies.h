@@ -156,13 +156,29 @@ constexpr int MP_COLD_G = 8;  // slots of the kernels that carry a buffer of the
   __shared__ __attribute__((aligned(16))) char mp_cold_lds[(BLOCK) / 64][(W) == 4 ? MpColdLds<N, MP_COLD_G>::BYTES : 16]
 #define MP_COLD_PTR (mp_cold_lds[threadIdx.x >> 6])
 
+// Hand the wave's flagged rows to the float64 pass that follows this kernel on the stream: one atomic per wave reserves the
+// places, every flagged lane writes its row index.  False (nothing handed over) without a list or when it is full.
+__device__ __forceinline__ bool mp_push_hard_rows(const MpCall<float>& C, unsigned long long mask, int rank, bool hard, long row) {
+  if (C.hard_rows == nullptr) return false;                   // wave-uniform (kernel argument)
+  const unsigned n = (unsigned)__builtin_popcountll(mask);
+  unsigned base = 0;
+  if (rank == 0 && hard) base = atomicAdd(C.hard_ctrl, n);  // the first flagged lane
+  base = __builtin_amdgcn_readlane(base, (int)__builtin_ctzll(mask));
+  if (base + n > C.hard_cap) return false;                    // full: wave-uniform; the count overshoots, the pass clamps it
+  if (hard) C.hard_rows[base + (unsigned)rank] = C.hard_row_base + (unsigned)row;
+  return true;
+}
+
+// True (wave-uniform) when flagged rows were re-evaluated HERE - tau of the flagged lanes then holds the float64 result; false when
+// there were none or they were handed to the float64 pass (`row`: the lane's row index for that list; < 0: never hand over).
 template <int N, bool HAS_FTIP, int G, typename MT, typename LoadFn>
-__device__ __forceinline__ void mp_cold_rows(const MT& M, const MpCall<float>& C, bool hard, char* __restrict__ lds, LoadFn load,
+__device__ __forceinline__ bool mp_cold_rows(const MT& M, const MpCall<float>& C, bool hard, long row, char* __restrict__ lds, LoadFn load,
                                              float (&tau)[N]) {
 #if MP_ADAPTIVE_F32 && defined(__HIP_DEVICE_COMPILE__)
   const unsigned long long mask = __builtin_amdgcn_ballot_w64(hard);
-  if (__builtin_expect(mask == 0ull, 1)) return;  // wave-uniform
+  if (__builtin_expect(mask == 0ull, 1)) return false;  // wave-uniform
   const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+  if (row >= 0 && mp_push_hard_rows(C, mask, rank, hard, row)) return false;
   const int total = __builtin_popcountll(mask);
   for (int base = 0; base < total; base += G) {  // wave-uniform trip count
     const int slot = rank - base;
@@ -178,7 +194,44 @@ __device__ __forceinline__ void mp_cold_rows(const MT& M, const MpCall<float>& C
 #endif
     }
   }
+  return true;
+#else
+  return false;
 #endif
+}
+
+// The float64 pass over the rows a float32 kernel handed over: one row per lane, everything in float64 from the row's float32
+// inputs (`Mc`: the float64 model; `M`: the float32 one, for the torque limits the float32 kernels clip against), unrolled - this
+// kernel is register-allocated on its own (~170 VGPRs), which is the point of making it one.  `load(row, q, qd, qdd)` fetches or
+// regenerates a row's inputs.  The last block to finish resets the list for its next user.
+template <int N, bool HAS_FTIP, typename MC, typename MF, typename LoadFn>
+__device__ __forceinline__ void mp_body_id_hard(const MC& Mc, const MF& M, const MpCall<float>& C, LoadFn load, float* __restrict__ tau) {
+  unsigned n = C.hard_ctrl[0];
+  n = n < C.hard_cap ? n : C.hard_cap;
+  const unsigned stride = gridDim.x * blockDim.x;
+  for (unsigned k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
+    const long r = (long)C.hard_rows[k];
+    float q[N], qd[N], qdd[N];
+    load(r, q, qd, qdd);
+    double a[N], b[N], c[N], t[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { a[i] = (double)q[i]; b[i] = (double)qd[i]; c[i] = (double)qdd[i]; }
+    MpCall<double> Cd;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { Cd.a0[i] = (double)C.a0[i]; Cd.F1n[i] = (double)C.F1n[i]; Cd.F1f[i] = (double)C.F1f[i]; }
+    MpJointState<double, N> js;
+    mp_joint_state<double, N>(Mc, a, js);
+    mp_rnea<double, N, HAS_FTIP>(Mc, Cd, js, b, c, t);
+    float out[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) out[i] = mp_clip((float)t[i], M.taumin[i], M.taumax[i]);
+    RunIO<float, N>::store(tau, r, out);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(C.hard_ctrl + 1, 1u) == gridDim.x - 1) { C.hard_ctrl[0] = 0; C.hard_ctrl[1] = 0; }
+  }
 }
 
 // ------------------------------------------------------------------ one row per lane (float / double)
@@ -196,7 +249,7 @@ __device__ __forceinline__ void mp_body_id(const MT& M, const MpCall<T>& C, cons
   bad.add(a); bad.add(b); bad.add(c);
   if constexpr (MpIsF32<T>::value) {
     const bool hard = mp_rnea_f32<N, HAS_FTIP>(M, C, js, b, c, t) && !bad.any();
-    mp_cold_rows<N, HAS_FTIP, MP_COLD_G>(M, C, hard, cold, [&](float (&x)[N], float (&y)[N], float (&z)[N]) {
+    mp_cold_rows<N, HAS_FTIP, MP_COLD_G>(M, C, hard, r, cold, [&](float (&x)[N], float (&y)[N], float (&z)[N]) {
       RunIO<float, N>::load(q, r, x); RunIO<float, N>::load(qd, r, y); RunIO<float, N>::load(qdd, r, z);
     }, t);
   } else {
@@ -299,10 +352,10 @@ __device__ __forceinline__ void mp_body_id_co(const MT& M, const MpCall<T>& C, c
       // shared with the fetch, and kept alive (or spilled) across the whole float32 pass for the sake of this branch
       long rr = row0 + lane;
       asm volatile("" : "+v"(rr));
-      mp_cold_rows<N, HAS_FTIP, G>(M, C, hard, lds, [&](float (&x)[N], float (&y)[N], float (&z)[N]) {
+      const bool here = mp_cold_rows<N, HAS_FTIP, G>(M, C, hard, rr, lds, [&](float (&x)[N], float (&y)[N], float (&z)[N]) {
         RunIO<float, N>::load(q, rr, x); RunIO<float, N>::load(qd, rr, y); RunIO<float, N>::load(qdd, rr, z);
       }, t);
-      if (hard) {
+      if (here && hard) {
 #pragma unroll
         for (int j = 0; j < N; ++j) t[j] = mp_clip(t[j], M.taumin[j], M.taumax[j]);
         RunIO<float, N>::store(tau, rr, t);
@@ -561,10 +614,10 @@ __device__ __forceinline__ void mp_body_fk_jac_id(const MT& M, const MpCall<T>& 
         ST::sync();
         mp_wait_stores();
         constexpr int G = MP_WAVE_LDS_BYTES / MpColdSlot<N>::BYTES;
-        mp_cold_rows<N, HAS_FTIP, G>(M, C, hard, lds, [&](float (&x)[N], float (&y)[N], float (&z)[N]) {
+        const bool here = mp_cold_rows<N, HAS_FTIP, G>(M, C, hard, -1L, lds, [&](float (&x)[N], float (&y)[N], float (&z)[N]) {
           RunIO<float, N>::load(q, rr, x); RunIO<float, N>::load(qd, rr, y); RunIO<float, N>::load(qdd, rr, z);
         }, t);
-        if (hard) {
+        if (here && hard) {
 #pragma unroll
           for (int j = 0; j < N; ++j) t[j] = mp_clip(t[j], M.taumin[j], M.taumax[j]);
           RunIO<float, N>::store(tau, r, t);
@@ -612,11 +665,11 @@ __device__ __forceinline__ void mp_rnea_pk(const MT& M, const MpCall<float>& C, 
   for (int i = 0; i < N; ++i) { tx[i] = tau[i].x; ty[i] = tau[i].y; }
   const bool hx = mp_id_row_is_hard<N>(tx, sN.x, sF.x, M.lscale) && !bad.x.any();
   const bool hy = mp_id_row_is_hard<N>(ty, sN.y, sF.y, M.lscale) && !bad.y.any();
-  mp_cold_rows<N, HAS_FTIP, MP_COLD_G>(M, C, hx, cold, [&](float (&a)[N], float (&b)[N], float (&c)[N]) {
+  mp_cold_rows<N, HAS_FTIP, MP_COLD_G>(M, C, hx, -1L, cold, [&](float (&a)[N], float (&b)[N], float (&c)[N]) {
 #pragma unroll
     for (int i = 0; i < N; ++i) { a[i] = q[i].x; b[i] = qd[i].x; c[i] = qdd[i].x; }
   }, tx);
-  mp_cold_rows<N, HAS_FTIP, MP_COLD_G>(M, C, hy, cold, [&](float (&a)[N], float (&b)[N], float (&c)[N]) {
+  mp_cold_rows<N, HAS_FTIP, MP_COLD_G>(M, C, hy, -1L, cold, [&](float (&a)[N], float (&b)[N], float (&c)[N]) {
 #pragma unroll
     for (int i = 0; i < N; ++i) { a[i] = q[i].y; b[i] = qd[i].y; c[i] = qdd[i].y; }
   }, ty);
@@ -769,7 +822,7 @@ __device__ __forceinline__ void mp_body_traj_id_tab(const MT& M, const MpCall<fl
   MpBad<float> bad;  // a non-finite end point makes the generated row non-finite
   bad.add(qq); bad.add(qd); bad.add(qdd);
   const bool hard = mp_rnea_f32<N, HAS_FTIP>(M, C, js, qd, qdd, tq) && !bad.any();
-  mp_cold_rows<N, HAS_FTIP, MP_COLD_G>(M, C, hard, cold, [&](float (&x)[N], float (&y)[N], float (&z)[N]) {
+  mp_cold_rows<N, HAS_FTIP, MP_COLD_G>(M, C, hard, -1L, cold, [&](float (&x)[N], float (&y)[N], float (&z)[N]) {
 #pragma unroll
     for (int j = 0; j < N; ++j) { x[j] = qq[j]; y[j] = qd[j]; z[j] = qdd[j]; }
   }, tq);
@@ -832,7 +885,7 @@ __device__ __forceinline__ void mp_body_traj_id_co(const MT& M, const MpCall<flo
     ST::sync();
     mp_wait_stores();
     constexpr int G = MP_TRAJ_CO_LDS / MpColdSlot<N>::BYTES;
-    mp_cold_rows<N, HAS_FTIP, G>(M, C, hard, lds, [&](float (&x)[N], float (&y)[N], float (&z)[N]) {
+    const bool here = mp_cold_rows<N, HAS_FTIP, G>(M, C, hard, (long)row0 + lane, lds, [&](float (&x)[N], float (&y)[N], float (&z)[N]) {
       float a2[N], e2[N];
       RunIO<float, N>::load(start, (long)b, a2);
       RunIO<float, N>::load(end, (long)b, e2);
@@ -845,7 +898,7 @@ __device__ __forceinline__ void mp_body_traj_id_co(const MT& M, const MpCall<flo
         z[j] = (float)(u2 * d);
       }
     }, tq);
-    if (hard) {
+    if (here && hard) {
 #pragma unroll
       for (int j = 0; j < N; ++j) tq[j] = mp_clip(tq[j], M.taumin[j], M.taumax[j]);
       RunIO<float, N>::store(tau, (long)row0 + lane, tq);

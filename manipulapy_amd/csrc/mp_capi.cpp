@@ -37,6 +37,7 @@ struct MpSpec {  // run-time specialised kernels of one model on one device
   hipFunction_t fd_traj_tm[2] = {nullptr, nullptr};                            // the roll-out on the time-major device layout
   hipFunction_t id_co[2] = {nullptr, nullptr};   // id_s with whole-line non-temporal row movement through LDS (full waves only); optional
   hipFunction_t traj_id_co[2] = {nullptr, nullptr};  // generation fused into it on flat rows, tau as whole lines; optional
+  hipFunction_t id_hard[2] = {nullptr, nullptr}, traj_id_hard[2] = {nullptr, nullptr};  // the float64 pass over handed-over rows; optional
 };
 struct mp_ctx {
   int device = -1;
@@ -51,6 +52,9 @@ struct mp_ctx {
   int compute_units = 0;
   bool capturing = false;                              // between mp_graph_begin and mp_graph_end
   void* queue_counter = nullptr;                       // 8-byte work-queue head of the IK kernel (lazily allocated)
+  unsigned* hard_rows = nullptr;                       // row indices the float32 inverse-dynamics kernels hand to the float64 pass
+  unsigned* hard_ctrl = nullptr;                       //   [0] how many, [1] blocks of the pass that have finished (it resets both)
+  unsigned hard_cap = 0;
   double* time_tab = nullptr;                          // per-timestep time-scaling table of the fused kernels
   long tab_cap = 0, tab_Nt = -1;                       // its capacity in timesteps / the call it currently holds
   double tab_Tf = 0;
@@ -313,6 +317,27 @@ void make_call_f32(mp_ctx* ctx, const mp_model* model, const double* g, const do
   }
   if (it != ctx->dev_models.end()) c->cold_model = (const char*)it->second + kDevModelD;
 }
+// The list a float32 inverse-dynamics launch of `rows` rows leaves its ill-conditioned rows in for the float64 pass that follows
+// it on the stream (csrc/mp_bodies.h, mp_push_hard_rows / mp_body_id_hard): room for one row in eight (c2-distributed rows flag
+// 0.5 - 1.5 %; a wave that finds the list full re-evaluates its rows itself).  0 blocks = no list (the kernels then re-evaluate in
+// place): more than 2^32 rows, or a first use inside a graph capture.
+unsigned attach_hard_list(mp_ctx* ctx, long rows, MpCall<float>* c) {
+  static const bool on = !(getenv("MANIPULAPY_HIP_HARD_PASS") && getenv("MANIPULAPY_HIP_HARD_PASS")[0] == '0');  // experiment switch
+  if (!on || rows >= 0xffffffffL) return 0;
+  const unsigned need = (unsigned)std::min<long>(std::max<long>(rows / 8, 1L << 16), 1L << 28);
+  if (ctx->hard_cap < need) {
+    if (ctx->capturing) return 0;
+    if (hipStreamSynchronize(ctx->compute) != hipSuccess) return 0;
+    if (ctx->hard_rows) (void)hipFree(ctx->hard_rows);
+    if (!ctx->hard_ctrl && (hipMalloc((void**)&ctx->hard_ctrl, 2 * sizeof(unsigned)) != hipSuccess ||
+                            hipMemset(ctx->hard_ctrl, 0, 2 * sizeof(unsigned)) != hipSuccess)) { ctx->hard_ctrl = nullptr; return 0; }
+    ctx->hard_rows = nullptr; ctx->hard_cap = 0;
+    if (hipMalloc((void**)&ctx->hard_rows, (size_t)need * sizeof(unsigned)) != hipSuccess) { ctx->hard_rows = nullptr; return 0; }
+    ctx->hard_cap = need;
+  }
+  c->hard_rows = ctx->hard_rows; c->hard_ctrl = ctx->hard_ctrl; c->hard_cap = ctx->hard_cap; c->hard_row_base = 0;
+  return (unsigned)std::min<long>((rows / 8 + 63) / 64 + 1, 1024);
+}
 template <typename T> void make_call_ctx(mp_ctx* ctx, const mp_model* model, const double* g, const double* Ftip, MpCall<T>* c);
 template <> void make_call_ctx<float>(mp_ctx* ctx, const mp_model* model, const double* g, const double* Ftip, MpCall<float>* c) {
   make_call_f32(ctx, model, g, Ftip, c);
@@ -382,6 +407,14 @@ int launch_id(mp_ctx* ctx, const mp_model* model, const MpCall<float>& c, bool f
   if (const MpSpec* sp = find_spec(ctx, model)) {
     if (spec_scalar_f32(model->d.n)) {  // one row per lane
       MpCall<float> cc = c;
+      // ill-conditioned rows go to a float64 pass of their own behind the float32 kernels (see attach_hard_list)
+      const unsigned hard_blocks = sp->id_hard[ftip ? 1 : 0] ? attach_hard_list(ctx, rows, &cc) : 0;
+      auto hard_pass = [&]() -> int {
+        if (!hard_blocks) return MP_OK;
+        cc.hard_row_base = 0;
+        void* args[] = {&cc, &q, &qd, &qdd, &tau};
+        return launch_spec(ctx, sp->id_hard[ftip ? 1 : 0], (long)hard_blocks * 64, args, 64);
+      };
       long done = 0;
       if (sp->id_co[ftip ? 1 : 0] && rows >= 64 && id_co_enabled()) {  // whole waves: rows moved as whole lines, non-temporal (mp_body_id_co)
         long rows64 = rows & ~63L;
@@ -389,13 +422,15 @@ int launch_id(mp_ctx* ctx, const mp_model* model, const MpCall<float>& c, bool f
         if (int rc = launch_spec(ctx, sp->id_co[ftip ? 1 : 0], rows64, args, MP_JIT_ID_CO_BLOCK)) return rc;
         done = rows64;
       }
-      if (done == rows) return MP_OK;
+      if (done == rows) return hard_pass();
       const long off = done * model->d.n;  // the last rows (< 64), or everything without the whole-line kernel: per-lane rows
       const float *q2 = q + off, *qd2 = qd + off, *qdd2 = qdd + off;
       float* tau2 = tau + off;
       long left = rows - done;
+      cc.hard_row_base = (unsigned)done;
       void* args[] = {&cc, &q2, &qd2, &qdd2, &tau2, &left};
-      return launch_spec(ctx, sp->id_s[ftip ? 1 : 0], left, args);
+      if (int rc = launch_spec(ctx, sp->id_s[ftip ? 1 : 0], left, args)) return rc;
+      return hard_pass();
     }
     if (pairs > 0) {
       MpCall<float> cc = c;
@@ -412,7 +447,10 @@ int launch_id(mp_ctx* ctx, const mp_model* model, const MpCall<float>& c, bool f
   if (generic_f32_mode() == 2 && !ctx->capturing) {  // one row per lane, device-resident model (not while capturing: first use uploads it)
     const MpModel<float>* dm = nullptr;
     if (int rc = device_model(ctx, model, &dm)) return rc;
-    HIP_TRY(mpk_id_dm(ctx->compute, dm, model->d.n, c, ftip, q, qd, qdd, tau, rows));
+    MpCall<float> cc = c;
+    const unsigned hard_blocks = cc.cold_model ? attach_hard_list(ctx, rows, &cc) : 0;
+    HIP_TRY(mpk_id_dm(ctx->compute, dm, model->d.n, cc, ftip, q, qd, qdd, tau, rows));
+    HIP_TRY(mpk_id_hard(ctx->compute, dm, model->d.n, cc, ftip, q, qd, qdd, tau, hard_blocks));
     return MP_OK;
   }
   HIP_TRY(mpk_id<float>(ctx->compute, model->f, c, ftip, q, qd, qdd, tau, rows));
@@ -760,6 +798,8 @@ int mp_ctx_destroy(mp_ctx* ctx) {
   for (hipModule_t m : ctx->retired_mods) (void)hipModuleUnload(m);
   for (auto& kv : ctx->live) (void)hipFree(kv.first);
   if (ctx->queue_counter) (void)hipFree(ctx->queue_counter);
+  if (ctx->hard_rows) (void)hipFree(ctx->hard_rows);
+  if (ctx->hard_ctrl) (void)hipFree(ctx->hard_ctrl);
   if (ctx->time_tab) (void)hipFree(ctx->time_tab);
   for (void* p : ctx->retired_tabs) (void)hipFree(p);
   if (ctx->compute) (void)hipStreamDestroy(ctx->compute);
@@ -1234,6 +1274,12 @@ int mp_model_specialize(mp_ctx* ctx, const mp_model* model) {
   if (hipModuleGetFunction(&sp.traj_id_co[0], sp.mod, "mp_spec_traj_id_co_f0") != hipSuccess ||
       hipModuleGetFunction(&sp.traj_id_co[1], sp.mod, "mp_spec_traj_id_co_f1") != hipSuccess)
     sp.traj_id_co[0] = sp.traj_id_co[1] = nullptr;
+  if (hipModuleGetFunction(&sp.id_hard[0], sp.mod, "mp_spec_id_hard_f0") != hipSuccess ||
+      hipModuleGetFunction(&sp.id_hard[1], sp.mod, "mp_spec_id_hard_f1") != hipSuccess)
+    sp.id_hard[0] = sp.id_hard[1] = nullptr;
+  if (hipModuleGetFunction(&sp.traj_id_hard[0], sp.mod, "mp_spec_traj_id_hard_f0") != hipSuccess ||
+      hipModuleGetFunction(&sp.traj_id_hard[1], sp.mod, "mp_spec_traj_id_hard_f1") != hipSuccess)
+    sp.traj_id_hard[0] = sp.traj_id_hard[1] = nullptr;
   // the second program: same kernels, other scheduling strategy; anything that goes wrong here leaves the first program's
   // versions in place (MANIPULAPY_HIP_ILP_PART=0 skips it)
   {
@@ -1430,8 +1476,12 @@ int mp_traj_id_fused_f32(mp_ctx* ctx, const mp_model* model, const float* d_star
     if (traj_co && sp->traj_id_co[ftip ? 1 : 0] && N >= 64 && (unsigned long long)B * (unsigned long long)N < 0xffffffc0ull) {
       unsigned rows = (unsigned)((unsigned long long)B * (unsigned long long)N), ntu = (unsigned)N;
       unsigned magic = (unsigned)(0x100000000ull / (unsigned long long)N);
+      const unsigned hard_blocks = sp->traj_id_hard[ftip ? 1 : 0] ? attach_hard_list(ctx, (long)rows, &c) : 0;
       void* args[] = {&c, &d_start, &d_end, &ntu, &magic, &tab, &d_tau, &rows};
-      return launch_spec(ctx, sp->traj_id_co[ftip ? 1 : 0], (long)rows, args, 64);
+      if (int rc = launch_spec(ctx, sp->traj_id_co[ftip ? 1 : 0], (long)rows, args, 64)) return rc;
+      if (!hard_blocks) return MP_OK;
+      void* hargs[] = {&c, &d_start, &d_end, &ntu, &tab, &d_tau};
+      return launch_spec(ctx, sp->traj_id_hard[ftip ? 1 : 0], (long)hard_blocks * 64, hargs, 64);
     }
     if (!mpk_packed_f32()) {  // MANIPULAPY_HIP_F32=scalar: one timestep per lane (measured slower: c2f 0.063 vs 0.054 ms)
       unsigned bpt = (unsigned)((nt + 255) / 256);

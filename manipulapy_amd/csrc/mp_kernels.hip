@@ -53,6 +53,18 @@ __global__ __launch_bounds__(kBlock) void k_id_dm(const MpModel<T>* __restrict__
   mp_body_id<T, N, HAS_FTIP>(*(MC*)Mdev, C, q, qd, qdd, tau, r, MP_COLD_PTR);
 }
 
+// The float64 pass over the rows k_id_dm handed over (mp_body_id_hard, csrc/mp_bodies.h): both models through device pointers.
+template <int N, bool HAS_FTIP>
+__global__ __launch_bounds__(64) void k_id_hard(const MpModel<float>* __restrict__ Mdev, const MpCall<float> C, const float* __restrict__ q,
+                                                const float* __restrict__ qd, const float* __restrict__ qdd, float* __restrict__ tau) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  mp_body_id_hard<N, HAS_FTIP>(*(MpModelConstD*)C.cold_model, *(MpModelConstF*)Mdev, C,
+                               [&](long r, float (&x)[N], float (&y)[N], float (&z)[N]) {
+                                 RunIO<float, N>::load(q, r, x); RunIO<float, N>::load(qd, r, y); RunIO<float, N>::load(qdd, r, z);
+                               }, tau);
+#endif
+}
+
 // -------------------------------------------------------------- trajectory generation pieces
 template <int N>
 __global__ __launch_bounds__(kBlock) void k_batch_traj(const MpModel<float> M, const float* __restrict__ start,
@@ -106,7 +118,7 @@ __global__ __launch_bounds__(kBlock) void k_traj_id(const MpModel<float> M, cons
   MpBad<float> bad;
   bad.add(p); bad.add(v); bad.add(a);
   const bool hard = mp_rnea_f32<N, HAS_FTIP>(M, C, js, v, a, tq) && !bad.any();
-  mp_cold_rows<N, HAS_FTIP, MP_COLD_G>(M, C, hard, MP_COLD_PTR, [&](float (&x)[N], float (&y)[N], float (&z)[N]) {
+  mp_cold_rows<N, HAS_FTIP, MP_COLD_G>(M, C, hard, -1L, MP_COLD_PTR, [&](float (&x)[N], float (&y)[N], float (&z)[N]) {
 #pragma unroll
     for (int j = 0; j < N; ++j) { x[j] = p[j]; y[j] = v[j]; z[j] = a[j]; }
   }, tq);
@@ -488,6 +500,16 @@ hipError_t mpk_id_dm(hipStream_t s, const MpModel<float>* d_model, int n, const 
   MP_DISPATCH_N(n, {
     if (ftip) hipLaunchKernelGGL((k_id_dm<T, N, true>), dim3(grid_for(rows)), dim3(kBlock), 0, s, d_model, C, q, qd, qdd, tau, rows);
     else hipLaunchKernelGGL((k_id_dm<T, N, false>), dim3(grid_for(rows)), dim3(kBlock), 0, s, d_model, C, q, qd, qdd, tau, rows);
+  })
+  return hipGetLastError();
+}
+
+hipError_t mpk_id_hard(hipStream_t s, const MpModel<float>* d_model, int n, const MpCall<float>& C, bool ftip, const float* q,
+                       const float* qd, const float* qdd, float* tau, unsigned blocks) {
+  if (blocks == 0 || !C.hard_rows || !C.cold_model) return hipSuccess;
+  MP_DISPATCH_N(n, {
+    if (ftip) hipLaunchKernelGGL((k_id_hard<N, true>), dim3(blocks), dim3(64), 0, s, d_model, C, q, qd, qdd, tau);
+    else hipLaunchKernelGGL((k_id_hard<N, false>), dim3(blocks), dim3(64), 0, s, d_model, C, q, qd, qdd, tau);
   })
   return hipGetLastError();
 }

@@ -67,4 +67,11 @@ struct MpCall {
   // (mp_core.h, mp_rnea_cold) reads its constants there; null makes it widen the float32 model instead.  The robot-specialised
   // programs carry the float64 model as a literal and ignore this.
   const void* cold_model;
+  // float32 device calls: where a kernel leaves the indices of its ill-conditioned rows for the float64 pass that follows it on
+  // the stream (mp_capi.cpp, launch_hard_rows) instead of re-evaluating them itself: `hard_rows` takes up to `hard_cap` row
+  // indices (+ hard_row_base), hard_ctrl[0] counts them.  Null: the kernel re-evaluates in place (mp_cold_rows).
+  unsigned* hard_rows;
+  unsigned* hard_ctrl;
+  unsigned hard_cap;
+  unsigned hard_row_base;
 };
