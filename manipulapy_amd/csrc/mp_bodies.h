@@ -203,14 +203,16 @@ __device__ __forceinline__ bool mp_cold_rows(const MT& M, const MpCall<float>& C
 // The float64 pass over the rows a float32 kernel handed over: one row per lane, everything in float64 from the row's float32
 // inputs (`Mc`: the float64 model; `M`: the float32 one, for the torque limits the float32 kernels clip against), unrolled - this
 // kernel is register-allocated on its own (~170 VGPRs), which is the point of making it one.  `load(row, q, qd, qdd)` fetches or
-// regenerates a row's inputs.  The last block to finish resets the list for its next user.
+// regenerates a row's inputs.  *hard_ctrl is this launch's count, *hard_next the next launch's.
 template <int N, bool HAS_FTIP, typename MC, typename MF, typename LoadFn>
-__device__ __forceinline__ void mp_body_id_hard(const MC& Mc, const MF& M, const MpCall<float>& C, LoadFn load, float* __restrict__ tau) {
+__device__ __forceinline__ void mp_body_id_hard(const MC& Mc, const MF& M, const MpCall<float>& C, LoadFn load, float* __restrict__ tau,
+                                                unsigned rows) {
   unsigned n = C.hard_ctrl[0];
   n = n < C.hard_cap ? n : C.hard_cap;
   const unsigned stride = gridDim.x * blockDim.x;
   for (unsigned k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
     const long r = (long)C.hard_rows[k];
+    if (r >= (long)rows) continue;  // (a list left behind by a launch whose pass never ran)
     float q[N], qd[N], qdd[N];
     load(r, q, qd, qdd);
     double a[N], b[N], c[N], t[N];
@@ -227,11 +229,10 @@ __device__ __forceinline__ void mp_body_id_hard(const MC& Mc, const MF& M, const
     for (int i = 0; i < N; ++i) out[i] = mp_clip((float)t[i], M.taumin[i], M.taumax[i]);
     RunIO<float, N>::store(tau, r, out);
   }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
-    if (atomicAdd(C.hard_ctrl + 1, 1u) == gridDim.x - 1) { C.hard_ctrl[0] = 0; C.hard_ctrl[1] = 0; }
-  }
+  // the OTHER counter is the next launch's (the context alternates between two): zeroed here, by the pass that runs between its
+  // previous reader and its next writers on the stream.  (Resetting this launch's own counter needs "every block has read it":
+  // one atomic per block on one address - 1024 of them measured 20 us per launch.)
+  if (blockIdx.x == 0 && threadIdx.x == 0) *C.hard_next = 0;
 }
 
 // ------------------------------------------------------------------ one row per lane (float / double)

@@ -53,8 +53,9 @@ struct mp_ctx {
   bool capturing = false;                              // between mp_graph_begin and mp_graph_end
   void* queue_counter = nullptr;                       // 8-byte work-queue head of the IK kernel (lazily allocated)
   unsigned* hard_rows = nullptr;                       // row indices the float32 inverse-dynamics kernels hand to the float64 pass
-  unsigned* hard_ctrl = nullptr;                       //   [0] how many, [1] blocks of the pass that have finished (it resets both)
+  unsigned* hard_ctrl = nullptr;                       //   two counters, used alternately: each pass zeroes the other one
   unsigned hard_cap = 0;
+  unsigned hard_turn = 0;
   double* time_tab = nullptr;                          // per-timestep time-scaling table of the fused kernels
   long tab_cap = 0, tab_Nt = -1;                       // its capacity in timesteps / the call it currently holds
   double tab_Tf = 0;
@@ -329,13 +330,18 @@ unsigned attach_hard_list(mp_ctx* ctx, long rows, MpCall<float>* c) {
     if (ctx->capturing) return 0;
     if (hipStreamSynchronize(ctx->compute) != hipSuccess) return 0;
     if (ctx->hard_rows) (void)hipFree(ctx->hard_rows);
-    if (!ctx->hard_ctrl && (hipMalloc((void**)&ctx->hard_ctrl, 2 * sizeof(unsigned)) != hipSuccess ||
-                            hipMemset(ctx->hard_ctrl, 0, 2 * sizeof(unsigned)) != hipSuccess)) { ctx->hard_ctrl = nullptr; return 0; }
+    if (!ctx->hard_ctrl && (hipMalloc((void**)&ctx->hard_ctrl, 4 * sizeof(unsigned)) != hipSuccess ||
+                            hipMemset(ctx->hard_ctrl, 0, 4 * sizeof(unsigned)) != hipSuccess)) { ctx->hard_ctrl = nullptr; return 0; }
     ctx->hard_rows = nullptr; ctx->hard_cap = 0;
     if (hipMalloc((void**)&ctx->hard_rows, (size_t)need * sizeof(unsigned)) != hipSuccess) { ctx->hard_rows = nullptr; return 0; }
     ctx->hard_cap = need;
   }
-  c->hard_rows = ctx->hard_rows; c->hard_ctrl = ctx->hard_ctrl; c->hard_cap = ctx->hard_cap; c->hard_row_base = 0;
+  // two counters: launch n counts in ctrl[n & 1], its pass zeroes the other one, which launch n + 1 counts in.  A launch captured
+  // into a graph would replay with the same counter every time and find it non-zero: captured launches get no list (in place).
+  if (ctx->capturing) return 0;
+  const unsigned turn = ctx->hard_turn++ & 1u;
+  c->hard_rows = ctx->hard_rows; c->hard_ctrl = ctx->hard_ctrl + turn; c->hard_next = ctx->hard_ctrl + (turn ^ 1u);
+  c->hard_cap = ctx->hard_cap; c->hard_row_base = 0;
   return (unsigned)std::min<long>((rows / 8 + 63) / 64 + 1, 1024);
 }
 template <typename T> void make_call_ctx(mp_ctx* ctx, const mp_model* model, const double* g, const double* Ftip, MpCall<T>* c);
@@ -412,7 +418,8 @@ int launch_id(mp_ctx* ctx, const mp_model* model, const MpCall<float>& c, bool f
       auto hard_pass = [&]() -> int {
         if (!hard_blocks) return MP_OK;
         cc.hard_row_base = 0;
-        void* args[] = {&cc, &q, &qd, &qdd, &tau};
+        unsigned nrows = (unsigned)rows;
+        void* args[] = {&cc, &q, &qd, &qdd, &tau, &nrows};
         return launch_spec(ctx, sp->id_hard[ftip ? 1 : 0], (long)hard_blocks * 64, args, 64);
       };
       long done = 0;
@@ -450,7 +457,7 @@ int launch_id(mp_ctx* ctx, const mp_model* model, const MpCall<float>& c, bool f
     MpCall<float> cc = c;
     const unsigned hard_blocks = cc.cold_model ? attach_hard_list(ctx, rows, &cc) : 0;
     HIP_TRY(mpk_id_dm(ctx->compute, dm, model->d.n, cc, ftip, q, qd, qdd, tau, rows));
-    HIP_TRY(mpk_id_hard(ctx->compute, dm, model->d.n, cc, ftip, q, qd, qdd, tau, hard_blocks));
+    HIP_TRY(mpk_id_hard(ctx->compute, dm, model->d.n, cc, ftip, q, qd, qdd, tau, (unsigned)rows, hard_blocks));
     return MP_OK;
   }
   HIP_TRY(mpk_id<float>(ctx->compute, model->f, c, ftip, q, qd, qdd, tau, rows));
@@ -1480,7 +1487,7 @@ int mp_traj_id_fused_f32(mp_ctx* ctx, const mp_model* model, const float* d_star
       void* args[] = {&c, &d_start, &d_end, &ntu, &magic, &tab, &d_tau, &rows};
       if (int rc = launch_spec(ctx, sp->traj_id_co[ftip ? 1 : 0], (long)rows, args, 64)) return rc;
       if (!hard_blocks) return MP_OK;
-      void* hargs[] = {&c, &d_start, &d_end, &ntu, &tab, &d_tau};
+      void* hargs[] = {&c, &d_start, &d_end, &ntu, &tab, &d_tau, &rows};
       return launch_spec(ctx, sp->traj_id_hard[ftip ? 1 : 0], (long)hard_blocks * 64, hargs, 64);
     }
     if (!mpk_packed_f32()) {  // MANIPULAPY_HIP_F32=scalar: one timestep per lane (measured slower: c2f 0.063 vs 0.054 ms)

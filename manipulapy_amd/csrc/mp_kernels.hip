@@ -56,12 +56,12 @@ __global__ __launch_bounds__(kBlock) void k_id_dm(const MpModel<T>* __restrict__
 // The float64 pass over the rows k_id_dm handed over (mp_body_id_hard, csrc/mp_bodies.h): both models through device pointers.
 template <int N, bool HAS_FTIP>
 __global__ __launch_bounds__(64) void k_id_hard(const MpModel<float>* __restrict__ Mdev, const MpCall<float> C, const float* __restrict__ q,
-                                                const float* __restrict__ qd, const float* __restrict__ qdd, float* __restrict__ tau) {
+                                                const float* __restrict__ qd, const float* __restrict__ qdd, float* __restrict__ tau, unsigned rows) {
 #if defined(__HIP_DEVICE_COMPILE__)
   mp_body_id_hard<N, HAS_FTIP>(*(MpModelConstD*)C.cold_model, *(MpModelConstF*)Mdev, C,
                                [&](long r, float (&x)[N], float (&y)[N], float (&z)[N]) {
                                  RunIO<float, N>::load(q, r, x); RunIO<float, N>::load(qd, r, y); RunIO<float, N>::load(qdd, r, z);
-                               }, tau);
+                               }, tau, rows);
 #endif
 }
 
@@ -505,11 +505,11 @@ hipError_t mpk_id_dm(hipStream_t s, const MpModel<float>* d_model, int n, const 
 }
 
 hipError_t mpk_id_hard(hipStream_t s, const MpModel<float>* d_model, int n, const MpCall<float>& C, bool ftip, const float* q,
-                       const float* qd, const float* qdd, float* tau, unsigned blocks) {
+                       const float* qd, const float* qdd, float* tau, unsigned rows, unsigned blocks) {
   if (blocks == 0 || !C.hard_rows || !C.cold_model) return hipSuccess;
   MP_DISPATCH_N(n, {
-    if (ftip) hipLaunchKernelGGL((k_id_hard<N, true>), dim3(blocks), dim3(64), 0, s, d_model, C, q, qd, qdd, tau);
-    else hipLaunchKernelGGL((k_id_hard<N, false>), dim3(blocks), dim3(64), 0, s, d_model, C, q, qd, qdd, tau);
+    if (ftip) hipLaunchKernelGGL((k_id_hard<N, true>), dim3(blocks), dim3(64), 0, s, d_model, C, q, qd, qdd, tau, rows);
+    else hipLaunchKernelGGL((k_id_hard<N, false>), dim3(blocks), dim3(64), 0, s, d_model, C, q, qd, qdd, tau, rows);
   })
   return hipGetLastError();
 }

@@ -319,7 +319,7 @@ int mp_compile_model_big(int n, const double* S, const double* Mcom, const doubl
 // per-call constants (gravity, tip wrench) seen from the frame link 1 is attached to
 void mp_make_call(const double R[9], const double p[3], const double g[3], const double Ftip[6], MpCall<double>* c) {
   c->cold_model = nullptr;
-  c->hard_rows = nullptr; c->hard_ctrl = nullptr; c->hard_cap = 0; c->hard_row_base = 0;
+  c->hard_rows = nullptr; c->hard_ctrl = nullptr; c->hard_next = nullptr; c->hard_cap = 0; c->hard_row_base = 0;
   for (int k = 0; k < 3; ++k) c->a0[k] = -(R[0 + k] * g[0] + R[3 + k] * g[1] + R[6 + k] * g[2]);
   double n[3] = {0, 0, 0}, f[3] = {0, 0, 0};
   if (Ftip) { n[0] = Ftip[0]; n[1] = Ftip[1]; n[2] = Ftip[2]; f[0] = Ftip[3]; f[1] = Ftip[4]; f[2] = Ftip[5]; }

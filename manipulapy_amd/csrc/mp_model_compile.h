@@ -47,5 +47,5 @@ template <typename T>
 inline void mp_call_cast(const MpCall<double>& s, MpCall<T>* d) {
   for (int k = 0; k < 3; ++k) { d->a0[k] = (T)s.a0[k]; d->F1n[k] = (T)s.F1n[k]; d->F1f[k] = (T)s.F1f[k]; }
   d->cold_model = nullptr;
-  d->hard_rows = nullptr; d->hard_ctrl = nullptr; d->hard_cap = 0; d->hard_row_base = 0;
+  d->hard_rows = nullptr; d->hard_ctrl = nullptr; d->hard_next = nullptr; d->hard_cap = 0; d->hard_row_base = 0;
 }
