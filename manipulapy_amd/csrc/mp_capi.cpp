@@ -52,10 +52,21 @@ struct mp_ctx {
   int compute_units = 0;
   bool capturing = false;                              // between mp_graph_begin and mp_graph_end
   void* queue_counter = nullptr;                       // 8-byte work-queue head of the IK kernel (lazily allocated)
-  unsigned* hard_rows = nullptr;                       // row indices the float32 inverse-dynamics kernels hand to the float64 pass
-  unsigned* hard_ctrl = nullptr;                       //   two counters, used alternately: each pass zeroes the other one
-  unsigned hard_cap = 0;
+  // The float64 pass over the ill-conditioned rows of a float32 inverse-dynamics launch (attach_hard_list / run_hard_pass): it
+  // runs on a stream of its own, behind an event, so that the NEXT launch's float32 kernel does not wait for it.  A ring of lists;
+  // a slot is `busy` from its launch until something on the compute stream has been made to wait for `done`.
+  struct HardSlot {
+    unsigned* rows = nullptr;     // row indices
+    unsigned* count = nullptr;    // how many (zeroed on the pass's stream behind the pass)
+    unsigned cap = 0;
+    hipEvent_t fork = nullptr, done = nullptr;
+    bool busy = false;
+    const char *lo = nullptr, *hi = nullptr;  // the torque rows the pending pass may still write
+  };
+  static constexpr int kHardSlots = 4;
+  HardSlot hard[kHardSlots];
   unsigned hard_turn = 0;
+  hipStream_t hard_stream = nullptr;
   double* time_tab = nullptr;                          // per-timestep time-scaling table of the fused kernels
   long tab_cap = 0, tab_Nt = -1;                       // its capacity in timesteps / the call it currently holds
   double tab_Tf = 0;
@@ -127,9 +138,16 @@ int bind(mp_ctx* ctx) {
 // Python threads sharing a planner do arrive concurrently - the reference runs its planners from several threads in
 // tests/test_trajectory_planning.py:1375) and binds the calling thread to the context's device.  Recursive: the
 // host-buffer entry points call the device-pointer ones.
-#define CTX_ENTER(ctx)                                         \
+// ... and makes the compute stream wait for float64 passes still pending on their own stream (hard_join_all): whatever the entry
+// point enqueues next may read the torques they write.  The float32 inverse-dynamics entry points, whose point it is NOT to wait,
+// enter with CTX_ENTER_NOJOIN and join only the passes whose rows overlap their own arrays.
+int hard_join_all(mp_ctx* ctx);
+#define CTX_ENTER_NOJOIN(ctx)                                  \
   std::lock_guard<std::recursive_mutex> ctx_lock_((ctx)->mu);  \
   if (int rc_enter_ = bind(ctx)) return rc_enter_
+#define CTX_ENTER(ctx)                                         \
+  CTX_ENTER_NOJOIN(ctx);                                       \
+  if (int rc_join_ = hard_join_all(ctx)) return rc_join_
 // every live context, so that mp_model_destroy can drop the per-context state of a model (specialised code object,
 // device-resident copy) instead of leaving it to mp_ctx_destroy
 std::mutex g_ctxs_mu;
@@ -284,9 +302,9 @@ const MpSpec* find_spec(mp_ctx* ctx, const mp_model* model) {
   auto it = ctx->specs.find(model->uid);
   return it == ctx->specs.end() ? nullptr : &it->second;
 }
-int launch_spec(mp_ctx* ctx, hipFunction_t fn, long threads, void** args, unsigned block = 256) {
+int launch_spec(mp_ctx* ctx, hipFunction_t fn, long threads, void** args, unsigned block = 256, hipStream_t stream = nullptr) {
   const unsigned grid = (unsigned)((threads + block - 1) / block);
-  HIP_TRY(hipModuleLaunchKernel(fn, grid, 1, 1, block, 1, 1, 0, ctx->compute, args, nullptr));
+  HIP_TRY(hipModuleLaunchKernel(fn, grid, 1, 1, block, 1, 1, 0, stream ? stream : ctx->compute, args, nullptr));
   return MP_OK;
 }
 
@@ -319,30 +337,76 @@ void make_call_f32(mp_ctx* ctx, const mp_model* model, const double* g, const do
   if (it != ctx->dev_models.end()) c->cold_model = (const char*)it->second + kDevModelD;
 }
 // The list a float32 inverse-dynamics launch of `rows` rows leaves its ill-conditioned rows in for the float64 pass that follows
-// it on the stream (csrc/mp_bodies.h, mp_push_hard_rows / mp_body_id_hard): room for one row in eight (c2-distributed rows flag
-// 0.5 - 1.5 %; a wave that finds the list full re-evaluates its rows itself).  0 blocks = no list (the kernels then re-evaluate in
-// place): more than 2^32 rows, or a first use inside a graph capture.
-unsigned attach_hard_list(mp_ctx* ctx, long rows, MpCall<float>* c) {
+// it (csrc/mp_bodies.h, mp_push_hard_rows / mp_body_id_hard): room for one row in eight (c2-distributed rows flag 0.5 - 1.5 %; a
+// wave that finds the list full re-evaluates its rows itself).  Returns the slot (c carries its pointers), or null = no list, the
+// kernels re-evaluate in place: more than 2^32 rows, a graph capture (a replay would reuse one list concurrently), or the switch.
+mp_ctx::HardSlot* attach_hard_list(mp_ctx* ctx, long rows, MpCall<float>* c) {
   static const bool on = !(getenv("MANIPULAPY_HIP_HARD_PASS") && getenv("MANIPULAPY_HIP_HARD_PASS")[0] == '0');  // experiment switch
-  if (!on || rows >= 0xffffffffL) return 0;
-  const unsigned need = (unsigned)std::min<long>(std::max<long>(rows / 8, 1L << 16), 1L << 28);
-  if (ctx->hard_cap < need) {
-    if (ctx->capturing) return 0;
-    if (hipStreamSynchronize(ctx->compute) != hipSuccess) return 0;
-    if (ctx->hard_rows) (void)hipFree(ctx->hard_rows);
-    if (!ctx->hard_ctrl && (hipMalloc((void**)&ctx->hard_ctrl, 4 * sizeof(unsigned)) != hipSuccess ||
-                            hipMemset(ctx->hard_ctrl, 0, 4 * sizeof(unsigned)) != hipSuccess)) { ctx->hard_ctrl = nullptr; return 0; }
-    ctx->hard_rows = nullptr; ctx->hard_cap = 0;
-    if (hipMalloc((void**)&ctx->hard_rows, (size_t)need * sizeof(unsigned)) != hipSuccess) { ctx->hard_rows = nullptr; return 0; }
-    ctx->hard_cap = need;
+  if (!on || rows >= 0xffffffffL || ctx->capturing) return nullptr;
+  mp_ctx::HardSlot& hs = ctx->hard[ctx->hard_turn % mp_ctx::kHardSlots];
+  if (hs.busy) {  // its previous pass (four launches ago) must be over before this launch's kernels write into the list
+    if (hipEventQuery(hs.done) != hipSuccess && hipStreamWaitEvent(ctx->compute, hs.done, 0) != hipSuccess) return nullptr;
+    hs.busy = false;
   }
-  // two counters: launch n counts in ctrl[n & 1], its pass zeroes the other one, which launch n + 1 counts in.  A launch captured
-  // into a graph would replay with the same counter every time and find it non-zero: captured launches get no list (in place).
-  if (ctx->capturing) return 0;
-  const unsigned turn = ctx->hard_turn++ & 1u;
-  c->hard_rows = ctx->hard_rows; c->hard_ctrl = ctx->hard_ctrl + turn; c->hard_next = ctx->hard_ctrl + (turn ^ 1u);
-  c->hard_cap = ctx->hard_cap; c->hard_row_base = 0;
-  return (unsigned)std::min<long>((rows / 8 + 63) / 64 + 1, 1024);
+  const unsigned need = (unsigned)std::min<long>(std::max<long>(rows / 8, 1L << 16), 1L << 28);
+  if (hs.cap < need) {
+    if (hipStreamSynchronize(ctx->compute) != hipSuccess) return nullptr;
+    if (ctx->hard_stream && hipStreamSynchronize(ctx->hard_stream) != hipSuccess) return nullptr;
+    if (!ctx->hard_stream && hipStreamCreateWithFlags(&ctx->hard_stream, hipStreamNonBlocking) != hipSuccess) { ctx->hard_stream = nullptr; return nullptr; }
+    if (!hs.fork && hipEventCreateWithFlags(&hs.fork, hipEventDisableTiming) != hipSuccess) { hs.fork = nullptr; return nullptr; }
+    if (!hs.done && hipEventCreateWithFlags(&hs.done, hipEventDisableTiming) != hipSuccess) { hs.done = nullptr; return nullptr; }
+    if (!hs.count && (hipMalloc((void**)&hs.count, sizeof(unsigned)) != hipSuccess || hipMemset(hs.count, 0, sizeof(unsigned)) != hipSuccess)) {
+      hs.count = nullptr;
+      return nullptr;
+    }
+    if (hs.rows) (void)hipFree(hs.rows);
+    hs.rows = nullptr; hs.cap = 0;
+    if (hipMalloc((void**)&hs.rows, (size_t)need * sizeof(unsigned)) != hipSuccess) { hs.rows = nullptr; return nullptr; }
+    hs.cap = need;
+  }
+  ++ctx->hard_turn;
+  c->hard_rows = hs.rows; c->hard_ctrl = hs.count; c->hard_next = nullptr; c->hard_cap = hs.cap; c->hard_row_base = 0;
+  return &hs;
+}
+unsigned hard_pass_blocks(long rows) { return (unsigned)std::min<long>((rows / 8 + 63) / 64 + 1, 1024); }
+// Behind the float32 kernels of a launch: the pass on its own stream (`launch` enqueues it there), the counter zeroed behind it,
+// `done` recorded.  [lo, hi) = the torque rows the pass may write.
+template <class LaunchFn>
+int run_hard_pass(mp_ctx* ctx, mp_ctx::HardSlot* hs, const void* lo, size_t bytes, LaunchFn launch) {
+  HIP_TRY(hipEventRecord(hs->fork, ctx->compute));
+  HIP_TRY(hipStreamWaitEvent(ctx->hard_stream, hs->fork, 0));
+  if (int rc = launch(ctx->hard_stream)) return rc;
+  HIP_TRY(hipMemsetAsync(hs->count, 0, sizeof(unsigned), ctx->hard_stream));
+  HIP_TRY(hipEventRecord(hs->done, ctx->hard_stream));
+  hs->busy = true;
+  hs->lo = (const char*)lo; hs->hi = (const char*)lo + bytes;
+  return MP_OK;
+}
+// the compute stream waits for the pending passes that may still write into [lo, hi) (the arrays of the launch about to be
+// enqueued); finished ones are just forgotten
+int hard_join_overlapping(mp_ctx* ctx, const void* const* lo, const size_t* bytes, int k) {
+  for (auto& hs : ctx->hard) {
+    if (!hs.busy) continue;
+    if (hipEventQuery(hs.done) == hipSuccess) { hs.busy = false; continue; }
+    bool overlap = false;
+    for (int i = 0; i < k && !overlap; ++i) {
+      const char* a = (const char*)lo[i];
+      overlap = a && a < hs.hi && hs.lo < a + bytes[i];
+    }
+    if (overlap) {
+      HIP_TRY(hipStreamWaitEvent(ctx->compute, hs.done, 0));
+      hs.busy = false;
+    }
+  }
+  return MP_OK;
+}
+int hard_join_all(mp_ctx* ctx) {
+  for (auto& hs : ctx->hard) {
+    if (!hs.busy) continue;
+    if (hipEventQuery(hs.done) != hipSuccess) HIP_TRY(hipStreamWaitEvent(ctx->compute, hs.done, 0));
+    hs.busy = false;
+  }
+  return MP_OK;
 }
 template <typename T> void make_call_ctx(mp_ctx* ctx, const mp_model* model, const double* g, const double* Ftip, MpCall<T>* c);
 template <> void make_call_ctx<float>(mp_ctx* ctx, const mp_model* model, const double* g, const double* Ftip, MpCall<float>* c) {
@@ -414,13 +478,15 @@ int launch_id(mp_ctx* ctx, const mp_model* model, const MpCall<float>& c, bool f
     if (spec_scalar_f32(model->d.n)) {  // one row per lane
       MpCall<float> cc = c;
       // ill-conditioned rows go to a float64 pass of their own behind the float32 kernels (see attach_hard_list)
-      const unsigned hard_blocks = sp->id_hard[ftip ? 1 : 0] ? attach_hard_list(ctx, rows, &cc) : 0;
+      mp_ctx::HardSlot* hs = sp->id_hard[ftip ? 1 : 0] ? attach_hard_list(ctx, rows, &cc) : nullptr;
       auto hard_pass = [&]() -> int {
-        if (!hard_blocks) return MP_OK;
+        if (!hs) return MP_OK;
         cc.hard_row_base = 0;
         unsigned nrows = (unsigned)rows;
         void* args[] = {&cc, &q, &qd, &qdd, &tau, &nrows};
-        return launch_spec(ctx, sp->id_hard[ftip ? 1 : 0], (long)hard_blocks * 64, args, 64);
+        return run_hard_pass(ctx, hs, tau, (size_t)rows * model->d.n * sizeof(float), [&](hipStream_t st) {
+          return launch_spec(ctx, sp->id_hard[ftip ? 1 : 0], (long)hard_pass_blocks(rows) * 64, args, 64, st);
+        });
       };
       long done = 0;
       if (sp->id_co[ftip ? 1 : 0] && rows >= 64 && id_co_enabled()) {  // whole waves: rows moved as whole lines, non-temporal (mp_body_id_co)
@@ -455,10 +521,13 @@ int launch_id(mp_ctx* ctx, const mp_model* model, const MpCall<float>& c, bool f
     const MpModel<float>* dm = nullptr;
     if (int rc = device_model(ctx, model, &dm)) return rc;
     MpCall<float> cc = c;
-    const unsigned hard_blocks = cc.cold_model ? attach_hard_list(ctx, rows, &cc) : 0;
+    mp_ctx::HardSlot* hs = cc.cold_model ? attach_hard_list(ctx, rows, &cc) : nullptr;
     HIP_TRY(mpk_id_dm(ctx->compute, dm, model->d.n, cc, ftip, q, qd, qdd, tau, rows));
-    HIP_TRY(mpk_id_hard(ctx->compute, dm, model->d.n, cc, ftip, q, qd, qdd, tau, (unsigned)rows, hard_blocks));
-    return MP_OK;
+    if (!hs) return MP_OK;
+    return run_hard_pass(ctx, hs, tau, (size_t)rows * model->d.n * sizeof(float), [&](hipStream_t st) {
+      HIP_TRY(mpk_id_hard(st, dm, model->d.n, cc, ftip, q, qd, qdd, tau, (unsigned)rows, hard_pass_blocks(rows)));
+      return (int)MP_OK;
+    });
   }
   HIP_TRY(mpk_id<float>(ctx->compute, model->f, c, ftip, q, qd, qdd, tau, rows));
   return MP_OK;
@@ -469,7 +538,13 @@ template <typename T>
 static int id_impl(const char* fn, mp_ctx* ctx, const mp_model* model, const T* d_q, const T* d_qd, const T* d_qdd,
                    int64_t rows, const double* g, const double* Ftip, T* d_tau) {
   REQUIRE(ctx && model, "%s: null context or model", fn);
-  CTX_ENTER(ctx);
+  CTX_ENTER_NOJOIN(ctx);
+  {  // pending float64 passes: only those that may still write rows this launch reads or writes make the compute stream wait
+    const size_t nb = (size_t)(rows > 0 ? rows : 0) * (size_t)model->d.n * sizeof(T);
+    const void* lo[4] = {d_q, d_qd, d_qdd, d_tau};
+    const size_t by[4] = {nb, nb, nb, nb};
+    if (int rc = (sizeof(T) == 4 && !ctx->profiling) ? hard_join_overlapping(ctx, lo, by, 4) : hard_join_all(ctx)) return rc;
+  }
   REQUIRE(rows >= 0, "%s: negative row count %lld", fn, (long long)rows);
   if (rows == 0) return MP_OK;
   REQUIRE(d_q && d_qd && d_qdd && d_tau, "%s: null device pointer", fn);
@@ -805,8 +880,13 @@ int mp_ctx_destroy(mp_ctx* ctx) {
   for (hipModule_t m : ctx->retired_mods) (void)hipModuleUnload(m);
   for (auto& kv : ctx->live) (void)hipFree(kv.first);
   if (ctx->queue_counter) (void)hipFree(ctx->queue_counter);
-  if (ctx->hard_rows) (void)hipFree(ctx->hard_rows);
-  if (ctx->hard_ctrl) (void)hipFree(ctx->hard_ctrl);
+  for (auto& hs : ctx->hard) {
+    if (hs.rows) (void)hipFree(hs.rows);
+    if (hs.count) (void)hipFree(hs.count);
+    if (hs.fork) (void)hipEventDestroy(hs.fork);
+    if (hs.done) (void)hipEventDestroy(hs.done);
+  }
+  if (ctx->hard_stream) (void)hipStreamDestroy(ctx->hard_stream);
   if (ctx->time_tab) (void)hipFree(ctx->time_tab);
   for (void* p : ctx->retired_tabs) (void)hipFree(p);
   if (ctx->compute) (void)hipStreamDestroy(ctx->compute);
@@ -850,6 +930,7 @@ int mp_ctx_synchronize(mp_ctx* ctx) {
   HIP_TRY(hipStreamSynchronize(ctx->compute));
   HIP_TRY(hipStreamSynchronize(ctx->copy));
   HIP_TRY(hipStreamSynchronize(ctx->copy_out));
+  if (ctx->hard_stream) HIP_TRY(hipStreamSynchronize(ctx->hard_stream));
   return MP_OK;
 }
 
@@ -1179,6 +1260,7 @@ int mp_model_destroy(mp_model* model) {
       if (!retire) {
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->compute);  // a launch of this model's kernels may still be in flight
+        if (ctx->hard_stream) (void)hipStreamSynchronize(ctx->hard_stream);
       }
       if (sp != ctx->specs.end()) {
         for (hipModule_t m : {sp->second.mod_ilp, sp->second.mod}) {
@@ -1436,7 +1518,14 @@ int mp_id_trajectory_f64(mp_ctx* ctx, const mp_model* model, const double* d_q, 
 
 int mp_traj_id_fused_f32(mp_ctx* ctx, const mp_model* model, const float* d_start, const float* d_end, int64_t B,
                          int64_t N, double Tf, int method, const double* g, const double* Ftip, float* d_tau) {
-  CHECK_COMMON("mp_traj_id_fused_f32");
+  REQUIRE(ctx && model, "mp_traj_id_fused_f32: null context or model");
+  CTX_ENTER_NOJOIN(ctx);
+  {
+    const size_t nrow = (size_t)(B > 0 ? B : 0) * (size_t)model->d.n * sizeof(float);
+    const void* lo[3] = {d_start, d_end, d_tau};
+    const size_t by[3] = {nrow, nrow, nrow * (size_t)(N > 0 ? N : 0)};
+    if (int rc = ctx->profiling ? hard_join_all(ctx) : hard_join_overlapping(ctx, lo, by, 3)) return rc;
+  }
   REQUIRE(B >= 0 && N >= 0, "mp_traj_id_fused_f32: negative B (%lld) or N (%lld)", (long long)B, (long long)N);
   if (B == 0 || N == 0) return MP_OK;
   REQUIRE(d_start && d_end && d_tau, "mp_traj_id_fused_f32: null device pointer");
@@ -1483,12 +1572,14 @@ int mp_traj_id_fused_f32(mp_ctx* ctx, const mp_model* model, const float* d_star
     if (traj_co && sp->traj_id_co[ftip ? 1 : 0] && N >= 64 && (unsigned long long)B * (unsigned long long)N < 0xffffffc0ull) {
       unsigned rows = (unsigned)((unsigned long long)B * (unsigned long long)N), ntu = (unsigned)N;
       unsigned magic = (unsigned)(0x100000000ull / (unsigned long long)N);
-      const unsigned hard_blocks = sp->traj_id_hard[ftip ? 1 : 0] ? attach_hard_list(ctx, (long)rows, &c) : 0;
+      mp_ctx::HardSlot* hs = sp->traj_id_hard[ftip ? 1 : 0] ? attach_hard_list(ctx, (long)rows, &c) : nullptr;
       void* args[] = {&c, &d_start, &d_end, &ntu, &magic, &tab, &d_tau, &rows};
       if (int rc = launch_spec(ctx, sp->traj_id_co[ftip ? 1 : 0], (long)rows, args, 64)) return rc;
-      if (!hard_blocks) return MP_OK;
+      if (!hs) return MP_OK;
       void* hargs[] = {&c, &d_start, &d_end, &ntu, &tab, &d_tau, &rows};
-      return launch_spec(ctx, sp->traj_id_hard[ftip ? 1 : 0], (long)hard_blocks * 64, hargs, 64);
+      return run_hard_pass(ctx, hs, d_tau, (size_t)rows * model->d.n * sizeof(float), [&](hipStream_t st) {
+        return launch_spec(ctx, sp->traj_id_hard[ftip ? 1 : 0], (long)hard_pass_blocks((long)rows) * 64, hargs, 64, st);
+      });
     }
     if (!mpk_packed_f32()) {  // MANIPULAPY_HIP_F32=scalar: one timestep per lane (measured slower: c2f 0.063 vs 0.054 ms)
       unsigned bpt = (unsigned)((nt + 255) / 256);

@@ -69,8 +69,7 @@ struct MpCall {
   const void* cold_model;
   // float32 device calls: where a kernel leaves the indices of its ill-conditioned rows for the float64 pass that follows it on
   // the stream (mp_capi.cpp, launch_hard_rows) instead of re-evaluating them itself: `hard_rows` takes up to `hard_cap` row
-  // indices (+ hard_row_base), *hard_ctrl counts them (*hard_next: the counter of the context's NEXT launch, which the pass
-  // zeroes).  Null: the kernel re-evaluates in place (mp_cold_rows).
+  // indices (+ hard_row_base), *hard_ctrl counts them (hard_next: unused).  Null: the kernel re-evaluates in place (mp_cold_rows).
   unsigned* hard_rows;
   unsigned* hard_ctrl;
   unsigned* hard_next;
