@@ -203,7 +203,7 @@ __device__ __forceinline__ bool mp_cold_rows(const MT& M, const MpCall<float>& C
 // The float64 pass over the rows a float32 kernel handed over: one row per lane, everything in float64 from the row's float32
 // inputs (`Mc`: the float64 model; `M`: the float32 one, for the torque limits the float32 kernels clip against), unrolled - this
 // kernel is register-allocated on its own (~170 VGPRs), which is the point of making it one.  `load(row, q, qd, qdd)` fetches or
-// regenerates a row's inputs.  *hard_ctrl is the count.
+// regenerates a row's inputs.  *hard_ctrl is the count, *hard_next the list's other counter.
 template <int N, bool HAS_FTIP, typename MC, typename MF, typename LoadFn>
 __device__ __forceinline__ void mp_body_id_hard(const MC& Mc, const MF& M, const MpCall<float>& C, LoadFn load, float* __restrict__ tau,
                                                 unsigned rows) {
@@ -229,8 +229,10 @@ __device__ __forceinline__ void mp_body_id_hard(const MC& Mc, const MF& M, const
     for (int i = 0; i < N; ++i) out[i] = mp_clip((float)t[i], M.taumin[i], M.taumax[i]);
     RunIO<float, N>::store(tau, r, out);
   }
-  // (the count is zeroed behind this kernel on its stream - a reset in here would need "every block has read it": one atomic
-  // per block on one address, measured 20 us per launch with 1024 blocks)
+  // the OTHER counter of the list (its next user's): zeroed here, by the pass that runs between that counter's previous reader
+  // and its next writers on the stream.  (Resetting this launch's own counter needs "every block has read it": one atomic per
+  // block on one address - 1024 of them measured 20 us per launch.)
+  if (blockIdx.x == 0 && threadIdx.x == 0) *C.hard_next = 0;
 }
 
 // ------------------------------------------------------------------ one row per lane (float / double)

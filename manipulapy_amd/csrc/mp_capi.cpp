@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <new>
@@ -52,21 +53,27 @@ struct mp_ctx {
   int compute_units = 0;
   bool capturing = false;                              // between mp_graph_begin and mp_graph_end
   void* queue_counter = nullptr;                       // 8-byte work-queue head of the IK kernel (lazily allocated)
-  // The float64 pass over the ill-conditioned rows of a float32 inverse-dynamics launch (attach_hard_list / run_hard_pass): it
-  // runs on a stream of its own, behind an event, so that the NEXT launch's float32 kernel does not wait for it.  A ring of lists;
-  // a slot is `busy` from its launch until something on the compute stream has been made to wait for `done`.
+  // The float64 pass over the ill-conditioned rows of a float32 inverse-dynamics launch (attach_hard_list / hard_defer /
+  // hard_flush).  The pass costs ~5 us of launch + memory latency however few rows it holds - 8 % of c2's kernel - so it is NOT
+  // launched behind every float32 kernel: a launch parks it (`busy`), and parked passes are run, up to four in ONE kernel, before
+  // anything that could see the difference - any other entry point, a float32 launch whose arrays overlap theirs, a fifth launch.
   struct HardSlot {
     unsigned* rows = nullptr;     // row indices
-    unsigned* count = nullptr;    // how many (zeroed on the pass's stream behind the pass)
-    unsigned cap = 0;
-    hipEvent_t fork = nullptr, done = nullptr;
+    unsigned* ctrl = nullptr;     // two counters used alternately: the pass zeroes the one the list's NEXT user counts in
+    unsigned cap = 0, uses = 0;
     bool busy = false;
-    const char *lo = nullptr, *hi = nullptr;  // the torque rows the pending pass may still write
+    unsigned long long seq = 0;   // launch order
+    hipFunction_t fn = nullptr;   // the specialised pass of its model, or null: the generic one, run through `generic`
+    std::function<int()> generic;
+    MpCall<float> C;
+    const float *q = nullptr, *qd = nullptr, *qdd = nullptr;
+    float* tau = nullptr;
+    unsigned nrows = 0;
+    size_t bytes = 0;             // of each of the four arrays
   };
-  static constexpr int kHardSlots = 4;
+  static constexpr int kHardSlots = MP_HARD_BATCH;
   HardSlot hard[kHardSlots];
-  unsigned hard_turn = 0;
-  hipStream_t hard_stream = nullptr;
+  unsigned long long hard_seq = 0;
   double* time_tab = nullptr;                          // per-timestep time-scaling table of the fused kernels
   long tab_cap = 0, tab_Nt = -1;                       // its capacity in timesteps / the call it currently holds
   double tab_Tf = 0;
@@ -138,16 +145,16 @@ int bind(mp_ctx* ctx) {
 // Python threads sharing a planner do arrive concurrently - the reference runs its planners from several threads in
 // tests/test_trajectory_planning.py:1375) and binds the calling thread to the context's device.  Recursive: the
 // host-buffer entry points call the device-pointer ones.
-// ... and makes the compute stream wait for float64 passes still pending on their own stream (hard_join_all): whatever the entry
-// point enqueues next may read the torques they write.  The float32 inverse-dynamics entry points, whose point it is NOT to wait,
-// enter with CTX_ENTER_NOJOIN and join only the passes whose rows overlap their own arrays.
-int hard_join_all(mp_ctx* ctx);
+// ... and runs the float64 passes that float32 inverse-dynamics launches have parked (hard_flush): whatever the entry point
+// enqueues next may read the torques they write.  The float32 inverse-dynamics entry points, whose point it is NOT to run one
+// pass per launch, enter with CTX_ENTER_NOJOIN and flush only when their arrays overlap a parked pass's.
+int hard_flush(mp_ctx* ctx);
 #define CTX_ENTER_NOJOIN(ctx)                                  \
   std::lock_guard<std::recursive_mutex> ctx_lock_((ctx)->mu);  \
   if (int rc_enter_ = bind(ctx)) return rc_enter_
 #define CTX_ENTER(ctx)                                         \
   CTX_ENTER_NOJOIN(ctx);                                       \
-  if (int rc_join_ = hard_join_all(ctx)) return rc_join_
+  if (int rc_join_ = hard_flush(ctx)) return rc_join_
 // every live context, so that mp_model_destroy can drop the per-context state of a model (specialised code object,
 // device-resident copy) instead of leaving it to mp_ctx_destroy
 std::mutex g_ctxs_mu;
@@ -302,9 +309,9 @@ const MpSpec* find_spec(mp_ctx* ctx, const mp_model* model) {
   auto it = ctx->specs.find(model->uid);
   return it == ctx->specs.end() ? nullptr : &it->second;
 }
-int launch_spec(mp_ctx* ctx, hipFunction_t fn, long threads, void** args, unsigned block = 256, hipStream_t stream = nullptr) {
+int launch_spec(mp_ctx* ctx, hipFunction_t fn, long threads, void** args, unsigned block = 256) {
   const unsigned grid = (unsigned)((threads + block - 1) / block);
-  HIP_TRY(hipModuleLaunchKernel(fn, grid, 1, 1, block, 1, 1, 0, stream ? stream : ctx->compute, args, nullptr));
+  HIP_TRY(hipModuleLaunchKernel(fn, grid, 1, 1, block, 1, 1, 0, ctx->compute, args, nullptr));
   return MP_OK;
 }
 
@@ -336,75 +343,91 @@ void make_call_f32(mp_ctx* ctx, const mp_model* model, const double* g, const do
   }
   if (it != ctx->dev_models.end()) c->cold_model = (const char*)it->second + kDevModelD;
 }
-// The list a float32 inverse-dynamics launch of `rows` rows leaves its ill-conditioned rows in for the float64 pass that follows
-// it (csrc/mp_bodies.h, mp_push_hard_rows / mp_body_id_hard): room for one row in eight (c2-distributed rows flag 0.5 - 1.5 %; a
-// wave that finds the list full re-evaluates its rows itself).  Returns the slot (c carries its pointers), or null = no list, the
-// kernels re-evaluate in place: more than 2^32 rows, a graph capture (a replay would reuse one list concurrently), or the switch.
+// The list a float32 inverse-dynamics launch of `rows` rows leaves its ill-conditioned rows in for the float64 pass
+// (csrc/mp_bodies.h, mp_push_hard_rows / mp_body_id_hard): room for one row in eight (c2-distributed rows flag 0.5 - 1.5 %; a wave
+// that finds the list full re-evaluates its rows itself).  Returns the slot (c carries its pointers), or null = no list, the
+// kernels re-evaluate in place: more than 2^32 rows, a graph capture (a replay would meet a used list), or the switch.
 mp_ctx::HardSlot* attach_hard_list(mp_ctx* ctx, long rows, MpCall<float>* c) {
   static const bool on = !(getenv("MANIPULAPY_HIP_HARD_PASS") && getenv("MANIPULAPY_HIP_HARD_PASS")[0] == '0');  // experiment switch
   if (!on || rows >= 0xffffffffL || ctx->capturing) return nullptr;
-  mp_ctx::HardSlot& hs = ctx->hard[ctx->hard_turn % mp_ctx::kHardSlots];
-  if (hs.busy) {  // its previous pass (four launches ago) must be over before this launch's kernels write into the list
-    if (hipEventQuery(hs.done) != hipSuccess && hipStreamWaitEvent(ctx->compute, hs.done, 0) != hipSuccess) return nullptr;
-    hs.busy = false;
+  mp_ctx::HardSlot* hs = nullptr;
+  for (auto& cand : ctx->hard)
+    if (!cand.busy) { hs = &cand; break; }
+  if (!hs) {  // all parked: run them (one kernel), then take the first
+    if (hard_flush(ctx) != MP_OK) return nullptr;
+    hs = &ctx->hard[0];
   }
   const unsigned need = (unsigned)std::min<long>(std::max<long>(rows / 8, 1L << 16), 1L << 28);
-  if (hs.cap < need) {
+  if (hs->cap < need) {
     if (hipStreamSynchronize(ctx->compute) != hipSuccess) return nullptr;
-    if (ctx->hard_stream && hipStreamSynchronize(ctx->hard_stream) != hipSuccess) return nullptr;
-    if (!ctx->hard_stream && hipStreamCreateWithFlags(&ctx->hard_stream, hipStreamNonBlocking) != hipSuccess) { ctx->hard_stream = nullptr; return nullptr; }
-    if (!hs.fork && hipEventCreateWithFlags(&hs.fork, hipEventDisableTiming) != hipSuccess) { hs.fork = nullptr; return nullptr; }
-    if (!hs.done && hipEventCreateWithFlags(&hs.done, hipEventDisableTiming) != hipSuccess) { hs.done = nullptr; return nullptr; }
-    if (!hs.count && (hipMalloc((void**)&hs.count, sizeof(unsigned)) != hipSuccess || hipMemset(hs.count, 0, sizeof(unsigned)) != hipSuccess)) {
-      hs.count = nullptr;
+    if (!hs->ctrl && (hipMalloc((void**)&hs->ctrl, 2 * sizeof(unsigned)) != hipSuccess || hipMemset(hs->ctrl, 0, 2 * sizeof(unsigned)) != hipSuccess)) {
+      hs->ctrl = nullptr;
       return nullptr;
     }
-    if (hs.rows) (void)hipFree(hs.rows);
-    hs.rows = nullptr; hs.cap = 0;
-    if (hipMalloc((void**)&hs.rows, (size_t)need * sizeof(unsigned)) != hipSuccess) { hs.rows = nullptr; return nullptr; }
-    hs.cap = need;
+    if (hs->rows) (void)hipFree(hs->rows);
+    hs->rows = nullptr; hs->cap = 0;
+    if (hipMalloc((void**)&hs->rows, (size_t)need * sizeof(unsigned)) != hipSuccess) { hs->rows = nullptr; return nullptr; }
+    hs->cap = need;
   }
-  ++ctx->hard_turn;
-  c->hard_rows = hs.rows; c->hard_ctrl = hs.count; c->hard_next = nullptr; c->hard_cap = hs.cap; c->hard_row_base = 0;
-  return &hs;
+  const unsigned turn = hs->uses++ & 1u;
+  c->hard_rows = hs->rows; c->hard_ctrl = hs->ctrl + turn; c->hard_next = hs->ctrl + (turn ^ 1u); c->hard_cap = hs->cap;
+  c->hard_row_base = 0;
+  return hs;
 }
 unsigned hard_pass_blocks(long rows) { return (unsigned)std::min<long>((rows / 8 + 63) / 64 + 1, 1024); }
-// Behind the float32 kernels of a launch: the pass on its own stream (`launch` enqueues it there), the counter zeroed behind it,
-// `done` recorded.  [lo, hi) = the torque rows the pass may write.
-template <class LaunchFn>
-int run_hard_pass(mp_ctx* ctx, mp_ctx::HardSlot* hs, const void* lo, size_t bytes, LaunchFn launch) {
-  HIP_TRY(hipEventRecord(hs->fork, ctx->compute));
-  HIP_TRY(hipStreamWaitEvent(ctx->hard_stream, hs->fork, 0));
-  if (int rc = launch(ctx->hard_stream)) return rc;
-  HIP_TRY(hipMemsetAsync(hs->count, 0, sizeof(unsigned), ctx->hard_stream));
-  HIP_TRY(hipEventRecord(hs->done, ctx->hard_stream));
-  hs->busy = true;
-  hs->lo = (const char*)lo; hs->hi = (const char*)lo + bytes;
-  return MP_OK;
+// park the pass of the launch just enqueued
+void hard_defer(mp_ctx* ctx, mp_ctx::HardSlot* hs, hipFunction_t fn, std::function<int()> generic, const MpCall<float>& C,
+                const float* q, const float* qd, const float* qdd, float* tau, long rows, int n) {
+  hs->busy = true; hs->seq = ++ctx->hard_seq; hs->fn = fn; hs->generic = std::move(generic); hs->C = C; hs->C.hard_row_base = 0;
+  hs->q = q; hs->qd = qd; hs->qdd = qdd; hs->tau = tau; hs->nrows = (unsigned)rows; hs->bytes = (size_t)rows * (size_t)n * sizeof(float);
 }
-// the compute stream waits for the pending passes that may still write into [lo, hi) (the arrays of the launch about to be
-// enqueued); finished ones are just forgotten
-int hard_join_overlapping(mp_ctx* ctx, const void* const* lo, const size_t* bytes, int k) {
-  for (auto& hs : ctx->hard) {
-    if (!hs.busy) continue;
-    if (hipEventQuery(hs.done) == hipSuccess) { hs.busy = false; continue; }
-    bool overlap = false;
-    for (int i = 0; i < k && !overlap; ++i) {
-      const char* a = (const char*)lo[i];
-      overlap = a && a < hs.hi && hs.lo < a + bytes[i];
+// run every parked pass on the compute stream, in launch order; passes of one specialised program share a kernel launch
+int hard_flush(mp_ctx* ctx) {
+  mp_ctx::HardSlot* order[mp_ctx::kHardSlots];
+  int k = 0;
+  for (auto& hs : ctx->hard)
+    if (hs.busy) order[k++] = &hs;
+  if (k == 0) return MP_OK;
+  std::sort(order, order + k, [](const mp_ctx::HardSlot* a, const mp_ctx::HardSlot* b) { return a->seq < b->seq; });
+  int rc = MP_OK;
+  for (int i = 0; i < k;) {
+    mp_ctx::HardSlot* h = order[i];
+    if (!h->fn) {  // generic kernels: one launch each
+      if (rc == MP_OK) rc = h->generic();
+      h->busy = false; h->generic = nullptr;
+      ++i;
+      continue;
     }
-    if (overlap) {
-      HIP_TRY(hipStreamWaitEvent(ctx->compute, hs.done, 0));
-      hs.busy = false;
+    MpHardBatch B;
+    std::memset(&B, 0, sizeof B);
+    int m = 0;
+    unsigned blocks = 1;
+    while (i < k && order[i]->fn == h->fn && m < MP_HARD_BATCH) {
+      mp_ctx::HardSlot* e = order[i++];
+      B.C[m] = e->C; B.q[m] = e->q; B.qd[m] = e->qd; B.qdd[m] = e->qdd; B.tau[m] = e->tau; B.rows[m] = e->nrows;
+      blocks = std::max(blocks, hard_pass_blocks((long)e->nrows));
+      e->busy = false;
+      ++m;
+    }
+    if (rc == MP_OK) {
+      void* args[] = {&B};
+      hipError_t he = hipModuleLaunchKernel(h->fn, blocks, (unsigned)m, 1, 64, 1, 1, 0, ctx->compute, args, nullptr);
+      if (he != hipSuccess) rc = hip_err(he, "float64 pass of the ill-conditioned float32 rows");
     }
   }
-  return MP_OK;
+  return rc;
 }
-int hard_join_all(mp_ctx* ctx) {
+// a float32 launch about to be enqueued on [lo, lo + bytes) arrays: parked passes that read or write any of them run first
+int hard_flush_if_overlapping(mp_ctx* ctx, const void* const* lo, const size_t* bytes, int k) {
   for (auto& hs : ctx->hard) {
     if (!hs.busy) continue;
-    if (hipEventQuery(hs.done) != hipSuccess) HIP_TRY(hipStreamWaitEvent(ctx->compute, hs.done, 0));
-    hs.busy = false;
+    const char* mine[4] = {(const char*)hs.q, (const char*)hs.qd, (const char*)hs.qdd, (const char*)hs.tau};
+    for (int i = 0; i < k; ++i) {
+      const char* a = (const char*)lo[i];
+      if (!a) continue;
+      for (const char* b : mine)
+        if (b && a < b + hs.bytes && b < a + bytes[i]) return hard_flush(ctx);
+    }
   }
   return MP_OK;
 }
@@ -480,13 +503,8 @@ int launch_id(mp_ctx* ctx, const mp_model* model, const MpCall<float>& c, bool f
       // ill-conditioned rows go to a float64 pass of their own behind the float32 kernels (see attach_hard_list)
       mp_ctx::HardSlot* hs = sp->id_hard[ftip ? 1 : 0] ? attach_hard_list(ctx, rows, &cc) : nullptr;
       auto hard_pass = [&]() -> int {
-        if (!hs) return MP_OK;
-        cc.hard_row_base = 0;
-        unsigned nrows = (unsigned)rows;
-        void* args[] = {&cc, &q, &qd, &qdd, &tau, &nrows};
-        return run_hard_pass(ctx, hs, tau, (size_t)rows * model->d.n * sizeof(float), [&](hipStream_t st) {
-          return launch_spec(ctx, sp->id_hard[ftip ? 1 : 0], (long)hard_pass_blocks(rows) * 64, args, 64, st);
-        });
+        if (hs) hard_defer(ctx, hs, sp->id_hard[ftip ? 1 : 0], nullptr, cc, q, qd, qdd, tau, rows, model->d.n);
+        return MP_OK;
       };
       long done = 0;
       if (sp->id_co[ftip ? 1 : 0] && rows >= 64 && id_co_enabled()) {  // whole waves: rows moved as whole lines, non-temporal (mp_body_id_co)
@@ -524,10 +542,15 @@ int launch_id(mp_ctx* ctx, const mp_model* model, const MpCall<float>& c, bool f
     mp_ctx::HardSlot* hs = cc.cold_model ? attach_hard_list(ctx, rows, &cc) : nullptr;
     HIP_TRY(mpk_id_dm(ctx->compute, dm, model->d.n, cc, ftip, q, qd, qdd, tau, rows));
     if (!hs) return MP_OK;
-    return run_hard_pass(ctx, hs, tau, (size_t)rows * model->d.n * sizeof(float), [&](hipStream_t st) {
-      HIP_TRY(mpk_id_hard(st, dm, model->d.n, cc, ftip, q, qd, qdd, tau, (unsigned)rows, hard_pass_blocks(rows)));
+    const int n = model->d.n;
+    hipStream_t st = ctx->compute;
+    hard_defer(ctx, hs, nullptr, [=]() -> int {
+      MpCall<float> c2 = cc;
+      c2.hard_row_base = 0;
+      HIP_TRY(mpk_id_hard(st, dm, n, c2, ftip, q, qd, qdd, tau, (unsigned)rows, hard_pass_blocks(rows)));
       return (int)MP_OK;
-    });
+    }, cc, q, qd, qdd, tau, rows, n);
+    return MP_OK;
   }
   HIP_TRY(mpk_id<float>(ctx->compute, model->f, c, ftip, q, qd, qdd, tau, rows));
   return MP_OK;
@@ -543,7 +566,7 @@ static int id_impl(const char* fn, mp_ctx* ctx, const mp_model* model, const T* 
     const size_t nb = (size_t)(rows > 0 ? rows : 0) * (size_t)model->d.n * sizeof(T);
     const void* lo[4] = {d_q, d_qd, d_qdd, d_tau};
     const size_t by[4] = {nb, nb, nb, nb};
-    if (int rc = (sizeof(T) == 4 && !ctx->profiling) ? hard_join_overlapping(ctx, lo, by, 4) : hard_join_all(ctx)) return rc;
+    if (int rc = (sizeof(T) == 4 && !ctx->profiling) ? hard_flush_if_overlapping(ctx, lo, by, 4) : hard_flush(ctx)) return rc;
   }
   REQUIRE(rows >= 0, "%s: negative row count %lld", fn, (long long)rows);
   if (rows == 0) return MP_OK;
@@ -882,11 +905,8 @@ int mp_ctx_destroy(mp_ctx* ctx) {
   if (ctx->queue_counter) (void)hipFree(ctx->queue_counter);
   for (auto& hs : ctx->hard) {
     if (hs.rows) (void)hipFree(hs.rows);
-    if (hs.count) (void)hipFree(hs.count);
-    if (hs.fork) (void)hipEventDestroy(hs.fork);
-    if (hs.done) (void)hipEventDestroy(hs.done);
+    if (hs.ctrl) (void)hipFree(hs.ctrl);
   }
-  if (ctx->hard_stream) (void)hipStreamDestroy(ctx->hard_stream);
   if (ctx->time_tab) (void)hipFree(ctx->time_tab);
   for (void* p : ctx->retired_tabs) (void)hipFree(p);
   if (ctx->compute) (void)hipStreamDestroy(ctx->compute);
@@ -930,7 +950,6 @@ int mp_ctx_synchronize(mp_ctx* ctx) {
   HIP_TRY(hipStreamSynchronize(ctx->compute));
   HIP_TRY(hipStreamSynchronize(ctx->copy));
   HIP_TRY(hipStreamSynchronize(ctx->copy_out));
-  if (ctx->hard_stream) HIP_TRY(hipStreamSynchronize(ctx->hard_stream));
   return MP_OK;
 }
 
@@ -1257,10 +1276,13 @@ int mp_model_destroy(mp_model* model) {
       const bool has_big = ctx->dev_big[0].count(model->uid) || ctx->dev_big[1].count(model->uid);
       if (sp == ctx->specs.end() && dm == ctx->dev_models.end() && !has_big) continue;
       const bool retire = ctx->capturing || ctx->live_graphs > 0;
+      if (!ctx->capturing) {  // parked float64 passes may belong to this model's code object
+        (void)hipSetDevice(ctx->device);
+        (void)hard_flush(ctx);
+      }
       if (!retire) {
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->compute);  // a launch of this model's kernels may still be in flight
-        if (ctx->hard_stream) (void)hipStreamSynchronize(ctx->hard_stream);
       }
       if (sp != ctx->specs.end()) {
         for (hipModule_t m : {sp->second.mod_ilp, sp->second.mod}) {
@@ -1518,14 +1540,7 @@ int mp_id_trajectory_f64(mp_ctx* ctx, const mp_model* model, const double* d_q, 
 
 int mp_traj_id_fused_f32(mp_ctx* ctx, const mp_model* model, const float* d_start, const float* d_end, int64_t B,
                          int64_t N, double Tf, int method, const double* g, const double* Ftip, float* d_tau) {
-  REQUIRE(ctx && model, "mp_traj_id_fused_f32: null context or model");
-  CTX_ENTER_NOJOIN(ctx);
-  {
-    const size_t nrow = (size_t)(B > 0 ? B : 0) * (size_t)model->d.n * sizeof(float);
-    const void* lo[3] = {d_start, d_end, d_tau};
-    const size_t by[3] = {nrow, nrow, nrow * (size_t)(N > 0 ? N : 0)};
-    if (int rc = ctx->profiling ? hard_join_all(ctx) : hard_join_overlapping(ctx, lo, by, 3)) return rc;
-  }
+  CHECK_COMMON("mp_traj_id_fused_f32");
   REQUIRE(B >= 0 && N >= 0, "mp_traj_id_fused_f32: negative B (%lld) or N (%lld)", (long long)B, (long long)N);
   if (B == 0 || N == 0) return MP_OK;
   REQUIRE(d_start && d_end && d_tau, "mp_traj_id_fused_f32: null device pointer");
@@ -1576,10 +1591,9 @@ int mp_traj_id_fused_f32(mp_ctx* ctx, const mp_model* model, const float* d_star
       void* args[] = {&c, &d_start, &d_end, &ntu, &magic, &tab, &d_tau, &rows};
       if (int rc = launch_spec(ctx, sp->traj_id_co[ftip ? 1 : 0], (long)rows, args, 64)) return rc;
       if (!hs) return MP_OK;
+      // (the generated rows' pass runs at once: it reads the per-call time table, which the next fused call may rewrite)
       void* hargs[] = {&c, &d_start, &d_end, &ntu, &tab, &d_tau, &rows};
-      return run_hard_pass(ctx, hs, d_tau, (size_t)rows * model->d.n * sizeof(float), [&](hipStream_t st) {
-        return launch_spec(ctx, sp->traj_id_hard[ftip ? 1 : 0], (long)hard_pass_blocks((long)rows) * 64, hargs, 64, st);
-      });
+      return launch_spec(ctx, sp->traj_id_hard[ftip ? 1 : 0], (long)hard_pass_blocks((long)rows) * 64, hargs, 64);
     }
     if (!mpk_packed_f32()) {  // MANIPULAPY_HIP_F32=scalar: one timestep per lane (measured slower: c2f 0.063 vs 0.054 ms)
       unsigned bpt = (unsigned)((nt + 255) / 256);

@@ -69,10 +69,23 @@ struct MpCall {
   const void* cold_model;
   // float32 device calls: where a kernel leaves the indices of its ill-conditioned rows for the float64 pass that follows it on
   // the stream (mp_capi.cpp, launch_hard_rows) instead of re-evaluating them itself: `hard_rows` takes up to `hard_cap` row
-  // indices (+ hard_row_base), *hard_ctrl counts them (hard_next: unused).  Null: the kernel re-evaluates in place (mp_cold_rows).
+  // indices (+ hard_row_base), *hard_ctrl counts them; *hard_next is the list's other counter (the pass zeroes it for the list's
+  // next user).  Null: the kernel re-evaluates in place (mp_cold_rows).
   unsigned* hard_rows;
   unsigned* hard_ctrl;
   unsigned* hard_next;
   unsigned hard_cap;
   unsigned hard_row_base;
+};
+
+// Up to four launches' worth of that pass in ONE kernel (blockIdx.y picks the launch): the pass costs ~5 us of launch and memory
+// latency however few rows it holds, so the host lets passes wait (mp_capi.cpp, hard_flush) and runs them together.
+constexpr int MP_HARD_BATCH = 4;
+struct MpHardBatch {
+  MpCall<float> C[MP_HARD_BATCH];
+  const float* q[MP_HARD_BATCH];
+  const float* qd[MP_HARD_BATCH];
+  const float* qdd[MP_HARD_BATCH];
+  float* tau[MP_HARD_BATCH];
+  unsigned rows[MP_HARD_BATCH];
 };
