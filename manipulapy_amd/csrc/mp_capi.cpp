@@ -684,7 +684,9 @@ static int id_host_impl(const char* fn, mp_ctx* ctx, const mp_model* model, cons
     H2D(dq, q, bytes);
     H2D(dqd, qd, bytes);
     H2D(dqdd, qdd, bytes);
-    if (int rc = id_impl<T>(fn, ctx, model, (T*)dq, (T*)dqd, (T*)dqdd, rows, g, Ftip, (T*)dt)) {
+    int rc = id_impl<T>(fn, ctx, model, (T*)dq, (T*)dqd, (T*)dqdd, rows, g, Ftip, (T*)dt);
+    if (!rc) rc = hard_flush(ctx);  // the download below reads the torques: a parked float64 pass runs now
+    if (rc) {
       (void)hipStreamSynchronize(ctx->compute);
       return rc;
     }
@@ -704,7 +706,8 @@ static int id_host_impl(const char* fn, mp_ctx* ctx, const mp_model* model, cons
       },
       [&](int64_t r0, int64_t nr) -> int {
         const size_t off = (size_t)r0 * row_b;
-        return id_impl<T>(fn, ctx, model, (T*)(cq + off), (T*)(cqd + off), (T*)(cqdd + off), nr, g, Ftip, (T*)(ct + off));
+        if (int rc = id_impl<T>(fn, ctx, model, (T*)(cq + off), (T*)(cqd + off), (T*)(cqdd + off), nr, g, Ftip, (T*)(ct + off))) return rc;
+        return hard_flush(ctx);  // the chunk's download follows
       },
       [&](int64_t r0, int64_t nr) -> int {
         const size_t off = (size_t)r0 * row_b;
@@ -2053,6 +2056,11 @@ int mp_inverse_kinematics_host_f64(mp_ctx* ctx, const mp_model* model, const dou
 
 
 // exposed to mp_comm.cpp
-hipStream_t mp_ctx_compute_stream(mp_ctx* ctx) { return ctx->compute; }
+// (whoever asks for the stream is about to enqueue something that may read torques: parked float64 passes run first)
+hipStream_t mp_ctx_compute_stream(mp_ctx* ctx) {
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  if (hipSetDevice(ctx->device) == hipSuccess) (void)hard_flush(ctx);
+  return ctx->compute;
+}
 int mp_ctx_device(mp_ctx* ctx) { return ctx->device; }
 int mp_set_error(int code, const char* msg) { return set_err(code, "%s", msg); }
