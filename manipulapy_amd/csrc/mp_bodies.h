@@ -659,13 +659,13 @@ __device__ __forceinline__ void mp_rnea_pk(const MT& M, const MpCall<float>& C, 
 #if MP_ADAPTIVE_F32
   const mp_f2 tn[3] = {(mp_f2)(C.F1n[0]), (mp_f2)(C.F1n[1]), (mp_f2)(C.F1n[2])};
   const mp_f2 tf[3] = {(mp_f2)(C.F1f[0]), (mp_f2)(C.F1f[1]), (mp_f2)(C.F1f[2])};
-  mp_f2 sN, sF;
-  mp_rnea_impl<mp_f2, N, HAS_FTIP, true>(M, C.a0, tn, tf, js, qd, qdd, tau, sN, sF);
+  mp_f2 sF;
+  mp_rnea_impl<mp_f2, N, HAS_FTIP, true>(M, C.a0, tn, tf, js, qd, qdd, tau, sF);
   float tx[N], ty[N];
 #pragma unroll
   for (int i = 0; i < N; ++i) { tx[i] = tau[i].x; ty[i] = tau[i].y; }
-  const bool hx = mp_id_row_is_hard<N>(tx, sN.x, sF.x, M.lscale) && !bad.x.any();
-  const bool hy = mp_id_row_is_hard<N>(ty, sN.y, sF.y, M.lscale) && !bad.y.any();
+  const bool hx = mp_id_row_is_hard<N>(tx, sF.x, M.lscale) && !bad.x.any();
+  const bool hy = mp_id_row_is_hard<N>(ty, sF.y, M.lscale) && !bad.y.any();
   mp_cold_rows<N, HAS_FTIP, MP_COLD_G>(M, C, hx, -1L, cold, [&](float (&a)[N], float (&b)[N], float (&c)[N]) {
 #pragma unroll
     for (int i = 0; i < N; ++i) { a[i] = q[i].x; b[i] = qd[i].x; c[i] = qdd[i].x; }

@@ -346,11 +346,12 @@ MP_HD void mp_joint_state(const MT& M, const T (&q)[N], MpJointState<T, N>& js) 
 // Recursive Newton-Euler in the compiled link frames.  tau is NOT clipped here.
 // a0: linear acceleration of the base in the pre-joint-1 frame (= base_R^T (-g)), wave-uniform.
 // tipn / tipf: the tip wrench [moment; force] expressed in the pre-joint-1 frame, per row (ignored unless HAS_FTIP).
-// SCALE: also return the largest joint-wrench moment / force component met on the way back (sN, sF): what a float32 row's
-// rounding errors scale with - mp_id_row_is_hard below compares them with the row's own torques.
+// SCALE: also return the largest joint FORCE component met on the way back (sF): what a float32 row's rounding errors scale with
+// - mp_id_row_is_hard below compares it, times the robot's length scale, with the row's own torques.  (The joint moments were
+// in the test at first; forces alone separate the same rows - profiles/r04_f32_precision_study.txt - and cost half.)
 template <typename T, int N, bool HAS_FTIP, bool SCALE, typename MT>
 MP_HD void mp_rnea_impl(const MT& M, const typename MpTraits<T>::S (&a0)[3], const T (&tipn)[3], const T (&tipf)[3],
-                        const MpJointState<T, N>& js, const T (&qd)[N], const T (&qdd)[N], T (&tau)[N], T& sN, T& sF) {
+                        const MpJointState<T, N>& js, const T (&qd)[N], const T (&qdd)[N], T (&tau)[N], T& sF) {
   using S = typename MpTraits<T>::S;
   using TR = MpTraits<T>;
   const T zero = TR::splat(S(0));
@@ -407,17 +408,15 @@ MP_HD void mp_rnea_impl(const MT& M, const typename MpTraits<T>::S (&a0)[3], con
     ffx[N - 1] += tfx; ffy[N - 1] += tfy; ffz[N - 1] += tfz;
   }
   // backward pass
-  if (SCALE) { sN = zero; sF = zero; }
+  if (SCALE) sF = zero;
 #pragma unroll
   for (int i = N - 1; i >= 0; --i) {
     const auto& J = mp_joint_of(M, i);
     tau[i] = J.rev * fnz[i] + (S(1) - J.rev) * ffz[i];
-    // (joint 0's wrench is left out: only its z component is a torque, the other five - and the last force transform that makes
-    // them - are dead code without this test, ~35 instructions; joint 1's wrench is the same load seen one frame further out)
-    if (SCALE && (i > 0 || N == 1)) {  // |.| are source modifiers, the maxima v_max3_f32: four instructions per joint
-      sN = mp_max(mp_max(mp_max(sN, mp_abs(fnx[i])), mp_abs(fny[i])), mp_abs(fnz[i]));
+    // (joint 0's force is left out: it is dead code without this test - it feeds no torque of a revolute base - and joint 1's is the
+    // same load seen one frame further out)
+    if (SCALE && (i > 0 || N == 1))  // |.| are source modifiers, the maxima v_max3_f32: two instructions per joint
       sF = mp_max(mp_max(mp_max(sF, mp_abs(ffx[i])), mp_abs(ffy[i])), mp_abs(ffz[i]));
-    }
     if (i > 0) {
       T nx = fnx[i], ny = fny[i], nz = fnz[i], fx = ffx[i], fy = ffy[i], fz = ffz[i];
       mp_force_up_B(js.c[i], js.s[i], js.d[i], nx, ny, nz, fx, fy, fz);
@@ -431,8 +430,8 @@ MP_HD void mp_rnea_impl(const MT& M, const typename MpTraits<T>::S (&a0)[3], con
 template <typename T, int N, bool HAS_FTIP, typename MT>
 MP_HD void mp_rnea(const MT& M, const typename MpTraits<T>::S (&a0)[3], const T (&tipn)[3], const T (&tipf)[3],
                    const MpJointState<T, N>& js, const T (&qd)[N], const T (&qdd)[N], T (&tau)[N]) {
-  T sN, sF;
-  mp_rnea_impl<T, N, HAS_FTIP, false>(M, a0, tipn, tipf, js, qd, qdd, tau, sN, sF);
+  T sF;
+  mp_rnea_impl<T, N, HAS_FTIP, false>(M, a0, tipn, tipf, js, qd, qdd, tau, sF);
 }
 
 // Same with the wave-uniform per-call constants (gravity + one tip wrench for every row).
@@ -450,24 +449,24 @@ MP_HD void mp_rnea(const MT& M, const MpCall<typename MpTraits<T>::S>& C, const 
 // parity bound (1e-4 |ref| + 5e-6 max|row|); it is not on the few rows per thousand whose torques are a small difference of large
 // terms - an arm swinging at 10 rad/s whose joint wrenches reach hundreds of N.m while every torque of the row is a few N.m (over
 // c2's 12.3 M rows the plain float32 kernel missed the bound on 76, by up to 4.8 x; with the joint offsets taken exactly - MpJoint
-// co / so - on 1, by 1.3 x).  Such a row announces itself: the largest joint-wrench component the backward pass meets, moments
-// plus forces times the robot's length scale, is more than MP_HARD_ROW_K x the row's largest torque.  Those rows - a fraction of a
-// per cent to 1.5 % of c2-distributed rows, in runs of consecutive timesteps - are evaluated again with the twist / acceleration /
-// wrench recursion in float64 from the same float32 inputs, model constants and sin / cos (mp_rnea_cold).  What stays float32 sits
-// at <= 0.4 x the bound on 12.3 M rows, the re-evaluated rows at <= 0.25 x (profiles/r04_f32_precision_study.txt).
+// co / so - on 1, by 1.3 x).  Such a row announces itself: the largest joint-force component the backward pass meets, times the
+// robot's length scale, is more than MP_HARD_ROW_K x the row's largest torque.  Those rows - 0.4 - 0.7 % of c2-distributed rows, in
+// runs of consecutive timesteps - are evaluated again in float64 from the same float32 inputs: by a pass of their own behind the
+// float32 kernel (mp_body_id_hard, csrc/mp_bodies.h) or, where no list is attached, in place (mp_rnea_cold).  What stays float32
+// sits at <= 0.45 x the bound on 12.3 M rows, the re-evaluated rows at <= 0.1 x (profiles/r04_f32_precision_study.txt).
 // Deterministic: a row's precision depends on that row's values only.
 #ifndef MP_HARD_ROW_K
-#define MP_HARD_ROW_K 16.0f
+#define MP_HARD_ROW_K 20.0f
 #endif
 #ifndef MP_ADAPTIVE_F32   // 0 (experiment switch): plain float32 rows, for A/B measurements of what the test and the float64 rows cost
 #define MP_ADAPTIVE_F32 1
 #endif
 template <int N>
-MP_HD bool mp_id_row_is_hard(const float (&tau)[N], float sN, float sF, float lscale) {
+MP_HD bool mp_id_row_is_hard(const float (&tau)[N], float sF, float lscale) {
   float rowmax = 0.0f;
 #pragma unroll
   for (int i = 0; i < N; ++i) rowmax = mp_max(rowmax, mp_abs(tau[i]));
-  return sN + lscale * sF > MP_HARD_ROW_K * rowmax;   // false for NaN rows: they are poisoned by the callers as before
+  return lscale * sF > MP_HARD_ROW_K * rowmax;   // (callers rule NaN rows out themselves)
 }
 
 // The float32 recursion of one row + its verdict.  tau is NOT clipped.
@@ -476,9 +475,9 @@ MP_HD bool mp_rnea_f32(const MT& M, const MpCall<float>& C, const MpJointState<f
                        const float (&qdd)[N], float (&tau)[N]) {
 #if MP_ADAPTIVE_F32
   const float tn[3] = {C.F1n[0], C.F1n[1], C.F1n[2]}, tf[3] = {C.F1f[0], C.F1f[1], C.F1f[2]};
-  float sN, sF;
-  mp_rnea_impl<float, N, HAS_FTIP, true>(M, C.a0, tn, tf, js, qd, qdd, tau, sN, sF);
-  return mp_id_row_is_hard<N>(tau, sN, sF, M.lscale);
+  float sF;
+  mp_rnea_impl<float, N, HAS_FTIP, true>(M, C.a0, tn, tf, js, qd, qdd, tau, sF);
+  return mp_id_row_is_hard<N>(tau, sF, M.lscale);
 #else
   mp_rnea<float, N, HAS_FTIP>(M, C, js, qd, qdd, tau);
   return false;
