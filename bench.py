@@ -82,7 +82,9 @@ def kernel_name(cfg):
     co = os.environ.get("MANIPULAPY_HIP_ID_CO", "1") != "0"   # whole-line row movement (mp_spec_id_co) unless switched off for an A/B
     return {"id": ((("mp_spec_id_co_f0" if co else "mp_spec_id_s_f0") if scalar else "mp_spec_id_pk_f0") if cfg["dtype"] == "f32" else "mp_spec_id_d_f0") if spec else
                   (({"p": "k_id_pk", "s": "k_id"}.get(forced, "k_id_dm")) if cfg["dtype"] == "f32" else "k_id"),
-            "fused": ("mp_spec_traj_id_s_f0" if forced == "s" else "mp_spec_traj_id_pk_f0") if spec else ("k_traj_id" if forced == "s" else "k_traj_id_pk_tab"),
+            "fused": ("mp_spec_traj_id_s_f0" if forced == "s" else
+                      ("mp_spec_traj_id_co_f0" if os.environ.get("MANIPULAPY_HIP_TRAJ_CO", "0") == "1" else "mp_spec_traj_id_pk_f0")) if spec
+                     else ("k_traj_id" if forced == "s" else "k_traj_id_pk_tab"),
             "fk_jac_id": "mp_spec_fk_jac_id_d_f0" if spec else "k_fk_jac_id",
             "fd_traj": (("mp_spec_fd_traj_tm_f1" if spec else "k_fd_traj_tm") if cfg.get("layout") == "time_major" else
                         ("mp_spec_fd_traj_f1" if spec else "k_fd_traj"))}[cfg["op"]]

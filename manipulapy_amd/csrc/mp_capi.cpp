@@ -1584,9 +1584,12 @@ int mp_traj_id_fused_f32(mp_ctx* ctx, const mp_model* model, const float* d_star
   if (const MpSpec* sp = find_spec(ctx, model)) {
     long nt = (long)N;
     const double* tab = ctx->time_tab;
-    // default: flat rows, one timestep per lane in scalar arithmetic, tau as whole lines (csrc/mp_bodies.h, mp_body_traj_id_co);
-    // MANIPULAPY_HIP_TRAJ_CO=0 (experiment switch) keeps the two-timesteps-per-lane packed form
-    static const bool traj_co = !(getenv("MANIPULAPY_HIP_TRAJ_CO") && getenv("MANIPULAPY_HIP_TRAJ_CO")[0] == '0');
+    // MANIPULAPY_HIP_TRAJ_CO=1 (experiment switch): flat rows, one timestep per lane in scalar arithmetic, tau as whole lines
+    // (csrc/mp_bodies.h, mp_body_traj_id_co).  It writes exactly the algorithmic bytes (the packed form 1.036 x) and is SLOWER:
+    // the kernel is bound by instruction issue, 719 VALU per row of which 48 float64-rate = 1486 issue cycles per row against
+    // 1334 per row for the packed pair (803 per pair: 447 packed + 84 float64-rate at 4 cycles, 272 at 2) - c2f 0.0553-0.0571 ms
+    // against 0.0533 on one box without the conditioning test, 0.0628 against 0.0575 with it (profiles/r04_c2f_ab.txt)
+    static const bool traj_co = getenv("MANIPULAPY_HIP_TRAJ_CO") && getenv("MANIPULAPY_HIP_TRAJ_CO")[0] == '1';
     if (traj_co && sp->traj_id_co[ftip ? 1 : 0] && N >= 64 && (unsigned long long)B * (unsigned long long)N < 0xffffffc0ull) {
       unsigned rows = (unsigned)((unsigned long long)B * (unsigned long long)N), ntu = (unsigned)N;
       unsigned magic = (unsigned)(0x100000000ull / (unsigned long long)N);
@@ -1604,8 +1607,15 @@ int mp_traj_id_fused_f32(mp_ctx* ctx, const mp_model* model, const float* d_star
       return launch_spec(ctx, sp->traj_id_s[ftip ? 1 : 0], (long)B * bpt * 256, args);
     }
     unsigned bpt = mpk_traj_blocks_per_trajectory(nt);
+    const long rows_l = (long)B * (long)N;
+    mp_ctx::HardSlot* hs = sp->traj_id_hard[ftip ? 1 : 0] ? attach_hard_list(ctx, rows_l, &c) : nullptr;
     void* args[] = {&c, &d_start, &d_end, &nt, &bpt, &tab, &d_tau};
-    return launch_spec(ctx, sp->traj_id_pk[ftip ? 1 : 0], (long)B * bpt * 256, args);
+    if (int rc = launch_spec(ctx, sp->traj_id_pk[ftip ? 1 : 0], (long)B * bpt * 256, args)) return rc;
+    if (!hs) return MP_OK;
+    // (the generated rows' float64 pass runs at once: it reads the per-call time table, which the next fused call may rewrite)
+    unsigned rows_u = (unsigned)rows_l, ntu = (unsigned)N;
+    void* hargs[] = {&c, &d_start, &d_end, &ntu, &tab, &d_tau, &rows_u};
+    return launch_spec(ctx, sp->traj_id_hard[ftip ? 1 : 0], (long)hard_pass_blocks(rows_l) * 64, hargs, 64);
   }
   HIP_TRY(mpk_traj_id_tab(ctx->compute, model->f, c, ftip, d_start, d_end, (long)B, (long)N, ctx->time_tab, d_tau));
   return MP_OK;

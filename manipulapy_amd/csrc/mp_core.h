@@ -456,7 +456,7 @@ MP_HD void mp_rnea(const MT& M, const MpCall<typename MpTraits<T>::S>& C, const 
 // sits at <= 0.45 x the bound on 12.3 M rows, the re-evaluated rows at <= 0.1 x (profiles/r04_f32_precision_study.txt).
 // Deterministic: a row's precision depends on that row's values only.
 #ifndef MP_HARD_ROW_K
-#define MP_HARD_ROW_K 20.0f
+#define MP_HARD_ROW_K 14.0f
 #endif
 #ifndef MP_ADAPTIVE_F32   // 0 (experiment switch): plain float32 rows, for A/B measurements of what the test and the float64 rows cost
 #define MP_ADAPTIVE_F32 1

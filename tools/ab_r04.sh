@@ -6,9 +6,9 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 ROUNDS=${1:-3}
 for round in $(seq $ROUNDS); do
   for cfg in c2 c4 c4s c2f; do
-    for f in "adaptive|MANIPULAPY_X=0" "plain_f32_w6|MANIPULAPY_HIP_JIT_DEFINES=MP_ADAPTIVE_F32=0,MP_ID_CO_WAVES=6,MP_TRAJ_CO_WAVES=6" "plain_f32_w5|MANIPULAPY_HIP_JIT_DEFINES=MP_ADAPTIVE_F32=0" "K24|MANIPULAPY_HIP_JIT_DEFINES=MP_HARD_ROW_K=24.0f" "in_place|MANIPULAPY_HIP_HARD_PASS=0" "packed_fused|MANIPULAPY_HIP_TRAJ_CO=0" "packed_fused_plain|MANIPULAPY_HIP_TRAJ_CO=0 MANIPULAPY_HIP_JIT_DEFINES=MP_ADAPTIVE_F32=0"; do
+    for f in "adaptive|MANIPULAPY_X=0" "plain_f32_w6|MANIPULAPY_HIP_JIT_DEFINES=MP_ADAPTIVE_F32=0,MP_ID_CO_WAVES=6,MP_TRAJ_CO_WAVES=6" "plain_f32_w5|MANIPULAPY_HIP_JIT_DEFINES=MP_ADAPTIVE_F32=0" "K24|MANIPULAPY_HIP_JIT_DEFINES=MP_HARD_ROW_K=24.0f" "in_place|MANIPULAPY_HIP_HARD_PASS=0" "flat_fused|MANIPULAPY_HIP_TRAJ_CO=1" "flat_fused_plain|MANIPULAPY_HIP_TRAJ_CO=1 MANIPULAPY_HIP_JIT_DEFINES=MP_ADAPTIVE_F32=0"; do
       name=${f%%|*}; kv=${f##*|}
-      if [ "${name#packed_fused}" != "$name" ] && [ "$cfg" != c2f ]; then continue; fi
+      if [ "${name#flat_fused}" != "$name" ] && [ "$cfg" != c2f ]; then continue; fi
       env $kv python $R/bench.py --config $cfg --steps 200 --warmup 10 --no-cpu-baseline 2>/dev/null \
         | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$cfg', '$name', d['roofline']['kernel_ms'], d['roofline'].get('kernel'))"
     done
