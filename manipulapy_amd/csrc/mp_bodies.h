@@ -178,7 +178,8 @@ __device__ __forceinline__ bool mp_cold_rows(const MT& M, const MpCall<float>& C
   const unsigned long long mask = __builtin_amdgcn_ballot_w64(hard);
   if (__builtin_expect(mask == 0ull, 1)) return false;  // wave-uniform
   const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-  if (row >= 0 && mp_push_hard_rows(C, mask, rank, hard, row)) return false;
+  // handed over only if EVERY flagged lane of the wave has a row index to hand over (wave-uniform decision)
+  if (__builtin_amdgcn_ballot_w64(hard && row < 0) == 0ull && mp_push_hard_rows(C, mask, rank, hard, row)) return false;
   const int total = __builtin_popcountll(mask);
   for (int base = 0; base < total; base += G) {  // wave-uniform trip count
     const int slot = rank - base;
@@ -655,7 +656,7 @@ __device__ __forceinline__ void store_pair(float* __restrict__ base, long pair, 
 template <int N, bool HAS_FTIP, typename MT>
 __device__ __forceinline__ void mp_rnea_pk(const MT& M, const MpCall<float>& C, const MpJointState<mp_f2, N>& js, const mp_f2 (&q)[N],
                                            const mp_f2 (&qd)[N], const mp_f2 (&qdd)[N], mp_f2 (&tau)[N], const MpBad<mp_f2>& bad,
-                                           char* __restrict__ cold, long rowx = -1, long rowy = -1) {
+                                           char* __restrict__ cold, long rowx = -1, long rowy = -1, bool usey = true) {
 #if MP_ADAPTIVE_F32
   const mp_f2 tn[3] = {(mp_f2)(C.F1n[0]), (mp_f2)(C.F1n[1]), (mp_f2)(C.F1n[2])};
   const mp_f2 tf[3] = {(mp_f2)(C.F1f[0]), (mp_f2)(C.F1f[1]), (mp_f2)(C.F1f[2])};
@@ -665,7 +666,7 @@ __device__ __forceinline__ void mp_rnea_pk(const MT& M, const MpCall<float>& C, 
 #pragma unroll
   for (int i = 0; i < N; ++i) { tx[i] = tau[i].x; ty[i] = tau[i].y; }
   const bool hx = mp_id_row_is_hard<N>(tx, sF.x, M.lscale) && !bad.x.any();
-  const bool hy = mp_id_row_is_hard<N>(ty, sF.y, M.lscale) && !bad.y.any();
+  const bool hy = mp_id_row_is_hard<N>(ty, sF.y, M.lscale) && !bad.y.any() && usey;  // (usey false: a duplicate the caller drops)
   mp_cold_rows<N, HAS_FTIP, MP_COLD_G>(M, C, hx, rowx, cold, [&](float (&a)[N], float (&b)[N], float (&c)[N]) {
 #pragma unroll
     for (int i = 0; i < N; ++i) { a[i] = q[i].x; b[i] = qd[i].x; c[i] = qdd[i].x; }
@@ -787,7 +788,7 @@ __device__ __forceinline__ void mp_body_traj_id_pk_tab(const MT& M, const MpCall
   mp_joint_state<mp_f2, N>(M, qq, js);
   MpBad<mp_f2> bad;  // a non-finite end point makes the generated row non-finite
   bad.add(qq); bad.add(qd); bad.add(qdd);
-  mp_rnea_pk<N, HAS_FTIP>(M, C, js, qq, qd, qdd, tq, bad, cold, b * Nt + t0, valid1 ? b * Nt + t1 : -1L);
+  mp_rnea_pk<N, HAS_FTIP>(M, C, js, qq, qd, qdd, tq, bad, cold, b * Nt + t0, b * Nt + t1, valid1);
   float lo[N], hi[N];
 #pragma unroll
   for (int j = 0; j < N; ++j) {
