@@ -1639,7 +1639,14 @@ def test_planner_profiling_specialised_dispatch_and_model_release(tables):
         assert 0.0 < st["gpu_kernel_ms_last"] < 50.0 and st["gpu_kernel_ms_total"] >= st["gpu_kernel_ms_last"]
         r = pl.batch_joint_trajectory(s_, e_, 2.0, N, 5)
         t2 = pl.inverse_dynamics_trajectory(r["positions"].reshape(-1, 6), r["velocities"].reshape(-1, 6), r["accelerations"].reshape(-1, 6))
-        np.testing.assert_array_equal(t2.reshape(B, N, 6), tau)
+        # (two different kernels - the fused one keeps two timesteps per lane in packed arithmetic, the plain one a row per lane: the
+        # same operations, but the compiler contracts them into FMAs independently, so the float32 results agree to rounding, not
+        # to the bit; rows re-evaluated in float64 do agree exactly)
+        t2 = t2.reshape(B, N, 6)
+        np.testing.assert_allclose(t2, tau, rtol=1e-4, atol=1e-5 * float(np.abs(tau).max(axis=2).max()))
+        hard = _hip.cpu_id_row_precision(pl._hip_model(), r["positions"].reshape(-1, 6), r["velocities"].reshape(-1, 6),
+                                         r["accelerations"].reshape(-1, 6)).reshape(B, N)
+        assert hard.any() and np.array_equal(t2[hard], tau[hard])
         st2 = pl.get_performance_stats()
         assert st2["gpu_timed_calls"] >= st["gpu_timed_calls"] + 2 and st2["gpu_kernel_ms_total"] > st["gpu_kernel_ms_total"]
         assert st2["gpu_kernel_ms_total"] <= st2["total_gpu_time"] * 1e3  # kernel time is inside the wall time of the calls
