@@ -417,14 +417,289 @@ def bench_fd(args, cfg, info, hg, ctx, model, t, props, headline=True):
         # for q / qd and within eps * cond(M) for qdd
         bounds = {"positions": 2e-6, "velocities": 2e-5, "accelerations": 1e-4}
         par["one_step_defect"] = {"trajectories": nd, "steps_each": N - 1, "max_rel_to_row_max": defect, "bounds": bounds}
-        par["ok"] = bool(finite and all(defect[k] <= bounds[k] for k in bounds) and par["drift_over_scale"]["p99"] <= 1e-4)
-        par["rule"] = "all outputs finite, one-step defect within bounds, 99 % of the trajectories within 1e-4 of each array's scale over all N steps"
+        # round 3 asked only for the 99th percentile: one trajectory in a hundred could have been arbitrarily wrong.  Now 99.9 % of the
+        # trajectories within 1e-4 AND none beyond 1e-2 of scale (a released arm amplifies float32 rounding chaotically: the worst of
+        # 12 - 50 thousand trajectories has measured 2e-4 ... 8e-3 from run to run; a broken integrator is off by O(1))
+        par["ok"] = bool(finite and all(defect[k] <= bounds[k] for k in bounds) and par["drift_over_scale"]["fraction_within_1e-4"] >= 0.999
+                         and par["drift_over_scale"]["max"] <= 1e-2)
+        par["rule"] = ("all outputs finite, one-step defect within bounds, >= 99.9 % of the trajectories within 1e-4 of each array's scale over "
+                       "all N steps and none beyond 1e-2")
         result["parity_sample"] = par
         if not headline:
             result.pop("cpu_baseline", None)
     for b in bufs:
         b.free()
     return result
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# N > 1: the two BASELINE configurations that NAME the 8-GPU split, strong-scaled (the total batch fixed, cut over the ranks)
+# ----------------------------------------------------------------------------------------------------------------------
+STRONG = {
+    # BASELINE configs[3]: Franka Panda, B = 262144 x N = 200, sharded over the GPUs with the all-gather of the torque history
+    "c4": dict(robot="panda", B_total=262144, N=200, dtype="f32", op="id", seed=40,
+               desc="Franka Panda (8 DOF as the reference parses it), B=262144 x N=200 in total, cut over the ranks (shard_range, uneven "
+                    "allowed), ID fp32, torque history reassembled on every GPU (BASELINE configs[3])"),
+    # BASELINE configs[4]: B = 1M x N = 100 roll-outs on 8 GPUs
+    "c5": dict(robot="xarm6", B_total=1048576, N=100, dtype="f32", op="fd_traj", layout="time_major", seed=50,
+               desc="xArm6, gravity + per-step Ftip, B=1048576 x N=100 roll-outs in total, cut over the ranks, time-major device arrays, "
+                    "positions / velocities / accelerations reassembled on every GPU (BASELINE configs[4])"),
+}
+
+
+def strong_plan(name, world, n=None):
+    """Host logic of a strong-scaled configuration, identical on every rank: who owns which trajectories, how many bytes each
+    rank contributes to each gathered array and where they land, the chunks of the overlapped exchange, the seeds the
+    verification regenerates inputs from.  No GPU involved (the dry run and the gloo tests execute exactly this)."""
+    from manipulapy_amd import robots, sharding
+
+    cfg = STRONG[name]
+    if n is None:
+        n = robots.robot_tables(cfg["robot"])["S_list"].shape[1]
+    Bt, N = cfg["B_total"], cfg["N"]
+    ranges = [sharding.shard_range(Bt, world, r) for r in range(world)]
+    row_b = n * 4
+    counts, offsets = sharding.shard_layout(Bt, world, N * row_b)     # bytes of each rank's block of one gathered (.., n) float32 array
+    plan = {"config": name, "B_total": Bt, "N": N, "dof": n, "world": world, "trajectories_of_rank": [hi - lo for lo, hi in ranges],
+            "first_trajectory_of_rank": [lo for lo, _ in ranges], "bytes_of_rank": counts, "slot_offset": offsets,
+            "gathered_bytes_per_array": sum(counts), "arrays_gathered": 1 if cfg["op"] == "id" else 3,
+            "verify": {"what": "rank 0 recomputes the FIRST trajectory of every rank's shard and compares it bit for bit with that rank's block",
+                       "seed_start_end": SEED + cfg["seed"], "seed_of_rank_streams": [SEED + cfg["seed"] + 1 + r for r in range(world)]}}
+    if cfg["op"] == "id":
+        chunks = 4
+        layout = []
+        for k in range(chunks):   # chunk k of EVERY rank travels in round k: rows [r0, r1) of that rank's own shard
+            off, nbytes = [], []
+            for lo, hi in ranges:
+                rows_r = (hi - lo) * N
+                per = ((rows_r // chunks) + 1) & ~1
+                r0, r1 = min(rows_r, k * per), min(rows_r, (k + 1) * per)
+                off.append(r0 * row_b); nbytes.append((r1 - r0) * row_b)
+            layout.append({"chunk_offset": off, "chunk_bytes": nbytes})
+        plan["overlapped_exchange"] = {"chunks": chunks, "rounds": layout}
+        assert all(sum(rd["chunk_bytes"][r] for rd in layout) == counts[r] for r in range(world))
+    assert ranges[0][0] == 0 and ranges[-1][1] == Bt and all(ranges[r][1] == ranges[r + 1][0] for r in range(world - 1))
+    return plan
+
+
+def strong_inputs(name, plan, rank, model_limits):
+    """This rank's synthetic inputs (host arrays), reproducible trajectory by trajectory: start / end (or initial states) are slices
+    of ONE seeded draw over all B_total trajectories; per-step streams (torque disturbance, wrench scale) are drawn per rank."""
+    cfg = STRONG[name]
+    n, N, Bt = plan["dof"], plan["N"], plan["B_total"]
+    lo = plan["first_trajectory_of_rank"][rank]
+    Bs = plan["trajectories_of_rank"][rank]
+    rng = np.random.default_rng(plan["verify"]["seed_start_end"])
+    if cfg["op"] == "id":
+        a, b = model_limits[:, 0], model_limits[:, 1]
+        start = rng.uniform(a, b, (Bt, n)).astype(np.float32)[lo:lo + Bs]
+        end = rng.uniform(a, b, (Bt, n)).astype(np.float32)[lo:lo + Bs]
+        return {"start": start, "end": end}
+    th0 = rng.uniform(-0.5, 0.5, (Bt, n)).astype(np.float32)[lo:lo + Bs]
+    dth0 = rng.uniform(-0.2, 0.2, (Bt, n)).astype(np.float32)[lo:lo + Bs]
+    return {"th0": th0, "dth0": dth0, "stream_seed": plan["verify"]["seed_of_rank_streams"][rank]}
+
+
+def strong_fd_streams(seed, Bs, N, n, hold, time_major=False):
+    """(taumat, Fm) of a rank - (Bs,N,n) / (Bs,N,6), or (N,Bs,n) / (N,Bs,6) with time_major: gravity-holding torques + 1e-3
+    disturbance, wrench 0.02 x reference x U(0.5,1).  The two streams come from generators of their own and are drawn 65536
+    trajectories at a time (a million trajectories are 5 GB of float64 draws at once), so trajectory 0 of a rank can be regenerated
+    without drawing the rest."""
+    r1, r2 = np.random.default_rng(seed), np.random.default_rng(seed + 7919)
+    shape = (lambda k: (N, Bs, k)) if time_major else (lambda k: (Bs, N, k))
+    taumat, Fm = np.empty(shape(n), np.float32), np.empty(shape(6), np.float32)
+    f = FTIP_REF.astype(np.float32) * np.float32(0.02)
+    for b0 in range(0, Bs, 65536):
+        b1 = min(Bs, b0 + 65536)
+        tm = (hold[b0:b1, None, :] + r1.uniform(-1, 1, (b1 - b0, N, n)).astype(np.float32) * np.float32(1e-3)).astype(np.float32)
+        fm = (f * r2.uniform(0.5, 1.0, (b1 - b0, N, 1)).astype(np.float32)).astype(np.float32)
+        if time_major:
+            taumat[:, b0:b1], Fm[:, b0:b1] = np.swapaxes(tm, 0, 1), np.swapaxes(fm, 0, 1)
+        else:
+            taumat[b0:b1], Fm[b0:b1] = tm, fm
+    return taumat, Fm
+
+
+def bench_strong(name, args, info, hg, ctx, props):
+    """One strong-scaled configuration on this rank's shard: compute-only timing (no collective in the step), then the reassembly
+    (RCCL all-gather with per-rank byte counts; for inverse dynamics also the chunked exchange overlapped with compute), verified."""
+    from manipulapy_amd import _hip, robots
+
+    cfg = dict(STRONG[name]); cfg["name"] = name
+    world, rank = info.world, info.rank
+    t = robots.robot_tables(cfg["robot"])
+    n = t["S_list"].shape[1]
+    plan = strong_plan(name, world, n)
+    N, Bs = plan["N"], plan["trajectories_of_rank"][rank]
+    model = _hip.HipModel(t["S_list"], t["Mlist_per_link"], t["Glist"], t["M_ee"], t["joint_limits"])
+    if not args.no_specialize:
+        ctx.specialize(model)
+    cfg["specialized"] = ctx.is_specialized(model)
+    cfg["dof"] = n
+    inp = strong_inputs(name, plan, rank, t["joint_limits"])
+    g = np.array([0.0, 0.0, -9.81])
+    rows = Bs * N
+    mine = plan["bytes_of_rank"][rank]
+    bufs = []
+
+    def keep(b):
+        bufs.append(b)
+        return b
+
+    if cfg["op"] == "id":
+        d_start, d_end = keep(ctx.to_device(inp["start"])), keep(ctx.to_device(inp["end"]))
+        d_q, d_qd, d_qdd, d_tau = (keep(ctx.alloc(max(mine, 16))) for _ in range(4))
+        ctx.batch_trajectory(model, d_start, d_end, Bs, N, 2.0, 5, d_q, d_qd, d_qdd)
+        ctx.synchronize()
+        outs = [d_tau]
+
+        def step(dst=None):
+            ctx.id_trajectory(model, d_q, d_qd, d_qdd, rows, dst if dst is not None else d_tau, dtype=np.float32)
+        alg = 16 * n * rows
+    else:
+        th0, dth0 = inp["th0"], inp["dth0"]
+        zero = np.zeros_like(th0)
+        hold = ctx.id_trajectory_host(model, th0, zero, zero, g, None, dtype=np.float32)
+        taumat, Fm = strong_fd_streams(inp["stream_seed"], Bs, N, n, hold, time_major=True)
+        d_th0, d_dth0 = keep(ctx.to_device(th0)), keep(ctx.to_device(dth0))
+        d_tm, d_F = keep(ctx.to_device(taumat)), keep(ctx.to_device(Fm))
+        del taumat, Fm
+        outs = [keep(ctx.alloc(max(mine, 16))) for _ in range(3)]
+
+        def step(dst=None):
+            ctx.fd_trajectory(model, d_th0, d_dth0, d_tm, d_F, Bs, N, g, 0.01, 1, outs[0], outs[1], outs[2], dtype=np.float32, time_major=True)
+        alg = ((n + 6) * 4 + 12 * n) * rows
+
+    def timed(fn):
+        ramp(ctx, fn, args.ramp_ms)
+        for _ in range(args.warmup):
+            fn()
+        a, b = ctx.event(), ctx.event()
+        hg.barrier(); ctx.synchronize()
+        t0 = time.perf_counter()
+        a.record()
+        for _ in range(args.steps):
+            fn()
+        b.record()
+        ctx.synchronize()
+        dt = time.perf_counter() - t0
+        hg.barrier()
+        wall = hg.max(dt)
+        kms = b.elapsed_ms_since(a) / args.steps
+        a.destroy(); b.destroy()
+        return wall, kms
+
+    elapsed, kern_ms = timed(step)
+    kern_ms_all = hg.max(kern_ms)
+    alg_max = hg.max(float(alg))                     # the largest shard's bytes: the rank whose kernel sets the step
+    total_jt = plan["B_total"] * N * n
+    entry = {"metric": "joint-timesteps/sec (NxBxDOF) " + ("inverse-dynamics trajectory" if cfg["op"] == "id" else "forward-dynamics trajectory"),
+             "value": total_jt * args.steps / elapsed, "unit": "joint-timesteps/s", "n_gpus": world, "steps": args.steps,
+             "ms_per_step": elapsed / args.steps * 1e3, "scaling": "strong", "dtype": "f32", "workload": cfg["desc"],
+             "kernel_variant": "robot-specialised (hiprtc)" if cfg["specialized"] else "generic",
+             "shard": {k: plan[k] for k in ("B_total", "N", "dof", "trajectories_of_rank", "first_trajectory_of_rank", "bytes_of_rank",
+                                            "slot_offset", "gathered_bytes_per_array", "arrays_gathered")},
+             "kernel": kernel_name(dict(cfg, layout=cfg.get("layout"))), "kernel_ms_max_over_ranks": kern_ms_all,
+             "roofline": {"bound": "hbm", "achieved": alg_max / (kern_ms_all * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                          "frac": alg_max / (kern_ms_all * 1e-3) / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": alg_max,
+                          "traffic": None, "what": "the largest shard's algorithmic bytes / the slowest rank's kernel time"}}
+
+    gather = {"collective": "mp_comm_allgatherv (grouped ncclSend / ncclRecv, per-rank byte counts)", "arrays": plan["arrays_gathered"],
+              "bytes_of_rank": plan["bytes_of_rank"]}
+    entry["allgather"] = gather
+
+    def first_trajectory_of(r):
+        """what rank r's first trajectory must come out as, recomputed here from the seeds"""
+        pr = strong_inputs(name, plan, r, t["joint_limits"])
+        if cfg["op"] == "id":
+            p, v, a = ctx.batch_trajectory_host(model, pr["start"][:1], pr["end"][:1], 2.0, N, 5)
+            return [ctx.id_trajectory_host(model, p[0], v[0], a[0])]
+        h = ctx.id_trajectory_host(model, pr["th0"][:1], np.zeros((1, n), np.float32), np.zeros((1, n), np.float32), g, None, dtype=np.float32)
+        tmr, Fr = strong_fd_streams(pr["stream_seed"], 1, N, n, h)
+        o = ctx.fd_trajectory_host(model, pr["th0"][:1], pr["dth0"][:1], tmr, g, Fr, 0.01, 1, dtype=np.float32)
+        return [np.asarray(x[0], np.float32) for x in o]
+
+    def verify(d_alls):
+        try:
+            ctx.synchronize()
+            for r in range(world):
+                want = first_trajectory_of(r)
+                Br = plan["trajectories_of_rank"][r]
+                for d_all, w in zip(d_alls, want):
+                    if cfg["op"] == "id":    # rank r's block is (B_r, N, n): its first N rows
+                        got = np.empty((N, n), np.float32)
+                        _hip._check(ctx.lib.mp_memcpy_d2h(ctx.handle, got.ctypes.data, d_all.offset(plan["slot_offset"][r]), got.nbytes))
+                    else:                    # rank r's block is time-major (N, B_r, n): row 0 of every step
+                        blk = np.empty((N, Br, n), np.float32)
+                        _hip._check(ctx.lib.mp_memcpy_d2h(ctx.handle, blk.ctypes.data, d_all.offset(plan["slot_offset"][r]), blk.nbytes))
+                        got = blk[:, 0, :]
+                    if not np.array_equal(got, w):
+                        return f"mismatch in the block of rank {r}: max abs diff {float(np.abs(got - w).max()):.3e}"
+            return True
+        except Exception as exc:
+            return f"not checked: {str(exc)[:200]}"
+
+    def gather_phase():
+        try:
+            uid = _hip.HipContext.comm_unique_id() if rank == 0 else None
+            uid = hg.broadcast_bytes(uid, _hip.UNIQUE_ID_BYTES)
+            comm = ctx.comm_create(uid, world, rank)
+            d_alls = [keep(ctx.alloc(plan["gathered_bytes_per_array"])) for _ in outs]
+
+            def step_and_gather():
+                step()
+                for o, d_all in zip(outs, d_alls):
+                    comm.allgatherv(o, d_all, plan["bytes_of_rank"])
+
+            wall_g, _ = timed(step_and_gather)
+            ms_g = wall_g / args.steps * 1e3
+            gather.update({"ms_per_step_with_allgather": ms_g, "value_with_allgather": total_jt * args.steps / wall_g})
+            if rank == 0:
+                gather["verified"] = verify(d_alls)
+            if cfg["op"] == "id":
+                ov = plan["overlapped_exchange"]
+                d_all = d_alls[0]
+                ctx.memset(d_all, 0, plan["gathered_bytes_per_array"])
+                row_b = n * 4
+
+                def step_overlapped():
+                    for rd in ov["rounds"]:
+                        off, nbytes = rd["chunk_offset"][rank], rd["chunk_bytes"][rank]
+                        if nbytes:
+                            ctx.id_trajectory(model, d_q.offset(off), d_qd.offset(off), d_qdd.offset(off), nbytes // row_b,
+                                              d_all.offset(plan["slot_offset"][rank] + off), dtype=np.float32)
+                        comm.exchange_chunk_v(d_all, plan["slot_offset"], rd["chunk_offset"], rd["chunk_bytes"])
+                    comm.join()
+
+                wall_o, _ = timed(step_overlapped)
+                gather["overlapped"] = {"chunks": ov["chunks"], "ms_per_step": wall_o / args.steps * 1e3, "value": total_jt * args.steps / wall_o,
+                                        "how": "per chunk: kernel on the compute stream straight into this rank's block, then grouped "
+                                               "ncclSend / ncclRecv to every peer on the communicator's stream (mp_comm_exchange_chunk_v)"}
+                if rank == 0:
+                    gather["overlapped"]["verified"] = verify([d_all])
+            else:
+                gather["overlapped"] = None   # a roll-out is sequential in time: its outputs are complete only at the end of the launch
+            comm.destroy()
+        except Exception as exc:
+            gather["error"] = str(exc)[:300]
+
+    hung = False
+    if (world > 1 or os.environ.get("MANIPULAPY_BENCH_FORCE_GATHER") == "1") and not args.no_gather:
+        import threading
+
+        th = threading.Thread(target=gather_phase, daemon=True)
+        th.start()
+        th.join(timeout=float(os.environ.get("MANIPULAPY_BENCH_GATHER_TIMEOUT", "180")))
+        if th.is_alive():
+            gather["error"] = "timeout: the RCCL phase did not complete"
+            hung = True
+    if not hung:
+        ctx.synchronize()
+        for b in bufs:
+            b.free()
+        ctx.trim_pool()
+    entry["verified"] = bool(gather.get("verified") is True and (gather.get("overlapped") or {}).get("verified", True) is True)
+    return entry, hung
 
 
 def attach_counters(result, config):
@@ -533,9 +808,17 @@ def main():
         hg.barrier()
         top = hg.max(float(info.rank))
         ids = hg.broadcast_bytes(bytes(range(128)) if info.rank == 0 else None, 128)
+        # the strong-scaled entries of an N > 1 line: every rank derives the plan, the ranks' views are compared over gloo
+        plans = {name: strong_plan(name, world, {"c4": 8, "c5": 6}[name]) for name in STRONG}
+        mine = np.array([[plans[k]["first_trajectory_of_rank"][info.rank], plans[k]["trajectories_of_rank"][info.rank],
+                          plans[k]["slot_offset"][info.rank], plans[k]["bytes_of_rank"][info.rank]] for k in sorted(STRONG)], dtype=np.int64)
+        seen = hg.allgather(mine[None])          # (world, 2, 4)
+        agree = all(int(seen[r, i, 0]) == plans[k]["first_trajectory_of_rank"][r] and int(seen[r, i, 3]) == plans[k]["bytes_of_rank"][r]
+                    for r in range(world) for i, k in enumerate(sorted(STRONG)))
         if info.rank == 0:
             emit({"dryrun": True, "n_gpus": world, "max_rank_seen": top, "broadcast_ok": ids == bytes(range(128)),
-                  "config": {"workload": CONFIGS["c2" if args.config == "all" else args.config]["desc"]}})
+                  "config": {"workload": CONFIGS["c2" if args.config == "all" else args.config]["desc"]},
+                  "configs": {k: dict(plans[k], scaling="strong", ranks_agree=bool(agree)) for k in plans}})
         return
 
     dev = info.local_rank
@@ -562,6 +845,20 @@ def main():
             result["configs"][name] = entry
             if "error" in entry or not (entry.get("parity_sample") or {"ok": True}).get("ok", True):
                 failed.append(name)
+    strong_on = args.config == "all" and not hung and (world > 1 or os.environ.get("MANIPULAPY_BENCH_FORCE_GATHER") == "1")
+    if strong_on:
+        # the configurations BASELINE defines on the 8-GPU split, strong-scaled over the ranks, each with its reassembly
+        result.setdefault("configs", {})
+        for name in STRONG:
+            t0 = time.perf_counter()
+            try:
+                entry, hung = bench_strong(name, args, info, hg, ctx, props)
+            except Exception as exc:
+                entry, hung = {"error": f"{type(exc).__name__}: {str(exc)[:300]}"}, False
+            entry["wall_s"] = round(time.perf_counter() - t0, 2)
+            result["configs"][name + "_strong"] = entry
+            if hung:
+                break
     if failed:
         result["parity_failed"] = failed
     if info.rank == 0:
@@ -569,8 +866,9 @@ def main():
     if hung:
         os._exit(3)  # a stuck collective cannot be cancelled from Python: leave, non-zero, without another context call
     ctx.destroy()
-    if world > 1 and result.get("allgather") is not None and result.get("verified") is False and info.rank == 0:
-        raise SystemExit(5)   # the reassembled torque history did not match the recomputation: not a result
+    unverified = [k for k, v in (result.get("configs") or {}).items() if k.endswith("_strong") and "allgather" in v and not v.get("verified")]
+    if world > 1 and info.rank == 0 and ((result.get("allgather") is not None and result.get("verified") is False) or unverified):
+        raise SystemExit(5)   # a reassembled history did not match the recomputation: not a result
     if failed:
         raise SystemExit(4)
 

@@ -709,11 +709,28 @@ def test_bench_self_launches_one_worker_per_gpu():
     env = dict(os.environ, PYTHONPATH=ROOT, MANIPULAPY_BENCH_DRYRUN="1")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env,
-                         capture_output=True, text=True, timeout=300)
-    assert res.returncode == 0, res.stderr[-2000:]
-    line = json.loads(res.stdout.strip().splitlines()[-1])
-    assert line["dryrun"] and line["n_gpus"] == 2 and line["max_rank_seen"] == 1.0 and line["broadcast_ok"]
+    for world in (2, 3):
+        res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1"], env=env,
+                             capture_output=True, text=True, timeout=300)
+        assert res.returncode == 0, res.stderr[-2000:]
+        line = json.loads(res.stdout.strip().splitlines()[-1])
+        assert line["dryrun"] and line["n_gpus"] == world and line["max_rank_seen"] == world - 1.0 and line["broadcast_ok"]
+        # the strong-scaled entries an N > 1 line carries (BASELINE configs[3] and [4] cut over the ranks): every rank derived the
+        # same plan (compared over gloo), shards cover the batch exactly, blocks are back to back in the gathered arrays, uneven
+        # at world 3, and the overlapped exchange's rounds add up to each rank's block
+        for name, Bt, N, n, arrays in (("c4", 262144, 200, 8, 1), ("c5", 1048576, 100, 6, 3)):
+            c = line["configs"][name]
+            assert c["scaling"] == "strong" and c["ranks_agree"] and c["B_total"] == Bt and c["arrays_gathered"] == arrays
+            assert sum(c["trajectories_of_rank"]) == Bt and max(c["trajectories_of_rank"]) - min(c["trajectories_of_rank"]) == (1 if Bt % world else 0)
+            assert c["first_trajectory_of_rank"] == [sum(c["trajectories_of_rank"][:r]) for r in range(world)]
+            assert c["bytes_of_rank"] == [b * N * n * 4 for b in c["trajectories_of_rank"]]
+            assert c["slot_offset"] == [sum(c["bytes_of_rank"][:r]) for r in range(world)] and c["gathered_bytes_per_array"] == Bt * N * n * 4
+            assert len(c["verify"]["seed_of_rank_streams"]) == world
+            if name == "c4":
+                rounds = c["overlapped_exchange"]["rounds"]
+                for r in range(world):
+                    assert sum(rd["chunk_bytes"][r] for rd in rounds) == c["bytes_of_rank"][r]
+                    assert [rd["chunk_offset"][r] for rd in rounds] == [sum(x["chunk_bytes"][r] for x in rounds[:k]) for k in range(len(rounds))]
     # a worker that fails makes the launcher fail: without the dry-run flag the first HIP call raises on this box
     if not os.path.exists("/dev/kfd"):
         env.pop("MANIPULAPY_BENCH_DRYRUN")
