@@ -612,8 +612,12 @@ def bench_strong(name, args, info, hg, ctx, props):
         """what rank r's first trajectory must come out as, recomputed here from the seeds"""
         pr = strong_inputs(name, plan, r, t["joint_limits"])
         if cfg["op"] == "id":
-            p, v, a = ctx.batch_trajectory_host(model, pr["start"][:1], pr["end"][:1], 2.0, N, 5)
-            return [ctx.id_trajectory_host(model, p[0], v[0], a[0])]
+            # as many leading trajectories as make whole 64-row waves: every row then goes through the same kernel as in the shard
+            # (the last < 64 rows of a launch take the per-lane kernel, whose FMA contraction may differ in the last bit)
+            import math
+            kk = min(64 // math.gcd(64, N), len(pr["start"]))
+            p, v, a = ctx.batch_trajectory_host(model, pr["start"][:kk], pr["end"][:kk], 2.0, N, 5)
+            return [ctx.id_trajectory_host(model, p.reshape(-1, n), v.reshape(-1, n), a.reshape(-1, n))[:N]]
         h = ctx.id_trajectory_host(model, pr["th0"][:1], np.zeros((1, n), np.float32), np.zeros((1, n), np.float32), g, None, dtype=np.float32)
         tmr, Fr = strong_fd_streams(pr["stream_seed"], 1, N, n, h)
         o = ctx.fd_trajectory_host(model, pr["th0"][:1], pr["dth0"][:1], tmr, g, Fr, 0.01, 1, dtype=np.float32)
