@@ -155,8 +155,8 @@ class OptimizedTrajectoryPlanning:
         entry = _reg.get_registered_kernel(name)
         t0 = time.time()
         if self._gpu_routed():
-            out = entry.gpu_launcher(*args, **kwargs)
-            self._count("gpu", t0)
+            out, route = _reg.run_gpu_launcher(entry, *args, **kwargs)   # "cpu" only under MANIPULAPY_HIP_FALLBACK=1 after a failed launch
+            self._count(route, t0)
         else:
             if not self._forced_cpu:
                 _reg._refuse_silent_cpu(name)
@@ -178,8 +178,8 @@ class OptimizedTrajectoryPlanning:
         if self._should_use_gpu(int(N), len(start)):
             variant = kernel_type or self.kernel_type or "auto"
             entry = _reg.get_registered_kernel(f"trajectory.{variant}")  # fail-closed on unknown names
-            pos, vel, acc = entry.gpu_launcher(self._hip_model(), start, end, Tf, int(N), int(method))
-            self._count("gpu", t0)
+            (pos, vel, acc), route = _reg.run_gpu_launcher(entry, self._hip_model(), start, end, Tf, int(N), int(method))
+            self._count(route, t0)
         else:
             pos, vel, acc = _reg.trajectory_cpu(start, end, float(Tf), int(N), int(method))
             pos = self._clip_positions(pos)
@@ -200,8 +200,9 @@ class OptimizedTrajectoryPlanning:
             z = np.zeros((0, int(N), n), dtype=np.float32)
             return {"positions": z, "velocities": z.copy(), "accelerations": z.copy()}
         if self._gpu_routed():
-            pos, vel, acc = _reg.execute_registered_kernel("trajectory.batch", self._hip_model(), sb, eb, Tf, int(N), int(method))
-            self._count("gpu", t0)
+            (pos, vel, acc), route = _reg.run_gpu_launcher(_reg.get_registered_kernel("trajectory.batch"), self._hip_model(), sb, eb, Tf,
+                                                           int(N), int(method))
+            self._count(route, t0)
         else:
             pos, vel, acc = _reg.trajectory_cpu(sb, eb, float(Tf), int(N), int(method))
             pos = self._clip_positions(pos)

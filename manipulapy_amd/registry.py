@@ -18,6 +18,7 @@ the host.  Batched IK has no CPU launcher (`BackendNotSupportedError`).
 """
 from __future__ import annotations
 
+import logging
 import os
 import threading
 from dataclasses import dataclass
@@ -31,7 +32,8 @@ from .backend import get_backend
 
 __all__ = ["KernelRegistration", "KernelRegistry", "execute_registered_kernel", "get_registered_kernel",
            "check_hip_availability", "get_context", "get_gpu_properties", "BackendNotSupportedError",
-           "trajectory_cpu", "potential_field_cpu", "HIP_DEVICE_ENV"]
+           "trajectory_cpu", "potential_field_cpu", "HIP_DEVICE_ENV", "FALLBACK_ENV", "fallback_enabled", "fallback_stats",
+           "run_gpu_launcher"]
 
 HIP_DEVICE_ENV = "MANIPULAPY_HIP_DEVICE"
 
@@ -78,9 +80,38 @@ class KernelRegistry:
     def execute(self, name: str, *args: Any, **kwargs: Any) -> Any:
         entry = self.get(name)
         if _hip_routing_enabled():
-            return entry.gpu_launcher(*args, **kwargs)
+            return run_gpu_launcher(entry, *args, **kwargs)[0]
         _refuse_silent_cpu(name)
         return entry.cpu_launcher(*args, **kwargs)
+
+
+# ------------------------------------------------------------------------ reference failure semantics
+# The reference wraps every GPU path in try / except and recomputes on the CPU (planning/trajectory.py:270-274,
+# planning/trajectory_dynamics.py:292-302, cuda_kernels/trajectory_kernels.py:1083-1086).  Here a failing launch RAISES by default -
+# a silent recompute would void every parity and throughput claim - and MANIPULAPY_HIP_FALLBACK=1 opts into the reference's
+# behaviour for drop-in users: the HipError is logged with the reference's wording, the operation's registered cpu_launcher runs
+# (the C ABI's *_cpu launchers or the NumPy ones - never oracle/), and the event is counted (fallback_stats, and the planner's
+# performance_stats["cpu_calls"]).  bench.py and the GPU test suite never set it.
+FALLBACK_ENV = "MANIPULAPY_HIP_FALLBACK"
+fallback_stats: Dict[str, int] = {"calls": 0}
+logger = logging.getLogger("manipulapy_amd")
+
+
+def fallback_enabled() -> bool:
+    return os.environ.get(FALLBACK_ENV) == "1"
+
+
+def run_gpu_launcher(entry: KernelRegistration, *args: Any, **kwargs: Any):
+    """(result, "gpu" | "cpu"): the entry's GPU launcher; with MANIPULAPY_HIP_FALLBACK=1 a HipError / HipUnavailableError from it
+    is logged and answered by the entry's CPU launcher, as the reference does."""
+    try:
+        return entry.gpu_launcher(*args, **kwargs), "gpu"
+    except (_hip.HipError, _hip.HipUnavailableError) as exc:
+        if not fallback_enabled():
+            raise
+        logger.warning("GPU %s failed: %s, falling back to CPU", entry.name, exc)
+        fallback_stats["calls"] += 1
+        return entry.cpu_launcher(*args, **kwargs), "cpu"
 
 
 # ------------------------------------------------------------------------------ device probe / ctx

@@ -739,6 +739,38 @@ def test_bench_self_launches_one_worker_per_gpu():
         assert res.returncode != 0
 
 
+def test_opt_in_reference_failure_semantics(monkeypatch, caplog):
+    """MANIPULAPY_HIP_FALLBACK=1: a HipError from a GPU launcher is logged with the reference's wording, the operation's registered
+    CPU launcher answers, and the planner counts a CPU call (reference planning/trajectory.py:270-274, trajectory_dynamics.py:292-302).
+    Without the switch the same failure raises (the default, see test_gpu_launcher_errors_propagate)."""
+    import logging
+
+    if _hip.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    sm, dyn, lim = mp.load_robot("ur5")
+    pl = mp.OptimizedTrajectoryPlanning(sm, None, dyn, lim, cuda_threshold=1)
+    monkeypatch.setattr(registry, "_probe_result", True)   # pretend the probe saw a GPU: launches reach the (absent) device and fail
+    rng = np.random.default_rng(3)
+    s_, e_ = rng.uniform(-1, 1, (3, 6)).astype(np.float32), rng.uniform(-1, 1, (3, 6)).astype(np.float32)
+    want = pl.batch_joint_trajectory(s_, e_, 1.0, 50, 5)                       # NumPy backend: the CPU route
+    base_cpu = pl.performance_stats["cpu_calls"]
+    with mp.use_backend("hip"):
+        pl._physical_cuda = True
+        with pytest.raises((_hip.HipUnavailableError, _hip.HipError)):
+            pl.batch_joint_trajectory(s_, e_, 1.0, 50, 5)
+        monkeypatch.setenv("MANIPULAPY_HIP_FALLBACK", "1")
+        before = registry.fallback_stats["calls"]
+        with caplog.at_level(logging.WARNING, logger="manipulapy_amd"):
+            got = pl.batch_joint_trajectory(s_, e_, 1.0, 50, 5)
+            tau = pl.inverse_dynamics_trajectory(want["positions"][0], want["velocities"][0], want["accelerations"][0])
+        assert registry.fallback_stats["calls"] == before + 2
+        assert any("falling back to CPU" in r.getMessage() for r in caplog.records)
+        for k in ("positions", "velocities", "accelerations"):
+            np.testing.assert_array_equal(np.asarray(got[k]), np.asarray(want[k]))
+        assert tau.shape == (50, 6) and np.isfinite(tau).all()
+        assert pl.performance_stats["cpu_calls"] == base_cpu + 2 and pl.performance_stats["gpu_calls"] == 0
+
+
 @pytest.mark.parametrize("robot", ROBOTS)
 def test_device_inverse_kinematics_on_host(robot, hostsim, tables):
     """mp_ik_solve (csrc/mp_ik.h) compiled for the host against the reference's own iterative_inverse_kinematics runs
