@@ -699,8 +699,12 @@ class HipContext:
         return out
 
     def fd_trajectory_host(self, model: HipModel, theta0, dtheta0, taumat, g, Ftipmat, dt, intRes, dtype=np.float64,
-                           layout: str = "batch_major", device_layout: str | None = None):
+                           layout: str = "batch_major", device_layout: str | None = None, out=None):
         """B trajectories: theta0/dtheta0 (B,n), taumat (B,N,n), Ftipmat (B,N,6) or None -> 3 x (B,N,n) float32.
+
+        `out`: optional triple of C-contiguous float32 arrays of the result's shape to write into.  With page-locked inputs AND
+        outputs (`pinned_empty`) a batch-major call is cut into chunks of whole trajectories whose upload, roll-out and download
+        overlap (csrc/mp_capi.cpp, fdtraj_host_impl).
 
         layout="time_major": the HOST arrays are (N,B,n) / (N,B,6) and so are the results.  device_layout selects the kernel
         ("batch_major": 4-step LDS tiles on (B,N,n); "time_major": whole lines per step on (N,B,n)); when it differs from the
@@ -720,7 +724,12 @@ class HipContext:
         N = tm.shape[1 - bax]
         Fm = None if Ftipmat is None else _as_c(Ftipmat, dtype, tm.shape[:2] + (6,), "Ftipmat")
         g = _vec_or_none(g, 3, "g")
-        out = [np.zeros(tm.shape[:2] + (n,), dtype=np.float32) for _ in range(3)]
+        if out is None:
+            out = [np.zeros(tm.shape[:2] + (n,), dtype=np.float32) for _ in range(3)]
+        else:
+            out = [_out_or_new(o, tm.shape[:2] + (n,), np.dtype(np.float32)) for o in out]
+            if len(out) != 3:
+                raise ValueError("out must hold three arrays (positions, velocities, accelerations)")
         if layout == "batch_major" and device_layout in (None, "batch_major"):
             if dtype == np.float32:
                 fn, ptr = self.lib.mp_fd_trajectory_host_f32, _fptr

@@ -835,6 +835,38 @@ static int fdtraj_host_impl(const char* fn, mp_ctx* ctx, const mp_model* model, 
   if (int rc = sc.get(ob, &dp)) return rc;
   if (int rc = sc.get(ob, &dv)) return rc;
   if (int rc = sc.get(ob, &da)) return rc;
+  // Page-locked arrays: the batch is cut into chunks of whole trajectories and the three stages overlap - upload of chunk k + 1,
+  // roll-out of chunk k, download of chunk k - 1 (host_pipeline, as for the inverse-dynamics and FK entry points).  A roll-out
+  // moves (n + 6) sizeof(T) bytes up and 12 n down per step, so with full-duplex PCIe the call costs about its larger direction.
+  {
+    const bool pinned = is_pinned_host(theta0) && is_pinned_host(dtheta0) && is_pinned_host(taumat) && (!Ftipmat || is_pinned_host(Ftipmat)) &&
+                        is_pinned_host(pos) && is_pinned_host(vel) && is_pinned_host(acc);
+    const int64_t cb = std::max<int64_t>(64, (host_chunk_rows() / std::max<int64_t>(N, 1)) & ~(int64_t)63);  // trajectories per chunk
+    if (pinned && B >= 2 * cb) {
+      const size_t srow = n * sizeof(T), trow = (size_t)N * n * sizeof(T), frow = (size_t)N * 6 * sizeof(T), orow = (size_t)N * n * sizeof(float);
+      char *c0 = (char*)d0, *c1 = (char*)d1, *ct = (char*)dt_, *cf = (char*)df, *cp = (char*)dp, *cv = (char*)dv, *ca = (char*)da;
+      return host_pipeline(
+          ctx, B, cb,
+          [&](int64_t b0, int64_t nb) -> int {
+            UP(c0 + b0 * srow, (const char*)theta0 + b0 * srow, nb * srow);
+            UP(c1 + b0 * srow, (const char*)dtheta0 + b0 * srow, nb * srow);
+            UP(ct + b0 * trow, (const char*)taumat + b0 * trow, nb * trow);
+            if (Ftipmat) UP(cf + b0 * frow, (const char*)Ftipmat + b0 * frow, nb * frow);
+            return MP_OK;
+          },
+          [&](int64_t b0, int64_t nb) -> int {
+            return fdtraj_impl<T>(fn, ctx, model, (T*)(c0 + b0 * srow), (T*)(c1 + b0 * srow), (T*)(ct + b0 * trow),
+                                  Ftipmat ? (T*)(cf + b0 * frow) : nullptr, nb, N, g, dt, intRes, (float*)(cp + b0 * orow),
+                                  (float*)(cv + b0 * orow), (float*)(ca + b0 * orow));
+          },
+          [&](int64_t b0, int64_t nb) -> int {
+            DOWN((char*)pos + b0 * orow, cp + b0 * orow, nb * orow);
+            DOWN((char*)vel + b0 * orow, cv + b0 * orow, nb * orow);
+            DOWN((char*)acc + b0 * orow, ca + b0 * orow, nb * orow);
+            return MP_OK;
+          });
+    }
+  }
   H2D(d0, theta0, sb);
   H2D(d1, dtheta0, sb);
   H2D(dt_, taumat, tb);

@@ -90,7 +90,7 @@ class KernelRegistry:
 # planning/trajectory_dynamics.py:292-302, cuda_kernels/trajectory_kernels.py:1083-1086).  Here a failing launch RAISES by default -
 # a silent recompute would void every parity and throughput claim - and MANIPULAPY_HIP_FALLBACK=1 opts into the reference's
 # behaviour for drop-in users: the HipError is logged with the reference's wording, the operation's registered cpu_launcher runs
-# (the C ABI's *_cpu launchers or the NumPy ones - never oracle/), and the event is counted (fallback_stats, and the planner's
+# (the C ABI's *_cpu launchers or the NumPy ones - never the test suite's checker), and the event is counted (fallback_stats, and the planner's
 # performance_stats["cpu_calls"]).  bench.py and the GPU test suite never set it.
 FALLBACK_ENV = "MANIPULAPY_HIP_FALLBACK"
 fallback_stats: Dict[str, int] = {"calls": 0}

@@ -939,6 +939,25 @@ def test_host_paths_pinned_pipelined_and_prefaulted(models, tables):
         assert rJ2 is None and rt2 is None
         np.testing.assert_array_equal(oT, Tw)
         del pq64, pqd64, pqdd64, oT, oJ, ot, rT, rJ, rt, rT2
+        # the roll-out through the same pipeline (round 4): page-locked in / out, chunks of whole trajectories, == the pageable call
+        xs, xd, xl = mp.load_robot("xarm6")
+        xm = _hip.HipModel(xd.S_list, xd.Mlist_per_link, xd.Glist, xs.M_list, xl)
+        Bf, Nf = 9000 + 37, 25
+        th0, dth0 = rng.uniform(-0.5, 0.5, (Bf, 6)).astype(np.float32), rng.uniform(-0.2, 0.2, (Bf, 6)).astype(np.float32)
+        tmf = rng.uniform(-1, 1, (Bf, Nf, 6)).astype(np.float32)
+        Fmf = (rng.uniform(-1, 1, (Bf, Nf, 6)) * 0.05).astype(np.float32)
+        G = np.array([0.0, 0.0, -9.81])
+        for F in (Fmf, None):
+            wantf = ctx.fd_trajectory_host(xm, th0, dth0, tmf, G, F, 0.01, 1, dtype=np.float32)
+            pinf = lambda a: (lambda b: (b.__setitem__(slice(None), a), b)[1])(ctx.pinned_empty(a.shape, np.float32))
+            outs = [ctx.pinned_empty((Bf, Nf, 6), np.float32) for _ in range(3)]
+            for o in outs: o[:] = np.nan
+            gotf = ctx.fd_trajectory_host(xm, pinf(th0), pinf(dth0), pinf(tmf), G, None if F is None else pinf(F), 0.01, 1,
+                                          dtype=np.float32, out=outs)
+            for k in range(3):
+                assert gotf[k] is outs[k]
+                np.testing.assert_array_equal(outs[k], wantf[k])
+        del outs, gotf
         del pq, pqd, pqdd
         ctx.destroy()                       # page-locked arrays outlive the context that allocated them
         np.testing.assert_array_equal(pt, want)
@@ -946,6 +965,7 @@ def test_host_paths_pinned_pipelined_and_prefaulted(models, tables):
         del pt, pf
         print("OK")
     """ % ROOT)
+    # (100001 rows per chunk: 7 chunks of the 700001-row ID call, 4000-trajectory chunks of the 9037 x 25 roll-out)
     for env_extra in ({"MANIPULAPY_HIP_HOST_CHUNK_ROWS": "100001"}, {}):
         env = dict(os.environ, **env_extra)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)

@@ -194,7 +194,12 @@ def main():
     tm = (hold[:, None, :] + rng.uniform(-1e-3, 1e-3, (B, N, n))).astype(np.float32)
     Fm = rng.uniform(-0.02, 0.02, (B, N, 6)).astype(np.float32)
     tmT, FmT = np.ascontiguousarray(np.swapaxes(tm, 0, 1)), np.ascontiguousarray(np.swapaxes(Fm, 0, 1))
+    pin32 = lambda a: (lambda b: (b.__setitem__(slice(None), a), b)[1])(ctx.pinned_empty(a.shape, np.float32))
+    p_th0, p_dth0, p_tm, p_Fm = pin32(th0), pin32(dth0), pin32(tm), pin32(Fm)
+    p_out = [ctx.pinned_empty(tm.shape, np.float32) for _ in range(3)]
     for name, fn in (("fd_trajectory_host (B,N,n) arrays, batch-major kernel", lambda: ctx.fd_trajectory_host(xm, th0, dth0, tm, None, Fm, 0.01, 1, dtype=np.float32)),
+                     ("fd_trajectory_host (B,N,n) PAGE-LOCKED arrays in / out: chunked upload / roll-out / download pipeline",
+                      lambda: ctx.fd_trajectory_host(xm, p_th0, p_dth0, p_tm, None, p_Fm, 0.01, 1, dtype=np.float32, out=p_out)),
                      ("fd_trajectory_host (B,N,n) arrays, device transposes + time-major kernel",
                       lambda: ctx.fd_trajectory_host(xm, th0, dth0, tm, None, Fm, 0.01, 1, dtype=np.float32, device_layout="time_major")),
                      ("fd_trajectory_host (N,B,n) arrays, time-major kernel",
