@@ -286,9 +286,20 @@ struct MpRowStage {
       if (j * 64 + lane < NCH) *reinterpret_cast<mp_u4*>(region + (j * 64 + lane) * 16) = buf[j];
   }
   static __device__ __forceinline__ void row_in(const char* __restrict__ region, int lane, T (&v)[N]) {
-    const T* src = reinterpret_cast<const T*>(region + lane * ROWB);
+    if constexpr (sizeof(T) == 8 && ROWB % 16 != 0) {
+      // 8-byte values in rows that are not whole 16-byte chunks (n = 7 float64: 56-byte rows, stride 14 dwords): left alone the
+      // loads are merged into ds_read_b128, which serves 8 lanes per cycle - lanes 0 and 7 then meet in banks 2..3 (14 * 7 = 98 = 2
+      // mod 32): SQ_LDS_BANK_CONFLICT 69.6 M cycles per c3 launch in round 3.  As separate 8-byte reads 16 lanes are served per
+      // cycle and 14 l mod 32 is distinct for l = 0..15: none.  (volatile = do not merge; the address space is spelled out because
+      // a volatile access through a generic pointer is emitted as a FLAT load)
+      const volatile MP_LDS_AS T* src = (const volatile MP_LDS_AS T*)(region + lane * ROWB);
 #pragma unroll
-    for (int j = 0; j < N; ++j) v[j] = src[j];
+      for (int j = 0; j < N; ++j) v[j] = src[j];
+    } else {
+      const T* src = reinterpret_cast<const T*>(region + lane * ROWB);
+#pragma unroll
+      for (int j = 0; j < N; ++j) v[j] = src[j];
+    }
   }
   static __device__ __forceinline__ void row_out(char* __restrict__ region, int lane, const T (&v)[N]) {
     T* dst = reinterpret_cast<T*>(region + lane * ROWB);
@@ -1606,7 +1617,7 @@ __device__ __forceinline__ void mp_body_fd_traj_tm(const MT& M, const MpCall<T>&
 // the time-major device layout (N, B, n), either way.  A block moves a TO x TI tile of rows through LDS: it reads TI * W
 // contiguous dwords per outer index and writes TO * W contiguous dwords per inner index (768 bytes each at n = 6).
 constexpr int MP_TR_TO = 32;
-__device__ __host__ constexpr int mp_tr_ti(int W) { return W <= 8 ? 32 : 16; }  // tile extent along `inner`: <= 33 KB of LDS up to 64-byte rows
+__device__ __host__ constexpr int mp_tr_ti(int W) { return W <= 8 ? 32 : (W <= 16 ? 16 : 8); }  // tile extent along `inner`: <= 33 KB of LDS up to 128-byte rows (16 float64 joints)
 __device__ __forceinline__ void mp_body_transpose_rows(const unsigned* __restrict__ src, unsigned* __restrict__ dst, long outer,
                                                        long inner, int W, long o0, long i0, unsigned* __restrict__ lds, int tid,
                                                        int nthreads) {

@@ -51,6 +51,7 @@ struct mp_ctx {
   std::map<uint64_t, void*> dev_big[2];                // model uid -> MpBigModel<float> [0] / <double> [1] resident on this device
   std::map<uint64_t, MpSpec> specs;                    // model uid -> specialised kernels (mp_model_specialize)
   int compute_units = 0;
+  uint64_t uid = 0;                                    // never reused (graphs identify their context by it, not by address)
   bool capturing = false;                              // between mp_graph_begin and mp_graph_end
   void* queue_counter = nullptr;                       // 8-byte work-queue head of the IK kernel (lazily allocated)
   // The float64 pass over the ill-conditioned rows of a float32 inverse-dynamics launch (attach_hard_list / hard_defer /
@@ -101,7 +102,8 @@ struct mp_graph {
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
   int device = -1;
-  mp_ctx* ctx = nullptr;  // the context it was captured on (only dereferenced while that context is still registered)
+  mp_ctx* ctx = nullptr;  // the context it was captured on (only dereferenced while that context is still registered ...
+  uint64_t ctx_uid = 0;   // ... under the SAME never-reused id: a later context may be allocated at the same address)
 };
 
 namespace {
@@ -907,6 +909,10 @@ int mp_ctx_create(int device_id, mp_ctx** out) {
   REQUIRE(c, "mp_ctx_create: out of host memory");
   c->device = device_id;
   {
+    static std::atomic<uint64_t> next_uid{1};
+    c->uid = next_uid.fetch_add(1);
+  }
+  {
     hipDeviceProp_t p;
     if (hipGetDeviceProperties(&p, device_id) == hipSuccess) c->compute_units = p.multiProcessorCount;
   }
@@ -1212,7 +1218,7 @@ int mp_graph_end(mp_ctx* ctx, mp_graph** out) {
   mp_graph* gr = new (std::nothrow) mp_graph;
   if (!gr) { (void)hipGraphExecDestroy(ex); (void)hipGraphDestroy(g); }
   REQUIRE(gr, "mp_graph_end: out of host memory");
-  gr->graph = g; gr->exec = ex; gr->device = ctx->device; gr->ctx = ctx;
+  gr->graph = g; gr->exec = ex; gr->device = ctx->device; gr->ctx = ctx; gr->ctx_uid = ctx->uid;
   ++ctx->live_graphs;
   *out = gr;
   return MP_OK;
@@ -1242,7 +1248,8 @@ int mp_graph_destroy(mp_graph* graph) {
   (void)hipGraphDestroy(graph->graph);
   {
     std::lock_guard<std::mutex> lk(g_ctxs_mu);
-    if (graph->ctx && g_ctxs.count(graph->ctx)) {  // the context may have been destroyed first (it took the retired objects with it)
+    // the context may have been destroyed first (it took the retired objects with it) - and another one created at its address
+    if (graph->ctx && g_ctxs.count(graph->ctx) && graph->ctx->uid == graph->ctx_uid) {
       std::lock_guard<std::recursive_mutex> cl(graph->ctx->mu);
       if (--graph->ctx->live_graphs <= 0 && !graph->ctx->capturing) {
         graph->ctx->live_graphs = 0;
@@ -1822,8 +1829,8 @@ int mp_transpose_rows(mp_ctx* ctx, const void* d_src, int64_t outer, int64_t inn
   REQUIRE(ctx, "mp_transpose_rows: null context");
   CTX_ENTER(ctx);
   REQUIRE(outer >= 0 && inner >= 0, "mp_transpose_rows: negative extent");
-  REQUIRE(row_bytes > 0 && row_bytes % 4 == 0 && row_bytes <= 64, "mp_transpose_rows: row_bytes %lld must be a multiple of 4 in 4..64",
-          (long long)row_bytes);
+  REQUIRE(row_bytes > 0 && row_bytes % 4 == 0 && row_bytes <= MP_BIG_DOF * 8, "mp_transpose_rows: row_bytes %lld must be a multiple of 4 in 4..%d",
+          (long long)row_bytes, MP_BIG_DOF * 8);
   if (outer == 0 || inner == 0) return MP_OK;
   REQUIRE(d_src && d_dst && d_src != d_dst, "mp_transpose_rows: null or aliased device pointer");
   PROFILE_SCOPE(ctx, "mp_transpose_rows");

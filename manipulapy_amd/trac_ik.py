@@ -46,8 +46,12 @@ def _pose_error(T_current, T_desired):
     if angle < 1e-6:
         w = 0.5 * vee
     elif abs(angle - np.pi) < 1e-6:
-        w = np.zeros(3)
-        w[int(np.argmax(np.diag(E)))] = angle
+        # half turn: the reference's rule (kinematics/trac_ik.py:678-700) - component k = argmax diag is 1, every other component j
+        # is E[k, j] / (1 + E[k, k]) (0 when that denominator degenerates), normalised
+        k = int(np.argmax(np.diag(E)))
+        denom = 1.0 + E[k, k]
+        axis = np.array([1.0 if j == k else (E[k, j] / denom if abs(denom) > 1e-6 else 0.0) for j in range(3)])
+        w = angle * axis / (np.linalg.norm(axis) + 1e-10)
     else:
         w = angle * vee / (2.0 * np.sin(angle) + 1e-10)
     return np.concatenate([Tc[:3, :3] @ w, dp]), angle, float(np.linalg.norm(dp))
@@ -133,7 +137,10 @@ class TracIKSolver:
             _, rot, tr = self.error_func(np.asarray(self.fk_func(th)), T_desired)
             return float(rot) ** 2 + float(tr) ** 2
 
-        def grad(th):   # d/dtheta of |V|^2 with dV/dtheta = -J (space Jacobian, [omega; v] order)
+        # d/dtheta of |V|^2 with dV/dtheta = -J (space Jacobian, [omega; v] order).  DELIBERATE difference: the reference hands SLSQP
+        # +2 J^T V (kinematics/trac_ik.py:570-577) - the gradient with the sign flipped, an ascent direction its line search has to
+        # reject; only reached when no damped-least-squares row converged, and never changes what a converged solve returns
+        def grad(th):
             V, _, _ = self.error_func(np.asarray(self.fk_func(th)), T_desired)
             return -2.0 * np.asarray(self.jacobian_func(th), dtype=np.float64).T @ np.asarray(V, dtype=np.float64)
 
