@@ -456,7 +456,12 @@ __device__ __forceinline__ void mp_wave_store_flat(T* __restrict__ gbase, long r
   using IO = RunIO<T, COUNT>;
   using V = typename IO::V;
   constexpr int W = IO::W, K = IO::K, CH = COUNT / K, ROWS = 16;
-  constexpr int PITCH = ((CH * W + 127) / 128) * 128 + W;
+  // Row pitch in the staging slice.  In 16-byte chunks: the 8 lanes a ds_write_b128 serves per cycle (one row each) hit distinct
+  // bank groups iff the pitch is ODD, and the 8 consecutive flat chunks a ds_read_b128 serves per cycle stay distinct across a
+  // row boundary iff the padding is a multiple of 8.  An odd row (the 6 x 7 float64 Jacobian: 21 chunks) needs no padding at all;
+  // round 1's rule (next multiple of 128 bytes + one chunk: 25 chunks, padding 4) was conflict-free on the writes and collided on
+  // every read group that crossed a row end: SQ_LDS_BANK_CONFLICT 69.6 M cycles per c3 launch, 14 % of the LDS cycles.
+  constexpr int PITCH = (W == 16 && CH % 2 == 1) ? CH * W : ((CH * W + 127) / 128) * 128 + W;
   static_assert(ROWS * PITCH <= MP_WAVE_LDS_BYTES, "wave staging slice too small");
   constexpr int TOTAL = ROWS * CH, NJ = (TOTAL + 63) / 64;
   V* gout = reinterpret_cast<V*>(gbase + row0 * COUNT);
