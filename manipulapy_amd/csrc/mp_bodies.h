@@ -461,7 +461,11 @@ __device__ __forceinline__ void mp_wave_store_flat(T* __restrict__ gbase, long r
   // row boundary iff the padding is a multiple of 8.  An odd row (the 6 x 7 float64 Jacobian: 21 chunks) needs no padding at all;
   // round 1's rule (next multiple of 128 bytes + one chunk: 25 chunks, padding 4) was conflict-free on the writes and collided on
   // every read group that crossed a row end: SQ_LDS_BANK_CONFLICT 69.6 M cycles per c3 launch, 14 % of the LDS cycles.
+#if defined(MP_WSF_PAD_R01)   // experiment switch: round 1's padding, for the A/B (profiles/r04_c3_lds_ab.txt)
+  constexpr int PITCH = ((CH * W + 127) / 128) * 128 + W;
+#else
   constexpr int PITCH = (W == 16 && CH % 2 == 1) ? CH * W : ((CH * W + 127) / 128) * 128 + W;
+#endif
   static_assert(ROWS * PITCH <= MP_WAVE_LDS_BYTES, "wave staging slice too small");
   constexpr int TOTAL = ROWS * CH, NJ = (TOTAL + 63) / 64;
   V* gout = reinterpret_cast<V*>(gbase + row0 * COUNT);
