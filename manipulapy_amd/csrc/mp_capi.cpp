@@ -1656,7 +1656,17 @@ int mp_traj_id_fused_f32(mp_ctx* ctx, const mp_model* model, const float* d_star
     void* hargs[] = {&c, &d_start, &d_end, &ntu, &tab, &d_tau, &rows_u};
     return launch_spec(ctx, sp->traj_id_hard[ftip ? 1 : 0], (long)hard_pass_blocks(rows_l) * 64, hargs, 64);
   }
-  HIP_TRY(mpk_traj_id_tab(ctx->compute, model->f, c, ftip, d_start, d_end, (long)B, (long)N, ctx->time_tab, d_tau));
+  {
+    // generic kernels: the same hand-over (the float64 model and the float32 limits come from the device copy)
+    const long rows_l = (long)B * (long)N;
+    mp_ctx::HardSlot* hs = nullptr;
+    const MpModel<float>* dm = nullptr;
+    if (c.cold_model && device_model(ctx, model, &dm) == MP_OK) hs = attach_hard_list(ctx, rows_l, &c);
+    HIP_TRY(mpk_traj_id_tab(ctx->compute, model->f, c, ftip, d_start, d_end, (long)B, (long)N, ctx->time_tab, d_tau));
+    if (hs)
+      HIP_TRY(mpk_traj_id_hard(ctx->compute, dm, model->d.n, c, ftip, d_start, d_end, (unsigned)N, ctx->time_tab, d_tau, (unsigned)rows_l,
+                               hard_pass_blocks(rows_l)));
+  }
   return MP_OK;
 }
 

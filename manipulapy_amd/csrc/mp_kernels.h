@@ -93,6 +93,9 @@ hipError_t mpk_dyn_ik(hipStream_t s, const MpBigModel<double>* d_model, const Mp
 bool mpk_packed_f32();  // false under MANIPULAPY_HIP_F32=scalar
 hipError_t mpk_time_table(hipStream_t s, double* tab, long Nt, double Tf, int method);
 unsigned mpk_traj_blocks_per_trajectory(long Nt);
+// the float64 pass over the rows the fused generic kernel handed over (inputs regenerated)
+hipError_t mpk_traj_id_hard(hipStream_t s, const MpModel<float>* d_model, int n, const MpCall<float>& C, bool ftip, const float* start,
+                            const float* end, unsigned Nt, const double* tab, float* tau, unsigned rows, unsigned blocks);
 hipError_t mpk_traj_id_tab(hipStream_t s, const MpModel<float>& M, const MpCall<float>& C, bool ftip, const float* start,
                            const float* end, long B, long Nt, const double* tab, float* tau);
 

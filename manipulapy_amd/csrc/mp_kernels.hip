@@ -43,8 +43,10 @@ __global__ __launch_bounds__(kBlock) void k_id(const MpModel<T> M, const MpCall<
 // struct: the joints' constants are then loaded joint by joint where the recursion uses them (mp_joint_of, mp_core.h), not all
 // 185 dwords at the top of the kernel - which overflows the SGPR file into VGPR lanes (60 v_writelane / v_readlane of 1203
 // instructions at n = 6) and keeps the wave count down.
+// (five waves per SIMD asked for without a tip wrench, four with one: the float64 re-evaluation loop behind the float32 pass raised
+// the unconstrained allocation from 85 to 106 VGPRs; held to 96 / 128 neither pass touches scratch)
 template <typename T, int N, bool HAS_FTIP>
-__global__ __launch_bounds__(kBlock) void k_id_dm(const MpModel<T>* __restrict__ Mdev, const MpCall<T> C, const T* __restrict__ q,
+__global__ __launch_bounds__(kBlock, HAS_FTIP ? 4 : 5) void k_id_dm(const MpModel<T>* __restrict__ Mdev, const MpCall<T> C, const T* __restrict__ q,
                                                   const T* __restrict__ qd, const T* __restrict__ qdd, T* __restrict__ tau, long rows) {
   MP_COLD_BUFFER(N, kBlock, sizeof(T));
   const long r = (long)blockIdx.x * kBlock + threadIdx.x;
@@ -61,6 +63,31 @@ __global__ __launch_bounds__(64) void k_id_hard(const MpModel<float>* __restrict
   mp_body_id_hard<N, HAS_FTIP>(*(MpModelConstD*)C.cold_model, *(MpModelConstF*)Mdev, C,
                                [&](long r, float (&x)[N], float (&y)[N], float (&z)[N]) {
                                  RunIO<float, N>::load(q, r, x); RunIO<float, N>::load(qd, r, y); RunIO<float, N>::load(qdd, r, z);
+                               }, tau, rows);
+#endif
+}
+
+// the same pass for rows the fused generic kernel handed over: a row's inputs are generated again from start / end / the time table
+template <int N, bool HAS_FTIP>
+__global__ __launch_bounds__(64) void k_traj_id_hard(const MpModel<float>* __restrict__ Mdev, const MpCall<float> C, const float* __restrict__ start,
+                                                     const float* __restrict__ end, unsigned Nt, const double* __restrict__ tab,
+                                                     float* __restrict__ tau, unsigned rows) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  MpModelConstF& M = *(MpModelConstF*)Mdev;
+  mp_body_id_hard<N, HAS_FTIP>(*(MpModelConstD*)C.cold_model, M, C,
+                               [&](long r, float (&x)[N], float (&y)[N], float (&z)[N]) {
+                                 const unsigned b = (unsigned)r / Nt, t = (unsigned)r - b * Nt;
+                                 float a[N], e[N];
+                                 RunIO<float, N>::load(start, (long)b, a);
+                                 RunIO<float, N>::load(end, (long)b, e);
+                                 const double u0 = tab[3 * t], u1 = tab[3 * t + 1], u2 = tab[3 * t + 2];
+#pragma unroll
+                                 for (int j = 0; j < N; ++j) {
+                                   const double d = (double)(e[j] - a[j]);
+                                   x[j] = mp_clip((float)(u0 * d + (double)a[j]), M.qmin[j], M.qmax[j]);
+                                   y[j] = (float)(u1 * d);
+                                   z[j] = (float)(u2 * d);
+                                 }
                                }, tau, rows);
 #endif
 }
@@ -555,6 +582,16 @@ hipError_t mpk_traj_id_tab(hipStream_t s, const MpModel<float>& M, const MpCall<
   MP_DISPATCH_N(M.n, {
     if (ftip) hipLaunchKernelGGL((k_traj_id_pk_tab<N, true>), dim3(grid), dim3(kBlock), 0, s, M, C, start, end, Nt, bpt, tab, tau);
     else hipLaunchKernelGGL((k_traj_id_pk_tab<N, false>), dim3(grid), dim3(kBlock), 0, s, M, C, start, end, Nt, bpt, tab, tau);
+  })
+  return hipGetLastError();
+}
+
+hipError_t mpk_traj_id_hard(hipStream_t s, const MpModel<float>* d_model, int n, const MpCall<float>& C, bool ftip, const float* start,
+                            const float* end, unsigned Nt, const double* tab, float* tau, unsigned rows, unsigned blocks) {
+  if (blocks == 0 || !C.hard_rows || !C.cold_model) return hipSuccess;
+  MP_DISPATCH_N(n, {
+    if (ftip) hipLaunchKernelGGL((k_traj_id_hard<N, true>), dim3(blocks), dim3(64), 0, s, d_model, C, start, end, Nt, tab, tau, rows);
+    else hipLaunchKernelGGL((k_traj_id_hard<N, false>), dim3(blocks), dim3(64), 0, s, d_model, C, start, end, Nt, tab, tau, rows);
   })
   return hipGetLastError();
 }
