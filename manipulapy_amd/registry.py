@@ -262,7 +262,7 @@ def _no_cpu(name: str) -> Callable[..., Any]:
 
 # CPU launchers of the dynamics / kinematics operations: the C ABI's *_cpu twins (csrc/mp_cpu.cpp - the same per-row
 # templates the kernels instantiate, on host threads).  The registry picks them by the reference's rule (NumPy backend
-# active, registry.py:85-89); they are never a fallback of a failing GPU launch.
+# active, registry.py:85-89); they are not a fallback of a failing GPU launch unless MANIPULAPY_HIP_FALLBACK=1 asks for the reference's behaviour.
 def _launch_id_cpu(model, q, qd, qdd, g=None, Ftip=None, dtype=np.float32):
     return _hip.cpu_id_trajectory(model, q, qd, qdd, g, Ftip, dtype=dtype)
 
