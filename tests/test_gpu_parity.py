@@ -2226,3 +2226,82 @@ def test_whole_line_kernel_small_joint_counts(n):
                 np.testing.assert_allclose(got, want, rtol=1e-4, atol=5e-6 * float(np.abs(want).max()))
     finally:
         ctx.destroy()
+
+
+@pytest.mark.parametrize("specialise", [False, True])
+def test_float64_pass_is_parked_and_run_before_anything_can_see_the_difference(specialise, tables):
+    """Round 4: a device-pointer float32 inverse-dynamics launch leaves its ill-conditioned rows to a float64 pass that the
+    context parks (csrc/mp_capi.cpp, hard_defer / hard_flush) and runs - several launches' worth in one kernel - before the next entry
+    point that could read the torques.  Whatever is launched in between, a download must return exactly what the host-buffer entry
+    point returns (which flushes at once): launches on other buffers (parked side by side, more than four of them), a launch that
+    overwrites a parked launch's INPUT (the pass re-reads its rows: it must run first), a launch onto a parked launch's OUTPUT, a
+    captured graph replay (re-evaluates in place) and an empty launch."""
+    from manipulapy_amd import _hip
+    from oracle import c_oracle
+
+    tab = tables["ur5"]
+    lim = tab.joint_limits
+    rng = np.random.default_rng(77)
+    ctx = _hip.HipContext(0)
+    try:
+        m = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee, lim)
+        if specialise:
+            ctx.specialize(m)
+        sets = []
+        for k in range(6):   # six independent (q, qd, qdd) histories of fast trajectories: ~1 % of their rows are ill-conditioned
+            s_ = rng.uniform(lim[:, 0], lim[:, 1], (40, 6)).astype(np.float32)
+            e_ = rng.uniform(lim[:, 0], lim[:, 1], (40, 6)).astype(np.float32)
+            o = ref.batch_joint_trajectory(lim, s_, e_, 2.0, 1000 + k, 5)     # row counts that are not multiples of 64: the tail kernel joins in
+            q, qd, qdd = (np.ascontiguousarray(o[key].reshape(-1, 6), dtype=np.float32) for key in ("positions", "velocities", "accelerations"))
+            want = ctx.id_trajectory_host(m, q, qd, qdd, dtype=np.float32)
+            assert _hip.cpu_id_row_precision(m, q, qd, qdd).sum() > 50
+            sets.append({"q": q, "qd": qd, "qdd": qdd, "want": want, "rows": len(q),
+                         "d": [ctx.to_device(a) for a in (q, qd, qdd)], "d_tau": ctx.alloc(q.nbytes)})
+        get = lambda st: st["d_tau"].download(st["q"].shape, np.float32)
+        run = lambda st: ctx.id_trajectory(m, *st["d"], st["rows"], st["d_tau"], dtype=np.float32)
+        # (1) six launches back to back on disjoint buffers (more than the context parks), then the downloads
+        for st in sets:
+            ctx.memset(st["d_tau"], 0, st["q"].nbytes)
+        for st in sets:
+            run(st)
+        for st in sets:
+            np.testing.assert_array_equal(get(st), st["want"])
+        # every row inside the suite's bound against the oracle, the float64-evaluated ones with room to spare
+        w64 = c_oracle.inverse_dynamics_rows(tab, *(sets[0][k].astype(np.float64) for k in ("q", "qd", "qdd")))[0]
+        assert_f32(sets[0]["want"], w64)
+        # (2) a launch parked, then its INPUT buffer overwritten through the API and another launch: each result is its own inputs'
+        a, b = sets[0], sets[1]
+        run(a)
+        n = min(a["rows"], b["rows"])
+        for d, key in zip(a["d"], ("q", "qd", "qdd")):
+            d.upload(np.ascontiguousarray(np.concatenate([b[key][:n], a[key][n:]])))
+        mixed = ctx.id_trajectory_host(m, *(np.concatenate([b[k][:n], a[k][n:]]) for k in ("q", "qd", "qdd")), dtype=np.float32)
+        np.testing.assert_array_equal(get(a), a["want"])          # the parked pass ran on the OLD rows before the upload replaced them
+        run(a)
+        np.testing.assert_array_equal(get(a), mixed)
+        for d, key in zip(a["d"], ("q", "qd", "qdd")):
+            d.upload(a[key])
+        # (3) two launches onto the SAME output buffer from different inputs: the second one's result stands
+        c, d_ = sets[2], sets[3]
+        n = min(c["rows"], d_["rows"])
+        ctx.id_trajectory(m, *c["d"], n, c["d_tau"], dtype=np.float32)
+        ctx.id_trajectory(m, *d_["d"], n, c["d_tau"], dtype=np.float32)
+        np.testing.assert_array_equal(get(c)[:n], d_["want"][:n])
+        # (4) a captured replay re-evaluates its rows in place: same bound, and the float32 rows bit-equal
+        e = sets[4]
+        run(e); ctx.synchronize()
+        with ctx.capture() as cap:
+            run(e)
+        ctx.memset(e["d_tau"], 0, e["q"].nbytes)
+        cap.graph.launch()
+        ctx.synchronize()
+        got = get(e)
+        hard = _hip.cpu_id_row_precision(m, e["q"], e["qd"], e["qdd"])
+        np.testing.assert_array_equal(got[~hard], e["want"][~hard])
+        np.testing.assert_allclose(got[hard], e["want"][hard], rtol=2e-6, atol=2e-6 * float(np.abs(e["want"]).max()))
+        cap.graph.destroy()
+        # (5) nothing parked, nothing to run: an empty launch and a synchronise are fine
+        ctx.id_trajectory(m, *sets[5]["d"], 0, sets[5]["d_tau"], dtype=np.float32)
+        ctx.synchronize()
+    finally:
+        ctx.destroy()
