@@ -688,7 +688,8 @@ def bench_strong(name, args, info, hg, ctx, props):
             gather["error"] = str(exc)[:300]
 
     hung = False
-    if (world > 1 or os.environ.get("MANIPULAPY_BENCH_FORCE_GATHER") == "1") and not args.no_gather:
+    ran_gather = (world > 1 or os.environ.get("MANIPULAPY_BENCH_FORCE_GATHER") == "1") and not args.no_gather
+    if ran_gather:
         import threading
 
         th = threading.Thread(target=gather_phase, daemon=True)
@@ -702,7 +703,10 @@ def bench_strong(name, args, info, hg, ctx, props):
         for b in bufs:
             b.free()
         ctx.trim_pool()
-    entry["verified"] = bool(gather.get("verified") is True and (gather.get("overlapped") or {}).get("verified", True) is True)
+    if ran_gather:
+        entry["verified"] = bool(gather.get("verified") is True and (gather.get("overlapped") or {}).get("verified", True) is True)
+    else:
+        entry["allgather"] = None   # --no-gather: compute-only figures, nothing to verify
     return entry, hung
 
 
@@ -870,7 +874,7 @@ def main():
     if hung:
         os._exit(3)  # a stuck collective cannot be cancelled from Python: leave, non-zero, without another context call
     ctx.destroy()
-    unverified = [k for k, v in (result.get("configs") or {}).items() if k.endswith("_strong") and "allgather" in v and not v.get("verified")]
+    unverified = [k for k, v in (result.get("configs") or {}).items() if k.endswith("_strong") and v.get("allgather") is not None and not v.get("verified")]
     if world > 1 and info.rank == 0 and ((result.get("allgather") is not None and result.get("verified") is False) or unverified):
         raise SystemExit(5)   # a reassembled history did not match the recomputation: not a result
     if failed:
