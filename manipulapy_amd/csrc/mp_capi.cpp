@@ -376,7 +376,10 @@ mp_ctx::HardSlot* attach_hard_list(mp_ctx* ctx, long rows, MpCall<float>* c) {
   c->hard_row_base = 0;
   return hs;
 }
-unsigned hard_pass_blocks(long rows) { return (unsigned)std::min<long>((rows / 8 + 63) / 64 + 1, 1024); }
+unsigned hard_pass_blocks(long rows) {
+  static const long cap = [] { const char* e = getenv("MANIPULAPY_HIP_HARD_BLOCKS"); return e ? std::max(1L, atol(e)) : 1024L; }();  // experiment switch
+  return (unsigned)std::min<long>((rows / 8 + 63) / 64 + 1, cap);
+}
 // park the pass of the launch just enqueued
 void hard_defer(mp_ctx* ctx, mp_ctx::HardSlot* hs, hipFunction_t fn, std::function<int()> generic, const MpCall<float>& C,
                 const float* q, const float* qd, const float* qdd, float* tau, long rows, int n) {
