@@ -138,6 +138,20 @@ __device__ __forceinline__ void traj_row(const MT& M, const float* __restrict__ 
 }
 
 
+// Torque limits.  A robot-specialised program of a model WITHOUT torque limits (the planner's default: the reference clips only when
+// it is given limits, planning/trajectory_dynamics.py:280-282) is built with MP_TAU_UNLIMITED: the clip against +-3e38 - which the
+// compiler may not fold, finite-math or not - is then not emitted (n v_med3_f32 per row: 1 % of the c2 kernel, whose time follows
+// its instruction count).
+template <typename T, typename S>
+__device__ __forceinline__ T mp_clip_tau(T v, S lo, S hi) {
+#if defined(MP_TAU_UNLIMITED)
+  (void)lo; (void)hi;
+  return v;
+#else
+  return mp_clip(v, lo, hi);
+#endif
+}
+
 // ------------------------------------------------------------ the float64 re-evaluation, wave by wave
 // Rows whose float32 result is ill-conditioned (`hard`, mp_rnea_f32) are evaluated again by mp_rnea_cold with the per-joint state
 // in LDS: `lds` is MpColdLds<N, G>::BYTES bytes that belong to this wave alone, G lanes work at a time (slot = the lane's rank among
@@ -227,7 +241,7 @@ __device__ __forceinline__ void mp_body_id_hard(const MC& Mc, const MF& M, const
     mp_rnea<double, N, HAS_FTIP>(Mc, Cd, js, b, c, t);
     float out[N];
 #pragma unroll
-    for (int i = 0; i < N; ++i) out[i] = mp_clip((float)t[i], M.taumin[i], M.taumax[i]);
+    for (int i = 0; i < N; ++i) out[i] = mp_clip_tau((float)t[i], M.taumin[i], M.taumax[i]);
     RunIO<float, N>::store(tau, r, out);
   }
   // the OTHER counter of the list (its next user's): zeroed here, by the pass that runs between that counter's previous reader
@@ -258,7 +272,7 @@ __device__ __forceinline__ void mp_body_id(const MT& M, const MpCall<T>& C, cons
     mp_rnea<T, N, HAS_FTIP>(M, C, js, b, c, t);
   }
 #pragma unroll
-  for (int j = 0; j < N; ++j) t[j] = mp_clip(t[j], M.taumin[j], M.taumax[j]);
+  for (int j = 0; j < N; ++j) t[j] = mp_clip_tau(t[j], M.taumin[j], M.taumax[j]);
   mp_poison_if(bad.any(), t);
   RunIO<T, N>::store(tau, r, t);
 }
@@ -346,7 +360,7 @@ __device__ __forceinline__ void mp_body_id_co(const MT& M, const MpCall<T>& C, c
   if constexpr (MpIsF32<T>::value) hard = mp_rnea_f32<N, HAS_FTIP>(M, C, js, b, c, t) && !poison;
   else mp_rnea<T, N, HAS_FTIP>(M, C, js, b, c, t);
 #pragma unroll
-  for (int j = 0; j < N; ++j) t[j] = mp_clip(t[j], M.taumin[j], M.taumax[j]);
+  for (int j = 0; j < N; ++j) t[j] = mp_clip_tau(t[j], M.taumin[j], M.taumax[j]);
   mp_poison_if(poison, t);
   ST::sync();  // every lane has read its rows: the first region is free
   ST::row_out(lds, lane, t);
@@ -370,7 +384,7 @@ __device__ __forceinline__ void mp_body_id_co(const MT& M, const MpCall<T>& C, c
       }, t);
       if (here && hard) {
 #pragma unroll
-        for (int j = 0; j < N; ++j) t[j] = mp_clip(t[j], M.taumin[j], M.taumax[j]);
+        for (int j = 0; j < N; ++j) t[j] = mp_clip_tau(t[j], M.taumin[j], M.taumax[j]);
         RunIO<float, N>::store(tau, rr, t);
       }
     }
@@ -622,7 +636,7 @@ __device__ __forceinline__ void mp_body_fk_jac_id(const MT& M, const MpCall<T>& 
     if constexpr (MpIsF32<T>::value) hard = mp_rnea_f32<N, HAS_FTIP>(M, C, js, b, c, t) && !bad.any() && valid;
     else mp_rnea<T, N, HAS_FTIP>(M, C, js, b, c, t);
 #pragma unroll
-    for (int j = 0; j < N; ++j) t[j] = mp_clip(t[j], M.taumin[j], M.taumax[j]);
+    for (int j = 0; j < N; ++j) t[j] = mp_clip_tau(t[j], M.taumin[j], M.taumax[j]);
     mp_poison_if(bad.any(), t);
     if (full) {
       ST::row_out(lds, lane, t);
@@ -641,7 +655,7 @@ __device__ __forceinline__ void mp_body_fk_jac_id(const MT& M, const MpCall<T>& 
         }, t);
         if (here && hard) {
 #pragma unroll
-          for (int j = 0; j < N; ++j) t[j] = mp_clip(t[j], M.taumin[j], M.taumax[j]);
+          for (int j = 0; j < N; ++j) t[j] = mp_clip_tau(t[j], M.taumin[j], M.taumax[j]);
           RunIO<float, N>::store(tau, r, t);
         }
       }
@@ -717,7 +731,7 @@ __device__ __forceinline__ void mp_body_id_pk(const MT& M, const MpCall<float>& 
   bad.add(a); bad.add(b); bad.add(c);
   mp_rnea_pk<N, HAS_FTIP>(M, C, js, a, b, c, t, bad, cold);
 #pragma unroll
-  for (int j = 0; j < N; ++j) t[j] = mp_clip(t[j], M.taumin[j], M.taumax[j]);
+  for (int j = 0; j < N; ++j) t[j] = mp_clip_tau(t[j], M.taumin[j], M.taumax[j]);
   store_pair<N>(tau, p, t, bad);
 }
 
@@ -746,7 +760,7 @@ __device__ __forceinline__ void mp_body_id_pk_split(const MT& M, const MpCall<fl
   float lo[N], hi[N];
 #pragma unroll
   for (int j = 0; j < N; ++j) {
-    const mp_f2 c = mp_clip(t[j], M.taumin[j], M.taumax[j]);
+    const mp_f2 c = mp_clip_tau(t[j], M.taumin[j], M.taumax[j]);
     lo[j] = c.x; hi[j] = c.y;
   }
   mp_poison_if(bad.x.any(), lo);
@@ -776,7 +790,7 @@ __device__ __forceinline__ void mp_body_traj_id_pk(const MT& M, const MpCall<flo
   bad.add(qq); bad.add(qd); bad.add(qdd);
   mp_rnea_pk<N, HAS_FTIP>(M, C, js, qq, qd, qdd, tq, bad, cold);
 #pragma unroll
-  for (int j = 0; j < N; ++j) tq[j] = mp_clip(tq[j], M.taumin[j], M.taumax[j]);
+  for (int j = 0; j < N; ++j) tq[j] = mp_clip_tau(tq[j], M.taumin[j], M.taumax[j]);
   store_pair<N>(tau, p, tq, bad);
 }
 
@@ -812,7 +826,7 @@ __device__ __forceinline__ void mp_body_traj_id_pk_tab(const MT& M, const MpCall
   float lo[N], hi[N];
 #pragma unroll
   for (int j = 0; j < N; ++j) {
-    const mp_f2 c = mp_clip(tq[j], M.taumin[j], M.taumax[j]);
+    const mp_f2 c = mp_clip_tau(tq[j], M.taumin[j], M.taumax[j]);
     lo[j] = c.x; hi[j] = c.y;
   }
   mp_poison_if(bad.x.any(), lo);
@@ -849,7 +863,7 @@ __device__ __forceinline__ void mp_body_traj_id_tab(const MT& M, const MpCall<fl
     for (int j = 0; j < N; ++j) { x[j] = qq[j]; y[j] = qd[j]; z[j] = qdd[j]; }
   }, tq);
 #pragma unroll
-  for (int j = 0; j < N; ++j) tq[j] = mp_clip(tq[j], M.taumin[j], M.taumax[j]);
+  for (int j = 0; j < N; ++j) tq[j] = mp_clip_tau(tq[j], M.taumin[j], M.taumax[j]);
   mp_poison_if(bad.any(), tq);
   RunIO<float, N>::store_wo(tau, b * Nt + t, tq);
 }
@@ -893,7 +907,7 @@ __device__ __forceinline__ void mp_body_traj_id_co(const MT& M, const MpCall<flo
   const bool poison = bad.any();
   const bool hard = mp_rnea_f32<N, HAS_FTIP>(M, C, js, qd, qdd, tq) && !poison && valid;
 #pragma unroll
-  for (int j = 0; j < N; ++j) tq[j] = mp_clip(tq[j], M.taumin[j], M.taumax[j]);
+  for (int j = 0; j < N; ++j) tq[j] = mp_clip_tau(tq[j], M.taumin[j], M.taumax[j]);
   mp_poison_if(poison, tq);
   if (full) {
     ST::row_out(lds, lane, tq);
@@ -922,7 +936,7 @@ __device__ __forceinline__ void mp_body_traj_id_co(const MT& M, const MpCall<flo
     }, tq);
     if (here && hard) {
 #pragma unroll
-      for (int j = 0; j < N; ++j) tq[j] = mp_clip(tq[j], M.taumin[j], M.taumax[j]);
+      for (int j = 0; j < N; ++j) tq[j] = mp_clip_tau(tq[j], M.taumin[j], M.taumax[j]);
       RunIO<float, N>::store(tau, (long)row0 + lane, tq);
     }
   }
