@@ -38,7 +38,7 @@ extern "C" {
 #define MP_ERR_COMM 5         /* RCCL failure */
 
 #define MP_MAX_DOF 8      /* joints of the fully unrolled / run-time-specialisable kernels */
-#define MP_BIG_DOF 16     /* joints mp_model_create accepts: 9..16 run looped run-time-n kernels (csrc/mp_dyn.h; every operation
+#define MP_BIG_DOF 32     /* joints mp_model_create accepts: 9..32 run looped run-time-n kernels (csrc/mp_dyn.h; every operation
                              incl. inverse kinematics; run-time specialisation is MP_ERR_UNSUPPORTED) */
 #define MP_UNIQUE_ID_BYTES 128
 

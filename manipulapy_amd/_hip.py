@@ -19,7 +19,7 @@ DEFAULT_LIB = os.path.join(_PKG, "libmanipula_hip.so")
 
 MP_OK = 0
 MP_MAX_DOF = 8    # fully unrolled / specialisable kernels
-MP_BIG_DOF = 16   # run-time-n kernels (csrc/mp_dyn.h)
+MP_BIG_DOF = 32   # run-time-n kernels (csrc/mp_dyn.h)
 UNIQUE_ID_BYTES = 128
 
 

@@ -1640,7 +1640,7 @@ __device__ __forceinline__ void mp_body_fd_traj_tm(const MT& M, const MpCall<T>&
 // the time-major device layout (N, B, n), either way.  A block moves a TO x TI tile of rows through LDS: it reads TI * W
 // contiguous dwords per outer index and writes TO * W contiguous dwords per inner index (768 bytes each at n = 6).
 constexpr int MP_TR_TO = 32;
-__device__ __host__ constexpr int mp_tr_ti(int W) { return W <= 8 ? 32 : (W <= 16 ? 16 : 8); }  // tile extent along `inner`: <= 33 KB of LDS up to 128-byte rows (16 float64 joints)
+__device__ __host__ constexpr int mp_tr_ti(int W) { return W <= 8 ? 32 : (W <= 16 ? 16 : (W <= 32 ? 8 : 4)); }  // tile extent along `inner`: <= 33 KB of LDS up to 256-byte rows (32 float64 joints)
 __device__ __forceinline__ void mp_body_transpose_rows(const unsigned* __restrict__ src, unsigned* __restrict__ dst, long outer,
                                                        long inner, int W, long o0, long i0, unsigned* __restrict__ lds, int tid,
                                                        int nthreads) {

@@ -444,7 +444,7 @@ template <> void make_call_ctx<double>(mp_ctx*, const mp_model* model, const dou
   make_call<double>(model, g, Ftip, c);
 }
 
-// MpBigModel<T> of a 9..16-joint model resident in device memory (read by the looped k_dyn_* kernels through scalar loads)
+// MpBigModel<T> of a 9..32-joint model resident in device memory (read by the looped k_dyn_* kernels through scalar loads)
 template <typename T> const MpBigModel<T>& pick_big(const mp_model* m);
 template <> const MpBigModel<float>& pick_big<float>(const mp_model* m) { return m->bf; }
 template <> const MpBigModel<double>& pick_big<double>(const mp_model* m) { return m->bd; }
@@ -483,7 +483,7 @@ int launch_big_fk_jac_id(mp_ctx* ctx, const mp_model* model, const MpCall<T>& c,
                          T* Jout, T* tau, long rows) {
   const MpBigModel<T>* dm = nullptr;
   if (int rc = device_big_model<T>(ctx, model, &dm)) return rc;
-  HIP_TRY(mpk_dyn_fk_jac_id<T>(ctx->compute, dm, c, ftip, q, qd, qdd, Tout, Jout, tau, rows));
+  HIP_TRY(mpk_dyn_fk_jac_id<T>(ctx->compute, model->d.n, dm, c, ftip, q, qd, qdd, Tout, Jout, tau, rows));
   return MP_OK;
 }
 
@@ -733,7 +733,7 @@ static int mm_impl(const char* fn, mp_ctx* ctx, const mp_model* model, const T* 
   if (model->big) {
     const MpBigModel<T>* dm = nullptr;
     if (int rc = device_big_model<T>(ctx, model, &dm)) return rc;
-    HIP_TRY(mpk_dyn_mass_matrix<T>(ctx->compute, dm, d_q, d_M, (long)rows));
+    HIP_TRY(mpk_dyn_mass_matrix<T>(ctx->compute, model->d.n, dm, d_q, d_M, (long)rows));
     return MP_OK;
   }
   HIP_TRY(mpk_mass_matrix<T>(ctx->compute, pick<T>(model), d_q, d_M, (long)rows));
@@ -756,7 +756,7 @@ static int fdyn_impl(const char* fn, mp_ctx* ctx, const mp_model* model, const T
   if (model->big) {
     const MpBigModel<T>* dm = nullptr;
     if (int rc = device_big_model<T>(ctx, model, &dm)) return rc;
-    HIP_TRY(mpk_dyn_forward_dynamics<T>(ctx->compute, dm, c, ftip, d_q, d_qd, d_tau, d_qdd, (long)rows));
+    HIP_TRY(mpk_dyn_forward_dynamics<T>(ctx->compute, model->d.n, dm, c, ftip, d_q, d_qd, d_tau, d_qdd, (long)rows));
     return MP_OK;
   }
   if (const MpSpec* sp = find_spec(ctx, model)) {
@@ -803,7 +803,7 @@ static int fdtraj_impl(const char* fn, mp_ctx* ctx, const mp_model* model, const
   if (model->big) {
     const MpBigModel<T>* dm = nullptr;
     if (int rc = device_big_model<T>(ctx, model, &dm)) return rc;
-    HIP_TRY(mpk_dyn_fd_traj<T>(ctx->compute, dm, c, d_theta0, d_dtheta0, d_taumat, d_Ftipmat, (long)B, (long)N, h, intRes, d_pos, d_vel,
+    HIP_TRY(mpk_dyn_fd_traj<T>(ctx->compute, model->d.n, dm, c, d_theta0, d_dtheta0, d_taumat, d_Ftipmat, (long)B, (long)N, h, intRes, d_pos, d_vel,
                                d_acc, time_major));
     return MP_OK;
   }
@@ -1282,7 +1282,7 @@ int mp_model_create(int n, const double* S, const double* Mcom, const double* G,
   if (n <= MP_MAX_DOF && !(looped && looped[0] == '1')) {
     rc = mp_compile_model(n, S, Mcom, G, M_ee, joint_limits, torque_limits, &m->d, msg, sizeof msg);
     if (!rc) mp_model_cast(m->d, &m->f);
-  } else {  // 9..16 joints: the looped kernels' model; d / f only carry the joint count
+  } else {  // 9..32 joints: the looped kernels' model; d / f only carry the joint count
     m->big = true;
     rc = mp_compile_model_big(n, S, Mcom, G, M_ee, joint_limits, torque_limits, &m->bd, msg, sizeof msg);
     if (!rc) {
@@ -1567,7 +1567,7 @@ int mp_batch_trajectory_f32(mp_ctx* ctx, const mp_model* model, const float* d_s
     const MpBigModel<float>* dm = nullptr;
     if (int rc = device_big_model<float>(ctx, model, &dm)) return rc;
     MpCall<float> c0 = {};
-    HIP_TRY(mpk_dyn_traj(ctx->compute, dm, c0, false, d_start, d_end, (long)B, (long)N, Tf, method, d_pos, d_vel, d_acc, nullptr));
+    HIP_TRY(mpk_dyn_traj(ctx->compute, model->d.n, dm, c0, false, d_start, d_end, (long)B, (long)N, Tf, method, d_pos, d_vel, d_acc, nullptr));
     return MP_OK;
   }
   HIP_TRY(mpk_batch_traj(ctx->compute, model->f, d_start, d_end, (long)B, (long)N, Tf, method, d_pos, d_vel, d_acc));
@@ -1598,7 +1598,7 @@ int mp_traj_id_fused_f32(mp_ctx* ctx, const mp_model* model, const float* d_star
   if (model->big) {
     const MpBigModel<float>* dm = nullptr;
     if (int rc = device_big_model<float>(ctx, model, &dm)) return rc;
-    HIP_TRY(mpk_dyn_traj(ctx->compute, dm, c, ftip, d_start, d_end, (long)B, (long)N, Tf, method, nullptr, nullptr, nullptr, d_tau));
+    HIP_TRY(mpk_dyn_traj(ctx->compute, model->d.n, dm, c, ftip, d_start, d_end, (long)B, (long)N, Tf, method, nullptr, nullptr, nullptr, d_tau));
     return MP_OK;
   }
   if (!mpk_packed_f32() && !find_spec(ctx, model)) {  // MANIPULAPY_HIP_F32=scalar, generic: one row per lane, time scaling per row
@@ -1930,7 +1930,7 @@ int mp_pd_regulation_host_f64(mp_ctx* ctx, const mp_model* model, const double* 
     if (model->big) {
       const MpBigModel<double>* dm = nullptr;
       if (int rc = device_big_model<double>(ctx, model, &dm)) return rc;
-      HIP_TRY(mpk_dyn_pd_regulation(ctx->compute, dm, c, (double*)d0, (double*)dd, (double*)dkp, (double*)dkd, (long)K, dt, steps,
+      HIP_TRY(mpk_dyn_pd_regulation(ctx->compute, model->d.n, dm, c, (double*)d0, (double*)dd, (double*)dkp, (double*)dkd, (long)K, dt, steps,
                                     (double*)de, (int*)dc));
     } else {
       HIP_TRY(mpk_pd_regulation(ctx->compute, model->d, c, (double*)d0, (double*)dd, (double*)dkp, (double*)dkd, (long)K, dt, steps,
@@ -2049,7 +2049,7 @@ int mp_inverse_kinematics_f64(mp_ctx* ctx, const mp_model* model, const double* 
     REQUIRE(!ctx->capturing, "mp_inverse_kinematics_f64: first use allocates; call it once before capturing a launch graph");
     HIP_TRY(hipMalloc(&ctx->queue_counter, 256));
   }
-  if (model->big) {  // 9..16 joints: the same iteration on the run-time-n kinematics (csrc/mp_dyn.h)
+  if (model->big) {  // 9..32 joints: the same iteration on the run-time-n kinematics (csrc/mp_dyn.h)
     MpIkBigParams PB;
     if (int rc = ik_params<MpIkBigParams, MP_BIG_DOF>("mp_inverse_kinematics_f64", model, joint_limits, eomg, ev, max_iterations, damping,
                                                       step_cap, weight_orientation, weight_position, adaptive_tuning, backtracking, seed, &PB))

@@ -143,12 +143,12 @@ int fk_jac_id_cpu(const char* fn, const mp_model* model, const T* q, const T* qd
   const MpModel<T>& M = pick<T>(model);
   const MpCall<T> C = make_call<T>(model, g, Ftip);
   const bool ftip = any_nonzero(Ftip);
-  if (model->big) {  // 9..16 joints: the looped rows of csrc/mp_dyn.h
+  if (model->big) {  // 9..32 joints: the looped rows of csrc/mp_dyn.h
     const MpBigModel<T>& MB = pick_big<T>(model);
     parallel_for(rows, 128, nthreads, [&](int64_t lo, int64_t hi) {
       for (int64_t r = lo; r < hi; ++r) {
-        if (ftip) mp_dyn_row_fk_jac_id<T, true>(MB, C, q, qd, qdd, Tout, Jout, tau, (long)r);
-        else mp_dyn_row_fk_jac_id<T, false>(MB, C, q, qd, qdd, Tout, Jout, tau, (long)r);
+        if (ftip) mp_dyn_row_fk_jac_id<MP_BIG_DOF, T, true>(MB, C, q, qd, qdd, Tout, Jout, tau, (long)r);
+        else mp_dyn_row_fk_jac_id<MP_BIG_DOF, T, false>(MB, C, q, qd, qdd, Tout, Jout, tau, (long)r);
       }
     });
     return MP_OK;
@@ -254,8 +254,8 @@ int fd_trajectory_cpu(const mp_model* model, const T* theta0, const T* dtheta0, 
     const MpBigModel<T>& MB = pick_big<T>(model);
     parallel_for(B, 1, nthreads, [&](int64_t lo, int64_t hi) {
       for (int64_t b = lo; b < hi; ++b) {
-        if (Ftipmat) mp_dyn_rollout<T, true>(MB, C, theta0, dtheta0, taumat, Ftipmat, (long)b, (long)B, (long)Nt, h, intRes, pos, vel, acc, false);
-        else mp_dyn_rollout<T, false>(MB, C, theta0, dtheta0, taumat, Ftipmat, (long)b, (long)B, (long)Nt, h, intRes, pos, vel, acc, false);
+        if (Ftipmat) mp_dyn_rollout<MP_BIG_DOF, T, true>(MB, C, theta0, dtheta0, taumat, Ftipmat, (long)b, (long)B, (long)Nt, h, intRes, pos, vel, acc, false);
+        else mp_dyn_rollout<MP_BIG_DOF, T, false>(MB, C, theta0, dtheta0, taumat, Ftipmat, (long)b, (long)B, (long)Nt, h, intRes, pos, vel, acc, false);
       }
     });
     return MP_OK;
@@ -325,7 +325,7 @@ int mp_mass_matrix_cpu_f64(const mp_model* model, const double* q, int64_t rows,
   const MpModel<double>& M = model->d;
   if (model->big) {
     parallel_for(rows, 128, nthreads, [&](int64_t lo, int64_t hi) {
-      for (int64_t r = lo; r < hi; ++r) mp_dyn_row_mass_matrix<double>(model->bd, q, Mout, (long)r);
+      for (int64_t r = lo; r < hi; ++r) mp_dyn_row_mass_matrix<MP_BIG_DOF, double>(model->bd, q, Mout, (long)r);
     });
     return MP_OK;
   }
@@ -345,8 +345,8 @@ int mp_forward_dynamics_cpu_f64(const mp_model* model, const double* q, const do
   if (model->big) {
     parallel_for(rows, 64, nthreads, [&](int64_t lo, int64_t hi) {
       for (int64_t r = lo; r < hi; ++r) {
-        if (ftip) mp_dyn_row_forward_dynamics<double, true>(model->bd, C, q, qd, tau, qdd, (long)r);
-        else mp_dyn_row_forward_dynamics<double, false>(model->bd, C, q, qd, tau, qdd, (long)r);
+        if (ftip) mp_dyn_row_forward_dynamics<MP_BIG_DOF, double, true>(model->bd, C, q, qd, tau, qdd, (long)r);
+        else mp_dyn_row_forward_dynamics<MP_BIG_DOF, double, false>(model->bd, C, q, qd, tau, qdd, (long)r);
       }
     });
     return MP_OK;
@@ -394,7 +394,7 @@ int mp_inverse_kinematics_cpu_f64(const mp_model* model, const double* T_desired
     }
     return true;
   };
-  if (model->big) {  // 9..16 joints: the body of k_dyn_ik (run-time-n kinematics of csrc/mp_dyn.h under the same iteration)
+  if (model->big) {  // 9..32 joints: the body of k_dyn_ik (run-time-n kinematics of csrc/mp_dyn.h under the same iteration)
     MpIkBigParams PB;
     if (!fill(PB, MP_BIG_DOF)) return fail("mp_inverse_kinematics_cpu_f64: a joint has its lower limit above its upper limit");
     const MpBigModel<double>& MB = model->bd;
@@ -405,7 +405,7 @@ int mp_inverse_kinematics_cpu_f64(const mp_model* model, const double* T_desired
         for (int j = 0; j < MP_BIG_DOF; ++j) S.theta[j] = j < n ? theta0[row * n + j] : 0.0;
         mp_ik_begin(S, PB);
         int done = 0;
-        while (!(done = mp_ik_iterate<MP_BIG_DOF, MpIkLooped>(MB, PB, S, T_desired + row * 16, theta0 + row * n))) {}
+        while (!(done = mp_ik_iterate<MP_BIG_DOF, MpIkLooped<MP_BIG_DOF>>(MB, PB, S, T_desired + row * 16, theta0 + row * n))) {}
         for (int j = 0; j < n; ++j) theta[row * n + j] = S.theta[j];
         success[row] = done == 2 ? 1 : 0;
         iterations[row] = S.k + 1;
@@ -447,7 +447,7 @@ int mp_pd_regulation_cpu_f64(const mp_model* model, const double* theta0, const 
   if (model->big) {  // the body of k_dyn_pd_regulation
     parallel_for(K, 1, nthreads, [&](int64_t lo, int64_t hi) {
       for (int64_t k = lo; k < hi; ++k)
-        count[k] = mp_dyn_pd_regulation_run<double>(model->bd, C.a0, theta0 + k * n, theta_des + k * n, Kp[k], Kd[k], dt, steps,
+        count[k] = mp_dyn_pd_regulation_run<MP_BIG_DOF, double>(model->bd, C.a0, theta0 + k * n, theta_des + k * n, Kp[k], Kd[k], dt, steps,
                                                     errors + k * steps);
     });
     return MP_OK;

@@ -1,5 +1,5 @@
 // Run-time-n ("looped") forms of the per-row recursions of mp_core.h, for robots with more joints than the fully
-// unrolled kernels are instantiated for (MP_MAX_DOF = 8 < n <= MP_BIG_DOF = 16: the reference's Jaco arms with their
+// unrolled kernels are instantiated for (MP_MAX_DOF = 8 < n <= MP_BIG_DOF = 32: the reference's Jaco arms with their
 // three-finger hands have 9 and 10 actuated joints, ManipulaPy_data/__init__.py:174-189, and its algorithms loop over any n,
 // dynamics/mass_matrix.py:62-96, kinematics/jacobian.py:62-73).  Same compiled link frames, same axis-aligned steps
 // (mp_motion_* / mp_force_* / mp_rbi_up_* of mp_core.h), same arithmetic order per joint; the joint index is a run-time loop
@@ -16,13 +16,15 @@
 #define MP_NOUNROLL
 #endif
 
-template <typename T>
+// CAP: the capacity of a row's per-joint arrays - MP_MID_DOF (16) or MP_BIG_DOF (32), picked by the launchers from the joint count,
+// so that the 9..16-joint robots do not pay for a 32 x 32 mass matrix of scratch memory per lane.
+template <typename T, int CAP>
 struct MpDynState {  // sin / cos of the joint angles and the z shifts of one row
-  T s[MP_BIG_DOF], c[MP_BIG_DOF], d[MP_BIG_DOF];
+  T s[CAP], c[CAP], d[CAP];
 };
 
-template <typename T, typename MT>
-MP_HD void mp_dyn_joint_state(const MT& M, int n, const T* q, MpDynState<T>& js) {
+template <typename T, typename MT, int CAP>
+MP_HD void mp_dyn_joint_state(const MT& M, int n, const T* q, MpDynState<T, CAP>& js) {
   MP_NOUNROLL
   for (int i = 0; i < n; ++i) {
     const auto& J = M.j[i];
@@ -36,10 +38,10 @@ MP_HD void mp_dyn_joint_state(const MT& M, int n, const T* q, MpDynState<T>& js)
 }
 
 // mp_rnea of mp_core.h with a run-time joint count.  tau is NOT clipped here.
-template <typename T, bool HAS_FTIP, typename MT>
-MP_HD void mp_dyn_rnea(const MT& M, int n, const T (&a0)[3], const T (&tipn)[3], const T (&tipf)[3], const MpDynState<T>& js,
+template <typename T, bool HAS_FTIP, typename MT, int CAP>
+MP_HD void mp_dyn_rnea(const MT& M, int n, const T (&a0)[3], const T (&tipn)[3], const T (&tipf)[3], const MpDynState<T, CAP>& js,
                        const T* qd, const T* qdd, T* tau) {
-  T fnx[MP_BIG_DOF], fny[MP_BIG_DOF], fnz[MP_BIG_DOF], ffx[MP_BIG_DOF], ffy[MP_BIG_DOF], ffz[MP_BIG_DOF];
+  T fnx[CAP], fny[CAP], fnz[CAP], ffx[CAP], ffy[CAP], ffz[CAP];
   T wx = 0, wy = 0, wz = 0, vx = 0, vy = 0, vz = 0;
   T dwx = 0, dwy = 0, dwz = 0, dvx = a0[0], dvy = a0[1], dvz = a0[2];
   T tnx = 0, tny = 0, tnz = 0, tfx = 0, tfy = 0, tfz = 0;
@@ -98,8 +100,8 @@ MP_HD void mp_dyn_rnea(const MT& M, int n, const T (&a0)[3], const T (&tipn)[3],
 }
 
 // mp_mass_matrix_crba of mp_core.h with a run-time joint count; Mq is n x n row-major with row pitch `ld`.
-template <typename T, typename MT>
-MP_HD void mp_dyn_mass_matrix(const MT& M, int n, const MpDynState<T>& js, T* Mq, int ld) {
+template <typename T, typename MT, int CAP>
+MP_HD void mp_dyn_mass_matrix(const MT& M, int n, const MpDynState<T, CAP>& js, T* Mq, int ld) {
   MpRbi<T> Ic;
   Ic.m = 0; Ic.hx = 0; Ic.hy = 0; Ic.hz = 0; Ic.xx = 0; Ic.xy = 0; Ic.xz = 0; Ic.yy = 0; Ic.yz = 0; Ic.zz = 0;
   MP_NOUNROLL
@@ -159,22 +161,22 @@ MP_HD void mp_dyn_spd_solve(int n, T* A, int ld, T* b) {
 }
 
 // qdd = M(q)^-1 (tau - bias), bias = ID(q, qd, 0, g, F)   (reference dynamics/id_fd.py:71-83)
-template <typename T, bool HAS_FTIP, typename MT>
+template <int CAP, typename T, bool HAS_FTIP, typename MT>
 MP_HD void mp_dyn_forward_dynamics(const MT& M, int n, const T (&a0)[3], const T (&tipn)[3], const T (&tipf)[3], const T* q,
                                    const T* qd, const T* tau, T* qdd) {
-  MpDynState<T> js;
+  MpDynState<T, CAP> js;
   mp_dyn_joint_state<T>(M, n, q, js);
-  T zero[MP_BIG_DOF], bias[MP_BIG_DOF], Mq[MP_BIG_DOF * MP_BIG_DOF];
+  T zero[CAP], bias[CAP], Mq[CAP * CAP];
   for (int k = 0; k < n; ++k) zero[k] = T(0);
   mp_dyn_rnea<T, HAS_FTIP>(M, n, a0, tipn, tipf, js, qd, zero, bias);
-  mp_dyn_mass_matrix<T>(M, n, js, Mq, MP_BIG_DOF);
+  mp_dyn_mass_matrix<T>(M, n, js, Mq, CAP);
   for (int k = 0; k < n; ++k) qdd[k] = tau[k] - bias[k];
-  mp_dyn_spd_solve<T>(n, Mq, MP_BIG_DOF, qdd);
+  mp_dyn_spd_solve<T>(n, Mq, CAP, qdd);
 }
 
 // mp_fk_jac of mp_core.h with a run-time joint count: Tout 4x4 row-major, Jout 6 x n row-major (either may be null)
-template <typename T, typename MT>
-MP_HD void mp_dyn_fk_jac(const MT& M, int n, const MpDynState<T>& js, T* Tout, T* Jout) {
+template <typename T, typename MT, int CAP>
+MP_HD void mp_dyn_fk_jac(const MT& M, int n, const MpDynState<T, CAP>& js, T* Tout, T* Jout) {
   T x0 = M.base_R[0], x1 = M.base_R[3], x2 = M.base_R[6];
   T y0 = M.base_R[1], y1 = M.base_R[4], y2 = M.base_R[7];
   T z0 = M.base_R[2], z1 = M.base_R[5], z2 = M.base_R[8];
@@ -222,25 +224,25 @@ MP_HD bool mp_dyn_bad(const T* v, int n, MpBad<T>& bad) {
   return bad.any();
 }
 
-template <typename T, bool HAS_FTIP, typename MT>
+template <int CAP, typename T, bool HAS_FTIP, typename MT>
 MP_HD void mp_dyn_row_fk_jac_id(const MT& M, const MpCall<T>& C, const T* q, const T* qd, const T* qdd, T* Tout, T* Jout, T* tau,
                                 long r) {
   const int n = M.n;
-  T a[MP_BIG_DOF];
+  T a[CAP];
   for (int j = 0; j < n; ++j) a[j] = q[r * n + j];
-  MpDynState<T> js;
+  MpDynState<T, CAP> js;
   mp_dyn_joint_state<T>(M, n, a, js);
   MpBad<T> bad;
   mp_dyn_bad(a, n, bad);
   if (Tout || Jout) {
-    T TT[16], JJ[6 * MP_BIG_DOF];
+    T TT[16], JJ[6 * CAP];
     mp_dyn_fk_jac<T>(M, n, js, Tout ? TT : nullptr, Jout ? JJ : nullptr);
     const bool p = bad.any();
     if (Tout) for (int k = 0; k < 16; ++k) { T v = TT[k]; mp_poison_if(p, v); Tout[r * 16 + k] = v; }
     if (Jout) for (int k = 0; k < 6 * n; ++k) { T v = JJ[k]; mp_poison_if(p, v); Jout[r * 6 * n + k] = v; }
   }
   if (tau) {
-    T b[MP_BIG_DOF], c[MP_BIG_DOF], t[MP_BIG_DOF];
+    T b[CAP], c[CAP], t[CAP];
     for (int j = 0; j < n; ++j) { b[j] = qd[r * n + j]; c[j] = qdd[r * n + j]; }
     mp_dyn_rnea<T, HAS_FTIP>(M, n, C.a0, C.F1n, C.F1f, js, b, c, t);
     mp_dyn_bad(b, n, bad);
@@ -253,26 +255,26 @@ MP_HD void mp_dyn_row_fk_jac_id(const MT& M, const MpCall<T>& C, const T* q, con
   }
 }
 
-template <typename T, typename MT>
+template <int CAP, typename T, typename MT>
 MP_HD void mp_dyn_row_mass_matrix(const MT& M, const T* q, T* Mout, long r) {
   const int n = M.n;
-  T a[MP_BIG_DOF], Mq[MP_BIG_DOF * MP_BIG_DOF];
+  T a[CAP], Mq[CAP * CAP];
   for (int j = 0; j < n; ++j) a[j] = q[r * n + j];
-  MpDynState<T> js;
+  MpDynState<T, CAP> js;
   mp_dyn_joint_state<T>(M, n, a, js);
-  mp_dyn_mass_matrix<T>(M, n, js, Mq, MP_BIG_DOF);
+  mp_dyn_mass_matrix<T>(M, n, js, Mq, CAP);
   MpBad<T> bad;
   const bool p = mp_dyn_bad(a, n, bad);
   for (int i = 0; i < n; ++i)
-    for (int j = 0; j < n; ++j) { T v = Mq[i * MP_BIG_DOF + j]; mp_poison_if(p, v); Mout[(r * n + i) * n + j] = v; }
+    for (int j = 0; j < n; ++j) { T v = Mq[i * CAP + j]; mp_poison_if(p, v); Mout[(r * n + i) * n + j] = v; }
 }
 
-template <typename T, bool HAS_FTIP, typename MT>
+template <int CAP, typename T, bool HAS_FTIP, typename MT>
 MP_HD void mp_dyn_row_forward_dynamics(const MT& M, const MpCall<T>& C, const T* q, const T* qd, const T* tau, T* qdd, long r) {
   const int n = M.n;
-  T a[MP_BIG_DOF], b[MP_BIG_DOF], t[MP_BIG_DOF], o[MP_BIG_DOF];
+  T a[CAP], b[CAP], t[CAP], o[CAP];
   for (int j = 0; j < n; ++j) { a[j] = q[r * n + j]; b[j] = qd[r * n + j]; t[j] = tau[r * n + j]; }
-  mp_dyn_forward_dynamics<T, HAS_FTIP>(M, n, C.a0, C.F1n, C.F1f, a, b, t, o);
+  mp_dyn_forward_dynamics<CAP, T, HAS_FTIP>(M, n, C.a0, C.F1n, C.F1f, a, b, t, o);
   MpBad<T> bad;
   mp_dyn_bad(a, n, bad); mp_dyn_bad(b, n, bad);
   const bool p = mp_dyn_bad(t, n, bad);
@@ -282,11 +284,11 @@ MP_HD void mp_dyn_row_forward_dynamics(const MT& M, const MpCall<T>& C, const T*
 // forward_dynamics_trajectory for trajectory `b` of B (reference planning/trajectory_dynamics.py:580-708): the loop of
 // mp_body_fd_traj / mp_body_fd_traj_tm with a run-time joint count.  Row (b, i) sits at b * Nt + i (batch-major arrays) or
 // i * B + b (time-major arrays).
-template <typename T, bool HAS_FTIP, typename MT>
+template <int CAP, typename T, bool HAS_FTIP, typename MT>
 MP_HD void mp_dyn_rollout(const MT& M, const MpCall<T>& C, const T* theta0, const T* dtheta0, const T* taumat, const T* Ftipmat,
                           long b, long B, long Nt, T h, int intRes, float* pos, float* vel, float* acc, bool time_major) {
   const int n = M.n;
-  T q[MP_BIG_DOF], qd[MP_BIG_DOF], tau[MP_BIG_DOF], last[MP_BIG_DOF];
+  T q[CAP], qd[CAP], tau[CAP], last[CAP];
   for (int j = 0; j < n; ++j) { q[j] = theta0[b * n + j]; qd[j] = dtheta0[b * n + j]; }
   MpBad<T> bad;
   mp_dyn_bad(q, n, bad); mp_dyn_bad(qd, n, bad);
@@ -305,7 +307,7 @@ MP_HD void mp_dyn_rollout(const MT& M, const MpCall<T>& C, const T* theta0, cons
         mp_wrench_to_frame1(M, F, tn, tf);
       }
       for (int k = 0; k < intRes; ++k) {
-        mp_dyn_forward_dynamics<T, HAS_FTIP>(M, n, C.a0, tn, tf, q, qd, tau, last);
+        mp_dyn_forward_dynamics<CAP, T, HAS_FTIP>(M, n, C.a0, tn, tf, q, qd, tau, last);
         for (int j = 0; j < n; ++j) {
           qd[j] = qd[j] + last[j] * h;
           q[j] = mp_clip(q[j] + qd[j] * h, M.qmin[j], M.qmax[j]);
@@ -324,14 +326,14 @@ MP_HD void mp_dyn_rollout(const MT& M, const MpCall<T>& C, const T* theta0, cons
 }
 
 // row (b, t) of the time-scaled trajectory (the arithmetic of traj_row, mp_bodies.h) and, optionally, its torques
-template <bool HAS_FTIP, typename MT>
+template <int CAP, bool HAS_FTIP, typename MT>
 MP_HD void mp_dyn_row_traj(const MT& M, const MpCall<float>& C, const float* start, const float* end, long b, long t, long Nt,
                            double Tf, int method, float* pos, float* vel, float* acc, float* tau) {
   const int n = M.n;
   const double tt = (double)t * (Tf / (double)(Nt - 1));
   double s, sd, sdd;
   mp_time_scaling(method, tt / Tf, Tf, s, sd, sdd);
-  float p[MP_BIG_DOF], v[MP_BIG_DOF], a[MP_BIG_DOF];
+  float p[CAP], v[CAP], a[CAP];
   for (int j = 0; j < n; ++j) {
     const float a0 = start[b * n + j];
     const double d = (double)(end[b * n + j] - a0);  // float32 difference first, as the reference types it
@@ -342,9 +344,9 @@ MP_HD void mp_dyn_row_traj(const MT& M, const MpCall<float>& C, const float* sta
   const long r = b * Nt + t;
   if (pos) for (int j = 0; j < n; ++j) { pos[r * n + j] = p[j]; vel[r * n + j] = v[j]; acc[r * n + j] = a[j]; }
   if (tau) {
-    MpDynState<float> js;
+    MpDynState<float, CAP> js;
     mp_dyn_joint_state<float>(M, n, p, js);
-    float tq[MP_BIG_DOF];
+    float tq[CAP];
     mp_dyn_rnea<float, HAS_FTIP>(M, n, C.a0, C.F1n, C.F1f, js, v, a, tq);
     MpBad<float> bad;
     mp_dyn_bad(p, n, bad); mp_dyn_bad(v, n, bad);
@@ -358,16 +360,16 @@ MP_HD void mp_dyn_row_traj(const MT& M, const MpCall<float>& C, const float* sta
 }
 
 // mp_pd_regulation_run of mp_core.h with a run-time joint count
-template <typename T, typename MT>
+template <int CAP, typename T, typename MT>
 MP_HD int mp_dyn_pd_regulation_run(const MT& M, const T (&a0)[3], const T* theta0, const T* des, T Kp, T Kd, T dt, int steps, T* err) {
   const int n = M.n;
-  T th[MP_BIG_DOF], om[MP_BIG_DOF], tau[MP_BIG_DOF], al[MP_BIG_DOF];
+  T th[CAP], om[CAP], tau[CAP], al[CAP];
   const T z3[3] = {T(0), T(0), T(0)};
   for (int j = 0; j < n; ++j) { th[j] = theta0[j]; om[j] = T(0); }
   int done = 0;
   for (int step = 0; step < steps; ++step) {
     for (int j = 0; j < n; ++j) tau[j] = Kp * (des[j] - th[j]) - Kd * om[j];
-    mp_dyn_forward_dynamics<T, false>(M, n, a0, z3, z3, th, om, tau, al);
+    mp_dyn_forward_dynamics<CAP, T, false>(M, n, a0, z3, z3, th, om, tau, al);
     T e2 = T(0);
     for (int j = 0; j < n; ++j) {
       om[j] += al[j] * dt;
@@ -382,16 +384,17 @@ MP_HD int mp_dyn_pd_regulation_run(const MT& M, const T (&a0)[3], const T* theta
   return done;
 }
 
-// ------------------------------------------------------------------------------- inverse kinematics, 9..16 joints
+// ------------------------------------------------------------------------------- inverse kinematics, 9..32 joints
 // The kinematics policy of mp_ik.h for a run-time joint count: the damped-least-squares iteration itself (error, step,
 // restart, adaptive damping, line search) is the one template of mp_ik.h; only the joint count and FK + Jacobian differ.
 #include "mp_ik.h"
+template <int CAP>
 struct MpIkLooped {
   template <typename MT>
   MP_HD static int count(const MT& M) { return M.n; }
   template <bool WANT_J, typename MT>
-  MP_HD static void fk(const MT& M, const double (&theta)[MP_BIG_DOF], double (&Tc)[16], double (&J)[6 * MP_BIG_DOF]) {
-    MpDynState<double> js;
+  MP_HD static void fk(const MT& M, const double (&theta)[CAP], double (&Tc)[16], double (&J)[6 * CAP]) {
+    MpDynState<double, CAP> js;
     mp_dyn_joint_state<double>(M, M.n, theta, js);
     mp_dyn_fk_jac<double>(M, M.n, js, Tc, WANT_J ? J : nullptr);  // J: 6 x n row-major, as the iteration indexes it
   }

@@ -31,7 +31,7 @@ struct MpIkParamsT {
   double lo[CAP], hi[CAP];
 };
 typedef MpIkParamsT<MP_MAX_DOF> MpIkParams;     // up to 8 joints: the unrolled kernels
-typedef MpIkParamsT<MP_BIG_DOF> MpIkBigParams;  // 9..16 joints: the run-time-n form (MpIkLooped, csrc/mp_dyn.h)
+typedef MpIkParamsT<MP_BIG_DOF> MpIkBigParams;  // 9..32 joints: the run-time-n form (MpIkLooped, csrc/mp_dyn.h)
 
 // Where the iteration gets its joint count and its forward kinematics / Jacobian from.  MpIkUnrolled<N>: N is the joint
 // count, every loop below unrolls, mp_fk_jac of mp_core.h.  MpIkLooped (csrc/mp_dyn.h): N is the CAPACITY of the per-problem

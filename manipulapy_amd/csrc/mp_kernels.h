@@ -46,21 +46,22 @@ hipError_t mpk_fd_traj_tm(hipStream_t s, const MpModel<T>& M, const MpCall<T>& C
 // (outer, inner, row_dwords x 4 bytes) -> (inner, outer, row_dwords x 4 bytes)
 hipError_t mpk_transpose_rows(hipStream_t s, const void* src, void* dst, long outer, long inner, int row_dwords);
 
-// ---- 9..16 joints (csrc/mp_dyn.h): run-time-n kernels, the model (MpBigModel<T>) resident in device memory
+// ---- 9..32 joints (csrc/mp_dyn.h): run-time-n kernels, the model (MpBigModel<T>) resident in device memory; n = its joint count
+// (picks the kernels' per-row array capacity, MP_MID_DOF or MP_BIG_DOF)
 template <typename T>
-hipError_t mpk_dyn_fk_jac_id(hipStream_t s, const MpBigModel<T>* d_model, const MpCall<T>& C, bool ftip, const T* q, const T* qd,
+hipError_t mpk_dyn_fk_jac_id(hipStream_t s, int n, const MpBigModel<T>* d_model, const MpCall<T>& C, bool ftip, const T* q, const T* qd,
                              const T* qdd, T* Tout, T* Jout, T* tau, long rows);
 template <typename T>
-hipError_t mpk_dyn_mass_matrix(hipStream_t s, const MpBigModel<T>* d_model, const T* q, T* Mout, long rows);
+hipError_t mpk_dyn_mass_matrix(hipStream_t s, int n, const MpBigModel<T>* d_model, const T* q, T* Mout, long rows);
 template <typename T>
-hipError_t mpk_dyn_forward_dynamics(hipStream_t s, const MpBigModel<T>* d_model, const MpCall<T>& C, bool ftip, const T* q, const T* qd,
+hipError_t mpk_dyn_forward_dynamics(hipStream_t s, int n, const MpBigModel<T>* d_model, const MpCall<T>& C, bool ftip, const T* q, const T* qd,
                                     const T* tau, T* qdd, long rows);
 template <typename T>
-hipError_t mpk_dyn_fd_traj(hipStream_t s, const MpBigModel<T>* d_model, const MpCall<T>& C, const T* theta0, const T* dtheta0,
+hipError_t mpk_dyn_fd_traj(hipStream_t s, int n, const MpBigModel<T>* d_model, const MpCall<T>& C, const T* theta0, const T* dtheta0,
                            const T* taumat, const T* Ftipmat, long B, long Nt, T h, int intRes, float* pos, float* vel, float* acc,
                            bool time_major);
 // pos / vel / acc (all three or none) and / or tau of the time-scaled trajectories
-hipError_t mpk_dyn_traj(hipStream_t s, const MpBigModel<float>* d_model, const MpCall<float>& C, bool ftip, const float* start,
+hipError_t mpk_dyn_traj(hipStream_t s, int n, const MpBigModel<float>* d_model, const MpCall<float>& C, bool ftip, const float* start,
                         const float* end, long B, long Nt, double Tf, int method, float* pos, float* vel, float* acc, float* tau);
 
 // Cartesian straight-line trajectories between B pose pairs (4x4 row-major float64): float32 (B,Nt,3) x3, (B,Nt,3,3)
@@ -81,9 +82,9 @@ hipError_t mpk_ik(hipStream_t s, const MpModel<double>& M, const MpIkParams& P, 
 // K closed-loop PD regulation runs (csrc/mp_core.h mp_pd_regulation_run): theta0 / des (K,n), Kp / Kd (K), err (K,steps), count (K)
 hipError_t mpk_pd_regulation(hipStream_t s, const MpModel<double>& M, const MpCall<double>& C, const double* theta0, const double* des,
                              const double* Kp, const double* Kd, long K, double dt, int steps, double* err, int* count);
-hipError_t mpk_dyn_pd_regulation(hipStream_t s, const MpBigModel<double>* d_model, const MpCall<double>& C, const double* theta0,
+hipError_t mpk_dyn_pd_regulation(hipStream_t s, int n, const MpBigModel<double>* d_model, const MpCall<double>& C, const double* theta0,
                                  const double* des, const double* Kp, const double* Kd, long K, double dt, int steps, double* err, int* count);
-// the same for 9..16 joints (run-time joint count, the model resident in device memory)
+// the same for 9..32 joints (run-time joint count, the model resident in device memory)
 hipError_t mpk_dyn_ik(hipStream_t s, const MpBigModel<double>* d_model, const MpIkBigParams& P, const double* Tdes, const double* theta0,
                       long B, double* theta, int* success, int* iterations, int* restarts, unsigned long long* queue_counter,
                       int compute_units);

@@ -393,35 +393,36 @@ __global__ __launch_bounds__(kBlock) void k_ik(const MpModel<double> M, const Mp
   }
 }
 
-// ------------------------------------------------------------------- 9..16 joints: run-time-n kernels (csrc/mp_dyn.h)
+// ------------------------------------------------------------------- 9..32 joints: run-time-n kernels (csrc/mp_dyn.h)
 // One lane per row (or per trajectory), the model read through a pointer to device memory, per-joint state in indexed
 // arrays.  Plain per-lane accesses: these kernels exist so that every robot the reference can evaluate computes here too.
+// CAP = the capacity of those arrays (MP_MID_DOF or MP_BIG_DOF; the launchers pick it from the joint count).
 template <typename T> using MpBigConst = const __attribute__((address_space(4))) MpBigModel<T>;
 
-template <typename T, bool HAS_FTIP>
+template <int CAP, typename T, bool HAS_FTIP>
 __global__ __launch_bounds__(kBlock) void k_dyn_fk_jac_id(const MpBigModel<T>* __restrict__ Mdev, const MpCall<T> C,
                                                           const T* __restrict__ q, const T* __restrict__ qd, const T* __restrict__ qdd,
                                                           T* __restrict__ Tout, T* __restrict__ Jout, T* __restrict__ tau, long rows) {
   const long r = (long)blockIdx.x * kBlock + threadIdx.x;
   if (r >= rows) return;
-  mp_dyn_row_fk_jac_id<T, HAS_FTIP>(*(MpBigConst<T>*)Mdev, C, q, qd, qdd, Tout, Jout, tau, r);
+  mp_dyn_row_fk_jac_id<CAP, T, HAS_FTIP>(*(MpBigConst<T>*)Mdev, C, q, qd, qdd, Tout, Jout, tau, r);
 }
-template <typename T>
+template <int CAP, typename T>
 __global__ __launch_bounds__(kBlock) void k_dyn_mass_matrix(const MpBigModel<T>* __restrict__ Mdev, const T* __restrict__ q,
                                                             T* __restrict__ Mout, long rows) {
   const long r = (long)blockIdx.x * kBlock + threadIdx.x;
   if (r >= rows) return;
-  mp_dyn_row_mass_matrix<T>(*(MpBigConst<T>*)Mdev, q, Mout, r);
+  mp_dyn_row_mass_matrix<CAP, T>(*(MpBigConst<T>*)Mdev, q, Mout, r);
 }
-template <typename T, bool HAS_FTIP>
+template <int CAP, typename T, bool HAS_FTIP>
 __global__ __launch_bounds__(kBlock) void k_dyn_forward_dynamics(const MpBigModel<T>* __restrict__ Mdev, const MpCall<T> C,
                                                                  const T* __restrict__ q, const T* __restrict__ qd,
                                                                  const T* __restrict__ tau, T* __restrict__ qdd, long rows) {
   const long r = (long)blockIdx.x * kBlock + threadIdx.x;
   if (r >= rows) return;
-  mp_dyn_row_forward_dynamics<T, HAS_FTIP>(*(MpBigConst<T>*)Mdev, C, q, qd, tau, qdd, r);
+  mp_dyn_row_forward_dynamics<CAP, T, HAS_FTIP>(*(MpBigConst<T>*)Mdev, C, q, qd, tau, qdd, r);
 }
-template <typename T, bool HAS_FTIP>
+template <int CAP, typename T, bool HAS_FTIP>
 __global__ __launch_bounds__(64) void k_dyn_fd_traj(const MpBigModel<T>* __restrict__ Mdev, const MpCall<T> C,
                                                     const T* __restrict__ theta0, const T* __restrict__ dtheta0,
                                                     const T* __restrict__ taumat, const T* __restrict__ Ftipmat, long B, long Nt, T h,
@@ -429,10 +430,10 @@ __global__ __launch_bounds__(64) void k_dyn_fd_traj(const MpBigModel<T>* __restr
                                                     float* __restrict__ acc, int time_major) {
   const long b = (long)blockIdx.x * 64 + threadIdx.x;
   if (b >= B) return;
-  mp_dyn_rollout<T, HAS_FTIP>(*(MpBigConst<T>*)Mdev, C, theta0, dtheta0, taumat, Ftipmat, b, B, Nt, h, intRes, pos, vel, acc,
+  mp_dyn_rollout<CAP, T, HAS_FTIP>(*(MpBigConst<T>*)Mdev, C, theta0, dtheta0, taumat, Ftipmat, b, B, Nt, h, intRes, pos, vel, acc,
                               time_major != 0);
 }
-template <bool HAS_FTIP>
+template <int CAP, bool HAS_FTIP>
 __global__ __launch_bounds__(kBlock) void k_dyn_traj(const MpBigModel<float>* __restrict__ Mdev, const MpCall<float> C,
                                                      const float* __restrict__ start, const float* __restrict__ end, long B, long Nt,
                                                      double Tf, int method, float* __restrict__ pos, float* __restrict__ vel,
@@ -440,7 +441,7 @@ __global__ __launch_bounds__(kBlock) void k_dyn_traj(const MpBigModel<float>* __
   const long r = (long)blockIdx.x * kBlock + threadIdx.x;
   if (r >= B * Nt) return;
   const long b = r / Nt;
-  mp_dyn_row_traj<HAS_FTIP>(*(MpBigConst<float>*)Mdev, C, start, end, b, r - b * Nt, Nt, Tf, method, pos, vel, acc, tau);
+  mp_dyn_row_traj<CAP, HAS_FTIP>(*(MpBigConst<float>*)Mdev, C, start, end, b, r - b * Nt, Nt, Tf, method, pos, vel, acc, tau);
 }
 
 inline unsigned grid_for(long rows) { return (unsigned)((rows + kBlock - 1) / kBlock); }
@@ -466,6 +467,11 @@ inline bool use_packed_f32() {
     case 8: { constexpr int N = 8; __VA_ARGS__; } break;        \
     default: return hipErrorInvalidValue;                       \
   }
+// the looped kernels' array capacity for a model of n joints
+#define MP_DISPATCH_CAP(n, ...)                                                       \
+  if ((n) <= MP_MID_DOF) { constexpr int CAP = MP_MID_DOF; __VA_ARGS__; }             \
+  else if ((n) <= MP_BIG_DOF) { constexpr int CAP = MP_BIG_DOF; __VA_ARGS__; }        \
+  else return hipErrorInvalidValue;
 
 }  // namespace
 
@@ -693,57 +699,66 @@ template hipError_t mpk_fd_traj_tm<double>(hipStream_t, const MpModel<double>&, 
 
 // ---- launchers of the run-time-n kernels (d_model: MpBigModel<T> resident in device memory)
 template <typename T>
-hipError_t mpk_dyn_fk_jac_id(hipStream_t s, const MpBigModel<T>* d_model, const MpCall<T>& C, bool ftip, const T* q, const T* qd,
+hipError_t mpk_dyn_fk_jac_id(hipStream_t s, int n, const MpBigModel<T>* d_model, const MpCall<T>& C, bool ftip, const T* q, const T* qd,
                              const T* qdd, T* Tout, T* Jout, T* tau, long rows) {
   if (rows <= 0) return hipSuccess;
-  if (ftip) hipLaunchKernelGGL((k_dyn_fk_jac_id<T, true>), dim3(grid_for(rows)), dim3(kBlock), 0, s, d_model, C, q, qd, qdd, Tout, Jout, tau, rows);
-  else hipLaunchKernelGGL((k_dyn_fk_jac_id<T, false>), dim3(grid_for(rows)), dim3(kBlock), 0, s, d_model, C, q, qd, qdd, Tout, Jout, tau, rows);
+  MP_DISPATCH_CAP(n, {
+    if (ftip) hipLaunchKernelGGL((k_dyn_fk_jac_id<CAP, T, true>), dim3(grid_for(rows)), dim3(kBlock), 0, s, d_model, C, q, qd, qdd, Tout, Jout, tau, rows);
+    else hipLaunchKernelGGL((k_dyn_fk_jac_id<CAP, T, false>), dim3(grid_for(rows)), dim3(kBlock), 0, s, d_model, C, q, qd, qdd, Tout, Jout, tau, rows);
+  })
   return hipGetLastError();
 }
-template hipError_t mpk_dyn_fk_jac_id<float>(hipStream_t, const MpBigModel<float>*, const MpCall<float>&, bool, const float*, const float*,
-                                             const float*, float*, float*, float*, long);
-template hipError_t mpk_dyn_fk_jac_id<double>(hipStream_t, const MpBigModel<double>*, const MpCall<double>&, bool, const double*,
+template hipError_t mpk_dyn_fk_jac_id<float>(hipStream_t, int, const MpBigModel<float>*, const MpCall<float>&, bool, const float*,
+                                             const float*, const float*, float*, float*, float*, long);
+template hipError_t mpk_dyn_fk_jac_id<double>(hipStream_t, int, const MpBigModel<double>*, const MpCall<double>&, bool, const double*,
                                               const double*, const double*, double*, double*, double*, long);
 template <typename T>
-hipError_t mpk_dyn_mass_matrix(hipStream_t s, const MpBigModel<T>* d_model, const T* q, T* Mout, long rows) {
+hipError_t mpk_dyn_mass_matrix(hipStream_t s, int n, const MpBigModel<T>* d_model, const T* q, T* Mout, long rows) {
   if (rows <= 0) return hipSuccess;
-  hipLaunchKernelGGL((k_dyn_mass_matrix<T>), dim3(grid_for(rows)), dim3(kBlock), 0, s, d_model, q, Mout, rows);
+  MP_DISPATCH_CAP(n, { hipLaunchKernelGGL((k_dyn_mass_matrix<CAP, T>), dim3(grid_for(rows)), dim3(kBlock), 0, s, d_model, q, Mout, rows); })
   return hipGetLastError();
 }
-template hipError_t mpk_dyn_mass_matrix<float>(hipStream_t, const MpBigModel<float>*, const float*, float*, long);
-template hipError_t mpk_dyn_mass_matrix<double>(hipStream_t, const MpBigModel<double>*, const double*, double*, long);
+template hipError_t mpk_dyn_mass_matrix<float>(hipStream_t, int, const MpBigModel<float>*, const float*, float*, long);
+template hipError_t mpk_dyn_mass_matrix<double>(hipStream_t, int, const MpBigModel<double>*, const double*, double*, long);
 template <typename T>
-hipError_t mpk_dyn_forward_dynamics(hipStream_t s, const MpBigModel<T>* d_model, const MpCall<T>& C, bool ftip, const T* q, const T* qd,
-                                    const T* tau, T* qdd, long rows) {
+hipError_t mpk_dyn_forward_dynamics(hipStream_t s, int n, const MpBigModel<T>* d_model, const MpCall<T>& C, bool ftip, const T* q,
+                                    const T* qd, const T* tau, T* qdd, long rows) {
   if (rows <= 0) return hipSuccess;
-  if (ftip) hipLaunchKernelGGL((k_dyn_forward_dynamics<T, true>), dim3(grid_for(rows)), dim3(kBlock), 0, s, d_model, C, q, qd, tau, qdd, rows);
-  else hipLaunchKernelGGL((k_dyn_forward_dynamics<T, false>), dim3(grid_for(rows)), dim3(kBlock), 0, s, d_model, C, q, qd, tau, qdd, rows);
+  MP_DISPATCH_CAP(n, {
+    if (ftip) hipLaunchKernelGGL((k_dyn_forward_dynamics<CAP, T, true>), dim3(grid_for(rows)), dim3(kBlock), 0, s, d_model, C, q, qd, tau, qdd, rows);
+    else hipLaunchKernelGGL((k_dyn_forward_dynamics<CAP, T, false>), dim3(grid_for(rows)), dim3(kBlock), 0, s, d_model, C, q, qd, tau, qdd, rows);
+  })
   return hipGetLastError();
 }
-template hipError_t mpk_dyn_forward_dynamics<float>(hipStream_t, const MpBigModel<float>*, const MpCall<float>&, bool, const float*,
+template hipError_t mpk_dyn_forward_dynamics<float>(hipStream_t, int, const MpBigModel<float>*, const MpCall<float>&, bool, const float*,
                                                     const float*, const float*, float*, long);
-template hipError_t mpk_dyn_forward_dynamics<double>(hipStream_t, const MpBigModel<double>*, const MpCall<double>&, bool, const double*,
-                                                     const double*, const double*, double*, long);
+template hipError_t mpk_dyn_forward_dynamics<double>(hipStream_t, int, const MpBigModel<double>*, const MpCall<double>&, bool,
+                                                     const double*, const double*, const double*, double*, long);
 template <typename T>
-hipError_t mpk_dyn_fd_traj(hipStream_t s, const MpBigModel<T>* d_model, const MpCall<T>& C, const T* theta0, const T* dtheta0,
+hipError_t mpk_dyn_fd_traj(hipStream_t s, int n, const MpBigModel<T>* d_model, const MpCall<T>& C, const T* theta0, const T* dtheta0,
                            const T* taumat, const T* Ftipmat, long B, long Nt, T h, int intRes, float* pos, float* vel, float* acc,
                            bool time_major) {
   if (B <= 0 || Nt <= 0) return hipSuccess;
   const dim3 grid((unsigned)((B + 63) / 64));
   const int tm = time_major ? 1 : 0;
-  if (Ftipmat) hipLaunchKernelGGL((k_dyn_fd_traj<T, true>), grid, dim3(64), 0, s, d_model, C, theta0, dtheta0, taumat, Ftipmat, B, Nt, h, intRes, pos, vel, acc, tm);
-  else hipLaunchKernelGGL((k_dyn_fd_traj<T, false>), grid, dim3(64), 0, s, d_model, C, theta0, dtheta0, taumat, Ftipmat, B, Nt, h, intRes, pos, vel, acc, tm);
+  MP_DISPATCH_CAP(n, {
+    if (Ftipmat) hipLaunchKernelGGL((k_dyn_fd_traj<CAP, T, true>), grid, dim3(64), 0, s, d_model, C, theta0, dtheta0, taumat, Ftipmat, B, Nt, h, intRes, pos, vel, acc, tm);
+    else hipLaunchKernelGGL((k_dyn_fd_traj<CAP, T, false>), grid, dim3(64), 0, s, d_model, C, theta0, dtheta0, taumat, Ftipmat, B, Nt, h, intRes, pos, vel, acc, tm);
+  })
   return hipGetLastError();
 }
-template hipError_t mpk_dyn_fd_traj<float>(hipStream_t, const MpBigModel<float>*, const MpCall<float>&, const float*, const float*,
+template hipError_t mpk_dyn_fd_traj<float>(hipStream_t, int, const MpBigModel<float>*, const MpCall<float>&, const float*, const float*,
                                            const float*, const float*, long, long, float, int, float*, float*, float*, bool);
-template hipError_t mpk_dyn_fd_traj<double>(hipStream_t, const MpBigModel<double>*, const MpCall<double>&, const double*, const double*,
-                                            const double*, const double*, long, long, double, int, float*, float*, float*, bool);
-hipError_t mpk_dyn_traj(hipStream_t s, const MpBigModel<float>* d_model, const MpCall<float>& C, bool ftip, const float* start,
+template hipError_t mpk_dyn_fd_traj<double>(hipStream_t, int, const MpBigModel<double>*, const MpCall<double>&, const double*,
+                                            const double*, const double*, const double*, long, long, double, int, float*, float*, float*,
+                                            bool);
+hipError_t mpk_dyn_traj(hipStream_t s, int n, const MpBigModel<float>* d_model, const MpCall<float>& C, bool ftip, const float* start,
                         const float* end, long B, long Nt, double Tf, int method, float* pos, float* vel, float* acc, float* tau) {
   if (B <= 0 || Nt <= 0) return hipSuccess;
-  if (ftip) hipLaunchKernelGGL((k_dyn_traj<true>), dim3(grid_for(B * Nt)), dim3(kBlock), 0, s, d_model, C, start, end, B, Nt, Tf, method, pos, vel, acc, tau);
-  else hipLaunchKernelGGL((k_dyn_traj<false>), dim3(grid_for(B * Nt)), dim3(kBlock), 0, s, d_model, C, start, end, B, Nt, Tf, method, pos, vel, acc, tau);
+  MP_DISPATCH_CAP(n, {
+    if (ftip) hipLaunchKernelGGL((k_dyn_traj<CAP, true>), dim3(grid_for(B * Nt)), dim3(kBlock), 0, s, d_model, C, start, end, B, Nt, Tf, method, pos, vel, acc, tau);
+    else hipLaunchKernelGGL((k_dyn_traj<CAP, false>), dim3(grid_for(B * Nt)), dim3(kBlock), 0, s, d_model, C, start, end, B, Nt, Tf, method, pos, vel, acc, tau);
+  })
   return hipGetLastError();
 }
 
@@ -771,6 +786,7 @@ __global__ __launch_bounds__(64) void k_pd_regulation(const MpModel<double> M, c
   RunIO<double, N>::load(des, k, d);
   count[k] = mp_pd_regulation_run<double, N>(M, C.a0, a, d, Kp[k], Kd[k], dt, steps, err + k * steps);
 }
+template <int CAP>
 __global__ __launch_bounds__(64) void k_dyn_pd_regulation(const MpBigModel<double>* __restrict__ Mdev, const MpCall<double> C,
                                                           const double* __restrict__ theta0, const double* __restrict__ des,
                                                           const double* __restrict__ Kp, const double* __restrict__ Kd, long K, double dt,
@@ -778,7 +794,7 @@ __global__ __launch_bounds__(64) void k_dyn_pd_regulation(const MpBigModel<doubl
   const long k = (long)blockIdx.x * 64 + threadIdx.x;
   if (k >= K) return;
   MpBigConst<double>& M = *(MpBigConst<double>*)Mdev;
-  count[k] = mp_dyn_pd_regulation_run<double>(M, C.a0, theta0 + k * M.n, des + k * M.n, Kp[k], Kd[k], dt, steps, err + k * steps);
+  count[k] = mp_dyn_pd_regulation_run<CAP, double>(M, C.a0, theta0 + k * M.n, des + k * M.n, Kp[k], Kd[k], dt, steps, err + k * steps);
 }
 
 // inverse kinematics with a run-time joint count: the work queue of k_ik, the looped kinematics of mp_dyn.h
@@ -799,7 +815,7 @@ __global__ __launch_bounds__(kBlock) void k_dyn_ik(const MpBigModel<double>* __r
       mp_ik_begin(S, P);
       have = true;
     }
-    if (const int done = mp_ik_iterate<MP_BIG_DOF, MpIkLooped>(M, P, S, Tdes + row * 16, theta0 + row * n)) {
+    if (const int done = mp_ik_iterate<MP_BIG_DOF, MpIkLooped<MP_BIG_DOF>>(M, P, S, Tdes + row * 16, theta0 + row * n)) {
       for (int j = 0; j < n; ++j) theta[row * n + j] = S.theta[j];
       success[row] = done == 2 ? 1 : 0;
       iterations[row] = S.k + 1;
@@ -834,10 +850,10 @@ hipError_t mpk_pd_regulation(hipStream_t s, const MpModel<double>& M, const MpCa
   MP_DISPATCH_N(M.n, { hipLaunchKernelGGL((k_pd_regulation<N>), dim3((unsigned)((K + 63) / 64)), dim3(64), 0, s, M, C, theta0, des, Kp, Kd, K, dt, steps, err, count); })
   return hipGetLastError();
 }
-hipError_t mpk_dyn_pd_regulation(hipStream_t s, const MpBigModel<double>* d_model, const MpCall<double>& C, const double* theta0,
+hipError_t mpk_dyn_pd_regulation(hipStream_t s, int n, const MpBigModel<double>* d_model, const MpCall<double>& C, const double* theta0,
                                  const double* des, const double* Kp, const double* Kd, long K, double dt, int steps, double* err, int* count) {
   if (K <= 0) return hipSuccess;  // (steps == 0 still launches: every run reports a count of 0)
-  hipLaunchKernelGGL(k_dyn_pd_regulation, dim3((unsigned)((K + 63) / 64)), dim3(64), 0, s, d_model, C, theta0, des, Kp, Kd, K, dt, steps, err, count);
+  MP_DISPATCH_CAP(n, { hipLaunchKernelGGL((k_dyn_pd_regulation<CAP>), dim3((unsigned)((K + 63) / 64)), dim3(64), 0, s, d_model, C, theta0, des, Kp, Kd, K, dt, steps, err, count); })
   return hipGetLastError();
 }
 

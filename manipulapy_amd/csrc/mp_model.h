@@ -17,8 +17,9 @@
 #define MP_MAX_DOF 8    // fully unrolled kernels (model in kernel arguments / constexpr literal): 1..8 joints
 #endif
 #ifndef MP_BIG_DOF
-#define MP_BIG_DOF 16   // looped run-time-n kernels (csrc/mp_dyn.h, model in device memory): 9..16 joints
+#define MP_BIG_DOF 32   // looped run-time-n kernels (csrc/mp_dyn.h, model in device memory): 9..32 joints
 #endif
+#define MP_MID_DOF 16   // ... whose per-row arrays are instantiated for 16 and for MP_BIG_DOF joints: 9..16 keep the small ones
 
 template <typename T>
 struct MpJoint {

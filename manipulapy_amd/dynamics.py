@@ -72,7 +72,7 @@ class ManipulatorDynamics(SerialManipulator):
         dynamics kernel runs 3x faster with this robot's constants baked in)."""
         model = self.hip_model()
         if (rows >= 16384 and os.environ.get("MANIPULAPY_HIP_SPECIALIZE", "1") != "0" and not self._spec_tried
-                and model.n <= _hip.MP_MAX_DOF):   # (9..16 joints run the looped generic kernels: nothing to specialise)
+                and model.n <= _hip.MP_MAX_DOF):   # (9..32 joints run the looped generic kernels: nothing to specialise)
             from .registry import _hip_routing_enabled, get_context
 
             if _hip_routing_enabled():

@@ -229,7 +229,7 @@ def test_looped_rows_equal_the_unrolled_rows_on_the_benchmark_robots(robot, tabl
     monkeypatch.setenv("MANIPULAPY_HIP_LOOPED", "1")
     looped = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee, tab.joint_limits)
     monkeypatch.delenv("MANIPULAPY_HIP_LOOPED")
-    assert looped.blob()["joints"].shape == (16, 18) and unrolled.blob()["joints"].shape == (8, 18)
+    assert looped.blob()["joints"].shape == (32, 18) and unrolled.blob()["joints"].shape == (8, 18)
     q, qd, qdd = z["thetas"], z["dthetas"], z["ddthetas"]
     g = z["g"]
     for dtype, tol in ((np.float64, 1e-12), (np.float32, 2e-5)):
