@@ -63,6 +63,7 @@ struct mp_ctx {
     unsigned* ctrl = nullptr;     // two counters used alternately: the pass zeroes the one the list's NEXT user counts in
     unsigned cap = 0, uses = 0;
     bool busy = false;
+    bool orphan = false;          // attached to a launch whose pass never followed (a failed launch): its counters are reset on reuse
     unsigned long long seq = 0;   // launch order
     hipFunction_t fn = nullptr;   // the specialised pass of its model, or null: the generic one, run through `generic`
     std::function<int()> generic;
@@ -371,6 +372,8 @@ mp_ctx::HardSlot* attach_hard_list(mp_ctx* ctx, long rows, MpCall<float>* c) {
     if (hipMalloc((void**)&hs->rows, (size_t)need * sizeof(unsigned)) != hipSuccess) { hs->rows = nullptr; return nullptr; }
     hs->cap = need;
   }
+  if (hs->orphan && hipMemsetAsync(hs->ctrl, 0, 2 * sizeof(unsigned), ctx->compute) != hipSuccess) return nullptr;
+  hs->orphan = true;  // until its pass is parked (hard_defer) or launched (hard_passed)
   const unsigned turn = hs->uses++ & 1u;
   c->hard_rows = hs->rows; c->hard_ctrl = hs->ctrl + turn; c->hard_next = hs->ctrl + (turn ^ 1u); c->hard_cap = hs->cap;
   c->hard_row_base = 0;
@@ -380,10 +383,15 @@ unsigned hard_pass_blocks(long rows) {
   static const long cap = [] { const char* e = getenv("MANIPULAPY_HIP_HARD_BLOCKS"); return e ? std::max(1L, atol(e)) : 1024L; }();  // experiment switch
   return (unsigned)std::min<long>((rows / 8 + 63) / 64 + 1, cap);
 }
+// the pass of the list's launch has been enqueued directly (the fused paths); returns rc for tail calls
+inline int hard_passed(mp_ctx::HardSlot* hs, int rc) {
+  if (rc == MP_OK) hs->orphan = false;
+  return rc;
+}
 // park the pass of the launch just enqueued
 void hard_defer(mp_ctx* ctx, mp_ctx::HardSlot* hs, hipFunction_t fn, std::function<int()> generic, const MpCall<float>& C,
                 const float* q, const float* qd, const float* qdd, float* tau, long rows, int n) {
-  hs->busy = true; hs->seq = ++ctx->hard_seq; hs->fn = fn; hs->generic = std::move(generic); hs->C = C; hs->C.hard_row_base = 0;
+  hs->busy = true; hs->orphan = false; hs->seq = ++ctx->hard_seq; hs->fn = fn; hs->generic = std::move(generic); hs->C = C; hs->C.hard_row_base = 0;
   hs->q = q; hs->qd = qd; hs->qdd = qdd; hs->tau = tau; hs->nrows = (unsigned)rows; hs->bytes = (size_t)rows * (size_t)n * sizeof(float);
 }
 // run every parked pass on the compute stream, in launch order; passes of one specialised program share a kernel launch
@@ -400,11 +408,13 @@ int hard_flush(mp_ctx* ctx) {
     if (!h->fn) {  // generic kernels: one launch each
       if (rc == MP_OK) rc = h->generic();
       h->busy = false; h->generic = nullptr;
+      h->orphan = rc != MP_OK;
       ++i;
       continue;
     }
     MpHardBatch B;
     std::memset(&B, 0, sizeof B);
+    mp_ctx::HardSlot* ent[MP_HARD_BATCH];
     int m = 0;
     unsigned blocks = 1;
     while (i < k && order[i]->fn == h->fn && m < MP_HARD_BATCH) {
@@ -412,13 +422,14 @@ int hard_flush(mp_ctx* ctx) {
       B.C[m] = e->C; B.q[m] = e->q; B.qd[m] = e->qd; B.qdd[m] = e->qdd; B.tau[m] = e->tau; B.rows[m] = e->nrows;
       blocks = std::max(blocks, hard_pass_blocks((long)e->nrows));
       e->busy = false;
-      ++m;
+      ent[m++] = e;
     }
     if (rc == MP_OK) {
       void* args[] = {&B};
       hipError_t he = hipModuleLaunchKernel(h->fn, blocks, (unsigned)m, 1, 64, 1, 1, 0, ctx->compute, args, nullptr);
       if (he != hipSuccess) rc = hip_err(he, "float64 pass of the ill-conditioned float32 rows");
     }
+    for (int j = 0; j < m; ++j) ent[j]->orphan = rc != MP_OK;  // a pass that did not run leaves its list's counters as they are
   }
   return rc;
 }
@@ -1641,7 +1652,7 @@ int mp_traj_id_fused_f32(mp_ctx* ctx, const mp_model* model, const float* d_star
       if (!hs) return MP_OK;
       // (the generated rows' pass runs at once: it reads the per-call time table, which the next fused call may rewrite)
       void* hargs[] = {&c, &d_start, &d_end, &ntu, &tab, &d_tau, &rows};
-      return launch_spec(ctx, sp->traj_id_hard[ftip ? 1 : 0], (long)hard_pass_blocks((long)rows) * 64, hargs, 64);
+      return hard_passed(hs, launch_spec(ctx, sp->traj_id_hard[ftip ? 1 : 0], (long)hard_pass_blocks((long)rows) * 64, hargs, 64));
     }
     if (!mpk_packed_f32()) {  // MANIPULAPY_HIP_F32=scalar: one timestep per lane (measured slower: c2f 0.063 vs 0.054 ms)
       unsigned bpt = (unsigned)((nt + 255) / 256);
@@ -1657,7 +1668,7 @@ int mp_traj_id_fused_f32(mp_ctx* ctx, const mp_model* model, const float* d_star
     // (the generated rows' float64 pass runs at once: it reads the per-call time table, which the next fused call may rewrite)
     unsigned rows_u = (unsigned)rows_l, ntu = (unsigned)N;
     void* hargs[] = {&c, &d_start, &d_end, &ntu, &tab, &d_tau, &rows_u};
-    return launch_spec(ctx, sp->traj_id_hard[ftip ? 1 : 0], (long)hard_pass_blocks(rows_l) * 64, hargs, 64);
+    return hard_passed(hs, launch_spec(ctx, sp->traj_id_hard[ftip ? 1 : 0], (long)hard_pass_blocks(rows_l) * 64, hargs, 64));
   }
   {
     // generic kernels: the same hand-over (the float64 model and the float32 limits come from the device copy)
@@ -1666,9 +1677,11 @@ int mp_traj_id_fused_f32(mp_ctx* ctx, const mp_model* model, const float* d_star
     const MpModel<float>* dm = nullptr;
     if (c.cold_model && device_model(ctx, model, &dm) == MP_OK) hs = attach_hard_list(ctx, rows_l, &c);
     HIP_TRY(mpk_traj_id_tab(ctx->compute, model->f, c, ftip, d_start, d_end, (long)B, (long)N, ctx->time_tab, d_tau));
-    if (hs)
+    if (hs) {
       HIP_TRY(mpk_traj_id_hard(ctx->compute, dm, model->d.n, c, ftip, d_start, d_end, (unsigned)N, ctx->time_tab, d_tau, (unsigned)rows_l,
                                hard_pass_blocks(rows_l)));
+      (void)hard_passed(hs, MP_OK);
+    }
   }
   return MP_OK;
 }
