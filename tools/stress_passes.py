@@ -1,0 +1,128 @@
+#!/usr/bin/env python3
+"""Dev stress run (not part of the suite): random sequences of device-pointer float32 inverse-dynamics launches whose float64
+passes the context parks (csrc/mp_capi.cpp, hard_defer / hard_flush), on overlapping sub-ranges of shared device arrays - outputs
+landing in other launches' inputs and outputs, three models (two specialised programs and a generic one), interleaved with
+uploads, memsets, float64 launches and downloads.  A host mirror of every device array is advanced with what a SECOND context's
+host entry point returns for the same rows (it flushes at once); every download must equal its mirror bit for bit.
+
+    SEED=3 OPS=400 python tools/stress_passes.py
+"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import manipulapy_amd as mp  # noqa: E402
+from manipulapy_amd import _hip  # noqa: E402
+
+R = 24000  # rows per array
+
+
+def fast_rows(rng, lim, n, rows):
+    """rows of quintic point-to-point trajectories at bench speed: ~1 % of them ill-conditioned in float32"""
+    out = []
+    N = 600
+    for _ in range(-(-rows // N)):
+        a, b = rng.uniform(lim[:, 0], lim[:, 1], (2, n))
+        t = np.linspace(0.0, 1.0, N)[:, None]
+        s, sd, sdd = 10 * t**3 - 15 * t**4 + 6 * t**5, (30 * t**2 - 60 * t**3 + 30 * t**4) / 2.0, (60 * t - 180 * t**2 + 120 * t**3) / 4.0
+        out.append(np.stack([a + s * (b - a), sd * (b - a), sdd * (b - a)]))
+    o = np.concatenate(out, axis=1)[:, :rows].astype(np.float32)
+    return [np.ascontiguousarray(o[k]) for k in range(3)]
+
+
+def main():
+    seed, ops = int(os.environ.get("SEED", "0")), int(os.environ.get("OPS", "300"))
+    rng = np.random.default_rng(seed)
+    ctx, ref_ctx = _hip.HipContext(0), _hip.HipContext(0)
+    models = []
+    for robot, spec in (("ur5", True), ("xarm6", False), ("panda", True)):
+        t = mp.robot_tables(robot)
+        m = _hip.HipModel(t["S_list"], t["Mlist_per_link"], t["Glist"], t["M_ee"], t["joint_limits"])
+        if spec:
+            ctx.specialize(m); ref_ctx.specialize(m)
+        lim = np.asarray(t["joint_limits"], dtype=np.float64)
+        host = fast_rows(rng, lim, m.n, R) + [np.zeros((R, m.n), np.float32) for _ in range(3)]   # q, qd, qdd, tau0..2
+        dev = [ctx.to_device(a) for a in host]
+        flagged = int(_hip.cpu_id_row_precision(m, *host[:3]).sum())
+        models.append({"name": robot, "m": m, "n": m.n, "host": host, "dev": dev, "flagged": flagged})
+    launches = checks = 0
+    bad = []
+
+    def expected(M, rows_in, start, length):
+        sl = slice(start, start + length)
+        return ref_ctx.id_trajectory_host(M["m"], *(np.ascontiguousarray(M["host"][k][sl]) for k in rows_in), dtype=np.float32)
+
+    def check(M, k, what):
+        nonlocal checks
+        got = M["dev"][k].download((R, M["n"]), np.float32)
+        checks += 1
+        if not np.array_equal(got, M["host"][k], equal_nan=True):
+            diff = np.flatnonzero((got != M["host"][k]).any(axis=1))
+            bad.append((what, M["name"], k, len(diff), int(diff[0]), int(diff[-1])))
+            M["host"][k][:] = got   # carry on from what the device holds
+
+    for op in range(ops):
+        M = models[int(rng.integers(len(models)))]
+        n, rb = M["n"], M["n"] * 4
+        kind = rng.choice(["launch"] * 12 + ["launch_into_input"] * 2 + ["download", "memset", "upload", "f64", "fused", "sync"])
+        if kind in ("launch", "launch_into_input"):
+            length = int(rng.choice([1, 63, 64, 65, 200, 1000, int(rng.integers(1, 6000))]))
+            s_in, s_out = (2 * int(rng.integers(0, (R - length) // 2 + 1)) for _ in range(2))   # (device pointers: 16-byte aligned)
+            dst = int(rng.integers(0, 3)) if kind == "launch_into_input" else int(rng.integers(3, 6))
+            rows_in = (0, 1, 2)
+            if dst < 3 and not (s_out + length <= s_in or s_in + length <= s_out):
+                continue    # a launch whose output overlaps its OWN input rows is undefined for any kernel
+            want = expected(M, rows_in, s_in, length)
+            ctx.id_trajectory(M["m"], *(M["dev"][k].offset(s_in * rb) for k in rows_in), length, M["dev"][dst].offset(s_out * rb), dtype=np.float32)
+            M["host"][dst][s_out:s_out + length] = want
+            launches += 1
+        elif kind == "download":
+            check(M, int(rng.integers(0, 6)), f"op {op}")
+        elif kind == "memset":
+            k = int(rng.integers(3, 6))
+            a, b = sorted(int(x) for x in rng.integers(0, R + 1, 2))
+            if b > a:
+                ctx.memset(M["dev"][k].offset(a * rb), 0, (b - a) * rb)
+                M["host"][k][a:b] = 0
+        elif kind == "upload":
+            k = int(rng.integers(0, 6))
+            fresh = (M["host"][k] * np.float32(0.5)).astype(np.float32) if k < 3 else rng.uniform(-1, 1, (R, n)).astype(np.float32)
+            M["dev"][k].upload(fresh)
+            M["host"][k][:] = fresh
+        elif kind == "f64":    # another entry point altogether: parked passes run first
+            rows = 500
+            q64 = [ctx.to_device(M["host"][k][:rows].astype(np.float64)) for k in range(3)]
+            out = ctx.alloc(rows * n * 8)
+            ctx.id_trajectory(M["m"], *q64, rows, out, dtype=np.float64)
+            out.download((rows, n), np.float64)
+            for b_ in q64 + [out]:
+                b_.free()
+        elif kind == "fused":
+            B, N = 7, 300
+            lim = M["m"].joint_limits_f32()
+            st, en = rng.uniform(lim[:, 0], lim[:, 1], (2, B, n)).astype(np.float32)
+            k = int(rng.integers(3, 6))
+            s_out = 2 * int(rng.integers(0, (R - B * N) // 2 + 1))
+            want = ref_ctx.traj_id_fused_host(M["m"], st, en, 2.0, N, 5).reshape(-1, n)
+            ds, de = ctx.to_device(st), ctx.to_device(en)
+            ctx.traj_id_fused(M["m"], ds, de, B, N, 2.0, 5, M["dev"][k].offset(s_out * rb))
+            M["host"][k][s_out:s_out + B * N] = want
+            ctx.synchronize()
+            ds.free(); de.free()
+        else:
+            ctx.synchronize()
+    for M in models:
+        for k in range(6):
+            check(M, k, "end")
+    print(f"seed {seed}: {ops} ops, {launches} float32 launches, {checks} downloads, flagged rows per model "
+          f"{[M['flagged'] for M in models]}, mismatches {len(bad)}")
+    for b_ in bad[:10]:
+        print("  MISMATCH", b_)
+    ctx.destroy(); ref_ctx.destroy()
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
