@@ -71,7 +71,9 @@ struct mp_ctx {
     const float *q = nullptr, *qd = nullptr, *qdd = nullptr;
     float* tau = nullptr;
     unsigned nrows = 0;
-    size_t bytes = 0;             // of each of the four arrays
+    unsigned nt = 0;              // generated rows (the fused kernels): timesteps per trajectory, q / qd = start / end points, qdd = the time table
+    size_t bytes = 0;             // of the torque array
+    size_t bytes_in = 0;          // of each input array the caller owns (q, qd, qdd; start, end)
   };
   static constexpr int kHardSlots = MP_HARD_BATCH;
   HardSlot hard[kHardSlots];
@@ -363,7 +365,11 @@ mp_ctx::HardSlot* attach_hard_list(mp_ctx* ctx, long rows, MpCall<float>* c) {
   const unsigned need = (unsigned)std::min<long>(std::max<long>(rows / 8, 1L << 16), 1L << 28);
   if (hs->cap < need) {
     if (hipStreamSynchronize(ctx->compute) != hipSuccess) return nullptr;
-    if (!hs->ctrl && (hipMalloc((void**)&hs->ctrl, 2 * sizeof(unsigned)) != hipSuccess || hipMemset(hs->ctrl, 0, 2 * sizeof(unsigned)) != hipSuccess)) {
+    // (zeroed ON the compute stream: a plain hipMemset of device memory is not ordered with a kernel launched on another,
+    // non-blocking stream right behind it - a kernel that met the allocation's old bytes as its counter took the list for full and
+    // re-evaluated in place, correct but not bit-equal to the pass: seen once, as 27 elements of a 240 000-element comparison)
+    if (!hs->ctrl && (hipMalloc((void**)&hs->ctrl, 2 * sizeof(unsigned)) != hipSuccess ||
+                      hipMemsetAsync(hs->ctrl, 0, 2 * sizeof(unsigned), ctx->compute) != hipSuccess)) {
       hs->ctrl = nullptr;
       return nullptr;
     }
@@ -393,6 +399,14 @@ void hard_defer(mp_ctx* ctx, mp_ctx::HardSlot* hs, hipFunction_t fn, std::functi
                 const float* q, const float* qd, const float* qdd, float* tau, long rows, int n) {
   hs->busy = true; hs->orphan = false; hs->seq = ++ctx->hard_seq; hs->fn = fn; hs->generic = std::move(generic); hs->C = C; hs->C.hard_row_base = 0;
   hs->q = q; hs->qd = qd; hs->qdd = qdd; hs->tau = tau; hs->nrows = (unsigned)rows; hs->bytes = (size_t)rows * (size_t)n * sizeof(float);
+  hs->bytes_in = hs->bytes; hs->nt = 0;
+}
+// ... of a fused launch: its rows are generated from B start / end points and the context's time table, which therefore must
+// not be rewritten while the pass is parked (mp_traj_id_fused_f32 runs the parked passes before it touches the table)
+void hard_defer_generated(mp_ctx* ctx, mp_ctx::HardSlot* hs, hipFunction_t fn, const MpCall<float>& C, const float* start, const float* end,
+                          const double* tab, float* tau, long rows, int n, long B, unsigned nt) {
+  hard_defer(ctx, hs, fn, nullptr, C, start, end, (const float*)tab, tau, rows, n);
+  hs->bytes_in = (size_t)B * (size_t)n * sizeof(float); hs->nt = nt;
 }
 // run every parked pass on the compute stream, in launch order; passes of one specialised program share a kernel launch
 int hard_flush(mp_ctx* ctx) {
@@ -419,7 +433,7 @@ int hard_flush(mp_ctx* ctx) {
     unsigned blocks = 1;
     while (i < k && order[i]->fn == h->fn && m < MP_HARD_BATCH) {
       mp_ctx::HardSlot* e = order[i++];
-      B.C[m] = e->C; B.q[m] = e->q; B.qd[m] = e->qd; B.qdd[m] = e->qdd; B.tau[m] = e->tau; B.rows[m] = e->nrows;
+      B.C[m] = e->C; B.q[m] = e->q; B.qd[m] = e->qd; B.qdd[m] = e->qdd; B.tau[m] = e->tau; B.rows[m] = e->nrows; B.nt[m] = e->nt;
       blocks = std::max(blocks, hard_pass_blocks((long)e->nrows));
       e->busy = false;
       ent[m++] = e;
@@ -433,16 +447,18 @@ int hard_flush(mp_ctx* ctx) {
   }
   return rc;
 }
-// a float32 launch about to be enqueued on [lo, lo + bytes) arrays: parked passes that read or write any of them run first
+// a float32 launch about to be enqueued on [lo, lo + bytes) arrays: parked passes run first if they read or write what it writes, or
+// write what it reads
 int hard_flush_if_overlapping(mp_ctx* ctx, const void* const* lo, const size_t* bytes, int k) {
   for (auto& hs : ctx->hard) {
     if (!hs.busy) continue;
-    const char* mine[4] = {(const char*)hs.q, (const char*)hs.qd, (const char*)hs.qdd, (const char*)hs.tau};
-    for (int i = 0; i < k; ++i) {
+    const char* mine[4] = {(const char*)hs.q, (const char*)hs.qd, hs.nt ? nullptr : (const char*)hs.qdd, (const char*)hs.tau};
+    const size_t size[4] = {hs.bytes_in, hs.bytes_in, hs.bytes_in, hs.bytes};
+    for (int i = 0; i < k; ++i) {  // lo[k - 1] is the array the launch WRITES, the others it reads: two reads do not conflict
       const char* a = (const char*)lo[i];
       if (!a) continue;
-      for (const char* b : mine)
-        if (b && a < b + hs.bytes && b < a + bytes[i]) return hard_flush(ctx);
+      for (int j = i == k - 1 ? 0 : 3; j < 4; ++j)
+        if (mine[j] && a < mine[j] + size[j] && mine[j] < a + bytes[i]) return hard_flush(ctx);
     }
   }
   return MP_OK;
@@ -1596,7 +1612,14 @@ int mp_id_trajectory_f64(mp_ctx* ctx, const mp_model* model, const double* d_q, 
 
 int mp_traj_id_fused_f32(mp_ctx* ctx, const mp_model* model, const float* d_start, const float* d_end, int64_t B,
                          int64_t N, double Tf, int method, const double* g, const double* Ftip, float* d_tau) {
-  CHECK_COMMON("mp_traj_id_fused_f32");
+  REQUIRE(ctx && model, "mp_traj_id_fused_f32: null context or model");
+  CTX_ENTER_NOJOIN(ctx);
+  {  // parked float64 passes run first only where they touch this launch's arrays (as in id_impl): its own pass is parked too
+    const size_t in_b = (size_t)(B > 0 ? B : 0) * (size_t)model->d.n * sizeof(float), out_b = in_b * (size_t)(N > 0 ? N : 0);
+    const void* lo[3] = {d_start, d_end, d_tau};
+    const size_t by[3] = {in_b, in_b, out_b};
+    if (int rc = ctx->profiling ? hard_flush(ctx) : hard_flush_if_overlapping(ctx, lo, by, 3)) return rc;
+  }
   REQUIRE(B >= 0 && N >= 0, "mp_traj_id_fused_f32: negative B (%lld) or N (%lld)", (long long)B, (long long)N);
   if (B == 0 || N == 0) return MP_OK;
   REQUIRE(d_start && d_end && d_tau, "mp_traj_id_fused_f32: null device pointer");
@@ -1619,6 +1642,7 @@ int mp_traj_id_fused_f32(mp_ctx* ctx, const mp_model* model, const float* d_star
   // per-timestep table of (s, s', s''): rebuilt on the stream only when (N, Tf, method) differ from the last call
   if (ctx->tab_cap < (long)N) {
     REQUIRE(!ctx->capturing, "mp_traj_id_fused_f32: the first call for this N allocates; run it once before capturing a launch graph");
+    if (int rc = hard_flush(ctx)) return rc;      // parked passes of fused launches read the old table
     HIP_TRY(hipStreamSynchronize(ctx->compute));  // earlier kernels may still read the old table
     if (ctx->time_tab && ctx->tab_volatile) ctx->retired_tabs.push_back(ctx->time_tab);  // a launch graph still points at it
     else if (ctx->time_tab) (void)hipFree(ctx->time_tab);
@@ -1631,6 +1655,7 @@ int mp_traj_id_fused_f32(mp_ctx* ctx, const mp_model* model, const float* d_star
   // call then writes its own table first (one extra ~2 us kernel, stream-ordered before the kernel that reads it).
   if (ctx->capturing) ctx->tab_volatile = true;
   if (ctx->tab_volatile || ctx->tab_Nt != (long)N || ctx->tab_Tf != Tf || ctx->tab_method != method) {
+    if (int rc = hard_flush(ctx)) return rc;      // (as above)
     HIP_TRY(mpk_time_table(ctx->compute, ctx->time_tab, (long)N, Tf, method));
     ctx->tab_Nt = (long)N; ctx->tab_Tf = Tf; ctx->tab_method = method;
   }
@@ -1650,9 +1675,8 @@ int mp_traj_id_fused_f32(mp_ctx* ctx, const mp_model* model, const float* d_star
       void* args[] = {&c, &d_start, &d_end, &ntu, &magic, &tab, &d_tau, &rows};
       if (int rc = launch_spec(ctx, sp->traj_id_co[ftip ? 1 : 0], (long)rows, args, 64)) return rc;
       if (!hs) return MP_OK;
-      // (the generated rows' pass runs at once: it reads the per-call time table, which the next fused call may rewrite)
-      void* hargs[] = {&c, &d_start, &d_end, &ntu, &tab, &d_tau, &rows};
-      return hard_passed(hs, launch_spec(ctx, sp->traj_id_hard[ftip ? 1 : 0], (long)hard_pass_blocks((long)rows) * 64, hargs, 64));
+      hard_defer_generated(ctx, hs, sp->traj_id_hard[ftip ? 1 : 0], c, d_start, d_end, tab, d_tau, (long)rows, model->d.n, (long)B, ntu);
+      return ctx->tab_volatile ? hard_flush(ctx) : (int)MP_OK;  // (a table rewritten by every call cannot wait for a parked pass)
     }
     if (!mpk_packed_f32()) {  // MANIPULAPY_HIP_F32=scalar: one timestep per lane (measured slower: c2f 0.063 vs 0.054 ms)
       unsigned bpt = (unsigned)((nt + 255) / 256);
@@ -1665,10 +1689,11 @@ int mp_traj_id_fused_f32(mp_ctx* ctx, const mp_model* model, const float* d_star
     void* args[] = {&c, &d_start, &d_end, &nt, &bpt, &tab, &d_tau};
     if (int rc = launch_spec(ctx, sp->traj_id_pk[ftip ? 1 : 0], (long)B * bpt * 256, args)) return rc;
     if (!hs) return MP_OK;
-    // (the generated rows' float64 pass runs at once: it reads the per-call time table, which the next fused call may rewrite)
-    unsigned rows_u = (unsigned)rows_l, ntu = (unsigned)N;
-    void* hargs[] = {&c, &d_start, &d_end, &ntu, &tab, &d_tau, &rows_u};
-    return hard_passed(hs, launch_spec(ctx, sp->traj_id_hard[ftip ? 1 : 0], (long)hard_pass_blocks(rows_l) * 64, hargs, 64));
+    // the generated rows' float64 pass is parked like a given-rows launch's; it reads the time table, so a call that rewrites the
+    // table runs the parked passes first (above)
+    hard_defer_generated(ctx, hs, sp->traj_id_hard[ftip ? 1 : 0], c, d_start, d_end, tab, d_tau, rows_l, model->d.n, (long)B, (unsigned)N);
+    static const bool park = !(getenv("MANIPULAPY_HIP_FUSED_PARK") && getenv("MANIPULAPY_HIP_FUSED_PARK")[0] == '0');  // experiment switch
+    return ctx->tab_volatile || !park ? hard_flush(ctx) : (int)MP_OK;  // (a table rewritten by every call cannot wait for a parked pass)
   }
   {
     // generic kernels: the same hand-over (the float64 model and the float32 limits come from the device copy)
@@ -1744,6 +1769,7 @@ int mp_traj_id_fused_host_f32(mp_ctx* ctx, const mp_model* model, const float* s
   H2D(ds, start, in_b);
   H2D(de, end, in_b);
   if (int rc = mp_traj_id_fused_f32(ctx, model, (float*)ds, (float*)de, B, N, Tf, method, g, Ftip, (float*)dt)) return rc;
+  if (int rc = hard_flush(ctx)) return rc;  // the launch's float64 pass, parked: the download reads its rows
   D2H(tau, dt, out_b);
   HIP_TRY(hipStreamSynchronize(ctx->compute));
   return MP_OK;

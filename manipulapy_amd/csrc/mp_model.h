@@ -89,4 +89,7 @@ struct MpHardBatch {
   const float* qdd[MP_HARD_BATCH];
   float* tau[MP_HARD_BATCH];
   unsigned rows[MP_HARD_BATCH];
+  // passes over GENERATED rows (the fused trajectory + inverse-dynamics kernels): q = the start points, qd = the end points (B, n),
+  // qdd = the per-timestep time-scaling table (doubles), nt = timesteps per trajectory; 0 for given rows
+  unsigned nt[MP_HARD_BATCH];
 };

@@ -2303,5 +2303,28 @@ def test_float64_pass_is_parked_and_run_before_anything_can_see_the_difference(s
         # (5) nothing parked, nothing to run: an empty launch and a synchronise are fine
         ctx.id_trajectory(m, *sets[5]["d"], 0, sets[5]["d_tau"], dtype=np.float32)
         ctx.synchronize()
+        # (6) the fused generation + inverse dynamics parks its pass too (specialised kernels; it re-reads the end points and the
+        # context's time table): five launches back to back on their own outputs, then one with another N - which rewrites the table,
+        # so the parked passes run first - then the end points of a parked launch replaced through the API
+        B, N = 9, 700
+        pairs = [rng.uniform(lim[:, 0], lim[:, 1], (2, B, 6)).astype(np.float32) for _ in range(6)]
+        want = [ctx.traj_id_fused_host(m, se[0], se[1], 2.0, N, 5) for se in pairs]
+        d_se = [(ctx.to_device(se[0]), ctx.to_device(se[1])) for se in pairs]
+        d_out = [ctx.alloc(B * N * 6 * 4) for _ in pairs]
+        for (ds, de), do in zip(d_se[:5], d_out[:5]):
+            ctx.traj_id_fused(m, ds, de, B, N, 2.0, 5, do)
+        other = ctx.traj_id_fused_host(m, pairs[5][0], pairs[5][1], 1.5, N - 43, 5)       # host entry: flushes, rewrites the table
+        ctx.traj_id_fused(m, *d_se[5], B, N - 43, 1.5, 5, d_out[5])
+        for k in range(5):
+            np.testing.assert_array_equal(d_out[k].download((B, N, 6), np.float32), want[k])
+        np.testing.assert_array_equal(d_out[5].download((B, N - 43, 6), np.float32), other)
+        ctx.traj_id_fused(m, *d_se[0], B, N, 2.0, 5, d_out[0])
+        d_se[0][1].upload(pairs[1][1])                                   # an entry point: the parked pass ran on the OLD end points
+        np.testing.assert_array_equal(d_out[0].download((B, N, 6), np.float32), want[0])
+        ctx.traj_id_fused(m, *d_se[0], B, N, 2.0, 5, d_out[0])
+        np.testing.assert_array_equal(d_out[0].download((B, N, 6), np.float32), ctx.traj_id_fused_host(m, pairs[0][0], pairs[1][1], 2.0, N, 5))
+        w64 = c_oracle.inverse_dynamics_rows(tab, *(ref.batch_joint_trajectory(lim, pairs[2][0], pairs[2][1], 2.0, N, 5)[key].reshape(-1, 6).astype(np.float64)
+                                                    for key in ("positions", "velocities", "accelerations")))[0]
+        assert_f32(want[2].reshape(-1, 6), w64)
     finally:
         ctx.destroy()

@@ -710,8 +710,12 @@ def test_bench_self_launches_one_worker_per_gpu():
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     for world in (2, 3):
-        res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1"], env=env,
-                             capture_output=True, text=True, timeout=300)
+        for attempt in range(2):   # (the launcher's port is picked by bind(0) and released before the workers take it: a CPU-only
+            # rehearsal may lose that race to another process of a busy box once)
+            res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1"], env=env,
+                                 capture_output=True, text=True, timeout=300)
+            if res.returncode == 0:
+                break
         assert res.returncode == 0, res.stderr[-2000:]
         line = json.loads(res.stdout.strip().splitlines()[-1])
         assert line["dryrun"] and line["n_gpus"] == world and line["max_rank_seen"] == world - 1.0 and line["broadcast_ok"]
