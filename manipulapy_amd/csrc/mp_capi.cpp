@@ -328,8 +328,11 @@ int device_model(mp_ctx* ctx, const mp_model* model, const MpModel<float>** out)
   if (it == ctx->dev_models.end()) {
     void* d = nullptr;
     if (int rc = mp_malloc(ctx, kDevModelD + sizeof(MpModel<double>), &d)) return rc;
-    HIP_TRY(hipMemcpy(d, &model->f, sizeof(MpModel<float>), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy((char*)d + kDevModelD, &model->d, sizeof(MpModel<double>), hipMemcpyHostToDevice));
+    // (on the compute stream and waited for: the first kernel that reads the copy follows on that stream, and the streams are
+    // non-blocking - nothing orders them with a copy on the null stream)
+    HIP_TRY(hipMemcpyAsync(d, &model->f, sizeof(MpModel<float>), hipMemcpyHostToDevice, ctx->compute));
+    HIP_TRY(hipMemcpyAsync((char*)d + kDevModelD, &model->d, sizeof(MpModel<double>), hipMemcpyHostToDevice, ctx->compute));
+    HIP_TRY(hipStreamSynchronize(ctx->compute));
     it = ctx->dev_models.emplace(model->uid, d).first;
   }
   *out = static_cast<const MpModel<float>*>(it->second);
@@ -483,7 +486,8 @@ int device_big_model(mp_ctx* ctx, const mp_model* model, const MpBigModel<T>** o
     REQUIRE(!ctx->capturing, "a model with more than %d joints is uploaded on first use: call once before capturing a launch graph", MP_MAX_DOF);
     void* d = nullptr;
     if (int rc = mp_malloc(ctx, sizeof(MpBigModel<T>), &d)) return rc;
-    HIP_TRY(hipMemcpy(d, &pick_big<T>(model), sizeof(MpBigModel<T>), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpyAsync(d, &pick_big<T>(model), sizeof(MpBigModel<T>), hipMemcpyHostToDevice, ctx->compute));  // (as device_model)
+    HIP_TRY(hipStreamSynchronize(ctx->compute));
     it = table.emplace(model->uid, d).first;
   }
   *out = static_cast<const MpBigModel<T>*>(it->second);
