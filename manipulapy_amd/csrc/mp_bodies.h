@@ -171,16 +171,16 @@ constexpr int MP_COLD_G = 8;  // slots of the kernels that carry a buffer of the
 #define MP_COLD_PTR (mp_cold_lds[threadIdx.x >> 6])
 
 // Hand the wave's flagged rows to the float64 pass that follows this kernel on the stream: one atomic per wave reserves the
-// places, every flagged lane writes its row index.  False (nothing handed over) without a list or when it is full.
+// places, every flagged lane writes its row index.  False (nothing handed over) without a list.  A FULL list counts as handed
+// over: the count then exceeds the capacity, which tells the pass to evaluate every row of the launch (mp_body_id_hard).
 __device__ __forceinline__ bool mp_push_hard_rows(const MpCall<float>& C, unsigned long long mask, int rank, bool hard, long row) {
   if (C.hard_rows == nullptr) return false;                   // wave-uniform (kernel argument)
   const unsigned n = (unsigned)__builtin_popcountll(mask);
   unsigned base = 0;
   if (rank == 0 && hard) base = atomicAdd(C.hard_ctrl, n);  // the first flagged lane
   base = __builtin_amdgcn_readlane(base, (int)__builtin_ctzll(mask));
-  if (base + n > C.hard_cap) return false;                    // full: wave-uniform; the count overshoots, the pass clamps it
-  if (hard) C.hard_rows[base + (unsigned)rank] = C.hard_row_base + (unsigned)row;
-  return true;
+  if (base + n <= C.hard_cap && hard) C.hard_rows[base + (unsigned)rank] = C.hard_row_base + (unsigned)row;
+  return true;                                                // (full: the count has overshot, the pass takes every row)
 }
 
 // True (wave-uniform) when flagged rows were re-evaluated HERE - tau of the flagged lanes then holds the float64 result; false when
@@ -222,11 +222,17 @@ __device__ __forceinline__ bool mp_cold_rows(const MT& M, const MpCall<float>& C
 template <int N, bool HAS_FTIP, typename MC, typename MF, typename LoadFn>
 __device__ __forceinline__ void mp_body_id_hard(const MC& Mc, const MF& M, const MpCall<float>& C, LoadFn load, float* __restrict__ tau,
                                                 unsigned rows) {
-  unsigned n = C.hard_ctrl[0];
-  n = n < C.hard_cap ? n : C.hard_cap;
+  // A list that overflowed (more than one row in eight AND more than 65 536 of a launch ill-conditioned: an arm balanced upright for
+  // a whole trajectory) holds an arbitrary subset - which waves found room depends on their order - and the rest were re-evaluated in
+  // place by rolled code whose last bits differ from this pass's.  So that the launch's result does not depend on the order of its
+  // waves, the pass then evaluates EVERY row of the launch: float64 throughout, three times the float32 kernel's time, same bits
+  // every time (tests/test_gpu_parity.py, test_more_ill_conditioned_rows_than_the_list_holds).
+  const unsigned count = C.hard_ctrl[0];
+  const bool all = count > C.hard_cap;
+  const unsigned n = all ? rows : count;
   const unsigned stride = gridDim.x * blockDim.x;
   for (unsigned k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
-    const long r = (long)C.hard_rows[k];
+    const long r = all ? (long)k : (long)C.hard_rows[k];
     if (r >= (long)rows) continue;  // (a list left behind by a launch whose pass never ran)
     float q[N], qd[N], qdd[N];
     load(r, q, qd, qdd);

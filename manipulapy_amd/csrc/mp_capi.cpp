@@ -352,8 +352,8 @@ void make_call_f32(mp_ctx* ctx, const mp_model* model, const double* g, const do
   if (it != ctx->dev_models.end()) c->cold_model = (const char*)it->second + kDevModelD;
 }
 // The list a float32 inverse-dynamics launch of `rows` rows leaves its ill-conditioned rows in for the float64 pass
-// (csrc/mp_bodies.h, mp_push_hard_rows / mp_body_id_hard): room for one row in eight (c2-distributed rows flag 0.5 - 1.5 %; a wave
-// that finds the list full re-evaluates its rows itself).  Returns the slot (c carries its pointers), or null = no list, the
+// (csrc/mp_bodies.h, mp_push_hard_rows / mp_body_id_hard): room for one row in eight, at least 65 536 (c2-distributed rows flag 0.5 - 1.5 %; a list that
+// overflows makes the pass evaluate every row of the launch).  Returns the slot (c carries its pointers), or null = no list, the
 // kernels re-evaluate in place: more than 2^32 rows, a graph capture (a replay would meet a used list), or the switch.
 mp_ctx::HardSlot* attach_hard_list(mp_ctx* ctx, long rows, MpCall<float>* c) {
   static const bool on = !(getenv("MANIPULAPY_HIP_HARD_PASS") && getenv("MANIPULAPY_HIP_HARD_PASS")[0] == '0');  // experiment switch

@@ -2328,3 +2328,44 @@ def test_float64_pass_is_parked_and_run_before_anything_can_see_the_difference(s
         assert_f32(want[2].reshape(-1, 6), w64)
     finally:
         ctx.destroy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("specialise", [False, True])
+def test_more_ill_conditioned_rows_than_the_list_holds(specialise, tables):
+    """An arm balanced upright: joint forces carry its weight, every torque is ~0.1 N.m - EVERY row is ill-conditioned in float32.  The
+    list a launch hands its rows to the float64 pass in holds one row in eight (at least 65 536): past that the count tells the pass
+    to evaluate EVERY row of the launch (csrc/mp_bodies.h, mp_push_hard_rows / mp_body_id_hard), so that the result does not depend on
+    which waves found room.  Every row inside a tenth of the float32 bound, and twice the same launch gives the same bits."""
+    from manipulapy_amd import _hip
+    from oracle import c_oracle
+
+    tab = tables["ur5"]
+    rng = np.random.default_rng(5)
+    rows = 600_000 + 37
+    q = (np.array([0.0, -np.pi / 2, 0.0, -np.pi / 2, 0.0, 0.0]) + rng.uniform(-2e-3, 2e-3, (rows, 6))).astype(np.float32)
+    z = np.zeros_like(q)
+    ctx = _hip.HipContext(0)
+    try:
+        m = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee, tab.joint_limits)
+        if specialise:
+            ctx.specialize(m)
+        assert _hip.cpu_id_row_precision(m, q[:4096], z[:4096], z[:4096]).all()
+        d = [ctx.to_device(a) for a in (q, z, z)]
+        d_tau = ctx.alloc(q.nbytes)
+        got = []
+        for _ in range(2):
+            ctx.memset(d_tau, 0, q.nbytes)
+            ctx.id_trajectory(m, *d, rows, d_tau, dtype=np.float32)
+            got.append(d_tau.download(q.shape, np.float32))
+        np.testing.assert_array_equal(got[0], got[1])
+        sample = np.r_[0:3000, rows - 3000:rows]
+        want = c_oracle.inverse_dynamics_rows(tab, q[sample].astype(np.float64), z[sample].astype(np.float64), z[sample].astype(np.float64))[0]
+        err = np.abs(got[0][sample].astype(np.float64) - want)
+        tol = 1e-4 * np.abs(want) + 5e-6 * np.abs(want).max(axis=1, keepdims=True)
+        assert (err / tol).max() < 0.1, float((err / tol).max())   # float32 rows of this kind sit at 1 - 5 x the bound
+        f64 = ctx.id_trajectory_host(m, q[sample], z[sample], z[sample], dtype=np.float64)
+        np.testing.assert_allclose(got[0][sample], f64, rtol=0, atol=2e-7)
+    finally:
+        ctx.destroy()
+
