@@ -41,6 +41,7 @@
 #define MP_HAS_PACKED 1
 typedef float mp_f2 __attribute__((ext_vector_type(2)));
 typedef int mp_i2 __attribute__((ext_vector_type(2)));
+typedef unsigned mp_u2 __attribute__((ext_vector_type(2)));
 #endif
 
 template <typename T> struct MpTraits;
@@ -76,8 +77,15 @@ MP_HD void mp_sincos(float x, float& s, float& c) {
   const int q = (int)k;
   const float a = (q & 1) ? pc : ps;
   const float b = (q & 1) ? ps : pc;
+#if defined(MP_SINCOS_SELECT_SIGNS)   // A/B switch: the signs by compare + select, as until round 4 (same bits, one instruction more)
   s = (q & 2) ? -a : a;
   c = ((q + 1) & 2) ? -b : b;
+#else
+  // the signs straight from the quadrant's bits: bit 1 of q (sine) and of q + 1 (cosine) moved to bit 31 and XORed in
+  const unsigned qs = (unsigned)q << 30;
+  s = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, a) ^ (qs & 0x80000000u));
+  c = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, b) ^ ((qs + 0x40000000u) & 0x80000000u));
+#endif
 }
 // double: the same structure in float64 - reduction by pi/2 carried in three FMAs (pi/2 split in a 53-bit head and two
 // tails; inside an FMA the product k * head is exact, so x - k pi/2 keeps full accuracy for every |x| whose own
@@ -106,8 +114,14 @@ MP_HD void mp_sincos(double x, double& s, double& c) {
   const int q = (int)(k - 4.0 * floor(k * 0.25));  // k mod 4 in {0, 1, 2, 3}
   const double a = (q & 1) ? pc : ps;
   const double b = (q & 1) ? ps : pc;
+#if defined(MP_SINCOS_SELECT_SIGNS)
   s = (q & 2) ? -a : a;
   c = ((q + 1) & 2) ? -b : b;
+#else
+  const unsigned qs = (unsigned)q << 30;  // (as the float routine: the signs from the quadrant's bits)
+  s = __builtin_bit_cast(double, __builtin_bit_cast(unsigned long long, a) ^ ((unsigned long long)(qs & 0x80000000u) << 32));
+  c = __builtin_bit_cast(double, __builtin_bit_cast(unsigned long long, b) ^ ((unsigned long long)((qs + 0x40000000u) & 0x80000000u) << 32));
+#endif
 }
 #if MP_HAS_PACKED
 // the same algorithm on two rows at once (packed FMAs; rint / cvt / selects stay per component)
@@ -126,8 +140,14 @@ MP_HD void mp_sincos(mp_f2 x, mp_f2& s, mp_f2& c) {
   const mp_i2 odd = (q & 1) != 0;
   const mp_f2 a = odd ? pc : ps;
   const mp_f2 b = odd ? ps : pc;
+#if defined(MP_SINCOS_SELECT_SIGNS)
   s = ((q & 2) != 0) ? -a : a;
   c = (((q + 1) & 2) != 0) ? -b : b;
+#else
+  const mp_u2 qs = __builtin_bit_cast(mp_u2, q) << 30;  // (as the scalar routine: the signs from the quadrant's bits)
+  s = __builtin_bit_cast(mp_f2, __builtin_bit_cast(mp_u2, a) ^ (qs & 0x80000000u));
+  c = __builtin_bit_cast(mp_f2, __builtin_bit_cast(mp_u2, b) ^ ((qs + 0x40000000u) & 0x80000000u));
+#endif
 }
 #endif
 
