@@ -64,7 +64,14 @@ template <> struct MpTraits<mp_f2> {
 // float: Cody-Waite reduction by pi/2 (two FMAs, exact enough for |x| < ~1e4) + the classic minimax
 // polynomials on [-pi/4, pi/4]; ~1 ulp, branch-free, ~24 VALU instructions for BOTH results.
 MP_HD void mp_sincos(float x, float& s, float& c) {
+#if !defined(MP_SINCOS_RNDNE)
+  // x * 2/pi rounded to an integer by adding 1.5 * 2^23 inside the FMA: the sum's low mantissa bits ARE the quadrant (|x| < 6e6),
+  // one instruction less than multiply + v_rndne + v_cvt (round 4: c2 -1.6 %, c5 -0.5 %, profiles/r04_ab_sincos_signs.txt)
+  const float kf = fmaf(x, 0.636619772367581343f, 12582912.0f);
+  const float k = kf - 12582912.0f;
+#else   // A/B switch: as until round 4
   const float k = rintf(x * 0.636619772367581343f);
+#endif
   float r = fmaf(-k, 1.57079637050628662109375f, x);
   r = fmaf(-k, -4.37113900018624283e-8f, r);
   const float r2 = r * r;
@@ -74,7 +81,11 @@ MP_HD void mp_sincos(float x, float& s, float& c) {
   float pc = fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
   pc = fmaf(r2, pc, 4.166664568298827e-2f);
   pc = fmaf(r2 * r2, pc, fmaf(r2, -0.5f, 1.0f));
+#if !defined(MP_SINCOS_RNDNE)
+  const int q = __builtin_bit_cast(int, kf);
+#else
   const int q = (int)k;
+#endif
   const float a = (q & 1) ? pc : ps;
   const float b = (q & 1) ? ps : pc;
 #if defined(MP_SINCOS_SELECT_SIGNS)   // A/B switch: the signs by compare + select, as until round 4 (same bits, one instruction more)
@@ -126,7 +137,12 @@ MP_HD void mp_sincos(double x, double& s, double& c) {
 #if MP_HAS_PACKED
 // the same algorithm on two rows at once (packed FMAs; rint / cvt / selects stay per component)
 MP_HD void mp_sincos(mp_f2 x, mp_f2& s, mp_f2& c) {
+#if !defined(MP_SINCOS_RNDNE)
+  const mp_f2 kf = __builtin_elementwise_fma(x, (mp_f2)(0.636619772367581343f), (mp_f2)(12582912.0f));
+  const mp_f2 k = kf - 12582912.0f;
+#else
   const mp_f2 k = __builtin_elementwise_rint(x * 0.636619772367581343f);
+#endif
   mp_f2 r = __builtin_elementwise_fma(-k, (mp_f2)(1.57079637050628662109375f), x);
   r = __builtin_elementwise_fma(-k, (mp_f2)(-4.37113900018624283e-8f), r);
   const mp_f2 r2 = r * r;
@@ -136,7 +152,11 @@ MP_HD void mp_sincos(mp_f2 x, mp_f2& s, mp_f2& c) {
   mp_f2 pc = __builtin_elementwise_fma(r2, (mp_f2)(2.443315711809948e-5f), (mp_f2)(-1.388731625493765e-3f));
   pc = __builtin_elementwise_fma(r2, pc, (mp_f2)(4.166664568298827e-2f));
   pc = __builtin_elementwise_fma(r2 * r2, pc, __builtin_elementwise_fma(r2, (mp_f2)(-0.5f), (mp_f2)(1.0f)));
+#if !defined(MP_SINCOS_RNDNE)
+  const mp_i2 q = __builtin_bit_cast(mp_i2, kf);
+#else
   const mp_i2 q = __builtin_convertvector(k, mp_i2);
+#endif
   const mp_i2 odd = (q & 1) != 0;
   const mp_f2 a = odd ? pc : ps;
   const mp_f2 b = odd ? ps : pc;
