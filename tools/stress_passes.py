@@ -5,7 +5,7 @@ landing in other launches' inputs and outputs, three models (two specialised pro
 uploads, memsets, float64 launches and downloads.  A host mirror of every device array is advanced with what a SECOND context's
 host entry point returns for the same rows (it flushes at once); every download must equal its mirror bit for bit.
 
-    SEED=3 OPS=400 python tools/stress_passes.py
+    SEED=3 OPS=400 [THREADS=3] python tools/stress_passes.py      (THREADS: the models are dealt out to threads sharing both contexts)
 """
 import os
 import sys
@@ -49,6 +49,7 @@ def main():
         models.append({"name": robot, "m": m, "n": m.n, "host": host, "dev": dev, "flagged": flagged})
     launches = checks = 0
     bad, held = [], []
+    nthreads = int(os.environ.get("THREADS", "1"))   # > 1: the models are dealt out to threads that share BOTH contexts
 
     def expected(M, rows_in, start, length):
         sl = slice(start, start + length)
@@ -63,56 +64,70 @@ def main():
             bad.append((what, M["name"], k, len(diff), int(diff[0]), int(diff[-1])))
             M["host"][k][:] = got   # carry on from what the device holds
 
-    for op in range(ops):
-        M = models[int(rng.integers(len(models)))]
-        n, rb = M["n"], M["n"] * 4
-        kind = rng.choice(["launch"] * 10 + ["launch_into_input"] * 2 + ["fused"] * 4 + ["download", "memset", "upload", "f64", "sync"])
-        if kind in ("launch", "launch_into_input"):
-            length = int(rng.choice([1, 63, 64, 65, 200, 1000, int(rng.integers(1, 6000))]))
-            s_in, s_out = (2 * int(rng.integers(0, (R - length) // 2 + 1)) for _ in range(2))   # (device pointers: 16-byte aligned)
-            dst = int(rng.integers(0, 3)) if kind == "launch_into_input" else int(rng.integers(3, 6))
-            rows_in = (0, 1, 2)
-            if dst < 3 and not (s_out + length <= s_in or s_in + length <= s_out):
-                continue    # a launch whose output overlaps its OWN input rows is undefined for any kernel
-            want = expected(M, rows_in, s_in, length)
-            ctx.id_trajectory(M["m"], *(M["dev"][k].offset(s_in * rb) for k in rows_in), length, M["dev"][dst].offset(s_out * rb), dtype=np.float32)
-            M["host"][dst][s_out:s_out + length] = want
-            launches += 1
-        elif kind == "download":
-            check(M, int(rng.integers(0, 6)), f"op {op}")
-        elif kind == "memset":
-            k = int(rng.integers(3, 6))
-            a, b = sorted(int(x) for x in rng.integers(0, R + 1, 2))
-            if b > a:
-                ctx.memset(M["dev"][k].offset(a * rb), 0, (b - a) * rb)
-                M["host"][k][a:b] = 0
-        elif kind == "upload":
-            k = int(rng.integers(0, 6))
-            fresh = (M["host"][k] * np.float32(0.5)).astype(np.float32) if k < 3 else rng.uniform(-1, 1, (R, n)).astype(np.float32)
-            M["dev"][k].upload(fresh)
-            M["host"][k][:] = fresh
-        elif kind == "f64":    # another entry point altogether: parked passes run first
-            rows = 500
-            q64 = [ctx.to_device(M["host"][k][:rows].astype(np.float64)) for k in range(3)]
-            out = ctx.alloc(rows * n * 8)
-            ctx.id_trajectory(M["m"], *q64, rows, out, dtype=np.float64)
-            out.download((rows, n), np.float64)
-            for b_ in q64 + [out]:
-                b_.free()
-        elif kind == "fused":
-            B, N = 7, int(rng.choice([300, 300, 300, 257]))     # (a new N or Tf rewrites the time table: parked passes run first)
-            Tf = float(rng.choice([2.0, 2.0, 2.0, 1.5]))
-            lim = M["m"].joint_limits_f32()
-            st, en = rng.uniform(lim[:, 0], lim[:, 1], (2, B, n)).astype(np.float32)
-            k = int(rng.integers(3, 6))
-            s_out = 2 * int(rng.integers(0, (R - B * N) // 2 + 1))
-            want = ref_ctx.traj_id_fused_host(M["m"], st, en, Tf, N, 5).reshape(-1, n)
-            ds, de = ctx.to_device(st), ctx.to_device(en)
-            ctx.traj_id_fused(M["m"], ds, de, B, N, Tf, 5, M["dev"][k].offset(s_out * rb))
-            M["host"][k][s_out:s_out + B * N] = want
-            held.append((ds, de))       # the launch's float64 pass is parked and re-reads the end points: freed at the end
-        else:
-            ctx.synchronize()
+    import threading
+    lock = threading.Lock()
+
+    def worker(my_models, rng):
+      nonlocal launches
+      for op in range(ops):
+          M = my_models[int(rng.integers(len(my_models)))]
+          n, rb = M["n"], M["n"] * 4
+          kind = rng.choice(["launch"] * 10 + ["launch_into_input"] * 2 + ["fused"] * 4 + ["download", "memset", "upload", "f64", "sync"])
+          if kind in ("launch", "launch_into_input"):
+              length = int(rng.choice([1, 63, 64, 65, 200, 1000, int(rng.integers(1, 6000))]))
+              s_in, s_out = (2 * int(rng.integers(0, (R - length) // 2 + 1)) for _ in range(2))   # (device pointers: 16-byte aligned)
+              dst = int(rng.integers(0, 3)) if kind == "launch_into_input" else int(rng.integers(3, 6))
+              rows_in = (0, 1, 2)
+              if dst < 3 and not (s_out + length <= s_in or s_in + length <= s_out):
+                  continue    # a launch whose output overlaps its OWN input rows is undefined for any kernel
+              want = expected(M, rows_in, s_in, length)
+              ctx.id_trajectory(M["m"], *(M["dev"][k].offset(s_in * rb) for k in rows_in), length, M["dev"][dst].offset(s_out * rb), dtype=np.float32)
+              M["host"][dst][s_out:s_out + length] = want
+              with lock:
+                launches += 1
+          elif kind == "download":
+              check(M, int(rng.integers(0, 6)), f"op {op}")
+          elif kind == "memset":
+              k = int(rng.integers(3, 6))
+              a, b = sorted(int(x) for x in rng.integers(0, R + 1, 2))
+              if b > a:
+                  ctx.memset(M["dev"][k].offset(a * rb), 0, (b - a) * rb)
+                  M["host"][k][a:b] = 0
+          elif kind == "upload":
+              k = int(rng.integers(0, 6))
+              fresh = (M["host"][k] * np.float32(0.5)).astype(np.float32) if k < 3 else rng.uniform(-1, 1, (R, n)).astype(np.float32)
+              M["dev"][k].upload(fresh)
+              M["host"][k][:] = fresh
+          elif kind == "f64":    # another entry point altogether: parked passes run first
+              rows = 500
+              q64 = [ctx.to_device(M["host"][k][:rows].astype(np.float64)) for k in range(3)]
+              out = ctx.alloc(rows * n * 8)
+              ctx.id_trajectory(M["m"], *q64, rows, out, dtype=np.float64)
+              out.download((rows, n), np.float64)
+              for b_ in q64 + [out]:
+                  b_.free()
+          elif kind == "fused":
+              B, N = 7, int(rng.choice([300, 300, 300, 257]))     # (a new N or Tf rewrites the time table: parked passes run first)
+              Tf = float(rng.choice([2.0, 2.0, 2.0, 1.5]))
+              lim = M["m"].joint_limits_f32()
+              st, en = rng.uniform(lim[:, 0], lim[:, 1], (2, B, n)).astype(np.float32)
+              k = int(rng.integers(3, 6))
+              s_out = 2 * int(rng.integers(0, (R - B * N) // 2 + 1))
+              want = ref_ctx.traj_id_fused_host(M["m"], st, en, Tf, N, 5).reshape(-1, n)
+              ds, de = ctx.to_device(st), ctx.to_device(en)
+              ctx.traj_id_fused(M["m"], ds, de, B, N, Tf, 5, M["dev"][k].offset(s_out * rb))
+              M["host"][k][s_out:s_out + B * N] = want
+              held.append((ds, de))       # the launch's float64 pass is parked and re-reads the end points: freed at the end
+          else:
+              ctx.synchronize()
+    if nthreads <= 1:
+        worker(models, rng)
+    else:
+        ths = [threading.Thread(target=worker, args=(models[i::nthreads], np.random.default_rng(seed * 100 + i))) for i in range(nthreads)]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
     for M in models:
         for k in range(6):
             check(M, k, "end")
