@@ -874,9 +874,15 @@ def main():
     if hung:
         os._exit(3)  # a stuck collective cannot be cancelled from Python: leave, non-zero, without another context call
     ctx.destroy()
-    unverified = [k for k, v in (result.get("configs") or {}).items() if k.endswith("_strong") and v.get("allgather") is not None and not v.get("verified")]
-    if world > 1 and info.rank == 0 and ((result.get("allgather") is not None and result.get("verified") is False) or unverified):
-        raise SystemExit(5)   # a reassembled history did not match the recomputation: not a result
+    # A reassembled history that did not match its recomputation is not a result: exit 5.  A collective that could not RUN (RCCL
+    # unusable on this node: the entry carries "error", `verified` stays false, the compute-only `value` is unaffected) is reported
+    # in the line and does not fail the run.
+    def mismatched(entry):
+        g = entry.get("allgather")
+        return g is not None and "error" not in g and not entry.get("verified")
+    unverified = [k for k, v in (result.get("configs") or {}).items() if k.endswith("_strong") and mismatched(v)]
+    if world > 1 and info.rank == 0 and (mismatched(result) or unverified):
+        raise SystemExit(5)
     if failed:
         raise SystemExit(4)
 
