@@ -811,6 +811,8 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     hg = sharding.HostGather(info)  # gloo; no-op for a single process
+    if world > 1:
+        os.environ.setdefault("NCCL_DEBUG", "WARN")  # a collective that cannot start says why on stderr (the line only carries RCCL's one-line error)
     if os.environ.get("MANIPULAPY_BENCH_DRYRUN") == "1":
         # launcher / rendezvous rehearsal for GPU-less boxes: everything up to (not including) the first HIP call
         hg.barrier()
