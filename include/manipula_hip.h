@@ -57,6 +57,12 @@ int mp_device_count(int* count);
 int mp_ctx_create(int device_id, mp_ctx** out);
 int mp_ctx_destroy(mp_ctx* ctx);
 int mp_ctx_synchronize(mp_ctx* ctx);  /* waits for every stream of the context */
+/* The context's compute stream as a hipStream_t (returned through a void*: no HIP header is needed to include this file), for a
+ * caller that orders its own HIP work - a copy, a kernel of its own - behind the library's launches.  Stream order is the whole
+ * contract: every device-pointer entry point returns with everything its result needs enqueued on this stream (see the note at
+ * mp_id_trajectory_f32 for the one case where "enqueued" depends on who owns the arrays).  The reference has no streams of its
+ * own to expose (its launchers return finished host arrays, cuda_kernels/trajectory_kernels.py:1043-1081). */
+int mp_ctx_get_stream(mp_ctx* ctx, void** hip_stream);
 /* name, CU count, total HBM bytes — replaces get_gpu_properties(), cuda_kernels/registry.py:335-356 */
 int mp_ctx_properties(mp_ctx* ctx, char* name, size_t name_len, int* compute_units, uint64_t* hbm_bytes);
 /* Launch a 1-block probe kernel that writes its lane ids and check the result on the host.
@@ -68,6 +74,11 @@ int mp_selftest(mp_ctx* ctx);
  * reads = 11 / 13: the same two kernels with non-temporal loads and stores (what the whole-line row movers use).
  * Nothing in the reference corresponds to it. */
 int mp_stream_bandwidth(mp_ctx* ctx, size_t bytes_per_array, int reads, int reps, double* gb_per_s);
+/* The same probe for any of the byte mixes the kernels have (reads : writes = 0:1, 1:1, 2:1, 3:1, 1:2, 1:3, 2:3): every lane
+ * reads one 16-byte chunk from each of `reads` arrays and writes one to each of `writes` arrays of bytes_per_array bytes, plain
+ * or non-temporal; *gb_per_s = (reads + writes) * bytes * reps / elapsed.  bench.py runs it with a configuration's own mix and
+ * size right before its timed region: roofline.frac_of_probe says how much of what THIS box streams the kernel reaches. */
+int mp_stream_bandwidth_mix(mp_ctx* ctx, size_t bytes_per_array, int reads, int writes, int nontemporal, int reps, double* gb_per_s);
 
 /* Profiling (replaces the reference's profile_start / profile_stop hooks, planning/trajectory_planning.py:295-296, and
  * the timing part of its performance_stats): while on, every device-pointer entry point (and so every *_host one)
@@ -162,7 +173,21 @@ int mp_batch_trajectory_f32(mp_ctx* ctx, const mp_model* model, const float* d_s
 /* tau (rows,n) = clip(inverse_dynamics(q, qd, qdd, g, Ftip), torque_limits) for `rows` independent
  * (trajectory, timestep) rows.  Replaces _inverse_dynamics_gpu / inverse_dynamics_kernel
  * (planning/trajectory_dynamics.py:92-306, cuda_kernels/trajectory_kernels.py:521-602) with the
- * arithmetic of _inverse_dynamics_cpu (:308-380) -> dynamics/id_fd.py:16-48. */
+ * arithmetic of _inverse_dynamics_cpu (:308-380) -> dynamics/id_fd.py:16-48.
+ *
+ * float32 rows, adaptive precision.  The float32 kernels hand the few rows per thousand whose torques are a small difference of
+ * large terms (csrc/mp_core.h, MpRowScale / mp_id_row_is_hard) to a float64 pass behind them, so that EVERY row holds the
+ * float32 parity bound.  When the call returns:
+ *   - arrays the CALLER allocated (hipMalloc, a framework tensor - anything not from mp_malloc): kernel and pass are both
+ *     enqueued on the compute stream.  Whatever the caller enqueues there next - or a wait on that stream - sees the complete
+ *     torques; the arrays may be freed or reused as soon as the stream has passed the call, like after any asynchronous launch.
+ *   - arrays from this context's pool (mp_malloc), all four of them: the pass may stay PARKED, to be run together with the passes
+ *     of up to three more launches.  It runs before anything can see the difference: every other entry point of the context
+ *     (mp_memcpy_*, mp_ctx_synchronize, mp_event_record, mp_ctx_get_stream, the *_host calls, the communicator ...), a launch
+ *     whose arrays overlap the parked one's, a fifth launch, mp_ctx_destroy.  Pool memory is only reachable through those.
+ *   MANIPULAPY_HIP_PARK_FOREIGN=1 (experiment switch) parks for foreign arrays too; the caller must then pass a
+ *   synchronising entry point before touching them with its own HIP calls.
+ * The same holds for mp_traj_id_fused_f32 (start / end / tau). */
 int mp_id_trajectory_f32(mp_ctx* ctx, const mp_model* model, const float* d_q, const float* d_qd,
                          const float* d_qdd, int64_t rows, const double* g, const double* Ftip, float* d_tau);
 int mp_id_trajectory_f64(mp_ctx* ctx, const mp_model* model, const double* d_q, const double* d_qd,

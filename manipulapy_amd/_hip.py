@@ -48,9 +48,11 @@ SIGNATURES = {
     "mp_ctx_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_vp)]),
     "mp_ctx_destroy": (ctypes.c_int, [_vp]),
     "mp_ctx_synchronize": (ctypes.c_int, [_vp]),
+    "mp_ctx_get_stream": (ctypes.c_int, [_vp, ctypes.POINTER(_vp)]),
     "mp_ctx_properties": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint64)]),
     "mp_selftest": (ctypes.c_int, [_vp]),
     "mp_stream_bandwidth": (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
+    "mp_stream_bandwidth_mix": (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
     "mp_ctx_set_profiling": (ctypes.c_int, [_vp, ctypes.c_int]),
     "mp_ctx_profile": (ctypes.c_int, [_vp, _c_dp, ctypes.POINTER(ctypes.c_int64), _c_dp, ctypes.c_int]),
     "mp_malloc": (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.POINTER(_vp)]),
@@ -439,6 +441,13 @@ class HipContext:
                                             ctypes.byref(out)))
         return float(out.value)
 
+    def stream_bandwidth_mix(self, bytes_per_array: int, reads: int, writes: int, reps: int = 10, nontemporal: bool = True) -> float:
+        """GB/s of a streaming kernel that reads `reads` and writes `writes` arrays of bytes_per_array bytes (a kernel's own byte mix)."""
+        out = ctypes.c_double(0.0)
+        _check(self.lib.mp_stream_bandwidth_mix(self.handle, ctypes.c_size_t(int(bytes_per_array)), int(reads), int(writes),
+                                                1 if nontemporal else 0, int(reps), ctypes.byref(out)))
+        return float(out.value)
+
     def properties(self) -> dict:
         name = ctypes.create_string_buffer(256)
         cu = ctypes.c_int(0)
@@ -487,6 +496,12 @@ class HipContext:
         dtype = np.dtype(dtype)
         n = int(np.prod(shape))
         return PinnedBuffer(self, max(1, n) * dtype.itemsize).array(shape, dtype)
+
+    def stream(self) -> int:
+        """The compute stream (a hipStream_t as an integer) for callers that order their own HIP work behind the launches."""
+        p = _vp()
+        _check(self.lib.mp_ctx_get_stream(self.handle, ctypes.byref(p)))
+        return p.value or 0
 
     def capture(self) -> _Capture:
         """``with ctx.capture() as cap: <device-pointer launches>`` -> ``cap.graph`` (HipGraph)."""

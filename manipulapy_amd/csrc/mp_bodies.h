@@ -236,6 +236,14 @@ __device__ __forceinline__ void mp_body_id_hard(const MC& Mc, const MF& M, const
     if (r >= (long)rows) continue;  // (a list left behind by a launch whose pass never ran)
     float q[N], qd[N], qdd[N];
     load(r, q, qd, qdd);
+    if (all) {
+      // every row of the launch arrives here, also those the float32 kernel never listed because an input is NaN / inf: their
+      // NaN rows stay as that kernel stored them (this code is compiled with -ffinite-math-only in the specialised programs, and the
+      // torque clip would turn a NaN into a limit)
+      MpBad<float> bad;
+      bad.add(q); bad.add(qd); bad.add(qdd);
+      if (bad.any()) continue;
+    }
     double a[N], b[N], c[N], t[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) { a[i] = (double)q[i]; b[i] = (double)qd[i]; c[i] = (double)qdd[i]; }
@@ -700,13 +708,14 @@ __device__ __forceinline__ void mp_rnea_pk(const MT& M, const MpCall<float>& C, 
 #if MP_ADAPTIVE_F32
   const mp_f2 tn[3] = {(mp_f2)(C.F1n[0]), (mp_f2)(C.F1n[1]), (mp_f2)(C.F1n[2])};
   const mp_f2 tf[3] = {(mp_f2)(C.F1f[0]), (mp_f2)(C.F1f[1]), (mp_f2)(C.F1f[2])};
-  mp_f2 sF;
-  mp_rnea_impl<mp_f2, N, HAS_FTIP, true>(M, C.a0, tn, tf, js, qd, qdd, tau, sF);
+  MpRowScale<mp_f2, N> sc;
+  mp_rnea_impl<mp_f2, N, HAS_FTIP>(M, C.a0, tn, tf, js, qd, qdd, tau, sc);
+  const mp_f2 sF = sc.scale(M.lscale);
   float tx[N], ty[N];
 #pragma unroll
   for (int i = 0; i < N; ++i) { tx[i] = tau[i].x; ty[i] = tau[i].y; }
-  const bool hx = mp_id_row_is_hard<N>(tx, sF.x, M.lscale) && !bad.x.any();
-  const bool hy = mp_id_row_is_hard<N>(ty, sF.y, M.lscale) && !bad.y.any() && usey;  // (usey false: a duplicate the caller drops)
+  const bool hx = mp_id_row_is_hard<N>(tx, sF.x) && !bad.x.any();
+  const bool hy = mp_id_row_is_hard<N>(ty, sF.y) && !bad.y.any() && usey;  // (usey false: a duplicate the caller drops)
   mp_cold_rows<N, HAS_FTIP, MP_COLD_G>(M, C, hx, rowx, cold, [&](float (&a)[N], float (&b)[N], float (&c)[N]) {
 #pragma unroll
     for (int i = 0; i < N; ++i) { a[i] = q[i].x; b[i] = qd[i].x; c[i] = qdd[i].x; }

@@ -76,8 +76,15 @@ struct mp_ctx {
     size_t bytes_in = 0;          // of each input array the caller owns (q, qd, qdd; start, end)
   };
   static constexpr int kHardSlots = MP_HARD_BATCH;
-  HardSlot hard[kHardSlots];
-  unsigned long long hard_seq = 0;
+  // The slots of one owner: the context's own (launches on the stream), or those of a launch graph being captured - a graph keeps
+  // its lists for its lifetime, its passes are nodes of the graph, and its counters are zeroed by a node ahead of their first user.
+  struct HardPool {
+    HardSlot slot[kHardSlots];
+    unsigned long long seq = 0;
+    std::vector<void*> retired;  // lists outgrown during a capture: earlier nodes of the graph still point at them
+  };
+  HardPool own_pool;
+  HardPool* hp = &own_pool;      // the pool launches attach to: own_pool, or the open capture's
   double* time_tab = nullptr;                          // per-timestep time-scaling table of the fused kernels
   long tab_cap = 0, tab_Nt = -1;                       // its capacity in timesteps / the call it currently holds
   double tab_Tf = 0;
@@ -107,6 +114,7 @@ struct mp_graph {
   int device = -1;
   mp_ctx* ctx = nullptr;  // the context it was captured on (only dereferenced while that context is still registered ...
   uint64_t ctx_uid = 0;   // ... under the SAME never-reused id: a later context may be allocated at the same address)
+  mp_ctx::HardPool* pool = nullptr;  // row lists + counters of the float64 passes captured in it
 };
 
 namespace {
@@ -154,6 +162,7 @@ int bind(mp_ctx* ctx) {
 // enqueues next may read the torques they write.  The float32 inverse-dynamics entry points, whose point it is NOT to run one
 // pass per launch, enter with CTX_ENTER_NOJOIN and flush only when their arrays overlap a parked pass's.
 int hard_flush(mp_ctx* ctx);
+int hard_park_or_run(mp_ctx* ctx, const void* a, const void* b, const void* c, const void* out, size_t bytes_out, size_t bytes_in);
 #define CTX_ENTER_NOJOIN(ctx)                                  \
   std::lock_guard<std::recursive_mutex> ctx_lock_((ctx)->mu);  \
   if (int rc_enter_ = bind(ctx)) return rc_enter_
@@ -320,6 +329,25 @@ int launch_spec(mp_ctx* ctx, hipFunction_t fn, long threads, void** args, unsign
   return MP_OK;
 }
 
+// While a capture is open on this thread (hipStreamCaptureModeThreadLocal) an allocation or a blocking copy is refused; the few
+// that belong to a captured launch (its row list, a model's device copy on first use) run under the relaxed mode - they execute
+// at once, outside the graph.
+struct RelaxedCapture {
+  hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+  bool on;
+  explicit RelaxedCapture(bool capturing) : on(capturing) { if (on) (void)hipThreadExchangeStreamCaptureMode(&mode); }
+  ~RelaxedCapture() { if (on) (void)hipThreadExchangeStreamCaptureMode(&mode); }
+};
+// true when [p, p + bytes) lies inside one allocation of this context's pool (mp_malloc): memory the library owns, which no
+// caller can read, free or hand to another allocator behind the library's back
+bool pool_owned(mp_ctx* ctx, const void* p, size_t bytes) {
+  if (!p) return true;
+  auto it = ctx->live.upper_bound(const_cast<void*>(p));
+  if (it == ctx->live.begin()) return false;
+  --it;
+  const char* base = (const char*)it->first;
+  return (const char*)p >= base && (const char*)p + bytes <= base + it->second;
+}
 // float32 model resident in device memory (read by the *_dm kernels with scalar loads), followed in the same buffer by the
 // float64 model (read by the float64 re-evaluation of ill-conditioned float32 rows in the generic kernels, MpCall::cold_model)
 constexpr size_t kDevModelD = (sizeof(MpModel<float>) + 255) & ~(size_t)255;  // offset of the float64 copy
@@ -327,24 +355,36 @@ int device_model(mp_ctx* ctx, const mp_model* model, const MpModel<float>** out)
   auto it = ctx->dev_models.find(model->uid);
   if (it == ctx->dev_models.end()) {
     void* d = nullptr;
-    if (int rc = mp_malloc(ctx, kDevModelD + sizeof(MpModel<double>), &d)) return rc;
-    // (on the compute stream and waited for: the first kernel that reads the copy follows on that stream, and the streams are
-    // non-blocking - nothing orders them with a copy on the null stream)
-    HIP_TRY(hipMemcpyAsync(d, &model->f, sizeof(MpModel<float>), hipMemcpyHostToDevice, ctx->compute));
-    HIP_TRY(hipMemcpyAsync((char*)d + kDevModelD, &model->d, sizeof(MpModel<double>), hipMemcpyHostToDevice, ctx->compute));
-    HIP_TRY(hipStreamSynchronize(ctx->compute));
+    if (ctx->capturing) {
+      // first use inside a capture: the copy is made at once, outside the graph (blocking copies: complete on return, so the
+      // replays' kernels - and the eager launches after the capture - find it)
+      RelaxedCapture relaxed(true);
+      const size_t bytes = (kDevModelD + sizeof(MpModel<double>) + 255) & ~size_t(255);
+      HIP_TRY(hipMalloc(&d, bytes));
+      ctx->live[d] = bytes;
+      hipError_t he = hipMemcpy(d, &model->f, sizeof(MpModel<float>), hipMemcpyHostToDevice);
+      if (he == hipSuccess) he = hipMemcpy((char*)d + kDevModelD, &model->d, sizeof(MpModel<double>), hipMemcpyHostToDevice);
+      if (he != hipSuccess) { ctx->free_by_size[bytes].push_back(d); return hip_err(he, "hipMemcpy (device copy of the model)"); }
+    } else {
+      if (int rc = mp_malloc(ctx, kDevModelD + sizeof(MpModel<double>), &d)) return rc;
+      // (on the compute stream and waited for: the first kernel that reads the copy follows on that stream, and the streams are
+      // non-blocking - nothing orders them with a copy on the null stream)
+      HIP_TRY(hipMemcpyAsync(d, &model->f, sizeof(MpModel<float>), hipMemcpyHostToDevice, ctx->compute));
+      HIP_TRY(hipMemcpyAsync((char*)d + kDevModelD, &model->d, sizeof(MpModel<double>), hipMemcpyHostToDevice, ctx->compute));
+      HIP_TRY(hipStreamSynchronize(ctx->compute));
+    }
     it = ctx->dev_models.emplace(model->uid, d).first;
   }
   *out = static_cast<const MpModel<float>*>(it->second);
   return MP_OK;
 }
 // a float32 call's constants + where its kernels find the float64 model.  Generic kernels only (the specialised programs carry
-// the literal); never uploads during a graph capture (the kernels then widen the float32 model: same rows, a little less exact).
+// the literal).
 void make_call_f32(mp_ctx* ctx, const mp_model* model, const double* g, const double* Ftip, MpCall<float>* c) {
   make_call<float>(model, g, Ftip, c);
   if (model->big || find_spec(ctx, model)) return;
   auto it = ctx->dev_models.find(model->uid);
-  if (it == ctx->dev_models.end() && !ctx->capturing) {
+  if (it == ctx->dev_models.end()) {
     const MpModel<float>* dm = nullptr;
     if (device_model(ctx, model, &dm) != MP_OK) return;
     it = ctx->dev_models.find(model->uid);
@@ -354,29 +394,34 @@ void make_call_f32(mp_ctx* ctx, const mp_model* model, const double* g, const do
 // The list a float32 inverse-dynamics launch of `rows` rows leaves its ill-conditioned rows in for the float64 pass
 // (csrc/mp_bodies.h, mp_push_hard_rows / mp_body_id_hard): room for one row in eight, at least 65 536 (c2-distributed rows flag 0.5 - 1.5 %; a list that
 // overflows makes the pass evaluate every row of the launch).  Returns the slot (c carries its pointers), or null = no list, the
-// kernels re-evaluate in place: more than 2^32 rows, a graph capture (a replay would meet a used list), or the switch.
+// kernels re-evaluate in place: more than 2^32 rows, or the switch.  A launch that is being CAPTURED takes its list from the
+// capture's own pool (mp_graph_begin): the graph owns it, the pass is a node of the graph.
 mp_ctx::HardSlot* attach_hard_list(mp_ctx* ctx, long rows, MpCall<float>* c) {
   static const bool on = !(getenv("MANIPULAPY_HIP_HARD_PASS") && getenv("MANIPULAPY_HIP_HARD_PASS")[0] == '0');  // experiment switch
-  if (!on || rows >= 0xffffffffL || ctx->capturing) return nullptr;
+  if (!on || rows >= 0xffffffffL) return nullptr;
+  mp_ctx::HardPool* pool = ctx->hp;
   mp_ctx::HardSlot* hs = nullptr;
-  for (auto& cand : ctx->hard)
+  for (auto& cand : pool->slot)
     if (!cand.busy) { hs = &cand; break; }
   if (!hs) {  // all parked: run them (one kernel), then take the first
     if (hard_flush(ctx) != MP_OK) return nullptr;
-    hs = &ctx->hard[0];
+    hs = &pool->slot[0];
   }
   const unsigned need = (unsigned)std::min<long>(std::max<long>(rows / 8, 1L << 16), 1L << 28);
   if (hs->cap < need) {
-    if (hipStreamSynchronize(ctx->compute) != hipSuccess) return nullptr;
+    RelaxedCapture relaxed(ctx->capturing);
+    if (!ctx->capturing && hipStreamSynchronize(ctx->compute) != hipSuccess) return nullptr;
     // (zeroed ON the compute stream: a plain hipMemset of device memory is not ordered with a kernel launched on another,
     // non-blocking stream right behind it - a kernel that met the allocation's old bytes as its counter took the list for full and
-    // re-evaluated in place, correct but not bit-equal to the pass: seen once, as 27 elements of a 240 000-element comparison)
+    // re-evaluated in place, correct but not bit-equal to the pass: seen once, as 27 elements of a 240 000-element comparison.
+    // In a capture this is the node that zeroes the graph's counters ahead of their first user, on every replay.)
     if (!hs->ctrl && (hipMalloc((void**)&hs->ctrl, 2 * sizeof(unsigned)) != hipSuccess ||
                       hipMemsetAsync(hs->ctrl, 0, 2 * sizeof(unsigned), ctx->compute) != hipSuccess)) {
       hs->ctrl = nullptr;
       return nullptr;
     }
-    if (hs->rows) (void)hipFree(hs->rows);
+    if (hs->rows && ctx->capturing) pool->retired.push_back(hs->rows);  // earlier nodes of the graph still write it
+    else if (hs->rows) (void)hipFree(hs->rows);
     hs->rows = nullptr; hs->cap = 0;
     if (hipMalloc((void**)&hs->rows, (size_t)need * sizeof(unsigned)) != hipSuccess) { hs->rows = nullptr; return nullptr; }
     hs->cap = need;
@@ -387,6 +432,15 @@ mp_ctx::HardSlot* attach_hard_list(mp_ctx* ctx, long rows, MpCall<float>* c) {
   c->hard_rows = hs->rows; c->hard_ctrl = hs->ctrl + turn; c->hard_next = hs->ctrl + (turn ^ 1u); c->hard_cap = hs->cap;
   c->hard_row_base = 0;
   return hs;
+}
+void free_hard_pool(mp_ctx::HardPool* pool) {
+  for (auto& hs : pool->slot) {
+    if (hs.rows) (void)hipFree(hs.rows);
+    if (hs.ctrl) (void)hipFree(hs.ctrl);
+    hs.rows = nullptr; hs.ctrl = nullptr; hs.cap = 0; hs.busy = false; hs.generic = nullptr;
+  }
+  for (void* p : pool->retired) (void)hipFree(p);
+  pool->retired.clear();
 }
 unsigned hard_pass_blocks(long rows) {
   static const long cap = [] { const char* e = getenv("MANIPULAPY_HIP_HARD_BLOCKS"); return e ? std::max(1L, atol(e)) : 1024L; }();  // experiment switch
@@ -400,7 +454,7 @@ inline int hard_passed(mp_ctx::HardSlot* hs, int rc) {
 // park the pass of the launch just enqueued
 void hard_defer(mp_ctx* ctx, mp_ctx::HardSlot* hs, hipFunction_t fn, std::function<int()> generic, const MpCall<float>& C,
                 const float* q, const float* qd, const float* qdd, float* tau, long rows, int n) {
-  hs->busy = true; hs->orphan = false; hs->seq = ++ctx->hard_seq; hs->fn = fn; hs->generic = std::move(generic); hs->C = C; hs->C.hard_row_base = 0;
+  hs->busy = true; hs->orphan = false; hs->seq = ++ctx->hp->seq; hs->fn = fn; hs->generic = std::move(generic); hs->C = C; hs->C.hard_row_base = 0;
   hs->q = q; hs->qd = qd; hs->qdd = qdd; hs->tau = tau; hs->nrows = (unsigned)rows; hs->bytes = (size_t)rows * (size_t)n * sizeof(float);
   hs->bytes_in = hs->bytes; hs->nt = 0;
 }
@@ -411,11 +465,23 @@ void hard_defer_generated(mp_ctx* ctx, mp_ctx::HardSlot* hs, hipFunction_t fn, c
   hard_defer(ctx, hs, fn, nullptr, C, start, end, (const float*)tab, tau, rows, n);
   hs->bytes_in = (size_t)B * (size_t)n * sizeof(float); hs->nt = nt;
 }
+// What becomes of the pass just parked.  It STAYS parked only when every array of its launch lies in this context's pool: such
+// memory is read, freed and reused through the library alone, and every entry point runs the parked passes first.  Arrays the
+// caller allocated itself (hipMalloc, a framework tensor) may be read with the caller's own HIP calls on the compute stream, or
+// handed back to another allocator, without the library hearing of it - their pass is enqueued at once, so that the entry point
+// returns with the complete result stream-ordered behind it, as the reference's launchers return finished arrays
+// (cuda_kernels/trajectory_kernels.py:1043-1081).
+int hard_park_or_run(mp_ctx* ctx, const void* a, const void* b, const void* c, const void* out, size_t bytes_out, size_t bytes_in) {
+  static const bool always = getenv("MANIPULAPY_HIP_PARK_FOREIGN") && getenv("MANIPULAPY_HIP_PARK_FOREIGN")[0] == '1';  // experiment switch
+  if (always || (pool_owned(ctx, a, bytes_in) && pool_owned(ctx, b, bytes_in) && pool_owned(ctx, c, bytes_in) && pool_owned(ctx, out, bytes_out)))
+    return MP_OK;
+  return hard_flush(ctx);
+}
 // run every parked pass on the compute stream, in launch order; passes of one specialised program share a kernel launch
 int hard_flush(mp_ctx* ctx) {
   mp_ctx::HardSlot* order[mp_ctx::kHardSlots];
   int k = 0;
-  for (auto& hs : ctx->hard)
+  for (auto& hs : ctx->hp->slot)
     if (hs.busy) order[k++] = &hs;
   if (k == 0) return MP_OK;
   std::sort(order, order + k, [](const mp_ctx::HardSlot* a, const mp_ctx::HardSlot* b) { return a->seq < b->seq; });
@@ -453,7 +519,7 @@ int hard_flush(mp_ctx* ctx) {
 // a float32 launch about to be enqueued on [lo, lo + bytes) arrays: parked passes run first if they read or write what it writes, or
 // write what it reads
 int hard_flush_if_overlapping(mp_ctx* ctx, const void* const* lo, const size_t* bytes, int k) {
-  for (auto& hs : ctx->hard) {
+  for (auto& hs : ctx->hp->slot) {
     if (!hs.busy) continue;
     const char* mine[4] = {(const char*)hs.q, (const char*)hs.qd, hs.nt ? nullptr : (const char*)hs.qdd, (const char*)hs.tau};
     const size_t size[4] = {hs.bytes_in, hs.bytes_in, hs.bytes_in, hs.bytes};
@@ -539,8 +605,9 @@ int launch_id(mp_ctx* ctx, const mp_model* model, const MpCall<float>& c, bool f
       // ill-conditioned rows go to a float64 pass of their own behind the float32 kernels (see attach_hard_list)
       mp_ctx::HardSlot* hs = sp->id_hard[ftip ? 1 : 0] ? attach_hard_list(ctx, rows, &cc) : nullptr;
       auto hard_pass = [&]() -> int {
-        if (hs) hard_defer(ctx, hs, sp->id_hard[ftip ? 1 : 0], nullptr, cc, q, qd, qdd, tau, rows, model->d.n);
-        return MP_OK;
+        if (!hs) return MP_OK;
+        hard_defer(ctx, hs, sp->id_hard[ftip ? 1 : 0], nullptr, cc, q, qd, qdd, tau, rows, model->d.n);
+        return hard_park_or_run(ctx, q, qd, qdd, tau, (size_t)rows * (size_t)model->d.n * sizeof(float), (size_t)rows * (size_t)model->d.n * sizeof(float));
       };
       long done = 0;
       if (sp->id_co[ftip ? 1 : 0] && rows >= 64 && id_co_enabled()) {  // whole waves: rows moved as whole lines, non-temporal (mp_body_id_co)
@@ -571,7 +638,7 @@ int launch_id(mp_ctx* ctx, const mp_model* model, const MpCall<float>& c, bool f
     HIP_TRY(mpk_id<float>(ctx->compute, model->f, c, ftip, q + off, qd + off, qdd + off, tau + off, rows - done));
     return MP_OK;
   }
-  if (generic_f32_mode() == 2 && !ctx->capturing) {  // one row per lane, device-resident model (not while capturing: first use uploads it)
+  if (generic_f32_mode() == 2) {  // one row per lane, device-resident model (a capture's first use uploads it outside the graph)
     const MpModel<float>* dm = nullptr;
     if (int rc = device_model(ctx, model, &dm)) return rc;
     MpCall<float> cc = c;
@@ -586,7 +653,7 @@ int launch_id(mp_ctx* ctx, const mp_model* model, const MpCall<float>& c, bool f
       HIP_TRY(mpk_id_hard(st, dm, n, c2, ftip, q, qd, qdd, tau, (unsigned)rows, hard_pass_blocks(rows)));
       return (int)MP_OK;
     }, cc, q, qd, qdd, tau, rows, n);
-    return MP_OK;
+    return hard_park_or_run(ctx, q, qd, qdd, tau, (size_t)rows * (size_t)n * sizeof(float), (size_t)rows * (size_t)n * sizeof(float));
   }
   HIP_TRY(mpk_id<float>(ctx->compute, model->f, c, ftip, q, qd, qdd, tau, rows));
   return MP_OK;
@@ -969,6 +1036,7 @@ int mp_ctx_destroy(mp_ctx* ctx) {
     g_ctxs.erase(ctx);
   }
   (void)hipSetDevice(ctx->device);
+  if (!ctx->capturing) (void)hard_flush(ctx);  // parked float64 passes: their launches' results are complete before the memory goes
   (void)hipDeviceSynchronize();
   for (auto& pe : ctx->prof_pending) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
   for (auto& kv : ctx->specs) {
@@ -978,10 +1046,8 @@ int mp_ctx_destroy(mp_ctx* ctx) {
   for (hipModule_t m : ctx->retired_mods) (void)hipModuleUnload(m);
   for (auto& kv : ctx->live) (void)hipFree(kv.first);
   if (ctx->queue_counter) (void)hipFree(ctx->queue_counter);
-  for (auto& hs : ctx->hard) {
-    if (hs.rows) (void)hipFree(hs.rows);
-    if (hs.ctrl) (void)hipFree(hs.ctrl);
-  }
+  free_hard_pool(&ctx->own_pool);
+  if (ctx->hp != &ctx->own_pool) { free_hard_pool(ctx->hp); delete ctx->hp; }  // a capture left open
   if (ctx->time_tab) (void)hipFree(ctx->time_tab);
   for (void* p : ctx->retired_tabs) (void)hipFree(p);
   if (ctx->compute) (void)hipStreamDestroy(ctx->compute);
@@ -1016,6 +1082,13 @@ int mp_ctx_profile(mp_ctx* ctx, double* kernel_ms_total, int64_t* timed_calls, d
   if (timed_calls) *timed_calls = ctx->prof_launches;
   if (kernel_ms_last) *kernel_ms_last = ctx->prof_last_ms;
   if (reset) { ctx->prof_total_ms = 0; ctx->prof_last_ms = 0; ctx->prof_launches = 0; }
+  return MP_OK;
+}
+
+int mp_ctx_get_stream(mp_ctx* ctx, void** hip_stream) {
+  REQUIRE(ctx && hip_stream, "mp_ctx_get_stream: null argument");
+  CTX_ENTER(ctx);  // (parked float64 passes run first: what the caller enqueues behind this call sees complete results)
+  *hip_stream = (void*)ctx->compute;
   return MP_OK;
 }
 
@@ -1083,6 +1156,37 @@ int mp_stream_bandwidth(mp_ctx* ctx, size_t bytes_per_array, int reads, int reps
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   if (e != hipSuccess) return set_err(MP_ERR_HIP, "mp_stream_bandwidth: %s", hipGetErrorString(e));
   *gb_per_s = (double)(reads + 1) * (double)nb * (double)reps / ((double)ms * 1e-3) / 1e9;
+  return MP_OK;
+}
+
+int mp_stream_bandwidth_mix(mp_ctx* ctx, size_t bytes_per_array, int reads, int writes, int nontemporal, int reps, double* gb_per_s) {
+  REQUIRE(ctx && gb_per_s, "mp_stream_bandwidth_mix: null argument");
+  REQUIRE(bytes_per_array >= 16 && reps >= 1 && reads >= 0 && writes >= 1, "mp_stream_bandwidth_mix: nothing to move");
+  CTX_ENTER(ctx);
+  const size_t nb = bytes_per_array & ~(size_t)15;
+  Scratch sc(ctx);
+  void *a = nullptr, *d = nullptr;
+  if (int rc = sc.get(nb * (size_t)std::max(reads, 1), &a)) return rc;
+  if (int rc = sc.get(nb * (size_t)writes, &d)) return rc;
+  HIP_TRY(hipMemsetAsync(a, 0, nb * (size_t)std::max(reads, 1), ctx->compute));
+  HIP_TRY(hipMemsetAsync(d, 0, nb * (size_t)writes, ctx->compute));
+  const long n4 = (long)(nb / 16);
+  hipError_t e = hipSuccess;
+  for (int w = 0; w < 2 && e == hipSuccess; ++w) e = mpk_stream_mix(ctx->compute, reads, writes, nontemporal != 0, a, d, n4);
+  if (e == hipErrorInvalidValue) return set_err(MP_ERR_INVALID, "mp_stream_bandwidth_mix: no probe kernel for %d reads : %d writes", reads, writes);
+  if (e != hipSuccess) return hip_err(e, "mp_stream_bandwidth_mix");
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  HIP_TRY(hipEventCreate(&e0));
+  if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return set_err(MP_ERR_HIP, "mp_stream_bandwidth_mix: hipEventCreate failed"); }
+  e = hipEventRecord(e0, ctx->compute);
+  for (int r = 0; r < reps && e == hipSuccess; ++r) e = mpk_stream_mix(ctx->compute, reads, writes, nontemporal != 0, a, d, n4);
+  if (e == hipSuccess) e = hipEventRecord(e1, ctx->compute);
+  if (e == hipSuccess) e = hipEventSynchronize(e1);
+  float ms = 0.f;
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (e != hipSuccess) return set_err(MP_ERR_HIP, "mp_stream_bandwidth_mix: %s", hipGetErrorString(e));
+  *gb_per_s = (double)(reads + writes) * (double)nb * (double)reps / ((double)ms * 1e-3) / 1e9;
   return MP_OK;
 }
 
@@ -1233,7 +1337,13 @@ int mp_graph_begin(mp_ctx* ctx) {
   REQUIRE(ctx, "mp_graph_begin: null context");
   CTX_ENTER(ctx);
   REQUIRE(!ctx->capturing, "mp_graph_begin: a capture is already open on this context");
-  HIP_TRY(hipStreamBeginCapture(ctx->compute, hipStreamCaptureModeThreadLocal));
+  // (CTX_ENTER has run the context's own parked passes on the stream.)  Captured float32 inverse-dynamics launches park their
+  // float64 passes in a pool of the graph's own: lists and counters live as long as the graph, the passes become its nodes
+  mp_ctx::HardPool* pool = new (std::nothrow) mp_ctx::HardPool;
+  REQUIRE(pool, "mp_graph_begin: out of host memory");
+  hipError_t he = hipStreamBeginCapture(ctx->compute, hipStreamCaptureModeThreadLocal);
+  if (he != hipSuccess) { delete pool; return hip_err(he, "hipStreamBeginCapture"); }
+  ctx->hp = pool;
   ctx->capturing = true;
   return MP_OK;
 }
@@ -1242,17 +1352,23 @@ int mp_graph_end(mp_ctx* ctx, mp_graph** out) {
   *out = nullptr;
   CTX_ENTER(ctx);
   REQUIRE(ctx->capturing, "mp_graph_end: no capture is open on this context");
+  // (CTX_ENTER has captured the passes still parked in the capture's pool: they are the graph's last nodes)
+  mp_ctx::HardPool* pool = ctx->hp;
+  ctx->hp = &ctx->own_pool;
   ctx->capturing = false;
+  auto drop_pool = [&] { (void)hipStreamSynchronize(ctx->compute); free_hard_pool(pool); delete pool; };
   hipGraph_t g = nullptr;
-  HIP_TRY(hipStreamEndCapture(ctx->compute, &g));
+  hipError_t he = hipStreamEndCapture(ctx->compute, &g);
+  if (he != hipSuccess) { drop_pool(); return hip_err(he, "hipStreamEndCapture"); }
+  if (!g) drop_pool();
   REQUIRE(g, "mp_graph_end: the capture was invalidated (a non-capturable call ran between begin and end)");
   hipGraphExec_t ex = nullptr;
-  hipError_t he = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
-  if (he != hipSuccess) { (void)hipGraphDestroy(g); return hip_err(he, "hipGraphInstantiate"); }
+  he = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+  if (he != hipSuccess) { (void)hipGraphDestroy(g); drop_pool(); return hip_err(he, "hipGraphInstantiate"); }
   mp_graph* gr = new (std::nothrow) mp_graph;
-  if (!gr) { (void)hipGraphExecDestroy(ex); (void)hipGraphDestroy(g); }
+  if (!gr) { (void)hipGraphExecDestroy(ex); (void)hipGraphDestroy(g); drop_pool(); }
   REQUIRE(gr, "mp_graph_end: out of host memory");
-  gr->graph = g; gr->exec = ex; gr->device = ctx->device; gr->ctx = ctx; gr->ctx_uid = ctx->uid;
+  gr->graph = g; gr->exec = ex; gr->device = ctx->device; gr->ctx = ctx; gr->ctx_uid = ctx->uid; gr->pool = pool;
   ++ctx->live_graphs;
   *out = gr;
   return MP_OK;
@@ -1278,8 +1394,10 @@ int mp_graph_destroy(mp_graph* graph) {
   int prev = -1;
   (void)hipGetDevice(&prev);
   (void)hipSetDevice(graph->device);
+  (void)hipDeviceSynchronize();  // a replay still running writes the graph's row lists
   (void)hipGraphExecDestroy(graph->exec);
   (void)hipGraphDestroy(graph->graph);
+  if (graph->pool) { free_hard_pool(graph->pool); delete graph->pool; }
   {
     std::lock_guard<std::mutex> lk(g_ctxs_mu);
     // the context may have been destroyed first (it took the retired objects with it) - and another one created at its address
@@ -1680,7 +1798,8 @@ int mp_traj_id_fused_f32(mp_ctx* ctx, const mp_model* model, const float* d_star
       if (int rc = launch_spec(ctx, sp->traj_id_co[ftip ? 1 : 0], (long)rows, args, 64)) return rc;
       if (!hs) return MP_OK;
       hard_defer_generated(ctx, hs, sp->traj_id_hard[ftip ? 1 : 0], c, d_start, d_end, tab, d_tau, (long)rows, model->d.n, (long)B, ntu);
-      return ctx->tab_volatile ? hard_flush(ctx) : (int)MP_OK;  // (a table rewritten by every call cannot wait for a parked pass)
+      if (ctx->tab_volatile) return hard_flush(ctx);  // (a table rewritten by every call cannot wait for a parked pass)
+      return hard_park_or_run(ctx, d_start, d_end, nullptr, d_tau, (size_t)rows * (size_t)model->d.n * sizeof(float), (size_t)B * (size_t)model->d.n * sizeof(float));
     }
     if (!mpk_packed_f32()) {  // MANIPULAPY_HIP_F32=scalar: one timestep per lane (measured slower: c2f 0.063 vs 0.054 ms)
       unsigned bpt = (unsigned)((nt + 255) / 256);
@@ -1697,7 +1816,8 @@ int mp_traj_id_fused_f32(mp_ctx* ctx, const mp_model* model, const float* d_star
     // table runs the parked passes first (above)
     hard_defer_generated(ctx, hs, sp->traj_id_hard[ftip ? 1 : 0], c, d_start, d_end, tab, d_tau, rows_l, model->d.n, (long)B, (unsigned)N);
     static const bool park = !(getenv("MANIPULAPY_HIP_FUSED_PARK") && getenv("MANIPULAPY_HIP_FUSED_PARK")[0] == '0');  // experiment switch
-    return ctx->tab_volatile || !park ? hard_flush(ctx) : (int)MP_OK;  // (a table rewritten by every call cannot wait for a parked pass)
+    if (ctx->tab_volatile || !park) return hard_flush(ctx);  // (a table rewritten by every call cannot wait for a parked pass)
+    return hard_park_or_run(ctx, d_start, d_end, nullptr, d_tau, (size_t)rows_l * (size_t)model->d.n * sizeof(float), (size_t)B * (size_t)model->d.n * sizeof(float));
   }
   {
     // generic kernels: the same hand-over (the float64 model and the float32 limits come from the device copy)
@@ -2162,10 +2282,12 @@ int mp_inverse_kinematics_host_f64(mp_ctx* ctx, const mp_model* model, const dou
 
 // exposed to mp_comm.cpp
 // (whoever asks for the stream is about to enqueue something that may read torques: parked float64 passes run first)
-hipStream_t mp_ctx_compute_stream(mp_ctx* ctx) {
-  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
-  if (hipSetDevice(ctx->device) == hipSuccess) (void)hard_flush(ctx);
-  return ctx->compute;
+hipStream_t mp_ctx_compute_stream(mp_ctx* ctx) { return ctx->compute; }
+// ... after this: the communicator is about to enqueue something that reads torques, so the parked float64 passes run first - and
+// a pass that cannot be launched fails the collective instead of letting it send float32-only rows
+int mp_ctx_flush_parked(mp_ctx* ctx) {
+  CTX_ENTER(ctx);
+  return MP_OK;
 }
 int mp_ctx_device(mp_ctx* ctx) { return ctx->device; }
 int mp_set_error(int code, const char* msg) { return set_err(code, "%s", msg); }

@@ -12,6 +12,7 @@
 #include "../../include/manipula_hip.h"
 
 hipStream_t mp_ctx_compute_stream(mp_ctx* ctx);
+int mp_ctx_flush_parked(mp_ctx* ctx);  // runs the float64 passes parked behind float32 launches; its failure fails the collective
 int mp_ctx_device(mp_ctx* ctx);
 int mp_set_error(int code, const char* msg);
 
@@ -117,6 +118,7 @@ int mp_comm_allgather(mp_comm* comm, const void* d_send, void* d_recv, size_t by
   if (!comm || !d_send || !d_recv) return mp_set_error(MP_ERR_INVALID, "mp_comm_allgather: null argument");
   if (bytes_per_rank == 0) return MP_OK;
   if (hipSetDevice(mp_ctx_device(comm->ctx)) != hipSuccess) return mp_set_error(MP_ERR_HIP, "mp_comm_allgather: hipSetDevice failed");
+  if (int rc = mp_ctx_flush_parked(comm->ctx)) return rc;
   // ncclInt8 == 0 (rccl.h:459): the payload is opaque bytes
   if (int rc = g_api.AllGather(d_send, d_recv, bytes_per_rank, 0, comm->comm, mp_ctx_compute_stream(comm->ctx)))
     return nccl_fail("ncclAllGather", rc);
@@ -129,6 +131,7 @@ int mp_comm_allgather(mp_comm* comm, const void* d_send, void* d_recv, size_t by
 int mp_comm_allgatherv(mp_comm* comm, const void* d_send, void* d_recv, const size_t* bytes_of_rank) {
   if (!comm || !d_recv || !bytes_of_rank) return mp_set_error(MP_ERR_INVALID, "mp_comm_allgatherv: null argument");
   if (hipSetDevice(mp_ctx_device(comm->ctx)) != hipSuccess) return mp_set_error(MP_ERR_HIP, "mp_comm_allgatherv: hipSetDevice failed");
+  if (int rc = mp_ctx_flush_parked(comm->ctx)) return rc;
   hipStream_t s = mp_ctx_compute_stream(comm->ctx);
   char* base = static_cast<char*>(d_recv);
   size_t mine_off = 0;
@@ -170,6 +173,7 @@ int mp_comm_exchange_chunk(mp_comm* comm, void* d_all, size_t bytes_per_rank, si
   if (hipSetDevice(mp_ctx_device(comm->ctx)) != hipSuccess) return mp_set_error(MP_ERR_HIP, "mp_comm_exchange_chunk: hipSetDevice failed");
   // the chunk was produced by kernels already queued on the compute stream: the exchange starts when they are done,
   // on its own stream, so the kernels of the NEXT chunk run beside it
+  if (int rc = mp_ctx_flush_parked(comm->ctx)) return rc;
   if (int rc = chain(mp_ctx_compute_stream(comm->ctx), comm->stream, "mp_comm_exchange_chunk: event chain failed")) return rc;
   if (comm->nranks == 1) return MP_OK;
   char* base = static_cast<char*>(d_all);
@@ -192,6 +196,7 @@ int mp_comm_exchange_chunk(mp_comm* comm, void* d_all, size_t bytes_per_rank, si
 int mp_comm_exchange_chunk_v(mp_comm* comm, void* d_all, const size_t* slot_offset, const size_t* chunk_offset, const size_t* chunk_bytes) {
   if (!comm || !d_all || !slot_offset || !chunk_offset || !chunk_bytes) return mp_set_error(MP_ERR_INVALID, "mp_comm_exchange_chunk_v: null argument");
   if (hipSetDevice(mp_ctx_device(comm->ctx)) != hipSuccess) return mp_set_error(MP_ERR_HIP, "mp_comm_exchange_chunk_v: hipSetDevice failed");
+  if (int rc = mp_ctx_flush_parked(comm->ctx)) return rc;
   if (int rc = chain(mp_ctx_compute_stream(comm->ctx), comm->stream, "mp_comm_exchange_chunk_v: event chain failed")) return rc;
   if (comm->nranks == 1) return MP_OK;
   char* base = static_cast<char*>(d_all);

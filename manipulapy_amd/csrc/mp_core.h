@@ -386,12 +386,46 @@ MP_HD void mp_joint_state(const MT& M, const T (&q)[N], MpJointState<T, N>& js) 
 // Recursive Newton-Euler in the compiled link frames.  tau is NOT clipped here.
 // a0: linear acceleration of the base in the pre-joint-1 frame (= base_R^T (-g)), wave-uniform.
 // tipn / tipf: the tip wrench [moment; force] expressed in the pre-joint-1 frame, per row (ignored unless HAS_FTIP).
-// SCALE: also return the largest joint FORCE component met on the way back (sF): what a float32 row's rounding errors scale with
-// - mp_id_row_is_hard below compares it, times the robot's length scale, with the row's own torques.  (The joint moments were
-// in the test at first; forces alone separate the same rows - profiles/r04_f32_precision_study.txt - and cost half.)
-template <typename T, int N, bool HAS_FTIP, bool SCALE, typename MT>
+// `sc`: what the recursion shows of its intermediate wrenches on the way - MpNoScale for a plain recursion; MpRowScale keeps the
+// size of the terms a float32 row's rounding errors scale with (mp_id_row_is_hard below compares it with the row's own torques):
+//   sc.body(i, n, f)   link i's own body wrench (forward pass),
+//   sc.joint(i, n, f)  the wrench joint i transmits, in link frame i (backward pass, before it is moved to the parent),
+//   sc.child(i, n, f)  the same wrench as link i - 1 receives it.
+struct MpNoScale {
+  template <typename T> MP_HD void joint(int, const T&, const T&, const T&, const T&, const T&, const T&) {}
+  template <typename T> MP_HD void body(int, const T&, const T&, const T&, const T&, const T&, const T&) {}
+  template <typename T> MP_HD void child(int, const T&, const T&, const T&, const T&, const T&, const T&) {}
+};
+// The scale of a row's large intermediate terms, from values the recursion needs anyway (round 4 took the largest force component
+// of joint 1, which a plain recursion of a robot without a lever at joints 0 and 1 never forms: 26 instructions of resurrected
+// dead code on the UR5, tools/rule_sweep.py): the moments that meet at link J = 1 - the link's own and the one joint 2 hands down,
+// whose SUM is what the two base torques are read from - and the force through joint 2 (times a length: the lever products
+// further out are parts of it).  One v_max3_f32 each.  Models of one or two joints: what exists of the three.
+template <typename T, int N>
+struct MpRowScale {
+  static constexpr int J = N > 1 ? 1 : 0;           // the link where the moments are looked at
+  static constexpr int JF = N > 2 ? 2 : N - 1;      // the joint whose force is looked at
+  T bm, cm, f;
+  static MP_HD T inf3(const T& x, const T& y, const T& z) { return mp_max(mp_max(mp_abs(x), mp_abs(y)), mp_abs(z)); }
+  MP_HD void body(int i, const T& nx, const T& ny, const T& nz, const T&, const T&, const T&) {
+    if (i == J) bm = inf3(nx, ny, nz);
+  }
+  MP_HD void joint(int i, const T&, const T&, const T&, const T& fx, const T& fy, const T& fz) {
+    if (i == JF) f = inf3(fx, fy, fz);
+  }
+  MP_HD void child(int i, const T& nx, const T& ny, const T& nz, const T&, const T&, const T&) {
+    if (i == J + 1) cm = inf3(nx, ny, nz);
+  }
+  // lscale: the robot's longest joint-to-joint offset
+  template <typename S> MP_HD T scale(S lscale) const {
+    const T lf = f * MpTraits<T>::splat(lscale);
+    if (N > J + 1) return mp_max(mp_max(bm, cm), lf);
+    return mp_max(bm, lf);
+  }
+};
+template <typename T, int N, bool HAS_FTIP, typename SC, typename MT>
 MP_HD void mp_rnea_impl(const MT& M, const typename MpTraits<T>::S (&a0)[3], const T (&tipn)[3], const T (&tipf)[3],
-                        const MpJointState<T, N>& js, const T (&qd)[N], const T (&qdd)[N], T (&tau)[N], T& sF) {
+                        const MpJointState<T, N>& js, const T (&qd)[N], const T (&qdd)[N], T (&tau)[N], SC& sc) {
   using S = typename MpTraits<T>::S;
   using TR = MpTraits<T>;
   const T zero = TR::splat(S(0));
@@ -442,25 +476,23 @@ MP_HD void mp_rnea_impl(const MT& M, const typename MpTraits<T>::S (&a0)[3], con
     ffx[i] = J.m * dvx - (J.hy * dwz - J.hz * dwy) + (wy * pfz - wz * pfy);
     ffy[i] = J.m * dvy - (J.hz * dwx - J.hx * dwz) + (wz * pfx - wx * pfz);
     ffz[i] = J.m * dvz - (J.hx * dwy - J.hy * dwx) + (wx * pfy - wy * pfx);
+    sc.body(i, fnx[i], fny[i], fnz[i], ffx[i], ffy[i], ffz[i]);
   }
   if (HAS_FTIP) {  // Js^T Ftip: the space-frame wrench, now expressed in link frame N, rides the backward pass
     fnx[N - 1] += tnx; fny[N - 1] += tny; fnz[N - 1] += tnz;
     ffx[N - 1] += tfx; ffy[N - 1] += tfy; ffz[N - 1] += tfz;
   }
   // backward pass
-  if (SCALE) sF = zero;
 #pragma unroll
   for (int i = N - 1; i >= 0; --i) {
     const auto& J = mp_joint_of(M, i);
     tau[i] = J.rev * fnz[i] + (S(1) - J.rev) * ffz[i];
-    // (joint 0's force is left out: it is dead code without this test - it feeds no torque of a revolute base - and joint 1's is the
-    // same load seen one frame further out)
-    if (SCALE && (i > 0 || N == 1))  // |.| are source modifiers, the maxima v_max3_f32: two instructions per joint
-      sF = mp_max(mp_max(mp_max(sF, mp_abs(ffx[i])), mp_abs(ffy[i])), mp_abs(ffz[i]));
+    sc.joint(i, fnx[i], fny[i], fnz[i], ffx[i], ffy[i], ffz[i]);
     if (i > 0) {
       T nx = fnx[i], ny = fny[i], nz = fnz[i], fx = ffx[i], fy = ffy[i], fz = ffz[i];
       mp_force_up_B(js.c[i], js.s[i], js.d[i], nx, ny, nz, fx, fy, fz);
       mp_force_up_A(J.ca, J.sa, J.a, nx, ny, nz, fx, fy, fz);
+      sc.child(i, nx, ny, nz, fx, fy, fz);   // joint i's wrench as link i - 1 receives it
       fnx[i - 1] += nx; fny[i - 1] += ny; fnz[i - 1] += nz;
       ffx[i - 1] += fx; ffy[i - 1] += fy; ffz[i - 1] += fz;
     }
@@ -470,8 +502,8 @@ MP_HD void mp_rnea_impl(const MT& M, const typename MpTraits<T>::S (&a0)[3], con
 template <typename T, int N, bool HAS_FTIP, typename MT>
 MP_HD void mp_rnea(const MT& M, const typename MpTraits<T>::S (&a0)[3], const T (&tipn)[3], const T (&tipf)[3],
                    const MpJointState<T, N>& js, const T (&qd)[N], const T (&qdd)[N], T (&tau)[N]) {
-  T sF;
-  mp_rnea_impl<T, N, HAS_FTIP, false>(M, a0, tipn, tipf, js, qd, qdd, tau, sF);
+  MpNoScale sc;
+  mp_rnea_impl<T, N, HAS_FTIP>(M, a0, tipn, tipf, js, qd, qdd, tau, sc);
 }
 
 // Same with the wave-uniform per-call constants (gravity + one tip wrench for every row).
@@ -487,26 +519,27 @@ MP_HD void mp_rnea(const MT& M, const MpCall<typename MpTraits<T>::S>& C, const 
 // ------------------------------------------------------------- float32 rows, adaptive precision
 // A float32 recursion carries ~1 ulp of its LARGEST intermediate terms into every torque.  Almost always that is far inside the
 // parity bound (1e-4 |ref| + 5e-6 max|row|); it is not on the few rows per thousand whose torques are a small difference of large
-// terms - an arm swinging at 10 rad/s whose joint wrenches reach hundreds of N.m while every torque of the row is a few N.m (over
-// c2's 12.3 M rows the plain float32 kernel missed the bound on 76, by up to 4.8 x; with the joint offsets taken exactly - MpJoint
-// co / so - on 1, by 1.3 x).  Such a row announces itself: the largest joint-force component the backward pass meets, times the
-// robot's length scale, is more than MP_HARD_ROW_K x the row's largest torque.  Those rows - 0.4 - 0.7 % of c2-distributed rows, in
-// runs of consecutive timesteps - are evaluated again in float64 from the same float32 inputs: by a pass of their own behind the
-// float32 kernel (mp_body_id_hard, csrc/mp_bodies.h) or, where no list is attached, in place (mp_rnea_cold).  What stays float32
-// sits at <= 0.45 x the bound on 12.3 M rows, the re-evaluated rows at <= 0.1 x (profiles/r04_f32_precision_study.txt).
-// Deterministic: a row's precision depends on that row's values only.
+// terms - an arm swinging at 10 rad/s, or balanced near upright, whose joint wrenches reach tens or hundreds of N.m while every
+// torque of the row is a fraction of one (over c2's 12.3 M rows the plain float32 kernel missed the bound on 76, by up to 4.8 x;
+// with the joint offsets taken exactly - MpJoint co / so - on 1, by 1.3 x; the torque that misses is almost always the shoulder's,
+// read from the sum of the upper arm's own moment and the one the forearm hands down).  Such a row announces itself: the scale of
+// its intermediate terms (MpRowScale above) is more than MP_HARD_ROW_K x the row's largest torque.  Those rows - 0.6 % of
+// c2-distributed rows, in runs of consecutive timesteps - are evaluated again in float64 from the same float32 inputs: by a pass of
+// their own behind the float32 kernel (mp_body_id_hard, csrc/mp_bodies.h) or, where no list is attached, in place (mp_rnea_cold).
+// What stays float32 sits at <= 0.36 x the bound on 12.3 M rows, the re-evaluated rows at <= 0.01 x (tools/rule_sweep.py,
+// profiles/r05_rule_sweep.txt).  Deterministic: a row's precision depends on that row's values only.
 #ifndef MP_HARD_ROW_K
-#define MP_HARD_ROW_K 14.0f
+#define MP_HARD_ROW_K 8.0f
 #endif
 #ifndef MP_ADAPTIVE_F32   // 0 (experiment switch): plain float32 rows, for A/B measurements of what the test and the float64 rows cost
 #define MP_ADAPTIVE_F32 1
 #endif
 template <int N>
-MP_HD bool mp_id_row_is_hard(const float (&tau)[N], float sF, float lscale) {
-  float rowmax = 0.0f;
+MP_HD bool mp_id_row_is_hard(const float (&tau)[N], float scale) {
+  float rowmax = mp_abs(tau[0]);
 #pragma unroll
-  for (int i = 0; i < N; ++i) rowmax = mp_max(rowmax, mp_abs(tau[i]));
-  return lscale * sF > MP_HARD_ROW_K * rowmax;   // (callers rule NaN rows out themselves)
+  for (int i = 1; i < N; ++i) rowmax = mp_max(rowmax, mp_abs(tau[i]));
+  return scale > MP_HARD_ROW_K * rowmax;   // (callers rule NaN rows out themselves)
 }
 
 // The float32 recursion of one row + its verdict.  tau is NOT clipped.
@@ -515,9 +548,9 @@ MP_HD bool mp_rnea_f32(const MT& M, const MpCall<float>& C, const MpJointState<f
                        const float (&qdd)[N], float (&tau)[N]) {
 #if MP_ADAPTIVE_F32
   const float tn[3] = {C.F1n[0], C.F1n[1], C.F1n[2]}, tf[3] = {C.F1f[0], C.F1f[1], C.F1f[2]};
-  float sF;
-  mp_rnea_impl<float, N, HAS_FTIP, true>(M, C.a0, tn, tf, js, qd, qdd, tau, sF);
-  return mp_id_row_is_hard<N>(tau, sF, M.lscale);
+  MpRowScale<float, N> sc;
+  mp_rnea_impl<float, N, HAS_FTIP>(M, C.a0, tn, tf, js, qd, qdd, tau, sc);
+  return mp_id_row_is_hard<N>(tau, sc.scale(M.lscale));
 #else
   mp_rnea<float, N, HAS_FTIP>(M, C, js, qd, qdd, tau);
   return false;

@@ -299,13 +299,14 @@ int mp_id_row_precision_cpu_f32(const mp_model* model, const float* q, const flo
     parallel_for(rows, 256, nthreads, [&](int64_t lo, int64_t hi) {
       const float tn[3] = {C.F1n[0], C.F1n[1], C.F1n[2]}, tf[3] = {C.F1f[0], C.F1f[1], C.F1f[2]};
       for (int64_t r = lo; r < hi; ++r) {
-        float a[N], b[N], c[N], t[N], sF;
+        float a[N], b[N], c[N], t[N];
         for (int j = 0; j < N; ++j) { a[j] = q[r * N + j]; b[j] = qd[r * N + j]; c[j] = qdd[r * N + j]; }
         MpJointState<float, N> js;
         mp_joint_state<float, N>(M, a, js);
-        if (ftip) mp_rnea_impl<float, N, true, true>(M, C.a0, tn, tf, js, b, c, t, sF);
-        else mp_rnea_impl<float, N, false, true>(M, C.a0, tn, tf, js, b, c, t, sF);
-        in_f64[r] = mp_id_row_is_hard<N>(t, sF, M.lscale) ? 1 : 0;
+        MpRowScale<float, N> sc;
+        if (ftip) mp_rnea_impl<float, N, true>(M, C.a0, tn, tf, js, b, c, t, sc);
+        else mp_rnea_impl<float, N, false>(M, C.a0, tn, tf, js, b, c, t, sc);
+        in_f64[r] = mp_id_row_is_hard<N>(t, sc.scale(M.lscale)) ? 1 : 0;
       }
     });
   })

@@ -6,6 +6,7 @@
 
 hipError_t mpk_selftest(hipStream_t s, int* d_out /* 64 ints */);
 hipError_t mpk_stream(hipStream_t s, int reads, bool nontemporal, const void* a, const void* b, const void* c, void* d, long n4);
+hipError_t mpk_stream_mix(hipStream_t s, int reads, int writes, bool nontemporal, const void* a, void* d, long n4);
 
 template <typename T>
 hipError_t mpk_id(hipStream_t s, const MpModel<T>& M, const MpCall<T>& C, bool ftip, const T* q, const T* qd,

@@ -496,6 +496,34 @@ hipError_t mpk_stream(hipStream_t s, int reads, bool nontemporal, const void* a,
   return hipGetLastError();
 }
 
+// the same with any byte mix: every lane reads R 16-byte chunks (one from each of R arrays laid back to back in `a`) and writes W
+// (into W arrays back to back in `d`) - c3's kernel writes three bytes for every one it reads, the roll-out reads two for three
+template <int R, int W, bool NT>
+__global__ __launch_bounds__(256) void k_stream_mix(const mp_f4v* __restrict__ a, mp_f4v* __restrict__ d, long n4) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  mp_f4v v = {1.f, 2.f, 3.f, 4.f};
+#pragma unroll
+  for (int r = 0; r < R; ++r) v = v + (NT ? __builtin_nontemporal_load(a + r * n4 + i) : a[r * n4 + i]);
+#pragma unroll
+  for (int w = 0; w < W; ++w) {
+    if (NT) __builtin_nontemporal_store(v, d + w * n4 + i);
+    else d[w * n4 + i] = v;
+  }
+}
+hipError_t mpk_stream_mix(hipStream_t s, int reads, int writes, bool nontemporal, const void* a, void* d, long n4) {
+  const unsigned grid = (unsigned)((n4 + 255) / 256);
+#define MP_MIX(R, W)                                                                                                              \
+  if (reads == R && writes == W) {                                                                                                \
+    if (nontemporal) hipLaunchKernelGGL((k_stream_mix<R, W, true>), dim3(grid), dim3(256), 0, s, (const mp_f4v*)a, (mp_f4v*)d, n4); \
+    else hipLaunchKernelGGL((k_stream_mix<R, W, false>), dim3(grid), dim3(256), 0, s, (const mp_f4v*)a, (mp_f4v*)d, n4);          \
+    return hipGetLastError();                                                                                                     \
+  }
+  MP_MIX(0, 1) MP_MIX(1, 1) MP_MIX(3, 1) MP_MIX(1, 3) MP_MIX(2, 3) MP_MIX(1, 2) MP_MIX(2, 1)
+#undef MP_MIX
+  return hipErrorInvalidValue;
+}
+
 hipError_t mpk_selftest(hipStream_t s, int* d_out) {
   hipLaunchKernelGGL(k_selftest, dim3(1), dim3(64), 0, s, d_out);
   return hipGetLastError();

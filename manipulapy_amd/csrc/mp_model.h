@@ -43,7 +43,7 @@ constexpr int MP_JOINT_FIELDS = 18;
 template <typename T, int CAP>
 struct MpModelT {
   int n;
-  float lscale;  // the robot's length scale, max_i (|a_i| + |d_i|): weighs joint forces against moments in the float32 kernels'
+  float lscale;  // the robot's length scale, max_i max(|a_i| + |d_i|, |com_i|): weighs joint forces against moments in the float32 kernels'
                  // conditioning test (mp_core.h, mp_id_row_is_hard); float whatever T is
   int pad_[2];
   T base_R[9];   // pose of link frame 1 (at q1 = 0, before its own Rz/Tz) in the space frame

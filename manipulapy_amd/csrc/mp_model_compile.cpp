@@ -262,9 +262,15 @@ int compile_model(int n, const double* S, const double* Mcom, const double* G, c
     j.Iyy = Io[4]; j.Iyz = 0.5 * (Io[5] + Io[7]); j.Izz = Io[8];
   }
 
-  {  // length scale for the float32 kernels' conditioning test: the longest joint-to-joint offset (never zero)
+  {  // length scale for the float32 kernels' conditioning test: the longest lever a force meets on its way down - a joint-to-joint
+     // offset, or a link's centre of mass seen from its joint (round 5: a short fat chain whose joints coincide still multiplies its
+     // weight by the distance of its centres of mass) - never zero
     double L = 0;
-    for (int i = 0; i < n; ++i) L = std::fmax(L, std::fabs(out->j[i].a) + std::fabs(out->j[i].d));
+    for (int i = 0; i < n; ++i) {
+      const MpJoint<double>& j = out->j[i];
+      L = std::fmax(L, std::fabs(j.a) + std::fabs(j.d));
+      if (j.m > 0) L = std::fmax(L, std::sqrt(j.hx * j.hx + j.hy * j.hy + j.hz * j.hz) / j.m);
+    }
     out->lscale = (float)std::fmax(L, 1e-3);
   }
 

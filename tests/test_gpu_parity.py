@@ -34,7 +34,7 @@ def assert_f64(got, want):
 def assert_f32(got, want):
     want = np.asarray(want, dtype=np.float64)
     got = np.asarray(got, dtype=np.float64)
-    floor = F32_ROW * np.abs(want).max(axis=-1, keepdims=True)
+    floor = F32_ROW * np.abs(want).max(axis=-1, keepdims=True) + 1e-12   # (absolute: rows whose true torques are exactly zero)
     bad = np.abs(got - want) > F32_RTOL * np.abs(want) + floor
     assert not bad.any(), f"max abs err {np.abs(got - want).max():.3e}, {bad.sum()} elements outside tolerance"
 
@@ -1066,12 +1066,16 @@ def test_random_robots_on_gpu(seed, ctx):
     for r in range(0, rows, 16):
         np.testing.assert_allclose(T[r], ref.fk_space(tab, q[r]), atol=1e-10)
         np.testing.assert_allclose(J[r], ref.jacobian_space(tab, q[r]), atol=1e-10)
-    t32 = ctx.id_trajectory_host(m, q, qd, qdd, g, F, dtype=np.float32)
-    assert np.abs(t32[:9] - want).max() <= 2e-4 * scale
+    # float32: the suite's ELEMENT-WISE rule (1e-4 |ref| + 5e-6 max|row|), against the oracle on the same float32-rounded inputs
+    q32, qd32, qdd32 = (a.astype(np.float32) for a in (q, qd, qdd))
+    want32 = ref.inverse_dynamics_trajectory(tab, q32[:17].astype(np.float64), qd32[:17].astype(np.float64), qdd32[:17].astype(np.float64), g, F,
+                                             dtype=np.float64)
+    t32 = ctx.id_trajectory_host(m, q32, qd32, qdd32, g, F, dtype=np.float32)
+    assert_f32(t32[:17], want32)
     ctx.specialize(m)
-    s32 = ctx.id_trajectory_host(m, q, qd, qdd, g, F, dtype=np.float32)
+    s32 = ctx.id_trajectory_host(m, q32, qd32, qdd32, g, F, dtype=np.float32)
     s64 = ctx.id_trajectory_host(m, q, qd, qdd, g, F, dtype=np.float64)
-    assert np.abs(s32[:9] - want).max() <= 2e-4 * scale
+    assert_f32(s32[:17], want32)
     np.testing.assert_allclose(s64[:9], want, rtol=1e-6, atol=1e-6 * scale)
     assert np.abs(s32 - t32).max() <= 2e-4 * scale
     # mass matrix, forward dynamics, roll-out (every DOF has its own LDS tile shape) and IK on the same chain
@@ -2235,7 +2239,7 @@ def test_float64_pass_is_parked_and_run_before_anything_can_see_the_difference(s
     point that could read the torques.  Whatever is launched in between, a download must return exactly what the host-buffer entry
     point returns (which flushes at once): launches on other buffers (parked side by side, more than four of them), a launch that
     overwrites a parked launch's INPUT (the pass re-reads its rows: it must run first), a launch onto a parked launch's OUTPUT, a
-    captured graph replay (re-evaluates in place) and an empty launch."""
+    captured graph (its passes are nodes of the graph) and an empty launch."""
     from manipulapy_amd import _hip
     from oracle import c_oracle
 
@@ -2287,19 +2291,32 @@ def test_float64_pass_is_parked_and_run_before_anything_can_see_the_difference(s
         ctx.id_trajectory(m, *c["d"], n, c["d_tau"], dtype=np.float32)
         ctx.id_trajectory(m, *d_["d"], n, c["d_tau"], dtype=np.float32)
         np.testing.assert_array_equal(get(c)[:n], d_["want"][:n])
-        # (4) a captured replay re-evaluates its rows in place: same bound, and the float32 rows bit-equal
-        e = sets[4]
-        run(e); ctx.synchronize()
-        with ctx.capture() as cap:
-            run(e)
-        ctx.memset(e["d_tau"], 0, e["q"].nbytes)
-        cap.graph.launch()
+        # (4) captured launches carry their float64 passes as nodes of the graph (round 5; lists and counters belong to the graph):
+        # SIX launches on disjoint buffers in one capture - more than a pool parks, so a pass is captured in between and the rest at
+        # mp_graph_end - replayed on the captured inputs and then on exchanged ones; every download bit-equal to the host entry point
+        # (the in-place re-evaluation a capture used to fall back to is correct but NOT bit-equal to the pass)
         ctx.synchronize()
-        got = get(e)
-        hard = _hip.cpu_id_row_precision(m, e["q"], e["qd"], e["qdd"])
-        np.testing.assert_array_equal(got[~hard], e["want"][~hard])
-        np.testing.assert_allclose(got[hard], e["want"][hard], rtol=2e-6, atol=2e-6 * float(np.abs(e["want"]).max()))
+        with ctx.capture() as cap:
+            for st in sets:
+                run(st)
+        for rep in range(3):
+            want = [st["want"] for st in sets]
+            if rep == 2:   # fresh contents in the same buffers: every history reversed in time
+                for st in sets:
+                    for d, key in zip(st["d"], ("q", "qd", "qdd")):
+                        d.upload(np.ascontiguousarray(st[key][::-1]))
+                want = [ctx.id_trajectory_host(m, *(np.ascontiguousarray(st[k][::-1]) for k in ("q", "qd", "qdd")), dtype=np.float32) for st in sets]
+            for st in sets:
+                ctx.memset(st["d_tau"], 0, st["q"].nbytes)
+            cap.graph.launch()
+            if rep == 0:
+                run(sets[0])   # an eager launch right behind a replay: the context's own pool, not the graph's
+            for st, w in zip(sets, want):
+                np.testing.assert_array_equal(get(st), w)
         cap.graph.destroy()
+        for st in sets:
+            for d, key in zip(st["d"], ("q", "qd", "qdd")):
+                d.upload(st[key])
         # (5) nothing parked, nothing to run: an empty launch and a synchronise are fine
         ctx.id_trajectory(m, *sets[5]["d"], 0, sets[5]["d_tau"], dtype=np.float32)
         ctx.synchronize()
@@ -2331,6 +2348,129 @@ def test_float64_pass_is_parked_and_run_before_anything_can_see_the_difference(s
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["ur10", "iiwa7", "gen3", "crx10ia", "fanuc_m16ib", "abb_irb2400"])
+def test_adaptive_rows_on_arms_the_rule_was_not_fitted_on(name):
+    """Round 5: the float32 rows' conditioning rule (csrc/mp_core.h, MpRowScale) was chosen on the UR5.  Six arms
+    the benchmark does not use, 60 000 c2-distributed rows each (joint speeds up to ~10 rad/s), generic and robot-specialised
+    KERNELS against the pinned C oracle: no row over the suite's element-wise float32 bound, the worst at <= 0.6 x.  The CPU
+    launcher's side of the statement, on all 34 suite robots: tests/test_round5_rule.py."""
+    import bench
+    from manipulapy_amd import _hip
+    from oracle import c_oracle
+    from test_round5_rule import c2_rows, suite_robot
+
+    tab, model, lim = suite_robot(name)
+    q, qd, qdd = c2_rows(lim, 60, 4242)
+    want = c_oracle.inverse_dynamics_rows(tab, q.astype(np.float64), qd.astype(np.float64), qdd.astype(np.float64))[0]
+    ctx = _hip.HipContext(0)
+    try:
+        for tag in ("generic", "specialised"):
+            if tag == "specialised":
+                ctx.specialize(model)
+                assert ctx.is_specialized(model)
+            tau = ctx.id_trajectory_host(model, q, qd, qdd, dtype=np.float32)
+            par = bench.parity_rows(tau, want, "f32")
+            assert par["ok"] and par["rows_over_first_bound"] == 0 and par["worst_over_tol"] <= 0.6, (name, tag, par)
+    finally:
+        ctx.destroy()
+
+
+class _RawHip:
+    """The HIP runtime itself through ctypes: what a C-ABI caller with arrays of its own (hipMalloc, a framework tensor) uses next
+    to the library.  Test helper only."""
+
+    def __init__(self):
+        import ctypes
+        self.c = ctypes
+        self.rt = ctypes.CDLL("libamdhip64.so")
+        self.rt.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+        self.rt.hipFree.argtypes = [ctypes.c_void_p]
+        self.rt.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        self.rt.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+        self.rt.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
+        self.rt.hipMemsetAsync.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p]
+
+    def malloc(self, nbytes):
+        p = self.c.c_void_p()
+        assert self.rt.hipMalloc(self.c.byref(p), max(nbytes, 16)) == 0
+        return p
+
+    def upload(self, p, a):
+        assert self.rt.hipMemcpy(p, a.ctypes.data_as(self.c.c_void_p), a.nbytes, 1) == 0   # hipMemcpyHostToDevice, blocking
+
+    def download_on(self, stream, p, shape, dtype):
+        out = np.empty(shape, dtype)
+        assert self.rt.hipMemcpyAsync(out.ctypes.data_as(self.c.c_void_p), p, out.nbytes, 2, self.c.c_void_p(stream)) == 0
+        assert self.rt.hipStreamSynchronize(self.c.c_void_p(stream)) == 0
+        return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("specialise", [False, True])
+def test_caller_owned_device_arrays_are_complete_in_stream_order(specialise, tables):
+    """Round 5: the float64 pass over a float32 launch's ill-conditioned rows is parked only when
+    every array of the launch comes from the context's pool.  For arrays the CALLER allocated (hipMalloc here) it is enqueued at
+    once behind the kernel: a raw hipMemcpyAsync on the compute stream - no mp_* call between the launch and the read - returns
+    exactly what the host-buffer entry point returns, as the reference's launchers return finished arrays
+    (cuda_kernels/trajectory_kernels.py:1043-1081).  Given rows and generated rows (the fused launch), and a mixed launch (inputs
+    from the pool, output the caller's)."""
+    from manipulapy_amd import _hip
+
+    tab = tables["ur5"]
+    lim = tab.joint_limits
+    rng = np.random.default_rng(91)
+    hip = _RawHip()
+    ctx = _hip.HipContext(0)
+    raw = []
+    try:
+        m = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee, lim)
+        if specialise:
+            ctx.specialize(m)
+        B, N = 70, 1001
+        s_ = rng.uniform(lim[:, 0], lim[:, 1], (B, 6)).astype(np.float32)
+        e_ = rng.uniform(lim[:, 0], lim[:, 1], (B, 6)).astype(np.float32)
+        o = ref.batch_joint_trajectory(lim, s_, e_, 2.0, N, 5)
+        q, qd, qdd = (np.ascontiguousarray(o[key].reshape(-1, 6), dtype=np.float32) for key in ("positions", "velocities", "accelerations"))
+        rows = len(q)
+        assert _hip.cpu_id_row_precision(m, q, qd, qdd).sum() > 100          # there ARE rows the pass has to rewrite
+        want = ctx.id_trajectory_host(m, q, qd, qdd, dtype=np.float32)
+        want_fused = ctx.traj_id_fused_host(m, s_, e_, 2.0, N, 5)
+        stream = ctx.stream()
+        assert stream
+        d = [hip.malloc(a.nbytes) for a in (q, qd, qdd)]
+        d_tau = hip.malloc(q.nbytes)
+        raw += d + [d_tau]
+        for p_, a in zip(d, (q, qd, qdd)):
+            hip.upload(p_, a)
+        for _ in range(3):   # (three times: a parked pass of an earlier launch would show up as a stale row of a later read)
+            assert hip.rt.hipMemsetAsync(d_tau, 0, q.nbytes, hip.c.c_void_p(stream)) == 0
+            ctx.id_trajectory(m, *d, rows, d_tau, dtype=np.float32)
+            np.testing.assert_array_equal(hip.download_on(stream, d_tau, q.shape, np.float32), want)
+        # inputs from the pool, the output the caller's: still at once
+        pool_in = [ctx.to_device(a) for a in (q, qd, qdd)]
+        assert hip.rt.hipMemsetAsync(d_tau, 0, q.nbytes, hip.c.c_void_p(stream)) == 0
+        ctx.id_trajectory(m, *pool_in, rows, d_tau, dtype=np.float32)
+        np.testing.assert_array_equal(hip.download_on(stream, d_tau, q.shape, np.float32), want)
+        # the fused generation + inverse dynamics on the caller's start / end / tau arrays
+        ds, de = hip.malloc(s_.nbytes), hip.malloc(e_.nbytes)
+        raw += [ds, de]
+        hip.upload(ds, s_); hip.upload(de, e_)
+        ctx.traj_id_fused_host(m, s_[:2], e_[:2], 2.0, N, 5)                 # sizes the time table for this N
+        assert hip.rt.hipMemsetAsync(d_tau, 0, q.nbytes, hip.c.c_void_p(stream)) == 0
+        ctx.traj_id_fused(m, ds, de, B, N, 2.0, 5, d_tau)
+        np.testing.assert_array_equal(hip.download_on(stream, d_tau, (B, N, 6), np.float32), want_fused)
+        # and a launch on pool arrays in between stays parked - until the stream accessor (an entry point) is called again
+        d_pool_tau = ctx.alloc(q.nbytes)
+        ctx.id_trajectory(m, *pool_in, rows, d_pool_tau, dtype=np.float32)
+        np.testing.assert_array_equal(d_pool_tau.download(q.shape, np.float32), want)
+    finally:
+        ctx.synchronize()
+        for p_ in raw:
+            hip.rt.hipFree(p_)
+        ctx.destroy()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("specialise", [False, True])
 def test_more_ill_conditioned_rows_than_the_list_holds(specialise, tables):
     """An arm balanced upright: joint forces carry its weight, every torque is ~0.1 N.m - EVERY row is ill-conditioned in float32.  The
@@ -2345,13 +2485,20 @@ def test_more_ill_conditioned_rows_than_the_list_holds(specialise, tables):
     rows = 600_000 + 37
     q = (np.array([0.0, -np.pi / 2, 0.0, -np.pi / 2, 0.0, 0.0]) + rng.uniform(-2e-3, 2e-3, (rows, 6))).astype(np.float32)
     z = np.zeros_like(q)
+    # non-finite rows in a launch whose list overflows: the pass then walks EVERY row and must leave these as the float32 kernel
+    # stored them (NaN rows, reference planning/trajectory_dynamics.py:345-358) - with torque limits, so that a clip could launder them
+    qd = z.copy()
+    bad_rows = [100, 70_001, rows - 5]
+    q[bad_rows[0], 2] = np.nan
+    qd[bad_rows[1], 0] = np.inf
+    qd[bad_rows[2], 5] = -np.inf
     ctx = _hip.HipContext(0)
     try:
-        m = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee, tab.joint_limits)
+        m = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee, tab.joint_limits, np.tile([-150.0, 150.0], (6, 1)))
         if specialise:
             ctx.specialize(m)
-        assert _hip.cpu_id_row_precision(m, q[:4096], z[:4096], z[:4096]).all()
-        d = [ctx.to_device(a) for a in (q, z, z)]
+        assert _hip.cpu_id_row_precision(m, q[:4096], z[:4096], z[:4096])[np.r_[0:100, 101:4096]].all()
+        d = [ctx.to_device(a) for a in (q, qd, z)]
         d_tau = ctx.alloc(q.nbytes)
         got = []
         for _ in range(2):
@@ -2359,7 +2506,10 @@ def test_more_ill_conditioned_rows_than_the_list_holds(specialise, tables):
             ctx.id_trajectory(m, *d, rows, d_tau, dtype=np.float32)
             got.append(d_tau.download(q.shape, np.float32))
         np.testing.assert_array_equal(got[0], got[1])
-        sample = np.r_[0:3000, rows - 3000:rows]
+        assert np.isnan(got[0][bad_rows]).all(), got[0][bad_rows]
+        neighbours = np.array([r + k for r in bad_rows for k in (-1, 1)])
+        assert np.isfinite(got[0][neighbours]).all()
+        sample = np.setdiff1d(np.r_[0:3000, rows - 3000:rows], bad_rows)
         want = c_oracle.inverse_dynamics_rows(tab, q[sample].astype(np.float64), z[sample].astype(np.float64), z[sample].astype(np.float64))[0]
         err = np.abs(got[0][sample].astype(np.float64) - want)
         tol = 1e-4 * np.abs(want) + 5e-6 * np.abs(want).max(axis=1, keepdims=True)
