@@ -102,7 +102,23 @@ def oracle_tables(ref, robot):
                            B=t["B_list"].astype(np.float64), name=robot)
 
 
-def cpu_baseline(robot, q, qd, qdd, budget_s=12.0):
+def oracle_rows_in(tab, q, qd, qdd, budget_s):
+    """How many of the rows the C oracle evaluates in `budget_s` seconds on this box's cores.  Two probes: 2048 rows start the OpenMP
+    threads (on 128 threads that call IS the start-up: round 4 sized the headline's sample from it and stopped at 1.09 M of 4.1 M
+    rows after 2.3 s of a 12 s budget), then a sample large enough to keep every thread busy gives the rate."""
+    from oracle import c_oracle
+
+    total = q.shape[0]
+    probe = min(2048, total)
+    c_oracle.inverse_dynamics_rows(tab, q[:probe], qd[:probe], qdd[:probe])
+    probe2 = min(total, 65536)
+    t0 = time.perf_counter()
+    c_oracle.inverse_dynamics_rows(tab, q[:probe2], qd[:probe2], qdd[:probe2])
+    rate = probe2 / max(time.perf_counter() - t0, 1e-6)
+    return int(min(total, max(probe2, rate * budget_s)))
+
+
+def cpu_baseline(robot, q, qd, qdd, budget_s=15.0):
     """The CPU oracle — the reference's algorithm (1 + 2n mass matrices per point, finite-difference Coriolis)
     restated in C (oracle/oracle.c, pinned to the reference's golden vectors) — timed on this box's host
     cores (OpenMP over rows) on a bounded sample of the SAME rows.  Reported, never shipped."""
@@ -112,11 +128,7 @@ def cpu_baseline(robot, q, qd, qdd, budget_s=12.0):
     tab = oracle_tables(ref, robot)
     n = tab.n
     q, qd, qdd = (np.ascontiguousarray(x, dtype=np.float64) for x in (q, qd, qdd))
-    probe = min(2048, q.shape[0])
-    t0 = time.perf_counter()
-    _, threads = c_oracle.inverse_dynamics_rows(tab, q[:probe], qd[:probe], qdd[:probe])
-    rate = probe / max(time.perf_counter() - t0, 1e-6)            # rows/s incl. thread start-up
-    rows = int(min(q.shape[0], max(probe, rate * budget_s)))
+    rows = oracle_rows_in(tab, q, qd, qdd, budget_s)
     t0 = time.perf_counter()
     tau, threads = c_oracle.inverse_dynamics_rows(tab, q[:rows], qd[:rows], qdd[:rows])
     dt = time.perf_counter() - t0
@@ -184,6 +196,49 @@ def device_copy_probe(ctx):
                        "non-temporal pair is the access form of the whole-line row movers (mp_spec_id_co)"}
     except Exception as exc:   # a diagnostic: never costs the line
         return {"error": str(exc)[:200]}
+
+
+def mix_probe(ctx, cfg, n, rows):
+    """A configuration's OWN byte mix and size through a plain streaming kernel, in this process, right before the timed region
+    (mp_stream_bandwidth_mix): what THIS box in THIS state streams.  `frac_of_probe` = the kernel's achieved rate / this - the
+    box-independent figure beside `frac` (c3's 1 : 3 mix measured 3.6 - 4.1 ms on boxes whose power state differed)."""
+    w = 4 if cfg["dtype"] == "f32" else 8
+    alg = algorithmic_bytes_per_row(cfg, n) * rows
+    reads, writes = {"id": (3, 1), "fused": (0, 1), "fk_jac_id": (1, 3), "fd_traj": (2, 3)}[cfg["op"]]
+    nb = (alg // (reads + writes)) & ~15
+    reps = int(max(3, min(20, 4_000_000_000 // max(alg, 1))))
+    try:
+        out = {"reads": reads, "writes": writes, "bytes_per_array": nb, "reps": reps}
+        for _ in range(2):   # (the first round ramps the clocks)
+            out["plain_GBps"] = ctx.stream_bandwidth_mix(nb, reads, writes, reps, nontemporal=False)
+            out["nontemporal_GBps"] = ctx.stream_bandwidth_mix(nb, reads, writes, reps, nontemporal=True)
+        out["GBps"] = max(out["plain_GBps"], out["nontemporal_GBps"])
+        out["how"] = ("mp_stream_bandwidth_mix: float4 per lane, `reads` arrays in, `writes` arrays out, the faster of plain and non-temporal "
+                      "accesses, same process, right before this configuration's timed region")
+        return out
+    except Exception as exc:   # a diagnostic: never costs the line
+        return {"error": str(exc)[:200]}
+    finally:
+        ctx.synchronize()
+        ctx.trim_pool()
+
+
+def parity_brief(par, rows_total=None, sets=None):
+    """The few numbers that say whether (and on how many rows) a configuration met parity - small enough for the driver's record."""
+    if not par:
+        return None
+    out = {"ok": bool(par.get("ok")), "rows_checked": int(par.get("rows_all_sets", par.get("rows", par.get("trajectories_checked", 0)) or 0))}
+    if rows_total is not None:
+        out["rows_total"] = int(rows_total)
+    for k in ("rows_over_first_bound", "worst_over_tol"):
+        if k in par:
+            out[k] = par[k]
+    if "other_input_sets" in par:
+        out["rows_over_first_bound"] = int(par.get("rows_over_first_bound", 0) + sum(o["rows_over_first_bound"] for o in par["other_input_sets"]))
+        out["worst_over_tol"] = float(max([par.get("worst_over_tol", 0.0)] + [o["worst_over_tol"] for o in par["other_input_sets"]]))
+    if sets is not None:
+        out["sets_checked"] = int(sets)
+    return out
 
 
 def ramp(ctx, step, ms):
@@ -273,11 +328,7 @@ def oracle_id_rows(robot, q, qd, qdd, budget_s):
 
     tab = oracle_tables(ref, robot)
     q, qd, qdd = (np.ascontiguousarray(x, dtype=np.float64) for x in (q, qd, qdd))
-    probe = min(2048, q.shape[0])
-    t0 = time.perf_counter()
-    c_oracle.inverse_dynamics_rows(tab, q[:probe], qd[:probe], qdd[:probe])
-    rate = probe / max(time.perf_counter() - t0, 1e-6)
-    rows = int(min(q.shape[0], max(probe, rate * budget_s)))
+    rows = oracle_rows_in(tab, q, qd, qdd, budget_s)
     return c_oracle.inverse_dynamics_rows(tab, q[:rows], qd[:rows], qdd[:rows])[0], tab
 
 
@@ -331,6 +382,8 @@ def bench_fd(args, cfg, info, hg, ctx, model, t, props, headline=True):
     ctx.synchronize()
     kern_ms_cold = cb.elapsed_ms_since(ca) / ncold
     ca.destroy(); cb.destroy()
+    probe = mix_probe(ctx, cfg, n, B * N) if world == 1 else None   # this box's streaming rate for the roll-out's byte mix, same process
+    single = None
     ramp(ctx, step, args.ramp_ms)
     for _ in range(args.warmup):
         step()
@@ -372,6 +425,15 @@ def bench_fd(args, cfg, info, hg, ctx, model, t, props, headline=True):
         "device": props["name"],
     }
     attach_counters(result, cfg["name"])
+    if probe is not None:
+        result["roofline"]["probe"] = probe
+        if probe.get("GBps"):
+            result["roofline"]["frac_of_probe"] = achieved / probe["GBps"]
+    if single is not None:
+        result["roofline"]["kernel_ms_single_set"] = single["kernel_ms"]
+        result["roofline"]["frac_single_set"] = alg_bytes / (single["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS
+        result["roofline"]["single_set"] = ("the same K launches on ONE set of arrays (a caller that reuses its buffers): a float64 pass runs "
+                                            "behind every launch; `frac` / `value` rotate over `config.input_sets` sets")
     if info.rank == 0 and headline:
         result["roofline"]["device_copy"] = device_copy_probe(ctx)
     if info.rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -427,6 +489,8 @@ def bench_fd(args, cfg, info, hg, ctx, model, t, props, headline=True):
         par["rule"] = ("all outputs finite, one-step defect within bounds, >= 99.9 % of the trajectories within 1e-4 of each array's scale over "
                        "all N steps and none beyond 1e-2")
         result["parity_sample"] = par
+        result["roofline"]["parity"] = {"ok": par["ok"], "rows_checked": int(nbt * N), "rows_total": int(B * N), "trajectories_checked": int(nbt),
+                                        "worst_drift_over_scale": par["drift_over_scale"]["max"]}
         if not headline:
             result.pop("cpu_baseline", None)
     for b in bufs:
@@ -645,6 +709,28 @@ def bench_strong(name, args, info, hg, ctx, props):
         except Exception as exc:
             return f"not checked: {str(exc)[:200]}"
 
+    def blocks_agree(d_alls):
+        """Every byte of every rank's block, on EVERY rank (comparing one recomputed trajectory only covers the first chunk
+        of every block): each rank sums the 32-bit words of each block as it holds it, the sums travel over gloo, and a block counts
+        only when every rank's copy sums to what its owner's own copy does.  Collective: every rank calls it."""
+        try:
+            ctx.synchronize()
+            mine = np.zeros((len(d_alls), world), np.int64)
+            for a, d_all in enumerate(d_alls):
+                for r in range(world):
+                    nbytes = plan["bytes_of_rank"][r]
+                    if nbytes == 0:
+                        continue
+                    buf = np.empty(nbytes // 4, np.uint32)
+                    _hip._check(ctx.lib.mp_memcpy_d2h(ctx.handle, buf.ctypes.data, d_all.offset(plan["slot_offset"][r]), buf.nbytes))
+                    mine[a, r] = int(buf.sum(dtype=np.uint64) & np.uint64(0x7fffffffffffffff))
+                    del buf
+            seen = hg.allgather(mine.reshape(1, -1)).reshape(world, len(d_alls), world)   # [holder, array, owner]
+            bad = [(int(h), int(a), int(o)) for h in range(world) for a in range(len(d_alls)) for o in range(world) if seen[h, a, o] != seen[o, a, o]]
+            return True if not bad else f"{len(bad)} (holder, array, owner) blocks differ from their owner's copy, first {bad[0]}"
+        except Exception as exc:
+            return f"not checked: {str(exc)[:200]}"
+
     def gather_phase():
         try:
             uid = _hip.HipContext.comm_unique_id() if rank == 0 else None
@@ -660,8 +746,10 @@ def bench_strong(name, args, info, hg, ctx, props):
             wall_g, _ = timed(step_and_gather)
             ms_g = wall_g / args.steps * 1e3
             gather.update({"ms_per_step_with_allgather": ms_g, "value_with_allgather": total_jt * args.steps / wall_g})
+            whole = blocks_agree(d_alls)          # every rank
             if rank == 0:
-                gather["verified"] = verify(d_alls)
+                first = verify(d_alls)
+                gather["verified"] = True if (first is True and whole is True) else f"first trajectories: {first}; whole blocks: {whole}"
             if cfg["op"] == "id":
                 ov = plan["overlapped_exchange"]
                 d_all = d_alls[0]
@@ -681,8 +769,10 @@ def bench_strong(name, args, info, hg, ctx, props):
                 gather["overlapped"] = {"chunks": ov["chunks"], "ms_per_step": wall_o / args.steps * 1e3, "value": total_jt * args.steps / wall_o,
                                         "how": "per chunk: kernel on the compute stream straight into this rank's block, then grouped "
                                                "ncclSend / ncclRecv to every peer on the communicator's stream (mp_comm_exchange_chunk_v)"}
+                whole = blocks_agree([d_all])     # every rank: all four chunks of every peer's block
                 if rank == 0:
-                    gather["overlapped"]["verified"] = verify([d_all])
+                    first = verify([d_all])
+                    gather["overlapped"]["verified"] = True if (first is True and whole is True) else f"first trajectories: {first}; whole blocks: {whole}"
             else:
                 gather["overlapped"] = None   # a roll-out is sequential in time: its outputs are complete only at the end of the launch
             comm.destroy()
@@ -871,8 +961,36 @@ def main():
             result["configs"][name + "_strong"] = entry
             if hung:
                 break
+    if world > 1 or os.environ.get("MANIPULAPY_BENCH_FORCE_GATHER") == "1":
+        # an N > 1 line whose collectives could not RUN still carries its compute-only figures; say so at the top level, where a
+        # reader of the line's first keys sees it: names of the entries whose reassembly raised or timed out
+        errs = [k for k, v in [(names[0], result)] + list((result.get("configs") or {}).items())
+                if isinstance(v.get("allgather"), dict) and "error" in v["allgather"]]
+        result["collectives"] = {"ran": not errs, "failed_in": errs}
     if failed:
         result["parity_failed"] = failed
+    # The LAST key of the line (so that the last kilobyte of stdout always holds it, however long the "configs" object grew): every
+    # configuration in one row each - ms per step, fraction of the HBM peak, of this box's probe, and whether / on how many rows
+    # it met parity.
+    def brief(e):
+        rl = e.get("roofline") or {}
+        b = {"ms": round(e["ms_per_step"], 5) if "ms_per_step" in e else None, "frac": round(rl["frac"], 3) if "frac" in rl else None}
+        if "frac_of_probe" in rl:
+            b["of_probe"] = round(rl["frac_of_probe"], 3)
+        if "frac_single_set" in rl:
+            b["frac_1set"] = round(rl["frac_single_set"], 3)
+        par = rl.get("parity") or parity_brief(e.get("parity_sample"))
+        if par:
+            b["parity_ok"], b["rows"] = par["ok"], par["rows_checked"]
+            if "worst_over_tol" in par:
+                b["worst"] = round(par["worst_over_tol"], 3)
+        if "error" in e:
+            b["error"] = e["error"][:80]
+        return b
+    summary = {names[0]: brief(result)}
+    for k, v in (result.get("configs") or {}).items():
+        summary[k] = brief(v)
+    result["summary"] = summary
     if info.rank == 0:
         emit(result)
     if hung:
@@ -899,7 +1017,10 @@ def compact(r):
     out["kernel_variant"] = r["config"].get("kernel_variant")
     rl = r["roofline"]
     out["kernel"], out["kernel_ms"], out["kernel_ms_cold"] = rl["kernel"], rl["kernel_ms"], rl["kernel_ms_cold"]
-    out["roofline"] = {k: rl[k] for k in ("bound", "achieved", "peak", "unit", "frac", "frac_cold", "traffic", "algorithmic_bytes_per_launch") if k in rl}
+    out["roofline"] = {k: rl[k] for k in ("bound", "achieved", "peak", "unit", "frac", "frac_cold", "frac_of_probe", "frac_single_set", "kernel_ms_single_set",
+                                          "traffic", "algorithmic_bytes_per_launch", "parity") if k in rl}
+    if "probe" in rl:
+        out["roofline"]["probe"] = {k: rl["probe"][k] for k in ("GBps", "plain_GBps", "nontemporal_GBps", "reads", "writes", "bytes_per_array", "error") if k in rl["probe"]}
     if "roofline_valu" in r:
         out["roofline_valu"] = {k: r["roofline_valu"][k] for k in ("frac", "valu_insts_per_launch", "issue_cycles_per_inst", "clock_hz", "source")}
     if "parity_sample" in r:
@@ -1081,9 +1202,23 @@ def bench_id(args, cfg, info, hg, ctx, model, t, props, headline):
     kern_ms_cold = cb.elapsed_ms_since(ca) / ncold
     ca.destroy(); cb.destroy()
 
+    # ---- this box's streaming rate for the configuration's own byte mix and size, right before the timed region
+    probe = mix_probe(ctx, cfg, n, rows) if world == 1 else None
+
     # ---- the timed step: every rank evaluates its own shard; the path has no exchange step, so no collective
     elapsed, kern_ms = timed()
     kern_ms_all = hg.max(kern_ms)
+
+    # ---- what a caller that reuses ONE set of arrays gets (the reference's usage, planning/trajectory_dynamics.py:31-90: one
+    #      trajectory's arrays, evaluated again and again): every launch's arrays overlap the previous launch's parked float64 pass,
+    #      so a pass runs behind every launch instead of one per `nsets` launches.  Reported beside the headline, never as `value`.
+    single = None
+    if world == 1 and cfg["dtype"] == "f32" and cfg["op"] in ("id", "fused") and nsets > 1 and args.launch == "stream":
+        def step_single():
+            turn[0] = 0
+            step()
+        wall1, kms1 = timed(step_fn=step_single)
+        single = {"ms_per_step": wall1 / args.steps * 1e3, "kernel_ms": kms1}
 
     # ---- multi-GPU only: the RCCL all-gather that reassembles the sharded torque history on every GPU,
     #      measured as a second timed loop (step + all-gather) and reported next to `value`
@@ -1206,6 +1341,15 @@ def bench_id(args, cfg, info, hg, ctx, model, t, props, headline):
         "device": props["name"],
     }
     attach_counters(result, cfg["name"])
+    if probe is not None:
+        result["roofline"]["probe"] = probe
+        if probe.get("GBps"):
+            result["roofline"]["frac_of_probe"] = achieved / probe["GBps"]
+    if single is not None:
+        result["roofline"]["kernel_ms_single_set"] = single["kernel_ms"]
+        result["roofline"]["frac_single_set"] = alg_bytes / (single["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS
+        result["roofline"]["single_set"] = ("the same K launches on ONE set of arrays (a caller that reuses its buffers): a float64 pass runs "
+                                            "behind every launch; `frac` / `value` rotate over `config.input_sets` sets")
     if info.rank == 0 and headline:
         result["roofline"]["device_copy"] = device_copy_probe(ctx)
 
@@ -1230,6 +1374,9 @@ def bench_id(args, cfg, info, hg, ctx, model, t, props, headline):
             result["cpu_baseline"] = {"value": None, "unit": "joint-timesteps/s", "cores": 0, "kind": "port",
                                       "sample": f"not measured: {type(exc).__name__}: {str(exc)[:200]}"}
             result["parity_sample"] = {"ok": False, "error": f"{type(exc).__name__}: {str(exc)[:200]}"}
+    if "parity_sample" in result:
+        checked_sets = 1 + len(result["parity_sample"].get("other_input_sets", []))
+        result["roofline"]["parity"] = parity_brief(result["parity_sample"], rows_total=rows * (nsets if cfg["op"] == "id" else 1), sets=checked_sets)
     if allgather is not None:
         result["allgather"] = allgather
         # the three figures of an N > 1 line side by side: `value` is compute only (the timed step has no collective)

@@ -245,7 +245,7 @@ int mp_fd_trajectory_tm_f64(mp_ctx* ctx, const mp_model* model, const double* d_
                             const double* d_taumat, const double* d_Ftipmat, int64_t B, int64_t N, const double* g,
                             double dt, int intRes, float* d_pos, float* d_vel, float* d_acc);
 /* d_dst (inner, outer, row_bytes) <- d_src (outer, inner, row_bytes): converts between the batch-major API arrays
- * (B,N,n) and the time-major layout (N,B,n), either way.  row_bytes: a multiple of 4, at most 128 (16 float64 joints). */
+ * (B,N,n) and the time-major layout (N,B,n), either way.  row_bytes: a multiple of 4, at most 256 (32 float64 joints). */
 int mp_transpose_rows(mp_ctx* ctx, const void* d_src, int64_t outer, int64_t inner, int64_t row_bytes, void* d_dst);
 
 /* cartesian_trajectory for B pose pairs (planning/trajectory.py:504-594, :676-737; replaces

@@ -507,7 +507,11 @@ int hard_flush(mp_ctx* ctx) {
       e->busy = false;
       ent[m++] = e;
     }
-    if (rc == MP_OK) {
+    // MANIPULAPY_HIP_EXPERIMENT=1 MANIPULAPY_HIP_SKIP_PASS=1 (measurements only - the results are then float32-only and the lists'
+    // counters are never reset): what a step costs without the pass kernel, i.e. the bound for any scheme that hides it
+    static const bool skip = getenv("MANIPULAPY_HIP_EXPERIMENT") && getenv("MANIPULAPY_HIP_EXPERIMENT")[0] == '1' &&
+                             getenv("MANIPULAPY_HIP_SKIP_PASS") && getenv("MANIPULAPY_HIP_SKIP_PASS")[0] == '1';
+    if (rc == MP_OK && !skip) {
       void* args[] = {&B};
       hipError_t he = hipModuleLaunchKernel(h->fn, blocks, (unsigned)m, 1, 64, 1, 1, 0, ctx->compute, args, nullptr);
       if (he != hipSuccess) rc = hip_err(he, "float64 pass of the ill-conditioned float32 rows");
@@ -2219,7 +2223,7 @@ int mp_inverse_kinematics_f64(mp_ctx* ctx, const mp_model* model, const double* 
       return rc;
     const MpBigModel<double>* dm = nullptr;
     if (int rc = device_big_model<double>(ctx, model, &dm)) return rc;
-    HIP_TRY(mpk_dyn_ik(ctx->compute, dm, PB, d_T_desired, d_theta0, (long)B, d_theta, d_success, d_iterations, d_restarts,
+    HIP_TRY(mpk_dyn_ik(ctx->compute, model->d.n, dm, PB, d_T_desired, d_theta0, (long)B, d_theta, d_success, d_iterations, d_restarts,
                        (unsigned long long*)ctx->queue_counter, ctx->compute_units));
     return MP_OK;
   }

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/manipula_hip.h"
@@ -400,19 +401,24 @@ int mp_inverse_kinematics_cpu_f64(const mp_model* model, const double* T_desired
     if (!fill(PB, MP_BIG_DOF)) return fail("mp_inverse_kinematics_cpu_f64: a joint has its lower limit above its upper limit");
     const MpBigModel<double>& MB = model->bd;
     const int n = MB.n;
-    parallel_for(B, 1, nthreads, [&](int64_t lo, int64_t hi) {
-      for (int64_t row = lo; row < hi; ++row) {
-        MpIkState<MP_BIG_DOF> S;
-        for (int j = 0; j < MP_BIG_DOF; ++j) S.theta[j] = j < n ? theta0[row * n + j] : 0.0;
-        mp_ik_begin(S, PB);
-        int done = 0;
-        while (!(done = mp_ik_iterate<MP_BIG_DOF, MpIkLooped<MP_BIG_DOF>>(MB, PB, S, T_desired + row * 16, theta0 + row * n))) {}
-        for (int j = 0; j < n; ++j) theta[row * n + j] = S.theta[j];
-        success[row] = done == 2 ? 1 : 0;
-        iterations[row] = S.k + 1;
-        restarts[row] = S.restarts;
-      }
-    });
+    auto rows_of = [&](auto cap_tag) {   // per-problem arrays of 16 entries for 9..16 joints, 32 beyond (as the kernels: MP_DISPATCH_CAP)
+      constexpr int CAP = decltype(cap_tag)::value;
+      parallel_for(B, 1, nthreads, [&](int64_t lo, int64_t hi) {
+        for (int64_t row = lo; row < hi; ++row) {
+          MpIkState<CAP> S;
+          for (int j = 0; j < CAP; ++j) S.theta[j] = j < n ? theta0[row * n + j] : 0.0;
+          mp_ik_begin(S, PB);
+          int done = 0;
+          while (!(done = mp_ik_iterate<CAP, MpIkLooped<CAP>>(MB, PB, S, T_desired + row * 16, theta0 + row * n))) {}
+          for (int j = 0; j < n; ++j) theta[row * n + j] = S.theta[j];
+          success[row] = done == 2 ? 1 : 0;
+          iterations[row] = S.k + 1;
+          restarts[row] = S.restarts;
+        }
+      });
+    };
+    if (n <= MP_MID_DOF) rows_of(std::integral_constant<int, MP_MID_DOF>{});
+    else rows_of(std::integral_constant<int, MP_BIG_DOF>{});
     return MP_OK;
   }
   MpIkParams P;

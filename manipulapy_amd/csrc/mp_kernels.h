@@ -86,7 +86,7 @@ hipError_t mpk_pd_regulation(hipStream_t s, const MpModel<double>& M, const MpCa
 hipError_t mpk_dyn_pd_regulation(hipStream_t s, int n, const MpBigModel<double>* d_model, const MpCall<double>& C, const double* theta0,
                                  const double* des, const double* Kp, const double* Kd, long K, double dt, int steps, double* err, int* count);
 // the same for 9..32 joints (run-time joint count, the model resident in device memory)
-hipError_t mpk_dyn_ik(hipStream_t s, const MpBigModel<double>* d_model, const MpIkBigParams& P, const double* Tdes, const double* theta0,
+hipError_t mpk_dyn_ik(hipStream_t s, int n, const MpBigModel<double>* d_model, const MpIkBigParams& P, const double* Tdes, const double* theta0,
                       long B, double* theta, int* success, int* iterations, int* restarts, unsigned long long* queue_counter,
                       int compute_units);
 

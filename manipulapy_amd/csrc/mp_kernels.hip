@@ -825,25 +825,27 @@ __global__ __launch_bounds__(64) void k_dyn_pd_regulation(const MpBigModel<doubl
   count[k] = mp_dyn_pd_regulation_run<CAP, double>(M, C.a0, theta0 + k * M.n, des + k * M.n, Kp[k], Kd[k], dt, steps, err + k * steps);
 }
 
-// inverse kinematics with a run-time joint count: the work queue of k_ik, the looped kinematics of mp_dyn.h
-__global__ __launch_bounds__(kBlock) void k_dyn_ik(const MpBigModel<double>* __restrict__ Mdev, const MpIkBigParams P,
+// inverse kinematics with a run-time joint count: the work queue of k_ik, the looped kinematics of mp_dyn.h.  CAP: the capacity of
+// the per-problem arrays (16 for the reference's 9- and 10-joint Jaco arms, 32 beyond: MP_DISPATCH_CAP, as the dynamics kernels)
+template <int CAP>
+__global__ __launch_bounds__(kBlock) void k_dyn_ik(const MpBigModel<double>* __restrict__ Mdev, const MpIkParamsT<CAP> P,
                                                    const double* __restrict__ Tdes, const double* __restrict__ theta0, long B,
                                                    double* __restrict__ theta, int* __restrict__ success, int* __restrict__ iterations,
                                                    int* __restrict__ restarts, unsigned long long* __restrict__ next) {
   MpBigConst<double>& M = *(MpBigConst<double>*)Mdev;
   const int n = M.n;
-  MpIkState<MP_BIG_DOF> S;
+  MpIkState<CAP> S;
   bool have = false;
   long row = 0;
   for (;;) {  // exit: the counter only grows, so every lane sees row >= B eventually
     if (!have) {
       row = (long)atomicAdd(next, 1ull);
       if (row >= B) break;
-      for (int j = 0; j < MP_BIG_DOF; ++j) S.theta[j] = j < n ? theta0[row * n + j] : 0.0;
+      for (int j = 0; j < CAP; ++j) S.theta[j] = j < n ? theta0[row * n + j] : 0.0;
       mp_ik_begin(S, P);
       have = true;
     }
-    if (const int done = mp_ik_iterate<MP_BIG_DOF, MpIkLooped<MP_BIG_DOF>>(M, P, S, Tdes + row * 16, theta0 + row * n)) {
+    if (const int done = mp_ik_iterate<CAP, MpIkLooped<CAP>>(M, P, S, Tdes + row * 16, theta0 + row * n)) {
       for (int j = 0; j < n; ++j) theta[row * n + j] = S.theta[j];
       success[row] = done == 2 ? 1 : 0;
       iterations[row] = S.k + 1;
@@ -885,15 +887,26 @@ hipError_t mpk_dyn_pd_regulation(hipStream_t s, int n, const MpBigModel<double>*
   return hipGetLastError();
 }
 
-hipError_t mpk_dyn_ik(hipStream_t s, const MpBigModel<double>* d_model, const MpIkBigParams& P, const double* Tdes, const double* theta0,
+template <int CAP>
+static MpIkParamsT<CAP> ik_params_for(const MpIkBigParams& P) {
+  MpIkParamsT<CAP> Q;
+  Q.eomg = P.eomg; Q.ev = P.ev; Q.damping = P.damping; Q.step_cap = P.step_cap; Q.w_o = P.w_o; Q.w_p = P.w_p;
+  Q.max_iterations = P.max_iterations; Q.seed = P.seed; Q.adaptive_tuning = P.adaptive_tuning; Q.backtracking = P.backtracking;
+  for (int j = 0; j < CAP; ++j) { Q.lo[j] = P.lo[j]; Q.hi[j] = P.hi[j]; }
+  return Q;
+}
+hipError_t mpk_dyn_ik(hipStream_t s, int n, const MpBigModel<double>* d_model, const MpIkBigParams& P, const double* Tdes, const double* theta0,
                       long B, double* theta, int* success, int* iterations, int* restarts, unsigned long long* queue_counter,
                       int compute_units) {
   if (B <= 0) return hipSuccess;
   hipError_t e = hipMemsetAsync(queue_counter, 0, sizeof(unsigned long long), s);
   if (e != hipSuccess) return e;
   const long want = (B + kBlock - 1) / kBlock, cap = 2L * (compute_units > 0 ? compute_units : 256);
-  hipLaunchKernelGGL(k_dyn_ik, dim3((unsigned)(want < cap ? want : cap)), dim3(kBlock), 0, s, d_model, P, Tdes, theta0, B, theta, success,
-                     iterations, restarts, queue_counter);
+  MP_DISPATCH_CAP(n, {
+    const MpIkParamsT<CAP> Q = ik_params_for<CAP>(P);
+    hipLaunchKernelGGL((k_dyn_ik<CAP>), dim3((unsigned)(want < cap ? want : cap)), dim3(kBlock), 0, s, d_model, Q, Tdes, theta0, B, theta, success,
+                       iterations, restarts, queue_counter);
+  })
   return hipGetLastError();
 }
 

@@ -658,18 +658,20 @@ def test_shard_ranges_cover_exactly():
         sharding.shard_range(4, 2, 2)
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_multi_process_gloo_shard_and_gather(world, tmp_path):
-    """world_size = 2 and 3 over gloo on the CPU: each rank generates its shard of a batch trajectory AND evaluates its shard of
+    """world_size = 2, 3 and 8 (the size north_star names) over gloo on the CPU: each rank generates its shard of a batch trajectory AND evaluates its shard of
     the torque history (the array north_star all-gathers) through the CPU launchers; the all-gather reassembles both in rank
-    order - with B = 10 the shards are uneven at world 3 (4 / 3 / 3 trajectories) - and equals the single-process result."""
+    order - with B = 10 the shards are uneven at world 3 (4 / 3 / 3 trajectories) and at world 8 (2 / 2 / 1 / 1 / 1 / 1 / 1 / 1) - and
+    equals the single-process result."""
     worker = os.path.join(ROOT, "tests", "_dist_worker.py")
     out = tmp_path / "result.npz"
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", PYTHONPATH=ROOT, MANIPULAPY_FORCE_CPU="1", MANIPULAPY_CPU_THREADS="2")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", PYTHONPATH=ROOT, MANIPULAPY_FORCE_CPU="1", MANIPULAPY_CPU_THREADS="1" if world > 4 else "2",
+               OMP_NUM_THREADS="1")
     port = 29500 + (os.getpid() % 400) + world
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), worker, str(out)]
-    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
     z = np.load(out)
     np.testing.assert_array_equal(z["gathered"], z["single"])
@@ -703,17 +705,17 @@ def test_potential_field_cpu_launcher_against_reference_dump():
 
 
 def test_bench_self_launches_one_worker_per_gpu():
-    """`python bench.py --gpus 2` as ONE command (the way the driver starts the scaling runs): the launcher spawns two
-    fresh workers with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*, they meet over gloo, rank 0's JSON line is relayed and
+    """`python bench.py --gpus N` as ONE command (the way the driver starts the scaling runs; N = 2, 3 and 8, the size north_star
+    names): the launcher spawns N fresh workers with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*, they meet over gloo, rank 0's JSON line is relayed and
     the exit code is the workers'.  Dry run = everything up to the first HIP call (there is no GPU here)."""
     env = dict(os.environ, PYTHONPATH=ROOT, MANIPULAPY_BENCH_DRYRUN="1")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    for world in (2, 3):
+    for world in (2, 3, 8):
         for attempt in range(2):   # (the launcher's port is picked by bind(0) and released before the workers take it: a CPU-only
             # rehearsal may lose that race to another process of a busy box once)
             res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1"], env=env,
-                                 capture_output=True, text=True, timeout=300)
+                                 capture_output=True, text=True, timeout=600)
             if res.returncode == 0:
                 break
         assert res.returncode == 0, res.stderr[-2000:]
@@ -730,8 +732,11 @@ def test_bench_self_launches_one_worker_per_gpu():
             assert c["bytes_of_rank"] == [b * N * n * 4 for b in c["trajectories_of_rank"]]
             assert c["slot_offset"] == [sum(c["bytes_of_rank"][:r]) for r in range(world)] and c["gathered_bytes_per_array"] == Bt * N * n * 4
             assert len(c["verify"]["seed_of_rank_streams"]) == world
+            if world == 8:   # BASELINE's own split: even shards
+                assert c["trajectories_of_rank"] == [Bt // 8] * 8 and (Bt // 8 == (32768 if name == "c4" else 131072))
             if name == "c4":
                 rounds = c["overlapped_exchange"]["rounds"]
+                assert len(rounds) == 4
                 for r in range(world):
                     assert sum(rd["chunk_bytes"][r] for rd in rounds) == c["bytes_of_rank"][r]
                     assert [rd["chunk_offset"][r] for rd in rounds] == [sum(x["chunk_bytes"][r] for x in rounds[:k]) for k in range(len(rounds))]
