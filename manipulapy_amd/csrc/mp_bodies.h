@@ -219,9 +219,11 @@ __device__ __forceinline__ bool mp_cold_rows(const MT& M, const MpCall<float>& C
 // inputs (`Mc`: the float64 model; `M`: the float32 one, for the torque limits the float32 kernels clip against), unrolled - this
 // kernel is register-allocated on its own (~170 VGPRs), which is the point of making it one.  `load(row, q, qd, qdd)` fetches or
 // regenerates a row's inputs.  *hard_ctrl is the count, *hard_next the list's other counter.
+// `first` / `stride` / `leader`: which list entries this lane takes and whether it is the one that zeroes the other counter - the
+// stand-alone pass: its place in the grid; the float32 kernel's leading workgroups (mp_body_id_lead): their place among those.
 template <int N, bool HAS_FTIP, typename MC, typename MF, typename LoadFn>
 __device__ __forceinline__ void mp_body_id_hard(const MC& Mc, const MF& M, const MpCall<float>& C, LoadFn load, float* __restrict__ tau,
-                                                unsigned rows) {
+                                                unsigned rows, unsigned first, unsigned stride, bool leader) {
   // A list that overflowed (more than one row in eight AND more than 65 536 of a launch ill-conditioned: an arm balanced upright for
   // a whole trajectory) holds an arbitrary subset - which waves found room depends on their order - and the rest were re-evaluated in
   // place by rolled code whose last bits differ from this pass's.  So that the launch's result does not depend on the order of its
@@ -230,8 +232,7 @@ __device__ __forceinline__ void mp_body_id_hard(const MC& Mc, const MF& M, const
   const unsigned count = C.hard_ctrl[0];
   const bool all = count > C.hard_cap;
   const unsigned n = all ? rows : count;
-  const unsigned stride = gridDim.x * blockDim.x;
-  for (unsigned k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
+  for (unsigned k = first; k < n; k += stride) {
     const long r = all ? (long)k : (long)C.hard_rows[k];
     if (r >= (long)rows) continue;  // (a list left behind by a launch whose pass never ran)
     float q[N], qd[N], qdd[N];
@@ -261,7 +262,56 @@ __device__ __forceinline__ void mp_body_id_hard(const MC& Mc, const MF& M, const
   // the OTHER counter of the list (its next user's): zeroed here, by the pass that runs between that counter's previous reader
   // and its next writers on the stream.  (Resetting this launch's own counter needs "every block has read it": one atomic per
   // block on one address - 1024 of them measured 20 us per launch.)
-  if (blockIdx.x == 0 && threadIdx.x == 0) *C.hard_next = 0;
+  if (leader) *C.hard_next = 0;
+}
+template <int N, bool HAS_FTIP, typename MC, typename MF, typename LoadFn>
+__device__ __forceinline__ void mp_body_id_hard(const MC& Mc, const MF& M, const MpCall<float>& C, LoadFn load, float* __restrict__ tau,
+                                                unsigned rows) {
+  mp_body_id_hard<N, HAS_FTIP>(Mc, M, C, load, tau, rows, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x,
+                               blockIdx.x == 0 && threadIdx.x == 0);
+}
+// The float64 pass of an EARLIER float32 launch, worked off by the first L.blocks workgroups of a later one (round 5): a pass of its
+// own costs ~4.7 us of launch and dependent loads however few rows it holds, at the front of another kernel the same rows cost their
+// arithmetic only.  The host hands a launch's list to a later launch only when that launch touches none of its arrays (mp_capi.cpp,
+// launch_id / mp_traj_id_fused_f32).  The hosting kernel needs the registers of the unrolled float64 recursion (120 - 170 VGPRs): the
+// fused generation + inverse dynamics kernel, two waves per SIMD by design, hosts it for free and does so by default; the given-rows
+// kernel mp_spec_id_co would lose a wave per SIMD for its float32 rows, which costs more than the pass (csrc/mp_jit.cpp: MP_ID_LEAD,
+// an experiment).
+template <int N, bool HAS_FTIP, typename MC, typename MF>
+__device__ __forceinline__ void mp_body_id_lead(const MC& Mc, const MF& M, const MpLead& L) {
+  const float* __restrict__ q = L.q; const float* __restrict__ qd = L.qd; const float* __restrict__ qdd = L.qdd;
+  mp_body_id_hard<N, HAS_FTIP>(Mc, M, L.C, [&](long r, float (&x)[N], float (&y)[N], float (&z)[N]) {
+    RunIO<float, N>::load(q, r, x); RunIO<float, N>::load(qd, r, y); RunIO<float, N>::load(qdd, r, z); }, L.tau, L.rows,
+    blockIdx.x * blockDim.x + threadIdx.x, L.blocks * blockDim.x, blockIdx.x == 0 && threadIdx.x == 0);
+}
+
+// ... and of a FUSED launch (generation + inverse dynamics): the listed rows are regenerated from the earlier launch's start / end
+// points (L.q / L.qd) and the context's time table (L.qdd: three doubles per timestep, L.nt timesteps per trajectory), exactly as
+// that launch's float32 kernel generated them
+template <int N, typename MF>
+__device__ __forceinline__ void mp_regen_row(const MF& M, const float* __restrict__ start, const float* __restrict__ end,
+                                             const double* __restrict__ tab, unsigned Nt, long r, float (&x)[N], float (&y)[N], float (&z)[N]) {
+  const unsigned b = (unsigned)r / Nt, t = (unsigned)r - b * Nt;
+  float a[N], e[N];
+  RunIO<float, N>::load(start, (long)b, a);
+  RunIO<float, N>::load(end, (long)b, e);
+  const double u0 = tab[3 * t], u1 = tab[3 * t + 1], u2 = tab[3 * t + 2];
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const double d = (double)(e[j] - a[j]);
+    x[j] = mp_clip((float)(u0 * d + (double)a[j]), M.qmin[j], M.qmax[j]);
+    y[j] = (float)(u1 * d);
+    z[j] = (float)(u2 * d);
+  }
+}
+template <int N, bool HAS_FTIP, typename MC, typename MF>
+__device__ __forceinline__ void mp_body_traj_id_lead(const MC& Mc, const MF& M, const MpLead& L) {
+  const float* __restrict__ start = L.q; const float* __restrict__ end = L.qd;
+  const double* __restrict__ tab = (const double*)L.qdd;
+  const unsigned Nt = L.nt;
+  mp_body_id_hard<N, HAS_FTIP>(Mc, M, L.C, [&](long r, float (&x)[N], float (&y)[N], float (&z)[N]) {
+    mp_regen_row<N>(M, start, end, tab, Nt, r, x, y, z); }, L.tau, L.rows,
+    blockIdx.x * blockDim.x + threadIdx.x, L.blocks * blockDim.x, blockIdx.x == 0 && threadIdx.x == 0);
 }
 
 // ------------------------------------------------------------------ one row per lane (float / double)

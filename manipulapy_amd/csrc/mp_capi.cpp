@@ -536,6 +536,26 @@ int hard_flush_if_overlapping(mp_ctx* ctx, const void* const* lo, const size_t* 
   }
   return MP_OK;
 }
+// Whether a parked float64 pass rides with the next float32 launch of its program (the launch's first workgroups work it off)
+// instead of waiting for a kernel of its own.  Fused launches (generated rows): yes, MANIPULAPY_HIP_LEAD_FUSED=0 switches it off
+// for A/B runs.  Given-rows launches (mp_spec_id_co): no - that kernel would need the float64 recursion's registers and lose a
+// wave per SIMD for its float32 rows, which costs more than the pass (csrc/mp_jit.cpp); MANIPULAPY_HIP_LEAD=1 together with a
+// program built with -DMP_ID_LEAD=1 (MANIPULAPY_HIP_EXPERIMENT) is the measured experiment.
+bool lead_enabled(bool fused) {
+  static const bool on_fused = [] { const char* e = getenv("MANIPULAPY_HIP_LEAD_FUSED"); return !(e && e[0] == '0'); }();
+  static const bool on_given = [] {
+    const char *e = getenv("MANIPULAPY_HIP_LEAD"), *x = getenv("MANIPULAPY_HIP_EXPERIMENT");
+    return e && e[0] == '1' && x && x[0] == '1';
+  }();
+  return fused ? on_fused : on_given;
+}
+// the parked pass (given rows, specialised program `fn`) a launch may carry: the oldest; `self` is the launch's own slot
+mp_ctx::HardSlot* pick_rider(mp_ctx* ctx, hipFunction_t fn, const mp_ctx::HardSlot* self, bool generated = false) {
+  mp_ctx::HardSlot* best = nullptr;
+  for (auto& hs : ctx->hp->slot)
+    if (hs.busy && &hs != self && hs.fn == fn && fn && (hs.nt != 0) == generated && (!best || hs.seq < best->seq)) best = &hs;
+  return best;
+}
 template <typename T> void make_call_ctx(mp_ctx* ctx, const mp_model* model, const double* g, const double* Ftip, MpCall<T>* c);
 template <> void make_call_ctx<float>(mp_ctx* ctx, const mp_model* model, const double* g, const double* Ftip, MpCall<float>* c) {
   make_call_f32(ctx, model, g, Ftip, c);
@@ -616,8 +636,20 @@ int launch_id(mp_ctx* ctx, const mp_model* model, const MpCall<float>& c, bool f
       long done = 0;
       if (sp->id_co[ftip ? 1 : 0] && rows >= 64 && id_co_enabled()) {  // whole waves: rows moved as whole lines, non-temporal (mp_body_id_co)
         long rows64 = rows & ~63L;
-        void* args[] = {&cc, &q, &qd, &qdd, &tau, &rows64};
-        if (int rc = launch_spec(ctx, sp->id_co[ftip ? 1 : 0], rows64, args, MP_JIT_ID_CO_BLOCK)) return rc;
+        // (experiment, see lead_enabled) One float64 pass that is still parked - an earlier launch's of the same program, none of
+        // whose arrays this launch touches (the others were run by hard_flush_if_overlapping on the way in) - rides with this
+        // launch: its first workgroups work the list off beside the float32 rows (mp_body_id_lead).
+        MpLead lead;
+        std::memset(&lead, 0, sizeof lead);
+        mp_ctx::HardSlot* rider = lead_enabled(false) ? pick_rider(ctx, sp->id_hard[ftip ? 1 : 0], hs) : nullptr;
+        if (rider) {
+          lead.C = rider->C; lead.q = rider->q; lead.qd = rider->qd; lead.qdd = rider->qdd; lead.tau = rider->tau; lead.rows = rider->nrows;
+          lead.blocks = std::min(hard_pass_blocks((long)rider->nrows), 512u);
+        }
+        const unsigned grid = (unsigned)(rows64 / MP_JIT_ID_CO_BLOCK) + lead.blocks;
+        void* args[] = {&cc, &q, &qd, &qdd, &tau, &rows64, &lead};
+        HIP_TRY(hipModuleLaunchKernel(sp->id_co[ftip ? 1 : 0], grid, 1, 1, MP_JIT_ID_CO_BLOCK, 1, 1, 0, ctx->compute, args, nullptr));
+        if (rider) { rider->busy = false; rider->orphan = false; }   // its pass is enqueued: the slot is free for the next launch
         done = rows64;
       }
       if (done == rows) return hard_pass();
@@ -1649,7 +1681,9 @@ int mp_model_specialize(mp_ctx* ctx, const mp_model* model) {
     void* a1[] = {&cf, &q, &z, &z, &o1, &np_};
     void* a2[] = {&cd, &qd_, &zd, &zd, &o2, &nr};
     float* o3 = (float*)d3;
-    void* a3[] = {&cf, &q, &z, &z, &o3, &nr};
+    MpLead no_lead;
+    std::memset(&no_lead, 0, sizeof no_lead);
+    void* a3[] = {&cf, &q, &z, &z, &o3, &nr, &no_lead};
     int rc = launch_spec(ctx, sp.id_s[0], rows, a0);
     if (!rc) rc = launch_spec(ctx, sp.id_pk[0], pairs, a1);
     if (!rc) rc = launch_spec(ctx, sp.id_d[0], rows, a2);
@@ -1813,8 +1847,21 @@ int mp_traj_id_fused_f32(mp_ctx* ctx, const mp_model* model, const float* d_star
     unsigned bpt = mpk_traj_blocks_per_trajectory(nt);
     const long rows_l = (long)B * (long)N;
     mp_ctx::HardSlot* hs = sp->traj_id_hard[ftip ? 1 : 0] ? attach_hard_list(ctx, rows_l, &c) : nullptr;
-    void* args[] = {&c, &d_start, &d_end, &nt, &bpt, &tab, &d_tau};
-    if (int rc = launch_spec(ctx, sp->traj_id_pk[ftip ? 1 : 0], (long)B * bpt * 256, args)) return rc;
+    // (as launch_id: one parked pass of an earlier fused launch of this program rides with this launch's first workgroups)
+    MpLead lead;
+    std::memset(&lead, 0, sizeof lead);
+    mp_ctx::HardSlot* rider = lead_enabled(true) && !ctx->tab_volatile ? pick_rider(ctx, sp->traj_id_hard[ftip ? 1 : 0], hs, true) : nullptr;
+    if (rider) {
+      lead.C = rider->C; lead.q = rider->q; lead.qd = rider->qd; lead.qdd = rider->qdd; lead.tau = rider->tau; lead.rows = rider->nrows;
+      lead.nt = rider->nt;
+      lead.blocks = std::min((hard_pass_blocks((long)rider->nrows) + 3u) / 4u, 128u);   // 256-lane workgroups
+    }
+    void* args[] = {&c, &d_start, &d_end, &nt, &bpt, &tab, &d_tau, &lead};
+    {
+      const unsigned grid = (unsigned)((long)B * bpt) + lead.blocks;
+      HIP_TRY(hipModuleLaunchKernel(sp->traj_id_pk[ftip ? 1 : 0], grid, 1, 1, 256, 1, 1, 0, ctx->compute, args, nullptr));
+    }
+    if (rider) { rider->busy = false; rider->orphan = false; }
     if (!hs) return MP_OK;
     // the generated rows' float64 pass is parked like a given-rows launch's; it reads the time table, so a call that rewrites the
     // table runs the parked passes first (above)

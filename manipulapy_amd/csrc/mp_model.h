@@ -79,6 +79,18 @@ struct MpCall {
   unsigned hard_row_base;
 };
 
+// The float64 pass of ONE earlier launch carried by the next float32 launch: its first `blocks` workgroups work off that launch's
+// list (csrc/mp_bodies.h, mp_body_id_lead) beside the float32 rows of the others.  blocks = 0: nothing carried.
+struct MpLead {
+  MpCall<float> C;       // the earlier launch's constants and its list (hard_rows / hard_ctrl / hard_next / hard_cap)
+  const float* q;
+  const float* qd;
+  const float* qdd;
+  float* tau;
+  unsigned rows;
+  unsigned blocks;
+  unsigned nt;           // a fused launch's pass: q = start points, qd = end points, qdd = the time table, nt timesteps per trajectory
+};
 // Up to four launches' worth of that pass in ONE kernel (blockIdx.y picks the launch): the pass costs ~5 us of launch and memory
 // latency however few rows it holds, so the host lets passes wait (mp_capi.cpp, hard_flush) and runs them together.
 constexpr int MP_HARD_BATCH = 4;

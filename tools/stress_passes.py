@@ -5,8 +5,13 @@ landing in other launches' inputs and outputs, three models (two specialised pro
 uploads, memsets, float64 launches and downloads.  A host mirror of every device array is advanced with what a SECOND context's
 host entry point returns for the same rows (it flushes at once); every download must equal its mirror bit for bit.
 
-    SEED=3 OPS=400 [THREADS=3] python tools/stress_passes.py      (THREADS: the models are dealt out to threads sharing both contexts)
+    SEED=3 OPS=400 [THREADS=3] [FOREIGN=1] python tools/stress_passes.py      (THREADS: the models are dealt out to threads sharing both contexts)
+
+FOREIGN=1 (round 5): the arrays of the first and the second model are the CALLER's (hipMalloc through the HIP runtime, not mp_malloc) and
+are read, written and cleared with raw HIP calls on the context's compute stream only - no mp_* entry point between a launch and
+the read of its result.  Launches on such arrays get their float64 pass at once (csrc/mp_capi.cpp, hard_park_or_run).
 """
+import ctypes
 import os
 import sys
 
@@ -17,6 +22,53 @@ import manipulapy_amd as mp  # noqa: E402
 from manipulapy_amd import _hip  # noqa: E402
 
 R = 24000  # rows per array
+
+
+class Foreign:
+    """A device array the library does not own, used through raw HIP calls ordered on the context's compute stream."""
+    rt = None
+
+    def __init__(self, stream, host=None, nbytes=0, base=None, off=0):
+        if Foreign.rt is None:
+            rt = ctypes.CDLL("libamdhip64.so")
+            rt.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+            rt.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+            rt.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+            rt.hipMemsetAsync.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p]
+            rt.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
+            rt.hipFree.argtypes = [ctypes.c_void_p]
+            Foreign.rt = rt
+        self.stream = stream
+        if base is not None:
+            self.base, self.off, self.ptr = base, off, ctypes.c_void_p(base.ptr.value + off)
+            return
+        self.base, self.off = None, 0
+        nbytes = host.nbytes if host is not None else nbytes
+        self.ptr = ctypes.c_void_p()
+        assert Foreign.rt.hipMalloc(ctypes.byref(self.ptr), nbytes) == 0
+        if host is not None:
+            self.upload(host)
+
+    def offset(self, nbytes):
+        return Foreign(self.stream, base=self, off=nbytes).ptr
+
+    def upload(self, a):   # the caller orders its own copy: behind everything the stream holds, blocking
+        a = np.ascontiguousarray(a)
+        assert Foreign.rt.hipStreamSynchronize(ctypes.c_void_p(self.stream)) == 0
+        assert Foreign.rt.hipMemcpy(self.ptr, a.ctypes.data_as(ctypes.c_void_p), a.nbytes, 1) == 0
+
+    def download(self, shape, dtype):
+        out = np.empty(shape, dtype)
+        assert Foreign.rt.hipMemcpyAsync(out.ctypes.data_as(ctypes.c_void_p), self.ptr, out.nbytes, 2, ctypes.c_void_p(self.stream)) == 0
+        assert Foreign.rt.hipStreamSynchronize(ctypes.c_void_p(self.stream)) == 0
+        return out
+
+    def memset(self, off, nbytes):
+        assert Foreign.rt.hipMemsetAsync(ctypes.c_void_p(self.ptr.value + off), 0, nbytes, ctypes.c_void_p(self.stream)) == 0
+
+    def free(self):
+        Foreign.rt.hipStreamSynchronize(ctypes.c_void_p(self.stream))
+        Foreign.rt.hipFree(self.ptr)
 
 
 def fast_rows(rng, lim, n, rows):
@@ -37,6 +89,8 @@ def main():
     rng = np.random.default_rng(seed)
     ctx, ref_ctx = _hip.HipContext(0), _hip.HipContext(0)
     models = []
+    foreign = os.environ.get("FOREIGN", "0") == "1"
+    stream = ctx.stream()
     for robot, spec in (("ur5", True), ("xarm6", False), ("panda", True)):
         t = mp.robot_tables(robot)
         m = _hip.HipModel(t["S_list"], t["Mlist_per_link"], t["Glist"], t["M_ee"], t["joint_limits"])
@@ -44,7 +98,7 @@ def main():
             ctx.specialize(m); ref_ctx.specialize(m)
         lim = np.asarray(t["joint_limits"], dtype=np.float64)
         host = fast_rows(rng, lim, m.n, R) + [np.zeros((R, m.n), np.float32) for _ in range(3)]   # q, qd, qdd, tau0..2
-        dev = [ctx.to_device(a) for a in host]
+        dev = [Foreign(stream, host=a) for a in host] if foreign and len(models) < 2 else [ctx.to_device(a) for a in host]
         flagged = int(_hip.cpu_id_row_precision(m, *host[:3]).sum())
         models.append({"name": robot, "m": m, "n": m.n, "host": host, "dev": dev, "flagged": flagged})
     launches = checks = 0
@@ -91,7 +145,10 @@ def main():
               k = int(rng.integers(3, 6))
               a, b = sorted(int(x) for x in rng.integers(0, R + 1, 2))
               if b > a:
-                  ctx.memset(M["dev"][k].offset(a * rb), 0, (b - a) * rb)
+                  if isinstance(M["dev"][k], Foreign):
+                      M["dev"][k].memset(a * rb, (b - a) * rb)
+                  else:
+                      ctx.memset(M["dev"][k].offset(a * rb), 0, (b - a) * rb)
                   M["host"][k][a:b] = 0
           elif kind == "upload":
               k = int(rng.integers(0, 6))
@@ -138,6 +195,11 @@ def main():
     for pair in held:
         for b_ in pair:
             b_.free()
+    ctx.synchronize()
+    for M in models:
+        for d in M["dev"]:
+            if isinstance(d, Foreign):
+                d.free()
     ctx.destroy(); ref_ctx.destroy()
     return 1 if bad else 0
 
