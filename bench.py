@@ -888,6 +888,9 @@ def main():
     ap.add_argument("--B", type=int, default=0, help="experiments only: override the config's trajectories per GPU")
     ap.add_argument("--N", type=int, default=0, help="experiments only: override the config's timesteps")
     ap.add_argument("--robot", default="", help="experiments only: override the config's robot")
+    ap.add_argument("--no-single-set", action="store_true",
+                    help="skip the second timed loop on ONE set of arrays (roofline.frac_single_set); the profiling scripts pass it so that "
+                         "the last K dispatches in a kernel trace are the K timed steps")
     ap.add_argument("--input-sets", type=int, default=0,
                     help="distinct input/output sets the steps rotate over (0 = enough for > 1.1 GB in flight, so no step can "
                          "be served from the 256 MB Infinity Cache)")
@@ -1213,7 +1216,7 @@ def bench_id(args, cfg, info, hg, ctx, model, t, props, headline):
     #      trajectory's arrays, evaluated again and again): every launch's arrays overlap the previous launch's parked float64 pass,
     #      so a pass runs behind every launch instead of one per `nsets` launches.  Reported beside the headline, never as `value`.
     single = None
-    if world == 1 and cfg["dtype"] == "f32" and cfg["op"] in ("id", "fused") and nsets > 1 and args.launch == "stream":
+    if world == 1 and cfg["dtype"] == "f32" and cfg["op"] in ("id", "fused") and nsets > 1 and args.launch == "stream" and not args.no_single_set:
         def step_single():
             turn[0] = 0
             step()

@@ -8,7 +8,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for v in "default|" "predictor_only|MP_HARD_ROW_K=1e30f" "K24|MP_HARD_ROW_K=24.0f" "plain|MP_ADAPTIVE_F32=0"; do
   name=${v%%|*}; export MANIPULAPY_HIP_JIT_DEFINES=${v##*|}
-  rocprofv3 --kernel-trace --output-format csv -d $OUT/$name -- python3 $R/bench.py --config $CFG --steps 300 --warmup 10 --no-cpu-baseline > $OUT/$name.log 2>&1
+  rocprofv3 --kernel-trace --output-format csv -d $OUT/$name -- python3 $R/bench.py --config $CFG --steps 300 --warmup 10 --no-cpu-baseline --no-single-set > $OUT/$name.log 2>&1
 done
 cd $R
 python3 - $OUT <<'PY'
