@@ -65,8 +65,10 @@ struct mp_ctx {
     bool busy = false;
     bool orphan = false;          // attached to a launch whose pass never followed (a failed launch): its counters are reset on reuse
     unsigned long long seq = 0;   // launch order
-    hipFunction_t fn = nullptr;   // the specialised pass of its model, or null: the generic one, run through `generic`
-    std::function<int()> generic;
+    hipFunction_t fn = nullptr;   // the specialised pass of its model, or null: the generic one (k_id_hard_batch) on ...
+    const MpModel<float>* gen_dm = nullptr;  // ... this device copy of the model,
+    int gen_n = 0;                           // ... this joint count
+    bool gen_ftip = false;                   // ... and with / without a tip wrench
     MpCall<float> C;
     const float *q = nullptr, *qd = nullptr, *qdd = nullptr;
     float* tau = nullptr;
@@ -437,7 +439,7 @@ void free_hard_pool(mp_ctx::HardPool* pool) {
   for (auto& hs : pool->slot) {
     if (hs.rows) (void)hipFree(hs.rows);
     if (hs.ctrl) (void)hipFree(hs.ctrl);
-    hs.rows = nullptr; hs.ctrl = nullptr; hs.cap = 0; hs.busy = false; hs.generic = nullptr;
+    hs.rows = nullptr; hs.ctrl = nullptr; hs.cap = 0; hs.busy = false; hs.gen_dm = nullptr;
   }
   for (void* p : pool->retired) (void)hipFree(p);
   pool->retired.clear();
@@ -452,9 +454,10 @@ inline int hard_passed(mp_ctx::HardSlot* hs, int rc) {
   return rc;
 }
 // park the pass of the launch just enqueued
-void hard_defer(mp_ctx* ctx, mp_ctx::HardSlot* hs, hipFunction_t fn, std::function<int()> generic, const MpCall<float>& C,
+void hard_defer(mp_ctx* ctx, mp_ctx::HardSlot* hs, hipFunction_t fn, const MpModel<float>* gen_dm, bool gen_ftip, const MpCall<float>& C,
                 const float* q, const float* qd, const float* qdd, float* tau, long rows, int n) {
-  hs->busy = true; hs->orphan = false; hs->seq = ++ctx->hp->seq; hs->fn = fn; hs->generic = std::move(generic); hs->C = C; hs->C.hard_row_base = 0;
+  hs->busy = true; hs->orphan = false; hs->seq = ++ctx->hp->seq; hs->fn = fn; hs->gen_dm = gen_dm; hs->gen_n = n; hs->gen_ftip = gen_ftip;
+  hs->C = C; hs->C.hard_row_base = 0;
   hs->q = q; hs->qd = qd; hs->qdd = qdd; hs->tau = tau; hs->nrows = (unsigned)rows; hs->bytes = (size_t)rows * (size_t)n * sizeof(float);
   hs->bytes_in = hs->bytes; hs->nt = 0;
 }
@@ -462,7 +465,7 @@ void hard_defer(mp_ctx* ctx, mp_ctx::HardSlot* hs, hipFunction_t fn, std::functi
 // not be rewritten while the pass is parked (mp_traj_id_fused_f32 runs the parked passes before it touches the table)
 void hard_defer_generated(mp_ctx* ctx, mp_ctx::HardSlot* hs, hipFunction_t fn, const MpCall<float>& C, const float* start, const float* end,
                           const double* tab, float* tau, long rows, int n, long B, unsigned nt) {
-  hard_defer(ctx, hs, fn, nullptr, C, start, end, (const float*)tab, tau, rows, n);
+  hard_defer(ctx, hs, fn, nullptr, false, C, start, end, (const float*)tab, tau, rows, n);
   hs->bytes_in = (size_t)B * (size_t)n * sizeof(float); hs->nt = nt;
 }
 // What becomes of the pass just parked.  It STAYS parked only when every array of its launch lies in this context's pool: such
@@ -488,19 +491,16 @@ int hard_flush(mp_ctx* ctx) {
   int rc = MP_OK;
   for (int i = 0; i < k;) {
     mp_ctx::HardSlot* h = order[i];
-    if (!h->fn) {  // generic kernels: one launch each
-      if (rc == MP_OK) rc = h->generic();
-      h->busy = false; h->generic = nullptr;
-      h->orphan = rc != MP_OK;
-      ++i;
-      continue;
-    }
     MpHardBatch B;
     std::memset(&B, 0, sizeof B);
     mp_ctx::HardSlot* ent[MP_HARD_BATCH];
     int m = 0;
     unsigned blocks = 1;
-    while (i < k && order[i]->fn == h->fn && m < MP_HARD_BATCH) {
+    // passes of one program - a specialised one (fn), or the generic kernel of one (device model, joint count, wrench) - share a launch
+    auto same = [&](const mp_ctx::HardSlot* o) {
+      return o->fn == h->fn && (h->fn || (o->gen_dm == h->gen_dm && o->gen_n == h->gen_n && o->gen_ftip == h->gen_ftip));
+    };
+    while (i < k && same(order[i]) && m < MP_HARD_BATCH) {
       mp_ctx::HardSlot* e = order[i++];
       B.C[m] = e->C; B.q[m] = e->q; B.qd[m] = e->qd; B.qdd[m] = e->qdd; B.tau[m] = e->tau; B.rows[m] = e->nrows; B.nt[m] = e->nt;
       blocks = std::max(blocks, hard_pass_blocks((long)e->nrows));
@@ -513,7 +513,8 @@ int hard_flush(mp_ctx* ctx) {
                              getenv("MANIPULAPY_HIP_SKIP_PASS") && getenv("MANIPULAPY_HIP_SKIP_PASS")[0] == '1';
     if (rc == MP_OK && !skip) {
       void* args[] = {&B};
-      hipError_t he = hipModuleLaunchKernel(h->fn, blocks, (unsigned)m, 1, 64, 1, 1, 0, ctx->compute, args, nullptr);
+      hipError_t he = h->fn ? hipModuleLaunchKernel(h->fn, blocks, (unsigned)m, 1, 64, 1, 1, 0, ctx->compute, args, nullptr)
+                            : mpk_id_hard_batch(ctx->compute, h->gen_dm, h->gen_n, h->gen_ftip, B, m, blocks);
       if (he != hipSuccess) rc = hip_err(he, "float64 pass of the ill-conditioned float32 rows");
     }
     for (int j = 0; j < m; ++j) ent[j]->orphan = rc != MP_OK;  // a pass that did not run leaves its list's counters as they are
@@ -630,7 +631,7 @@ int launch_id(mp_ctx* ctx, const mp_model* model, const MpCall<float>& c, bool f
       mp_ctx::HardSlot* hs = sp->id_hard[ftip ? 1 : 0] ? attach_hard_list(ctx, rows, &cc) : nullptr;
       auto hard_pass = [&]() -> int {
         if (!hs) return MP_OK;
-        hard_defer(ctx, hs, sp->id_hard[ftip ? 1 : 0], nullptr, cc, q, qd, qdd, tau, rows, model->d.n);
+        hard_defer(ctx, hs, sp->id_hard[ftip ? 1 : 0], nullptr, false, cc, q, qd, qdd, tau, rows, model->d.n);
         return hard_park_or_run(ctx, q, qd, qdd, tau, (size_t)rows * (size_t)model->d.n * sizeof(float), (size_t)rows * (size_t)model->d.n * sizeof(float));
       };
       long done = 0;
@@ -682,13 +683,7 @@ int launch_id(mp_ctx* ctx, const mp_model* model, const MpCall<float>& c, bool f
     HIP_TRY(mpk_id_dm(ctx->compute, dm, model->d.n, cc, ftip, q, qd, qdd, tau, rows));
     if (!hs) return MP_OK;
     const int n = model->d.n;
-    hipStream_t st = ctx->compute;
-    hard_defer(ctx, hs, nullptr, [=]() -> int {
-      MpCall<float> c2 = cc;
-      c2.hard_row_base = 0;
-      HIP_TRY(mpk_id_hard(st, dm, n, c2, ftip, q, qd, qdd, tau, (unsigned)rows, hard_pass_blocks(rows)));
-      return (int)MP_OK;
-    }, cc, q, qd, qdd, tau, rows, n);
+    hard_defer(ctx, hs, nullptr, dm, ftip, cc, q, qd, qdd, tau, rows, n);
     return hard_park_or_run(ctx, q, qd, qdd, tau, (size_t)rows * (size_t)n * sizeof(float), (size_t)rows * (size_t)n * sizeof(float));
   }
   HIP_TRY(mpk_id<float>(ctx->compute, model->f, c, ftip, q, qd, qdd, tau, rows));

@@ -19,6 +19,7 @@ hipError_t mpk_id_dm(hipStream_t s, const MpModel<float>* d_model, int n, const 
 // the float64 pass over the rows the kernel above handed over (C.hard_rows / hard_ctrl), `blocks` blocks of 64 lanes
 hipError_t mpk_id_hard(hipStream_t s, const MpModel<float>* d_model, int n, const MpCall<float>& C, bool ftip, const float* q,
                        const float* qd, const float* qdd, float* tau, unsigned rows, unsigned blocks);
+hipError_t mpk_id_hard_batch(hipStream_t s, const MpModel<float>* d_model, int n, bool ftip, const MpHardBatch& B, int entries, unsigned blocks);
 
 hipError_t mpk_batch_traj(hipStream_t s, const MpModel<float>& M, const float* start, const float* end, long B,
                           long Nt, double Tf, int method, float* pos, float* vel, float* acc);

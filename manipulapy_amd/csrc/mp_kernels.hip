@@ -67,6 +67,20 @@ __global__ __launch_bounds__(64) void k_id_hard(const MpModel<float>* __restrict
 #endif
 }
 
+// ... up to four launches' lists in one kernel (blockIdx.y picks the launch), as the specialised programs' pass: a pass costs ~5 us of
+// launch and latency however few rows it holds (round 5: the generic passes ran one kernel each until then)
+template <int N, bool HAS_FTIP>
+__global__ __launch_bounds__(64) void k_id_hard_batch(const MpModel<float>* __restrict__ Mdev, const MpHardBatch B) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int e = blockIdx.y;
+  const float* __restrict__ q = B.q[e]; const float* __restrict__ qd = B.qd[e]; const float* __restrict__ qdd = B.qdd[e];
+  mp_body_id_hard<N, HAS_FTIP>(*(MpModelConstD*)B.C[e].cold_model, *(MpModelConstF*)Mdev, B.C[e],
+                               [&](long r, float (&x)[N], float (&y)[N], float (&z)[N]) {
+                                 RunIO<float, N>::load(q, r, x); RunIO<float, N>::load(qd, r, y); RunIO<float, N>::load(qdd, r, z);
+                               }, B.tau[e], B.rows[e]);
+#endif
+}
+
 // the same pass for rows the fused generic kernel handed over: a row's inputs are generated again from start / end / the time table
 template <int N, bool HAS_FTIP>
 __global__ __launch_bounds__(64) void k_traj_id_hard(const MpModel<float>* __restrict__ Mdev, const MpCall<float> C, const float* __restrict__ start,
@@ -571,6 +585,15 @@ hipError_t mpk_id_hard(hipStream_t s, const MpModel<float>* d_model, int n, cons
   MP_DISPATCH_N(n, {
     if (ftip) hipLaunchKernelGGL((k_id_hard<N, true>), dim3(blocks), dim3(64), 0, s, d_model, C, q, qd, qdd, tau, rows);
     else hipLaunchKernelGGL((k_id_hard<N, false>), dim3(blocks), dim3(64), 0, s, d_model, C, q, qd, qdd, tau, rows);
+  })
+  return hipGetLastError();
+}
+
+hipError_t mpk_id_hard_batch(hipStream_t s, const MpModel<float>* d_model, int n, bool ftip, const MpHardBatch& B, int entries, unsigned blocks) {
+  if (blocks == 0 || entries <= 0) return hipSuccess;
+  MP_DISPATCH_N(n, {
+    if (ftip) hipLaunchKernelGGL((k_id_hard_batch<N, true>), dim3(blocks, (unsigned)entries), dim3(64), 0, s, d_model, B);
+    else hipLaunchKernelGGL((k_id_hard_batch<N, false>), dim3(blocks, (unsigned)entries), dim3(64), 0, s, d_model, B);
   })
   return hipGetLastError();
 }
