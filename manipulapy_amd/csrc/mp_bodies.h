@@ -273,10 +273,9 @@ __device__ __forceinline__ void mp_body_id_hard(const MC& Mc, const MF& M, const
 // The float64 pass of an EARLIER float32 launch, worked off by the first L.blocks workgroups of a later one (round 5): a pass of its
 // own costs ~4.7 us of launch and dependent loads however few rows it holds, at the front of another kernel the same rows cost their
 // arithmetic only.  The host hands a launch's list to a later launch only when that launch touches none of its arrays (mp_capi.cpp,
-// launch_id / mp_traj_id_fused_f32).  The hosting kernel needs the registers of the unrolled float64 recursion (120 - 170 VGPRs): the
-// fused generation + inverse dynamics kernel, two waves per SIMD by design, hosts it for free and does so by default; the given-rows
-// kernel mp_spec_id_co would lose a wave per SIMD for its float32 rows, which costs more than the pass (csrc/mp_jit.cpp: MP_ID_LEAD,
-// an experiment).
+// launch_id / mp_traj_id_fused_f32).  The unrolled float64 recursion wants 120 - 170 VGPRs: the fused generation + inverse dynamics
+// kernel, two waves per SIMD by design, has them; the given-rows kernel mp_spec_id_co is held to its five waves and lets this path
+// spill to scratch instead (csrc/mp_jit.cpp) - the float32 rows keep their registers, their waves and scratch-free code.
 template <int N, bool HAS_FTIP, typename MC, typename MF>
 __device__ __forceinline__ void mp_body_id_lead(const MC& Mc, const MF& M, const MpLead& L) {
   const float* __restrict__ q = L.q; const float* __restrict__ qd = L.qd; const float* __restrict__ qdd = L.qdd;

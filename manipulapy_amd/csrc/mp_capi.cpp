@@ -358,15 +358,17 @@ int device_model(mp_ctx* ctx, const mp_model* model, const MpModel<float>** out)
   if (it == ctx->dev_models.end()) {
     void* d = nullptr;
     if (ctx->capturing) {
-      // first use inside a capture: the copy is made at once, outside the graph (blocking copies: complete on return, so the
-      // replays' kernels - and the eager launches after the capture - find it)
+      // first use inside a capture: the copy is made at once, outside the graph - on the context's upload stream (not capturing;
+      // a blocking hipMemcpy would tie the legacy stream to the capturing one and is refused) and waited for, so the replays'
+      // kernels - and the eager launches after the capture - find it
       RelaxedCapture relaxed(true);
       const size_t bytes = (kDevModelD + sizeof(MpModel<double>) + 255) & ~size_t(255);
       HIP_TRY(hipMalloc(&d, bytes));
       ctx->live[d] = bytes;
-      hipError_t he = hipMemcpy(d, &model->f, sizeof(MpModel<float>), hipMemcpyHostToDevice);
-      if (he == hipSuccess) he = hipMemcpy((char*)d + kDevModelD, &model->d, sizeof(MpModel<double>), hipMemcpyHostToDevice);
-      if (he != hipSuccess) { ctx->free_by_size[bytes].push_back(d); return hip_err(he, "hipMemcpy (device copy of the model)"); }
+      hipError_t he = hipMemcpyAsync(d, &model->f, sizeof(MpModel<float>), hipMemcpyHostToDevice, ctx->copy);
+      if (he == hipSuccess) he = hipMemcpyAsync((char*)d + kDevModelD, &model->d, sizeof(MpModel<double>), hipMemcpyHostToDevice, ctx->copy);
+      if (he == hipSuccess) he = hipStreamSynchronize(ctx->copy);
+      if (he != hipSuccess) { ctx->free_by_size[bytes].push_back(d); return hip_err(he, "device copy of the model (first use inside a capture)"); }
     } else {
       if (int rc = mp_malloc(ctx, kDevModelD + sizeof(MpModel<double>), &d)) return rc;
       // (on the compute stream and waited for: the first kernel that reads the copy follows on that stream, and the streams are
@@ -538,16 +540,13 @@ int hard_flush_if_overlapping(mp_ctx* ctx, const void* const* lo, const size_t* 
   return MP_OK;
 }
 // Whether a parked float64 pass rides with the next float32 launch of its program (the launch's first workgroups work it off)
-// instead of waiting for a kernel of its own.  Fused launches (generated rows): yes, MANIPULAPY_HIP_LEAD_FUSED=0 switches it off
-// for A/B runs.  Given-rows launches (mp_spec_id_co): no - that kernel would need the float64 recursion's registers and lose a
-// wave per SIMD for its float32 rows, which costs more than the pass (csrc/mp_jit.cpp); MANIPULAPY_HIP_LEAD=1 together with a
-// program built with -DMP_ID_LEAD=1 (MANIPULAPY_HIP_EXPERIMENT) is the measured experiment.
+// instead of waiting for a kernel of its own: yes for both specialised kernels that host the path - the fused one (two waves per SIMD
+// by design: the float64 recursion's registers are free) and the given-rows one (held to its five waves: the carried path spills to
+// scratch, csrc/mp_jit.cpp).  MANIPULAPY_HIP_LEAD_FUSED=0 / MANIPULAPY_HIP_LEAD=0 switch them off for A/B runs (the latter belongs
+// with a program built with -DMP_ID_LEAD=0).
 bool lead_enabled(bool fused) {
   static const bool on_fused = [] { const char* e = getenv("MANIPULAPY_HIP_LEAD_FUSED"); return !(e && e[0] == '0'); }();
-  static const bool on_given = [] {
-    const char *e = getenv("MANIPULAPY_HIP_LEAD"), *x = getenv("MANIPULAPY_HIP_EXPERIMENT");
-    return e && e[0] == '1' && x && x[0] == '1';
-  }();
+  static const bool on_given = [] { const char* e = getenv("MANIPULAPY_HIP_LEAD"); return !(e && e[0] == '0'); }();
   return fused ? on_fused : on_given;
 }
 // the parked pass (given rows, specialised program `fn`) a launch may carry: the oldest; `self` is the launch's own slot
@@ -637,9 +636,9 @@ int launch_id(mp_ctx* ctx, const mp_model* model, const MpCall<float>& c, bool f
       long done = 0;
       if (sp->id_co[ftip ? 1 : 0] && rows >= 64 && id_co_enabled()) {  // whole waves: rows moved as whole lines, non-temporal (mp_body_id_co)
         long rows64 = rows & ~63L;
-        // (experiment, see lead_enabled) One float64 pass that is still parked - an earlier launch's of the same program, none of
-        // whose arrays this launch touches (the others were run by hard_flush_if_overlapping on the way in) - rides with this
-        // launch: its first workgroups work the list off beside the float32 rows (mp_body_id_lead).
+        // One float64 pass that is still parked - an earlier launch's of the same program, none of whose arrays this launch
+        // touches (the others were run by hard_flush_if_overlapping on the way in) - rides with this launch: its first workgroups
+        // work the list off beside the float32 rows (mp_body_id_lead) instead of a kernel of its own doing so later.
         MpLead lead;
         std::memset(&lead, 0, sizeof lead);
         mp_ctx::HardSlot* rider = lead_enabled(false) ? pick_rider(ctx, sp->id_hard[ftip ? 1 : 0], hs) : nullptr;

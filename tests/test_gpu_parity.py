@@ -1044,6 +1044,37 @@ def test_launch_graph_replays_the_captured_calls(ctx, models, tables):
         b.free()
 
 
+@pytest.mark.gpu
+def test_first_use_of_a_model_inside_a_capture(tables):
+    """A generic model whose FIRST launch on a fresh context is a captured one: its device copy (float32 + float64 model, read by the
+    one-row kernel and by the float64 pass) is made at once, outside the graph, on a stream that is not capturing; the capture stays
+    valid and the replay returns the host entry point's bits - rows that need the float64 pass included."""
+    from manipulapy_amd import _hip
+
+    tab = tables["ur5"]
+    lim = tab.joint_limits
+    rng = np.random.default_rng(12)
+    s_ = rng.uniform(lim[:, 0], lim[:, 1], (30, 6)).astype(np.float32)
+    e_ = rng.uniform(lim[:, 0], lim[:, 1], (30, 6)).astype(np.float32)
+    o = ref.batch_joint_trajectory(lim, s_, e_, 2.0, 700, 5)
+    q, qd, qdd = (np.ascontiguousarray(o[k].reshape(-1, 6), dtype=np.float32) for k in ("positions", "velocities", "accelerations"))
+    ctx = _hip.HipContext(0)
+    try:
+        m = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee, lim)
+        assert _hip.cpu_id_row_precision(m, q, qd, qdd).sum() > 20
+        d = [ctx.to_device(a) for a in (q, qd, qdd)]
+        d_tau = ctx.alloc(q.nbytes)
+        with ctx.capture() as cap:
+            ctx.id_trajectory(m, *d, len(q), d_tau, dtype=np.float32)      # first use of `m` on this context
+        ctx.memset(d_tau, 0, q.nbytes)
+        cap.graph.launch()
+        got = d_tau.download(q.shape, np.float32)
+        np.testing.assert_array_equal(got, ctx.id_trajectory_host(m, q, qd, qdd, dtype=np.float32))
+        cap.graph.destroy()
+    finally:
+        ctx.destroy()
+
+
 @pytest.mark.parametrize("seed", [0, 2, 4, 5, 6, 8, 11, 16])
 def test_random_robots_on_gpu(seed, ctx):
     """Randomised chains (tests/test_random_robots.py) through the C ABI: generic fp64 / fp32 and specialised kernels."""

@@ -104,3 +104,20 @@ def test_more_than_eight_joints_state_what_float32_holds(name):
     assert ratio.max() <= 1.0, float(ratio.max())
     with pytest.raises(_hip.HipError, match="more than 8 joints"):
         _hip.cpu_id_row_precision(model, q[:4], qd[:4], qdd[:4])
+
+
+def test_carried_float64_path_keeps_the_float32_rows_free_of_scratch():
+    """Round 5: mp_spec_id_co's first workgroups carry the previous launch's float64 pass while the kernel stays at five waves per SIMD
+    (96 VGPRs), so that path spills to scratch - which is only acceptable while NO float32 wave ever executes a scratch access
+    (csrc/mp_jit.cpp).  The UR5 program of the headline configuration, compiled as the launcher's second (max-ILP) program is
+    (hipcc cross-compiles here): scratch accesses exist, and all of them lie behind the branch that separates the carried path."""
+    import shutil
+    import sys
+
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("no hipcc")
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+    import check_scratch
+
+    total, inside = check_scratch.hot_path_scratch("ur5", max_ilp=True)
+    assert total > 0 and inside == 0, (total, inside)
