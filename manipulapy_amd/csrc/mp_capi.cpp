@@ -599,12 +599,24 @@ int generic_f32_mode() {
   return mode;
 }
 
+// float32 calls on a 9..32-joint model: where the kernels find the float64 model for their ill-conditioned rows (mp_dyn.h,
+// mp_dyn_row_id_f64); float64 calls need nothing
+int big_cold_model(mp_ctx* ctx, const mp_model* model, MpCall<float>* c) {
+  const MpBigModel<double>* dd = nullptr;
+  if (int rc = device_big_model<double>(ctx, model, &dd)) return rc;
+  c->cold_model = dd;
+  return MP_OK;
+}
+int big_cold_model(mp_ctx*, const mp_model*, MpCall<double>*) { return MP_OK; }
+
 template <typename T>
 int launch_big_fk_jac_id(mp_ctx* ctx, const mp_model* model, const MpCall<T>& c, bool ftip, const T* q, const T* qd, const T* qdd, T* Tout,
                          T* Jout, T* tau, long rows) {
   const MpBigModel<T>* dm = nullptr;
   if (int rc = device_big_model<T>(ctx, model, &dm)) return rc;
-  HIP_TRY(mpk_dyn_fk_jac_id<T>(ctx->compute, model->d.n, dm, c, ftip, q, qd, qdd, Tout, Jout, tau, rows));
+  MpCall<T> cc = c;
+  if (int rc = big_cold_model(ctx, model, &cc)) return rc;
+  HIP_TRY(mpk_dyn_fk_jac_id<T>(ctx->compute, model->d.n, dm, cc, ftip, q, qd, qdd, Tout, Jout, tau, rows));
   return MP_OK;
 }
 
@@ -1786,6 +1798,7 @@ int mp_traj_id_fused_f32(mp_ctx* ctx, const mp_model* model, const float* d_star
   if (model->big) {
     const MpBigModel<float>* dm = nullptr;
     if (int rc = device_big_model<float>(ctx, model, &dm)) return rc;
+    if (int rc = big_cold_model(ctx, model, &c)) return rc;
     HIP_TRY(mpk_dyn_traj(ctx->compute, model->d.n, dm, c, ftip, d_start, d_end, (long)B, (long)N, Tf, method, nullptr, nullptr, nullptr, d_tau));
     return MP_OK;
   }

@@ -86,7 +86,8 @@ MpCall<T> make_call(const mp_model* m, const double* g, const double* Ftip) {
   else mp_make_call(m->d, g ? g : kG, Ftip, &cd);
   MpCall<T> c;
   mp_call_cast(cd, &c);
-  if (!m->big) c.cold_model = &m->d;  // the float64 model for the re-evaluated float32 rows (mp_core.h, mp_rnea_row)
+  // the float64 model for the re-evaluated float32 rows (mp_core.h, mp_rnea_row / mp_dyn.h, mp_dyn_row_id_f64)
+  c.cold_model = m->big ? (const void*)&m->bd : (const void*)&m->d;
   return c;
 }
 
@@ -292,10 +293,24 @@ int mp_id_row_precision_cpu_f32(const mp_model* model, const float* q, const flo
   if (rows < 0) return fail("mp_id_row_precision_cpu_f32: negative row count");
   if (rows == 0) return MP_OK;
   if (!q || !qd || !qdd || !in_f64) return fail("mp_id_row_precision_cpu_f32: null pointer");
-  if (model->big) return fail("mp_id_row_precision_cpu_f32: models of more than 8 joints run the looped kernels, which stay float32");
   const MpModel<float>& M = model->f;
   const MpCall<float> C = make_call<float>(model, g, Ftip);
   const bool ftip = any_nonzero(Ftip);
+  if (model->big) {  // 9..32 joints: the same verdict from the looped recursion (mp_dyn.h)
+    const MpBigModel<float>& MB = model->bf;
+    const int n = MB.n;
+    parallel_for(rows, 128, nthreads, [&](int64_t lo, int64_t hi) {
+      for (int64_t r = lo; r < hi; ++r) {
+        float t[MP_BIG_DOF], scale = 0.0f;
+        MpDynState<float, MP_BIG_DOF> js;
+        mp_dyn_joint_state<float>(MB, n, q + r * n, js);
+        if (ftip) mp_dyn_rnea<float, true>(MB, n, C.a0, C.F1n, C.F1f, js, qd + r * n, qdd + r * n, t, &scale);
+        else mp_dyn_rnea<float, false>(MB, n, C.a0, C.F1n, C.F1f, js, qd + r * n, qdd + r * n, t, &scale);
+        in_f64[r] = mp_dyn_row_is_hard(t, n, scale) ? 1 : 0;
+      }
+    });
+    return MP_OK;
+  }
   MP_CPU_DISPATCH(M.n, {
     parallel_for(rows, 256, nthreads, [&](int64_t lo, int64_t hi) {
       const float tn[3] = {C.F1n[0], C.F1n[1], C.F1n[2]}, tf[3] = {C.F1f[0], C.F1f[1], C.F1f[2]};

@@ -38,9 +38,13 @@ MP_HD void mp_dyn_joint_state(const MT& M, int n, const T* q, MpDynState<T, CAP>
 }
 
 // mp_rnea of mp_core.h with a run-time joint count.  tau is NOT clipped here.
+// `scale` (optional): the size of the row's large intermediate terms, the statistic of MpRowScale (mp_core.h) with run-time indices -
+// the own body moment of link J = min(1, n - 1), the moment joint J + 1 hands down, lscale x the force through joint min(2, n - 1).
 template <typename T, bool HAS_FTIP, typename MT, int CAP>
 MP_HD void mp_dyn_rnea(const MT& M, int n, const T (&a0)[3], const T (&tipn)[3], const T (&tipf)[3], const MpDynState<T, CAP>& js,
-                       const T* qd, const T* qdd, T* tau) {
+                       const T* qd, const T* qdd, T* tau, T* scale = nullptr) {
+  const int sJ = n > 1 ? 1 : 0, sJF = n > 2 ? 2 : n - 1;
+  T s_bm = 0, s_cm = 0, s_f = 0;
   T fnx[CAP], fny[CAP], fnz[CAP], ffx[CAP], ffy[CAP], ffz[CAP];
   T wx = 0, wy = 0, wz = 0, vx = 0, vy = 0, vz = 0;
   T dwx = 0, dwy = 0, dwz = 0, dvx = a0[0], dvy = a0[1], dvz = a0[2];
@@ -80,6 +84,7 @@ MP_HD void mp_dyn_rnea(const MT& M, int n, const T (&a0)[3], const T (&tipn)[3],
     ffx[i] = J.m * dvx - (J.hy * dwz - J.hz * dwy) + (wy * pfz - wz * pfy);
     ffy[i] = J.m * dvy - (J.hz * dwx - J.hx * dwz) + (wz * pfx - wx * pfz);
     ffz[i] = J.m * dvz - (J.hx * dwy - J.hy * dwx) + (wx * pfy - wy * pfx);
+    if (scale && i == sJ) s_bm = mp_max(mp_max(mp_abs(fnx[i]), mp_abs(fny[i])), mp_abs(fnz[i]));
   }
   if (HAS_FTIP) {
     fnx[n - 1] += tnx; fny[n - 1] += tny; fnz[n - 1] += tnz;
@@ -89,14 +94,44 @@ MP_HD void mp_dyn_rnea(const MT& M, int n, const T (&a0)[3], const T (&tipn)[3],
   for (int i = n - 1; i >= 0; --i) {  // backward pass
     const auto& J = M.j[i];
     tau[i] = J.rev * fnz[i] + (T(1) - J.rev) * ffz[i];
+    if (scale && i == sJF) s_f = mp_max(mp_max(mp_abs(ffx[i]), mp_abs(ffy[i])), mp_abs(ffz[i]));
     if (i > 0) {
       T nx = fnx[i], ny = fny[i], nz = fnz[i], fx = ffx[i], fy = ffy[i], fz = ffz[i];
       mp_force_up_B(js.c[i], js.s[i], js.d[i], nx, ny, nz, fx, fy, fz);
       mp_force_up_A(J.ca, J.sa, J.a, nx, ny, nz, fx, fy, fz);
+      if (scale && i == sJ + 1) s_cm = mp_max(mp_max(mp_abs(nx), mp_abs(ny)), mp_abs(nz));
       fnx[i - 1] += nx; fny[i - 1] += ny; fnz[i - 1] += nz;
       ffx[i - 1] += fx; ffy[i - 1] += fy; ffz[i - 1] += fz;
     }
   }
+  if (scale) *scale = mp_max(mp_max(s_bm, s_cm), s_f * (T)M.lscale);
+}
+
+// ---- float32 rows, adaptive precision (round 5: the run-time-n rows too).  The float64 model of the same robot travels in
+// MpCall<float>::cold_model (device memory for the kernels, the handle's own copy for the CPU launchers); null = float32 throughout.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const __attribute__((address_space(4))) MpBigModel<double> MpBigConstD;
+#else
+typedef const MpBigModel<double> MpBigConstD;
+#endif
+// largest |tau| of the row against the scale of its intermediate terms (mp_id_row_is_hard of mp_core.h, run-time n)
+MP_HD bool mp_dyn_row_is_hard(const float* tau, int n, float scale) {
+  float rowmax = 0.0f;
+  for (int i = 0; i < n; ++i) rowmax = mp_max(rowmax, mp_abs(tau[i]));
+  return scale > MP_HARD_ROW_K * rowmax;
+}
+// the row again, everything in float64 from its float32 inputs (sin / cos and model constants too); tau unclipped
+template <int CAP, bool HAS_FTIP>
+MP_HD void mp_dyn_row_id_f64(MpBigConstD& Md, const MpCall<float>& C, const float* q, const float* qd, const float* qdd, float* tau) {
+  const int n = Md.n;
+  double a[CAP], b[CAP], c[CAP], t[CAP];
+  for (int j = 0; j < n; ++j) { a[j] = (double)q[j]; b[j] = (double)qd[j]; c[j] = (double)qdd[j]; }
+  const double a0[3] = {(double)C.a0[0], (double)C.a0[1], (double)C.a0[2]};
+  const double tn[3] = {(double)C.F1n[0], (double)C.F1n[1], (double)C.F1n[2]}, tf[3] = {(double)C.F1f[0], (double)C.F1f[1], (double)C.F1f[2]};
+  MpDynState<double, CAP> js;
+  mp_dyn_joint_state<double>(Md, n, a, js);
+  mp_dyn_rnea<double, HAS_FTIP>(Md, n, a0, tn, tf, js, b, c, t);
+  for (int j = 0; j < n; ++j) tau[j] = (float)t[j];
 }
 
 // mp_mass_matrix_crba of mp_core.h with a run-time joint count; Mq is n x n row-major with row pitch `ld`.
@@ -244,9 +279,17 @@ MP_HD void mp_dyn_row_fk_jac_id(const MT& M, const MpCall<T>& C, const T* q, con
   if (tau) {
     T b[CAP], c[CAP], t[CAP];
     for (int j = 0; j < n; ++j) { b[j] = qd[r * n + j]; c[j] = qdd[r * n + j]; }
-    mp_dyn_rnea<T, HAS_FTIP>(M, n, C.a0, C.F1n, C.F1f, js, b, c, t);
     mp_dyn_bad(b, n, bad);
     const bool p = mp_dyn_bad(c, n, bad);
+    if constexpr (MpIsF32<T>::value) {
+      // (as the unrolled kernels: rows whose torques are a small difference of large terms are evaluated again in float64 - in place:
+      // these kernels keep their per-joint state in indexed arrays anyway and make no speed claim)
+      T scale = 0;
+      mp_dyn_rnea<T, HAS_FTIP>(M, n, C.a0, C.F1n, C.F1f, js, b, c, t, C.cold_model ? &scale : nullptr);
+      if (C.cold_model && !p && mp_dyn_row_is_hard(t, n, scale)) mp_dyn_row_id_f64<CAP, HAS_FTIP>(*(MpBigConstD*)C.cold_model, C, a, b, c, t);
+    } else {
+      mp_dyn_rnea<T, HAS_FTIP>(M, n, C.a0, C.F1n, C.F1f, js, b, c, t);
+    }
     for (int j = 0; j < n; ++j) {
       T v = mp_clip(t[j], M.taumin[j], M.taumax[j]);
       mp_poison_if(p, v);
@@ -346,11 +389,12 @@ MP_HD void mp_dyn_row_traj(const MT& M, const MpCall<float>& C, const float* sta
   if (tau) {
     MpDynState<float, CAP> js;
     mp_dyn_joint_state<float>(M, n, p, js);
-    float tq[CAP];
-    mp_dyn_rnea<float, HAS_FTIP>(M, n, C.a0, C.F1n, C.F1f, js, v, a, tq);
+    float tq[CAP], scale = 0.0f;
+    mp_dyn_rnea<float, HAS_FTIP>(M, n, C.a0, C.F1n, C.F1f, js, v, a, tq, C.cold_model ? &scale : nullptr);
     MpBad<float> bad;
     mp_dyn_bad(p, n, bad); mp_dyn_bad(v, n, bad);
     const bool poison = mp_dyn_bad(a, n, bad);
+    if (C.cold_model && !poison && mp_dyn_row_is_hard(tq, n, scale)) mp_dyn_row_id_f64<CAP, HAS_FTIP>(*(MpBigConstD*)C.cold_model, C, p, v, a, tq);
     for (int j = 0; j < n; ++j) {
       float x = mp_clip(tq[j], M.taumin[j], M.taumax[j]);
       mp_poison_if(poison, x);

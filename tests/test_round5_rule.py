@@ -83,12 +83,12 @@ def test_adaptive_rule_holds_on_every_suite_robot_cpu_launcher():
 
 
 @pytest.mark.parametrize("name", ["jaco_6dof", "jaco_7dof"])
-def test_more_than_eight_joints_state_what_float32_holds(name):
-    """The run-time-n rows (csrc/mp_dyn.h, 9 - 32 joints) stay float32 throughout: no conditioning test, no float64 rows.  What
-    they hold on FAST trajectories of the reference's two such robots (the Jaco arms with their three-finger hands, joint speeds
-    up to ~10 rad/s) is stated here and in INTEGRATION.md section 4: every row within 1e-4 |ref| + 2e-5 max|row| of the float64
-    launcher (the reference's algorithm is checked against that launcher on these robots in test_round3_host.py) - the suite's
-    element-wise bound with a floor four times wider - while the element-wise bound itself is NOT guaranteed above eight joints."""
+def test_more_than_eight_joints_hold_the_element_wise_bound_too(name):
+    """The run-time-n rows (csrc/mp_dyn.h, 9 - 32 joints: the reference's Jaco arms with their three-finger hands) carry the
+    conditioning test and evaluate ill-conditioned rows in float64 as well since round 5 (in place: mp_dyn_row_id_f64).  20 000 FAST
+    rows (joint speeds up to ~10 rad/s) against the float64 launcher - which test_round3_host.py pins to the reference's own values on
+    these robots; the C oracle stops at eight joints - inside the suite's element-wise float32 bound with room to spare, and the
+    verdict is reported per row."""
     z = np.load(golden_path("urdf_suite.npz"))
     proc = mp.URDFToSerialManipulator(golden_path(os.path.join("urdf_suite", f"{name}.urdf")), tip_link=str(z[f"{name}__ee"]))
     t = proc.tables
@@ -96,14 +96,17 @@ def test_more_than_eight_joints_state_what_float32_holds(name):
     lim[~np.isfinite(lim[:, 0]), 0] = -np.pi
     lim[~np.isfinite(lim[:, 1]), 1] = np.pi
     model = _hip.HipModel(t["S_list"], t["Mlist_per_link"], t["G_list"], t["M"], lim)
+    assert model.n in (9, 10)
     q, qd, qdd = c2_rows(lim, 20, 77)
     t64 = _hip.cpu_id_trajectory(model, q.astype(np.float64), qd.astype(np.float64), qdd.astype(np.float64), dtype=np.float64)
     t32 = _hip.cpu_id_trajectory(model, q, qd, qdd, dtype=np.float32)
-    tol = 1e-4 * np.abs(t64) + 2e-5 * np.abs(t64).max(axis=1, keepdims=True)
+    tol = 1e-4 * np.abs(t64) + 5e-6 * np.abs(t64).max(axis=1, keepdims=True) + 1e-12
     ratio = np.abs(t32.astype(np.float64) - t64) / tol
-    assert ratio.max() <= 1.0, float(ratio.max())
-    with pytest.raises(_hip.HipError, match="more than 8 joints"):
-        _hip.cpu_id_row_precision(model, q[:4], qd[:4], qdd[:4])
+    assert ratio.max() <= 0.6, float(ratio.max())
+    hard = _hip.cpu_id_row_precision(model, q, qd, qdd)
+    assert hard.dtype == bool or hard.dtype == np.uint8
+    assert 0 < hard.mean() < 0.1, float(hard.mean())
+    assert (ratio[hard.astype(bool)].max() if hard.any() else 0.0) <= 0.05
 
 
 def test_carried_float64_path_keeps_the_float32_rows_free_of_scratch():
