@@ -181,8 +181,9 @@ int mp_batch_trajectory_f32(mp_ctx* ctx, const mp_model* model, const float* d_s
  *   - arrays the CALLER allocated (hipMalloc, a framework tensor - anything not from mp_malloc): kernel and pass are both
  *     enqueued on the compute stream.  Whatever the caller enqueues there next - or a wait on that stream - sees the complete
  *     torques; the arrays may be freed or reused as soon as the stream has passed the call, like after any asynchronous launch.
- *   - arrays from this context's pool (mp_malloc), all four of them: the pass may stay PARKED, to be run together with the passes
- *     of up to three more launches.  It runs before anything can see the difference: every other entry point of the context
+ *   - arrays from this context's pool (mp_malloc), all four of them: the pass may stay PARKED - to ride with the next launch of the
+ *     same robot-specialised kernel on other arrays (that launch's first workgroups work it off), or to run together with the
+ *     passes of up to three more launches.  It runs before anything can see the difference: every other entry point of the context
  *     (mp_memcpy_*, mp_ctx_synchronize, mp_event_record, mp_ctx_get_stream, the *_host calls, the communicator ...), a launch
  *     whose arrays overlap the parked one's, a fifth launch, mp_ctx_destroy.  Pool memory is only reachable through those.
  *   MANIPULAPY_HIP_PARK_FOREIGN=1 (experiment switch) parks for foreign arrays too; the caller must then pass a
