@@ -691,7 +691,21 @@ int launch_id(mp_ctx* ctx, const mp_model* model, const MpCall<float>& c, bool f
     if (int rc = device_model(ctx, model, &dm)) return rc;
     MpCall<float> cc = c;
     mp_ctx::HardSlot* hs = cc.cold_model ? attach_hard_list(ctx, rows, &cc) : nullptr;
-    HIP_TRY(mpk_id_dm(ctx->compute, dm, model->d.n, cc, ftip, q, qd, qdd, tau, rows));
+    // (as the specialised kernels: one parked pass of an earlier launch of this model rides with this launch's first workgroups)
+    MpLead lead;
+    std::memset(&lead, 0, sizeof lead);
+    mp_ctx::HardSlot* rider = nullptr;
+    if (lead_enabled(false))
+      for (auto& cand : ctx->hp->slot)
+        if (cand.busy && &cand != hs && !cand.fn && cand.gen_dm == dm && cand.gen_n == model->d.n && cand.gen_ftip == ftip && cand.nt == 0 &&
+            cand.C.cold_model && (!rider || cand.seq < rider->seq))
+          rider = &cand;
+    if (rider) {
+      lead.C = rider->C; lead.q = rider->q; lead.qd = rider->qd; lead.qdd = rider->qdd; lead.tau = rider->tau; lead.rows = rider->nrows;
+      lead.blocks = std::min((hard_pass_blocks((long)rider->nrows) + 3u) / 4u, 128u);   // 256-lane workgroups
+    }
+    HIP_TRY(mpk_id_dm(ctx->compute, dm, model->d.n, cc, ftip, q, qd, qdd, tau, rows, lead));
+    if (rider) { rider->busy = false; rider->orphan = false; }
     if (!hs) return MP_OK;
     const int n = model->d.n;
     hard_defer(ctx, hs, nullptr, dm, ftip, cc, q, qd, qdd, tau, rows, n);

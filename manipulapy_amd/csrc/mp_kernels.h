@@ -14,7 +14,7 @@ hipError_t mpk_id(hipStream_t s, const MpModel<T>& M, const MpCall<T>& C, bool f
 
 // float32, one row per lane, the model read through a pointer to a device-resident copy (scalar loads joint by joint)
 hipError_t mpk_id_dm(hipStream_t s, const MpModel<float>* d_model, int n, const MpCall<float>& C, bool ftip, const float* q,
-                     const float* qd, const float* qdd, float* tau, long rows);
+                     const float* qd, const float* qdd, float* tau, long rows, const MpLead& L);
 
 // the float64 pass over the rows the kernel above handed over (C.hard_rows / hard_ctrl), `blocks` blocks of 64 lanes
 hipError_t mpk_id_hard(hipStream_t s, const MpModel<float>* d_model, int n, const MpCall<float>& C, bool ftip, const float* q,

@@ -45,13 +45,24 @@ __global__ __launch_bounds__(kBlock) void k_id(const MpModel<T> M, const MpCall<
 // instructions at n = 6) and keeps the wave count down.
 // (five waves per SIMD asked for without a tip wrench, four with one: the float64 re-evaluation loop behind the float32 pass raised
 // the unconstrained allocation from 85 to 106 VGPRs; held to 96 / 128 neither pass touches scratch)
+// Round 5: the kernel's first L.blocks workgroups carry the float64 pass of an earlier launch of the same model (mp_body_id_lead, as
+// the robot-specialised kernels do); the float64 path spills under this kernel's register cap - in those workgroups only.
 template <typename T, int N, bool HAS_FTIP>
 __global__ __launch_bounds__(kBlock, HAS_FTIP ? 4 : 5) void k_id_dm(const MpModel<T>* __restrict__ Mdev, const MpCall<T> C, const T* __restrict__ q,
-                                                  const T* __restrict__ qd, const T* __restrict__ qdd, T* __restrict__ tau, long rows) {
+                                                  const T* __restrict__ qd, const T* __restrict__ qdd, T* __restrict__ tau, long rows,
+                                                  const MpLead L) {
   MP_COLD_BUFFER(N, kBlock, sizeof(T));
-  const long r = (long)blockIdx.x * kBlock + threadIdx.x;
-  if (r >= rows) return;
   typedef const __attribute__((address_space(4))) MpModel<T> MC;
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (sizeof(T) == 4) {
+    if (blockIdx.x < L.blocks) {
+      mp_body_id_lead<N, HAS_FTIP>(*(MpModelConstD*)L.C.cold_model, *(MC*)Mdev, L);
+      return;
+    }
+  }
+#endif
+  const long r = (long)(blockIdx.x - L.blocks) * kBlock + threadIdx.x;
+  if (r >= rows) return;
   mp_body_id<T, N, HAS_FTIP>(*(MC*)Mdev, C, q, qd, qdd, tau, r, MP_COLD_PTR);
 }
 
@@ -569,12 +580,12 @@ hipError_t mpk_id<float>(hipStream_t s, const MpModel<float>& M, const MpCall<fl
 
 // one row per lane, model through a device pointer (k_id_dm)
 hipError_t mpk_id_dm(hipStream_t s, const MpModel<float>* d_model, int n, const MpCall<float>& C, bool ftip, const float* q,
-                     const float* qd, const float* qdd, float* tau, long rows) {
+                     const float* qd, const float* qdd, float* tau, long rows, const MpLead& L) {
   if (rows <= 0) return hipSuccess;
   using T = float;
   MP_DISPATCH_N(n, {
-    if (ftip) hipLaunchKernelGGL((k_id_dm<T, N, true>), dim3(grid_for(rows)), dim3(kBlock), 0, s, d_model, C, q, qd, qdd, tau, rows);
-    else hipLaunchKernelGGL((k_id_dm<T, N, false>), dim3(grid_for(rows)), dim3(kBlock), 0, s, d_model, C, q, qd, qdd, tau, rows);
+    if (ftip) hipLaunchKernelGGL((k_id_dm<T, N, true>), dim3(grid_for(rows) + L.blocks), dim3(kBlock), 0, s, d_model, C, q, qd, qdd, tau, rows, L);
+    else hipLaunchKernelGGL((k_id_dm<T, N, false>), dim3(grid_for(rows) + L.blocks), dim3(kBlock), 0, s, d_model, C, q, qd, qdd, tau, rows, L);
   })
   return hipGetLastError();
 }
