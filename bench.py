@@ -709,27 +709,38 @@ def bench_strong(name, args, info, hg, ctx, props):
         except Exception as exc:
             return f"not checked: {str(exc)[:200]}"
 
-    def blocks_agree(d_alls):
-        """Every byte of every rank's block, on EVERY rank (comparing one recomputed trajectory only covers the first chunk
-        of every block): each rank sums the 32-bit words of each block as it holds it, the sums travel over gloo, and a block counts
-        only when every rank's copy sums to what its owner's own copy does.  Collective: every rank calls it."""
-        try:
-            ctx.synchronize()
-            mine = np.zeros((len(d_alls), world), np.int64)
-            for a, d_all in enumerate(d_alls):
-                for r in range(world):
-                    nbytes = plan["bytes_of_rank"][r]
-                    if nbytes == 0:
-                        continue
-                    buf = np.empty(nbytes // 4, np.uint32)
-                    _hip._check(ctx.lib.mp_memcpy_d2h(ctx.handle, buf.ctypes.data, d_all.offset(plan["slot_offset"][r]), buf.nbytes))
-                    mine[a, r] = int(buf.sum(dtype=np.uint64) & np.uint64(0x7fffffffffffffff))
-                    del buf
-            seen = hg.allgather(mine.reshape(1, -1)).reshape(world, len(d_alls), world)   # [holder, array, owner]
-            bad = [(int(h), int(a), int(o)) for h in range(world) for a in range(len(d_alls)) for o in range(world) if seen[h, a, o] != seen[o, a, o]]
-            return True if not bad else f"{len(bad)} (holder, array, owner) blocks differ from their owner's copy, first {bad[0]}"
-        except Exception as exc:
-            return f"not checked: {str(exc)[:200]}"
+    def block_sums(d_alls):
+        """Word sums of every rank's block of every gathered array AS THIS RANK HOLDS IT (comparing one recomputed
+        trajectory only covers the first chunk of every block).  No collective here - the sums travel over gloo later, from the main
+        thread, whatever became of this rank's RCCL phase (a collective only some ranks enter would hang the others)."""
+        ctx.synchronize()
+        mine = np.zeros((len(d_alls), world), np.int64)
+        for a, d_all in enumerate(d_alls):
+            for r in range(world):
+                nbytes = plan["bytes_of_rank"][r]
+                if nbytes == 0:
+                    continue
+                buf = np.empty(nbytes // 4, np.uint32)
+                _hip._check(ctx.lib.mp_memcpy_d2h(ctx.handle, buf.ctypes.data, d_all.offset(plan["slot_offset"][r]), buf.nbytes))
+                mine[a, r] = int(buf.sum(dtype=np.uint64) & np.uint64(0x7fffffffffffffff))
+                del buf
+        return mine
+
+    sums = {}   # phase -> this rank's (arrays, world) table of word sums
+
+    def blocks_agree(phase, arrays):
+        """Every rank's copy of every block against its owner's own copy; collective over gloo, called by EVERY rank from the main thread."""
+        mine = sums.get(phase)
+        flat = np.full((1, arrays * world + 1), -1, np.int64)
+        if mine is not None:
+            flat[0, 0] = 1
+            flat[0, 1:] = mine.reshape(-1)
+        seen = hg.allgather(flat)
+        if (seen[:, 0] != 1).any():
+            return f"not checked: {int((seen[:, 0] != 1).sum())} rank(s) did not finish the phase"
+        tab = seen[:, 1:].reshape(world, arrays, world)   # [holder, array, owner]
+        bad = [(h, a, o) for h in range(world) for a in range(arrays) for o in range(world) if tab[h, a, o] != tab[o, a, o]]
+        return True if not bad else f"{len(bad)} (holder, array, owner) blocks differ from their owner's copy, first {bad[0]}"
 
     def gather_phase():
         try:
@@ -746,10 +757,9 @@ def bench_strong(name, args, info, hg, ctx, props):
             wall_g, _ = timed(step_and_gather)
             ms_g = wall_g / args.steps * 1e3
             gather.update({"ms_per_step_with_allgather": ms_g, "value_with_allgather": total_jt * args.steps / wall_g})
-            whole = blocks_agree(d_alls)          # every rank
+            sums["allgatherv"] = block_sums(d_alls)
             if rank == 0:
-                first = verify(d_alls)
-                gather["verified"] = True if (first is True and whole is True) else f"first trajectories: {first}; whole blocks: {whole}"
+                gather["verified"] = verify(d_alls)   # (first trajectories; the whole blocks are compared after the phase, below)
             if cfg["op"] == "id":
                 ov = plan["overlapped_exchange"]
                 d_all = d_alls[0]
@@ -769,10 +779,9 @@ def bench_strong(name, args, info, hg, ctx, props):
                 gather["overlapped"] = {"chunks": ov["chunks"], "ms_per_step": wall_o / args.steps * 1e3, "value": total_jt * args.steps / wall_o,
                                         "how": "per chunk: kernel on the compute stream straight into this rank's block, then grouped "
                                                "ncclSend / ncclRecv to every peer on the communicator's stream (mp_comm_exchange_chunk_v)"}
-                whole = blocks_agree([d_all])     # every rank: all four chunks of every peer's block
+                sums["overlapped"] = block_sums([d_all])   # all four chunks of every peer's block
                 if rank == 0:
-                    first = verify([d_all])
-                    gather["overlapped"]["verified"] = True if (first is True and whole is True) else f"first trajectories: {first}; whole blocks: {whole}"
+                    gather["overlapped"]["verified"] = verify([d_all])
             else:
                 gather["overlapped"] = None   # a roll-out is sequential in time: its outputs are complete only at the end of the launch
             comm.destroy()
@@ -790,6 +799,15 @@ def bench_strong(name, args, info, hg, ctx, props):
         if th.is_alive():
             gather["error"] = "timeout: the RCCL phase did not complete"
             hung = True
+        if not hung:
+            # the whole-block comparison: every rank takes part, with or without sums of its own
+            for phase, arrays in (("allgatherv", len(outs)),) + ((("overlapped", 1),) if cfg["op"] == "id" else ()):
+                whole = blocks_agree(phase, arrays)
+                if rank == 0:
+                    tgt = gather if phase == "allgatherv" else gather.get("overlapped")
+                    if isinstance(tgt, dict) and "verified" in tgt:
+                        first = tgt["verified"]
+                        tgt["verified"] = True if (first is True and whole is True) else f"first trajectories: {first}; whole blocks: {whole}"
     if not hung:
         ctx.synchronize()
         for b in bufs:
