@@ -591,7 +591,7 @@ def test_planner_benchmark_helpers_without_a_gpu():
 
 def test_f32_rows_adaptive_precision_on_the_cpu_launcher(tables):
     """Round 4: the float32 inverse dynamics (kernels and CPU launcher share mp_rnea_row, csrc/mp_core.h) takes joint offsets as
-    exact rotations of (sin q, cos q) and evaluates ill-conditioned rows - joint wrenches above 16 x the row's largest torque - in
+    exact rotations of (sin q, cos q) and evaluates ill-conditioned rows - intermediate wrenches above 8 x the row's largest torque (MpRowScale) - in
     float64.  On 100 000 c2-distributed UR5 rows against the pinned C oracle: every row inside 1e-4 |ref| + 5e-6 max|row| with
     room to spare, a small share of the rows in float64 (in runs of consecutive timesteps), those at <= 0.2 x the bound, and the
     verdict a function of the row alone (the same row gives the same bits in any batch)."""
