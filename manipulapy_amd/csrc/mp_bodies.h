@@ -164,6 +164,19 @@ struct MpColdLds { static constexpr int BYTES = G * MpColdSlot<N>::BYTES; };
 // whole-line flush, then the re-evaluated row).  A release FENCE is the wrong tool: at agent scope it is `buffer_wbl2` - the
 // whole L2 written back, ~30 us per wave that takes the branch, c2 0.066 -> 0.275 ms - and at workgroup scope it is nothing at all.
 __device__ __forceinline__ void mp_wait_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#ifndef MP_FK_UNIFORM_ROW0
+#define MP_FK_UNIFORM_ROW0 1
+#endif
+// a 64-bit value every active lane holds alike, moved to scalar registers (the first active lane's copy)
+__device__ __forceinline__ long mp_wave_uniform(long v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)v);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long)v >> 32));
+  return (long)(((unsigned long)hi << 32) | (unsigned long)lo);
+#else
+  return v;
+#endif
+}
 constexpr int MP_COLD_G = 8;  // slots of the kernels that carry a buffer of their own (256-thread blocks: one buffer per wave)
 // that buffer, declared in a kernel of BLOCK threads (float32 rows only: W = sizeof(T)), and this wave's part of it
 #define MP_COLD_BUFFER(N, BLOCK, W) \
@@ -351,16 +364,26 @@ struct MpRowStage {
   static constexpr int ROWB = N * (int)sizeof(T), SPAN = 64 * ROWB, NCH = SPAN / 16, NJ = (NCH + 63) / 64;
   static constexpr int BYTES = 3 * SPAN;
   static_assert(SPAN % 16 == 0, "64 rows are whole 16-byte chunks");
+  // (MP_STAGE_CLAMP, round 5: lanes past the span's last chunk - n = 6: lanes 32..63 of the second instruction - load and stage the
+  // LAST chunk again instead of being masked off: same line, same bytes to the same LDS address, and no exec-mask branch or zero
+  // fill around three loads and three LDS writes per wave.  The stores of the flush stay masked.)
+#ifndef MP_STAGE_CLAMP
+#define MP_STAGE_CLAMP 1
+#endif
+  static __device__ __forceinline__ int chunk_of(int j, int lane) {
+    const int c = j * 64 + lane;
+    return (MP_STAGE_CLAMP && (j + 1) * 64 > NCH) ? (c < NCH ? c : NCH - 1) : c;
+  }
   static __device__ __forceinline__ void fetch(const T* __restrict__ base, long row0, int lane, mp_u4 (&buf)[NJ]) {
     const mp_u4* g = reinterpret_cast<const mp_u4*>(base + row0 * N);
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
-      if (j * 64 + lane < NCH) buf[j] = mp_stream_load(g + j * 64 + lane);
+      if (MP_STAGE_CLAMP || j * 64 + lane < NCH) buf[j] = mp_stream_load(g + chunk_of(j, lane));
   }
   static __device__ __forceinline__ void stage(const mp_u4 (&buf)[NJ], int lane, char* __restrict__ region) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
-      if (j * 64 + lane < NCH) *reinterpret_cast<mp_u4*>(region + (j * 64 + lane) * 16) = buf[j];
+      if (MP_STAGE_CLAMP || j * 64 + lane < NCH) *reinterpret_cast<mp_u4*>(region + chunk_of(j, lane) * 16) = buf[j];
   }
   static __device__ __forceinline__ void row_in(const char* __restrict__ region, int lane, T (&v)[N]) {
     if constexpr (sizeof(T) == 8 && ROWB % 16 != 0) {
@@ -637,7 +660,13 @@ __device__ __forceinline__ void mp_body_fk_jac_id(const MT& M, const MpCall<T>& 
   using ST = MpRowStage<T, N>;
   static_assert(ST::SPAN <= MP_WAVE_LDS_BYTES, "one array's 64 rows fit the wave's staging slice");
   const int lane = (int)(threadIdx.x & 63);
+#if MP_FK_UNIFORM_ROW0 && defined(__HIP_DEVICE_COMPILE__)
+  // the wave's first row, SAID to be wave-uniform (lane 0's r: every lane of the wave is active here): the staging and flat-store
+  // addresses are then formed on the scalar unit (round 5: the same change took 2.4 us off the c2 kernel, profiles/r05_ab_h.txt)
+  const long row0 = mp_wave_uniform(r - lane);
+#else
   const long row0 = r - lane;
+#endif
   if (row0 >= rows) return;  // whole wave out of range (wave-uniform)
   const bool valid = r < rows;
   const long rr = valid ? r : rows - 1;  // out-of-range lanes recompute the last row and store nothing
@@ -1309,7 +1338,7 @@ __device__ __forceinline__ void mp_body_fd_traj(const MT& M, const MpCall<T>& C,
   constexpr int TW = TL::TW, STEP = TL::STEP, RS = TL::RS;
   // EVERY lane of the wave runs this body (the flat stores are wave-cooperative): lanes past the batch integrate the
   // last trajectory again and store nothing
-  const long b0 = bl - lane;                       // the wave's first trajectory (wave-uniform)
+  const long b0 = mp_wave_uniform(bl - lane);      // the wave's first trajectory (wave-uniform, and said to be)
   if (b0 >= B) return;
   const bool in_batch = bl < B;
   const long b = in_batch ? bl : B - 1;

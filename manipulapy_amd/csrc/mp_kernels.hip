@@ -131,7 +131,7 @@ __global__ __launch_bounds__(kBlock) void k_batch_traj(const MpModel<float> M, c
   const long total = B * Nt;
   const long r = (long)blockIdx.x * kBlock + threadIdx.x;
   const int lane = (int)(threadIdx.x & 63);
-  const long row0 = r - lane;
+  const long row0 = mp_wave_uniform(r - lane);   // (every lane is still active here: the flush addresses form on the scalar unit)
   if (row0 >= total) return;
   const bool full = row0 + 64 <= total;  // wave-uniform
   if (r >= total) return;                // (only in the partial wave)
