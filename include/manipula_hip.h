@@ -59,8 +59,10 @@ int mp_ctx_destroy(mp_ctx* ctx);
 int mp_ctx_synchronize(mp_ctx* ctx);  /* waits for every stream of the context */
 /* The context's compute stream as a hipStream_t (returned through a void*: no HIP header is needed to include this file), for a
  * caller that orders its own HIP work - a copy, a kernel of its own - behind the library's launches.  Stream order is the whole
- * contract: every device-pointer entry point returns with everything its result needs enqueued on this stream (see the note at
- * mp_id_trajectory_f32 for the one case where "enqueued" depends on who owns the arrays).  The reference has no streams of its
+ * contract: every device-pointer entry point returns with everything its result needs enqueued on this stream.  (Before this call
+ * the float64 pass of a float32 inverse-dynamics launch on pool arrays may stay parked - note at mp_id_trajectory_f32; the call runs
+ * what is parked and switches parking OFF for the rest of the context's life: mp_malloc returns plain device pointers, so a caller
+ * that holds the stream can read pool memory with its own copies and kernels.)  The reference has no streams of its
  * own to expose (its launchers return finished host arrays, cuda_kernels/trajectory_kernels.py:1043-1081). */
 int mp_ctx_get_stream(mp_ctx* ctx, void** hip_stream);
 /* name, CU count, total HBM bytes — replaces get_gpu_properties(), cuda_kernels/registry.py:335-356 */
@@ -79,6 +81,15 @@ int mp_stream_bandwidth(mp_ctx* ctx, size_t bytes_per_array, int reads, int reps
  * or non-temporal; *gb_per_s = (reads + writes) * bytes * reps / elapsed.  bench.py runs it with a configuration's own mix and
  * size right before its timed region: roofline.frac_of_probe says how much of what THIS box streams the kernel reaches. */
 int mp_stream_bandwidth_mix(mp_ctx* ctx, size_t bytes_per_array, int reads, int writes, int nontemporal, int reps, double* gb_per_s);
+
+/* The shader clock the GPU holds WHILE the caller's launches run (measurement plumbing, nothing in the reference corresponds to it):
+ * _begin starts a bounded sampler on a stream of its own (8 one-wave blocks stamping s_memtime / s_memrealtime over about
+ * duration_ms, 0 < duration_ms <= 2000), the caller launches what it wants measured, _end waits for the sampler and returns
+ * *clock_hz = median over the blocks of delta s_memtime / delta s_memrealtime x 100 MHz and, optionally, the time the stamps span.
+ * bench.py reports it as `clock_hz` beside every configuration's kernel time (the package's power controller runs the same code
+ * object at 1.7 - 2.5 GHz depending on the kernel's mix and the box). */
+int mp_clock_sample_begin(mp_ctx* ctx, double duration_ms);
+int mp_clock_sample_end(mp_ctx* ctx, double* clock_hz, double* sampled_ms);
 
 /* Profiling (replaces the reference's profile_start / profile_stop hooks, planning/trajectory_planning.py:295-296, and
  * the timing part of its performance_stats): while on, every device-pointer entry point (and so every *_host one)
@@ -153,9 +164,10 @@ int mp_model_fk_host(const mp_model* model, const double* q /* n */, double* T /
  * MANIPULAPY_HIP_SPECIALIZE=0 makes the launchers ignore specialised kernels (A/B measurements). */
 int mp_model_specialize(mp_ctx* ctx, const mp_model* model);
 int mp_model_is_specialized(mp_ctx* ctx, const mp_model* model, int* yes);
-/* Generate + compile only (needs hiprtc, no GPU): code-object size and whether it came from the cache. */
+/* Generate + compile only (needs hiprtc, no GPU): size of the two code objects together and whether both came from the cache. */
 int mp_model_specialize_compile(const mp_model* model, size_t* code_bytes, int* from_cache);
-/* The generated translation unit (NUL-terminated).  *len = required size incl. NUL; buf may be NULL. */
+/* The two generated translation units (NUL-terminated; the second - the one-row-per-lane float32 inverse dynamics, compiled with
+ * another scheduling strategy - behind a "// ==== second program" line).  *len = required size incl. NUL; buf may be NULL. */
 int mp_model_specialize_source(const mp_model* model, char* buf, size_t* len);
 
 /* ---- hot path, device pointers ----------------------------------------------------------------
@@ -185,7 +197,8 @@ int mp_batch_trajectory_f32(mp_ctx* ctx, const mp_model* model, const float* d_s
  *     same robot-specialised kernel on other arrays (that launch's first workgroups work it off), or to run together with the
  *     passes of up to three more launches.  It runs before anything can see the difference: every other entry point of the context
  *     (mp_memcpy_*, mp_ctx_synchronize, mp_event_record, mp_ctx_get_stream, the *_host calls, the communicator ...), a launch
- *     whose arrays overlap the parked one's, a fifth launch, mp_ctx_destroy.  Pool memory is only reachable through those.
+ *     whose arrays overlap the parked one's, a fifth launch, mp_ctx_destroy.  Without the compute stream (mp_ctx_get_stream) pool
+ *     memory is only reachable through those; once the stream has been handed out, nothing is parked any more (as for caller-owned arrays).
  *   MANIPULAPY_HIP_PARK_FOREIGN=1 (experiment switch) parks for foreign arrays too; the caller must then pass a
  *   synchronising entry point before touching them with its own HIP calls.
  * The same holds for mp_traj_id_fused_f32 (start / end / tau). */

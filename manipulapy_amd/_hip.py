@@ -53,6 +53,8 @@ SIGNATURES = {
     "mp_selftest": (ctypes.c_int, [_vp]),
     "mp_stream_bandwidth": (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
     "mp_stream_bandwidth_mix": (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
+    "mp_clock_sample_begin": (ctypes.c_int, [_vp, ctypes.c_double]),
+    "mp_clock_sample_end": (ctypes.c_int, [_vp, _c_dp, _c_dp]),
     "mp_ctx_set_profiling": (ctypes.c_int, [_vp, ctypes.c_int]),
     "mp_ctx_profile": (ctypes.c_int, [_vp, _c_dp, ctypes.POINTER(ctypes.c_int64), _c_dp, ctypes.c_int]),
     "mp_malloc": (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.POINTER(_vp)]),
@@ -350,13 +352,15 @@ class HipModel:
         _check(self.lib.mp_model_params(self.handle, _dptr(out)))
         return out
 
-    def specialize_source(self) -> str:
-        """The translation unit the run-time specialiser compiles for this robot."""
+    def specialize_source(self, part: int = 0) -> str:
+        """One of the two translation units the run-time specialiser compiles for this robot (part 1: the one-row-per-lane float32
+        inverse dynamics, built with the max-ILP scheduling strategy)."""
         n = ctypes.c_size_t(0)
         _check(self.lib.mp_model_specialize_source(self.handle, None, ctypes.byref(n)))
         buf = ctypes.create_string_buffer(n.value)
         _check(self.lib.mp_model_specialize_source(self.handle, buf, ctypes.byref(n)))
-        return buf.value.decode()
+        both = buf.value.decode().split("\n// ==== second program", 1)
+        return both[0] if part == 0 else "// ==== second program" + both[1]
 
     def specialize_compile(self):
         """hiprtc-compile the specialised kernels (no GPU needed): (code bytes, came from the disk cache)."""
@@ -447,6 +451,16 @@ class HipContext:
         _check(self.lib.mp_stream_bandwidth_mix(self.handle, ctypes.c_size_t(int(bytes_per_array)), int(reads), int(writes),
                                                 1 if nontemporal else 0, int(reps), ctypes.byref(out)))
         return float(out.value)
+
+    def clock_sample_begin(self, duration_ms: float) -> None:
+        """Start the bounded shader-clock sampler beside whatever is launched next (mp_clock_sample_begin)."""
+        _check(self.lib.mp_clock_sample_begin(self.handle, ctypes.c_double(float(duration_ms))))
+
+    def clock_sample_end(self):
+        """(clock in Hz held while the sampler ran, milliseconds its stamps span)."""
+        hz, ms = ctypes.c_double(0.0), ctypes.c_double(0.0)
+        _check(self.lib.mp_clock_sample_end(self.handle, ctypes.byref(hz), ctypes.byref(ms)))
+        return float(hz.value), float(ms.value)
 
     def properties(self) -> dict:
         name = ctypes.create_string_buffer(256)

@@ -20,50 +20,19 @@ template <> struct VecOf<double, 8> { using type = double; static constexpr int 
 // wave-cooperative movers below): on the c2 pattern - three 98 MB input streams, one output stream, rotating sets - plain
 // accesses reach 5.7 TB/s and non-temporal ones 6.4 (tools/ubench_nt.hip, 16 contiguous bytes per lane), but applied to the
 // per-lane 24-byte rows of RunIO, which touch every line with two or three instructions and rely on the caches to merge them,
-// they LOSE (c2 0.069 -> 0.085 ms, c3 3.8 -> 4.6 ms).  MP_STREAM_NT=0 (MANIPULAPY_HIP_JIT_DEFINES) gives the plain forms for an A/B.
-#if !defined(MP_STREAM_NT)
-#define MP_STREAM_NT 1
-#endif
-#if !defined(MP_WO_NT)
-#define MP_WO_NT 1
-#endif
+// they LOSE (c2 0.069 -> 0.085 ms, c3 3.8 -> 4.6 ms).  (The plain forms were build switches until round 5: profiles/HISTORY.md.)
 typedef unsigned mp_u4 __attribute__((ext_vector_type(4)));
 template <typename V>
-__device__ __forceinline__ V mp_stream_load(const V* p) {
-#if MP_STREAM_NT
-  return __builtin_nontemporal_load(p);
-#else
-  return *p;
-#endif
-}
+__device__ __forceinline__ V mp_stream_load(const V* p) { return __builtin_nontemporal_load(p); }
 template <typename V>
-__device__ __forceinline__ void mp_stream_store(V v, V* p) {
-#if MP_STREAM_NT
-  __builtin_nontemporal_store(v, p);
-#else
-  *p = v;
-#endif
-}
+__device__ __forceinline__ void mp_stream_store(V v, V* p) { __builtin_nontemporal_store(v, p); }
 
-// MP_FK_CO / MP_COOP_NT (default 1; 0 through MANIPULAPY_HIP_JIT_DEFINES for an A/B): whole-line non-temporal movement of the input
-// rows / tau of the FK + Jacobian + ID kernel, non-temporal wave-cooperative output stores.  c3 on a box in its fast state:
-// 3.71 ms plain, 3.66 stores only, 3.52 inputs only, 3.45 both (frac 0.82); in its slow (power-capped) state 4.09 / 3.99 /
-// 4.21 / 4.12 - the staging instructions cost there what the memory path gains (profiles/r03_nontemporal_ab.txt)
-#if !defined(MP_FK_CO)
-#define MP_FK_CO 1
-#endif
-// the wave-cooperative row stores further down (whole 16-byte chunks in flat order): non-temporal under MP_COOP_NT
-#if !defined(MP_COOP_NT)
-#define MP_COOP_NT 1
-#endif
+// The FK + Jacobian + ID kernel moves its input rows / tau as whole lines, non-temporal, and its wave-cooperative output stores
+// (whole 16-byte chunks in flat order) are non-temporal too.  c3 on a box in its fast state: 3.71 ms plain, 3.66 stores only,
+// 3.52 inputs only, 3.45 both (frac 0.82); in its slow (power-capped) state 4.09 / 3.99 / 4.21 / 4.12 - the staging instructions
+// cost there what the memory path gains (profiles/r03_nontemporal_ab.txt)
 template <typename V>
-__device__ __forceinline__ void mp_coop_store(V v, V* p) {
-#if MP_COOP_NT
-  __builtin_nontemporal_store(v, p);
-#else
-  *p = v;
-#endif
-}
+__device__ __forceinline__ void mp_coop_store(V v, V* p) { __builtin_nontemporal_store(v, p); }
 
 template <typename T, int COUNT>
 struct RunIO {
@@ -96,9 +65,8 @@ struct RunIO {
   }
   // per-lane row stores of a kernel that reads (almost) nothing - trajectory generation, the fused generation + inverse dynamics:
   // there is no read stream for the partial lines to disturb, and non-temporal stores measure a few per cent better there
-  // (MP_WO_NT, default 1: c2f 0.054 -> 0.052 ms)
+  // (c2f 0.054 -> 0.052 ms)
   static __device__ __forceinline__ void store_wo(T* __restrict__ base, long run, const T (&v)[COUNT]) {
-#if MP_WO_NT
     V* dst = reinterpret_cast<V*>(base + run * COUNT);
 #pragma unroll
     for (int k = 0; k < COUNT / K; ++k) {
@@ -107,9 +75,6 @@ struct RunIO {
       for (int j = 0; j < K; ++j) u.e[j] = v[k * K + j];
       __builtin_nontemporal_store(u.vec, dst + k);
     }
-#else
-    store(base, run, v);
-#endif
   }
 };
 
@@ -164,9 +129,6 @@ struct MpColdLds { static constexpr int BYTES = G * MpColdSlot<N>::BYTES; };
 // whole-line flush, then the re-evaluated row).  A release FENCE is the wrong tool: at agent scope it is `buffer_wbl2` - the
 // whole L2 written back, ~30 us per wave that takes the branch, c2 0.066 -> 0.275 ms - and at workgroup scope it is nothing at all.
 __device__ __forceinline__ void mp_wait_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-#ifndef MP_FK_UNIFORM_ROW0
-#define MP_FK_UNIFORM_ROW0 1
-#endif
 // a 64-bit value every active lane holds alike, moved to scalar registers (the first active lane's copy)
 __device__ __forceinline__ long mp_wave_uniform(long v) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -364,26 +326,23 @@ struct MpRowStage {
   static constexpr int ROWB = N * (int)sizeof(T), SPAN = 64 * ROWB, NCH = SPAN / 16, NJ = (NCH + 63) / 64;
   static constexpr int BYTES = 3 * SPAN;
   static_assert(SPAN % 16 == 0, "64 rows are whole 16-byte chunks");
-  // (MP_STAGE_CLAMP, round 5: lanes past the span's last chunk - n = 6: lanes 32..63 of the second instruction - load and stage the
-  // LAST chunk again instead of being masked off: same line, same bytes to the same LDS address, and no exec-mask branch or zero
-  // fill around three loads and three LDS writes per wave.  The stores of the flush stay masked.)
-#ifndef MP_STAGE_CLAMP
-#define MP_STAGE_CLAMP 1
-#endif
+  // (round 5: lanes past the span's last chunk - n = 6: lanes 32..63 of the second instruction - load and stage the LAST chunk
+  // again instead of being masked off: same line, same bytes to the same LDS address, and no exec-mask branch or zero fill around
+  // three loads and three LDS writes per wave.  The stores of the flush stay masked.)
   static __device__ __forceinline__ int chunk_of(int j, int lane) {
     const int c = j * 64 + lane;
-    return (MP_STAGE_CLAMP && (j + 1) * 64 > NCH) ? (c < NCH ? c : NCH - 1) : c;
+    return ((j + 1) * 64 > NCH) ? (c < NCH ? c : NCH - 1) : c;
   }
   static __device__ __forceinline__ void fetch(const T* __restrict__ base, long row0, int lane, mp_u4 (&buf)[NJ]) {
     const mp_u4* g = reinterpret_cast<const mp_u4*>(base + row0 * N);
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
-      if (MP_STAGE_CLAMP || j * 64 + lane < NCH) buf[j] = mp_stream_load(g + chunk_of(j, lane));
+      buf[j] = mp_stream_load(g + chunk_of(j, lane));
   }
   static __device__ __forceinline__ void stage(const mp_u4 (&buf)[NJ], int lane, char* __restrict__ region) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
-      if (MP_STAGE_CLAMP || j * 64 + lane < NCH) *reinterpret_cast<mp_u4*>(region + chunk_of(j, lane) * 16) = buf[j];
+      *reinterpret_cast<mp_u4*>(region + chunk_of(j, lane) * 16) = buf[j];
   }
   static __device__ __forceinline__ void row_in(const char* __restrict__ region, int lane, T (&v)[N]) {
     if constexpr (sizeof(T) == 8 && ROWB % 16 != 0) {
@@ -561,11 +520,8 @@ __device__ __forceinline__ void mp_wave_store_flat(T* __restrict__ gbase, long r
   // row boundary iff the padding is a multiple of 8.  An odd row (the 6 x 7 float64 Jacobian: 21 chunks) needs no padding at all;
   // round 1's rule (next multiple of 128 bytes + one chunk: 25 chunks, padding 4) was conflict-free on the writes and collided on
   // every read group that crossed a row end: SQ_LDS_BANK_CONFLICT 69.6 M cycles per c3 launch, 14 % of the LDS cycles.
-#if defined(MP_WSF_PAD_R01)   // experiment switch: round 1's padding, for the A/B (profiles/r04_c3_lds_ab.txt)
-  constexpr int PITCH = ((CH * W + 127) / 128) * 128 + W;
-#else
+  // (the A/B against round 1's padding: profiles/r04_c3_lds_ab.txt)
   constexpr int PITCH = (W == 16 && CH % 2 == 1) ? CH * W : ((CH * W + 127) / 128) * 128 + W;
-#endif
   static_assert(ROWS * PITCH <= MP_WAVE_LDS_BYTES, "wave staging slice too small");
   constexpr int TOTAL = ROWS * CH, NJ = (TOTAL + 63) / 64;
   V* gout = reinterpret_cast<V*>(gbase + row0 * COUNT);
@@ -660,25 +616,17 @@ __device__ __forceinline__ void mp_body_fk_jac_id(const MT& M, const MpCall<T>& 
   using ST = MpRowStage<T, N>;
   static_assert(ST::SPAN <= MP_WAVE_LDS_BYTES, "one array's 64 rows fit the wave's staging slice");
   const int lane = (int)(threadIdx.x & 63);
-#if MP_FK_UNIFORM_ROW0 && defined(__HIP_DEVICE_COMPILE__)
   // the wave's first row, SAID to be wave-uniform (lane 0's r: every lane of the wave is active here): the staging and flat-store
   // addresses are then formed on the scalar unit (round 5: the same change took 2.4 us off the c2 kernel, profiles/r05_ab_h.txt)
   const long row0 = mp_wave_uniform(r - lane);
-#else
-  const long row0 = r - lane;
-#endif
   if (row0 >= rows) return;  // whole wave out of range (wave-uniform)
   const bool valid = r < rows;
   const long rr = valid ? r : rows - 1;  // out-of-range lanes recompute the last row and store nothing
   const long left = rows - row0;
   const int nvalid = left < 64 ? (int)left : 64;
-#if MP_FK_CO
   // A full wave moves its input rows and tau as whole lines, non-temporal (MpRowStage; see mp_body_id_co): all three arrays are
   // requested up front, each is staged through the slice when its values are needed.  The last, partial wave: per-lane rows.
   const bool full = nvalid == 64;
-#else
-  const bool full = false;
-#endif
   mp_u4 bq[ST::NJ], bd[ST::NJ], ba[ST::NJ];
   if (full) {
     ST::fetch(q, row0, lane, bq);
@@ -756,29 +704,8 @@ __device__ __forceinline__ void mp_body_fk_jac_id(const MT& M, const MpCall<T>& 
 }
 
 // ------------------------------------------------- float32, two rows per lane (packed v_pk_* math)
-template <int N>
-__device__ __forceinline__ void load_pair(const float* __restrict__ base, long pair, mp_f2 (&v)[N]) {
-  float f[2 * N];
-  RunIO<float, 2 * N>::load(base, pair, f);
-#pragma unroll
-  for (int j = 0; j < N; ++j) v[j] = (mp_f2){f[j], f[N + j]};
-}
-template <int N>
-__device__ __forceinline__ void store_pair(float* __restrict__ base, long pair, const mp_f2 (&v)[N], const MpBad<mp_f2>& bad) {
-  float f[2 * N];
-  const bool bx = bad.x.any(), by = bad.y.any();
-#pragma unroll
-  for (int j = 0; j < N; ++j) {
-    f[j] = v[j].x; f[N + j] = v[j].y;
-    mp_poison_if(bx, f[j]);
-    mp_poison_if(by, f[N + j]);
-  }
-  RunIO<float, 2 * N>::store(base, pair, f);
-}
-
-
 // the packed recursion of a lane's two rows + the float64 re-evaluation of whichever of the two needs it (`cold`: this wave's
-// MpColdLds<N, MP_COLD_G> buffer; the inputs are still in the lane's registers here - these are the A/B forms, not register-tuned)
+// MpColdLds<N, MP_COLD_G> buffer; the inputs are still in the lane's registers here)
 template <int N, bool HAS_FTIP, typename MT>
 __device__ __forceinline__ void mp_rnea_pk(const MT& M, const MpCall<float>& C, const MpJointState<mp_f2, N>& js, const mp_f2 (&q)[N],
                                            const mp_f2 (&qd)[N], const mp_f2 (&qdd)[N], mp_f2 (&tau)[N], const MpBad<mp_f2>& bad,
@@ -809,89 +736,12 @@ __device__ __forceinline__ void mp_rnea_pk(const MT& M, const MpCall<float>& C, 
 #endif
 }
 
-// tau for the row pair `p` (rows 2p, 2p+1): the body of k_id_pk
-template <int N, bool HAS_FTIP, typename MT>
-__device__ __forceinline__ void mp_body_id_pk(const MT& M, const MpCall<float>& C, const float* __restrict__ q,
-                                              const float* __restrict__ qd, const float* __restrict__ qdd,
-                                              float* __restrict__ tau, long p, char* __restrict__ cold) {
-  mp_f2 a[N], b[N], c[N], t[N];
-  load_pair<N>(q, p, a);
-  load_pair<N>(qd, p, b);
-  load_pair<N>(qdd, p, c);
-  MpJointState<mp_f2, N> js;
-  mp_joint_state<mp_f2, N>(M, a, js);
-  MpBad<mp_f2> bad;
-  bad.add(a); bad.add(b); bad.add(c);
-  mp_rnea_pk<N, HAS_FTIP>(M, C, js, a, b, c, t, bad, cold);
-#pragma unroll
-  for (int j = 0; j < N; ++j) t[j] = mp_clip_tau(t[j], M.taumin[j], M.taumax[j]);
-  store_pair<N>(tau, p, t, bad);
-}
-
-// The same for the rows `p` and `p + stride` (instead of the adjacent 2p, 2p+1): each half of the batch is then read
-// in the one-row-per-lane pattern (24-byte runs at n = 6), which streams 7 % faster than 48-byte runs
-// (tools/ubench_mem.hip: 5.88 vs 5.47 TB/s).
-template <int N, bool HAS_FTIP, typename MT>
-__device__ __forceinline__ void mp_body_id_pk_split(const MT& M, const MpCall<float>& C, const float* __restrict__ q,
-                                                    const float* __restrict__ qd, const float* __restrict__ qdd,
-                                                    float* __restrict__ tau, long p, long stride, char* __restrict__ cold) {
-  mp_f2 v[3][N], t[N];
-  const float* src[3] = {q, qd, qdd};
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    float lo[N], hi[N];
-    RunIO<float, N>::load(src[a], p, lo);
-    RunIO<float, N>::load(src[a], p + stride, hi);
-#pragma unroll
-    for (int j = 0; j < N; ++j) v[a][j] = (mp_f2){lo[j], hi[j]};
-  }
-  MpJointState<mp_f2, N> js;
-  mp_joint_state<mp_f2, N>(M, v[0], js);
-  MpBad<mp_f2> bad;
-  bad.add(v[0]); bad.add(v[1]); bad.add(v[2]);
-  mp_rnea_pk<N, HAS_FTIP>(M, C, js, v[0], v[1], v[2], t, bad, cold);
-  float lo[N], hi[N];
-#pragma unroll
-  for (int j = 0; j < N; ++j) {
-    const mp_f2 c = mp_clip_tau(t[j], M.taumin[j], M.taumax[j]);
-    lo[j] = c.x; hi[j] = c.y;
-  }
-  mp_poison_if(bad.x.any(), lo);
-  mp_poison_if(bad.y.any(), hi);
-  RunIO<float, N>::store(tau, p, lo);
-  RunIO<float, N>::store(tau, p + stride, hi);
-}
-
-// generation fused into inverse dynamics for the row pair `p`: the body of k_traj_id_pk
-template <int N, bool HAS_FTIP, typename MT>
-__device__ __forceinline__ void mp_body_traj_id_pk(const MT& M, const MpCall<float>& C, const float* __restrict__ start,
-                                                   const float* __restrict__ end, long p, long Nt, double Tf, int method,
-                                                   float* __restrict__ tau, char* __restrict__ cold) {
-  const long r0 = 2 * p;
-  const long b0 = r0 / Nt, t0 = r0 - b0 * Nt;
-  const bool wrap = t0 + 1 >= Nt;  // the pair may straddle two trajectories
-  const long b1 = wrap ? b0 + 1 : b0, t1 = wrap ? 0 : t0 + 1;
-  float p0[N], v0[N], a0[N], p1[N], v1[N], a1[N];
-  traj_row<N>(M, start, end, b0, t0, Nt, Tf, method, p0, v0, a0);
-  traj_row<N>(M, start, end, b1, t1, Nt, Tf, method, p1, v1, a1);
-  mp_f2 qq[N], qd[N], qdd[N], tq[N];
-#pragma unroll
-  for (int j = 0; j < N; ++j) { qq[j] = (mp_f2){p0[j], p1[j]}; qd[j] = (mp_f2){v0[j], v1[j]}; qdd[j] = (mp_f2){a0[j], a1[j]}; }
-  MpJointState<mp_f2, N> js;
-  mp_joint_state<mp_f2, N>(M, qq, js);
-  MpBad<mp_f2> bad;  // a non-finite end point makes the generated row non-finite
-  bad.add(qq); bad.add(qd); bad.add(qdd);
-  mp_rnea_pk<N, HAS_FTIP>(M, C, js, qq, qd, qdd, tq, bad, cold);
-#pragma unroll
-  for (int j = 0; j < N; ++j) tq[j] = mp_clip_tau(tq[j], M.taumin[j], M.taumax[j]);
-  store_pair<N>(tau, p, tq, bad);
-}
-
-// The same with the time scaling taken from a per-call table (s, s', s'' per timestep, three doubles each, written by
-// k_time_table with exactly the arithmetic of traj_row) and with both rows of the lane in ONE trajectory: timesteps t0
-// and t1 = t0 + ceil(Nt / 2).  Per pair this removes the eleven float64 divisions and the 64-bit row -> (trajectory,
-// timestep) division of the form above (293 float64 + ~100 integer instructions of 1006), loads the end points once,
-// and stores tau in one-row-per-lane runs.  `valid1` is false for the unpaired middle row of an odd Nt.
+// Generation fused into inverse dynamics, two rows per lane in packed arithmetic.  The time scaling comes from a per-call table
+// (s, s', s'' per timestep, three doubles each, written by k_time_table with exactly the arithmetic of traj_row), and both rows of
+// a lane lie in ONE trajectory: timesteps t0 and t1 = t0 + ceil(Nt / 2).  Against the first form (time scaling per row, adjacent
+// rows: removed in round 6) a pair saves eleven float64 divisions and the 64-bit row -> (trajectory, timestep) division (293
+// float64 + ~100 integer instructions of 1006), loads the end points once and stores tau in one-row-per-lane runs.  `valid1` is
+// false for the unpaired middle row of an odd Nt.
 template <int N, bool HAS_FTIP, typename MT>
 __device__ __forceinline__ void mp_body_traj_id_pk_tab(const MT& M, const MpCall<float>& C, const float* __restrict__ start,
                                                        const float* __restrict__ end, long b, long t0, long t1, bool valid1,
@@ -928,112 +778,9 @@ __device__ __forceinline__ void mp_body_traj_id_pk_tab(const MT& M, const MpCall
   if (valid1) RunIO<float, N>::store_wo(tau, b * Nt + t1, hi);
 }
 
-// One timestep per lane (scalar float32 arithmetic): on gfx950 a scalar v_fma_f32 occupies the SIMD for ~2 cycles, a
-// packed one for ~4 (tools/ubench_issue2.hip), so for the VALU-bound fused kernel one row per lane is the faster form.
-template <int N, bool HAS_FTIP, typename MT>
-__device__ __forceinline__ void mp_body_traj_id_tab(const MT& M, const MpCall<float>& C, const float* __restrict__ start,
-                                                    const float* __restrict__ end, long b, long t, long Nt,
-                                                    const double* __restrict__ tab, float* __restrict__ tau, char* __restrict__ cold) {
-  float a[N], e[N];
-  RunIO<float, N>::load(start, b, a);
-  RunIO<float, N>::load(end, b, e);
-  const double s0 = tab[3 * t], sd0 = tab[3 * t + 1], sdd0 = tab[3 * t + 2];
-  float qq[N], qd[N], qdd[N], tq[N];
-#pragma unroll
-  for (int j = 0; j < N; ++j) {
-    const double d = (double)(e[j] - a[j]);  // float32 difference first, as the reference types it
-    qq[j] = mp_clip((float)(s0 * d + (double)a[j]), M.qmin[j], M.qmax[j]);
-    qd[j] = (float)(sd0 * d);
-    qdd[j] = (float)(sdd0 * d);
-  }
-  MpJointState<float, N> js;
-  mp_joint_state<float, N>(M, qq, js);
-  MpBad<float> bad;  // a non-finite end point makes the generated row non-finite
-  bad.add(qq); bad.add(qd); bad.add(qdd);
-  const bool hard = mp_rnea_f32<N, HAS_FTIP>(M, C, js, qd, qdd, tq) && !bad.any();
-  mp_cold_rows<N, HAS_FTIP, MP_COLD_G>(M, C, hard, -1L, cold, [&](float (&x)[N], float (&y)[N], float (&z)[N]) {
-#pragma unroll
-    for (int j = 0; j < N; ++j) { x[j] = qq[j]; y[j] = qd[j]; z[j] = qdd[j]; }
-  }, tq);
-#pragma unroll
-  for (int j = 0; j < N; ++j) tq[j] = mp_clip_tau(tq[j], M.taumin[j], M.taumax[j]);
-  mp_poison_if(bad.any(), tq);
-  RunIO<float, N>::store_wo(tau, b * Nt + t, tq);
-}
-
-// The same rows taken FLAT, one wave per 64 consecutive rows of the (B, Nt) torque history, tau leaving as whole lines (MpRowStage,
-// non-temporal) instead of per-lane 24-byte runs (PMC on the packed form: 1.036 x the algorithmic bytes written; this one 1.000).
-// row -> (trajectory, timestep) without a division per lane: the wave's first row is divided ON THE SCALAR UNIT by a host-supplied
-// reciprocal (`magic` = floor(2^32 / Nt): one s_mul_hi_u32 and one correction step; rows < 2^32), a lane past the end of that
-// trajectory belongs to the next one (Nt >= 64: at most one wrap per wave).  The last, partial wave stores per lane.
-constexpr int MP_TRAJ_CO_LDS = 4096;  // per wave (one wave per block): 64 tau rows (<= 2 KB) / eight or more re-evaluation slots
-template <int N, bool HAS_FTIP, typename MT>
-__device__ __forceinline__ void mp_body_traj_id_co(const MT& M, const MpCall<float>& C, const float* __restrict__ start,
-                                                   const float* __restrict__ end, unsigned row0, int lane, unsigned rows, unsigned Nt,
-                                                   unsigned magic, const double* __restrict__ tab, float* __restrict__ tau,
-                                                   char* __restrict__ lds) {
-  using ST = MpRowStage<float, N>;
-  const bool full = rows - row0 >= 64u;  // wave-uniform
-  const bool valid = row0 + (unsigned)lane < rows;
-  unsigned b0 = (unsigned)(((unsigned long long)row0 * magic) >> 32);
-  unsigned t0 = row0 - b0 * Nt;
-  if (t0 >= Nt) { t0 -= Nt; ++b0; }    // scalar compare / select
-  unsigned t = t0 + (valid ? (unsigned)lane : 0u);  // lanes past the end recompute the wave's first row and store nothing
-  unsigned b = b0;
-  if (t >= Nt) { t -= Nt; ++b; }
-  float a[N], e[N];
-  RunIO<float, N>::load(start, (long)b, a);
-  RunIO<float, N>::load(end, (long)b, e);
-  const double s0 = tab[3 * t], sd0 = tab[3 * t + 1], sdd0 = tab[3 * t + 2];
-  float qq[N], qd[N], qdd[N], tq[N];
-#pragma unroll
-  for (int j = 0; j < N; ++j) {
-    const double d = (double)(e[j] - a[j]);  // float32 difference first, as the reference types it
-    qq[j] = mp_clip((float)(s0 * d + (double)a[j]), M.qmin[j], M.qmax[j]);
-    qd[j] = (float)(sd0 * d);
-    qdd[j] = (float)(sdd0 * d);
-  }
-  MpJointState<float, N> js;
-  mp_joint_state<float, N>(M, qq, js);
-  MpBad<float> bad;  // a non-finite end point makes the generated row non-finite
-  bad.add(qq); bad.add(qd); bad.add(qdd);
-  const bool poison = bad.any();
-  const bool hard = mp_rnea_f32<N, HAS_FTIP>(M, C, js, qd, qdd, tq) && !poison && valid;
-#pragma unroll
-  for (int j = 0; j < N; ++j) tq[j] = mp_clip_tau(tq[j], M.taumin[j], M.taumax[j]);
-  mp_poison_if(poison, tq);
-  if (full) {
-    ST::row_out(lds, lane, tq);
-    ST::sync();
-    ST::flush(tau, (long)row0, lane, lds);
-  } else if (valid) {
-    RunIO<float, N>::store_wo(tau, (long)row0 + lane, tq);
-  }
-  // ill-conditioned rows again in float64 after the wave's rows have left (see mp_body_id_co); the inputs are generated again
-  if (__builtin_amdgcn_ballot_w64(hard) != 0ull) {
-    ST::sync();
-    mp_wait_stores();
-    constexpr int G = MP_TRAJ_CO_LDS / MpColdSlot<N>::BYTES;
-    const bool here = mp_cold_rows<N, HAS_FTIP, G>(M, C, hard, (long)row0 + lane, lds, [&](float (&x)[N], float (&y)[N], float (&z)[N]) {
-      float a2[N], e2[N];
-      RunIO<float, N>::load(start, (long)b, a2);
-      RunIO<float, N>::load(end, (long)b, e2);
-      const double u0 = tab[3 * t], u1 = tab[3 * t + 1], u2 = tab[3 * t + 2];
-#pragma unroll
-      for (int j = 0; j < N; ++j) {
-        const double d = (double)(e2[j] - a2[j]);
-        x[j] = mp_clip((float)(u0 * d + (double)a2[j]), M.qmin[j], M.qmax[j]);
-        y[j] = (float)(u1 * d);
-        z[j] = (float)(u2 * d);
-      }
-    }, tq);
-    if (here && hard) {
-#pragma unroll
-      for (int j = 0; j < N; ++j) tq[j] = mp_clip_tau(tq[j], M.taumin[j], M.taumax[j]);
-      RunIO<float, N>::store(tau, (long)row0 + lane, tq);
-    }
-  }
-}
+// (Two other forms of this kernel were built, measured and removed in round 6: one timestep per lane in scalar arithmetic - c2f 0.063
+// against 0.054 ms - and flat rows with tau as whole lines through LDS - exact traffic, 1486 issue cycles per row against 1334:
+// 0.0553 - 0.0571 against 0.0533 ms, profiles/r04_c2f_ab.txt, profiles/HISTORY.md.)
 
 // lane -> (trajectory, timestep pair) for the kernel above: `bpt` blocks of `block` lanes per trajectory
 __device__ __forceinline__ bool mp_traj_pair(unsigned block_idx, unsigned lane, unsigned block, unsigned bpt, long Nt, long& b,
@@ -1597,14 +1344,11 @@ __device__ __forceinline__ void mp_fd_rows_arrived(T (&tau)[N], T (&F)[6]) {
   }
 }
 
-// MP_TM_PRIO (default 1; A/B switch through MANIPULAPY_HIP_JIT_DEFINES): the favoured wave of a SIMD alternates step by step
+// The favoured wave of a SIMD alternates step by step
 // (s_setprio from step index ^ wave slot) - the arbiter serves the older wave first, which then runs ahead and leaves its
 // partner alone at the end (c5: 0.391 against 0.398 ms).  Measured and not kept (profiles/r03_c5_tm_experiments.txt):
 // requesting the rows two steps ahead (three register sets, time loop unrolled by three): 0.391 against 0.389 ms;
 // non-temporal output stores: 0.396 against 0.398 ms.
-#if !defined(MP_TM_PRIO)
-#define MP_TM_PRIO 1
-#endif
 
 // One row of a time-major array for this lane: `ubase` = the array, `urow` = wave-uniform element index of the wave's first
 // row, `off` = this lane's element offset inside the wave's span (lane * COUNT: constant over the steps).  Written as
@@ -1663,15 +1407,11 @@ __device__ __forceinline__ void mp_body_fd_traj_tm(const MT& M, const MpCall<T>&
     if (HAS_FTIP) RowIO<T, 6>::load(Ftipmat, r * 6, off6, R.F);
   };
   auto arrived = [&](Rows& R) __attribute__((always_inline)) { mp_fd_rows_arrived<T, N, HAS_FTIP>(R.tau, R.F); };
-#if MP_TM_PRIO
   const unsigned wave_slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1u;  // HW_ID.WAVE_ID bit 0
-#endif
   // one integration step from the rows in R; its output rows are stored and never waited for
   auto step = [&](long i, const Rows& R) __attribute__((always_inline)) {
-#if MP_TM_PRIO
     if (((unsigned)i ^ wave_slot) & 1u) __builtin_amdgcn_s_setprio(1);
     else __builtin_amdgcn_s_setprio(0);
-#endif
     T tau[N], tn[3] = {T(0), T(0), T(0)}, tf[3] = {T(0), T(0), T(0)}, last[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) {

@@ -28,23 +28,24 @@
 // ------------------------------------------------------------------------------------- objects
 struct MpSpec {  // run-time specialised kernels of one model on one device
   hipModule_t mod = nullptr;
-  hipModule_t mod_ilp = nullptr;  // second program (mp_jit part 1): id_s compiled with the max-ILP strategy; optional
-  hipFunction_t id_pk[2] = {nullptr, nullptr}, traj_id_pk[2] = {nullptr, nullptr}, fd_traj[2] = {nullptr, nullptr};
+  hipModule_t mod_ilp = nullptr;  // second program (mp_jit part 1): id_s / id_co, compiled with the max-ILP scheduling strategy
+  hipFunction_t traj_id_pk[2] = {nullptr, nullptr}, fd_traj[2] = {nullptr, nullptr};
   hipFunction_t id_d[2] = {nullptr, nullptr}, fk_jac_id_d[2] = {nullptr, nullptr};
   hipFunction_t ik = nullptr;
   hipFunction_t fd_s[2] = {nullptr, nullptr}, fd_d[2] = {nullptr, nullptr};  // forward dynamics per row, float32 / float64
   hipFunction_t id_s[2] = {nullptr, nullptr};                                  // inverse dynamics, float32, one row per lane
-  hipFunction_t traj_id_s[2] = {nullptr, nullptr};                             // generation fused into it, one timestep per lane
   hipFunction_t fd_traj_tm[2] = {nullptr, nullptr};                            // the roll-out on the time-major device layout
-  hipFunction_t id_co[2] = {nullptr, nullptr};   // id_s with whole-line non-temporal row movement through LDS (full waves only); optional
-  hipFunction_t traj_id_co[2] = {nullptr, nullptr};  // generation fused into it on flat rows, tau as whole lines; optional
-  hipFunction_t id_hard[2] = {nullptr, nullptr}, traj_id_hard[2] = {nullptr, nullptr};  // the float64 pass over handed-over rows; optional
+  hipFunction_t id_co[2] = {nullptr, nullptr};   // id_s with whole-line non-temporal row movement through LDS (full waves only)
+  hipFunction_t id_hard[2] = {nullptr, nullptr}, traj_id_hard[2] = {nullptr, nullptr};  // the float64 pass over handed-over rows
 };
 struct mp_ctx {
   int device = -1;
   hipStream_t compute = nullptr;
   hipStream_t copy = nullptr;      // host -> device leg of the chunked host-buffer pipeline
   hipStream_t copy_out = nullptr;  // device -> host leg
+  hipStream_t aux = nullptr;       // the shader-clock sampler's stream (mp_clock_sample_begin; created on first use)
+  unsigned long long* clock_buf = nullptr;  // its stamps
+  bool clock_sampling = false;
   std::map<size_t, std::vector<void*>> free_by_size;  // pool: exact-size free lists
   std::map<void*, size_t> live;                        // every buffer handed out -> its size
   std::map<uint64_t, void*> dev_models;                // model uid -> float32 model resident on this device
@@ -53,6 +54,7 @@ struct mp_ctx {
   int compute_units = 0;
   uint64_t uid = 0;                                    // never reused (graphs identify their context by it, not by address)
   bool capturing = false;                              // between mp_graph_begin and mp_graph_end
+  bool stream_exported = false;                        // mp_ctx_get_stream has handed the compute stream out: no pass stays parked any more
   void* queue_counter = nullptr;                       // 8-byte work-queue head of the IK kernel (lazily allocated)
   // The float64 pass over the ill-conditioned rows of a float32 inverse-dynamics launch (attach_hard_list / hard_defer /
   // hard_flush).  The pass costs ~5 us of launch + memory latency however few rows it holds - 8 % of c2's kernel - so it is NOT
@@ -302,24 +304,6 @@ bool specialize_enabled() {
   static const bool on = [] { const char* e = getenv("MANIPULAPY_HIP_SPECIALIZE"); return !(e && e[0] == '0'); }();
   return on;
 }
-// Which float32 form the robot-specialised inverse-dynamics kernels take.  MANIPULAPY_HIP_F32 = "scalar" | "packed" forces
-// one; by default the scalar one-row-per-lane form (v_fma_f32: ~2 cycles per wave instruction on gfx950, the packed forms ~4;
-// measured c2 +5 %, c4 +7.5 %).  Until the rows moved as whole lines (mp_spec_id_co) odd joint counts, whose 4 n-byte rows only
-// allow dword accesses per lane, measured 4 % better two rows per lane; now c4s (n = 7) takes 0.119-0.120 ms against 0.128-0.129.
-// MANIPULAPY_HIP_ID_CO=0: the per-lane kernel for every row (A/B against the whole-line kernel, tools/ab_co.sh)
-static bool id_co_enabled() {
-  static const bool on = [] { const char* e = getenv("MANIPULAPY_HIP_ID_CO"); return !(e && e[0] == '0'); }();
-  return on;
-}
-bool spec_scalar_f32(int n) {
-  static const int forced = [] {
-    const char* e = getenv("MANIPULAPY_HIP_F32");
-    return !e ? 0 : (e[0] == 's' ? 1 : (e[0] == 'p' ? 2 : 0));
-  }();
-  if (forced) return forced == 1;
-  (void)n;   // every joint count since the rows move as whole lines (mp_spec_id_co): c4s, n = 7: 0.119-0.120 ms against 0.128-0.129 packed
-  return true;
-}
 const MpSpec* find_spec(mp_ctx* ctx, const mp_model* model) {
   if (!specialize_enabled()) return nullptr;
   auto it = ctx->specs.find(model->uid);
@@ -415,20 +399,30 @@ mp_ctx::HardSlot* attach_hard_list(mp_ctx* ctx, long rows, MpCall<float>* c) {
   if (hs->cap < need) {
     RelaxedCapture relaxed(ctx->capturing);
     if (!ctx->capturing && hipStreamSynchronize(ctx->compute) != hipSuccess) return nullptr;
+    // EVERY free slot of the pool gets its counters and a list of this size now, not only the one this launch takes: a slot's first
+    // use in the middle of a run of launches put a stream synchronisation and two allocations between two 65 us kernels (round 5's
+    // "cold" c2 figure, 0.08 - 0.12 ms against 0.065 sustained: profiles/r06_cold_before_windows.json - the kernels themselves
+    // ran at their sustained duration).  A parked slot keeps its list (its pass reads it) and grows when it is next taken.
     // (zeroed ON the compute stream: a plain hipMemset of device memory is not ordered with a kernel launched on another,
     // non-blocking stream right behind it - a kernel that met the allocation's old bytes as its counter took the list for full and
     // re-evaluated in place, correct but not bit-equal to the pass: seen once, as 27 elements of a 240 000-element comparison.
     // In a capture this is the node that zeroes the graph's counters ahead of their first user, on every replay.)
-    if (!hs->ctrl && (hipMalloc((void**)&hs->ctrl, 2 * sizeof(unsigned)) != hipSuccess ||
-                      hipMemsetAsync(hs->ctrl, 0, 2 * sizeof(unsigned), ctx->compute) != hipSuccess)) {
-      hs->ctrl = nullptr;
-      return nullptr;
-    }
-    if (hs->rows && ctx->capturing) pool->retired.push_back(hs->rows);  // earlier nodes of the graph still write it
-    else if (hs->rows) (void)hipFree(hs->rows);
-    hs->rows = nullptr; hs->cap = 0;
-    if (hipMalloc((void**)&hs->rows, (size_t)need * sizeof(unsigned)) != hipSuccess) { hs->rows = nullptr; return nullptr; }
-    hs->cap = need;
+    auto grow = [&](mp_ctx::HardSlot* s) -> bool {
+      if (!s->ctrl && (hipMalloc((void**)&s->ctrl, 2 * sizeof(unsigned)) != hipSuccess ||
+                       hipMemsetAsync(s->ctrl, 0, 2 * sizeof(unsigned), ctx->compute) != hipSuccess)) {
+        s->ctrl = nullptr;
+        return false;
+      }
+      if (s->rows && ctx->capturing) pool->retired.push_back(s->rows);  // earlier nodes of the graph still write it
+      else if (s->rows) (void)hipFree(s->rows);
+      s->rows = nullptr; s->cap = 0;
+      if (hipMalloc((void**)&s->rows, (size_t)need * sizeof(unsigned)) != hipSuccess) { s->rows = nullptr; return false; }
+      s->cap = need;
+      return true;
+    };
+    if (!grow(hs)) return nullptr;
+    for (auto& other : pool->slot)
+      if (&other != hs && !other.busy && other.cap < need && !grow(&other)) break;  // (a slot left small grows when it is taken)
   }
   if (hs->orphan && hipMemsetAsync(hs->ctrl, 0, 2 * sizeof(unsigned), ctx->compute) != hipSuccess) return nullptr;
   hs->orphan = true;  // until its pass is parked (hard_defer) or launched (hard_passed)
@@ -447,8 +441,7 @@ void free_hard_pool(mp_ctx::HardPool* pool) {
   pool->retired.clear();
 }
 unsigned hard_pass_blocks(long rows) {
-  static const long cap = [] { const char* e = getenv("MANIPULAPY_HIP_HARD_BLOCKS"); return e ? std::max(1L, atol(e)) : 1024L; }();  // experiment switch
-  return (unsigned)std::min<long>((rows / 8 + 63) / 64 + 1, cap);
+  return (unsigned)std::min<long>((rows / 8 + 63) / 64 + 1, 1024L);
 }
 // the pass of the list's launch has been enqueued directly (the fused paths); returns rc for tail calls
 inline int hard_passed(mp_ctx::HardSlot* hs, int rc) {
@@ -478,7 +471,10 @@ void hard_defer_generated(mp_ctx* ctx, mp_ctx::HardSlot* hs, hipFunction_t fn, c
 // (cuda_kernels/trajectory_kernels.py:1043-1081).
 int hard_park_or_run(mp_ctx* ctx, const void* a, const void* b, const void* c, const void* out, size_t bytes_out, size_t bytes_in) {
   static const bool always = getenv("MANIPULAPY_HIP_PARK_FOREIGN") && getenv("MANIPULAPY_HIP_PARK_FOREIGN")[0] == '1';  // experiment switch
-  if (always || (pool_owned(ctx, a, bytes_in) && pool_owned(ctx, b, bytes_in) && pool_owned(ctx, c, bytes_in) && pool_owned(ctx, out, bytes_out)))
+  if (always) return MP_OK;
+  // ... and once the caller holds the compute stream (mp_ctx_get_stream) it can read pool memory too - mp_malloc returns a plain device
+  // pointer - with a copy or a kernel of its own on that stream, behind the library's back: from then on nothing stays parked
+  if (!ctx->stream_exported && pool_owned(ctx, a, bytes_in) && pool_owned(ctx, b, bytes_in) && pool_owned(ctx, c, bytes_in) && pool_owned(ctx, out, bytes_out))
     return MP_OK;
   return hard_flush(ctx);
 }
@@ -539,16 +535,10 @@ int hard_flush_if_overlapping(mp_ctx* ctx, const void* const* lo, const size_t* 
   }
   return MP_OK;
 }
-// Whether a parked float64 pass rides with the next float32 launch of its program (the launch's first workgroups work it off)
-// instead of waiting for a kernel of its own: yes for both specialised kernels that host the path - the fused one (two waves per SIMD
-// by design: the float64 recursion's registers are free) and the given-rows one (held to its five waves: the carried path spills to
-// scratch, csrc/mp_jit.cpp).  MANIPULAPY_HIP_LEAD_FUSED=0 / MANIPULAPY_HIP_LEAD=0 switch them off for A/B runs (the latter belongs
-// with a program built with -DMP_ID_LEAD=0).
-bool lead_enabled(bool fused) {
-  static const bool on_fused = [] { const char* e = getenv("MANIPULAPY_HIP_LEAD_FUSED"); return !(e && e[0] == '0'); }();
-  static const bool on_given = [] { const char* e = getenv("MANIPULAPY_HIP_LEAD"); return !(e && e[0] == '0'); }();
-  return fused ? on_fused : on_given;
-}
+// A parked float64 pass rides with the next float32 launch of its program (the launch's first workgroups work it off) instead of
+// waiting for a kernel of its own: both specialised kernels host the path - the fused one (two waves per SIMD by design: the float64
+// recursion's registers are free) and the given-rows one (held to its five waves: the carried path spills to scratch, csrc/mp_jit.cpp)
+// - and so does the generic k_id_dm.  (A/B against passes as kernels of their own: profiles/r05_ab_e.txt, r05_ab_g.txt.)
 // the parked pass (given rows, specialised program `fn`) a launch may carry: the oldest; `self` is the launch's own slot
 mp_ctx::HardSlot* pick_rider(mp_ctx* ctx, hipFunction_t fn, const mp_ctx::HardSlot* self, bool generated = false) {
   mp_ctx::HardSlot* best = nullptr;
@@ -590,15 +580,6 @@ int device_big_model(mp_ctx* ctx, const mp_model* model, const MpBigModel<T>** o
                      MP_MAX_DOF, model->d.n);                                                                          \
   } while (0)
 
-// Which generic (no run-time specialisation) float32 inverse-dynamics kernel runs.  Default: one row per lane with the model read
-// from device memory joint by joint (k_id_dm: c2 0.100 ms against 0.119 packed / 0.127 scalar with the model in the kernel
-// arguments, c4 0.213 / 0.221 / 0.281; tools/ab_generic.sh).  MANIPULAPY_HIP_F32 = "packed" | "scalar" selects the two
-// kernel-argument forms (A/B measurements).
-int generic_f32_mode() {
-  static const int mode = [] { const char* e = getenv("MANIPULAPY_HIP_F32"); return (e && (e[0] == 'p' || e[0] == 's')) ? 0 : 2; }();
-  return mode;
-}
-
 // float32 calls on a 9..32-joint model: where the kernels find the float64 model for their ill-conditioned rows (mp_dyn.h,
 // mp_dyn_row_id_f64); float64 calls need nothing
 int big_cold_model(mp_ctx* ctx, const mp_model* model, MpCall<float>* c) {
@@ -634,26 +615,26 @@ int launch_id(mp_ctx* ctx, const mp_model* model, const MpCall<double>& c, bool 
 int launch_id(mp_ctx* ctx, const mp_model* model, const MpCall<float>& c, bool ftip, const float* q, const float* qd,
               const float* qdd, float* tau, long rows) {
   if (model->big) return launch_big_fk_jac_id<float>(ctx, model, c, ftip, q, qd, qdd, nullptr, nullptr, tau, rows);
-  const long pairs = rows / 2;
   if (const MpSpec* sp = find_spec(ctx, model)) {
-    if (spec_scalar_f32(model->d.n)) {  // one row per lane
+    {  // one row per lane in scalar arithmetic (a wave64 v_fma_f32 holds its SIMD for 2 cycles, a packed one for 4: the two-rows-per-lane
+       // form measured 5 - 7.5 % slower and was removed in round 6)
       MpCall<float> cc = c;
       // ill-conditioned rows go to a float64 pass of their own behind the float32 kernels (see attach_hard_list)
-      mp_ctx::HardSlot* hs = sp->id_hard[ftip ? 1 : 0] ? attach_hard_list(ctx, rows, &cc) : nullptr;
+      mp_ctx::HardSlot* hs = attach_hard_list(ctx, rows, &cc);
       auto hard_pass = [&]() -> int {
         if (!hs) return MP_OK;
         hard_defer(ctx, hs, sp->id_hard[ftip ? 1 : 0], nullptr, false, cc, q, qd, qdd, tau, rows, model->d.n);
         return hard_park_or_run(ctx, q, qd, qdd, tau, (size_t)rows * (size_t)model->d.n * sizeof(float), (size_t)rows * (size_t)model->d.n * sizeof(float));
       };
       long done = 0;
-      if (sp->id_co[ftip ? 1 : 0] && rows >= 64 && id_co_enabled()) {  // whole waves: rows moved as whole lines, non-temporal (mp_body_id_co)
+      if (rows >= 64) {  // whole waves: rows moved as whole lines, non-temporal (mp_body_id_co)
         long rows64 = rows & ~63L;
         // One float64 pass that is still parked - an earlier launch's of the same program, none of whose arrays this launch
         // touches (the others were run by hard_flush_if_overlapping on the way in) - rides with this launch: its first workgroups
         // work the list off beside the float32 rows (mp_body_id_lead) instead of a kernel of its own doing so later.
         MpLead lead;
         std::memset(&lead, 0, sizeof lead);
-        mp_ctx::HardSlot* rider = lead_enabled(false) ? pick_rider(ctx, sp->id_hard[ftip ? 1 : 0], hs) : nullptr;
+        mp_ctx::HardSlot* rider = pick_rider(ctx, sp->id_hard[ftip ? 1 : 0], hs);
         if (rider) {
           lead.C = rider->C; lead.q = rider->q; lead.qd = rider->qd; lead.qdd = rider->qdd; lead.tau = rider->tau; lead.rows = rider->nrows;
           lead.blocks = std::min(hard_pass_blocks((long)rider->nrows), 512u);
@@ -665,7 +646,7 @@ int launch_id(mp_ctx* ctx, const mp_model* model, const MpCall<float>& c, bool f
         done = rows64;
       }
       if (done == rows) return hard_pass();
-      const long off = done * model->d.n;  // the last rows (< 64), or everything without the whole-line kernel: per-lane rows
+      const long off = done * model->d.n;  // the last rows (< 64): per-lane rows
       const float *q2 = q + off, *qd2 = qd + off, *qdd2 = qdd + off;
       float* tau2 = tau + off;
       long left = rows - done;
@@ -674,19 +655,8 @@ int launch_id(mp_ctx* ctx, const mp_model* model, const MpCall<float>& c, bool f
       if (int rc = launch_spec(ctx, sp->id_s[ftip ? 1 : 0], left, args)) return rc;
       return hard_pass();
     }
-    if (pairs > 0) {
-      MpCall<float> cc = c;
-      long np = pairs;
-      void* args[] = {&cc, &q, &qd, &qdd, &tau, &np};
-      if (int rc = launch_spec(ctx, sp->id_pk[ftip ? 1 : 0], pairs, args)) return rc;
-    }
-    const long done = 2 * pairs;
-    if (done == rows) return MP_OK;
-    const long off = done * model->d.n;  // odd trailing row: generic one-row kernel
-    HIP_TRY(mpk_id<float>(ctx->compute, model->f, c, ftip, q + off, qd + off, qdd + off, tau + off, rows - done));
-    return MP_OK;
   }
-  if (generic_f32_mode() == 2) {  // one row per lane, device-resident model (a capture's first use uploads it outside the graph)
+  {  // generic: one row per lane, device-resident model (a capture's first use uploads it outside the graph)
     const MpModel<float>* dm = nullptr;
     if (int rc = device_model(ctx, model, &dm)) return rc;
     MpCall<float> cc = c;
@@ -695,11 +665,10 @@ int launch_id(mp_ctx* ctx, const mp_model* model, const MpCall<float>& c, bool f
     MpLead lead;
     std::memset(&lead, 0, sizeof lead);
     mp_ctx::HardSlot* rider = nullptr;
-    if (lead_enabled(false))
-      for (auto& cand : ctx->hp->slot)
-        if (cand.busy && &cand != hs && !cand.fn && cand.gen_dm == dm && cand.gen_n == model->d.n && cand.gen_ftip == ftip && cand.nt == 0 &&
-            cand.C.cold_model && (!rider || cand.seq < rider->seq))
-          rider = &cand;
+    for (auto& cand : ctx->hp->slot)
+      if (cand.busy && &cand != hs && !cand.fn && cand.gen_dm == dm && cand.gen_n == model->d.n && cand.gen_ftip == ftip && cand.nt == 0 &&
+          cand.C.cold_model && (!rider || cand.seq < rider->seq))
+        rider = &cand;
     if (rider) {
       lead.C = rider->C; lead.q = rider->q; lead.qd = rider->qd; lead.qdd = rider->qdd; lead.tau = rider->tau; lead.rows = rider->nrows;
       lead.blocks = std::min((hard_pass_blocks((long)rider->nrows) + 3u) / 4u, 128u);   // 256-lane workgroups
@@ -711,8 +680,6 @@ int launch_id(mp_ctx* ctx, const mp_model* model, const MpCall<float>& c, bool f
     hard_defer(ctx, hs, nullptr, dm, ftip, cc, q, qd, qdd, tau, rows, n);
     return hard_park_or_run(ctx, q, qd, qdd, tau, (size_t)rows * (size_t)n * sizeof(float), (size_t)rows * (size_t)n * sizeof(float));
   }
-  HIP_TRY(mpk_id<float>(ctx->compute, model->f, c, ftip, q, qd, qdd, tau, rows));
-  return MP_OK;
 }
 
 // template bodies shared by the f32 / f64 entry points (C++ linkage)
@@ -1109,6 +1076,8 @@ int mp_ctx_destroy(mp_ctx* ctx) {
   if (ctx->compute) (void)hipStreamDestroy(ctx->compute);
   if (ctx->copy) (void)hipStreamDestroy(ctx->copy);
   if (ctx->copy_out) (void)hipStreamDestroy(ctx->copy_out);
+  if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
+  if (ctx->clock_buf) (void)hipFree(ctx->clock_buf);
   delete ctx;
   return MP_OK;
 }
@@ -1144,6 +1113,7 @@ int mp_ctx_profile(mp_ctx* ctx, double* kernel_ms_total, int64_t* timed_calls, d
 int mp_ctx_get_stream(mp_ctx* ctx, void** hip_stream) {
   REQUIRE(ctx && hip_stream, "mp_ctx_get_stream: null argument");
   CTX_ENTER(ctx);  // (parked float64 passes run first: what the caller enqueues behind this call sees complete results)
+  ctx->stream_exported = true;  // sticky: every later float32 launch enqueues its float64 pass at once, whoever owns its arrays
   *hip_stream = (void*)ctx->compute;
   return MP_OK;
 }
@@ -1243,6 +1213,47 @@ int mp_stream_bandwidth_mix(mp_ctx* ctx, size_t bytes_per_array, int reads, int 
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   if (e != hipSuccess) return set_err(MP_ERR_HIP, "mp_stream_bandwidth_mix: %s", hipGetErrorString(e));
   *gb_per_s = (double)(reads + writes) * (double)nb * (double)reps / ((double)ms * 1e-3) / 1e9;
+  return MP_OK;
+}
+
+// The shader clock the chip holds WHILE the caller's launches run (bench.py: `clock_hz` beside a kernel's time, so that two boxes'
+// figures can be compared at equal clock).  begin: a bounded sampler (k_clock_sampler: 8 one-wave blocks, 32 stamp pairs spread over
+// about duration_ms) starts on a stream of its own; the caller then launches what it wants measured on the compute stream; end: waits
+// for the sampler and returns the median over the blocks of delta s_memtime / delta s_memrealtime x 100 MHz.
+constexpr unsigned kClockBlocks = 8, kClockSamples = 32;
+int mp_clock_sample_begin(mp_ctx* ctx, double duration_ms) {
+  REQUIRE(ctx, "mp_clock_sample_begin: null context");
+  REQUIRE(duration_ms > 0 && duration_ms <= 2000.0, "mp_clock_sample_begin: duration %.3f ms outside (0, 2000]", duration_ms);
+  CTX_ENTER(ctx);
+  REQUIRE(!ctx->capturing, "mp_clock_sample_begin: not while a launch graph is being captured");
+  REQUIRE(!ctx->clock_sampling, "mp_clock_sample_begin: a sampler is already running (call mp_clock_sample_end)");
+  if (!ctx->aux) HIP_TRY(hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
+  if (!ctx->clock_buf) HIP_TRY(hipMalloc((void**)&ctx->clock_buf, (size_t)kClockBlocks * kClockSamples * 2 * sizeof(unsigned long long)));
+  // one nap = 64 x 127 shader cycles, ~3.9 us at 2.1 GHz
+  const unsigned naps = (unsigned)std::max(1.0, duration_ms * 1e3 / ((double)(kClockSamples - 1) * 3.9));
+  HIP_TRY(mpk_clock_sampler(ctx->aux, ctx->clock_buf, kClockBlocks, kClockSamples, naps));
+  ctx->clock_sampling = true;
+  return MP_OK;
+}
+int mp_clock_sample_end(mp_ctx* ctx, double* clock_hz, double* sampled_ms) {
+  REQUIRE(ctx && clock_hz, "mp_clock_sample_end: null argument");
+  CTX_ENTER(ctx);
+  REQUIRE(ctx->clock_sampling, "mp_clock_sample_end: no sampler running");
+  ctx->clock_sampling = false;
+  std::vector<unsigned long long> h((size_t)kClockBlocks * kClockSamples * 2);
+  HIP_TRY(hipMemcpyAsync(h.data(), ctx->clock_buf, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->aux));
+  HIP_TRY(hipStreamSynchronize(ctx->aux));
+  std::vector<double> hz;
+  double span = 0;
+  for (unsigned b = 0; b < kClockBlocks; ++b) {
+    const unsigned long long* o = h.data() + (size_t)b * kClockSamples * 2;
+    const double cyc = (double)(o[2 * (kClockSamples - 1)] - o[0]), ref = (double)(o[2 * (kClockSamples - 1) + 1] - o[1]);
+    if (ref > 0) { hz.push_back(cyc / ref * 1e8); span = std::max(span, ref / 1e5); }
+  }
+  REQUIRE(!hz.empty(), "mp_clock_sample_end: the sampler recorded nothing");
+  std::sort(hz.begin(), hz.end());
+  *clock_hz = hz[hz.size() / 2];
+  if (sampled_ms) *sampled_ms = span;
   return MP_OK;
 }
 
@@ -1571,7 +1582,8 @@ int mp_model_params(const mp_model* model, double* out) {
 int mp_model_specialize_source(const mp_model* model, char* buf, size_t* len) {
   REQUIRE(model && len, "mp_model_specialize_source: null argument");
   REQUIRE_SMALL("mp_model_specialize_source");
-  const std::string src = mp_jit_source(model->f, model->d);
+  // both translation units, the second behind a separator line (they are compiled separately: csrc/mp_jit.cpp)
+  const std::string src = mp_jit_source(model->f, model->d) + "\n// ==== second program (max-ILP scheduling strategy) ====\n" + mp_jit_source(model->f, model->d, 1);
   if (buf) {
     REQUIRE(*len >= src.size() + 1, "mp_model_specialize_source: buffer too small");
     std::memcpy(buf, src.c_str(), src.size() + 1);
@@ -1586,11 +1598,12 @@ int mp_model_specialize_compile(const mp_model* model, size_t* code_bytes, int* 
   std::string err;
   bool cached = false;
   if (mp_jit_compile(model->f, model->d, &code, &cached, &err)) return set_err(MP_ERR_UNSUPPORTED, "mp_model_specialize_compile: %s", err.c_str());
-  {  // warm the cache of the second program too (best effort, like its use in mp_model_specialize)
-    const char* e = getenv("MANIPULAPY_HIP_ILP_PART");
+  {  // the second program (the one-row float32 inverse dynamics under the max-ILP scheduling strategy): both are needed
     std::vector<char> code2;
-    std::string err2;
-    if (!(e && e[0] == '0')) (void)mp_jit_compile(model->f, model->d, &code2, nullptr, &err2, 1);
+    bool cached2 = false;
+    if (mp_jit_compile(model->f, model->d, &code2, &cached2, &err, 1)) return set_err(MP_ERR_UNSUPPORTED, "mp_model_specialize_compile: %s", err.c_str());
+    code.insert(code.end(), code2.begin(), code2.end());   // (the size reported is both programs')
+    cached = cached && cached2;
   }
   if (code_bytes) *code_bytes = code.size();
   if (from_cache) *from_cache = cached ? 1 : 0;
@@ -1612,15 +1625,14 @@ int mp_model_specialize(mp_ctx* ctx, const mp_model* model) {
   if (mp_jit_compile(model->f, model->d, &code, nullptr, &err)) return set_err(MP_ERR_UNSUPPORTED, "mp_model_specialize: %s", err.c_str());
   MpSpec sp;
   HIP_TRY(hipModuleLoadData(&sp.mod, code.data()));
-  const char* names[10][2] = {{"mp_spec_id_pk_f0", "mp_spec_id_pk_f1"}, {"mp_spec_traj_id_pk_f0", "mp_spec_traj_id_pk_f1"},
-                             {"mp_spec_fd_traj_f0", "mp_spec_fd_traj_f1"}, {"mp_spec_id_d_f0", "mp_spec_id_d_f1"},
-                             {"mp_spec_fk_jac_id_d_f0", "mp_spec_fk_jac_id_d_f1"},
-                             {"mp_spec_fd_s_f0", "mp_spec_fd_s_f1"}, {"mp_spec_fd_d_f0", "mp_spec_fd_d_f1"},
-                             {"mp_spec_id_s_f0", "mp_spec_id_s_f1"}, {"mp_spec_traj_id_s_f0", "mp_spec_traj_id_s_f1"},
-                             {"mp_spec_fd_traj_tm_f0", "mp_spec_fd_traj_tm_f1"}};
-  hipFunction_t* slots[10] = {sp.id_pk, sp.traj_id_pk, sp.fd_traj, sp.id_d, sp.fk_jac_id_d, sp.fd_s, sp.fd_d, sp.id_s, sp.traj_id_s,
-                              sp.fd_traj_tm};
-  for (int k = 0; k < 10; ++k)
+  // every kernel of the two programs is required: a program that lacks one is refused and the generic kernels serve
+  const char* names[9][2] = {{"mp_spec_traj_id_pk_f0", "mp_spec_traj_id_pk_f1"}, {"mp_spec_fd_traj_f0", "mp_spec_fd_traj_f1"},
+                            {"mp_spec_id_d_f0", "mp_spec_id_d_f1"}, {"mp_spec_fk_jac_id_d_f0", "mp_spec_fk_jac_id_d_f1"},
+                            {"mp_spec_fd_s_f0", "mp_spec_fd_s_f1"}, {"mp_spec_fd_d_f0", "mp_spec_fd_d_f1"},
+                            {"mp_spec_fd_traj_tm_f0", "mp_spec_fd_traj_tm_f1"}, {"mp_spec_id_hard_f0", "mp_spec_id_hard_f1"},
+                            {"mp_spec_traj_id_hard_f0", "mp_spec_traj_id_hard_f1"}};
+  hipFunction_t* slots[9] = {sp.traj_id_pk, sp.fd_traj, sp.id_d, sp.fk_jac_id_d, sp.fd_s, sp.fd_d, sp.fd_traj_tm, sp.id_hard, sp.traj_id_hard};
+  for (int k = 0; k < 9; ++k)
     for (int f = 0; f < 2; ++f) {
       hipError_t e = hipModuleGetFunction(&slots[k][f], sp.mod, names[k][f]);
       if (e != hipSuccess) { (void)hipModuleUnload(sp.mod); return hip_err(e, names[k][f]); }
@@ -1629,59 +1641,47 @@ int mp_model_specialize(mp_ctx* ctx, const mp_model* model) {
     hipError_t e = hipModuleGetFunction(&sp.ik, sp.mod, "mp_spec_ik");
     if (e != hipSuccess) { (void)hipModuleUnload(sp.mod); return hip_err(e, "mp_spec_ik"); }
   }
-  if (hipModuleGetFunction(&sp.id_co[0], sp.mod, "mp_spec_id_co_f0") != hipSuccess ||
-      hipModuleGetFunction(&sp.id_co[1], sp.mod, "mp_spec_id_co_f1") != hipSuccess)
-    sp.id_co[0] = sp.id_co[1] = nullptr;
-  if (hipModuleGetFunction(&sp.traj_id_co[0], sp.mod, "mp_spec_traj_id_co_f0") != hipSuccess ||
-      hipModuleGetFunction(&sp.traj_id_co[1], sp.mod, "mp_spec_traj_id_co_f1") != hipSuccess)
-    sp.traj_id_co[0] = sp.traj_id_co[1] = nullptr;
-  if (hipModuleGetFunction(&sp.id_hard[0], sp.mod, "mp_spec_id_hard_f0") != hipSuccess ||
-      hipModuleGetFunction(&sp.id_hard[1], sp.mod, "mp_spec_id_hard_f1") != hipSuccess)
-    sp.id_hard[0] = sp.id_hard[1] = nullptr;
-  if (hipModuleGetFunction(&sp.traj_id_hard[0], sp.mod, "mp_spec_traj_id_hard_f0") != hipSuccess ||
-      hipModuleGetFunction(&sp.traj_id_hard[1], sp.mod, "mp_spec_traj_id_hard_f1") != hipSuccess)
-    sp.traj_id_hard[0] = sp.traj_id_hard[1] = nullptr;
-  // the second program: same kernels, other scheduling strategy; anything that goes wrong here leaves the first program's
-  // versions in place (MANIPULAPY_HIP_ILP_PART=0 skips it)
+  // The second program: the float32 inverse dynamics, one row per lane - mp_spec_id_co (whole waves, rows as whole lines) and
+  // mp_spec_id_s (the last < 64 rows) - compiled with LLVM's max-ILP scheduling strategy (c2 0.0704 -> 0.0695 ms, c4 0.1417 -> 0.1411;
+  // as a flag for the whole program it costs the float64 and fused kernels as much as it gives: profiles/r02_d_c5_experiments.txt)
   {
-    const char* e = getenv("MANIPULAPY_HIP_ILP_PART");
-    if (!(e && e[0] == '0')) {
-      std::vector<char> code2;
-      std::string err2;
-      hipModule_t m2 = nullptr;
-      if (mp_jit_compile(model->f, model->d, &code2, nullptr, &err2, 1) == 0 && hipModuleLoadData(&m2, code2.data()) == hipSuccess) {
-        hipFunction_t f0 = nullptr, f1 = nullptr;
-        if (hipModuleGetFunction(&f0, m2, "mp_spec_id_s_f0") == hipSuccess && hipModuleGetFunction(&f1, m2, "mp_spec_id_s_f1") == hipSuccess) {
-          sp.mod_ilp = m2; sp.id_s[0] = f0; sp.id_s[1] = f1;
-          hipFunction_t c0 = nullptr, c1 = nullptr;
-          if (hipModuleGetFunction(&c0, m2, "mp_spec_id_co_f0") == hipSuccess && hipModuleGetFunction(&c1, m2, "mp_spec_id_co_f1") == hipSuccess) {
-            sp.id_co[0] = c0; sp.id_co[1] = c1;
-          }
-        } else {
-          (void)hipModuleUnload(m2);
-        }
-      }
+    std::vector<char> code2;
+    hipModule_t m2 = nullptr;
+    if (mp_jit_compile(model->f, model->d, &code2, nullptr, &err, 1)) {
+      (void)hipModuleUnload(sp.mod);
+      return set_err(MP_ERR_UNSUPPORTED, "mp_model_specialize: %s", err.c_str());
     }
+    hipError_t e = hipModuleLoadData(&m2, code2.data());
+    if (e != hipSuccess) { (void)hipModuleUnload(sp.mod); return hip_err(e, "hipModuleLoadData (second program)"); }
+    const char* names2[2][2] = {{"mp_spec_id_s_f0", "mp_spec_id_s_f1"}, {"mp_spec_id_co_f0", "mp_spec_id_co_f1"}};
+    hipFunction_t* slots2[2] = {sp.id_s, sp.id_co};
+    for (int k = 0; k < 2; ++k)
+      for (int f = 0; f < 2; ++f) {
+        e = hipModuleGetFunction(&slots2[k][f], m2, names2[k][f]);
+        if (e != hipSuccess) { (void)hipModuleUnload(m2); (void)hipModuleUnload(sp.mod); return hip_err(e, names2[k][f]); }
+      }
+    sp.mod_ilp = m2;
   }
   // Self-check of THIS code object's non-finite guard.  The specialised kernels are built with -ffinite-math-only; their guard
   // works on bit patterns (csrc/mp_core.h) and today's compiler leaves it alone, but that flag would let a future one fold it.
-  // A row with a NaN and a row with an infinity must come back NaN and their neighbours finite - from the one-row, the
-  // two-row and the float64 kernel - or the code object is refused and the generic kernels (built without the flag) serve.
+  // A row with a NaN and a row with an infinity must come back NaN and their neighbours finite - from the per-lane float32 kernel,
+  // the whole-line one (whose finite rows must carry the per-lane kernel's bits) and the float64 kernel - or the code object is
+  // refused and the generic kernels (built without the flag) serve.
   {
     const int n = model->d.n;
-    const long rows = 128, pairs = rows / 2;
-    std::vector<float> h((size_t)rows * n, 0.25f), out((size_t)rows * n * 3, 0.0f);
+    const long rows = 128;
+    std::vector<float> h((size_t)rows * n, 0.25f), out((size_t)rows * n * 2, 0.0f);
     std::vector<double> hd((size_t)rows * n, 0.25), outd((size_t)rows * n, 0.0);
     h[3 * n] = __builtin_nanf(""); h[(size_t)70 * n + (n > 1 ? 1 : 0)] = __builtin_inff();
     hd[3 * n] = __builtin_nan(""); hd[(size_t)70 * n + (n > 1 ? 1 : 0)] = -__builtin_inf();
     const size_t fb = h.size() * sizeof(float), db = hd.size() * sizeof(double);
     Scratch sc(ctx);
-    void *dq, *dz, *d0, *d1, *dqd, *dzd, *d2, *d3;
-    auto unload = [&] { if (sp.mod_ilp) (void)hipModuleUnload(sp.mod_ilp); (void)hipModuleUnload(sp.mod); };
+    void *dq, *dz, *d0, *d1, *dqd, *dzd, *d2;
+    auto unload = [&] { (void)hipModuleUnload(sp.mod_ilp); (void)hipModuleUnload(sp.mod); };
     {  // an allocation that fails (out of memory, an open graph capture) must not leak the two code objects loaded above
-      void** slot[8] = {&d3, &dq, &dz, &d0, &d1, &dqd, &dzd, &d2};
-      for (int k = 0; k < 8; ++k)
-        if (int rc = sc.get(k < 5 ? fb : db, slot[k])) { unload(); return rc; }
+      void** slot[7] = {&dq, &dz, &d0, &d1, &dqd, &dzd, &d2};
+      for (int k = 0; k < 7; ++k)
+        if (int rc = sc.get(k < 4 ? fb : db, slot[k])) { unload(); return rc; }
     }
     hipError_t he = hipMemcpyAsync(dq, h.data(), fb, hipMemcpyHostToDevice, ctx->compute);
     if (he == hipSuccess) he = hipMemsetAsync(dz, 0, fb, ctx->compute);
@@ -1692,38 +1692,33 @@ int mp_model_specialize(mp_ctx* ctx, const mp_model* model) {
     MpCall<double> cd;
     make_call<float>(model, nullptr, nullptr, &cf);
     make_call<double>(model, nullptr, nullptr, &cd);
-    long nr = rows, np_ = pairs;
+    long nr = rows;
     const float *q = (const float*)dq, *z = (const float*)dz;
     float *o0 = (float*)d0, *o1 = (float*)d1;
     const double *qd_ = (const double*)dqd, *zd = (const double*)dzd;
     double* o2 = (double*)d2;
-    void* a0[] = {&cf, &q, &z, &z, &o0, &nr};
-    void* a1[] = {&cf, &q, &z, &z, &o1, &np_};
-    void* a2[] = {&cd, &qd_, &zd, &zd, &o2, &nr};
-    float* o3 = (float*)d3;
     MpLead no_lead;
     std::memset(&no_lead, 0, sizeof no_lead);
-    void* a3[] = {&cf, &q, &z, &z, &o3, &nr, &no_lead};
+    void* a0[] = {&cf, &q, &z, &z, &o0, &nr};
+    void* a1[] = {&cf, &q, &z, &z, &o1, &nr, &no_lead};
+    void* a2[] = {&cd, &qd_, &zd, &zd, &o2, &nr};
     int rc = launch_spec(ctx, sp.id_s[0], rows, a0);
-    if (!rc) rc = launch_spec(ctx, sp.id_pk[0], pairs, a1);
+    if (!rc) rc = launch_spec(ctx, sp.id_co[0], rows, a1, MP_JIT_ID_CO_BLOCK);
     if (!rc) rc = launch_spec(ctx, sp.id_d[0], rows, a2);
-    if (!rc && sp.id_co[0]) rc = launch_spec(ctx, sp.id_co[0], rows, a3, MP_JIT_ID_CO_BLOCK);
     if (rc) { unload(); return rc; }
     he = hipMemcpyAsync(out.data(), d0, fb, hipMemcpyDeviceToHost, ctx->compute);
     if (he == hipSuccess) he = hipMemcpyAsync(out.data() + h.size(), d1, fb, hipMemcpyDeviceToHost, ctx->compute);
-    if (he == hipSuccess && sp.id_co[0]) he = hipMemcpyAsync(out.data() + 2 * h.size(), d3, fb, hipMemcpyDeviceToHost, ctx->compute);
     if (he == hipSuccess) he = hipMemcpyAsync(outd.data(), d2, db, hipMemcpyDeviceToHost, ctx->compute);
     if (he == hipSuccess) he = hipStreamSynchronize(ctx->compute);
     if (he != hipSuccess) { unload(); return hip_err(he, "mp_model_specialize: self-check download"); }
     bool ok = true;
-    for (int k = 0; k < 4 && ok; ++k) {  // 0: one row per lane, 1: two rows per lane, 2: float64, 3: whole-line row movement
-      if (k == 3 && !sp.id_co[0]) break;
+    for (int k = 0; k < 3 && ok; ++k) {  // 0: one row per lane, 1: whole-line row movement, 2: float64
       for (long r : {3L, 70L, 4L, 69L, 0L, 127L}) {
         const bool want_nan = r == 3 || r == 70;
         for (int j = 0; j < n; ++j) {
-          const double v = k == 2 ? outd[(size_t)r * n + j] : (double)out[(size_t)(k == 3 ? 2 : k) * h.size() + (size_t)r * n + j];
+          const double v = k == 2 ? outd[(size_t)r * n + j] : (double)out[(size_t)k * h.size() + (size_t)r * n + j];
           if ((v != v) != want_nan) ok = false;
-          if (k == 3 && !want_nan && out[2 * h.size() + (size_t)r * n + j] != out[(size_t)r * n + j]) ok = false;  // = the per-lane kernel's bits
+          if (k == 1 && !want_nan && out[h.size() + (size_t)r * n + j] != out[(size_t)r * n + j]) ok = false;  // = the per-lane kernel's bits
         }
       }
     }
@@ -1816,10 +1811,6 @@ int mp_traj_id_fused_f32(mp_ctx* ctx, const mp_model* model, const float* d_star
     HIP_TRY(mpk_dyn_traj(ctx->compute, model->d.n, dm, c, ftip, d_start, d_end, (long)B, (long)N, Tf, method, nullptr, nullptr, nullptr, d_tau));
     return MP_OK;
   }
-  if (!mpk_packed_f32() && !find_spec(ctx, model)) {  // MANIPULAPY_HIP_F32=scalar, generic: one row per lane, time scaling per row
-    HIP_TRY(mpk_traj_id(ctx->compute, model->f, c, ftip, d_start, d_end, (long)B, (long)N, Tf, method, d_tau));
-    return MP_OK;
-  }
   // per-timestep table of (s, s', s''): rebuilt on the stream only when (N, Tf, method) differ from the last call
   if (ctx->tab_cap < (long)N) {
     REQUIRE(!ctx->capturing, "mp_traj_id_fused_f32: the first call for this N allocates; run it once before capturing a launch graph");
@@ -1843,35 +1834,13 @@ int mp_traj_id_fused_f32(mp_ctx* ctx, const mp_model* model, const float* d_star
   if (const MpSpec* sp = find_spec(ctx, model)) {
     long nt = (long)N;
     const double* tab = ctx->time_tab;
-    // MANIPULAPY_HIP_TRAJ_CO=1 (experiment switch): flat rows, one timestep per lane in scalar arithmetic, tau as whole lines
-    // (csrc/mp_bodies.h, mp_body_traj_id_co).  It writes exactly the algorithmic bytes (the packed form 1.036 x) and is SLOWER:
-    // the kernel is bound by instruction issue, 719 VALU per row of which 48 float64-rate = 1486 issue cycles per row against
-    // 1334 per row for the packed pair (803 per pair: 447 packed + 84 float64-rate at 4 cycles, 272 at 2) - c2f 0.0553-0.0571 ms
-    // against 0.0533 on one box without the conditioning test, 0.0628 against 0.0575 with it (profiles/r04_c2f_ab.txt)
-    static const bool traj_co = getenv("MANIPULAPY_HIP_TRAJ_CO") && getenv("MANIPULAPY_HIP_TRAJ_CO")[0] == '1';
-    if (traj_co && sp->traj_id_co[ftip ? 1 : 0] && N >= 64 && (unsigned long long)B * (unsigned long long)N < 0xffffffc0ull) {
-      unsigned rows = (unsigned)((unsigned long long)B * (unsigned long long)N), ntu = (unsigned)N;
-      unsigned magic = (unsigned)(0x100000000ull / (unsigned long long)N);
-      mp_ctx::HardSlot* hs = sp->traj_id_hard[ftip ? 1 : 0] ? attach_hard_list(ctx, (long)rows, &c) : nullptr;
-      void* args[] = {&c, &d_start, &d_end, &ntu, &magic, &tab, &d_tau, &rows};
-      if (int rc = launch_spec(ctx, sp->traj_id_co[ftip ? 1 : 0], (long)rows, args, 64)) return rc;
-      if (!hs) return MP_OK;
-      hard_defer_generated(ctx, hs, sp->traj_id_hard[ftip ? 1 : 0], c, d_start, d_end, tab, d_tau, (long)rows, model->d.n, (long)B, ntu);
-      if (ctx->tab_volatile) return hard_flush(ctx);  // (a table rewritten by every call cannot wait for a parked pass)
-      return hard_park_or_run(ctx, d_start, d_end, nullptr, d_tau, (size_t)rows * (size_t)model->d.n * sizeof(float), (size_t)B * (size_t)model->d.n * sizeof(float));
-    }
-    if (!mpk_packed_f32()) {  // MANIPULAPY_HIP_F32=scalar: one timestep per lane (measured slower: c2f 0.063 vs 0.054 ms)
-      unsigned bpt = (unsigned)((nt + 255) / 256);
-      void* args[] = {&c, &d_start, &d_end, &nt, &bpt, &tab, &d_tau};
-      return launch_spec(ctx, sp->traj_id_s[ftip ? 1 : 0], (long)B * bpt * 256, args);
-    }
     unsigned bpt = mpk_traj_blocks_per_trajectory(nt);
     const long rows_l = (long)B * (long)N;
-    mp_ctx::HardSlot* hs = sp->traj_id_hard[ftip ? 1 : 0] ? attach_hard_list(ctx, rows_l, &c) : nullptr;
+    mp_ctx::HardSlot* hs = attach_hard_list(ctx, rows_l, &c);
     // (as launch_id: one parked pass of an earlier fused launch of this program rides with this launch's first workgroups)
     MpLead lead;
     std::memset(&lead, 0, sizeof lead);
-    mp_ctx::HardSlot* rider = lead_enabled(true) && !ctx->tab_volatile ? pick_rider(ctx, sp->traj_id_hard[ftip ? 1 : 0], hs, true) : nullptr;
+    mp_ctx::HardSlot* rider = !ctx->tab_volatile ? pick_rider(ctx, sp->traj_id_hard[ftip ? 1 : 0], hs, true) : nullptr;
     if (rider) {
       lead.C = rider->C; lead.q = rider->q; lead.qd = rider->qd; lead.qdd = rider->qdd; lead.tau = rider->tau; lead.rows = rider->nrows;
       lead.nt = rider->nt;
@@ -1887,8 +1856,7 @@ int mp_traj_id_fused_f32(mp_ctx* ctx, const mp_model* model, const float* d_star
     // the generated rows' float64 pass is parked like a given-rows launch's; it reads the time table, so a call that rewrites the
     // table runs the parked passes first (above)
     hard_defer_generated(ctx, hs, sp->traj_id_hard[ftip ? 1 : 0], c, d_start, d_end, tab, d_tau, rows_l, model->d.n, (long)B, (unsigned)N);
-    static const bool park = !(getenv("MANIPULAPY_HIP_FUSED_PARK") && getenv("MANIPULAPY_HIP_FUSED_PARK")[0] == '0');  // experiment switch
-    if (ctx->tab_volatile || !park) return hard_flush(ctx);  // (a table rewritten by every call cannot wait for a parked pass)
+    if (ctx->tab_volatile) return hard_flush(ctx);  // (a table rewritten by every call cannot wait for a parked pass)
     return hard_park_or_run(ctx, d_start, d_end, nullptr, d_tau, (size_t)rows_l * (size_t)model->d.n * sizeof(float), (size_t)B * (size_t)model->d.n * sizeof(float));
   }
   {

@@ -64,14 +64,10 @@ template <> struct MpTraits<mp_f2> {
 // float: Cody-Waite reduction by pi/2 (two FMAs, exact enough for |x| < ~1e4) + the classic minimax
 // polynomials on [-pi/4, pi/4]; ~1 ulp, branch-free, ~24 VALU instructions for BOTH results.
 MP_HD void mp_sincos(float x, float& s, float& c) {
-#if !defined(MP_SINCOS_RNDNE)
   // x * 2/pi rounded to an integer by adding 1.5 * 2^23 inside the FMA: the sum's low mantissa bits ARE the quadrant (|x| < 6e6),
   // one instruction less than multiply + v_rndne + v_cvt (round 4: c2 -1.6 %, c5 -0.5 %, profiles/r04_ab_sincos_signs.txt)
   const float kf = fmaf(x, 0.636619772367581343f, 12582912.0f);
   const float k = kf - 12582912.0f;
-#else   // A/B switch: as until round 4
-  const float k = rintf(x * 0.636619772367581343f);
-#endif
   float r = fmaf(-k, 1.57079637050628662109375f, x);
   r = fmaf(-k, -4.37113900018624283e-8f, r);
   const float r2 = r * r;
@@ -81,22 +77,13 @@ MP_HD void mp_sincos(float x, float& s, float& c) {
   float pc = fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
   pc = fmaf(r2, pc, 4.166664568298827e-2f);
   pc = fmaf(r2 * r2, pc, fmaf(r2, -0.5f, 1.0f));
-#if !defined(MP_SINCOS_RNDNE)
   const int q = __builtin_bit_cast(int, kf);
-#else
-  const int q = (int)k;
-#endif
   const float a = (q & 1) ? pc : ps;
   const float b = (q & 1) ? ps : pc;
-#if defined(MP_SINCOS_SELECT_SIGNS)   // A/B switch: the signs by compare + select, as until round 4 (same bits, one instruction more)
-  s = (q & 2) ? -a : a;
-  c = ((q + 1) & 2) ? -b : b;
-#else
   // the signs straight from the quadrant's bits: bit 1 of q (sine) and of q + 1 (cosine) moved to bit 31 and XORed in
   const unsigned qs = (unsigned)q << 30;
   s = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, a) ^ (qs & 0x80000000u));
   c = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, b) ^ ((qs + 0x40000000u) & 0x80000000u));
-#endif
 }
 // double: the same structure in float64 - reduction by pi/2 carried in three FMAs (pi/2 split in a 53-bit head and two
 // tails; inside an FMA the product k * head is exact, so x - k pi/2 keeps full accuracy for every |x| whose own
@@ -125,24 +112,15 @@ MP_HD void mp_sincos(double x, double& s, double& c) {
   const int q = (int)(k - 4.0 * floor(k * 0.25));  // k mod 4 in {0, 1, 2, 3}
   const double a = (q & 1) ? pc : ps;
   const double b = (q & 1) ? ps : pc;
-#if defined(MP_SINCOS_SELECT_SIGNS)
-  s = (q & 2) ? -a : a;
-  c = ((q + 1) & 2) ? -b : b;
-#else
   const unsigned qs = (unsigned)q << 30;  // (as the float routine: the signs from the quadrant's bits)
   s = __builtin_bit_cast(double, __builtin_bit_cast(unsigned long long, a) ^ ((unsigned long long)(qs & 0x80000000u) << 32));
   c = __builtin_bit_cast(double, __builtin_bit_cast(unsigned long long, b) ^ ((unsigned long long)((qs + 0x40000000u) & 0x80000000u) << 32));
-#endif
 }
 #if MP_HAS_PACKED
 // the same algorithm on two rows at once (packed FMAs; rint / cvt / selects stay per component)
 MP_HD void mp_sincos(mp_f2 x, mp_f2& s, mp_f2& c) {
-#if !defined(MP_SINCOS_RNDNE)
   const mp_f2 kf = __builtin_elementwise_fma(x, (mp_f2)(0.636619772367581343f), (mp_f2)(12582912.0f));
   const mp_f2 k = kf - 12582912.0f;
-#else
-  const mp_f2 k = __builtin_elementwise_rint(x * 0.636619772367581343f);
-#endif
   mp_f2 r = __builtin_elementwise_fma(-k, (mp_f2)(1.57079637050628662109375f), x);
   r = __builtin_elementwise_fma(-k, (mp_f2)(-4.37113900018624283e-8f), r);
   const mp_f2 r2 = r * r;
@@ -152,22 +130,13 @@ MP_HD void mp_sincos(mp_f2 x, mp_f2& s, mp_f2& c) {
   mp_f2 pc = __builtin_elementwise_fma(r2, (mp_f2)(2.443315711809948e-5f), (mp_f2)(-1.388731625493765e-3f));
   pc = __builtin_elementwise_fma(r2, pc, (mp_f2)(4.166664568298827e-2f));
   pc = __builtin_elementwise_fma(r2 * r2, pc, __builtin_elementwise_fma(r2, (mp_f2)(-0.5f), (mp_f2)(1.0f)));
-#if !defined(MP_SINCOS_RNDNE)
   const mp_i2 q = __builtin_bit_cast(mp_i2, kf);
-#else
-  const mp_i2 q = __builtin_convertvector(k, mp_i2);
-#endif
   const mp_i2 odd = (q & 1) != 0;
   const mp_f2 a = odd ? pc : ps;
   const mp_f2 b = odd ? ps : pc;
-#if defined(MP_SINCOS_SELECT_SIGNS)
-  s = ((q & 2) != 0) ? -a : a;
-  c = (((q + 1) & 2) != 0) ? -b : b;
-#else
   const mp_u2 qs = __builtin_bit_cast(mp_u2, q) << 30;  // (as the scalar routine: the signs from the quadrant's bits)
   s = __builtin_bit_cast(mp_f2, __builtin_bit_cast(mp_u2, a) ^ (qs & 0x80000000u));
   c = __builtin_bit_cast(mp_f2, __builtin_bit_cast(mp_u2, b) ^ ((qs + 0x40000000u) & 0x80000000u));
-#endif
 }
 #endif
 

@@ -7,8 +7,9 @@
 hipError_t mpk_selftest(hipStream_t s, int* d_out /* 64 ints */);
 hipError_t mpk_stream(hipStream_t s, int reads, bool nontemporal, const void* a, const void* b, const void* c, void* d, long n4);
 hipError_t mpk_stream_mix(hipStream_t s, int reads, int writes, bool nontemporal, const void* a, void* d, long n4);
+hipError_t mpk_clock_sampler(hipStream_t s, unsigned long long* out, unsigned blocks, unsigned samples, unsigned naps);
 
-template <typename T>
+template <typename T>   // (float64 only: float32 rows take mpk_id_dm)
 hipError_t mpk_id(hipStream_t s, const MpModel<T>& M, const MpCall<T>& C, bool ftip, const T* q, const T* qd,
                   const T* qdd, T* tau, long rows);
 
@@ -23,9 +24,6 @@ hipError_t mpk_id_hard_batch(hipStream_t s, const MpModel<float>* d_model, int n
 
 hipError_t mpk_batch_traj(hipStream_t s, const MpModel<float>& M, const float* start, const float* end, long B,
                           long Nt, double Tf, int method, float* pos, float* vel, float* acc);
-
-hipError_t mpk_traj_id(hipStream_t s, const MpModel<float>& M, const MpCall<float>& C, bool ftip, const float* start,
-                       const float* end, long B, long Nt, double Tf, int method, float* tau);
 
 template <typename T>
 hipError_t mpk_fk_jac_id(hipStream_t s, const MpModel<T>& M, const MpCall<T>& C, bool ftip, const T* q, const T* qd,
@@ -93,7 +91,6 @@ hipError_t mpk_dyn_ik(hipStream_t s, int n, const MpBigModel<double>* d_model, c
 
 // table-driven fused generation + ID (float32): `tab` = 3 doubles per timestep written by mpk_time_table for the same
 // (Nt, Tf, method); one lane takes timesteps t and t + ceil(Nt / 2) of one trajectory
-bool mpk_packed_f32();  // false under MANIPULAPY_HIP_F32=scalar
 hipError_t mpk_time_table(hipStream_t s, double* tab, long Nt, double Tf, int method);
 unsigned mpk_traj_blocks_per_trajectory(long Nt);
 // the float64 pass over the rows the fused generic kernel handed over (inputs regenerated)

@@ -18,12 +18,7 @@
 namespace {
 
 constexpr int kBlock = 256;
-#ifndef MP_PK_BLOCK
-#define MP_PK_BLOCK 256  // threads per block of the packed kernels (no LDS / barriers: any multiple of 64 works)
-#endif
-#ifndef MP_PK_MINW
-#define MP_PK_MINW 2  // min waves per SIMD requested for the packed kernels (register cap = 512 / MINW)
-#endif
+constexpr int kPkMinWaves = 2;  // waves per SIMD asked for by the packed (two rows per lane) fused kernel: register cap = 512 / 2
 
 // ------------------------------------------------------------------------------------- probe
 __global__ void k_selftest(int* out) { out[threadIdx.x] = (int)threadIdx.x; }
@@ -154,55 +149,9 @@ __global__ __launch_bounds__(kBlock) void k_batch_traj(const MpModel<float> M, c
   }
 }
 
-template <int N, bool HAS_FTIP>
-__global__ __launch_bounds__(kBlock) void k_traj_id(const MpModel<float> M, const MpCall<float> C,
-                                                    const float* __restrict__ start, const float* __restrict__ end,
-                                                    long row0, long rows, long Nt, double Tf, int method,
-                                                    float* __restrict__ tau) {
-  MP_COLD_BUFFER(N, kBlock, 4);
-  const long r = row0 + (long)blockIdx.x * kBlock + threadIdx.x;
-  if (r >= rows) return;
-  const long b = r / Nt, t = r - b * Nt;
-  float p[N], v[N], a[N], tq[N];
-  traj_row<N>(M, start, end, b, t, Nt, Tf, method, p, v, a);
-  MpJointState<float, N> js;
-  mp_joint_state<float, N>(M, p, js);
-  MpBad<float> bad;
-  bad.add(p); bad.add(v); bad.add(a);
-  const bool hard = mp_rnea_f32<N, HAS_FTIP>(M, C, js, v, a, tq) && !bad.any();
-  mp_cold_rows<N, HAS_FTIP, MP_COLD_G>(M, C, hard, -1L, MP_COLD_PTR, [&](float (&x)[N], float (&y)[N], float (&z)[N]) {
-#pragma unroll
-    for (int j = 0; j < N; ++j) { x[j] = p[j]; y[j] = v[j]; z[j] = a[j]; }
-  }, tq);
-#pragma unroll
-  for (int j = 0; j < N; ++j) tq[j] = mp_clip(tq[j], M.taumin[j], M.taumax[j]);
-  mp_poison_if(bad.any(), tq);
-  RunIO<float, N>::store(tau, r, tq);
-}
-
-// ------------------------------------------------- float32, two rows per lane (packed v_pk_* math)
-// Lane t owns rows 2t and 2t+1 — one contiguous 2*N*4-byte run per array, so the loads/stores are
-// also twice as wide per lane.  A lane's two rows are `p` and `p + pairs` (the two halves of the batch), so each half is
-// streamed in one-row-per-lane runs.  The launcher sends an odd trailing row to the one-row-per-lane kernel.
-template <int N, bool HAS_FTIP>
-__global__ __launch_bounds__(MP_PK_BLOCK, MP_PK_MINW) void k_id_pk(const MpModel<float> M, const MpCall<float> C,
-                                                     const float* __restrict__ q, const float* __restrict__ qd,
-                                                     const float* __restrict__ qdd, float* __restrict__ tau, long pairs) {
-  MP_COLD_BUFFER(N, MP_PK_BLOCK, 4);
-  const long p = (long)blockIdx.x * MP_PK_BLOCK + threadIdx.x;
-  if (p >= pairs) return;
-  mp_body_id_pk_split<N, HAS_FTIP>(M, C, q, qd, qdd, tau, p, pairs, MP_COLD_PTR);  // rows p and p + pairs
-}
-
-template <int N, bool HAS_FTIP>
-__global__ __launch_bounds__(kBlock, MP_PK_MINW) void k_traj_id_pk(const MpModel<float> M, const MpCall<float> C,
-                                                          const float* __restrict__ start, const float* __restrict__ end,
-                                                          long pairs, long Nt, double Tf, int method, float* __restrict__ tau) {
-  MP_COLD_BUFFER(N, kBlock, 4);
-  const long p = (long)blockIdx.x * kBlock + threadIdx.x;
-  if (p >= pairs) return;
-  mp_body_traj_id_pk<N, HAS_FTIP>(M, C, start, end, p, Nt, Tf, method, tau, MP_COLD_PTR);
-}
+// (Generic float32 forms removed in round 6, each slower than what is left - the one-row kernel k_id_dm for given rows, the table-driven
+// packed kernel k_traj_id_pk_tab for generated ones: k_id<float> / k_id_pk with the model in the kernel arguments (c2 0.126 / 0.119 ms
+// against 0.100), k_traj_id / k_traj_id_pk with the time scaling per row (0.0577 against 0.0525 specialised); profiles/HISTORY.md.)
 
 // per-call table of the time scaling, three doubles per timestep: exactly traj_row's arithmetic, once per timestep
 // instead of once per row
@@ -216,7 +165,7 @@ __global__ __launch_bounds__(kBlock) void k_time_table(double* __restrict__ tab,
 }
 
 template <int N, bool HAS_FTIP>
-__global__ __launch_bounds__(kBlock, MP_PK_MINW) void k_traj_id_pk_tab(const MpModel<float> M, const MpCall<float> C,
+__global__ __launch_bounds__(kBlock, kPkMinWaves) void k_traj_id_pk_tab(const MpModel<float> M, const MpCall<float> C,
                                                               const float* __restrict__ start, const float* __restrict__ end,
                                                               long Nt, unsigned bpt, const double* __restrict__ tab,
                                                               float* __restrict__ tau) {
@@ -471,15 +420,6 @@ __global__ __launch_bounds__(kBlock) void k_dyn_traj(const MpBigModel<float>* __
 
 inline unsigned grid_for(long rows) { return (unsigned)((rows + kBlock - 1) / kBlock); }
 
-// float32 variant selection (A/B switch for profiling): MANIPULAPY_HIP_F32 = "packed" (default) | "scalar"
-inline bool use_packed_f32() {
-  static const bool packed = [] {
-    const char* e = getenv("MANIPULAPY_HIP_F32");
-    return !(e && e[0] == 's');
-  }();
-  return packed;
-}
-
 #define MP_DISPATCH_N(n, ...)                                   \
   switch (n) {                                                  \
     case 1: { constexpr int N = 1; __VA_ARGS__; } break;        \
@@ -549,32 +489,26 @@ hipError_t mpk_stream_mix(hipStream_t s, int reads, int writes, bool nontemporal
   return hipErrorInvalidValue;
 }
 
-hipError_t mpk_selftest(hipStream_t s, int* d_out) {
-  hipLaunchKernelGGL(k_selftest, dim3(1), dim3(64), 0, s, d_out);
+// Shader-clock sampler for the measurement harness (MI355X_MICROARCH.md, "DVFS give-back" (6): the in-kernel clock is
+// delta s_memtime / delta s_memrealtime x 100 MHz).  One wave per block; lane 0 stamps both counters, naps `naps` x s_sleep 127
+// (64 x 127 cycles each) and stamps again, `samples` times - strictly bounded, nothing to wait for.  It is launched on a stream of its
+// own BESIDE the kernels whose clock is asked for and costs them one wave slot per block; out[block][sample] = {memtime, realtime}.
+__global__ __launch_bounds__(64) void k_clock_sampler(unsigned long long* __restrict__ out, unsigned samples, unsigned naps) {
+  if (threadIdx.x != 0) return;
+  unsigned long long* o = out + (size_t)blockIdx.x * samples * 2;
+  for (unsigned i = 0; i < samples; ++i) {
+    o[2 * i] = __builtin_amdgcn_s_memtime();
+    o[2 * i + 1] = __builtin_amdgcn_s_memrealtime();
+    for (unsigned k = 0; k < naps; ++k) __builtin_amdgcn_s_sleep(127);
+  }
+}
+hipError_t mpk_clock_sampler(hipStream_t s, unsigned long long* out, unsigned blocks, unsigned samples, unsigned naps) {
+  hipLaunchKernelGGL(k_clock_sampler, dim3(blocks), dim3(64), 0, s, out, samples, naps);
   return hipGetLastError();
 }
 
-template <>
-hipError_t mpk_id<float>(hipStream_t s, const MpModel<float>& M, const MpCall<float>& C, bool ftip, const float* q,
-                         const float* qd, const float* qdd, float* tau, long rows) {
-  if (rows <= 0) return hipSuccess;
-  using T = float;
-  long done = 0;
-  if (use_packed_f32() && rows >= 2) {  // two rows per lane; an odd trailing row goes to the scalar kernel
-    const long pairs = rows / 2;
-    MP_DISPATCH_N(M.n, {
-      const unsigned gb = (unsigned)((pairs + MP_PK_BLOCK - 1) / MP_PK_BLOCK);
-      if (ftip) hipLaunchKernelGGL((k_id_pk<N, true>), dim3(gb), dim3(MP_PK_BLOCK), 0, s, M, C, q, qd, qdd, tau, pairs);
-      else hipLaunchKernelGGL((k_id_pk<N, false>), dim3(gb), dim3(MP_PK_BLOCK), 0, s, M, C, q, qd, qdd, tau, pairs);
-    })
-    done = 2 * pairs;
-    if (done == rows) return hipGetLastError();
-  }
-  const long off = done * M.n, rest = rows - done;
-  MP_DISPATCH_N(M.n, {
-    if (ftip) hipLaunchKernelGGL((k_id<T, N, true>), dim3(grid_for(rest)), dim3(kBlock), 0, s, M, C, q + off, qd + off, qdd + off, tau + off, rest);
-    else hipLaunchKernelGGL((k_id<T, N, false>), dim3(grid_for(rest)), dim3(kBlock), 0, s, M, C, q + off, qd + off, qdd + off, tau + off, rest);
-  })
+hipError_t mpk_selftest(hipStream_t s, int* d_out) {
+  hipLaunchKernelGGL(k_selftest, dim3(1), dim3(64), 0, s, d_out);
   return hipGetLastError();
 }
 
@@ -631,8 +565,6 @@ hipError_t mpk_batch_traj(hipStream_t s, const MpModel<float>& M, const float* s
   return hipGetLastError();
 }
 
-bool mpk_packed_f32() { return use_packed_f32(); }
-
 hipError_t mpk_time_table(hipStream_t s, double* tab, long Nt, double Tf, int method) {
   if (Nt <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_time_table, dim3(grid_for(Nt)), dim3(kBlock), 0, s, tab, Nt, Tf, method);
@@ -660,28 +592,6 @@ hipError_t mpk_traj_id_hard(hipStream_t s, const MpModel<float>* d_model, int n,
   MP_DISPATCH_N(n, {
     if (ftip) hipLaunchKernelGGL((k_traj_id_hard<N, true>), dim3(blocks), dim3(64), 0, s, d_model, C, start, end, Nt, tab, tau, rows);
     else hipLaunchKernelGGL((k_traj_id_hard<N, false>), dim3(blocks), dim3(64), 0, s, d_model, C, start, end, Nt, tab, tau, rows);
-  })
-  return hipGetLastError();
-}
-
-hipError_t mpk_traj_id(hipStream_t s, const MpModel<float>& M, const MpCall<float>& C, bool ftip, const float* start,
-                       const float* end, long B, long Nt, double Tf, int method, float* tau) {
-  const long rows = B * Nt;
-  if (rows <= 0) return hipSuccess;
-  long done = 0;
-  if (use_packed_f32() && rows >= 2) {
-    const long pairs = rows / 2;
-    MP_DISPATCH_N(M.n, {
-      if (ftip) hipLaunchKernelGGL((k_traj_id_pk<N, true>), dim3(grid_for(pairs)), dim3(kBlock), 0, s, M, C, start, end, pairs, Nt, Tf, method, tau);
-      else hipLaunchKernelGGL((k_traj_id_pk<N, false>), dim3(grid_for(pairs)), dim3(kBlock), 0, s, M, C, start, end, pairs, Nt, Tf, method, tau);
-    })
-    done = 2 * pairs;
-    if (done == rows) return hipGetLastError();
-  }
-  const long rest = rows - done;
-  MP_DISPATCH_N(M.n, {
-    if (ftip) hipLaunchKernelGGL((k_traj_id<N, true>), dim3(grid_for(rest)), dim3(kBlock), 0, s, M, C, start, end, done, rows, Nt, Tf, method, tau);
-    else hipLaunchKernelGGL((k_traj_id<N, false>), dim3(grid_for(rest)), dim3(kBlock), 0, s, M, C, start, end, done, rows, Nt, Tf, method, tau);
   })
   return hipGetLastError();
 }

@@ -572,58 +572,6 @@ def test_overlapped_chunk_exchange_single_rank(ctx, models, tables):
         b.free()
 
 
-def test_forward_dynamics_trajectory_packed_variant(tables):
-    """MANIPULAPY_HIP_FD=packed (two trajectories per lane, off by default): same results as the default kernels to
-    float32 rounding and as the oracle, generic and specialised, odd batch, partial tiles, with and without wrenches."""
-    import subprocess, sys, textwrap
-
-    code = textwrap.dedent("""
-        import numpy as np, sys, os
-        sys.path.insert(0, %r)
-        import manipulapy_amd as mp
-        from manipulapy_amd import _hip
-        from oracle import ref_numpy as ref
-        tab = ref.load_tables(os.path.join(%r, "manipulapy_amd", "data", "model_xarm6.npz"))
-        ctx = _hip.HipContext(0)
-        gen = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee, tab.joint_limits)
-        spec = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee, tab.joint_limits)
-        ctx.specialize(spec)
-        G0 = np.array([0.0, 0.0, -9.81])
-        B, n = 67, tab.n
-        out = {}
-        for Nt in (1, 3, 4, 9):
-            rng = np.random.default_rng(100 + Nt)
-            th0 = rng.uniform(-0.5, 0.5, (B, n)); dth0 = rng.uniform(-0.2, 0.2, (B, n))
-            tm = rng.uniform(-1, 1, (B, Nt, n)); Fm = rng.uniform(-1, 1, (B, Nt, 6))
-            for w, wrench in enumerate((None, Fm)):
-                a = ctx.fd_trajectory_host(gen, th0, dth0, tm, G0, wrench, 0.01, 2, dtype=np.float32)
-                b = ctx.fd_trajectory_host(spec, th0, dth0, tm, G0, wrench, 0.01, 2, dtype=np.float32)
-                for x, y in zip(a, b):
-                    np.testing.assert_allclose(x, y, rtol=2e-4, atol=2e-4 * max(1.0, float(np.abs(x).max())))
-                for t in (0, 1, B - 1):
-                    o = ref.forward_dynamics_trajectory(tab, th0[t], dth0[t], tm[t], G0, np.zeros((Nt, 6)) if wrench is None else Fm[t],
-                                                        0.01, 2, joint_limits=tab.joint_limits)
-                    for k, name in enumerate(("positions", "velocities", "accelerations")):
-                        np.testing.assert_allclose(a[k][t], o[name], rtol=3e-4, atol=3e-4 * max(1.0, float(np.abs(o[name]).max())))
-                out["%%d_%%d" %% (Nt, w)] = np.stack(a)
-        np.savez(sys.argv[1], **out)
-        print("OK")
-    """ % (ROOT, ROOT))
-    import tempfile
-
-    res = {}
-    with tempfile.TemporaryDirectory() as d:
-        for mode in ("packed", "scalar"):
-            path = os.path.join(d, mode + ".npz")
-            r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, MANIPULAPY_HIP_FD=mode), capture_output=True,
-                               text=True, timeout=900)
-            assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
-            res[mode] = dict(np.load(path))
-    for k in res["packed"]:
-        x, y = res["packed"][k], res["scalar"][k]
-        assert np.abs(x - y).max() <= 2e-4 * max(1.0, float(np.abs(y).max())), k
-
-
 def test_seven_joint_panda_truncation(ctx):
     """"panda7" = the first seven joints of the reference's 8-joint Panda tables (the 7-DOF reading of BASELINE configs[3]):
     generic and specialised kernels against the oracle on the truncated tables, fp64 and fp32, with a wrench."""
@@ -2490,10 +2438,19 @@ def test_caller_owned_device_arrays_are_complete_in_stream_order(specialise, tab
         assert hip.rt.hipMemsetAsync(d_tau, 0, q.nbytes, hip.c.c_void_p(stream)) == 0
         ctx.traj_id_fused(m, ds, de, B, N, 2.0, 5, d_tau)
         np.testing.assert_array_equal(hip.download_on(stream, d_tau, (B, N, 6), np.float32), want_fused)
-        # and a launch on pool arrays in between stays parked - until the stream accessor (an entry point) is called again
+        # Pool arrays (mp_malloc: all four) read by a RAW copy on the handed-out stream, no mp_* call between launch and read (ADVICE
+        # r5): mp_malloc returns plain device pointers, so once mp_ctx_get_stream has been called nothing stays parked any more
+        # (mp_ctx::stream_exported, sticky) - given rows and generated rows, twice each
         d_pool_tau = ctx.alloc(q.nbytes)
-        ctx.id_trajectory(m, *pool_in, rows, d_pool_tau, dtype=np.float32)
-        np.testing.assert_array_equal(d_pool_tau.download(q.shape, np.float32), want)
+        pool_s, pool_e = ctx.to_device(s_), ctx.to_device(e_)
+        for _ in range(2):
+            ctx.memset(d_pool_tau, 0, q.nbytes)
+            ctx.id_trajectory(m, *pool_in, rows, d_pool_tau, dtype=np.float32)
+            np.testing.assert_array_equal(hip.download_on(stream, d_pool_tau.ptr, q.shape, np.float32), want)
+            ctx.memset(d_pool_tau, 0, q.nbytes)
+            ctx.traj_id_fused(m, pool_s, pool_e, B, N, 2.0, 5, d_pool_tau)
+            np.testing.assert_array_equal(hip.download_on(stream, d_pool_tau.ptr, (B, N, 6), np.float32), want_fused)
+        np.testing.assert_array_equal(d_pool_tau.download((B, N, 6), np.float32), want_fused)
     finally:
         ctx.synchronize()
         for p_ in raw:
@@ -2550,3 +2507,28 @@ def test_more_ill_conditioned_rows_than_the_list_holds(specialise, tables):
     finally:
         ctx.destroy()
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("foreign", [False, True])
+def test_parked_pass_stress_against_a_context_that_never_parks(foreign):
+    """Round 6: the parked / carried / captured float64 passes are the most intricate host logic of the library
+    (csrc/mp_capi.cpp: attach_hard_list, hard_defer, hard_park_or_run, hard_flush_if_overlapping, pick_rider); their randomised
+    coverage was a manual tool.  A bounded run of it, fixed seed: ~300 operations - float32 launches on overlapping sub-ranges of shared
+    arrays of three models (two specialised programs, one generic), outputs landing in other launches' inputs, fused launches with
+    table rewrites, memsets, uploads, float64 launches, synchronisations, launches on arrays that are FREED while their pass is parked
+    and allocated again at once ("recycle": the pool hands the same blocks back), and launch graphs of two or three launches replayed
+    once or twice.  Every download must equal, bit for bit, a host mirror advanced with what a SECOND context's host entry point
+    returns for the same rows (it runs its pass at once, never parks).  foreign=False: all arrays from the pool, the stream never
+    handed out - passes stay parked as long as the library allows.  foreign=True: two models' arrays are the caller's (hipMalloc) and
+    are touched with raw HIP calls on the handed-out compute stream only."""
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import stress_passes
+
+    summary, bad = stress_passes.run(seed=20260706, ops=300, foreign=foreign, verbose=False)
+    assert not bad, f"{len(bad)} mismatching downloads, first: {bad[:3]} ({summary})"
+    assert summary["float32_launches"] >= 150 and summary["downloads"] >= 18, summary
+    assert summary["recycles"] >= 5 and summary["graph_replays"] >= 5, summary
+    assert sum(summary["flagged_rows_per_model"]) >= 50, summary   # there ARE rows the passes have to rewrite

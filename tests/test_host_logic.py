@@ -205,22 +205,24 @@ def test_kernel_specialiser_generates_and_compiles_without_a_gpu(tables, tmp_pat
     m = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee, tab.joint_limits)
     src = m.specialize_source()
     assert "static constexpr MpModel<float> kM = {6," in src and 'extern "C" __global__' in src
-    for name in ("mp_spec_id_pk_f0", "mp_spec_id_pk_f1", "mp_spec_id_s_f0", "mp_spec_traj_id_s_f1", "mp_spec_traj_id_pk_f0", "mp_spec_fd_traj_f1"):
+    for name in ("mp_spec_traj_id_pk_f0", "mp_spec_traj_id_pk_f1", "mp_spec_fd_traj_f1", "mp_spec_fd_traj_tm_f0", "mp_spec_id_d_f0", "mp_spec_fk_jac_id_d_f1",
+                 "mp_spec_id_hard_f0", "mp_spec_traj_id_hard_f1", "mp_spec_fd_s_f0", "mp_spec_fd_d_f1", "mp_spec_ik"):
         assert name in src
+    # round 6: the variants that lost their A/B are no longer generated (one compile per robot is ~25 % shorter), and the generated
+    # source carries no experiment switch any more
+    for gone in ("mp_spec_id_pk", "mp_spec_traj_id_s", "mp_spec_traj_id_co", "#if", "#ifndef"):
+        assert gone not in src, gone
+    # the one-row-per-lane float32 inverse dynamics lives in the SECOND program (max-ILP scheduling strategy): both are required
+    src2 = m.specialize_source(part=1)
+    for name in ("mp_spec_id_s_f0", "mp_spec_id_s_f1", "mp_spec_id_co_f0", "mp_spec_id_co_f1", "mp_body_id_lead"):
+        assert name in src2
+    assert "mp_spec_id_co" not in src and "mp_spec_traj_id_pk" not in src2 and "#if" not in src2
     assert "e-10f" not in src and "e-17f" not in src  # URDF dust is snapped to exact zeros
     assert "inf" not in src.lower().replace("__builtin_inff", "")  # infinite limits are emitted as +-3e38
     nb, cached = m.specialize_compile()
     assert nb > 10000 and not cached
     nb2, cached2 = m.specialize_compile()
-    # two code objects: every kernel, and the one-row-per-lane float32 inverse dynamics built again with the max-ILP
-    # scheduling strategy (mp_jit part 1); MANIPULAPY_HIP_ILP_PART=0 leaves the second one out
-    assert nb2 == nb and cached2 and len(list(tmp_path.glob("*.hsaco"))) == 2
-    only = tmp_path / "first_program_only"
-    only.mkdir()
-    monkeypatch.setenv("MANIPULAPY_HIP_CACHE", str(only))
-    monkeypatch.setenv("MANIPULAPY_HIP_ILP_PART", "0")
-    nb3, cached3 = m.specialize_compile()
-    assert nb3 == nb and not cached3 and len(list(only.glob("*.hsaco"))) == 1
+    assert nb2 == nb and cached2 and len(list(tmp_path.glob("*.hsaco"))) == 2   # two code objects per robot
 
 
 # ----------------------------------------------------------------------------- device math on the host
@@ -721,6 +723,9 @@ def test_bench_self_launches_one_worker_per_gpu():
         assert res.returncode == 0, res.stderr[-2000:]
         line = json.loads(res.stdout.strip().splitlines()[-1])
         assert line["dryrun"] and line["n_gpus"] == world and line["max_rank_seen"] == world - 1.0 and line["broadcast_ok"]
+        # the headline's host legs at N > 1: rank 0 times the CPU oracle and checks parity on its own shard within a fixed budget
+        assert line["host_legs"]["rank"] == 0 and 0 < line["host_legs"]["budget_s"] <= 10.0
+        assert all(k in line["host_legs"] for k in ("cpu_baseline", "parity_sample", "frac_of_probe", "others"))
         # the strong-scaled entries an N > 1 line carries (BASELINE configs[3] and [4] cut over the ranks): every rank derived the
         # same plan (compared over gloo), shards cover the batch exactly, blocks are back to back in the gathered arrays, uneven
         # at world 3, and the overlapped exchange's rounds add up to each rank's block
@@ -732,6 +737,13 @@ def test_bench_self_launches_one_worker_per_gpu():
             assert c["bytes_of_rank"] == [b * N * n * 4 for b in c["trajectories_of_rank"]]
             assert c["slot_offset"] == [sum(c["bytes_of_rank"][:r]) for r in range(world)] and c["gathered_bytes_per_array"] == Bt * N * n * 4
             assert len(c["verify"]["seed_of_rank_streams"]) == world
+            # which rank runs the host legs of the entry and on what: rank 0, its own block, a fixed budget
+            legs = c["host_legs"]
+            assert legs["rank"] == 0 and 0 < legs["budget_s"] <= 10.0 and "barrier" in legs["others"] and "oracle" in legs["cpu_baseline"]
+            if name == "c4":
+                assert legs["parity_sample"]["rows"] == min(1 << 18, c["trajectories_of_rank"][0] * N)
+            else:
+                assert legs["parity_sample"]["trajectories"] == min(2048, c["trajectories_of_rank"][0])
             if world == 8:   # BASELINE's own split: even shards
                 assert c["trajectories_of_rank"] == [Bt // 8] * 8 and (Bt // 8 == (32768 if name == "c4" else 131072))
             if name == "c4":

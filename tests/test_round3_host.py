@@ -318,17 +318,42 @@ def test_bench_parity_rules_and_line_shape():
     fast = np.full((64, 6), 5.0)                                              # |qd|^2 = 150 -> + 6e-7
     assert bench.parity_rows(want + 5e-7, want, "f64", qd=fast)["ok"] and not bench.parity_rows(want + 5e-7, want, "f64")["ok"]
     assert not bench.parity_rows(want + 5e-7, want, "f64", qd=fast * 0.1)["ok"]
+    # round 6: how much of the float32 bound rides on the floor is IN the record - an element off by 3e-4 of a reference that is
+    # 1e-3 of its row's largest torque fails 1e-4 |ref| alone and passes through 5e-6 max|row|
+    small = want.copy()
+    j, jm = int(np.argmin(np.abs(want[7]))), int(np.argmax(np.abs(want[7])))
+    small[7, j] = want[7, jm] * 1e-3
+    got = small.copy(); got[7, j] *= 1.0 + 3e-4
+    fl = bench.parity_rows(got, small, "f32")
+    assert fl["ok"] and fl["elements_over_pure_rel"]["count"] == 1 and fl["elements_over_pure_rel"]["rows"] == 1
+    assert abs(fl["elements_over_pure_rel"]["max_ref_over_rowmax_of_those"] - 1e-3) < 1e-6
+    assert abs(fl["elements_over_pure_rel"]["fraction"] - 1.0 / want.size) < 1e-12
+    brief = bench.parity_brief(fl, rows_total=64, sets=1)
+    assert brief["elements_over_pure_rel"]["count"] == 1 and brief["max_ref_over_rowmax_of_those"] > 0 and brief["rows_checked"] == 64
+    assert bench.parity_rows(want + 1e-7, want, "f32")["elements_over_pure_rel"]["count"] >= 0
+    # the gathered blocks' checksum depends on where the words sit (a plain sum passed a permuted block)
+    words = rng.integers(0, 2**32, 5_000_003, dtype=np.uint64).astype(np.uint32)
+    swapped = words.copy(); swapped[[11, 4_500_000]] = swapped[[4_500_000, 11]]
+    assert int(words.sum(dtype=np.uint64)) == int(swapped.sum(dtype=np.uint64))
+    assert bench.weighted_word_sum(words) != bench.weighted_word_sum(swapped) and bench.weighted_word_sum(words) == bench.weighted_word_sum(words.copy())
+    assert bench.weighted_word_sum(np.zeros(0, np.uint32)) == 0
+    # a single process has nothing to agree on; the flag passes through
+    from manipulapy_amd import sharding
+    one = sharding.HostGather(sharding.ShardInfo(0, 1, 0))
+    assert bench.agree_hung(one, False, {}) is False and bench.agree_hung(one, True, {}) is True
     # the "configs" entry
     full = {"metric": "m", "value": 1.0, "unit": "u", "ms_per_step": 0.1, "steps": 5, "dtype": "f32",
             "config": {"workload": "w", "kernel_variant": "generic"},
             "roofline": {"bound": "hbm", "achieved": 1.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.1, "frac_cold": 0.1, "traffic": 3.0,
-                         "algorithmic_bytes_per_launch": 3, "kernel": "k", "kernel_ms": 0.1, "kernel_ms_cold": 0.2, "device_copy": {}},
+                         "algorithmic_bytes_per_launch": 3, "kernel": "k", "kernel_ms": 0.1, "kernel_ms_cold": 0.2, "device_copy": {},
+                         "clock": {"hz": 2.1e9}},
             "roofline_valu": {"frac": 0.5, "valu_insts_per_launch": 1, "issue_cycles_per_inst": 2.0, "clock_hz": 1.0, "source": "s", "peak": 1},
             "parity_sample": {"ok": True}, "cpu_baseline": {"value": 1}}
     entry = bench.compact(full)
     for key in ("ms_per_step", "value", "kernel", "kernel_ms", "kernel_ms_cold", "roofline", "roofline_valu", "parity_sample", "workload"):
         assert key in entry
     assert entry["roofline"]["traffic"] == 3.0 and "device_copy" not in entry["roofline"] and "cpu_baseline" not in entry
+    assert entry["roofline"]["clock"]["hz"] == 2.1e9
     assert set(bench.SECONDARY) == {"c2f", "c3", "c4", "c4s", "c5", "c5b"} and bench.CONFIGS["c5"]["layout"] == "time_major"
     for name, cfg in bench.CONFIGS.items():   # kernel names the traffic files must carry to be attached
         for spec in (True, False):

@@ -122,5 +122,5 @@ def test_carried_float64_path_keeps_the_float32_rows_free_of_scratch():
     sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
     import check_scratch
 
-    total, inside = check_scratch.hot_path_scratch("ur5", max_ilp=True)
+    total, inside = check_scratch.hot_path_scratch("ur5")
     assert total > 0 and inside == 0, (total, inside)

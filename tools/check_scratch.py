@@ -18,15 +18,15 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast", "-f
          "-ffinite-math-only", "-mllvm", "-disable-machine-licm", "-w", "-DMP_SPECIALISED=1"]
 
 
-def hot_path_scratch(robot, kernel="mp_spec_id_co_f0", max_ilp=True):
-    """(scratch accesses in the kernel, how many of them lie inside the float32 rows' code).  max_ilp: compiled as the SECOND program
-    is (csrc/mp_jit.cpp part 1: -amdgpu-sched-strategy=max-ilp) - the one whose mp_spec_id_co the launcher uses."""
+def hot_path_scratch(robot, kernel="mp_spec_id_co_f0"):
+    """(scratch accesses in the kernel, how many of them lie inside the float32 rows' code).  Compiled as the specialiser compiles the
+    SECOND program (csrc/mp_jit.cpp part 1: -amdgpu-sched-strategy=max-ilp), where mp_spec_id_co lives."""
     t = robots.robot_tables(robot)
     m = _hip.HipModel(t["S_list"], t["Mlist_per_link"], t["Glist"], t["M_ee"], t["joint_limits"])
-    src = m.specialize_source()
+    src = m.specialize_source(part=1)
     hip, asm = f"/tmp/chk_{robot}.hip", f"/tmp/chk_{robot}.s"
     open(hip, "w").write("#include <hip/hip_runtime.h>\n" + src)
-    subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + (["-mllvm", "-amdgpu-sched-strategy=max-ilp"] if max_ilp else []) + ["-I", os.path.join(ROOT, "manipulapy_amd", "csrc"), "--offload-device-only", "-S", "-o", asm, hip],
+    subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + ["-mllvm", "-amdgpu-sched-strategy=max-ilp", "-I", os.path.join(ROOT, "manipulapy_amd", "csrc"), "--offload-device-only", "-S", "-o", asm, hip],
                    check=True)
     s = open(asm).read()
     i = s.index(f"\n{kernel}:")
@@ -43,8 +43,7 @@ def hot_path_scratch(robot, kernel="mp_spec_id_co_f0", max_ilp=True):
 if __name__ == "__main__":
     bad = 0
     for robot in sys.argv[1:] or ["ur5", "panda", "panda7", "xarm6", "iiwa14"]:
-        for ilp in (True, False):
-            total, inside = hot_path_scratch(robot, max_ilp=ilp)
-            print(f"{robot} ({'max-ILP program' if ilp else 'first program'}): {total} scratch accesses in mp_spec_id_co_f0, {inside} of them inside the float32 rows' code")
-            bad += inside
+        total, inside = hot_path_scratch(robot)
+        print(f"{robot}: {total} scratch accesses in mp_spec_id_co_f0, {inside} of them inside the float32 rows' code")
+        bad += inside
     sys.exit(1 if bad else 0)

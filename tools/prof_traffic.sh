@@ -4,8 +4,8 @@ export MANIPULAPY_HIP_EXPERIMENT=1  # JIT_DEFINES / JIT_FLAGS are honoured only 
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 CFG=${1:-c5}; OUT=$R/gpurun_out/${2:-traffic_$CFG}; export MANIPULAPY_HIP_JIT_DEFINES="${3:-}"
 mkdir -p $OUT; cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --config $CFG --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --config $CFG --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --config $CFG --steps 3 --warmup 1 --no-cpu-baseline --no-single-set --no-clock-sample > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --config $CFG --steps 3 --warmup 1 --no-cpu-baseline --no-single-set --no-clock-sample > $OUT/pmc_write.log 2>&1
 cd $R
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections, statistics

@@ -4,7 +4,7 @@
     python tools/spec_asm.py xarm6 mp_spec_fd_traj_tm_f1 [more kernels] [-DNAME ...]
 
 Takes the very translation unit the run-time specialiser hands to hiprtc (mp_model_specialize_source), compiles it with
-hipcc for gfx950 with the specialiser's flags (device only, -S) into /tmp/spec_<robot>.s and prints per kernel: VGPRs,
+hipcc for gfx950 with the specialiser's flags (device only, -S) into /tmp/spec_<robot>_<part>.s and prints per kernel: VGPRs,
 scratch, LDS, the instruction histogram and the s_waitcnt vmcnt values in program order."""
 import collections
 import os
@@ -26,13 +26,17 @@ def main():
     extra = [a for a in sys.argv[2:] if a.startswith("-")]
     t = robots.robot_tables(robot)
     m = _hip.HipModel(t["S_list"], t["Mlist_per_link"], t["Glist"], t["M_ee"], t["joint_limits"])
-    src = m.specialize_source()
-    hip = f"/tmp/spec_{robot}.hip"
-    asm = f"/tmp/spec_{robot}.s"
-    open(hip, "w").write("#include <hip/hip_runtime.h>\n" + src)
-    subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + extra + ["-I", os.path.join(ROOT, "manipulapy_amd", "csrc"), "--offload-device-only", "-S",
-                                                               "-o", asm, hip], check=True)
-    s = open(asm).read()
+    # two translation units per robot (csrc/mp_jit.cpp): the float32 one-row inverse dynamics (mp_spec_id_s / _co) is the second,
+    # compiled with the max-ILP scheduling strategy; every other kernel the first
+    s = ""
+    for part, more in ((0, []), (1, ["-mllvm", "-amdgpu-sched-strategy=max-ilp"])):
+        src = m.specialize_source(part=part)
+        hip = f"/tmp/spec_{robot}_{part}.hip"
+        asm = f"/tmp/spec_{robot}_{part}.s"
+        open(hip, "w").write("#include <hip/hip_runtime.h>\n" + src)
+        subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + more + extra + ["-I", os.path.join(ROOT, "manipulapy_amd", "csrc"), "--offload-device-only", "-S",
+                                                                          "-o", asm, hip], check=True)
+        s += open(asm).read()
     for key in kernels:
         m_ = re.search(r"^(" + re.escape(key) + r"):", s, re.M)
         if not m_:

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Dev stress run (not part of the suite): random sequences of device-pointer float32 inverse-dynamics launches whose float64
+"""Stress run of the parked float64 passes (a bounded run of it is in the GPU suite: tests/test_gpu_parity.py::
+test_parked_pass_stress_against_a_context_that_never_parks): random sequences of device-pointer float32 inverse-dynamics launches whose float64
 passes the context parks (csrc/mp_capi.cpp, hard_defer / hard_flush), on overlapping sub-ranges of shared device arrays - outputs
 landing in other launches' inputs and outputs, three models (two specialised programs and a generic one), interleaved with
 uploads, memsets, float64 launches and downloads.  A host mirror of every device array is advanced with what a SECOND context's
@@ -9,7 +10,14 @@ host entry point returns for the same rows (it flushes at once); every download 
 
 FOREIGN=1 (round 5): the arrays of the first and the second model are the CALLER's (hipMalloc through the HIP runtime, not mp_malloc) and
 are read, written and cleared with raw HIP calls on the context's compute stream only - no mp_* entry point between a launch and
-the read of its result.  Launches on such arrays get their float64 pass at once (csrc/mp_capi.cpp, hard_park_or_run).
+the read of its result.  Launches on such arrays get their float64 pass at once (csrc/mp_capi.cpp, hard_park_or_run); and since
+round 6 the stream having been handed out (mp_ctx_get_stream) switches parking off for the pool arrays of the third model too.
+Without FOREIGN the stream is never asked for: everything stays parked as long as the library allows.
+
+Round 6 added two operations: "recycle" (a launch on freshly mp_malloc'd arrays that are freed while its pass is parked; the same
+sizes are allocated again at once - the pool hands the very blocks back - filled with a pattern and used by another launch: the
+pattern and that launch's result must come back untouched) and "graph" (two or three launches captured into a launch graph,
+replayed once or twice, the mirror advanced per replay).
 """
 import ctypes
 import os
@@ -84,13 +92,12 @@ def fast_rows(rng, lim, n, rows):
     return [np.ascontiguousarray(o[k]) for k in range(3)]
 
 
-def main():
-    seed, ops = int(os.environ.get("SEED", "0")), int(os.environ.get("OPS", "300"))
+def run(seed=0, ops=300, foreign=False, nthreads=1, verbose=True):
+    """-> (summary dict, list of mismatches)."""
     rng = np.random.default_rng(seed)
     ctx, ref_ctx = _hip.HipContext(0), _hip.HipContext(0)
     models = []
-    foreign = os.environ.get("FOREIGN", "0") == "1"
-    stream = ctx.stream()
+    stream = ctx.stream() if foreign else 0   # (asking for the stream switches parking off: only the FOREIGN mode does)
     for robot, spec in (("ur5", True), ("xarm6", False), ("panda", True)):
         t = mp.robot_tables(robot)
         m = _hip.HipModel(t["S_list"], t["Mlist_per_link"], t["Glist"], t["M_ee"], t["joint_limits"])
@@ -101,9 +108,8 @@ def main():
         dev = [Foreign(stream, host=a) for a in host] if foreign and len(models) < 2 else [ctx.to_device(a) for a in host]
         flagged = int(_hip.cpu_id_row_precision(m, *host[:3]).sum())
         models.append({"name": robot, "m": m, "n": m.n, "host": host, "dev": dev, "flagged": flagged})
-    launches = checks = 0
-    bad, held = [], []
-    nthreads = int(os.environ.get("THREADS", "1"))   # > 1: the models are dealt out to threads that share BOTH contexts
+    launches = checks = recycled = replays = 0
+    bad, held, graphs = [], [], []
 
     def expected(M, rows_in, start, length):
         sl = slice(start, start + length)
@@ -120,13 +126,15 @@ def main():
 
     import threading
     lock = threading.Lock()
+    nonlocal_counts = {"recycled": 0, "replays": 0}
 
     def worker(my_models, rng):
       nonlocal launches
       for op in range(ops):
           M = my_models[int(rng.integers(len(my_models)))]
           n, rb = M["n"], M["n"] * 4
-          kind = rng.choice(["launch"] * 10 + ["launch_into_input"] * 2 + ["fused"] * 4 + ["download", "memset", "upload", "f64", "sync"])
+          kind = rng.choice(["launch"] * 10 + ["launch_into_input"] * 2 + ["fused"] * 4 + ["download", "memset", "upload", "f64", "sync"]
+                            + ["recycle"] * 2 + (["graph"] * 2 if nthreads <= 1 else []))
           if kind in ("launch", "launch_into_input"):
               length = int(rng.choice([1, 63, 64, 65, 200, 1000, int(rng.integers(1, 6000))]))
               s_in, s_out = (2 * int(rng.integers(0, (R - length) // 2 + 1)) for _ in range(2))   # (device pointers: 16-byte aligned)
@@ -139,6 +147,52 @@ def main():
               M["host"][dst][s_out:s_out + length] = want
               with lock:
                 launches += 1
+          elif kind == "recycle":
+              # a launch on arrays of its own from the pool, freed while its float64 pass is (maybe) parked; the same sizes again at
+              # once - the pool's exact-size free lists hand those very blocks back - a pattern in each, another launch on them
+              nonlocal_counts["recycled"] += 1
+              length = int(rng.choice([64, 640, 2000]))
+              nb = length * rb
+              s1, s2 = (int(rng.integers(0, R - length + 1)) for _ in range(2))
+              first = [ctx.to_device(np.ascontiguousarray(M["host"][k][s1:s1 + length])) for k in range(3)] + [ctx.alloc(nb)]
+              ctx.id_trajectory(M["m"], *first[:3], length, first[3], dtype=np.float32)
+              for b_ in first:
+                  b_.free()
+              again = [ctx.alloc(nb) for _ in range(4)]
+              ins = [np.ascontiguousarray(M["host"][k][s2:s2 + length]) for k in range(3)]
+              pattern = rng.uniform(-1, 1, (length, n)).astype(np.float32)
+              for b_, a in zip(again, ins + [pattern]):
+                  b_.upload(a)
+              got_pat = again[3].download((length, n), np.float32)
+              ctx.id_trajectory(M["m"], *again[:3], length, again[3], dtype=np.float32)
+              got = again[3].download((length, n), np.float32)
+              got_in = [b_.download((length, n), np.float32) for b_ in again[:3]]
+              want = ref_ctx.id_trajectory_host(M["m"], *ins, dtype=np.float32)
+              with lock:
+                  launches += 2
+              if not (np.array_equal(got_pat, pattern) and np.array_equal(got, want, equal_nan=True) and all(np.array_equal(x, y) for x, y in zip(got_in, ins))):
+                  bad.append((f"op {op} recycle", M["name"], -1, int((got != want).any(axis=1).sum()), s1, s2))
+              for b_ in again:
+                  b_.free()
+          elif kind == "graph":
+              # two or three given-rows launches captured into ONE launch graph (their passes are nodes of the graph, lists and counters
+              # the graph's own), replayed once or twice; the mirror is advanced launch by launch at every replay
+              plan = []
+              for _ in range(int(rng.integers(2, 4))):
+                  length = int(rng.choice([64, 65, 200, 1000, int(rng.integers(1, 3000))]))
+                  s_in, s_out = (2 * int(rng.integers(0, (R - length) // 2 + 1)) for _ in range(2))
+                  plan.append((s_in, s_out, int(rng.integers(3, 6)), length))
+              with ctx.capture() as cap:
+                  for s_in, s_out, dst, length in plan:
+                      ctx.id_trajectory(M["m"], *(M["dev"][k].offset(s_in * rb) for k in range(3)), length, M["dev"][dst].offset(s_out * rb), dtype=np.float32)
+              graphs.append(cap.graph)
+              for _ in range(int(rng.integers(1, 3))):
+                  cap.graph.launch()
+                  nonlocal_counts["replays"] += 1
+                  for s_in, s_out, dst, length in plan:
+                      M["host"][dst][s_out:s_out + length] = expected(M, (0, 1, 2), s_in, length)
+                  with lock:
+                      launches += len(plan)
           elif kind == "download":
               check(M, int(rng.integers(0, 6)), f"op {op}")
           elif kind == "memset":
@@ -188,19 +242,31 @@ def main():
     for M in models:
         for k in range(6):
             check(M, k, "end")
-    print(f"seed {seed}: {ops} ops, {launches} float32 launches, {checks} downloads, flagged rows per model "
-          f"{[M['flagged'] for M in models]}, mismatches {len(bad)}")
-    for b_ in bad[:10]:
-        print("  MISMATCH", b_)
+    summary = {"seed": seed, "ops": ops, "foreign": bool(foreign), "threads": nthreads, "float32_launches": launches, "downloads": checks,
+               "recycles": nonlocal_counts["recycled"], "graph_replays": nonlocal_counts["replays"],
+               "flagged_rows_per_model": [M["flagged"] for M in models], "mismatches": len(bad)}
+    if verbose:
+        print(f"seed {seed}{' FOREIGN' if foreign else ''}: {ops} ops, {launches} float32 launches, {checks} downloads, {summary['recycles']} recycles, "
+              f"{summary['graph_replays']} graph replays, flagged rows per model {summary['flagged_rows_per_model']}, mismatches {len(bad)}")
+        for b_ in bad[:10]:
+            print("  MISMATCH", b_)
     for pair in held:
         for b_ in pair:
             b_.free()
     ctx.synchronize()
+    for gr in graphs:
+        gr.destroy()
     for M in models:
         for d in M["dev"]:
             if isinstance(d, Foreign):
                 d.free()
     ctx.destroy(); ref_ctx.destroy()
+    return summary, bad
+
+
+def main():
+    _, bad = run(int(os.environ.get("SEED", "0")), int(os.environ.get("OPS", "300")), os.environ.get("FOREIGN", "0") == "1",
+                 int(os.environ.get("THREADS", "1")))   # THREADS > 1: the models are dealt out to threads that share BOTH contexts
     return 1 if bad else 0
 
 
