@@ -520,9 +520,9 @@ def bench_fd(args, cfg, info, hg, ctx, model, t, props, headline=True):
         "setup": {"ramp_ms": args.ramp_ms, "what": "untimed launches before the W warm-up steps (clock ramp)"},
         "device": props["name"],
     }
-    attach_counters(result, cfg["name"])
     if clock is not None:
         result["roofline"]["clock"] = clock
+    attach_counters(result, cfg["name"])
     if probe is not None:
         result["roofline"]["probe"] = probe
         if probe.get("GBps"):
@@ -961,14 +961,20 @@ def attach_counters(result, config):
     result["roofline"]["traffic"] = tf.get("hbm_bytes_per_launch")
     if tf.get("valu") and result["roofline"].get("kernel_ms"):
         v = dict(tf["valu"])
-        # VALU issue roofline: instructions issued per launch x cycles one wave-instruction occupies its SIMD, against
-        # the SIMD-cycles the launch had (kernel time x sustained clock x SIMDs)
-        simd_cycles = result["roofline"]["kernel_ms"] * 1e-3 * v["clock_hz"] * v["simds"]
+        # VALU issue roofline: instructions issued per launch (PMC, a property of kernel + input) x cycles one wave-instruction
+        # occupies its SIMD, against the SIMD-cycles the launch had = kernel time x shader clock x SIMDs.  The clock is THIS run's
+        # (roofline.clock: s_memtime / s_memrealtime stamps beside the launches) when it was sampled; the profile's own figure
+        # (GRBM_GUI_ACTIVE / 8 / duration) reads high on dispatches shorter than ~0.3 ms - c2 2.49 GHz against a sampled 1.6 - 1.8 -
+        # and is kept as `clock_hz_pmc`.
+        live = (result["roofline"].get("clock") or {}).get("hz")
+        hz = live or v["clock_hz"]
+        simd_cycles = result["roofline"]["kernel_ms"] * 1e-3 * hz * v["simds"]
         busy = v["valu_insts_per_launch"] * v["issue_cycles_per_inst"]
         result["roofline_valu"] = {"bound": "valu-issue", "achieved": busy, "peak": simd_cycles, "unit": "SIMD-cycles per launch",
                                    "frac": busy / simd_cycles, "valu_insts_per_launch": v["valu_insts_per_launch"],
-                                   "issue_cycles_per_inst": v["issue_cycles_per_inst"], "clock_hz": v["clock_hz"], "simds": v["simds"],
-                                   "source": v.get("source")}
+                                   "issue_cycles_per_inst": v["issue_cycles_per_inst"], "clock_hz": hz,
+                                   "clock_source": "roofline.clock (sampled in this run)" if live else "the profile's GRBM_GUI_ACTIVE / 8 / duration",
+                                   "clock_hz_pmc": v["clock_hz"], "simds": v["simds"], "source": v.get("source")}
 
 
 def self_launch(gpus: int) -> int:
@@ -1184,7 +1190,7 @@ def compact(r):
     if "probe" in rl:
         out["roofline"]["probe"] = {k: rl["probe"][k] for k in ("GBps", "plain_GBps", "nontemporal_GBps", "reads", "writes", "bytes_per_array", "error") if k in rl["probe"]}
     if "roofline_valu" in r:
-        out["roofline_valu"] = {k: r["roofline_valu"][k] for k in ("frac", "valu_insts_per_launch", "issue_cycles_per_inst", "clock_hz", "source")}
+        out["roofline_valu"] = {k: r["roofline_valu"][k] for k in ("frac", "valu_insts_per_launch", "issue_cycles_per_inst", "clock_hz", "clock_source", "clock_hz_pmc", "source") if k in r["roofline_valu"]}
     if "parity_sample" in r:
         out["parity_sample"] = r["parity_sample"]
     return out
@@ -1502,9 +1508,9 @@ def bench_id(args, cfg, info, hg, ctx, model, t, props, headline):
         "setup": {"ramp_ms": args.ramp_ms, "what": "untimed launches before the W warm-up steps (clock ramp)"},
         "device": props["name"],
     }
-    attach_counters(result, cfg["name"])
     if clock is not None:
         result["roofline"]["clock"] = clock
+    attach_counters(result, cfg["name"])
     if probe is not None:
         result["roofline"]["probe"] = probe
         if probe.get("GBps"):

@@ -199,8 +199,6 @@ int mp_batch_trajectory_f32(mp_ctx* ctx, const mp_model* model, const float* d_s
  *     (mp_memcpy_*, mp_ctx_synchronize, mp_event_record, mp_ctx_get_stream, the *_host calls, the communicator ...), a launch
  *     whose arrays overlap the parked one's, a fifth launch, mp_ctx_destroy.  Without the compute stream (mp_ctx_get_stream) pool
  *     memory is only reachable through those; once the stream has been handed out, nothing is parked any more (as for caller-owned arrays).
- *   MANIPULAPY_HIP_PARK_FOREIGN=1 (experiment switch) parks for foreign arrays too; the caller must then pass a
- *   synchronising entry point before touching them with its own HIP calls.
  * The same holds for mp_traj_id_fused_f32 (start / end / tau). */
 int mp_id_trajectory_f32(mp_ctx* ctx, const mp_model* model, const float* d_q, const float* d_qd,
                          const float* d_qdd, int64_t rows, const double* g, const double* Ftip, float* d_tau);

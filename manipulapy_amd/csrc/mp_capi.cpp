@@ -385,7 +385,8 @@ void make_call_f32(mp_ctx* ctx, const mp_model* model, const double* g, const do
 // kernels re-evaluate in place: more than 2^32 rows, or the switch.  A launch that is being CAPTURED takes its list from the
 // capture's own pool (mp_graph_begin): the graph owns it, the pass is a node of the graph.
 mp_ctx::HardSlot* attach_hard_list(mp_ctx* ctx, long rows, MpCall<float>* c) {
-  static const bool on = !(getenv("MANIPULAPY_HIP_HARD_PASS") && getenv("MANIPULAPY_HIP_HARD_PASS")[0] == '0');  // experiment switch
+  // MANIPULAPY_HIP_HARD_PASS=0: no list - the path a launch of 2^32 rows or a failed list allocation takes (tested that way)
+  static const bool on = !(getenv("MANIPULAPY_HIP_HARD_PASS") && getenv("MANIPULAPY_HIP_HARD_PASS")[0] == '0');
   if (!on || rows >= 0xffffffffL) return nullptr;
   mp_ctx::HardPool* pool = ctx->hp;
   mp_ctx::HardSlot* hs = nullptr;
@@ -470,8 +471,6 @@ void hard_defer_generated(mp_ctx* ctx, mp_ctx::HardSlot* hs, hipFunction_t fn, c
 // returns with the complete result stream-ordered behind it, as the reference's launchers return finished arrays
 // (cuda_kernels/trajectory_kernels.py:1043-1081).
 int hard_park_or_run(mp_ctx* ctx, const void* a, const void* b, const void* c, const void* out, size_t bytes_out, size_t bytes_in) {
-  static const bool always = getenv("MANIPULAPY_HIP_PARK_FOREIGN") && getenv("MANIPULAPY_HIP_PARK_FOREIGN")[0] == '1';  // experiment switch
-  if (always) return MP_OK;
   // ... and once the caller holds the compute stream (mp_ctx_get_stream) it can read pool memory too - mp_malloc returns a plain device
   // pointer - with a copy or a kernel of its own on that stream, behind the library's back: from then on nothing stays parked
   if (!ctx->stream_exported && pool_owned(ctx, a, bytes_in) && pool_owned(ctx, b, bytes_in) && pool_owned(ctx, c, bytes_in) && pool_owned(ctx, out, bytes_out))
@@ -505,11 +504,7 @@ int hard_flush(mp_ctx* ctx) {
       e->busy = false;
       ent[m++] = e;
     }
-    // MANIPULAPY_HIP_EXPERIMENT=1 MANIPULAPY_HIP_SKIP_PASS=1 (measurements only - the results are then float32-only and the lists'
-    // counters are never reset): what a step costs without the pass kernel, i.e. the bound for any scheme that hides it
-    static const bool skip = getenv("MANIPULAPY_HIP_EXPERIMENT") && getenv("MANIPULAPY_HIP_EXPERIMENT")[0] == '1' &&
-                             getenv("MANIPULAPY_HIP_SKIP_PASS") && getenv("MANIPULAPY_HIP_SKIP_PASS")[0] == '1';
-    if (rc == MP_OK && !skip) {
+    if (rc == MP_OK) {
       void* args[] = {&B};
       hipError_t he = h->fn ? hipModuleLaunchKernel(h->fn, blocks, (unsigned)m, 1, 64, 1, 1, 0, ctx->compute, args, nullptr)
                             : mpk_id_hard_batch(ctx->compute, h->gen_dm, h->gen_n, h->gen_ftip, B, m, blocks);
