@@ -648,48 +648,64 @@ def bench_strong(name, args, info, hg, ctx, props):
 
     cfg = dict(STRONG[name]); cfg["name"] = name
     world, rank = info.world, info.rank
-    t = robots.robot_tables(cfg["robot"])
-    n = t["S_list"].shape[1]
-    plan = strong_plan(name, world, n)
-    N, Bs = plan["N"], plan["trajectories_of_rank"][rank]
-    model = _hip.HipModel(t["S_list"], t["Mlist_per_link"], t["Glist"], t["M_ee"], t["joint_limits"])
-    if not args.no_specialize:
-        ctx.specialize(model)
-    cfg["specialized"] = ctx.is_specialized(model)
-    cfg["dof"] = n
-    inp = strong_inputs(name, plan, rank, t["joint_limits"])
-    g = np.array([0.0, 0.0, -9.81])
-    rows = Bs * N
-    mine = plan["bytes_of_rank"][rank]
     bufs = []
+    setup_err = None
+    try:
+        t = robots.robot_tables(cfg["robot"])
+        n = t["S_list"].shape[1]
+        plan = strong_plan(name, world, n)
+        N, Bs = plan["N"], plan["trajectories_of_rank"][rank]
+        model = _hip.HipModel(t["S_list"], t["Mlist_per_link"], t["Glist"], t["M_ee"], t["joint_limits"])
+        if not args.no_specialize:
+            ctx.specialize(model)
+        cfg["specialized"] = ctx.is_specialized(model)
+        cfg["dof"] = n
+        inp = strong_inputs(name, plan, rank, t["joint_limits"])
+        g = np.array([0.0, 0.0, -9.81])
+        rows = Bs * N
+        mine = plan["bytes_of_rank"][rank]
 
-    def keep(b):
-        bufs.append(b)
-        return b
+        def keep(b):
+            bufs.append(b)
+            return b
 
-    if cfg["op"] == "id":
-        d_start, d_end = keep(ctx.to_device(inp["start"])), keep(ctx.to_device(inp["end"]))
-        d_q, d_qd, d_qdd, d_tau = (keep(ctx.alloc(max(mine, 16))) for _ in range(4))
-        ctx.batch_trajectory(model, d_start, d_end, Bs, N, 2.0, 5, d_q, d_qd, d_qdd)
-        ctx.synchronize()
-        outs = [d_tau]
+        if cfg["op"] == "id":
+            d_start, d_end = keep(ctx.to_device(inp["start"])), keep(ctx.to_device(inp["end"]))
+            d_q, d_qd, d_qdd, d_tau = (keep(ctx.alloc(max(mine, 16))) for _ in range(4))
+            ctx.batch_trajectory(model, d_start, d_end, Bs, N, 2.0, 5, d_q, d_qd, d_qdd)
+            ctx.synchronize()
+            outs = [d_tau]
 
-        def step(dst=None):
-            ctx.id_trajectory(model, d_q, d_qd, d_qdd, rows, dst if dst is not None else d_tau, dtype=np.float32)
-        alg = 16 * n * rows
-    else:
-        th0, dth0 = inp["th0"], inp["dth0"]
-        zero = np.zeros_like(th0)
-        hold = ctx.id_trajectory_host(model, th0, zero, zero, g, None, dtype=np.float32)
-        taumat, Fm = strong_fd_streams(inp["stream_seed"], Bs, N, n, hold, time_major=True)
-        d_th0, d_dth0 = keep(ctx.to_device(th0)), keep(ctx.to_device(dth0))
-        d_tm, d_F = keep(ctx.to_device(taumat)), keep(ctx.to_device(Fm))
-        del taumat, Fm
-        outs = [keep(ctx.alloc(max(mine, 16))) for _ in range(3)]
+            def step(dst=None):
+                ctx.id_trajectory(model, d_q, d_qd, d_qdd, rows, dst if dst is not None else d_tau, dtype=np.float32)
+            alg = 16 * n * rows
+        else:
+            th0, dth0 = inp["th0"], inp["dth0"]
+            zero = np.zeros_like(th0)
+            hold = ctx.id_trajectory_host(model, th0, zero, zero, g, None, dtype=np.float32)
+            taumat, Fm = strong_fd_streams(inp["stream_seed"], Bs, N, n, hold, time_major=True)
+            d_th0, d_dth0 = keep(ctx.to_device(th0)), keep(ctx.to_device(dth0))
+            d_tm, d_F = keep(ctx.to_device(taumat)), keep(ctx.to_device(Fm))
+            del taumat, Fm
+            outs = [keep(ctx.alloc(max(mine, 16))) for _ in range(3)]
 
-        def step(dst=None):
-            ctx.fd_trajectory(model, d_th0, d_dth0, d_tm, d_F, Bs, N, g, 0.01, 1, outs[0], outs[1], outs[2], dtype=np.float32, time_major=True)
-        alg = ((n + 6) * 4 + 12 * n) * rows
+            def step(dst=None):
+                ctx.fd_trajectory(model, d_th0, d_dth0, d_tm, d_F, Bs, N, g, 0.01, 1, outs[0], outs[1], outs[2], dtype=np.float32, time_major=True)
+            alg = ((n + 6) * 4 + 12 * n) * rows
+
+        step(); ctx.synchronize()                     # the shard is set up and one step has run
+    except Exception as exc:
+        setup_err = f"{type(exc).__name__}: {str(exc)[:240]}"
+    # A rank that failed up to here (out of memory, a specialisation that did not load, a launch that raised) must not leave its
+    # peers waiting in the barriers below: the ranks agree, and all of them leave together.
+    failed = hg.max(1.0 if setup_err else 0.0) > 0.0
+    if failed:
+        for b in bufs:
+            try:
+                b.free()
+            except Exception:
+                pass
+        return {"error": setup_err or "another rank failed while setting this configuration up", "scaling": "strong", "n_gpus": world}, False
 
     def timed(fn):
         ramp(ctx, fn, args.ramp_ms)
@@ -1117,13 +1133,16 @@ def main():
         result.setdefault("configs", {})
         for name in STRONG:
             t0 = time.perf_counter()
+            out_of_step = False
             try:
                 entry, hung = bench_strong(name, args, info, hg, ctx, props)
             except Exception as exc:
-                entry, hung = {"error": f"{type(exc).__name__}: {str(exc)[:300]}"}, False
+                # past the agreed set-up (bench_strong) an exception on one rank leaves the ranks out of step with each other's
+                # barriers: report it and run nothing further that needs them - the line with everything measured so far still goes out
+                entry, hung, out_of_step = {"error": f"{type(exc).__name__}: {str(exc)[:300]}"}, False, world > 1
             entry["wall_s"] = round(time.perf_counter() - t0, 2)
             result["configs"][name + "_strong"] = entry
-            if hung:
+            if hung or out_of_step:
                 break
     if world > 1 or os.environ.get("MANIPULAPY_BENCH_FORCE_GATHER") == "1":
         # an N > 1 line whose collectives could not RUN still carries its compute-only figures; say so at the top level, where a

@@ -64,7 +64,12 @@ class HostGather:
         self.dist = dist
         self.info = info or dist_env()
         if self.info.world > 1 and not dist.is_initialized():
-            dist.init_process_group("gloo", rank=self.info.rank, world_size=self.info.world)
+            # a peer that died must surface as an error within minutes, not after gloo's default half hour (bench.py still has a
+            # line to print); long enough for rank 0's host legs (the other ranks wait in a barrier meanwhile)
+            import datetime
+
+            limit = datetime.timedelta(seconds=float(os.environ.get("MANIPULAPY_GLOO_TIMEOUT_S", "600")))
+            dist.init_process_group("gloo", rank=self.info.rank, world_size=self.info.world, timeout=limit)
 
     def allgather(self, local: np.ndarray) -> np.ndarray:
         """(sum of the ranks' rows, ...) in rank order.  The shards may differ in their FIRST dimension (shard_range hands the

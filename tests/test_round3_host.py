@@ -341,6 +341,16 @@ def test_bench_parity_rules_and_line_shape():
     from manipulapy_amd import sharding
     one = sharding.HostGather(sharding.ShardInfo(0, 1, 0))
     assert bench.agree_hung(one, False, {}) is False and bench.agree_hung(one, True, {}) is True
+    # a strong-scaled entry whose set-up fails on a rank is an entry with "error" (agreed over gloo, so that no rank waits in the
+    # barriers that follow), not an exception
+    import argparse
+
+    class _NoDevice:
+        def specialize(self, model):
+            raise RuntimeError("no device in this test")
+
+    entry, hung = bench.bench_strong("c4", argparse.Namespace(no_specialize=False), sharding.ShardInfo(0, 1, 0), one, _NoDevice(), {})
+    assert hung is False and "no device in this test" in entry["error"] and entry["scaling"] == "strong"
     # the "configs" entry
     full = {"metric": "m", "value": 1.0, "unit": "u", "ms_per_step": 0.1, "steps": 5, "dtype": "f32",
             "config": {"workload": "w", "kernel_variant": "generic"},
