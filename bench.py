@@ -53,9 +53,12 @@ CONFIGS = {
                desc="xArm6 (6 DOF; the reference ships no xArm7), gravity + per-step Ftip, B=131072/GPU x N=100, mass matrix + "
                     "forward-dynamics roll-out fp32, dt=0.01 intRes=1 (BASELINE configs[4] per-GPU shard); device arrays TIME-MAJOR "
                     "(N,B,n): mp_fd_trajectory_tm_f32 - the reference has no batched roll-out, the batch axis' place in device memory "
-                    "is the library's choice"),
+                    "is the library's choice.  INPUTS deviate from SURVEY 8(d): gravity-holding torques + a 1e-3 disturbance and 0.02 x the "
+                    "reference's golden wrench per step, not a free fall under the full wrench - that overflows in the reference "
+                    "algorithm itself within ~20 steps (same arrays, bytes and instruction stream)"),
     "c5b": dict(robot="xarm6", B=131072, N=100, dtype="f32", op="fd_traj", layout="batch_major",
-                desc="the same roll-out as c5 on BATCH-MAJOR device arrays (B,N,n): mp_fd_trajectory_f32, 4-step LDS tiles"),
+                desc="the same roll-out as c5 (same inputs, same deviation from SURVEY 8(d)) on BATCH-MAJOR device arrays (B,N,n): "
+                     "mp_fd_trajectory_f32, 4-step LDS tiles"),
 }
 SECONDARY = ("c2f", "c3", "c4", "c4s", "c5", "c5b")   # what `--config all` adds to the c2 line's "configs" object
 F32_ROW = 5e-6   # the suite's float32 floor: 1e-4 |ref| + 5e-6 max|row| (tests/test_gpu_parity.py)
@@ -558,7 +561,9 @@ STRONG = {
     # BASELINE configs[4]: B = 1M x N = 100 roll-outs on 8 GPUs
     "c5": dict(robot="xarm6", B_total=1048576, N=100, dtype="f32", op="fd_traj", layout="time_major", seed=50,
                desc="xArm6, gravity + per-step Ftip, B=1048576 x N=100 roll-outs in total, cut over the ranks, time-major device arrays, "
-                    "positions / velocities / accelerations reassembled on every GPU (BASELINE configs[4])"),
+                    "positions / velocities / accelerations reassembled on every GPU (BASELINE configs[4]); inputs as c5: "
+                    "gravity-holding torques + 1e-3 disturbance, 0.02 x the reference wrench (the free fall of SURVEY 8(d) overflows "
+                    "in the reference algorithm within ~20 steps)"),
 }
 
 
