@@ -242,6 +242,54 @@ def parity_brief(par, rows_total=None, sets=None):
     return out
 
 
+def cold_figures(ctx, step, ncold, sample_clock=True):
+    """The first launches after 0.5 s of idle (reported beside the sustained figures, never as `value`): HIP events on the launch
+    stream before the first launch (a), behind it (m) and behind the last (b).  `kernel_ms_cold` = (b - a) / ncold is what a
+    caller sees who makes that many launches after an idle phase; it contains ONE wake-up - event -> first kernel start: ~10 us
+    after up to 100 ms of idle, ~45 us after 0.5 s, ~55 us after 2 s (profiles/r06_clock_probe_c2_idle.txt) - spread over the
+    window.  `launch_period_ms_after_first` = (b - m) / (ncold - 1) leaves it out: what the launches themselves cost in the cold
+    window (1.00 - 1.02 x sustained at every idle length in that sweep; a rocprofv3 trace of such a window has the kernels back to
+    back at their sustained duration, profiles/r06_cold_after_windows.json).  The event in the middle costs the window one small
+    queue bubble and - mp_event_record being an entry point - runs the first launch's float64 pass as a ~5 us kernel of its own."""
+    step(); ctx.synchronize()          # first-touch / lazy initialisation out of the way
+    time.sleep(0.5)
+    a, m, b = ctx.event(), ctx.event(), ctx.event()
+    a.record()
+    step()
+    m.record()
+    for _ in range(ncold - 1):
+        step()
+    b.record()
+    ctx.synchronize()
+    t1, tk = m.elapsed_ms_since(a), b.elapsed_ms_since(a)
+    for e in (a, m, b):
+        e.destroy()
+    out = {"kernel_ms_cold": tk / ncold, "launches": ncold, "first_launch_ms": t1, "idle_s": 0.5}
+    if ncold > 1:
+        out["launch_period_ms_after_first"] = (tk - t1) / (ncold - 1)
+    if sample_clock:
+        # the shader clock of such a window, from a second one (the sampler's own dispatch would take the wake-up off the timed launches)
+        try:
+            time.sleep(0.5)
+            ctx.clock_sample_begin(max(0.3, 0.8 * tk))
+            for _ in range(ncold):
+                step()
+            ctx.synchronize()
+            out["clock_hz"] = ctx.clock_sample_end()[0]
+        except Exception as exc:   # a diagnostic
+            out["clock_error"] = str(exc)[:120]
+    return out
+
+
+def cold_with_frac(cold, alg_bytes):
+    out = dict(cold)
+    if cold.get("launch_period_ms_after_first", 0) > 0:
+        out["frac_after_first"] = alg_bytes / (cold["launch_period_ms_after_first"] * 1e-3) / 1e9 / HBM_PEAK_GBPS
+    out["what"] = ("`launches` launches after 0.5 s idle: kernel_ms_cold = their mean incl. ONE wake-up (event -> first kernel start); first_launch_ms = "
+                   "wake-up + the first kernel; launch_period_ms_after_first = the other launches' mean")
+    return out
+
+
 def sampled_clock(ctx, step, steps, kern_ms):
     """The shader clock the GPU holds WHILE the step runs, in the sustained state the timed region just left it in: K more launches
     (not part of `value`) beside the library's bounded clock sampler (mp_clock_sample_begin: 8 one-wave blocks on a stream of their
@@ -468,19 +516,8 @@ def bench_fd(args, cfg, info, hg, ctx, model, t, props, headline=True):
     def step():
         ctx.fd_trajectory(model, d_th0, d_dth0, d_tau, d_F, B, N, g, 0.01, 1, d_pos, d_vel, d_acc, dtype=np.float32, time_major=tmaj)
 
-    # cold figure (reported beside the sustained one, never as `value`): the first launches after half a second of idle, before
-    # the power controller has settled - this kernel runs at the 1400 W package limit, sustained launches take ~1.2x the cold ones
-    step(); ctx.synchronize()
-    time.sleep(0.5)
-    ca, cb = ctx.event(), ctx.event()
-    ncold = max(1, min(8, args.steps))
-    ca.record()
-    for _ in range(ncold):
-        step()
-    cb.record()
-    ctx.synchronize()
-    kern_ms_cold = cb.elapsed_ms_since(ca) / ncold
-    ca.destroy(); cb.destroy()
+    cold = cold_figures(ctx, step, max(1, min(8, args.steps)), not args.no_clock_sample)
+    kern_ms_cold = cold["kernel_ms_cold"]
     probe = mix_probe(ctx, cfg, n, B * N)   # this box's streaming rate for the roll-out's byte mix, same process (every rank, its own GPU)
     ramp(ctx, step, args.ramp_ms)
     for _ in range(args.warmup):
@@ -514,7 +551,8 @@ def bench_fd(args, cfg, info, hg, ctx, model, t, props, headline=True):
                    "sharding": f"batch axis over {world} rank(s), no collective in the timed step"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                      "traffic": None, "kernel": kernel_name(cfg), "kernel_ms": kern_ms, "kernel_ms_cold": kern_ms_cold,
-                     "frac_cold": alg_bytes / (kern_ms_cold * 1e-3) / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": alg_bytes,
+                     "frac_cold": alg_bytes / (kern_ms_cold * 1e-3) / 1e9 / HBM_PEAK_GBPS, "cold": cold_with_frac(cold, alg_bytes),
+                     "algorithmic_bytes_per_launch": alg_bytes,
                      "kernel_ms_method": "HIP events on the launch stream around the K launches of the timed region, / K",
                      "note": ("sequential in time, one lane per trajectory; every step streams whole lines (64 x 24-byte rows per array), the next step's rows "
                               "are prefetched in registers; arithmetic alone 0.29 ms (DESIGN.md section 4)") if tmaj else
@@ -1167,6 +1205,8 @@ def main():
             b["of_probe"] = round(rl["frac_of_probe"], 3)
         if "frac_cold" in rl:
             b["frac_cold"] = round(rl["frac_cold"], 3)
+        if "frac_after_first" in (rl.get("cold") or {}):
+            b["frac_cold_after_first"] = round(rl["cold"]["frac_after_first"], 3)
         if "frac_single_set" in rl:
             b["frac_1set"] = round(rl["frac_single_set"], 3)
         if (rl.get("clock") or {}).get("hz"):
@@ -1210,7 +1250,7 @@ def compact(r):
     rl = r["roofline"]
     out["kernel"], out["kernel_ms"], out["kernel_ms_cold"] = rl["kernel"], rl["kernel_ms"], rl["kernel_ms_cold"]
     out["roofline"] = {k: rl[k] for k in ("bound", "achieved", "peak", "unit", "frac", "frac_cold", "frac_of_probe", "frac_single_set", "kernel_ms_single_set",
-                                          "traffic", "algorithmic_bytes_per_launch", "parity", "clock") if k in rl}
+                                          "traffic", "algorithmic_bytes_per_launch", "parity", "clock", "cold") if k in rl}
     if "probe" in rl:
         out["roofline"]["probe"] = {k: rl["probe"][k] for k in ("GBps", "plain_GBps", "nontemporal_GBps", "reads", "writes", "bytes_per_array", "error") if k in rl["probe"]}
     if "roofline_valu" in r:
@@ -1379,20 +1419,9 @@ def bench_id(args, cfg, info, hg, ctx, model, t, props, headline):
             x.destroy(); y.destroy()
         return wall, kms
 
-    # ---- cold figure (reported beside the sustained one, never as `value`): the first launches after the idle setup phase,
-    #      before the clock / power state has settled - a few percent slower on the 0.07 ms kernels (clock ramp), a few
-    #      percent FASTER on the multi-millisecond float64 kernel c3, which the power management throttles once it is warm
-    step(); ctx.synchronize()                      # first-touch / lazy initialisation out of the way
-    time.sleep(0.5)                                # idle: let the clocks fall back
-    ca, cb = ctx.event(), ctx.event()
-    ncold = max(1, min(5, args.steps))
-    ca.record()
-    for _ in range(ncold):
-        step()
-    cb.record()
-    ctx.synchronize()
-    kern_ms_cold = cb.elapsed_ms_since(ca) / ncold
-    ca.destroy(); cb.destroy()
+    # ---- cold figures (reported beside the sustained ones, never as `value`)
+    cold = cold_figures(ctx, step, max(1, min(5, args.steps)), not args.no_clock_sample)
+    kern_ms_cold = cold["kernel_ms_cold"]
 
     # ---- this box's streaming rate for the configuration's own byte mix and size, right before the timed region
     probe = mix_probe(ctx, cfg, n, rows)   # (every rank, on its own GPU: the ranks stay in step; rank 0's is reported)
@@ -1521,9 +1550,9 @@ def bench_id(args, cfg, info, hg, ctx, model, t, props, headline):
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                      "kernel": kernel_name(cfg), "kernel_ms": kern_ms, "kernel_ms_cold": kern_ms_cold,
-                     "frac_cold": alg_bytes / (kern_ms_cold * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                     "frac_cold": alg_bytes / (kern_ms_cold * 1e-3) / 1e9 / HBM_PEAK_GBPS, "cold": cold_with_frac(cold, alg_bytes),
                      "sustained_vs_cold": "`kernel_ms` / `frac` are the sustained figures of the timed region (after the ramp and warm-up); "
-                                          "`kernel_ms_cold` is the mean of the first launches after 0.5 s of idle",
+                                          "`kernel_ms_cold` is the mean of the first launches after 0.5 s of idle (see `cold`)",
                      "kernel_ms_max_over_ranks": kern_ms_all, "algorithmic_bytes_per_launch": alg_bytes,
                      "kernel_ms_method": ("HIP event pair around every %d-th launch of the timed region" % args.event_stride)
                      if args.event_stride > 0 else

@@ -74,4 +74,26 @@ for rnd in range(3):
     time.sleep(0.5)
     plain, _ = run(5, False, est)
     print(f"K=5 cold round {rnd}: plain {plain * 1e3:7.2f} us   beside the sampler {with_s * 1e3:7.2f} us   clock {hz / 1e9:.3f} GHz")
+# How long an idle phase must be before the first launches pay for it, and WHAT they pay: after `idle` seconds without GPU work,
+# one launch (t1) and five launches (t5), each behind its own idle phase, each bracketed by one event pair; median of five rounds.
+# t5 / 5 is bench.py's kernel_ms_cold; (t5 - t1) / 4 is what the launches cost without the wake-up (event -> first kernel start);
+# t1 - the sustained kernel time is that wake-up.
+run(2000, False, est)                  # well into the sustained state before the sweep starts
+print("after an idle phase of the given length (median of 5 rounds): t5 / 5 | (t5 - t1) / 4 | wake-up = t1 - sustained kernel | clock in the window")
+for idle in (0.0, 0.001, 0.005, 0.02, 0.1, 0.5, 2.0):
+    t1s, t5s, clocks = [], [], []
+    for rnd in range(5):
+        run(200, False, est)           # back to the sustained state
+        time.sleep(idle)
+        t1s.append(run(1, False, est)[0])
+        run(200, False, est)
+        time.sleep(idle)
+        t5s.append(run(5, False, est)[0] * 5)
+        run(200, False, est)
+        time.sleep(idle)
+        clocks.append(run(5, True, est)[1])
+    t1s.sort(); t5s.sort(); clocks.sort()
+    t1, t5 = t1s[2], t5s[2]
+    print(f"idle {idle * 1e3:7.1f} ms: {t5 / 5 * 1e3:7.2f} us ({t5 / 5 / est:5.3f} x) | {(t5 - t1) / 4 * 1e3:7.2f} us ({(t5 - t1) / 4 / est:5.3f} x) | "
+          f"{(t1 - est) * 1e3:6.1f} us | {clocks[2] / 1e9:.3f} GHz")
 ctx.destroy()
