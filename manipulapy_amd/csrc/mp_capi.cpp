@@ -611,45 +611,44 @@ int launch_id(mp_ctx* ctx, const mp_model* model, const MpCall<float>& c, bool f
               const float* qdd, float* tau, long rows) {
   if (model->big) return launch_big_fk_jac_id<float>(ctx, model, c, ftip, q, qd, qdd, nullptr, nullptr, tau, rows);
   if (const MpSpec* sp = find_spec(ctx, model)) {
-    {  // one row per lane in scalar arithmetic (a wave64 v_fma_f32 holds its SIMD for 2 cycles, a packed one for 4: the two-rows-per-lane
-       // form measured 5 - 7.5 % slower and was removed in round 6)
-      MpCall<float> cc = c;
-      // ill-conditioned rows go to a float64 pass of their own behind the float32 kernels (see attach_hard_list)
-      mp_ctx::HardSlot* hs = attach_hard_list(ctx, rows, &cc);
-      auto hard_pass = [&]() -> int {
-        if (!hs) return MP_OK;
-        hard_defer(ctx, hs, sp->id_hard[ftip ? 1 : 0], nullptr, false, cc, q, qd, qdd, tau, rows, model->d.n);
-        return hard_park_or_run(ctx, q, qd, qdd, tau, (size_t)rows * (size_t)model->d.n * sizeof(float), (size_t)rows * (size_t)model->d.n * sizeof(float));
-      };
-      long done = 0;
-      if (rows >= 64) {  // whole waves: rows moved as whole lines, non-temporal (mp_body_id_co)
-        long rows64 = rows & ~63L;
-        // One float64 pass that is still parked - an earlier launch's of the same program, none of whose arrays this launch
-        // touches (the others were run by hard_flush_if_overlapping on the way in) - rides with this launch: its first workgroups
-        // work the list off beside the float32 rows (mp_body_id_lead) instead of a kernel of its own doing so later.
-        MpLead lead;
-        std::memset(&lead, 0, sizeof lead);
-        mp_ctx::HardSlot* rider = pick_rider(ctx, sp->id_hard[ftip ? 1 : 0], hs);
-        if (rider) {
-          lead.C = rider->C; lead.q = rider->q; lead.qd = rider->qd; lead.qdd = rider->qdd; lead.tau = rider->tau; lead.rows = rider->nrows;
-          lead.blocks = std::min(hard_pass_blocks((long)rider->nrows), 512u);
-        }
-        const unsigned grid = (unsigned)(rows64 / MP_JIT_ID_CO_BLOCK) + lead.blocks;
-        void* args[] = {&cc, &q, &qd, &qdd, &tau, &rows64, &lead};
-        HIP_TRY(hipModuleLaunchKernel(sp->id_co[ftip ? 1 : 0], grid, 1, 1, MP_JIT_ID_CO_BLOCK, 1, 1, 0, ctx->compute, args, nullptr));
-        if (rider) { rider->busy = false; rider->orphan = false; }   // its pass is enqueued: the slot is free for the next launch
-        done = rows64;
+    // one row per lane in scalar arithmetic (a wave64 v_fma_f32 holds its SIMD for 2 cycles, a packed one for 4: the two-rows-per-lane
+    // form measured 5 - 7.5 % slower and was removed in round 6)
+    MpCall<float> cc = c;
+    // ill-conditioned rows go to a float64 pass of their own behind the float32 kernels (see attach_hard_list)
+    mp_ctx::HardSlot* hs = attach_hard_list(ctx, rows, &cc);
+    auto hard_pass = [&]() -> int {
+      if (!hs) return MP_OK;
+      hard_defer(ctx, hs, sp->id_hard[ftip ? 1 : 0], nullptr, false, cc, q, qd, qdd, tau, rows, model->d.n);
+      return hard_park_or_run(ctx, q, qd, qdd, tau, (size_t)rows * (size_t)model->d.n * sizeof(float), (size_t)rows * (size_t)model->d.n * sizeof(float));
+    };
+    long done = 0;
+    if (rows >= 64) {  // whole waves: rows moved as whole lines, non-temporal (mp_body_id_co)
+      long rows64 = rows & ~63L;
+      // One float64 pass that is still parked - an earlier launch's of the same program, none of whose arrays this launch
+      // touches (the others were run by hard_flush_if_overlapping on the way in) - rides with this launch: its first workgroups
+      // work the list off beside the float32 rows (mp_body_id_lead) instead of a kernel of its own doing so later.
+      MpLead lead;
+      std::memset(&lead, 0, sizeof lead);
+      mp_ctx::HardSlot* rider = pick_rider(ctx, sp->id_hard[ftip ? 1 : 0], hs);
+      if (rider) {
+        lead.C = rider->C; lead.q = rider->q; lead.qd = rider->qd; lead.qdd = rider->qdd; lead.tau = rider->tau; lead.rows = rider->nrows;
+        lead.blocks = std::min(hard_pass_blocks((long)rider->nrows), 512u);
       }
-      if (done == rows) return hard_pass();
-      const long off = done * model->d.n;  // the last rows (< 64): per-lane rows
-      const float *q2 = q + off, *qd2 = qd + off, *qdd2 = qdd + off;
-      float* tau2 = tau + off;
-      long left = rows - done;
-      cc.hard_row_base = (unsigned)done;
-      void* args[] = {&cc, &q2, &qd2, &qdd2, &tau2, &left};
-      if (int rc = launch_spec(ctx, sp->id_s[ftip ? 1 : 0], left, args)) return rc;
-      return hard_pass();
+      const unsigned grid = (unsigned)(rows64 / MP_JIT_ID_CO_BLOCK) + lead.blocks;
+      void* args[] = {&cc, &q, &qd, &qdd, &tau, &rows64, &lead};
+      HIP_TRY(hipModuleLaunchKernel(sp->id_co[ftip ? 1 : 0], grid, 1, 1, MP_JIT_ID_CO_BLOCK, 1, 1, 0, ctx->compute, args, nullptr));
+      if (rider) { rider->busy = false; rider->orphan = false; }   // its pass is enqueued: the slot is free for the next launch
+      done = rows64;
     }
+    if (done == rows) return hard_pass();
+    const long off = done * model->d.n;  // the last rows (< 64): per-lane rows
+    const float *q2 = q + off, *qd2 = qd + off, *qdd2 = qdd + off;
+    float* tau2 = tau + off;
+    long left = rows - done;
+    cc.hard_row_base = (unsigned)done;
+    void* args[] = {&cc, &q2, &qd2, &qdd2, &tau2, &left};
+    if (int rc = launch_spec(ctx, sp->id_s[ftip ? 1 : 0], left, args)) return rc;
+    return hard_pass();
   }
   {  // generic: one row per lane, device-resident model (a capture's first use uploads it outside the graph)
     const MpModel<float>* dm = nullptr;
