@@ -351,6 +351,38 @@ def test_bench_parity_rules_and_line_shape():
 
     entry, hung = bench.bench_strong("c4", argparse.Namespace(no_specialize=False), sharding.ShardInfo(0, 1, 0), one, _NoDevice(), {})
     assert hung is False and "no device in this test" in entry["error"] and entry["scaling"] == "strong"
+    # the cold window's three figures and the clock pass on a stand-in context: event times are scripted, the arithmetic is bench's
+    class _Ev:
+        def __init__(self, ctx): self.ctx, self.t = ctx, None
+        def record(self): self.t = self.ctx.now
+        def elapsed_ms_since(self, other): return self.t - other.t
+        def destroy(self): pass
+
+    class _FakeCtx:
+        """a launch costs 0.07 ms, the first one after a sleep 0.05 ms more (the wake-up)"""
+        def __init__(self): self.now, self.cold, self.sampling = 0.0, True, False
+        def event(self): return _Ev(self)
+        def synchronize(self): pass
+        def launch(self):
+            self.now += 0.07 + (0.05 if self.cold else 0.0)
+            self.cold = False
+        def clock_sample_begin(self, ms): assert ms > 0; self.sampling = True
+        def clock_sample_end(self): assert self.sampling; self.sampling = False; return 1.7e9, 0.3
+
+    fake = _FakeCtx()
+    real_sleep = bench.time.sleep
+    bench.time.sleep = lambda s_: setattr(fake, "cold", True)     # (no half seconds of waiting in the suite)
+    try:
+        cold = bench.cold_figures(fake, fake.launch, 5)
+    finally:
+        bench.time.sleep = real_sleep
+    assert abs(cold["first_launch_ms"] - 0.12) < 1e-12 and abs(cold["launch_period_ms_after_first"] - 0.07) < 1e-12
+    assert abs(cold["kernel_ms_cold"] - (0.12 + 4 * 0.07) / 5) < 1e-12 and cold["clock_hz"] == 1.7e9 and cold["launches"] == 5
+    cf = bench.cold_with_frac(cold, 393216000)
+    assert abs(cf["frac_after_first"] - 393216000 / 0.07e-3 / 1e9 / 8000.0) < 1e-9 and "what" in cf
+    clk = bench.sampled_clock(fake, fake.launch, 50, 0.07)
+    assert clk["hz"] == 1.7e9 and abs(clk["kernel_ms_while_sampling"] - 0.07) < 1e-9
+    assert "error" in bench.sampled_clock(object(), fake.launch, 5, 0.07)    # a diagnostic never raises
     # the "configs" entry
     full = {"metric": "m", "value": 1.0, "unit": "u", "ms_per_step": 0.1, "steps": 5, "dtype": "f32",
             "config": {"workload": "w", "kernel_variant": "generic"},
