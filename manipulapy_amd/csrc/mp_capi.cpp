@@ -667,7 +667,9 @@ int launch_id(mp_ctx* ctx, const mp_model* model, const MpCall<float>& c, bool f
       lead.C = rider->C; lead.q = rider->q; lead.qd = rider->qd; lead.qdd = rider->qdd; lead.tau = rider->tau; lead.rows = rider->nrows;
       lead.blocks = std::min((hard_pass_blocks((long)rider->nrows) + 3u) / 4u, 128u);   // 256-lane workgroups
     }
-    HIP_TRY(mpk_id_dm(ctx->compute, dm, model->d.n, cc, ftip, q, qd, qdd, tau, rows, lead));
+    bool all_rev = true;   // revolute joints only: the kernel instance without the revolute / prismatic blend (csrc/mp_model.h, MpModelRev)
+    for (int i = 0; i < model->d.n; ++i) all_rev = all_rev && model->f.j[i].rev == 1.0f;
+    HIP_TRY(mpk_id_dm(ctx->compute, dm, model->d.n, cc, ftip, q, qd, qdd, tau, rows, lead, all_rev));
     if (rider) { rider->busy = false; rider->orphan = false; }
     if (!hs) return MP_OK;
     const int n = model->d.n;

@@ -260,6 +260,14 @@ __device__ __forceinline__ const __attribute__((address_space(4))) MpJoint<doubl
   asm volatile("" : "+s"(p));
   return p->j[i];
 }
+typedef const __attribute__((address_space(4))) MpModelRev<float> MpModelRevConstF;   // (revolute joints only: mp_model.h)
+template <> struct MpAllRevolute<MpModelRevConstF> { static constexpr bool value = true; };
+template <> struct MpAllRevolute<__attribute__((address_space(4))) MpModelRev<float>> { static constexpr bool value = true; };   // (`const MT&` deduces MT without the const)
+__device__ __forceinline__ const __attribute__((address_space(4))) MpJoint<float>& mp_joint_of(MpModelRevConstF& M, int i) {
+  MpModelRevConstF* p = &M;
+  asm volatile("" : "+s"(p));
+  return p->j[i];
+}
 #endif
 
 // ------------------------------------------------------------------------------ axis-aligned steps
@@ -338,17 +346,19 @@ struct MpJointState {
 // constant-address-space pointer (persistent kernels re-read it with scalar loads every iteration).
 template <typename T, int N, typename MT>
 MP_HD void mp_joint_state(const MT& M, const T (&q)[N], MpJointState<T, N>& js) {
+  constexpr bool kAllRev = MpAllRevolute<MT>::value;   // (the model type says: revolute joints only - `rev` is 1)
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     const auto& J = mp_joint_of(M, i);
-    const T qr = J.rev * q[i];
+    const T qr = kAllRev ? q[i] : J.rev * q[i];
     // sin / cos of off + q through the constant rotation (co, so) - see MpJoint: exact for right-angle offsets (a swap / a sign,
     // folded away in the robot-specialised kernels), one rounding per product otherwise; q is never added to anything first
     T s0, c0;
     mp_sincos(qr, s0, c0);
     js.s[i] = s0 * J.co + c0 * J.so;
     js.c[i] = c0 * J.co - s0 * J.so;
-    js.d[i] = J.d + (q[i] - qr);
+    if (kAllRev) js.d[i] = MpTraits<T>::splat(J.d);
+    else js.d[i] = J.d + (q[i] - qr);
   }
 }
 
@@ -419,17 +429,27 @@ MP_HD void mp_rnea_impl(const MT& M, const typename MpTraits<T>::S (&a0)[3], con
     if (HAS_FTIP) mp_force_down_B(c, s, d, tnx, tny, tnz, tfx, tfy, tfz);
 
     // joint motion: S = [z;0] (revolute) or [0;z] (prismatic)
-    const T qdr = J.rev * qd[i], qdp = qd[i] - qdr;
-    const T ar = J.rev * qdd[i], ap = qdd[i] - ar;
-    wz += qdr;
-    vz += qdp;
-    // dV += S qdd + V x S qd
-    dwx += qdr * wy;
-    dwy -= qdr * wx;
-    dwz += ar;
-    dvx += qdr * vy + qdp * wy;
-    dvy -= qdr * vx + qdp * wx;
-    dvz += ap;
+    if (MpAllRevolute<MT>::value) {   // (compile time: the model type says revolute joints only)
+      const T qdr = qd[i], ar = qdd[i];
+      wz += qdr;
+      dwx += qdr * wy;
+      dwy -= qdr * wx;
+      dwz += ar;
+      dvx += qdr * vy;
+      dvy -= qdr * vx;
+    } else {
+      const T qdr = J.rev * qd[i], qdp = qd[i] - qdr;
+      const T ar = J.rev * qdd[i], ap = qdd[i] - ar;
+      wz += qdr;
+      vz += qdp;
+      // dV += S qdd + V x S qd
+      dwx += qdr * wy;
+      dwy -= qdr * wx;
+      dwz += ar;
+      dvx += qdr * vy + qdp * wy;
+      dvy -= qdr * vx + qdp * wx;
+      dvz += ap;
+    }
 
     // momentum P = G V = [Io w + h x v ; m v - h x w]
     const T pnx = J.Ixx * wx + J.Ixy * wy + J.Ixz * wz + (J.hy * vz - J.hz * vy);
@@ -439,6 +459,9 @@ MP_HD void mp_rnea_impl(const MT& M, const typename MpTraits<T>::S (&a0)[3], con
     const T pfy = J.m * vy - (J.hz * wx - J.hx * wz);
     const T pfz = J.m * vz - (J.hx * wy - J.hy * wx);
     // F = G dV + [w x Pn + v x Pf ; w x Pf]
+    // (Round 6 tried per-link wave-uniform branches on constants that vanish - products of inertia, the first moment: 12 + 30
+    // instructions a link - in the generic kernels: the branchy code spills under their 96-VGPR cap, c2 0.103 -> 0.178 ms, c4 x 7;
+    // profiles/r06_generic_ab.txt.  The robot-specialised programs fold those constants anyway.)
     fnx[i] = J.Ixx * dwx + J.Ixy * dwy + J.Ixz * dwz + (J.hy * dvz - J.hz * dvy) + (wy * pnz - wz * pny) + (vy * pfz - vz * pfy);
     fny[i] = J.Ixy * dwx + J.Iyy * dwy + J.Iyz * dwz + (J.hz * dvx - J.hx * dvz) + (wz * pnx - wx * pnz) + (vz * pfx - vx * pfz);
     fnz[i] = J.Ixz * dwx + J.Iyz * dwy + J.Izz * dwz + (J.hx * dvy - J.hy * dvx) + (wx * pny - wy * pnx) + (vx * pfy - vy * pfx);
@@ -455,7 +478,8 @@ MP_HD void mp_rnea_impl(const MT& M, const typename MpTraits<T>::S (&a0)[3], con
 #pragma unroll
   for (int i = N - 1; i >= 0; --i) {
     const auto& J = mp_joint_of(M, i);
-    tau[i] = J.rev * fnz[i] + (S(1) - J.rev) * ffz[i];
+    if (MpAllRevolute<MT>::value) tau[i] = fnz[i];
+    else tau[i] = J.rev * fnz[i] + (S(1) - J.rev) * ffz[i];
     sc.joint(i, fnx[i], fny[i], fnz[i], ffx[i], ffy[i], ffz[i]);
     if (i > 0) {
       T nx = fnx[i], ny = fny[i], nz = fnz[i], fx = ffx[i], fy = ffy[i], fz = ffz[i];

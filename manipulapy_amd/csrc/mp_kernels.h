@@ -14,8 +14,9 @@ hipError_t mpk_id(hipStream_t s, const MpModel<T>& M, const MpCall<T>& C, bool f
                   const T* qdd, T* tau, long rows);
 
 // float32, one row per lane, the model read through a pointer to a device-resident copy (scalar loads joint by joint)
+// all_revolute: every joint of the model is revolute (rev == 1) - the kernel instance that folds the revolute / prismatic blend
 hipError_t mpk_id_dm(hipStream_t s, const MpModel<float>* d_model, int n, const MpCall<float>& C, bool ftip, const float* q,
-                     const float* qd, const float* qdd, float* tau, long rows, const MpLead& L);
+                     const float* qd, const float* qdd, float* tau, long rows, const MpLead& L, bool all_revolute);
 
 // the float64 pass over the rows the kernel above handed over (C.hard_rows / hard_ctrl), `blocks` blocks of 64 lanes
 hipError_t mpk_id_hard(hipStream_t s, const MpModel<float>* d_model, int n, const MpCall<float>& C, bool ftip, const float* q,

@@ -56,6 +56,14 @@ struct MpModelT {
 };
 template <typename T> using MpModel = MpModelT<T, MP_MAX_DOF>;     // what the unrolled kernels take by value
 template <typename T> using MpBigModel = MpModelT<T, MP_BIG_DOF>;  // what the looped kernels read through a pointer
+// The same model SAID to hold revolute joints only - every arm of the reference's database but the ones with a gripper slide.  The
+// generic (not robot-specialised) float32 inverse-dynamics kernel is instantiated a second time on this type and folds `rev` to 1:
+// no revolute / prismatic blend of q, qd, qdd and tau, 13 VALU instructions per joint of ~190 (c2 generic 0.107 -> see DESIGN.md).
+// Same layout: a pointer to an MpModel<T> whose joints are all revolute may be read as one (the launcher checks).
+template <typename T> struct MpModelRev : MpModelT<T, MP_MAX_DOF> {};
+template <typename MT> struct MpAllRevolute { static constexpr bool value = false; };
+template <typename T> struct MpAllRevolute<MpModelRev<T>> { static constexpr bool value = true; };
+template <typename T> struct MpAllRevolute<const MpModelRev<T>> { static constexpr bool value = true; };
 
 // Per-call constants derived on the host in fp64 (gravity / tip wrench seen from link frame 1's parent).
 template <typename T>
