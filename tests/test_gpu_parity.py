@@ -2580,3 +2580,41 @@ def test_in_place_float64_rows_without_a_list(tables):
     """ % (ROOT, ROOT))
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MANIPULAPY_HIP_HARD_PASS="0"), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+@pytest.mark.gpu
+def test_bench_n2_line_end_to_end_with_two_ranks_sharing_the_gpu():
+    """The N > 1 bench line has never met a multi-GPU node (the pool gives one GPU; the driver's 8-GPU run decides).  What CAN run
+    here is its whole flow with two ranks sharing this GPU (MANIPULAPY_BENCH_SHARE_DEVICE=1; the figures mean nothing, the flow
+    does): launcher -> gloo rendezvous -> weak-scaled headline with rank 0's host legs (CPU oracle timed, parity on its own shard,
+    streaming probe) while rank 1 waits in the barrier -> both strong-scaled entries with THEIR oracle samples -> the RCCL phases,
+    which either run or - RCCL refuses two ranks on one device - are reported in `collectives` without costing the line or the exit
+    code (an N > 1 line without cpu_baseline / parity is unmeasured)."""
+    import json
+    import subprocess
+    import sys
+
+    env = dict(os.environ, PYTHONPATH=ROOT, MANIPULAPY_BENCH_SHARE_DEVICE="1", MANIPULAPY_BENCH_GATHER_TIMEOUT="90")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2"], env=env,
+                         capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0 and res.stdout.strip(), f"rc {res.returncode}\n{res.stdout[-1500:]}\n{res.stderr[-3000:]}"
+    line = json.loads(res.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0 and list(line)[-1] == "summary"
+    # the headline's host legs: rank 0, its own shard
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["value"] > 0 and "rank 0 of 2" in line["cpu_baseline"]["where"]
+    assert line["parity_sample"]["ok"] and line["roofline"]["parity"]["rows_checked"] > 0 and line["roofline"]["parity"]["sets_checked"] == 1
+    assert line["roofline"]["frac_of_probe"] > 0 and "elements_over_pure_rel" in line["roofline"]["parity"]
+    # the strong-scaled entries: compute-only figures + an oracle sample each, whatever became of the collectives
+    for name, key in (("c4_strong", "rows"), ("c5_strong", "trajectories")):
+        e = line["configs"][name]
+        assert "error" not in e, e.get("error")
+        assert e["scaling"] == "strong" and e["n_gpus"] == 2 and e["value"] > 0 and sum(e["shard"]["trajectories_of_rank"]) == e["shard"]["B_total"]
+        assert e["parity_sample"]["ok"] and e["roofline"]["parity"]["ok"] and e["roofline"]["parity"]["rows_checked"] > 0
+        assert e["cpu_baseline"]["value"] > 0 and e["roofline"]["frac_of_probe"] > 0
+        assert line["summary"][name]["parity_ok"] is True
+    c = line["collectives"]
+    assert c["ran"] or set(c["failed_in"]) <= {"c2", "c4_strong", "c5_strong"}
+    if c["ran"]:   # a node where RCCL accepts the two ranks: then the reassembly must have been verified
+        assert line["verified"] and all(line["configs"][k]["verified"] for k in ("c4_strong", "c5_strong"))
