@@ -99,6 +99,20 @@ def oracle_tables(ref, robot):
                            B=t["B_list"].astype(np.float64), name=robot)
 
 
+def host_threads():
+    """Threads for the CPU oracle (OpenMP): every core this process may run on.  Passed explicitly because the launcher of an
+    N > 1 run - torch.distributed.run - exports OMP_NUM_THREADS=1 to every worker, which is right for N workers computing at once
+    and wrong here: only rank 0 runs the oracle, the other ranks wait in a barrier (first seen in the two-rank rehearsal: the
+    headline's baseline ran on one thread and covered 0.48 M of 4.1 M rows).  MANIPULAPY_BENCH_CPU_THREADS overrides."""
+    e = os.environ.get("MANIPULAPY_BENCH_CPU_THREADS")
+    if e:
+        return max(1, int(e))
+    try:
+        return max(1, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        return max(1, os.cpu_count() or 1)
+
+
 def oracle_rows_in(tab, q, qd, qdd, budget_s):
     """How many of the rows the C oracle evaluates in `budget_s` seconds on this box's cores.  Two probes: 2048 rows start the OpenMP
     threads (on 128 threads that call IS the start-up: round 4 sized the headline's sample from it and stopped at 1.09 M of 4.1 M
@@ -107,10 +121,10 @@ def oracle_rows_in(tab, q, qd, qdd, budget_s):
 
     total = q.shape[0]
     probe = min(2048, total)
-    c_oracle.inverse_dynamics_rows(tab, q[:probe], qd[:probe], qdd[:probe])
+    c_oracle.inverse_dynamics_rows(tab, q[:probe], qd[:probe], qdd[:probe], nthreads=host_threads())
     probe2 = min(total, 65536)
     t0 = time.perf_counter()
-    c_oracle.inverse_dynamics_rows(tab, q[:probe2], qd[:probe2], qdd[:probe2])
+    c_oracle.inverse_dynamics_rows(tab, q[:probe2], qd[:probe2], qdd[:probe2], nthreads=host_threads())
     rate = probe2 / max(time.perf_counter() - t0, 1e-6)
     return int(min(total, max(probe2, rate * budget_s)))
 
@@ -127,7 +141,7 @@ def cpu_baseline(robot, q, qd, qdd, budget_s=15.0):
     q, qd, qdd = (np.ascontiguousarray(x, dtype=np.float64) for x in (q, qd, qdd))
     rows = oracle_rows_in(tab, q, qd, qdd, budget_s)
     t0 = time.perf_counter()
-    tau, threads = c_oracle.inverse_dynamics_rows(tab, q[:rows], qd[:rows], qdd[:rows])
+    tau, threads = c_oracle.inverse_dynamics_rows(tab, q[:rows], qd[:rows], qdd[:rows], nthreads=host_threads())
     dt = time.perf_counter() - t0
     out = {"value": rows * n / dt, "unit": "joint-timesteps/s", "cores": threads, "kind": "port",
            "sample": f"first {rows} rows of the benchmark input, {dt:.1f} s on {threads} OpenMP thread(s); C restatement of the "
@@ -391,7 +405,7 @@ def id_sensitivity(tab, q, qd, qdd):
     def sens(rows):
         n = q.shape[1]
         x = np.concatenate([q[rows], qd[rows], qdd[rows]], axis=1).astype(np.float32)
-        f = lambda y: c_oracle.inverse_dynamics_rows(tab, *(np.ascontiguousarray(y[:, k * n:(k + 1) * n], dtype=np.float64) for k in range(3)))[0]
+        f = lambda y: c_oracle.inverse_dynamics_rows(tab, *(np.ascontiguousarray(y[:, k * n:(k + 1) * n], dtype=np.float64) for k in range(3)), nthreads=host_threads())[0]
         base = f(x)
         S = np.zeros_like(base)
         for k in range(3 * n):
@@ -413,7 +427,7 @@ def oracle_id_rows(robot, q, qd, qdd, budget_s):
     tab = oracle_tables(ref, robot)
     q, qd, qdd = (np.ascontiguousarray(x, dtype=np.float64) for x in (q, qd, qdd))
     rows = oracle_rows_in(tab, q, qd, qdd, budget_s)
-    return c_oracle.inverse_dynamics_rows(tab, q[:rows], qd[:rows], qdd[:rows])[0], tab
+    return c_oracle.inverse_dynamics_rows(tab, q[:rows], qd[:rows], qdd[:rows], nthreads=host_threads())[0], tab
 
 
 FTIP_REF = np.array([1.0, -2.0, 0.5, 3.0, -1.5, 0.75])  # the reference's own non-zero wrench (tests/test_dynamics_golden.py:145)
@@ -437,13 +451,13 @@ def fd_host_leg(robot, th0, dth0, taumat, Fm, g, pos, vel, acc, budget, max_traj
     x64 = [v.astype(np.float64) for v in (th0[:B], dth0[:B], taumat[:B], Fm[:B])]
     probe = min(B, 2048)
     tc = time.perf_counter()
-    c_oracle.fd_trajectory(tab, x64[0][:probe], x64[1][:probe], x64[2][:probe], g, x64[3][:probe], dt, 1)
+    c_oracle.fd_trajectory(tab, x64[0][:probe], x64[1][:probe], x64[2][:probe], g, x64[3][:probe], dt, 1, nthreads=host_threads())
     rate = probe / max(time.perf_counter() - tc, 1e-6)
     nbt = int(min(B, max(probe, rate * budget)))
     if max_traj:
         nbt = min(nbt, int(max_traj))
     tc = time.perf_counter()
-    wp, wv, wa, threads = c_oracle.fd_trajectory(tab, x64[0][:nbt], x64[1][:nbt], x64[2][:nbt], g, x64[3][:nbt], dt, 1)
+    wp, wv, wa, threads = c_oracle.fd_trajectory(tab, x64[0][:nbt], x64[1][:nbt], x64[2][:nbt], g, x64[3][:nbt], dt, 1, nthreads=host_threads())
     dtc = time.perf_counter() - tc
     base = {"value": nbt * N * n / dtc, "unit": "joint-timesteps/s", "cores": threads, "kind": "port",
             "sample": f"all {N} steps of the first {nbt} trajectories of the benchmark input, {dtc:.1f} s on {threads} "
@@ -464,7 +478,7 @@ def fd_host_leg(robot, th0, dth0, taumat, Fm, g, pos, vel, acc, budget, max_traj
     p0 = pos[:nd, :-1].reshape(-1, n).astype(np.float64); v0 = vel[:nd, :-1].reshape(-1, n).astype(np.float64)
     t2 = np.stack([np.zeros_like(x64[2][:nd, 1:]), x64[2][:nd, 1:]], axis=2).reshape(-1, 2, n)
     f2 = np.stack([np.zeros_like(x64[3][:nd, 1:]), x64[3][:nd, 1:]], axis=2).reshape(-1, 2, 6)
-    op, ov, oa, _ = c_oracle.fd_trajectory(tab, p0, v0, t2, g, f2, dt, 1)
+    op, ov, oa, _ = c_oracle.fd_trajectory(tab, p0, v0, t2, g, f2, dt, 1, nthreads=host_threads())
     defect = {}
     for name, got, want in (("positions", pos[:nd, 1:], op[:, 1]), ("velocities", vel[:nd, 1:], ov[:, 1]), ("accelerations", acc[:nd, 1:], oa[:, 1])):
         e = np.abs(got.reshape(-1, n).astype(np.float64) - want)

@@ -341,6 +341,19 @@ def test_bench_parity_rules_and_line_shape():
     from manipulapy_amd import sharding
     one = sharding.HostGather(sharding.ShardInfo(0, 1, 0))
     assert bench.agree_hung(one, False, {}) is False and bench.agree_hung(one, True, {}) is True
+    # the oracle's thread count is bench's own choice, not the launcher's: torch.distributed.run exports OMP_NUM_THREADS=1
+    import os as _os
+    saved = _os.environ.get("MANIPULAPY_BENCH_CPU_THREADS")
+    _os.environ["MANIPULAPY_BENCH_CPU_THREADS"] = "3"
+    try:
+        assert bench.host_threads() == 3
+        assert c_oracle.inverse_dynamics_rows(tab, q.astype(np.float64), qd.astype(np.float64), qdd.astype(np.float64), nthreads=bench.host_threads())[1] == 3
+    finally:
+        if saved is None:
+            _os.environ.pop("MANIPULAPY_BENCH_CPU_THREADS")
+        else:
+            _os.environ["MANIPULAPY_BENCH_CPU_THREADS"] = saved
+    assert bench.host_threads() >= 1
     # a strong-scaled entry whose set-up fails on a rank is an entry with "error" (agreed over gloo, so that no rank waits in the
     # barriers that follow), not an exception
     import argparse
