@@ -99,18 +99,38 @@ def oracle_tables(ref, robot):
                            B=t["B_list"].astype(np.float64), name=robot)
 
 
+def cpu_quota():
+    """CPUs' worth of time the container may use (cgroup v2 cpu.max / v1 cfs quota), or None without a quota."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if quota == "max" else float(quota) / float(period)
+    except Exception:
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        return None if q <= 0 else q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+    except Exception:
+        return None
+
+
 def host_threads():
-    """Threads for the CPU oracle (OpenMP): every core this process may run on.  Passed explicitly because the launcher of an
-    N > 1 run - torch.distributed.run - exports OMP_NUM_THREADS=1 to every worker, which is right for N workers computing at once
-    and wrong here: only rank 0 runs the oracle, the other ranks wait in a barrier (first seen in the two-rank rehearsal: the
-    headline's baseline ran on one thread and covered 0.48 M of 4.1 M rows).  MANIPULAPY_BENCH_CPU_THREADS overrides."""
+    """Threads for the CPU oracle (OpenMP), passed explicitly for two reasons.  (1) The launcher of an N > 1 run -
+    torch.distributed.run - exports OMP_NUM_THREADS=1 to every worker, which is right for N workers computing at once and wrong
+    here: only rank 0 runs the oracle, the other ranks wait in a barrier (the two-rank rehearsal's baseline ran on one thread and
+    covered 0.48 M of 4.1 M rows).  (2) The OpenMP default is one thread per VISIBLE core; a GPU box shows 256 and grants a cgroup
+    quota of 16 CPUs' worth of time: 256 threads 0.27 M rows/s, 128: 0.57, 64: 0.68, 32: 0.64 (UR5, 400 k rows).  So: every core
+    this process may run on, but at most four threads per CPU of the quota.  MANIPULAPY_BENCH_CPU_THREADS overrides."""
     e = os.environ.get("MANIPULAPY_BENCH_CPU_THREADS")
     if e:
         return max(1, int(e))
     try:
-        return max(1, len(os.sched_getaffinity(0)))
+        n = len(os.sched_getaffinity(0))
     except AttributeError:
-        return max(1, os.cpu_count() or 1)
+        n = os.cpu_count() or 1
+    q = cpu_quota()
+    if q:
+        n = min(n, int(np.ceil(4 * q)))
+    return max(1, n)
 
 
 def oracle_rows_in(tab, q, qd, qdd, budget_s):
@@ -143,7 +163,9 @@ def cpu_baseline(robot, q, qd, qdd, budget_s=15.0):
     t0 = time.perf_counter()
     tau, threads = c_oracle.inverse_dynamics_rows(tab, q[:rows], qd[:rows], qdd[:rows], nthreads=host_threads())
     dt = time.perf_counter() - t0
+    quota = cpu_quota()
     out = {"value": rows * n / dt, "unit": "joint-timesteps/s", "cores": threads, "kind": "port",
+           "host": {"visible_cores": os.cpu_count(), "cgroup_cpu_quota": quota, "threads": threads},
            "sample": f"first {rows} rows of the benchmark input, {dt:.1f} s on {threads} OpenMP thread(s); C restatement of the "
                      f"reference algorithm (the reference's own NumPy code runs ~40-80 ms per row, BASELINE.md)"}
     out.update(reference_numpy_rate(robot))
@@ -169,11 +191,12 @@ def cpu_twin_rate(model, q, qd, qdd, dtype):
     from manipulapy_amd import _hip
 
     rows = min(q.shape[0], 1 << 20)
-    _hip.cpu_id_trajectory(model, q[:4096], qd[:4096], qdd[:4096], dtype=dtype)  # thread start-up
+    nt = host_threads()
+    _hip.cpu_id_trajectory(model, q[:4096], qd[:4096], qdd[:4096], dtype=dtype, nthreads=nt)  # thread start-up
     t0 = time.perf_counter()
-    _hip.cpu_id_trajectory(model, q[:rows], qd[:rows], qdd[:rows], dtype=dtype)
+    _hip.cpu_id_trajectory(model, q[:rows], qd[:rows], qdd[:rows], dtype=dtype, nthreads=nt)
     dt = time.perf_counter() - t0
-    return {"value": rows * q.shape[1] / dt, "unit": "joint-timesteps/s", "cores": _hip.cpu_threads(rows),
+    return {"value": rows * q.shape[1] / dt, "unit": "joint-timesteps/s", "cores": nt,
             "sample": f"first {rows} rows, {dt * 1e3:.1f} ms; mp_id_trajectory_cpu (the registry's CPU launcher under the NumPy backend)"}
 
 
