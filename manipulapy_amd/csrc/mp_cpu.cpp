@@ -5,8 +5,11 @@
 // `gpu_launcher if _cuda_routing_enabled() else cpu_launcher`.  They are NOT a fallback of the GPU path - a failing
 // or missing GPU under the "hip" backend raises - and they are the product's own analytic recursion, not the test
 // suite's restatement of the reference's 1 + 2n mass-matrix algorithm.  No HIP call is made here.
+#include <sched.h>
+
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <thread>
@@ -25,12 +28,39 @@ const double kG[3] = {0.0, 0.0, -9.81};
 
 int fail(const char* msg) { return mp_set_error(MP_ERR_INVALID, msg); }
 
+// Threads a launcher takes when the caller names none: every core this process may run on (its affinity mask) - but a container is
+// often SHOWN more cores than it is granted time on (the MI355X boxes of this project: 256 visible, a cgroup quota of 16 CPUs), and
+// one thread per visible core then loses to a fraction of them (the C oracle of bench.py: 256 threads 0.27 M rows/s, 64: 0.68): at
+// most four threads per CPU of a cgroup quota (v2 cpu.max, v1 cfs_quota_us / cfs_period_us).
+int default_threads() {
+  static const int n = [] {
+    int have = 0;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) have = CPU_COUNT(&set);
+    if (have <= 0) have = (int)std::thread::hardware_concurrency();
+    if (have <= 0) have = 1;
+    double quota = 0;
+    if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+      char q[32];
+      long period = 0;
+      if (std::fscanf(f, "%31s %ld", q, &period) == 2 && std::strcmp(q, "max") != 0 && period > 0) quota = std::atof(q) / (double)period;
+      std::fclose(f);
+    } else {
+      long q = 0, period = 0;
+      if (FILE* a = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (std::fscanf(a, "%ld", &q) != 1) q = 0; std::fclose(a); }
+      if (FILE* b = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (std::fscanf(b, "%ld", &period) != 1) period = 0; std::fclose(b); }
+      if (q > 0 && period > 0) quota = (double)q / (double)period;
+    }
+    if (quota > 0) have = std::min(have, std::max(1, (int)std::ceil(4.0 * quota)));
+    return have;
+  }();
+  return n;
+}
 int thread_count(int64_t items, int64_t grain, int nthreads) {
   int want = nthreads;
   if (want <= 0) {
     if (const char* e = getenv("MANIPULAPY_CPU_THREADS")) want = atoi(e);
-    if (want <= 0) want = (int)std::thread::hardware_concurrency();
-    if (want <= 0) want = 1;
+    if (want <= 0) want = default_threads();
   }
   const int64_t by_work = (items + grain - 1) / grain;
   return (int)std::max<int64_t>(1, std::min<int64_t>(want, by_work));
