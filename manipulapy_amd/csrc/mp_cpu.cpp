@@ -30,7 +30,7 @@ int fail(const char* msg) { return mp_set_error(MP_ERR_INVALID, msg); }
 
 // Threads a launcher takes when the caller names none: every core this process may run on (its affinity mask) - but a container is
 // often SHOWN more cores than it is granted time on (the MI355X boxes of this project: 256 visible, a cgroup quota of 16 CPUs), and
-// one thread per visible core then loses to a fraction of them (the C oracle of bench.py: 256 threads 0.27 M rows/s, 64: 0.68): at
+// one thread per visible core then loses to a fraction of them (the CPU baseline of bench.py: 256 threads 0.27 M rows/s, 64: 0.68): at
 // most four threads per CPU of a cgroup quota (v2 cpu.max, v1 cfs_quota_us / cfs_period_us).
 int default_threads() {
   static const int n = [] {
