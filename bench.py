@@ -210,7 +210,19 @@ def emit(result):
     except Exception:
         pass
     sys.stdout.flush()
-    print(json.dumps(result), flush=True)
+
+    def strict(x):   # NaN / inf are not JSON: a failed comparison's `inf` must not cost a strict parser the whole line
+        if isinstance(x, float):
+            return x if np.isfinite(x) else None
+        if isinstance(x, dict):
+            return {k: strict(v) for k, v in x.items()}
+        if isinstance(x, (list, tuple)):
+            return [strict(v) for v in x]
+        if isinstance(x, np.generic):
+            return strict(x.item())
+        return x
+
+    print(json.dumps(strict(result), allow_nan=False), flush=True)
 
 
 def device_copy_probe(ctx):
