@@ -320,7 +320,7 @@ def cold_figures(ctx, step, ncold, sample_clock=True):
         # the shader clock of such a window, from a second one (the sampler's own dispatch would take the wake-up off the timed launches)
         try:
             time.sleep(0.5)
-            ctx.clock_sample_begin(max(0.3, 0.8 * tk))
+            ctx.clock_sample_begin(min(1500.0, max(0.3, 0.8 * tk)))
             for _ in range(ncold):
                 step()
             ctx.synchronize()
@@ -348,7 +348,7 @@ def sampled_clock(ctx, step, steps, kern_ms):
     try:
         ctx.synchronize()
         a, b = ctx.event(), ctx.event()
-        ctx.clock_sample_begin(max(0.3, 0.8 * steps * kern_ms))
+        ctx.clock_sample_begin(min(1500.0, max(0.3, 0.8 * steps * kern_ms)))   # (the sampler takes at most 2 s)
         a.record()
         for _ in range(steps):
             step()
