@@ -1295,6 +1295,7 @@ def compact(r):
     keep = ("metric", "value", "unit", "ms_per_step", "steps", "dtype")
     out = {k: r[k] for k in keep if k in r}
     out["workload"] = r["config"]["workload"]
+    out["ramp_ms"] = (r.get("setup") or {}).get("ramp_ms")
     out["kernel_variant"] = r["config"].get("kernel_variant")
     rl = r["roofline"]
     out["kernel"], out["kernel_ms"], out["kernel_ms_cold"] = rl["kernel"], rl["kernel_ms"], rl["kernel_ms_cold"]
@@ -1406,11 +1407,19 @@ def bench_id(args, cfg, info, hg, ctx, model, t, props, headline):
         else:
             ctx.fk_jac_id(model, st["d_q"], st["d_qd"], st["d_qdd"], rows, st["d_T"], st["d_J"], st["d_tau"], dtype=dt_np)
 
+    # c3 is a power-capped kernel (22.5 GB per launch at ~1370 W of the 1400 W package limit): 60 ms into the load the power controller
+    # is anywhere between its boost and its settled state - 3.72 and 4.01 ms in two runs on ONE box, 3.63 - 4.17 over six.  Held for
+    # 16 s three boxes all read 3.96 - 3.97 ms (profiles/r06_c3_power_probe.txt); how fast a box gets there differs (after 1 s: 3.73
+    # on two boxes, 4.04 - 4.06 on a third).  Its ramp is a second long - a compromise between a settled figure and a default line
+    # that finishes in a minute; DESIGN.md quotes the 16 s figure beside the line's.  The short kernels do not move (c2: K = 1000
+    # equals K = 50).
+    ramp_ms = max(args.ramp_ms, 1000.0) if cfg["op"] == "fk_jac_id" else args.ramp_ms
+
     def timed(fn_after_step=None, step_fn=None):
         """W warm-up steps, then exactly K timed steps between barrier + device sync on both sides.
         Returns (max-over-ranks wall seconds, mean kernel ms from HIP events on the launch stream)."""
         do = step_fn or step
-        ramp(ctx, step, args.ramp_ms)
+        ramp(ctx, step, ramp_ms)
         for _ in range(args.warmup):
             do()
             if fn_after_step:
@@ -1473,6 +1482,8 @@ def bench_id(args, cfg, info, hg, ctx, model, t, props, headline):
     kern_ms_cold = cold["kernel_ms_cold"]
 
     # ---- this box's streaming rate for the configuration's own byte mix and size, right before the timed region
+    if cfg["op"] == "fk_jac_id":
+        ramp(ctx, step, ramp_ms)           # (the probe of a power-capped configuration is taken in the settled state too)
     probe = mix_probe(ctx, cfg, n, rows)   # (every rank, on its own GPU: the ranks stay in step; rank 0's is reported)
 
     # ---- the timed step: every rank evaluates its own shard; the path has no exchange step, so no collective
@@ -1607,7 +1618,7 @@ def bench_id(args, cfg, info, hg, ctx, model, t, props, headline):
                      if args.event_stride > 0 else
                      "HIP events on the launch stream around the K launches of the timed region, / K (launch period: duration + dispatch gap)"},
         "launch": "one hipGraph of K captured launches" if args.launch == "graph" else "one host call per step",
-        "setup": {"ramp_ms": args.ramp_ms, "what": "untimed launches before the W warm-up steps (clock ramp)"},
+        "setup": {"ramp_ms": ramp_ms, "what": "untimed launches before the W warm-up steps (clock / power ramp)"},
         "device": props["name"],
     }
     if clock is not None:
