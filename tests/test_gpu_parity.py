@@ -2618,3 +2618,81 @@ def test_bench_n2_line_end_to_end_with_two_ranks_sharing_the_gpu():
     assert c["ran"] or set(c["failed_in"]) <= {"c2", "c4_strong", "c5_strong"}
     if c["ran"]:   # a node where RCCL accepts the two ranks: then the reassembly must have been verified
         assert line["verified"] and all(line["configs"][k]["verified"] for k in ("c4_strong", "c5_strong"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("specialise", [False, True])
+def test_arrays_beyond_2_31_elements(specialise, tables):
+    """Maximum sizes: rows x n beyond 2^31 ELEMENTS (8.7 GB per float32 array; 288 GB of HBM hold far more), where a 32-bit index,
+    element offset or byte offset anywhere in the generation kernel, the inverse-dynamics kernels, the fused kernel, the row lists of
+    the float64 pass or the copies would wrap: UR5, B = 362 000 x N = 1000 = 3.62e8 rows = 2.17e9 elements per array.  Slices at the
+    start, on both sides of the 2^31st element, at 2^32 BYTES, and at the very end - of the generated histories against the oracle's
+    time scaling, and of tau (two-step and fused) against the pinned C oracle under the float32 bound; the flagged rows among them at
+    <= 0.2 x (their float64 pass found them through a list index beyond 2^28)."""
+    from manipulapy_amd import _hip
+    from oracle import c_oracle
+
+    tab = tables["ur5"]
+    lim = tab.joint_limits
+    n, B, N = 6, 362_000, 1000
+    rows = B * N
+    assert rows * n > 2**31 and rows < 2**32
+    ctx = _hip.HipContext(0)
+    bufs = []
+    try:
+        m = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee, lim)
+        if specialise:
+            ctx.specialize(m)
+        rng = np.random.default_rng(2031)
+        s_ = rng.uniform(lim[:, 0], lim[:, 1], (B, n)).astype(np.float32)
+        e_ = rng.uniform(lim[:, 0], lim[:, 1], (B, n)).astype(np.float32)
+        d_s, d_e = ctx.to_device(s_), ctx.to_device(e_)
+        nb = rows * n * 4
+        d_q, d_qd, d_qdd, d_tau, d_fused = (ctx.alloc(nb) for _ in range(5))
+        bufs += [d_s, d_e, d_q, d_qd, d_qdd, d_tau, d_fused]
+        ctx.batch_trajectory(m, d_s, d_e, B, N, 2.0, 5, d_q, d_qd, d_qdd)
+        ctx.id_trajectory(m, d_q, d_qd, d_qdd, rows, d_tau, dtype=np.float32)
+        ctx.traj_id_fused(m, d_s, d_e, B, N, 2.0, 5, d_fused)
+        ctx.synchronize()
+        K = 2048   # rows per slice
+        firsts = [0, (2**31 // n) - K // 2, (2**32 // (n * 4)) - K // 2, rows // 2 + 12345, rows - K]
+        for r0 in firsts:
+            def rows_of(buf):
+                out = np.empty((K, n), np.float32)
+                _hip._check(ctx.lib.mp_memcpy_d2h(ctx.handle, out.ctypes.data, buf.offset(r0 * n * 4), out.nbytes))
+                return out
+            q, qd, qdd, tau, fused = (rows_of(b_) for b_ in (d_q, d_qd, d_qdd, d_tau, d_fused))
+            # the generated rows: trajectory b, timestep t of every row of the slice, from the oracle's generator
+            b_idx, t_idx = np.divmod(np.arange(r0, r0 + K), N)
+            ub = np.unique(b_idx)
+            o = ref.batch_joint_trajectory(lim, s_[ub], e_[ub], 2.0, N, 5)
+            pick = (np.searchsorted(ub, b_idx), t_idx)
+            for got, key in ((q, "positions"), (qd, "velocities"), (qdd, "accelerations")):
+                want = o[key][pick]
+                assert np.abs(got - want).max() <= 2e-6 * max(1.0, float(np.abs(want).max())), (r0, key)
+            want = c_oracle.inverse_dynamics_rows(tab, q.astype(np.float64), qd.astype(np.float64), qdd.astype(np.float64))[0]
+            tol = 1e-4 * np.abs(want) + 5e-6 * np.abs(want).max(axis=1, keepdims=True) + 1e-12
+            flagged = _hip.cpu_id_row_precision(m, q, qd, qdd).astype(bool)
+            for name, got in (("two-step", tau), ("fused", fused)):
+                ratio = np.abs(got - want) / tol
+                assert np.isfinite(got).all() and ratio.max() <= 0.6, (r0, name, float(ratio.max()))
+                if name == "two-step" and flagged.any():
+                    assert ratio[flagged].max() <= 0.2, (r0, float(ratio[flagged].max()))
+        # rows that went through the float64 pass, far beyond the 2^31st element: the ill-conditioned rows of the last 2^18 rows
+        W = 1 << 18
+        r0 = rows - W
+        def window(buf):
+            out = np.empty((W, n), np.float32)
+            _hip._check(ctx.lib.mp_memcpy_d2h(ctx.handle, out.ctypes.data, buf.offset(r0 * n * 4), out.nbytes))
+            return out
+        q, qd, qdd, tau, fused = (window(b_) for b_ in (d_q, d_qd, d_qdd, d_tau, d_fused))
+        hard = np.flatnonzero(_hip.cpu_id_row_precision(m, q, qd, qdd))[:4096]
+        assert len(hard) > 100, len(hard)
+        want = c_oracle.inverse_dynamics_rows(tab, q[hard].astype(np.float64), qd[hard].astype(np.float64), qdd[hard].astype(np.float64))[0]
+        tol = 1e-4 * np.abs(want) + 5e-6 * np.abs(want).max(axis=1, keepdims=True) + 1e-12
+        assert (np.abs(tau[hard] - want) / tol).max() <= 0.2 and (np.abs(fused[hard] - want) / tol).max() <= 0.6
+    finally:
+        ctx.synchronize()
+        for b_ in bufs:
+            b_.free()
+        ctx.destroy()
