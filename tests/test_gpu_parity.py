@@ -2696,3 +2696,52 @@ def test_arrays_beyond_2_31_elements(specialise, tables):
         for b_ in bufs:
             b_.free()
         ctx.destroy()
+
+
+@pytest.mark.gpu
+def test_jacobian_array_beyond_2_31_elements(tables):
+    """Maximum sizes, the long output rows: the space Jacobian of 5.2e7 iiwa14 rows is 2.18e9 float32 ELEMENTS (8.7 GB) and leaves
+    through the wave-cooperative flat stores (mp_wave_store_flat: 16 rows staged, streamed out as 16-byte chunks across the row
+    boundaries) - element and byte offsets beyond 2^31 / 2^32 in J.  FK + Jacobian + ID fused, float32,
+    slices at the start, around J's 2^32nd byte and its 2^31st element, and at the very end (a partial wave: the
+    row count is not a multiple of 64) against the NumPy oracle's FK / Jacobian and the C oracle's torques."""
+    from manipulapy_amd import _hip
+    from oracle import c_oracle
+
+    tab = tables["iiwa14"]
+    lim = tab.joint_limits
+    n, B, N = 7, 52_013, 1000
+    rows = B * N - 29                      # ends in a partial wave
+    assert rows * 6 * n > 2**31 and rows % 64 != 0
+    ctx = _hip.HipContext(0)
+    bufs = []
+    try:
+        m = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee, lim)
+        rng = np.random.default_rng(2032)
+        s_ = rng.uniform(lim[:, 0], lim[:, 1], (B, n)).astype(np.float32)
+        e_ = rng.uniform(lim[:, 0], lim[:, 1], (B, n)).astype(np.float32)
+        d_s, d_e = ctx.to_device(s_), ctx.to_device(e_)
+        d_q, d_qd, d_qdd = (ctx.alloc(B * N * n * 4) for _ in range(3))
+        d_T, d_J, d_tau = ctx.alloc(rows * 16 * 4), ctx.alloc(rows * 6 * n * 4), ctx.alloc(rows * n * 4)
+        bufs += [d_s, d_e, d_q, d_qd, d_qdd, d_T, d_J, d_tau]
+        ctx.batch_trajectory(m, d_s, d_e, B, N, 2.0, 5, d_q, d_qd, d_qdd)
+        ctx.fk_jac_id(m, d_q, d_qd, d_qdd, rows, d_T, d_J, d_tau, dtype=np.float32)
+        ctx.synchronize()
+        K = 192
+        for r0 in (0, 2**32 // (6 * n * 4) - K // 2, 2**31 // (6 * n) - K // 2, rows - K):   # J's 2^32nd byte, its 2^31st element, the tail
+            def rows_of(buf, width):
+                out = np.empty((K, width), np.float32)
+                _hip._check(ctx.lib.mp_memcpy_d2h(ctx.handle, out.ctypes.data, buf.offset(r0 * width * 4), out.nbytes))
+                return out
+            q, qd, qdd = (rows_of(b_, n) for b_ in (d_q, d_qd, d_qdd))
+            T, J, tau = rows_of(d_T, 16), rows_of(d_J, 6 * n), rows_of(d_tau, n)
+            Tw = np.stack([ref.fk_space(tab, q[i].astype(np.float64)) for i in range(K)]).reshape(K, 16)
+            Jw = np.stack([ref.jacobian_space(tab, q[i].astype(np.float64)) for i in range(K)]).reshape(K, 6 * n)
+            assert np.abs(T - Tw).max() <= 2e-5 and np.abs(J - Jw).max() <= 2e-5, (r0, float(np.abs(T - Tw).max()), float(np.abs(J - Jw).max()))
+            want = c_oracle.inverse_dynamics_rows(tab, q.astype(np.float64), qd.astype(np.float64), qdd.astype(np.float64))[0]
+            assert_f32(tau, want)
+    finally:
+        ctx.synchronize()
+        for b_ in bufs:
+            b_.free()
+        ctx.destroy()
