@@ -2745,3 +2745,69 @@ def test_jacobian_array_beyond_2_31_elements(tables):
         for b_ in bufs:
             b_.free()
         ctx.destroy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["batch_major", "time_major"])
+def test_rollout_arrays_beyond_2_31_elements(layout, tables):
+    """Maximum sizes, the roll-out: 3.7e6 xarm6 trajectories x 100 steps x 6 joints = 2.22e9 elements per array (8.9 GB), on both
+    device layouts (batch-major: trajectory b's rows start at element 600 b - beyond 2^31 from b = 3.58e6; time-major: step t's
+    rows start at 6 t B - beyond 2^31 from t = 97).  Every trajectory is driven by the torques that hold its start pose (uploaded
+    step by step into the time-major array, transposed on the device for the batch-major run), no wrench; the first and the LAST 64
+    trajectories over all 100 steps against the C roll-out oracle, float32, within 1e-4 of each array's scale."""
+    from manipulapy_amd import _hip
+    from oracle import c_oracle
+
+    tab = tables["xarm6"]
+    n, B, N = 6, 3_700_037, 100            # (not a multiple of 64: a ragged last wave)
+    assert B * N * n > 2**31
+    g = np.array([0.0, 0.0, -9.81])
+    tmaj = layout == "time_major"
+    ctx = _hip.HipContext(0)
+    bufs = []
+    try:
+        m = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee, tab.joint_limits)
+        ctx.specialize(m)
+        rng = np.random.default_rng(2033)
+        th0 = rng.uniform(-0.5, 0.5, (B, n)).astype(np.float32)
+        dth0 = np.zeros((B, n), np.float32)
+        hold = ctx.id_trajectory_host(m, th0, dth0, dth0, g, None, dtype=np.float32)
+        nb = B * N * n * 4
+        d_th0, d_dth0, d_tau = ctx.to_device(th0), ctx.to_device(dth0), ctx.alloc(nb)
+        outs = [ctx.alloc(nb) for _ in range(3)]
+        bufs += [d_th0, d_dth0, d_tau] + outs
+        for t in range(N):                 # time-major (N, B, n): step t's B rows are contiguous
+            _hip._check(ctx.lib.mp_memcpy_h2d(ctx.handle, d_tau.offset(t * B * n * 4), hold.ctypes.data, hold.nbytes))
+        if not tmaj:
+            d_bm = ctx.alloc(nb)
+            bufs.append(d_bm)
+            ctx.transpose_rows(d_tau, N, B, n * 4, d_bm)      # -> (B, N, n)
+            d_tau = d_bm
+        ctx.fd_trajectory(m, d_th0, d_dth0, d_tau, None, B, N, g, 0.01, 1, *outs, dtype=np.float32, time_major=tmaj)
+        ctx.synchronize()
+
+        def trajectories(buf, b0, k):      # (k, N, n) of trajectories b0 .. b0 + k - 1
+            if not tmaj:
+                out = np.empty((k, N, n), np.float32)
+                _hip._check(ctx.lib.mp_memcpy_d2h(ctx.handle, out.ctypes.data, buf.offset(b0 * N * n * 4), out.nbytes))
+                return out
+            out = np.empty((N, k, n), np.float32)
+            for t in range(N):
+                _hip._check(ctx.lib.mp_memcpy_d2h(ctx.handle, out[t].ctypes.data, buf.offset((t * B + b0) * n * 4), out[t].nbytes))
+            return np.ascontiguousarray(np.swapaxes(out, 0, 1))
+
+        for b0 in (0, B - 64):
+            got = [trajectories(o, b0, 64) for o in outs]
+            tm = np.repeat(hold[b0:b0 + 64, None, :].astype(np.float64), N, axis=1)
+            want = c_oracle.fd_trajectory(tab, th0[b0:b0 + 64].astype(np.float64), dth0[b0:b0 + 64].astype(np.float64), tm, g, None, 0.01, 1)[:3]
+            for name, x, y in zip(("positions", "velocities", "accelerations"), got, want):
+                assert np.isfinite(x).all() and np.isfinite(y).all(), (b0, name)
+                scale = max(float(np.abs(y).max()), 1e-3)
+                drift = np.abs(x.astype(np.float64) - y).reshape(64, -1).max(axis=1) / scale
+                assert drift.max() <= 1e-4, (b0, name, float(np.median(drift)), float(drift.max()))
+            np.testing.assert_array_equal(got[0][:, 0], th0[b0:b0 + 64])   # row 0 = the initial state, bit for bit
+    finally:
+        ctx.synchronize()
+        for b_ in bufs:
+            b_.free()
+        ctx.destroy()
