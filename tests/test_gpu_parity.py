@@ -2811,3 +2811,46 @@ def test_rollout_arrays_beyond_2_31_elements(layout, tables):
         for b_ in bufs:
             b_.free()
         ctx.destroy()
+
+
+@pytest.mark.gpu
+def test_fused_launch_beyond_2_32_rows(tables):
+    """Maximum sizes, the row count itself: the fused generation + inverse dynamics writes tau only, so ONE launch can hold more than
+    2^32 rows in HBM - UR5, B = 4 300 000 x N = 1000 = 4.3e9 rows, a 103 GB torque array.  Such a launch has no row list (list
+    entries are 32-bit: csrc/mp_capi.cpp, attach_hard_list) and re-evaluates its ill-conditioned rows in place; every index on the
+    way (trajectory, timestep, row, byte offset) passes 2^32.  Slices at the start, on both sides of row 2^32, and at the very end
+    against the pinned C oracle under the float32 bound."""
+    from manipulapy_amd import _hip
+    from oracle import c_oracle
+
+    tab = tables["ur5"]
+    lim = tab.joint_limits
+    n, B, N = 6, 4_300_000, 1000
+    rows = B * N
+    assert rows > 2**32
+    ctx = _hip.HipContext(0)
+    bufs = []
+    try:
+        if ctx.properties()["total_memory"] < 150 * 2**30:
+            pytest.skip("needs a 103 GB array")
+        m = _hip.HipModel(tab.S, tab.Mcom, tab.G, tab.M_ee, lim)
+        ctx.specialize(m)
+        rng = np.random.default_rng(2034)
+        s_ = rng.uniform(lim[:, 0], lim[:, 1], (B, n)).astype(np.float32)
+        e_ = rng.uniform(lim[:, 0], lim[:, 1], (B, n)).astype(np.float32)
+        d_s, d_e, d_tau = ctx.to_device(s_), ctx.to_device(e_), ctx.alloc(rows * n * 4)
+        bufs += [d_s, d_e, d_tau]
+        ctx.traj_id_fused(m, d_s, d_e, B, N, 2.0, 5, d_tau)
+        ctx.synchronize()
+        K = 2000                                                   # two whole trajectories per slice
+        for b0 in (0, 2**32 // N - 1, B - 2):                      # trajectories; the middle pair straddles row 2^32
+            got = np.empty((K, n), np.float32)
+            _hip._check(ctx.lib.mp_memcpy_d2h(ctx.handle, got.ctypes.data, d_tau.offset(b0 * N * n * 4), got.nbytes))
+            o = ref.batch_joint_trajectory(lim, s_[b0:b0 + 2], e_[b0:b0 + 2], 2.0, N, 5)
+            q, qd, qdd = (o[k].reshape(-1, n).astype(np.float64) for k in ("positions", "velocities", "accelerations"))
+            assert_f32(got, c_oracle.inverse_dynamics_rows(tab, q, qd, qdd)[0])
+    finally:
+        ctx.synchronize()
+        for b_ in bufs:
+            b_.free()
+        ctx.destroy()
