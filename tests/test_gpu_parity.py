@@ -2854,3 +2854,40 @@ def test_fused_launch_beyond_2_32_rows(tables):
         for b_ in bufs:
             b_.free()
         ctx.destroy()
+
+
+@pytest.mark.gpu
+def test_the_ctypes_stub_of_integration_md_runs_as_written(tables):
+    """INTEGRATION.md section 2 shows the binding a ManipulaPy maintainer would add (`hip_kernels/_ffi.py`).  The block is executed
+    here exactly as printed - only the library's file name becomes its in-tree path - on a stand-in for the reference's
+    ManipulatorDynamics (the attributes the stub reads: S_list, M_list, Glist, Mlist_per_link), and its two functions are held to the
+    oracle: the documentation is under test."""
+    import re
+    import types
+    from oracle import c_oracle
+
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sec = text[text.index("## 2. ctypes stub"):text.index("## 3. Hooking the seams")]
+    code = re.search(r"```python\n(.*?)```", sec, re.S).group(1)
+    assert 'ctypes.CDLL("libmanipula_hip.so")' in code
+    code = code.replace('ctypes.CDLL("libmanipula_hip.so")', 'ctypes.CDLL(%r)' % os.path.join(ROOT, "manipulapy_amd", "libmanipula_hip.so"))
+    ns = {}
+    exec(compile(code, "INTEGRATION.md#2", "exec"), ns)
+    tab = tables["ur5"]
+    dyn = types.SimpleNamespace(S_list=tab.S, M_list=tab.M_ee, Glist=tab.G, Mlist_per_link=tab.Mcom)
+    model = ns["model_from_dynamics"](dyn, tab.joint_limits, None)
+    rng = np.random.default_rng(77)
+    q, qd, qdd = (rng.uniform(-1, 1, (1000, 6)).astype(np.float32) for _ in range(3))
+    g, F = np.array([0.0, 0.0, -9.81]), np.array([1.0, -2.0, 0.5, 3.0, -1.5, 0.75])
+    tau = ns["inverse_dynamics_trajectory"](model, q, qd, qdd, g, F)
+    assert_f32(tau, c_oracle.inverse_dynamics_rows(tab, q.astype(np.float64), qd.astype(np.float64), qdd.astype(np.float64), g, F)[0])
+    Bn, Nn = 5, 20
+    th0, dth0 = rng.uniform(-0.5, 0.5, (Bn, 6)), np.zeros((Bn, 6))
+    hold = c_oracle.inverse_dynamics_rows(tab, th0, dth0, dth0, g, np.zeros(6))[0]
+    tm = np.repeat(hold[:, None, :], Nn, axis=1) + rng.uniform(-1e-3, 1e-3, (Bn, Nn, 6))
+    Fm = rng.uniform(-0.02, 0.02, (Bn, Nn, 6))
+    out = ns["forward_dynamics_trajectories"](model, th0, dth0, tm, g, Fm, 0.01, 1)
+    want = c_oracle.fd_trajectory(tab, th0, dth0, tm, g, Fm, 0.01, 1)
+    for k, key in enumerate(("positions", "velocities", "accelerations")):
+        assert out[key].shape == (Bn, Nn, 6) and out[key].dtype == np.float32
+        assert np.abs(out[key] - want[k]).max() <= 1e-4 * max(1.0, float(np.abs(want[k]).max())), key
