@@ -33,6 +33,40 @@ def main(out_path):
     assert payload == bytes(range(128))
     mx = hg.max(float(info.rank))
     hg.barrier()
+    # bench.py's multi-rank agreements (round 6): one stuck rank makes EVERY rank treat the RCCL phase as stuck, and a strong-scaled
+    # entry whose set-up failed on one rank is left by all of them together with an "error" entry
+    import argparse
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    assert bench.agree_hung(hg, False, {}) is False
+    assert bench.agree_hung(hg, info.rank == info.world - 1, {}) is True
+
+    class _Buf:
+        def free(self): pass
+        def offset(self, nbytes): return None
+
+    class _FakeCtx:                        # a context whose launches do nothing; its set-up FAILS on the last rank only
+        def specialize(self, model):
+            if info.rank == info.world - 1:
+                raise RuntimeError("set-up failed on this rank")
+        def is_specialized(self, model): return False
+        def to_device(self, a): return _Buf()
+        def alloc(self, nbytes): return _Buf()
+        def batch_trajectory(self, *a, **k): pass
+        def id_trajectory(self, *a, **k): pass
+        def synchronize(self): pass
+
+    entry, hung = bench.bench_strong("c4", argparse.Namespace(no_specialize=False), info, hg, _FakeCtx(), {})
+    assert hung is False and "error" in entry and entry["scaling"] == "strong", entry
+    if info.rank == info.world - 1:
+        assert "set-up failed on this rank" in entry["error"]
+    else:                                  # their own set-up went through: they leave because a PEER failed, before any barrier
+        assert "another rank failed" in entry["error"], entry
+    words = np.arange(1000, dtype=np.uint32) * np.uint32(2654435761)
+    assert bench.weighted_word_sum(words) == bench.weighted_word_sum(words.copy()) != bench.weighted_word_sum(words[::-1].copy())
+    hg.barrier()
     if info.rank == 0:
         single = pl.batch_joint_trajectory(s, e, 2.0, N, 5)["positions"]
         tau_single = pl.batch_inverse_dynamics_trajectory(s, e, 2.0, N, 5)
